@@ -1,0 +1,39 @@
+"""CPU: pins the oracle restatement (oracle/) to the golden vectors produced by the real reference
+(tests/golden/make_golden.py).  No GPU, no /root/reference needed."""
+import numpy as np
+import pytest
+
+from oracle import ref_optimizer as RO
+from tests import util
+
+
+def test_gae_known_answer():
+    # SURVEY.md section 4 / reference advantage_returns(r=[1,2,3,0], v=[.5,.4,.3,0], .98, .97)
+    adv, ret = RO.advantage_returns(np.array([1, 2, 3, 0], np.float32), np.array([.5, .4, .3, 0], np.float32), 0.98, 0.97)
+    np.testing.assert_allclose(adv, [5.1322656, 4.4606204, 2.7], rtol=1e-6)
+    np.testing.assert_allclose(ret, [5.8412, 4.94, 3.0], rtol=1e-6)
+
+
+def test_gae_golden_bit_exact():
+    g = np.load(util.GOLDEN + '/gae_kat.npz')
+    adv, ret = RO.advantage_returns(g['r2'], g['v2'], 0.98, 0.97)
+    assert np.array_equal(adv, g['adv2']) and np.array_equal(ret, g['ret2'])
+
+
+@pytest.mark.parametrize('case', util.CASES)
+def test_oracle_matches_reference(case):
+    g, rollouts = util.load_case(case)
+    out, _, _ = util.oracle_run(g, rollouts)
+    assert list(out['param_names']) == list(g['param_names'])
+    # same torch build generated the fixtures here, so the restatement is expected to agree to
+    # the last few ulps; 1e-5 leaves room for op-order differences (einsum vs matmul)
+    for key in ['advantages', 'returns', 'values'] + ['old_logp_' + k for k in RO.HEADS]:
+        assert util.scaled_err(out[key], g[key]) < 1e-5, key
+    assert np.array_equal(out['argmax'], g['argmax'])
+    for ep in range(int(g['epochs'])):
+        for key in ['losses', 'entropies', 'grad_norms']:
+            k = 'ep%d_%s' % (ep, key)
+            assert util.rel_err(out[k], g[k]) < 2e-5, (k, out[k], g[k])
+        assert np.array_equal(out['ep%d_has_grad' % ep], g['ep%d_has_grad' % ep])
+        assert util.scaled_err(out['ep%d_param_samples' % ep], g['ep%d_param_samples' % ep]) < 1e-5
+        assert util.scaled_err(out['ep%d_grad_samples' % ep], g['ep%d_grad_samples' % ep]) < 1e-4

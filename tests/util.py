@@ -1,0 +1,76 @@
+"""Shared helpers for the parity tests: load a golden case, rebuild its inputs, run the oracle."""
+import os
+
+import numpy as np
+import torch
+
+from dotaclient_amd import synth
+from oracle import ref_optimizer as RO
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+CASES = ['ragged_s16', 'clip_s16', 'cfg1_4x128', 'emptyhead_s16']
+SAMPLE_STRIDE = 251
+
+
+def load_case(name):
+    g = dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
+    rollouts = synth.make_rollouts(int(g['data_seed']), [int(x) for x in g['lengths']],
+                                   forbid_enum=tuple(int(x) for x in g['forbid_enum']))
+    return g, rollouts
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / (np.abs(b) + 1e-30))) if a.size else 0.0
+
+
+def scaled_err(a, b):
+    """max |a-b| / max|b| : the right yardstick for vectors whose entries cross zero."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30)) if a.size else 0.0
+
+
+def tensor_summary(t):
+    f = t.detach().double().flatten().cpu()
+    return np.array([f.sum().item(), f.abs().sum().item(), f.norm().item()]), \
+        t.detach().flatten()[::SAMPLE_STRIDE][:1000].float().cpu().numpy().copy()
+
+
+def oracle_run(g, rollouts, cell='gru', hidden=256, layers=1, epochs=None):
+    """Runs the oracle restatement on a golden case's inputs; returns dict shaped like the fixture."""
+    torch.manual_seed(0)
+    pol = RO.make_policy(synth.init_state_dict(7, cell, hidden, layers), cell, hidden, layers)
+    opt = torch.optim.Adam(pol.parameters(), lr=float(g['lr']))
+    S = int(g['seq_len'])
+    chunks = []
+    for r in rollouts:
+        chunks.extend(RO.rollout_pass(pol, r, S))
+    out = {
+        'advantages': torch.stack([c.advantages for c in chunks]).numpy(),
+        'returns': torch.stack([c.returns for c in chunks]).numpy(),
+        'values': torch.stack([c.values for c in chunks]).numpy(),
+        'argmax': RO.masked_argmax(pol, chunks).numpy(),
+    }
+    for k in RO.HEADS:
+        out['old_logp_' + k] = torch.cat([c.old_logp[k] for c in chunks]).numpy()
+    n_ep = int(g['epochs']) if epochs is None else epochs
+    for ep in range(n_ep):
+        parts, ent, norms = RO.train_step(pol, opt, chunks, float(g['entropy_coef']), float(g['vf_coef']))
+        out['ep%d_losses' % ep] = np.array([float(parts[k]) for k in ('loss', 'policy_loss', 'entropy_loss', 'value_loss')])
+        out['ep%d_entropies' % ep] = np.array([float(ent[k]) for k in RO.HEADS])
+        out['ep%d_grad_norms' % ep] = np.array([float(norms['unclipped']), float(norms['clipped'])])
+        gs, gv, ps, pv, hg = [], [], [], [], []
+        for n, p in pol.named_parameters():
+            hg.append(p.grad is not None)
+            gr = p.grad if p.grad is not None else torch.zeros_like(p)
+            s, v = tensor_summary(gr); gs.append(s); gv.append(v)
+            s, v = tensor_summary(p); ps.append(s); pv.append(v)
+        out['ep%d_grad_summary' % ep] = np.stack(gs)
+        out['ep%d_grad_samples' % ep] = np.concatenate(gv)
+        out['ep%d_param_summary' % ep] = np.stack(ps)
+        out['ep%d_param_samples' % ep] = np.concatenate(pv)
+        out['ep%d_has_grad' % ep] = np.array(hg)
+    out['param_names'] = np.array([n for n, _ in pol.named_parameters()])
+    return out, pol, chunks
