@@ -1,0 +1,68 @@
+"""ctypes binding of libdotaclient_hip.so (the C ABI declared in include/dotaclient_hip.h).
+
+There is deliberately no fallback: if the library is missing the import of any compute entry point
+raises, so a GPU test can never pass on a silent CPU/PyTorch path.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libdotaclient_hip.so')
+
+c_f32p = ctypes.c_void_p
+c_ptr = ctypes.c_void_p
+c_int = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_dbl = ctypes.c_double
+c_flt = ctypes.c_float
+
+# name -> (restype, argtypes); must list every symbol declared in include/dotaclient_hip.h
+SIGNATURES = {
+    'dc_abi_version': (c_int, []),
+    'dc_last_error': (ctypes.c_char_p, []),
+    'dc_gae_scan': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_dbl, c_dbl, c_ptr, c_ptr, c_ptr]),
+    'dc_gemm_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                            c_ptr, c_int, c_ptr, c_int, c_int, c_int, c_ptr]),
+}
+
+_lib = None
+
+
+class DotaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library once; raises DotaHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DotaHipError('libdotaclient_hip.so not found at %s - run `python -m dotaclient_amd.build` '
+                           '(or __graft_entry__.build()); there is no CPU fallback' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what=''):
+    if code != 0:
+        msg = load().dc_last_error().decode('utf-8', 'replace')
+        raise DotaHipError('%s failed: %s' % (what or 'dotaclient_hip call', msg))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(stream=None):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(s.cuda_stream)

@@ -1,0 +1,70 @@
+"""Builds libdotaclient_hip.so (hipcc, --offload-arch=gfx950) in-tree next to the sources.
+
+The .so is git-ignored but travels to the GPU box with the gpurun snapshot.  There is no JIT and no
+fallback: `dotaclient_amd._lib` refuses to load a stale or missing library.
+"""
+import concurrent.futures
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, '_obj')
+LIB = os.path.join(HERE, 'libdotaclient_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def _digest(paths):
+    h = hashlib.sha1()
+    for p in paths:
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile_one(src):
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.h')]
+    deps.append(os.path.join(HERE, '..', 'include', 'dotaclient_hip.h'))
+    tag = _digest(deps)
+    obj = os.path.join(OBJ, src[:-4] + '.o')
+    stamp = obj + '.sha1'
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == tag:
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    with open(stamp, 'w') as f:
+        f.write(tag)
+    return obj, True
+
+
+def build_library(verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = _sources()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(_compile_one, srcs))
+    objs = [o for o, _ in results]
+    rebuilt = any(c for _, c in results)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+    if verbose:
+        print('libdotaclient_hip.so: %s (%d sources, %s)' % (LIB, len(srcs), 'rebuilt' if rebuilt else 'up to date'))
+    return LIB
+
+
+if __name__ == '__main__':
+    build_library()

@@ -1,0 +1,142 @@
+// GAE(lambda) advantage / rewards-to-go scan.
+//
+// Replaces /root/reference/optimizer.py:53-64 (discount + advantage_returns) together with the
+// per-step sub-reward sum of optimizer.py:397 and the terminal-zero append of optimizer.py:417-420.
+//
+//   r_t   = sum_k rewards[t, k]                         (float32, numpy's pairwise order for n = 10)
+//   d_t   = r_t + gamma * V_{t+1} - V_t                 (float32, one rounding per op; V_L = 0)
+//   A_t   = d_t + (gamma*lam) * A_{t+1}                 (float64 accumulate, cast to float32)
+//   R_t   = r_t + gamma * R_{t+1}                       (float64 accumulate, cast to float32)
+//
+// One wavefront per rollout.  The steps of a rollout are split into 64 contiguous lane chunks; each
+// lane reduces its chunk to the affine map y_in -> a*y_in + b, the 64 maps are combined with a
+// wavefront (Hillis-Steele, shuffle-based) suffix scan, and each lane then replays its chunk with the
+// exact carry-in.  Everything is staged through LDS so that global reads/writes are coalesced.
+// HBM-bound: 44 B read + 8 B written per env-step.
+#include "common.h"
+
+// hipcc defaults to -ffp-contract=fast, which would fuse the reference's separately-rounded
+// multiply/add pairs into fma (the __f*_rn helpers are inline header functions and do not help);
+// with contraction off every plain operator in this file rounds exactly once.
+#pragma clang fp contract(off)
+
+namespace dc {
+
+// numpy's pairwise summation for a contiguous run of 10 float32 (loops_utils.h.src, n in [8,128]):
+// eight running lanes, tree-combined, then the two leftovers added sequentially.
+__device__ __forceinline__ float reward_sum10(const float* r) {
+    const float a = (r[0] + r[1]) + (r[2] + r[3]);
+    const float b = (r[4] + r[5]) + (r[6] + r[7]);
+    float s = a + b;
+    s = s + r[8];
+    s = s + r[9];
+    return s;
+}
+
+struct Affine {  // y -> a*y + b
+    double a, b;
+};
+// apply `inner` first, then `outer`
+__device__ __forceinline__ Affine compose(const Affine& outer, const Affine& inner) {
+    Affine r;
+    r.a = outer.a * inner.a;
+    r.b = outer.b + outer.a * inner.b;
+    return r;
+}
+
+__global__ __launch_bounds__(64) void gae_scan_kernel(const float* __restrict__ rewards,   // [rows,10]
+                                                      const float* __restrict__ values,    // [rows]
+                                                      const int64_t* __restrict__ seq_off, // [n_seq]
+                                                      const int32_t* __restrict__ seq_len, // [n_seq]
+                                                      float gamma, double gamma_d, double gl_d,
+                                                      float* __restrict__ adv, float* __restrict__ ret) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int seq = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int L = seq_len[seq];
+    if (L <= 0) return;
+    const int64_t base = seq_off[seq];
+    float* s_delta = lds;       // [L]  later overwritten by advantages
+    float* s_rsum = lds + L;    // [L]  later overwritten by returns
+
+    // pass 1 (coalesced): per-step reward sum and TD residual
+    for (int t = lane; t < L; t += 64) {
+        const float* rp = rewards + (base + t) * 10;
+        float rr[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) rr[k] = rp[k];
+        const float r = reward_sum10(rr);
+        const float v0 = values[base + t];
+        const float v1 = (t + 1 < L) ? values[base + t + 1] : 0.0f;
+        // reference: rewards[:-1] + gamma * values[1:] - values[:-1]  in float32, left to right
+        const float gv = gamma * v1;
+        const float d = (r + gv) - v0;
+        s_rsum[t] = r;
+        s_delta[t] = d;
+    }
+    __syncthreads();
+
+    // pass 2: lane-local chunk -> affine map (reverse time)
+    const int chunk = (L + 63) / 64;
+    const int lo = min(lane * chunk, L);
+    const int hi = min(lo + chunk, L);
+    Affine ma = {1.0, 0.0}, mr = {1.0, 0.0};
+    for (int t = hi - 1; t >= lo; --t) {
+        ma.b = (double)s_delta[t] + gl_d * ma.b;
+        ma.a *= gl_d;
+        mr.b = (double)s_rsum[t] + gamma_d * mr.b;
+        mr.a *= gamma_d;
+    }
+    // suffix scan over lanes: after it, lane i holds the map of chunks i..63 (terminal carry 0)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        Affine na, nr;
+        na.a = __shfl_down(ma.a, o, 64); na.b = __shfl_down(ma.b, o, 64);
+        nr.a = __shfl_down(mr.a, o, 64); nr.b = __shfl_down(mr.b, o, 64);
+        if (lane + o < 64) {
+            ma = compose(ma, na);
+            mr = compose(mr, nr);
+        }
+    }
+    // carry into lane i = value at the first step of lane i+1's suffix = b of lane i+1
+    double ca = __shfl_down(ma.b, 1, 64);
+    double cr = __shfl_down(mr.b, 1, 64);
+    if (lane == 63) { ca = 0.0; cr = 0.0; }
+    // pass 3: replay the chunk with the exact carry
+    for (int t = hi - 1; t >= lo; --t) {
+        // one rounding per multiply and per add, like the C loop inside lfilter (no fma contraction)
+        const double pa = gl_d * ca, pr = gamma_d * cr;
+        ca = (double)s_delta[t] + pa;
+        cr = (double)s_rsum[t] + pr;
+        s_delta[t] = (float)ca;
+        s_rsum[t] = (float)cr;
+    }
+    __syncthreads();
+    for (int t = lane; t < L; t += 64) {
+        adv[base + t] = s_delta[t];
+        ret[base + t] = s_rsum[t];
+    }
+}
+
+int gae_scan(const float* rewards, const float* values, const int64_t* seq_off, const int32_t* seq_len,
+             int n_seq, int max_len, double gamma, double lam, float* adv, float* ret, hipStream_t stream) {
+    if (n_seq <= 0) return 0;
+    const size_t lds_bytes = (size_t)max_len * 2 * sizeof(float);
+    if (lds_bytes > 160 * 1024) {
+        set_error("gae_scan: rollout longer than 20480 steps is not supported", 1001);
+        return 1001;
+    }
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gae_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes);
+        if (e != hipSuccess) { set_error("gae_scan: hipFuncSetAttribute", (int)e); return (int)e; }
+    }
+    // The reference keeps gamma and lam as python doubles: gamma*lam is a double product
+    // (optimizer.py:61), lfilter runs in double with the double gamma (optimizer.py:63), and only the
+    // TD residuals use float32(gamma) (numpy scalar-times-float32-array arithmetic, optimizer.py:60).
+    hipLaunchKernelGGL(gae_scan_kernel, dim3(n_seq), dim3(64), lds_bytes, stream, rewards, values, seq_off,
+                       seq_len, (float)gamma, gamma, gamma * lam, adv, ret);
+    return launch_check("gae_scan");
+}
+
+}  // namespace dc

@@ -1,0 +1,291 @@
+// fp32 GEMM on the CDNA4 matrix cores: C[M,N] (op)= A[M,K] * B[K,N]  (+bias, relu, mask).
+//
+// This is the dense-contraction workhorse of the network (every nn.Linear of
+// /root/reference/policy.py:54-75 forward, and the dX / dW products of its backward, which the
+// reference gets from torch autograd at /root/reference/optimizer.py:672).  Inputs and accumulation
+// are exact fp32 (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain), which is what lets the 1e-4 parity
+// bar of BASELINE.json hold without a reduced-precision path.
+//
+// Layout: each operand is described by where its K index lives.
+//   A_KM = false : A stored row-major [M][lda], k contiguous  (activations, x of y = x W^T)
+//   A_KM = true  : A stored [K][lda],  m contiguous           (dY^T of dW = dY^T X)
+//   B_KM = false : B stored [N][ldb],  k contiguous           (a torch Linear weight [out,in])
+//   B_KM = true  : B stored [K][ldb],  n contiguous           (W of dX = dY W, X of dW = dY^T X)
+//
+// Tiling: 256 threads = 4 waves in a 2x2 grid; block tile BM x BN, K step 32; each wave owns
+// (BM/2)x(BN/2) as (BM/64)x(BN/64) MFMA tiles of 32x32.  Operand tiles are staged global -> VGPR
+// -> LDS with the next tile's global loads in flight during the MFMAs of the current one (two LDS
+// buffers, one barrier per K step).  k-contiguous tiles sit in LDS as [row][33] (pad 1 makes both
+// the 4-scalar staging writes and the 32-lane fragment reads conflict-free for ds_*_b32);
+// k-major tiles sit as [k][rows] (fragment reads are lane-consecutive, staging is ds_write_b128).
+// Split-K (gridDim.z) accumulates with fp32 global atomics into a caller-zeroed / live C.
+#include "common.h"
+
+namespace dc {
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;  // [N] or nullptr (added by split 0 only)
+    const float* aux;   // [M][ldaux] or nullptr: result is zeroed where aux <= 0 (relu backward)
+    int M, N, K;
+    int lda, ldb, ldc, ldaux;
+    int relu;        // apply max(0, .) (needs splits == 1)
+    int accumulate;  // C += result (non-atomic read-modify-write; splits == 1)
+    int atomic;      // C += result with atomics (split-K)
+    int k_per_split; // multiple of 32
+};
+
+enum { GEMM_BK = 32 };
+
+template <int BR, bool KM>
+struct TileLoader {
+    // registers: BR/32 float4 per thread
+    static constexpr int NV = BR / 32;
+    float4 v[NV];
+
+    __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int r_base, int R, int k_base,
+                                         int k_end, bool vec, int tid) {
+        if constexpr (!KM) {
+            const int c4 = tid & 7, r0 = tid >> 3;
+            const int k = k_base + c4 * 4;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int r = r_base + r0 + 32 * i;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < R) {
+                    const float* p = P + (size_t)r * ld + k;
+                    if (vec && k + 3 < k_end) {
+                        x = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (k + 0 < k_end) x.x = p[0];
+                        if (k + 1 < k_end) x.y = p[1];
+                        if (k + 2 < k_end) x.z = p[2];
+                        if (k + 3 < k_end) x.w = p[3];
+                    }
+                }
+                v[i] = x;
+            }
+        } else {
+            constexpr int V = BR / 4;       // float4 per k-row
+            constexpr int KSTEP = 256 / V;  // k-rows covered per pass
+            const int c4 = tid % V, k0 = tid / V;
+            const int r = r_base + c4 * 4;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int k = k_base + k0 + KSTEP * i;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < k_end) {
+                    const float* p = P + (size_t)k * ld + r;
+                    if (vec && r + 3 < R) {
+                        x = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (r + 0 < R) x.x = p[0];
+                        if (r + 1 < R) x.y = p[1];
+                        if (r + 2 < R) x.z = p[2];
+                        if (r + 3 < R) x.w = p[3];
+                    }
+                }
+                v[i] = x;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
+        if constexpr (!KM) {
+            const int c4 = tid & 7, r0 = tid >> 3;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                float* d = S + (r0 + 32 * i) * (GEMM_BK + 1) + c4 * 4;
+                d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+            }
+        } else {
+            constexpr int V = BR / 4;
+            constexpr int KSTEP = 256 / V;
+            const int c4 = tid % V, k0 = tid / V;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                *reinterpret_cast<float4*>(S + (k0 + KSTEP * i) * BR + c4 * 4) = v[i];
+            }
+        }
+    }
+
+    static constexpr int LDS_FLOATS = KM ? GEMM_BK * BR : BR * (GEMM_BK + 1);
+    // element (row r, k) of the staged tile
+    static __device__ __forceinline__ float frag(const float* __restrict__ S, int r, int k) {
+        if constexpr (!KM) return S[r * (GEMM_BK + 1) + k];
+        else return S[k * BR + r];
+    }
+};
+
+template <int BM, int BN, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
+    using LA = TileLoader<BM, A_KM>;
+    using LB = TileLoader<BN, B_KM>;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int A_FL = (LA::LDS_FLOATS + 3) / 4 * 4, B_FL = (LB::LDS_FLOATS + 3) / 4 * 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int STAGE_FL = A_FL + B_FL;  // buffer b: A at smem + b*STAGE_FL, B right after it
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m_blk = blockIdx.y * BM, n_blk = blockIdx.x * BN;
+    const int k_begin = blockIdx.z * p.k_per_split;
+    const int k_end = min(p.K, k_begin + p.k_per_split);
+    if (k_begin >= k_end) return;
+
+    const bool vecA = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
+    const bool vecB = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    LA la;
+    LB lb;
+    la.load(p.A, p.lda, m_blk, p.M, k_begin, k_end, vecA, tid);
+    lb.load(p.B, p.ldb, n_blk, p.N, k_begin, k_end, vecB, tid);
+    la.store(smem, tid);
+    lb.store(smem + A_FL, tid);
+    __syncthreads();
+
+    const int nk = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
+    const int fr = lane & 31, fk = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            la.load(p.A, p.lda, m_blk, p.M, k_begin + (kt + 1) * GEMM_BK, k_end, vecA, tid);
+            lb.load(p.B, p.ldb, n_blk, p.N, k_begin + (kt + 1) * GEMM_BK, k_end, vecB, tid);
+        }
+        const float* a_s = smem + cur * STAGE_FL;
+        const float* b_s = a_s + A_FL;
+#pragma unroll
+        for (int kk = 0; kk < GEMM_BK; kk += 2) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = LA::frag(a_s, wm * (BM / 2) + i * 32 + fr, kk + fk);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = LB::frag(b_s, wn * (BN / 2) + j * 32 + fr, kk + fk);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            la.store(smem + (cur ^ 1) * STAGE_FL, tid);
+            lb.store(smem + (cur ^ 1) * STAGE_FL + A_FL, tid);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const bool first_split = (blockIdx.z == 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n_blk + wn * (BN / 2) + j * 32 + fr;
+            if (col >= p.N) continue;
+            const float bv = (p.bias != nullptr && first_split) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m_blk + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.aux != nullptr && !(p.aux[(size_t)row * p.ldaux + col] > 0.f)) v = 0.f;
+                float* c = p.C + (size_t)row * p.ldc + col;
+                if (p.atomic) atomicAdd(c, v);
+                else if (p.accumulate) *c += v;
+                else *c = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, bool A_KM, bool B_KM>
+static int launch_gemm(const GemmArgs& a, int splits, hipStream_t stream) {
+    using LA = TileLoader<BM, A_KM>;
+    using LB = TileLoader<BN, B_KM>;
+    constexpr int A_FL = (LA::LDS_FLOATS + 3) / 4 * 4, B_FL = (LB::LDS_FLOATS + 3) / 4 * 4;
+    const size_t lds = (size_t)(A_FL + B_FL) * 2 * sizeof(float);
+    static bool attr_done = false;
+    if (lds > 64 * 1024 && !attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, A_KM, B_KM>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("gemm: hipFuncSetAttribute", (int)e); return (int)e; }
+        attr_done = true;
+    }
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KM, B_KM>), grid, dim3(256), lds, stream, a);
+    return launch_check("gemm_f32");
+}
+
+template <bool A_KM, bool B_KM>
+static int dispatch_tile(const GemmArgs& a, int splits, hipStream_t stream) {
+    // big tile when both dimensions can fill it and the grid still covers the chip
+    const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * splits;
+    if (a.M >= 128 && a.N >= 128 && tiles128 >= 256) return launch_gemm<128, 128, A_KM, B_KM>(a, splits, stream);
+    if (a.M >= 128 && a.N > 32) {
+        const long tiles = (long)((a.M + 127) / 128) * ((a.N + 63) / 64) * splits;
+        if (tiles >= 128) return launch_gemm<128, 64, A_KM, B_KM>(a, splits, stream);
+    }
+    return launch_gemm<64, 64, A_KM, B_KM>(a, splits, stream);
+}
+
+// C[M,N] (op)= A*B.  splits <= 0 -> chosen automatically (split-K is used when the output tile
+// grid alone cannot fill 256 CUs, i.e. for the weight-gradient products with K = rows).
+int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+             int a_kmajor, int b_kmajor, const float* bias, int relu, const float* aux, int ldaux,
+             int accumulate, int splits, hipStream_t stream) {
+    if (M <= 0 || N <= 0) return 0;
+    GemmArgs a;
+    a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
+    a.relu = relu; a.accumulate = accumulate; a.atomic = 0;
+    if (K <= 0) {
+        set_error("gemm_f32: K <= 0", 1002);
+        return 1002;
+    }
+    if (splits <= 0) {
+        const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+        splits = 1;
+        if (tiles < 256 && K >= 2048 && !relu && aux == nullptr) {
+            long want = (512 + tiles - 1) / tiles;
+            long maxs = K / 512;
+            splits = (int)(want < maxs ? want : maxs);
+            if (splits < 1) splits = 1;
+        }
+    }
+    int kper = (K + splits - 1) / splits;
+    kper = (kper + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+    splits = (K + kper - 1) / kper;
+    a.k_per_split = kper;
+    if (splits > 1) {
+        if (relu || aux != nullptr) {
+            set_error("gemm_f32: relu/mask epilogue is incompatible with split-K", 1003);
+            return 1003;
+        }
+        if (!accumulate) {
+            // split-K accumulates with atomics: start from zero
+            hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, stream);
+            if (e != hipSuccess) { set_error("gemm_f32: memset", (int)e); return (int)e; }
+        }
+        a.atomic = 1;
+        a.accumulate = 0;
+    }
+    if (!a_kmajor && !b_kmajor) return dispatch_tile<false, false>(a, splits, stream);
+    if (!a_kmajor && b_kmajor) return dispatch_tile<false, true>(a, splits, stream);
+    if (a_kmajor && !b_kmajor) return dispatch_tile<true, false>(a, splits, stream);
+    return dispatch_tile<true, true>(a, splits, stream);
+}
+
+}  // namespace dc

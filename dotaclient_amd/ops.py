@@ -1,0 +1,46 @@
+"""Thin tensor-level wrappers over the C ABI (argument checking + pointer plumbing only).
+
+torch is used here for device memory and streams; all arithmetic happens in libdotaclient_hip.so.
+"""
+import torch
+
+from . import _lib
+
+
+def _chk(t, dtype, name):
+    if not t.is_cuda:
+        raise _lib.DotaHipError('%s must live on the GPU (there is no CPU path)' % name)
+    if t.dtype != dtype:
+        raise TypeError('%s: expected %s, got %s' % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError('%s must be contiguous' % name)
+    return t
+
+
+def gae_scan(rewards, values, seq_off, seq_len, max_len, gamma=0.98, lam=0.97, adv=None, ret=None):
+    """rewards [rows,10] f32, values [rows] f32, seq_off i64 [n], seq_len i32 [n] -> (adv, ret) [rows] f32.
+    Replaces advantage_returns + sub-reward sum (optimizer.py:53-64,397,417-421)."""
+    lib = _lib.load()
+    _chk(rewards, torch.float32, 'rewards'); _chk(values, torch.float32, 'values')
+    _chk(seq_off, torch.int64, 'seq_off'); _chk(seq_len, torch.int32, 'seq_len')
+    rows = values.numel()
+    assert rewards.shape == (rows, 10)
+    if adv is None:
+        adv = torch.empty(rows, dtype=torch.float32, device=values.device)
+    if ret is None:
+        ret = torch.empty(rows, dtype=torch.float32, device=values.device)
+    _lib.check(lib.dc_gae_scan(_lib.ptr(rewards), _lib.ptr(values), _lib.ptr(seq_off), _lib.ptr(seq_len),
+                               seq_off.numel(), int(max_len), float(gamma), float(lam), _lib.ptr(adv),
+                               _lib.ptr(ret), _lib.stream_ptr()), 'dc_gae_scan')
+    return adv, ret
+
+
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, bias=None, relu=False, aux=None,
+         ldaux=0, accumulate=False, splits=0):
+    lib = _lib.load()
+    for t, n in ((A, 'A'), (B, 'B'), (C, 'C')):
+        _chk(t, torch.float32, n)
+    _lib.check(lib.dc_gemm_f32(_lib.ptr(A), _lib.ptr(B), _lib.ptr(C), M, N, K, lda, ldb, ldc, int(a_kmajor),
+                               int(b_kmajor), _lib.ptr(bias), int(relu), _lib.ptr(aux), ldaux, int(accumulate),
+                               splits, _lib.stream_ptr()), 'dc_gemm_f32')
+    return C

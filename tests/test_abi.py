@@ -1,0 +1,29 @@
+"""CPU: the C-ABI library loads and exports every symbol include/dotaclient_hip.h declares."""
+import os
+import re
+
+from dotaclient_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(REPO, 'include', 'dotaclient_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(dc_[a-z0-9_]+)\s*\(', txt)) - {'dc_stream_t'})
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    syms = _declared_symbols()
+    assert len(syms) >= 3
+    for s in syms:
+        assert hasattr(lib, s), s
+        assert s in _lib.SIGNATURES, 'ctypes signature missing for ' + s
+    assert sorted(_lib.SIGNATURES) == syms
+    assert lib.dc_abi_version() >= 1
+
+
+def test_every_declaration_cites_the_reference():
+    txt = open(os.path.join(REPO, 'include', 'dotaclient_hip.h')).read()
+    assert txt.count('optimizer.py:') + txt.count('policy.py:') >= 3

@@ -1,0 +1,104 @@
+"""GPU: unit parity of the individual HIP kernels (called through the C ABI) against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_optimizer as RO
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def _gae_oracle(rew10, values, lens):
+    adv, ret = [], []
+    o = 0
+    for L in lens:
+        r = rew10[o:o + L].sum(axis=1)
+        a, t = RO.advantage_returns(np.append(r, np.float32(0)), np.append(values[o:o + L], np.float32(0)), 0.98, 0.97)
+        adv.append(a); ret.append(t); o += L
+    return np.concatenate(adv), np.concatenate(ret)
+
+
+@pytest.mark.parametrize('lens', [[16], [1], [48, 64, 32], [256] * 64, [7, 300, 64, 1, 2049, 640], [20000]])
+def test_gae_scan_bit_exact(lens):
+    from dotaclient_amd import ops
+    dev = _dev()
+    rng = np.random.Generator(np.random.PCG64(len(lens) * 131 + lens[0]))
+    rows = sum(lens)
+    rew = (0.05 * rng.standard_normal((rows, 10))).astype(np.float32)
+    val = rng.standard_normal(rows).astype(np.float32)
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    adv, ret = ops.gae_scan(torch.from_numpy(rew).to(dev), torch.from_numpy(val).to(dev),
+                            torch.from_numpy(off).to(dev), torch.tensor(lens, dtype=torch.int32, device=dev), max(lens))
+    ea, er = _gae_oracle(rew, val, lens)
+    adv, ret = adv.cpu().numpy(), ret.cpu().numpy()
+    # integer-like bar: the float64 scan is re-associated across lanes (<= a few 1e-16 relative before
+    # the cast), so results are expected bit-identical to the reference's sequential lfilter
+    assert np.array_equal(ret, er), np.abs(ret - er).max()
+    assert np.array_equal(adv, ea), np.abs(adv - ea).max()
+
+
+def test_gae_scan_golden_vector():
+    from dotaclient_amd import ops
+    dev = _dev()
+    g = np.load(util.GOLDEN + '/gae_kat.npz')
+    r, v = g['r2'][:-1], g['v2'][:-1]
+    rew = np.zeros((r.size, 10), np.float32); rew[:, 3] = r
+    adv, ret = ops.gae_scan(torch.from_numpy(rew).to(dev), torch.from_numpy(v.copy()).to(dev),
+                            torch.zeros(1, dtype=torch.int64, device=dev),
+                            torch.tensor([r.size], dtype=torch.int32, device=dev), r.size)
+    assert np.array_equal(adv.cpu().numpy(), g['adv2']) and np.array_equal(ret.cpu().numpy(), g['ret2'])
+
+
+@pytest.mark.parametrize('akm,bkm', [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize('M,N,K', [(64, 64, 32), (200, 154, 256), (1000, 256, 896), (130, 70, 154), (768, 256, 5000),
+                                   (33, 12, 7), (2048, 768, 256)])
+def test_gemm_layouts(akm, bkm, M, N, K):
+    from dotaclient_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    lda = (M if akm else K) + 4
+    ldb = (N if bkm else K) + 8
+    A = torch.randn((K if akm else M), lda, generator=g)
+    B = torch.randn((K if bkm else N), ldb, generator=g)
+    bias = torch.randn(N, generator=g)
+    Am = (A[:, :M].t() if akm else A[:, :K]).double()
+    Bm = (B[:, :N] if bkm else B[:, :K].t()).double()
+    ref = Am @ Bm + bias.double()
+    ldc = N + 3
+    C = torch.full((M, ldc), 7.0, device=dev)
+    ops.gemm(A.to(dev), B.to(dev), C, M, N, K, lda, ldb, ldc, akm, bkm, bias=bias.to(dev))
+    out = C.cpu()
+    assert torch.all(out[:, N:] == 7.0), 'wrote outside the N columns'
+    err = (out[:, :N].double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+
+
+def test_gemm_epilogues():
+    from dotaclient_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 300, 128, 128
+    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    aux = torch.randn(M, N, generator=g)
+    ref = A.double() @ B.double().t()
+    C = torch.empty(M, N, device=dev)
+    ops.gemm(A.to(dev), B.to(dev), C, M, N, K, K, K, N, relu=True)
+    assert (C.cpu().double() - ref.clamp(min=0)).abs().max() < 1e-4
+    ops.gemm(A.to(dev), B.to(dev), C, M, N, K, K, K, N, aux=aux.to(dev), ldaux=N)
+    assert (C.cpu().double() - ref * (aux > 0)).abs().max() < 1e-4
+    C.fill_(1.0)
+    ops.gemm(A.to(dev), B.to(dev), C, M, N, K, K, K, N, accumulate=True)
+    assert (C.cpu().double() - (ref + 1)).abs().max() < 1e-4
+    # split-K with accumulate into live data
+    K2 = 4096
+    A2, B2 = torch.randn(K2, 96, generator=g), torch.randn(K2, 80, generator=g)
+    C2 = torch.full((96, 80), 2.0, device=dev)
+    ops.gemm(A2.to(dev), B2.to(dev), C2, 96, 80, K2, 96, 80, 80, True, True, accumulate=True, splits=8)
+    ref2 = A2.double().t() @ B2.double() + 2
+    assert (C2.cpu().double() - ref2).abs().max() / ref2.abs().max() < 2e-6

@@ -37,3 +37,23 @@ def test_oracle_matches_reference(case):
         assert np.array_equal(out['ep%d_has_grad' % ep], g['ep%d_has_grad' % ep])
         assert util.scaled_err(out['ep%d_param_samples' % ep], g['ep%d_param_samples' % ep]) < 1e-5
         assert util.scaled_err(out['ep%d_grad_samples' % ep], g['ep%d_grad_samples' % ep]) < 1e-4
+
+
+def test_c_oracle_matches_numpy_oracle_and_golden():
+    from oracle import build_c
+    g = np.load(util.GOLDEN + '/gae_kat.npz')
+    r, v = g['r2'][:-1], g['v2'][:-1]
+    rew = np.zeros((r.size, 10), np.float32); rew[:, 3] = r
+    adv, ret = build_c.gae_ref(rew, v, [0], [r.size])
+    assert np.array_equal(adv, g['adv2']) and np.array_equal(ret, g['ret2'])
+    rng = np.random.Generator(np.random.PCG64(3))
+    lens = [5, 300, 17]
+    rew = (0.05 * rng.standard_normal((sum(lens), 10))).astype(np.float32)
+    val = rng.standard_normal(sum(lens)).astype(np.float32)
+    adv, ret = build_c.gae_ref(rew, val, [0, 5, 305], lens)
+    o = 0
+    for L in lens:
+        a, t = RO.advantage_returns(np.append(rew[o:o + L].sum(axis=1), np.float32(0)),
+                                    np.append(val[o:o + L], np.float32(0)), 0.98, 0.97)
+        assert np.array_equal(adv[o:o + L], a) and np.array_equal(ret[o:o + L], t)
+        o += L
