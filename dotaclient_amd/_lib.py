@@ -23,6 +23,13 @@ SIGNATURES = {
     'dc_gae_scan': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_dbl, c_dbl, c_ptr, c_ptr, c_ptr]),
     'dc_gemm_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                             c_ptr, c_int, c_ptr, c_int, c_int, c_int, c_ptr]),
+    'dc_workspace_layout': (c_i64, [c_ptr, c_ptr]),
+    'dc_policy_forward': (c_int, [c_ptr] * 12),
+    'dc_select_logp': (c_int, [c_ptr] * 8),
+    'dc_ppo_loss_fwd_bwd': (c_int, [c_ptr] * 9 + [c_flt, c_flt, c_flt, c_ptr]),
+    'dc_policy_backward': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'dc_gradnorm_clip_adam': (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int] + [c_ptr] * 11 +
+                              [c_flt, c_flt, c_dbl, c_dbl, c_dbl, c_flt, c_ptr]),
 }
 
 _lib = None

@@ -1,0 +1,135 @@
+// Gradient-norm metrics, clip-by-global-norm and Adam over the flat fp32 parameter buffer.
+//
+// Replaces /root/reference/optimizer.py:674-681: mean_gradient_norm (optimizer.py:691-695, called
+// before and after the clip), torch.nn.utils.clip_grad_norm_(params, 0.5) (coef = 0.5/(norm+1e-6)
+// clamped to <= 1) and torch.optim.Adam(lr).step() (betas 0.9/0.999, eps 1e-8, no weight decay;
+// optimizer.py:275), including the two NaN guards (optimizer.py:667-669, 678-679): when the loss or
+// the gradient norm is NaN nothing is updated and `status` is set so the host can raise ValueError.
+//
+// The 34 named parameters are "segments" of the flat buffer (offset, length).  A segment whose head
+// took no action in the batch has no gradient in the reference (torch leaves .grad = None): it is
+// excluded from both norms, is not clipped and Adam does not advance its step counter.
+// HBM-bound: 4 B (norm pass) + 28 B (update: p,g,m,v read, p,g,m,v... written) per parameter.
+#include "kernels.h"
+
+namespace dc {
+
+enum { ADAM_CHUNK = 4096 };
+
+struct AdamSegs {
+    const int64_t* seg_off;    // [n_seg] offsets (floats)
+    const int32_t* seg_len;    // [n_seg]
+    const int32_t* seg_gate;   // [n_seg] -1: always has a grad; 0..4: needs head k active; 5: needs vf_coef > 0
+    int n_seg;
+};
+
+__device__ __forceinline__ bool seg_active(const AdamSegs& sg, int seg, const int32_t* head_on, float vf_coef) {
+    const int g = sg.seg_gate[seg];
+    if (g < 0) return true;
+    if (g < 5) return head_on[g] != 0;
+    return vf_coef > 0.f;
+}
+
+__global__ __launch_bounds__(256) void grad_sqnorm_kernel(AdamSegs sg, const float* __restrict__ grad,
+                                                          double* __restrict__ segsq) {
+    const int seg = blockIdx.y;
+    const long long len = sg.seg_len[seg];
+    const long long c0 = (long long)blockIdx.x * ADAM_CHUNK;
+    if (c0 >= len) return;
+    const float* g = grad + sg.seg_off[seg];
+    const long long c1 = min(len, c0 + ADAM_CHUNK);
+    double s = 0.0;
+    for (long long i = c0 + threadIdx.x; i < c1; i += 256) {
+        const double v = g[i];
+        s += v * v;
+    }
+    __shared__ double sh[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&segsq[seg], (sh[0] + sh[1]) + (sh[2] + sh[3]));
+}
+
+// ctl[0] = clip coefficient, ctl[1] = ok flag (1.0 = apply the update)
+__global__ void clip_finalize_kernel(AdamSegs sg, const double* __restrict__ segsq, const int32_t* __restrict__ head_on,
+                                     const float* __restrict__ losses, float* __restrict__ norms_out,
+                                     float* __restrict__ ctl, int32_t* __restrict__ seg_step,
+                                     int32_t* __restrict__ status, float max_norm, float vf_coef) {
+    if (threadIdx.x != 0) return;
+    double sum_norm = 0.0, tot_sq = 0.0;
+    int n_act = 0;
+    for (int s = 0; s < sg.n_seg; ++s) {
+        if (!seg_active(sg, s, head_on, vf_coef)) continue;
+        const float nrm = (float)sqrt(segsq[s]);
+        sum_norm += (double)nrm;
+        tot_sq += (double)nrm * (double)nrm;
+        ++n_act;
+    }
+    const float unclipped = (float)(sum_norm / (double)n_act);
+    const float total = (float)sqrt(tot_sq);
+    float coef = max_norm / (total + 1e-6f);
+    if (coef > 1.f) coef = 1.f;
+    norms_out[0] = unclipped;
+    norms_out[1] = unclipped * coef;   // every per-parameter norm scales by the same coefficient
+    const bool loss_nan = losses[0] != losses[0];
+    const bool norm_nan = unclipped != unclipped;
+    int st = 0;
+    if (loss_nan) st = 1; else if (norm_nan) st = 2;
+    *status = st;
+    ctl[0] = coef;
+    ctl[1] = st == 0 ? 1.f : 0.f;
+    if (st == 0)
+        for (int s = 0; s < sg.n_seg; ++s)
+            if (seg_active(sg, s, head_on, vf_coef)) seg_step[s] += 1;
+}
+
+__global__ __launch_bounds__(256) void adam_update_kernel(AdamSegs sg, float* __restrict__ param, float* __restrict__ grad,
+                                                          float* __restrict__ m, float* __restrict__ v,
+                                                          const float* __restrict__ ctl, const int32_t* __restrict__ seg_step,
+                                                          const int32_t* __restrict__ head_on, float vf_coef, double lr,
+                                                          double beta1, double beta2, float eps) {
+    const int seg = blockIdx.y;
+    const long long len = sg.seg_len[seg];
+    const long long c0 = (long long)blockIdx.x * ADAM_CHUNK;
+    if (c0 >= len) return;
+    if (ctl[1] == 0.f) return;                                   // NaN guard tripped: leave everything alone
+    if (!seg_active(sg, seg, head_on, vf_coef)) return;          // grad is None in the reference
+    const float coef = ctl[0];
+    const int step = seg_step[seg];                              // already incremented for this update
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - beta1), b2 = (float)beta2, w2 = (float)(1.0 - beta2);
+    const long long base = sg.seg_off[seg];
+    const long long c1 = min(len, c0 + ADAM_CHUNK);
+    for (long long i = base + c0 + threadIdx.x; i < base + c1; i += 256) {
+        const float g = grad[i] * coef;                          // clip_grad_norm_ scales in place
+        grad[i] = g;
+        float mi = m[i], vi = v[i];
+        mi = mi + w1 * (g - mi);                                 // exp_avg.lerp_(grad, 1-beta1)
+        vi = vi * b2 + w2 * g * g;                               // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        param[i] = param[i] - step_size * mi / denom;            // param.addcdiv_(exp_avg, denom, -step_size)
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+int gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const int32_t* seg_gate, int n_seg, int max_seg_len,
+                       float* param, float* grad, float* m, float* v, double* segsq, const int32_t* head_on,
+                       const float* losses, float* norms_out, float* ctl, int32_t* seg_step, int32_t* status,
+                       float max_norm, float vf_coef, double lr, double beta1, double beta2, float eps, hipStream_t s) {
+    AdamSegs sg{seg_off, seg_len, seg_gate, n_seg};
+    hipError_t e = hipMemsetAsync(segsq, 0, sizeof(double) * n_seg, s);
+    if (e != hipSuccess) { set_error("adam: memset", (int)e); return (int)e; }
+    dim3 grid((max_seg_len + ADAM_CHUNK - 1) / ADAM_CHUNK, n_seg);
+    hipLaunchKernelGGL(grad_sqnorm_kernel, grid, dim3(256), 0, s, sg, grad, segsq);
+    hipLaunchKernelGGL(clip_finalize_kernel, dim3(1), dim3(64), 0, s, sg, segsq, head_on, losses, norms_out, ctl, seg_step,
+                       status, max_norm, vf_coef);
+    hipLaunchKernelGGL(adam_update_kernel, grid, dim3(256), 0, s, sg, param, grad, m, v, ctl, seg_step, head_on, vf_coef, lr,
+                       beta1, beta2, eps);
+    return launch_check("gradnorm_clip_adam");
+}
+
+}  // namespace dc

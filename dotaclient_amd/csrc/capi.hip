@@ -1,6 +1,6 @@
 // extern "C" surface of libdotaclient_hip.so - see include/dotaclient_hip.h for the contract.
 #include "../../include/dotaclient_hip.h"
-#include "common.h"
+#include "kernels.h"
 #include <stdio.h>
 #include <string.h>
 
@@ -22,10 +22,12 @@ int launch_check(const char* what) {
     return 0;
 }
 
-int gae_scan(const float*, const float*, const int64_t*, const int32_t*, int, int, double, double, float*, float*,
-             hipStream_t);
-int gemm_f32(const float*, const float*, float*, int, int, int, int, int, int, int, int, const float*, int,
-             const float*, int, int, int, hipStream_t);
+int64_t workspace_layout(const dc_dims* d, int64_t* out);
+int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, const float* obs, const float* h0,
+                   const float* c0, const int64_t* seq_off, const int32_t* seq_len, void* ws_base, float* hT, float* cT,
+                   hipStream_t s);
+int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, float* grads, int64_t total_floats,
+                    const float* obs, const int64_t* seq_off, const int32_t* seq_len, void* ws_base, hipStream_t s);
 
 }  // namespace dc
 
@@ -44,6 +46,53 @@ int dc_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, i
                 int accumulate, int splits, dc_stream_t stream) {
     return dc::gemm_f32(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, bias, relu, aux, ldaux, accumulate,
                         splits, (hipStream_t)stream);
+}
+
+int64_t dc_workspace_layout(const dc_dims* dims, int64_t* offsets) { return dc::workspace_layout(dims, offsets); }
+
+int dc_policy_forward(const dc_dims* dims, const float* params, const int64_t* poff_host, const float* obs,
+                      const float* h0, const float* c0, const int64_t* seq_off, const int32_t* seq_len, void* ws,
+                      float* hT, float* cT, dc_stream_t stream) {
+    return dc::policy_forward(dims, params, poff_host, obs, h0, c0, seq_off, seq_len, ws, hT, cT, (hipStream_t)stream);
+}
+
+static float* ws_f(const dc_dims* dims, const void* ws, int idx) {
+    int64_t off[DC_WS_FIXED + DC_WS_PER_LAYER * DC_MAX_LAYERS];
+    dc::workspace_layout(dims, off);
+    return reinterpret_cast<float*>((char*)ws + off[idx]);
+}
+
+int dc_select_logp(const dc_dims* dims, const void* ws, const uint8_t* act, const uint8_t* mask, float* logp_sel,
+                   float* values, int32_t* argmax, dc_stream_t stream) {
+    if (dims->rows <= 0) return 0;
+    return dc::select_logp(ws_f(dims, ws, DC_WS_HEADOUT), ws_f(dims, ws, DC_WS_TU), act, mask, logp_sel, values, argmax,
+                           dims->rows, (hipStream_t)stream);
+}
+
+int dc_ppo_loss_fwd_bwd(const dc_dims* dims, void* ws, const uint8_t* act, const uint8_t* mask, const float* old_logp,
+                        const float* adv, const float* ret, float* losses_out, int32_t* head_on, float e_clip,
+                        float entropy_coef, float vf_coef, dc_stream_t stream) {
+    if (dims->rows <= 0) { dc::set_error("ppo_loss: empty batch", 1030); return 1030; }
+    return dc::ppo_loss_fwd_bwd(ws_f(dims, ws, DC_WS_HEADOUT), ws_f(dims, ws, DC_WS_TU), act, mask, old_logp, adv, ret,
+                                reinterpret_cast<double*>(ws_f(dims, ws, DC_WS_STATS)), ws_f(dims, ws, DC_WS_DHEADOUT),
+                                ws_f(dims, ws, DC_WS_DTU), losses_out, head_on, dims->rows, e_clip, entropy_coef, vf_coef,
+                                (hipStream_t)stream);
+}
+
+int dc_policy_backward(const dc_dims* dims, const float* params, const int64_t* poff_host, float* grads,
+                       int64_t total_floats, const float* obs, const int64_t* seq_off, const int32_t* seq_len, void* ws,
+                       dc_stream_t stream) {
+    return dc::policy_backward(dims, params, poff_host, grads, total_floats, obs, seq_off, seq_len, ws, (hipStream_t)stream);
+}
+
+int dc_gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const int32_t* seg_gate, int n_seg,
+                          int max_seg_len, float* params, float* grads, float* m, float* v, double* segsq,
+                          const int32_t* head_on, const float* losses, float* norms_out, float* ctl,
+                          int32_t* seg_step, int32_t* status, float max_norm, float vf_coef, double lr, double beta1,
+                          double beta2, float eps, dc_stream_t stream) {
+    return dc::gradnorm_clip_adam(seg_off, seg_len, seg_gate, n_seg, max_seg_len, params, grads, m, v, segsq, head_on,
+                                  losses, norms_out, ctl, seg_step, status, max_norm, vf_coef, lr, beta1, beta2, eps,
+                                  (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -13,7 +13,7 @@
 // wavefront (Hillis-Steele, shuffle-based) suffix scan, and each lane then replays its chunk with the
 // exact carry-in.  Everything is staged through LDS so that global reads/writes are coalesced.
 // HBM-bound: 44 B read + 8 B written per env-step.
-#include "common.h"
+#include "kernels.h"
 
 // hipcc defaults to -ffp-contract=fast, which would fuse the reference's separately-rounded
 // multiply/add pairs into fma (the __f*_rn helpers are inline header functions and do not help);

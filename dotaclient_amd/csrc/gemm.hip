@@ -19,7 +19,7 @@
 // the 4-scalar staging writes and the 32-lane fragment reads conflict-free for ds_*_b32);
 // k-major tiles sit as [k][rows] (fragment reads are lane-consecutive, staging is ds_write_b128).
 // Split-K (gridDim.z) accumulates with fp32 global atomics into a caller-zeroed / live C.
-#include "common.h"
+#include "kernels.h"
 
 namespace dc {
 

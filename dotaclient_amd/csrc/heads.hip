@@ -1,0 +1,331 @@
+// Action heads: target-unit attention, masked log-softmax, PPO clipped-ratio + value + entropy loss.
+//
+// Replaces /root/reference/policy.py:152 (query . unit_embedding), policy.py:169-178
+// (masked_softmax), /root/reference/optimizer.py:387-390 (old log-probs of the selected actions),
+// optimizer.py:587-665 (advantage normalisation + loss) and the backward seeds autograd derives
+// from them (optimizer.py:672).
+//
+// Per env-step record: headout[n][160] (cols: 0..127 query, 128..131 enum, 132..140 x, 141..149 y,
+// 150..152 ability, 153 value), tu[n][40] target-unit logits; act/mask uint8[n][65] with heads in
+// order enum(4) x(9) y(9) target_unit(40) ability(3).
+#include "kernels.h"
+
+namespace dc {
+
+enum { HO_LD = 160, HO_ENUM = 128, HO_X = 132, HO_Y = 141, HO_ABILITY = 150, HO_VALUE = 153, ACT = 65, NUNITS = 40,
+       EMBW = 128 };
+__constant__ int c_head_off[6] = {0, 4, 13, 22, 62, 65};   // offsets inside the 65-wide act/mask row
+__constant__ int c_t_units[6] = {1, 5, 16, 16, 1, 1};
+__constant__ int c_t_cum[7] = {0, 1, 6, 22, 38, 39, 40};
+
+// stats block (doubles), shared by the loss kernels and the finaliser
+enum { ST_ADV_SUM = 0, ST_ADV_SQ = 1, ST_NSEL = 2 /*5*/, ST_POL = 7 /*5*/, ST_ENT = 12 /*5*/, ST_VAL = 17, ST_COUNT = 18 };
+
+// ---------------------------------------------------------------------------------------------------
+// target-unit logits: tu[n][u] = sum_c q[n][c] * emb[n][u][c];  16 lanes per unit, 4 units per wave pass
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restrict__ headout, const float* __restrict__ emb,
+                                                          float* __restrict__ tu, long long nr) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 4, l16 = lane & 15;
+    for (long long n = (long long)blockIdx.x * 4 + wave; n < nr; n += (long long)gridDim.x * 4) {
+        const float4* qp = reinterpret_cast<const float4*>(headout + n * HO_LD);
+        const float4 q0 = qp[l16], q1 = qp[16 + l16];
+#pragma unroll
+        for (int u0 = 0; u0 < NUNITS; u0 += 4) {
+            const int u = u0 + sub;
+            int t = 0;
+#pragma unroll
+            for (int i = 1; i < 6; ++i) if (u >= c_t_cum[i]) t = i;
+            const float4* ep = reinterpret_cast<const float4*>(
+                emb + (nr * c_t_cum[t] + n * c_t_units[t] + (u - c_t_cum[t])) * EMBW);
+            const float4 e0 = ep[l16], e1 = ep[16 + l16];
+            float s = q0.x * e0.x + q0.y * e0.y + q0.z * e0.z + q0.w * e0.w + q1.x * e1.x + q1.y * e1.y + q1.z * e1.z +
+                      q1.w * e1.w;
+            s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+            if (l16 == 0) tu[n * NUNITS + u] = s;
+        }
+    }
+}
+
+// dq[n][c] = sum_u dtu[n][u] * emb[n][u][c]  -> dheadout[n][0..127]; 128 threads per env-step
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ dtu, const float* __restrict__ emb,
+                                                         float* __restrict__ dheadout, long long nr) {
+    const int c = threadIdx.x & 127, sub = threadIdx.x >> 7;
+    for (long long n = (long long)blockIdx.x * 2 + sub; n < nr; n += (long long)gridDim.x * 2) {
+        const float* dt = dtu + n * NUNITS;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int U = c_t_units[t];
+            const float* p = emb + (nr * c_t_cum[t] + n * U) * EMBW + c;
+            for (int u = 0; u < U; ++u) acc = fmaf(dt[c_t_cum[t] + u], p[(long long)u * EMBW], acc);
+        }
+        dheadout[n * HO_LD + c] = acc;
+    }
+}
+
+__device__ __forceinline__ float head_logit(const float* __restrict__ ho, const float* __restrict__ tu, int k, int c) {
+    switch (k) {
+        case 0: return ho[HO_ENUM + c];
+        case 1: return ho[HO_X + c];
+        case 2: return ho[HO_Y + c];
+        case 3: return tu[c];
+        default: return ho[HO_ABILITY + c];
+    }
+}
+__device__ __forceinline__ int head_grad_col(int k, int c) {
+    switch (k) {
+        case 0: return HO_ENUM + c;
+        case 1: return HO_X + c;
+        case 2: return HO_Y + c;
+        case 3: return -1;
+        default: return HO_ABILITY + c;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// rollout-pass epilogue (optimizer.py:387-390): log-prob of the selected action per head (0 where the
+// head has no action in that step), the value, and the masked argmax per head (-1 on an empty mask).
+// One thread per (env-step, head).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void select_logp_kernel(const float* __restrict__ headout, const float* __restrict__ tu,
+                                                          const uint8_t* __restrict__ act, const uint8_t* __restrict__ mask,
+                                                          float* __restrict__ logp_sel, float* __restrict__ values,
+                                                          int32_t* __restrict__ argmax, long long nr) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nr * 5) return;
+    const long long n = idx / 5;
+    const int k = (int)(idx - n * 5);
+    const float* ho = headout + n * HO_LD;
+    const float* tun = tu + n * NUNITS;
+    const int o = c_head_off[k], C = c_head_off[k + 1] - o;
+    const uint8_t* m = mask + n * ACT + o;
+    const uint8_t* a = act + n * ACT + o;
+    float se = 0.f, best = -INFINITY;
+    int bi = -1, ai = -1;
+    for (int c = 0; c < C; ++c) {
+        const float z = head_logit(ho, tun, k, c);
+        if (m[c]) {
+            se += expf(z);                     // policy.py:172-175: no max-subtraction
+            if (z > best) { best = z; bi = c; }
+        }
+        if (a[c] && ai < 0) ai = c;
+    }
+    float lp = 0.f;
+    if (ai >= 0) lp = head_logit(ho, tun, k, ai) - logf(se);
+    logp_sel[n * 5 + k] = lp;
+    if (argmax) argmax[n * 5 + k] = bi;
+    if (k == 0) values[n] = ho[HO_VALUE];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// batch statistics needed before the loss: sum / sum-of-squares of the advantages (optimizer.py:588)
+// and the number of steps that took an action per head (optimizer.py:626,643)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void batch_stats_kernel(const float* __restrict__ adv, const uint8_t* __restrict__ act,
+                                                          double* __restrict__ stats, long long nr) {
+    double s = 0.0, sq = 0.0;
+    double cnt[5] = {0, 0, 0, 0, 0};
+    for (long long n = (long long)blockIdx.x * 256 + threadIdx.x; n < nr; n += (long long)gridDim.x * 256) {
+        const double a = adv[n];
+        s += a; sq += a * a;
+        const uint8_t* ar = act + n * ACT;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            int any = 0;
+            for (int c = c_head_off[k]; c < c_head_off[k + 1]; ++c) any |= ar[c];
+            cnt[k] += any ? 1.0 : 0.0;
+        }
+    }
+    __shared__ double sh[4][7];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double v[7] = {s, sq, cnt[0], cnt[1], cnt[2], cnt[3], cnt[4]};
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const double r = wave_sum(v[i]);
+        if (lane == 0) sh[wave][i] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const double r = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+        atomicAdd(&stats[threadIdx.x], r);   // ST_ADV_SUM, ST_ADV_SQ, ST_NSEL..
+    }
+}
+
+struct LossArgs {
+    const float* headout; const float* tu;
+    const uint8_t* act; const uint8_t* mask;
+    const float* old_logp;   // [nr][5]
+    const float* adv;        // [nr] raw advantages
+    const float* ret;        // [nr]
+    double* stats;
+    float* dheadout;         // [nr][160] cols 128..153 written here (0..127 by attn_bwd_q)
+    float* dtu;              // [nr][40]
+    long long nr;
+    float e_clip, entropy_coef, vf_coef, adv_eps;
+};
+
+// One thread per (env-step, head): loss partial sums + d(loss)/d(logits); the head-0 thread also does
+// the value term.  Partial sums are reduced per block and accumulated in double.
+__global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    double pol = 0.0, ent = 0.0, val = 0.0;
+    int k = 0;
+    const bool on = idx < p.nr * 5;
+    if (on) {
+        const long long n = idx / 5;
+        k = (int)(idx - n * 5);
+        const double N = (double)p.nr;
+        const double mean = p.stats[ST_ADV_SUM] / N;
+        // torch.std: unbiased (N-1); optimizer.py:588
+        double var = (p.stats[ST_ADV_SQ] - N * mean * mean) / (N - 1.0);
+        if (var < 0.0) var = 0.0;
+        const float A = (float)(((double)p.adv[n] - mean) / (sqrt(var) + (double)p.adv_eps));
+        const double nsel = p.stats[ST_NSEL + k];
+        const float* ho = p.headout + n * HO_LD;
+        const float* tun = p.tu + n * NUNITS;
+        const int o = c_head_off[k], C = c_head_off[k + 1] - o;
+        const uint8_t* m = p.mask + n * ACT + o;
+        const uint8_t* a = p.act + n * ACT + o;
+        float se = 0.f;
+        int ai = -1, many = 0;
+        for (int c = 0; c < C; ++c) {
+            if (m[c]) { se += expf(head_logit(ho, tun, k, c)); many = 1; }
+            if (a[c] && ai < 0) ai = c;
+        }
+        const float lse = logf(se);
+        // entropy of this row over the masked entries (optimizer.py:643-646)
+        float Hrow = 0.f;
+        if (many) {
+            for (int c = 0; c < C; ++c)
+                if (m[c]) {
+                    const float lp = head_logit(ho, tun, k, c) - lse;
+                    Hrow -= expf(lp) * lp;
+                }
+        }
+        // clipped-ratio surrogate for the selected action (optimizer.py:633-641)
+        float g_lp = 0.f;  // d(total loss)/d(logp_sel)
+        if (ai >= 0 && nsel > 0.0) {
+            const float lp = head_logit(ho, tun, k, ai) - lse;
+            const float ratio = expf(lp - p.old_logp[n * 5 + k]);
+            const float s1 = ratio * A;
+            const float rc = fminf(fmaxf(ratio, 1.f - p.e_clip), 1.f + p.e_clip);
+            const float s2 = rc * A;
+            pol = -(double)fminf(s1, s2);
+            // d min(s1,s2)/d ratio: torch splits ties evenly; clamp passes gradient inside [lo,hi]
+            const bool inr = (ratio >= 1.f - p.e_clip) && (ratio <= 1.f + p.e_clip);
+            float w1, w2;
+            if (s1 < s2) { w1 = 1.f; w2 = 0.f; } else if (s1 > s2) { w1 = 0.f; w2 = 1.f; } else { w1 = 0.5f; w2 = 0.5f; }
+            const float dmin_dr = A * (w1 + (inr ? w2 : 0.f));
+            g_lp = (float)(-(double)dmin_dr * (double)ratio / (5.0 * nsel));
+        }
+        const float g_ent = (nsel > 0.0 && p.entropy_coef > 0.f) ? (float)((double)p.entropy_coef / nsel) : 0.f;
+        if (nsel > 0.0 && many) ent = (double)Hrow;
+        // d loss / d logit_c = g_lp * (delta_{c,a} - [mask_c] p_c) + g_ent * [mask_c] p_c (logp_c + Hrow)
+        for (int c = 0; c < C; ++c) {
+            float g = 0.f;
+            if (m[c]) {
+                const float lp = head_logit(ho, tun, k, c) - lse;
+                const float pc = expf(lp);
+                g = -g_lp * pc + g_ent * pc * (lp + Hrow);
+            }
+            if (c == ai) g += g_lp;
+            const int col = head_grad_col(k, c);
+            if (col >= 0) p.dheadout[n * HO_LD + col] = g;
+            else p.dtu[n * NUNITS + c] = g;
+        }
+        if (k == 0) {
+            const float v = ho[HO_VALUE];
+            const float d = p.ret[n] - v;
+            val = (double)d * (double)d;
+            // value_loss = vf_coef * 0.5 * mean((R - V)^2)  (optimizer.py:658-661)
+            p.dheadout[n * HO_LD + HO_VALUE] = (p.vf_coef > 0.f) ? (float)((double)p.vf_coef * (double)(v - p.ret[n]) / N) : 0.f;
+#pragma unroll
+            for (int c = HO_VALUE + 1; c < HO_LD; ++c) p.dheadout[n * HO_LD + c] = 0.f;
+        }
+    }
+    // block reduction: 5 policy sums + 5 entropy sums + value sum
+    __shared__ double sh[4][11];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) {
+        const double a = wave_sum((on && k == kk) ? pol : 0.0);
+        const double b = wave_sum((on && k == kk) ? ent : 0.0);
+        if (lane == 0) { sh[wave][kk] = a; sh[wave][5 + kk] = b; }
+    }
+    const double vs = wave_sum(val);
+    if (lane == 0) sh[wave][10] = vs;
+    __syncthreads();
+    if (threadIdx.x < 11) {
+        const double r = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+        if (r != 0.0) atomicAdd(&p.stats[ST_POL + threadIdx.x], r);   // ST_POL(5) ST_ENT(5) ST_VAL contiguous
+    }
+}
+
+// losses[0..3] = loss, policy_loss, entropy_loss, value_loss ; losses[4..8] = entropies per head
+// (optimizer.py:649-665, 682-689); flags[0..4] = 1 if head k had at least one action in the batch
+__global__ void loss_finalize_kernel(const double* __restrict__ stats, float* __restrict__ out, int32_t* __restrict__ head_on,
+                                     long long nr, float entropy_coef, float vf_coef) {
+    if (threadIdx.x != 0) return;
+    double pol_sum = 0.0, ent_sum = 0.0;
+    for (int k = 0; k < 5; ++k) {
+        const double nsel = stats[ST_NSEL + k];
+        // fp32 like the reference's 0-d tensors: mean of the per-step terms, then mean over the 5 heads
+        const float lk = nsel > 0.0 ? (float)(stats[ST_POL + k] / nsel) : 0.f;
+        const float hk = nsel > 0.0 ? (float)(stats[ST_ENT + k] / nsel) : 0.f;
+        pol_sum += (double)lk;
+        ent_sum += (double)hk;
+        out[4 + k] = hk;
+        head_on[k] = nsel > 0.0 ? 1 : 0;
+    }
+    const float policy_loss = (float)(pol_sum / 5.0);
+    const float entropy_loss = entropy_coef > 0.f ? -entropy_coef * (float)ent_sum : 0.f;
+    const float value_loss = vf_coef > 0.f ? vf_coef * (0.5f * (float)(stats[ST_VAL] / (double)nr)) : 0.f;
+    out[0] = policy_loss + entropy_loss + value_loss;
+    out[1] = policy_loss;
+    out[2] = entropy_loss;
+    out[3] = value_loss;
+}
+
+static inline int grid1d(long long items, int per_block, int cap) {
+    long long g = (items + per_block - 1) / per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int attn_logits(const float* headout, const float* emb, float* tu, long long nr, hipStream_t s) {
+    hipLaunchKernelGGL(attn_logits_kernel, dim3(grid1d(nr, 4, 256 * 16)), dim3(256), 0, s, headout, emb, tu, nr);
+    return launch_check("attn_logits");
+}
+
+int attn_bwd_q(const float* dtu, const float* emb, float* dheadout, long long nr, hipStream_t s) {
+    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(grid1d(nr, 2, 256 * 16)), dim3(256), 0, s, dtu, emb, dheadout, nr);
+    return launch_check("attn_bwd_q");
+}
+
+int select_logp(const float* headout, const float* tu, const uint8_t* act, const uint8_t* mask, float* logp_sel,
+                float* values, int32_t* argmax, long long nr, hipStream_t s) {
+    hipLaunchKernelGGL(select_logp_kernel, dim3((unsigned)((nr * 5 + 255) / 256)), dim3(256), 0, s, headout, tu, act, mask,
+                       logp_sel, values, argmax, nr);
+    return launch_check("select_logp");
+}
+
+int ppo_loss_fwd_bwd(const float* headout, const float* tu, const uint8_t* act, const uint8_t* mask, const float* old_logp,
+                     const float* adv, const float* ret, double* stats, float* dheadout, float* dtu, float* losses_out,
+                     int32_t* head_on, long long nr, float e_clip, float entropy_coef, float vf_coef, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(stats, 0, ST_COUNT * sizeof(double), s);
+    if (e != hipSuccess) { set_error("ppo_loss: memset", (int)e); return (int)e; }
+    hipLaunchKernelGGL(batch_stats_kernel, dim3(grid1d(nr, 256, 1024)), dim3(256), 0, s, adv, act, stats, nr);
+    LossArgs a;
+    a.headout = headout; a.tu = tu; a.act = act; a.mask = mask; a.old_logp = old_logp; a.adv = adv; a.ret = ret;
+    a.stats = stats; a.dheadout = dheadout; a.dtu = dtu; a.nr = nr;
+    a.e_clip = e_clip; a.entropy_coef = entropy_coef; a.vf_coef = vf_coef;
+    a.adv_eps = 1.1920928955078125e-07f;   // np.finfo(np.float32).eps, optimizer.py:38
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3((unsigned)((nr * 5 + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, stats, losses_out, head_on, nr, entropy_coef, vf_coef);
+    return launch_check("ppo_loss_fwd_bwd");
+}
+
+}  // namespace dc

@@ -1,0 +1,65 @@
+// Internal prototypes shared by the translation units of libdotaclient_hip.so.
+#pragma once
+#include "common.h"
+
+namespace dc {
+
+struct RnnStepArgs {
+    const int64_t* seq_off;
+    const int32_t* seq_len;
+    int n_seq, H, t;
+    // forward
+    const float* Whh;      // [G*H][H]
+    const float* bhh;      // [G*H]
+    float* gates;          // [rows][G*H] in: W_ih x + b_ih, out: activated gates
+    float* hn;             // [rows][H]   GRU: W_hn h + b_hn
+    float* hseq;           // [rows][H]
+    float* hprev;          // [rows][H]
+    float* cseq;           // [rows][H]   LSTM
+    float* cprev;          // [rows][H]   LSTM
+    // backward
+    const float* WhhT;     // [H][G*H]
+    float* dh;             // [rows][H]  in: dL/dh_t from above, out: total dL/dh_t
+    float* dc;             // [rows][H]  LSTM: total dL/dc_t
+    float* dgx;            // [rows][G*H] grad wrt (W_ih x + b_ih)
+    float* dgh;            // [rows][G*H] grad wrt (W_hh h + b_hh)   (GRU; LSTM: == dgx)
+};
+
+// gae.hip
+int gae_scan(const float* rewards, const float* values, const int64_t* seq_off, const int32_t* seq_len, int n_seq,
+             int max_len, double gamma, double lam, float* adv, float* ret, hipStream_t stream);
+// gemm.hip
+int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kmajor,
+             int b_kmajor, const float* bias, int relu, const float* aux, int ldaux, int accumulate, int splits,
+             hipStream_t stream);
+// embed.hip
+int unit_basic_fwd(const float* obs, const float* W1, const float* b1, float* basic, long long nr, hipStream_t s);
+int pool_env_fwd(const float* obs, const float* emb, const float* Wenv, const float* benv, float* xcat, uint8_t* amax,
+                 long long nr, hipStream_t s);
+int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, const float* dtu, const float* q, int ldq,
+                      const uint8_t* amax, float* demb, float* dWenv, float* dbenv, long long nr, hipStream_t s);
+int unit_basic_bwd(const float* obs, const float* dbasic, float* dW1, float* db1, long long nr, hipStream_t s);
+int colsum(const float* X, int ld, long long rows, int cols, float* out, hipStream_t s);
+// heads.hip
+int attn_logits(const float* headout, const float* emb, float* tu, long long nr, hipStream_t s);
+int attn_bwd_q(const float* dtu, const float* emb, float* dheadout, long long nr, hipStream_t s);
+int select_logp(const float* headout, const float* tu, const uint8_t* act, const uint8_t* mask, float* logp_sel,
+                float* values, int32_t* argmax, long long nr, hipStream_t s);
+int ppo_loss_fwd_bwd(const float* headout, const float* tu, const uint8_t* act, const uint8_t* mask, const float* old_logp,
+                     const float* adv, const float* ret, double* stats, float* dheadout, float* dtu, float* losses_out,
+                     int32_t* head_on, long long nr, float e_clip, float entropy_coef, float vf_coef, hipStream_t s);
+// rnn.hip
+int transpose(const float* in, float* out, int rows, int cols, hipStream_t s);
+int rnn_seed_state(const float* h0, float* hprev, const int64_t* seq_off, const int32_t* seq_len, int n_seq, int H,
+                   hipStream_t s);
+int rnn_final_state(const float* hseq, float* hT, const int64_t* seq_off, const int32_t* seq_len, int n_seq, int H,
+                    hipStream_t s);
+int rnn_forward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s);
+int rnn_backward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s);
+// adam.hip
+int gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const int32_t* seg_gate, int n_seg, int max_seg_len,
+                       float* param, float* grad, float* m, float* v, double* segsq, const int32_t* head_on,
+                       const float* losses, float* norms_out, float* ctl, int32_t* seg_step, int32_t* status,
+                       float max_norm, float vf_coef, double lr, double beta1, double beta2, float eps, hipStream_t s);
+
+}  // namespace dc

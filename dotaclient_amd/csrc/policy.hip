@@ -1,0 +1,214 @@
+// Whole-network orchestration: forward, loss seeds -> backward, on a caller-provided workspace.
+//
+// Replaces /root/reference/policy.py:92-167 (Policy.forward) and the reverse pass torch autograd
+// builds for it at /root/reference/optimizer.py:672.  Every matrix product goes through gemm.hip
+// (exact-fp32 MFMA); the sequential recurrent steps through rnn.hip; the HBM-bound glue through
+// embed.hip / heads.hip.  Nothing is allocated here: `ws` is one device buffer laid out by
+// workspace_layout() below (sizes depend only on dc_dims), so a whole epoch can be replayed as a
+// hipGraph by the caller.
+#include "../../include/dotaclient_hip.h"
+#include "kernels.h"
+
+namespace dc {
+
+static const int T_UNITS[6] = {1, 5, 16, 16, 1, 1};
+static const int T_CUM[7] = {0, 1, 6, 22, 38, 39, 40};
+enum { EMBW = 128, XCATW = 896, PREW = 256, HO_LD = 160, HO_N = 154 };
+
+// parameter offsets (floats) inside the flat buffer, in the order of dc_param_index (header)
+struct Params {
+    const float* base;
+    const int64_t* off;
+    const float* p(int i) const { return base + off[i]; }
+};
+struct Grads {
+    float* base;
+    const int64_t* off;
+    float* p(int i) const { return base + off[i]; }
+};
+
+static inline int64_t align_up(int64_t x) { return (x + 255) / 256 * 256; }
+
+// offsets (bytes) of every workspace buffer; returns total bytes.  out must hold
+// DC_WS_FIXED + DC_WS_PER_LAYER * layers entries.
+int64_t workspace_layout(const dc_dims* d, int64_t* out) {
+    const int64_t NR = d->rows, H = d->hidden, G = d->cell == 0 ? 3 : 4, B = d->n_seq;
+    (void)B;
+    int64_t off = 0;
+    auto put = [&](int idx, int64_t bytes) { out[idx] = off; off = align_up(off + bytes); };
+    put(DC_WS_BASIC, NR * 40 * EMBW * 4);
+    put(DC_WS_EMB, NR * 40 * EMBW * 4);
+    put(DC_WS_DEMB, NR * 40 * EMBW * 4);
+    put(DC_WS_XCAT, NR * XCATW * 4);
+    put(DC_WS_AMAX, NR * 3 * EMBW);
+    put(DC_WS_PRE, NR * PREW * 4);
+    put(DC_WS_HEADOUT, NR * HO_LD * 4);
+    put(DC_WS_TU, NR * 40 * 4);
+    put(DC_WS_DHEADOUT, NR * HO_LD * 4);
+    put(DC_WS_DTU, NR * 40 * 4);
+    put(DC_WS_DPRE, NR * PREW * 4);
+    put(DC_WS_DXCAT, NR * XCATW * 4);
+    put(DC_WS_STATS, 64 * 8);
+    put(DC_WS_WHHT, H * G * H * 4);
+    for (int l = 0; l < d->layers; ++l) {
+        const int b = DC_WS_FIXED + l * DC_WS_PER_LAYER;
+        put(b + DC_WSL_GATES, NR * G * H * 4);
+        put(b + DC_WSL_HN, NR * H * 4);
+        put(b + DC_WSL_HSEQ, NR * H * 4);
+        put(b + DC_WSL_HPREV, NR * H * 4);
+        put(b + DC_WSL_CSEQ, d->cell == 1 ? NR * H * 4 : 0);
+        put(b + DC_WSL_CPREV, d->cell == 1 ? NR * H * 4 : 0);
+        put(b + DC_WSL_DGX, NR * G * H * 4);
+        put(b + DC_WSL_DGH, d->cell == 0 ? NR * G * H * 4 : 0);
+        put(b + DC_WSL_DC, d->cell == 1 ? NR * H * 4 : 0);
+        put(b + DC_WSL_DH, NR * H * 4);
+    }
+    return off;
+}
+
+struct Ws {
+    char* base;
+    int64_t off[DC_WS_FIXED + DC_WS_PER_LAYER * DC_MAX_LAYERS];
+    float* f(int i) const { return reinterpret_cast<float*>(base + off[i]); }
+    float* fl(int l, int i) const { return f(DC_WS_FIXED + l * DC_WS_PER_LAYER + i); }
+};
+
+static int check_dims(const dc_dims* d) {
+    if (d->layers < 1 || d->layers > DC_MAX_LAYERS) { set_error("dims: layers out of range", 1020); return 1020; }
+    if (d->cell != 0 && d->cell != 1) { set_error("dims: cell must be 0 (gru) or 1 (lstm)", 1021); return 1021; }
+    if (d->hidden % 64 != 0 || d->hidden <= 0) { set_error("dims: hidden must be a multiple of 64", 1022); return 1022; }
+    if (d->rows * 40 * 128 >= (1LL << 31) * 8) { set_error("dims: too many rows for one call", 1023); return 1023; }
+    return 0;
+}
+
+#define DC_TRY(x) do { int _e = (x); if (_e) return _e; } while (0)
+
+int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, const float* obs, const float* h0,
+                   const float* c0, const int64_t* seq_off, const int32_t* seq_len, void* ws_base, float* hT, float* cT,
+                   hipStream_t s) {
+    DC_TRY(check_dims(d));
+    if (d->rows <= 0 || d->n_seq <= 0) return 0;
+    Ws w; w.base = (char*)ws_base; workspace_layout(d, w.off);
+    Params P{params, poff};
+    const long long NR = d->rows;
+    const int H = d->hidden, G = d->cell == 0 ? 3 : 4, B = d->n_seq;
+
+    // per-unit embedding MLP (policy.py:100-126): layer 1 on VALU, layer 2 as six dense GEMMs
+    DC_TRY(unit_basic_fwd(obs, P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), w.f(DC_WS_BASIC), NR, s));
+    for (int t = 0; t < 6; ++t) {
+        const size_t ro = (size_t)NR * T_CUM[t] * EMBW;
+        DC_TRY(gemm_f32(w.f(DC_WS_BASIC) + ro, P.p(DC_P_UNIT_W) + (size_t)t * EMBW * EMBW, w.f(DC_WS_EMB) + ro,
+                        (int)(NR * T_UNITS[t]), EMBW, EMBW, EMBW, EMBW, EMBW, 0, 0, P.p(DC_P_UNIT_B) + t * EMBW, 0, nullptr, 0,
+                        0, 1, s));
+    }
+    // env embedding + max-pools -> xcat (policy.py:97,102-136)
+    DC_TRY(pool_env_fwd(obs, w.f(DC_WS_EMB), P.p(DC_P_ENV_W), P.p(DC_P_ENV_B), w.f(DC_WS_XCAT),
+                        reinterpret_cast<uint8_t*>(w.base + w.off[DC_WS_AMAX]), NR, s));
+    // pre-rnn projection (policy.py:138)
+    DC_TRY(gemm_f32(w.f(DC_WS_XCAT), P.p(DC_P_PRE_W), w.f(DC_WS_PRE), (int)NR, PREW, XCATW, XCATW, XCATW, PREW, 0, 0,
+                    P.p(DC_P_PRE_B), 1, nullptr, 0, 0, 1, s));
+    // recurrent core (policy.py:141)
+    const float* x = w.f(DC_WS_PRE);
+    int in = PREW;
+    for (int l = 0; l < d->layers; ++l) {
+        const int pb = DC_P_RNN0 + 4 * l;
+        DC_TRY(gemm_f32(x, P.p(pb + 0), w.fl(l, DC_WSL_GATES), (int)NR, G * H, in, in, in, G * H, 0, 0, P.p(pb + 2), 0, nullptr,
+                        0, 0, 1, s));
+        DC_TRY(rnn_seed_state(h0 ? h0 + (size_t)l * B * H : nullptr, w.fl(l, DC_WSL_HPREV), seq_off, seq_len, B, H, s));
+        if (d->cell == 1)
+            DC_TRY(rnn_seed_state(c0 ? c0 + (size_t)l * B * H : nullptr, w.fl(l, DC_WSL_CPREV), seq_off, seq_len, B, H, s));
+        RnnStepArgs a{};
+        a.seq_off = seq_off; a.seq_len = seq_len; a.n_seq = B; a.H = H;
+        a.Whh = P.p(pb + 1); a.bhh = P.p(pb + 3);
+        a.gates = w.fl(l, DC_WSL_GATES); a.hn = w.fl(l, DC_WSL_HN); a.hseq = w.fl(l, DC_WSL_HSEQ);
+        a.hprev = w.fl(l, DC_WSL_HPREV); a.cseq = w.fl(l, DC_WSL_CSEQ); a.cprev = w.fl(l, DC_WSL_CPREV);
+        DC_TRY(rnn_forward_layer(d->cell, a, d->max_len, s));
+        if (hT) DC_TRY(rnn_final_state(w.fl(l, DC_WSL_HSEQ), hT + (size_t)l * B * H, seq_off, seq_len, B, H, s));
+        if (cT && d->cell == 1)
+            DC_TRY(rnn_final_state(w.fl(l, DC_WSL_CSEQ), cT + (size_t)l * B * H, seq_off, seq_len, B, H, s));
+        x = w.fl(l, DC_WSL_HSEQ);
+        in = H;
+    }
+    // all head projections as one GEMM (policy.py:144-155), then the attention logits (policy.py:152)
+    DC_TRY(gemm_f32(x, P.p(DC_P_HEADS_W), w.f(DC_WS_HEADOUT), (int)NR, HO_N, H, H, H, HO_LD, 0, 0, P.p(DC_P_HEADS_B), 0,
+                    nullptr, 0, 0, 1, s));
+    DC_TRY(attn_logits(w.f(DC_WS_HEADOUT), w.f(DC_WS_EMB), w.f(DC_WS_TU), NR, s));
+    return 0;
+}
+
+// Consumes DHEADOUT[:,128:154] and DTU (written by ppo_loss_fwd_bwd) and everything policy_forward
+// saved; overwrites the flat gradient buffer (total_floats long).
+int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, float* grads, int64_t total_floats,
+                    const float* obs, const int64_t* seq_off, const int32_t* seq_len, void* ws_base, hipStream_t s) {
+    DC_TRY(check_dims(d));
+    hipError_t e = hipMemsetAsync(grads, 0, (size_t)total_floats * sizeof(float), s);
+    if (e != hipSuccess) { set_error("policy_backward: memset", (int)e); return (int)e; }
+    if (d->rows <= 0 || d->n_seq <= 0) return 0;
+    Ws w; w.base = (char*)ws_base; workspace_layout(d, w.off);
+    Params P{params, poff};
+    Grads Gd{grads, poff};
+    const long long NR = d->rows;
+    const int H = d->hidden, G = d->cell == 0 ? 3 : 4, B = d->n_seq, L = d->layers;
+    const int TOP = L - 1;
+
+    // heads (policy.py:144-155)
+    DC_TRY(attn_bwd_q(w.f(DC_WS_DTU), w.f(DC_WS_EMB), w.f(DC_WS_DHEADOUT), NR, s));
+    DC_TRY(gemm_f32(w.f(DC_WS_DHEADOUT), P.p(DC_P_HEADS_W), w.fl(TOP, DC_WSL_DH), (int)NR, H, HO_N, HO_LD, H, H, 0, 1, nullptr,
+                    0, nullptr, 0, 0, 1, s));
+    DC_TRY(gemm_f32(w.f(DC_WS_DHEADOUT), w.fl(TOP, DC_WSL_HSEQ), Gd.p(DC_P_HEADS_W), HO_N, H, (int)NR, HO_LD, H, H, 1, 1,
+                    nullptr, 0, nullptr, 0, 1, 0, s));
+    DC_TRY(colsum(w.f(DC_WS_DHEADOUT), HO_LD, NR, HO_N, Gd.p(DC_P_HEADS_B), s));
+
+    // recurrent core, top layer first
+    for (int l = TOP; l >= 0; --l) {
+        const int pb = DC_P_RNN0 + 4 * l;
+        DC_TRY(transpose(P.p(pb + 1), w.f(DC_WS_WHHT), G * H, H, s));
+        RnnStepArgs a{};
+        a.seq_off = seq_off; a.seq_len = seq_len; a.n_seq = B; a.H = H;
+        a.gates = w.fl(l, DC_WSL_GATES); a.hn = w.fl(l, DC_WSL_HN); a.hseq = w.fl(l, DC_WSL_HSEQ);
+        a.hprev = w.fl(l, DC_WSL_HPREV); a.cseq = w.fl(l, DC_WSL_CSEQ); a.cprev = w.fl(l, DC_WSL_CPREV);
+        a.WhhT = w.f(DC_WS_WHHT); a.dh = w.fl(l, DC_WSL_DH); a.dc = w.fl(l, DC_WSL_DC);
+        a.dgx = w.fl(l, DC_WSL_DGX);
+        a.dgh = d->cell == 0 ? w.fl(l, DC_WSL_DGH) : w.fl(l, DC_WSL_DGX);
+        DC_TRY(rnn_backward_layer(d->cell, a, d->max_len, s));
+        const float* xin = l == 0 ? w.f(DC_WS_PRE) : w.fl(l - 1, DC_WSL_HSEQ);
+        const int in = l == 0 ? PREW : H;
+        // dW_ih = dgx^T x ; dW_hh = dgh^T h_prev ; biases = column sums
+        DC_TRY(gemm_f32(a.dgx, xin, Gd.p(pb + 0), G * H, in, (int)NR, G * H, in, in, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s));
+        DC_TRY(gemm_f32(a.dgh, a.hprev, Gd.p(pb + 1), G * H, H, (int)NR, G * H, H, H, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s));
+        DC_TRY(colsum(a.dgx, G * H, NR, G * H, Gd.p(pb + 2), s));
+        DC_TRY(colsum(a.dgh, G * H, NR, G * H, Gd.p(pb + 3), s));
+        if (l > 0) {
+            DC_TRY(gemm_f32(a.dgx, P.p(pb + 0), w.fl(l - 1, DC_WSL_DH), (int)NR, H, G * H, G * H, H, H, 0, 1, nullptr, 0, nullptr,
+                            0, 0, 1, s));
+        } else {
+            // through relu(affine_pre_rnn) (policy.py:138): mask with the stored activation
+            DC_TRY(gemm_f32(a.dgx, P.p(pb + 0), w.f(DC_WS_DPRE), (int)NR, PREW, G * H, G * H, PREW, PREW, 0, 1, nullptr, 0,
+                            w.f(DC_WS_PRE), PREW, 0, 1, s));
+        }
+    }
+    DC_TRY(gemm_f32(w.f(DC_WS_DPRE), w.f(DC_WS_XCAT), Gd.p(DC_P_PRE_W), PREW, XCATW, (int)NR, PREW, XCATW, XCATW, 1, 1, nullptr,
+                    0, nullptr, 0, 1, 0, s));
+    DC_TRY(colsum(w.f(DC_WS_DPRE), PREW, NR, PREW, Gd.p(DC_P_PRE_B), s));
+    DC_TRY(gemm_f32(w.f(DC_WS_DPRE), P.p(DC_P_PRE_W), w.f(DC_WS_DXCAT), (int)NR, XCATW, PREW, PREW, XCATW, XCATW, 0, 1, nullptr,
+                    0, nullptr, 0, 0, 1, s));
+
+    // max-pool routing + attention keys -> per-unit embedding gradients; env embedding weights
+    DC_TRY(embed_scatter_bwd(obs, w.f(DC_WS_XCAT), w.f(DC_WS_DXCAT), w.f(DC_WS_DTU), w.f(DC_WS_HEADOUT), HO_LD,
+                             reinterpret_cast<const uint8_t*>(w.base + w.off[DC_WS_AMAX]), w.f(DC_WS_DEMB),
+                             Gd.p(DC_P_ENV_W), Gd.p(DC_P_ENV_B), NR, s));
+    for (int t = 0; t < 6; ++t) {
+        const size_t ro = (size_t)NR * T_CUM[t] * EMBW;
+        const int rows_t = (int)(NR * T_UNITS[t]);
+        DC_TRY(gemm_f32(w.f(DC_WS_DEMB) + ro, w.f(DC_WS_BASIC) + ro, Gd.p(DC_P_UNIT_W) + (size_t)t * EMBW * EMBW, EMBW, EMBW,
+                        rows_t, EMBW, EMBW, EMBW, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s));
+        DC_TRY(colsum(w.f(DC_WS_DEMB) + ro, EMBW, rows_t, EMBW, Gd.p(DC_P_UNIT_B) + t * EMBW, s));
+        // dbasic (stored over the no-longer-needed emb buffer), relu-masked by basic
+        DC_TRY(gemm_f32(w.f(DC_WS_DEMB) + ro, P.p(DC_P_UNIT_W) + (size_t)t * EMBW * EMBW, w.f(DC_WS_EMB) + ro, rows_t, EMBW,
+                        EMBW, EMBW, EMBW, EMBW, 0, 1, nullptr, 0, w.f(DC_WS_BASIC) + ro, EMBW, 0, 1, s));
+    }
+    DC_TRY(unit_basic_bwd(obs, w.f(DC_WS_EMB), Gd.p(DC_P_BASIC_W), Gd.p(DC_P_BASIC_B), NR, s));
+    return 0;
+}
+
+}  // namespace dc

@@ -1,0 +1,255 @@
+"""Host-side driver of the HIP library: owns the flat parameter/gradient/Adam buffers, the workspace
+and the packed batches, and sequences the C-ABI calls.  No arithmetic happens here.
+
+Mirrors what the reference does implicitly through torch objects:
+  flat params + views      <->  Policy's nn.Parameters            (policy.py:54-75)
+  PackedBatch               <->  the stacked tensors of train()    (optimizer.py:587-615)
+  Engine.rollout_pass       <->  experiences_from_rollout          (optimizer.py:328-430)
+  Engine.train_epoch        <->  train                             (optimizer.py:581-689)
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import layout as L
+
+CELL_ID = {'gru': 0, 'lstm': 1}
+MAX_GRAD_NORM = 0.5        # optimizer.py:204
+ADAM_BETAS = (0.9, 0.999)  # torch.optim.Adam defaults used at optimizer.py:275
+ADAM_EPS = 1e-8
+
+
+class DcDims(ctypes.Structure):
+    _fields_ = [('cell', ctypes.c_int32), ('hidden', ctypes.c_int32), ('layers', ctypes.c_int32),
+                ('n_seq', ctypes.c_int32), ('max_len', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('rows', ctypes.c_int64)]
+
+
+WS_FIXED = ['BASIC', 'EMB', 'DEMB', 'XCAT', 'AMAX', 'PRE', 'HEADOUT', 'TU', 'DHEADOUT', 'DTU', 'DPRE', 'DXCAT',
+            'STATS', 'WHHT']
+WS_LAYER = ['GATES', 'HN', 'HSEQ', 'HPREV', 'CSEQ', 'CPREV', 'DGX', 'DGH', 'DC', 'DH']
+
+
+class PackedBatch:
+    """Env-steps of several sequences back to back ("packed rows"), all on the GPU."""
+
+    def __init__(self, obs, act, mask, rew, seq_off, seq_len, max_len):
+        self.obs, self.act, self.mask, self.rew = obs, act, mask, rew
+        self.seq_off, self.seq_len = seq_off, seq_len        # int64 / int32 device tensors
+        self.max_len = int(max_len)
+        self.rows = int(obs.shape[0])
+        self.n_seq = int(seq_off.numel())
+        # filled by the rollout pass
+        self.old_logp = self.values = self.adv = self.ret = self.argmax = None
+        self.h0 = self.c0 = None
+
+    def as_chunks(self, seq_len):
+        """Same rows viewed as B = rows/seq_len sequences of seq_len steps (rollouts are stored padded to a
+        multiple of seq_len, so the chunk batch of train() is this very memory)."""
+        assert self.rows % seq_len == 0
+        b = self.rows // seq_len
+        dev = self.obs.device
+        out = PackedBatch(self.obs, self.act, self.mask, self.rew,
+                          torch.arange(b, device=dev, dtype=torch.int64) * seq_len,
+                          torch.full((b,), seq_len, device=dev, dtype=torch.int32), seq_len)
+        out.old_logp, out.values, out.adv, out.ret, out.argmax = self.old_logp, self.values, self.adv, self.ret, self.argmax
+        return out
+
+
+def pack_rollouts(rollouts, seq_len, device):
+    """Wire-format rollout dicts (optimizer.py:314-326) -> PackedBatch with one sequence per rollout, each
+    zero-padded to a multiple of seq_len (optimizer.py:343-382).  Host work: one concatenation + one
+    H2D copy per field."""
+    from .synth import flatten_rollout
+    obs, act, msk, rew, lens = [], [], [], [], []
+    for d in rollouts:
+        o, a, m, r = flatten_rollout(d)
+        T = o.shape[0]
+        Lp = (T + seq_len - 1) // seq_len * seq_len
+        pad = Lp - T
+        if pad:
+            o = np.concatenate([o, np.zeros((pad, o.shape[1]), o.dtype)])
+            a = np.concatenate([a, np.zeros((pad, a.shape[1]), a.dtype)])
+            m = np.concatenate([m, np.zeros((pad, m.shape[1]), m.dtype)])
+            r = np.concatenate([r, np.zeros((pad, r.shape[1]), r.dtype)])
+        obs.append(o); act.append(a); msk.append(m); rew.append(r); lens.append(Lp)
+    lens = np.asarray(lens, dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    to = lambda x: torch.from_numpy(np.ascontiguousarray(np.concatenate(x))).to(device, non_blocking=True)
+    return PackedBatch(to(obs), to(act), to(msk), to(rew), torch.from_numpy(off).to(device),
+                       torch.from_numpy(lens.astype(np.int32)).to(device), int(lens.max()))
+
+
+class Engine:
+    def __init__(self, cell='gru', hidden=256, layers=1, device='cuda:0'):
+        self.lib = _lib.load()
+        self.cell, self.hidden, self.layers = cell, int(hidden), int(layers)
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.DotaHipError('the PPO hot path only runs on the GPU (no CPU fallback)')
+        self.layout, self.total = L.flat_layout(cell, hidden, layers)
+        z = lambda: torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        self.params, self.grads, self.adam_m, self.adam_v = z(), z(), z(), z()
+        # offsets in dc_param_index order
+        names = ['affine_env.weight', 'affine_env.bias', 'affine_unit_basic_stats.weight',
+                 'affine_unit_basic_stats.bias', 'affine_unit_ah.weight', 'affine_unit_ah.bias',
+                 'affine_pre_rnn.weight', 'affine_pre_rnn.bias', 'affine_unit_attention.weight',
+                 'affine_unit_attention.bias']
+        for l in range(layers):
+            names += ['rnn.weight_ih_l%d' % l, 'rnn.weight_hh_l%d' % l, 'rnn.bias_ih_l%d' % l, 'rnn.bias_hh_l%d' % l]
+        self.poff = (ctypes.c_int64 * len(names))(*[self.layout[n][0] for n in names])
+        # Adam segments = the named parameters (optimizer.py:275 iterates policy.parameters())
+        seg_names = list(L.param_shapes(cell, hidden, layers).keys())
+        gate = []
+        for n in seg_names:
+            g = -1
+            if n.startswith('affine_head_enum'): g = 0
+            elif n.startswith('affine_move_x'): g = 1
+            elif n.startswith('affine_move_y'): g = 2
+            elif n.startswith('affine_unit_attention') or n.startswith('affine_unit_eth'): g = 3
+            elif n.startswith('affine_head_ability'): g = 4
+            elif n.startswith('affine_value'): g = 5
+            gate.append(g)
+        self.seg_names = seg_names
+        self.seg_gate_host = gate
+        dev = self.device
+        self.seg_off = torch.tensor([self.layout[n][0] for n in seg_names], dtype=torch.int64, device=dev)
+        self.seg_len = torch.tensor([self.layout[n][1] for n in seg_names], dtype=torch.int32, device=dev)
+        self.seg_gate = torch.tensor(gate, dtype=torch.int32, device=dev)
+        self.max_seg_len = max(self.layout[n][1] for n in seg_names)
+        self.seg_step = torch.zeros(len(seg_names), dtype=torch.int32, device=dev)
+        self.segsq = torch.zeros(len(seg_names), dtype=torch.float64, device=dev)
+        self.out = torch.zeros(16, dtype=torch.float32, device=dev)     # 0..8 losses/entropies, 9..10 norms
+        self.ctl = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.head_on = torch.zeros(8, dtype=torch.int32, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._ws = None
+        self._ws_off = None
+        self._ws_dims_key = None
+
+    # ---- parameters ------------------------------------------------------------------------------
+    def param_view(self, name, buf=None):
+        off, numel, shape = self.layout[name]
+        return (self.params if buf is None else buf)[off:off + numel].view(shape)
+
+    def load_state_dict(self, sd):
+        for n in self.layout:
+            self.param_view(n).copy_(sd[n].to(self.device, torch.float32))
+
+    def state_dict(self):
+        return {n: self.param_view(n).detach().clone() for n in L.param_shapes(self.cell, self.hidden, self.layers)}
+
+    # ---- workspace -------------------------------------------------------------------------------
+    def dims(self, batch):
+        return DcDims(CELL_ID[self.cell], self.hidden, self.layers, batch.n_seq, batch.max_len, 0, batch.rows)
+
+    def _workspace(self, d):
+        n = len(WS_FIXED) + len(WS_LAYER) * self.layers
+        offs = (ctypes.c_int64 * n)()
+        total = self.lib.dc_workspace_layout(ctypes.byref(d), offs)
+        key = (d.rows, d.n_seq)
+        if self._ws is None or self._ws.numel() < total:
+            self._ws = None
+            self._ws = torch.empty(int(total), dtype=torch.uint8, device=self.device)
+        self._ws_off = list(offs)
+        self._ws_dims_key = key
+        return self._ws
+
+    def ws_view(self, d, name, layer=None, dtype=torch.float32):
+        """Tensor view of a workspace buffer (tests / plumbing)."""
+        n = len(WS_FIXED) + len(WS_LAYER) * self.layers
+        offs = (ctypes.c_int64 * n)()
+        total = self.lib.dc_workspace_layout(ctypes.byref(d), offs)
+        idx = WS_FIXED.index(name) if layer is None else len(WS_FIXED) + layer * len(WS_LAYER) + WS_LAYER.index(name)
+        nxt = offs[idx + 1] if idx + 1 < n else total
+        return self._ws[offs[idx]:nxt].view(dtype)
+
+    # ---- C-ABI calls -----------------------------------------------------------------------------
+    def forward(self, batch, h0=None, c0=None, want_final=False):
+        d = self.dims(batch)
+        ws = self._workspace(d)
+        hT = cT = None
+        if want_final:
+            hT = torch.empty(self.layers, batch.n_seq, self.hidden, device=self.device)
+            cT = torch.empty_like(hT) if self.cell == 'lstm' else None
+        _lib.check(self.lib.dc_policy_forward(ctypes.byref(d), _lib.ptr(self.params), self.poff, _lib.ptr(batch.obs),
+                                              _lib.ptr(h0), _lib.ptr(c0), _lib.ptr(batch.seq_off), _lib.ptr(batch.seq_len),
+                                              _lib.ptr(ws), _lib.ptr(hT), _lib.ptr(cT), _lib.stream_ptr()),
+                   'dc_policy_forward')
+        return d, hT, cT
+
+    def select_logp(self, d, batch, want_argmax=True):
+        dev = self.device
+        logp = torch.empty(batch.rows, 5, device=dev)
+        values = torch.empty(batch.rows, device=dev)
+        argmax = torch.empty(batch.rows, 5, dtype=torch.int32, device=dev) if want_argmax else None
+        _lib.check(self.lib.dc_select_logp(ctypes.byref(d), _lib.ptr(self._ws), _lib.ptr(batch.act), _lib.ptr(batch.mask),
+                                           _lib.ptr(logp), _lib.ptr(values), _lib.ptr(argmax), _lib.stream_ptr()),
+                   'dc_select_logp')
+        return logp, values, argmax
+
+    def loss(self, d, batch, e_clip, entropy_coef, vf_coef):
+        _lib.check(self.lib.dc_ppo_loss_fwd_bwd(ctypes.byref(d), _lib.ptr(self._ws), _lib.ptr(batch.act), _lib.ptr(batch.mask),
+                                                _lib.ptr(batch.old_logp), _lib.ptr(batch.adv), _lib.ptr(batch.ret),
+                                                _lib.ptr(self.out), _lib.ptr(self.head_on), float(e_clip),
+                                                float(entropy_coef), float(vf_coef), _lib.stream_ptr()),
+                   'dc_ppo_loss_fwd_bwd')
+
+    def backward(self, d, batch):
+        _lib.check(self.lib.dc_policy_backward(ctypes.byref(d), _lib.ptr(self.params), self.poff, _lib.ptr(self.grads),
+                                               self.total, _lib.ptr(batch.obs), _lib.ptr(batch.seq_off),
+                                               _lib.ptr(batch.seq_len), _lib.ptr(self._ws), _lib.stream_ptr()),
+                   'dc_policy_backward')
+
+    def adam(self, lr, vf_coef):
+        _lib.check(self.lib.dc_gradnorm_clip_adam(
+            _lib.ptr(self.seg_off), _lib.ptr(self.seg_len), _lib.ptr(self.seg_gate), len(self.seg_names),
+            self.max_seg_len, _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v),
+            _lib.ptr(self.segsq), _lib.ptr(self.head_on), _lib.ptr(self.out), _lib.ptr(self.out[9:]), _lib.ptr(self.ctl),
+            _lib.ptr(self.seg_step), _lib.ptr(self.status), MAX_GRAD_NORM, float(vf_coef), float(lr), ADAM_BETAS[0],
+            ADAM_BETAS[1], ADAM_EPS, _lib.stream_ptr()), 'dc_gradnorm_clip_adam')
+
+    # ---- the two passes of one optimizer iteration -------------------------------------------------
+    def rollout_pass(self, batch, seq_len, gamma=0.98, lam=0.97):
+        """optimizer.py:328-430 for all rollouts of `batch` at once: no-grad forward with the hidden state
+        carried across a rollout's chunks, old log-probs, values, GAE.  Returns the chunk view."""
+        from . import ops
+        d, _, _ = self.forward(batch)
+        batch.old_logp, batch.values, batch.argmax = self.select_logp(d, batch)
+        batch.adv, batch.ret = ops.gae_scan(batch.rew, batch.values, batch.seq_off, batch.seq_len, batch.max_len,
+                                            gamma, lam)
+        chunks = batch.as_chunks(seq_len)
+        # initial state of every chunk = state after the previous chunk of the same rollout (detached,
+        # optimizer.py:384,408), zeros for a rollout's first chunk (policy.py:77-78)
+        starts = chunks.seq_off
+        is_first = torch.isin(starts, batch.seq_off)
+        prev_row = (starts - 1).clamp(min=0)
+        H = self.hidden
+        h0 = []
+        c0 = []
+        for l in range(self.layers):
+            hs = self.ws_view(d, 'HSEQ', l)[:batch.rows * H].view(batch.rows, H)
+            h = hs.index_select(0, prev_row)
+            h[is_first] = 0
+            h0.append(h)
+            if self.cell == 'lstm':
+                cs = self.ws_view(d, 'CSEQ', l)[:batch.rows * H].view(batch.rows, H)
+                c = cs.index_select(0, prev_row)
+                c[is_first] = 0
+                c0.append(c)
+        chunks.h0 = torch.stack(h0)
+        chunks.c0 = torch.stack(c0) if c0 else None
+        return chunks
+
+    def train_epoch(self, chunks, lr, entropy_coef, vf_coef, e_clip=0.1, grad_hook=None):
+        """optimizer.py:581-689: one full-batch epoch.  Returns the device tensor `out`
+        (0 loss, 1 policy, 2 entropy, 3 value, 4..8 entropies, 9 unclipped, 10 clipped) and status."""
+        d, _, _ = self.forward(chunks, chunks.h0, chunks.c0)
+        self.loss(d, chunks, e_clip, entropy_coef, vf_coef)
+        self.backward(d, chunks)
+        if grad_hook is not None:
+            grad_hook(self)
+        self.adam(lr, vf_coef)
+        return self.out, self.status

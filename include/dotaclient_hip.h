@@ -46,6 +46,96 @@ int dc_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, i
                 int a_kmajor, int b_kmajor, const float* bias, int relu, const float* aux, int ldaux,
                 int accumulate, int splits, dc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Network + optimizer step.  Shapes: dc_dims; parameters: one flat fp32 buffer whose tensors are
+ * addressed by an offset table `poff` (floats, host array, index = dc_param_index); scratch: one
+ * device workspace laid out by dc_workspace_layout (buffers saved by the forward are consumed by the
+ * loss / backward of the same batch).
+ * ------------------------------------------------------------------------------------------------ */
+#define DC_MAX_LAYERS 4
+
+typedef struct dc_dims {
+    int32_t cell;     /* 0 = GRU (the reference, policy.py:66), 1 = LSTM (BASELINE.json extension) */
+    int32_t hidden;   /* H, multiple of 64 */
+    int32_t layers;   /* 1..DC_MAX_LAYERS */
+    int32_t n_seq;    /* B: sequences (trajectory chunks) in the batch */
+    int32_t max_len;  /* max(seq_len) */
+    int32_t reserved;
+    int64_t rows;     /* total env-steps = sum(seq_len) */
+} dc_dims;
+
+/* index into poff[]; policy.py:54-75 names in comments */
+enum dc_param_index {
+    DC_P_ENV_W = 0,   /* affine_env.weight [128,3] */
+    DC_P_ENV_B,       /* affine_env.bias */
+    DC_P_BASIC_W,     /* affine_unit_basic_stats.weight [128,12] */
+    DC_P_BASIC_B,
+    DC_P_UNIT_W,      /* affine_unit_{ah,eh,anh,enh,ath,eth}.weight, contiguous [6,128,128] */
+    DC_P_UNIT_B,      /* ... .bias contiguous [6,128] */
+    DC_P_PRE_W,       /* affine_pre_rnn.weight [256,896] */
+    DC_P_PRE_B,
+    DC_P_HEADS_W,     /* [154,H]: affine_unit_attention(128) | head_enum(4) | move_x(9) | move_y(9) |
+                         head_ability(3) | affine_value(1), contiguous */
+    DC_P_HEADS_B,     /* [154] same order */
+    DC_P_RNN0,        /* + 4*l: rnn.weight_ih_l, weight_hh_l, bias_ih_l, bias_hh_l */
+    DC_P_COUNT_FIXED = DC_P_RNN0
+};
+
+/* workspace buffer ids (for dc_workspace_layout's offsets[]; bytes) */
+enum dc_ws_index {
+    DC_WS_BASIC = 0, DC_WS_EMB, DC_WS_DEMB, DC_WS_XCAT, DC_WS_AMAX, DC_WS_PRE, DC_WS_HEADOUT, DC_WS_TU,
+    DC_WS_DHEADOUT, DC_WS_DTU, DC_WS_DPRE, DC_WS_DXCAT, DC_WS_STATS, DC_WS_WHHT,
+    DC_WS_FIXED,            /* per-layer blocks follow */
+    DC_WSL_GATES = 0, DC_WSL_HN, DC_WSL_HSEQ, DC_WSL_HPREV, DC_WSL_CSEQ, DC_WSL_CPREV, DC_WSL_DGX, DC_WSL_DGH,
+    DC_WSL_DC, DC_WSL_DH,
+    DC_WS_PER_LAYER
+};
+
+/* Byte offsets of every workspace buffer into offsets[DC_WS_FIXED + DC_WS_PER_LAYER*layers]; returns
+ * the total workspace size in bytes (host-only helper, no GPU work). */
+int64_t dc_workspace_layout(const dc_dims* dims, int64_t* offsets);
+
+/* Replaces Policy.forward (policy.py:92-167) for a packed batch.
+ *   obs [rows,483] f32; h0/c0 [layers,B,H] (NULL = zeros; c0 LSTM only); seq_off i64[B], seq_len i32[B];
+ *   hT/cT [layers,B,H] out (may be NULL).  Results live in the workspace: DC_WS_HEADOUT [rows,160]
+ *   (cols 0..127 attention query, 128..131 enum, 132..140 x, 141..149 y, 150..152 ability, 153 value)
+ *   and DC_WS_TU [rows,40] (target_unit logits). */
+int dc_policy_forward(const dc_dims* dims, const float* params, const int64_t* poff_host, const float* obs,
+                      const float* h0, const float* c0, const int64_t* seq_off, const int32_t* seq_len, void* ws,
+                      float* hT, float* cT, dc_stream_t stream);
+
+/* Rollout-pass epilogue, optimizer.py:387-390 + policy.py:169-178: log-prob of the selected action
+ * per head (0 where the head took no action), value, masked argmax per head (-1 on empty mask).
+ *   act/mask u8 [rows,65]; logp_sel f32 [rows,5]; values f32 [rows]; argmax i32 [rows,5] or NULL. */
+int dc_select_logp(const dc_dims* dims, const void* ws, const uint8_t* act, const uint8_t* mask, float* logp_sel,
+                   float* values, int32_t* argmax, dc_stream_t stream);
+
+/* Loss of DotaOptimizer.train, optimizer.py:587-665, and its gradient w.r.t. logits/value (written
+ * into the workspace for dc_policy_backward).  adv: RAW advantages (normalised inside, optimizer.py:588).
+ *   losses_out f32[9] = loss, policy_loss, entropy_loss, value_loss, entropy[enum,x,y,target_unit,ability]
+ *   head_on i32[5] = 1 if that head took at least one action in the batch. */
+int dc_ppo_loss_fwd_bwd(const dc_dims* dims, void* ws, const uint8_t* act, const uint8_t* mask, const float* old_logp,
+                        const float* adv, const float* ret, float* losses_out, int32_t* head_on, float e_clip,
+                        float entropy_coef, float vf_coef, dc_stream_t stream);
+
+/* loss.backward() of optimizer.py:672 for the network: fills the flat gradient buffer
+ * (total_floats long, same offsets as the parameters; overwritten). */
+int dc_policy_backward(const dc_dims* dims, const float* params, const int64_t* poff_host, float* grads,
+                       int64_t total_floats, const float* obs, const int64_t* seq_off, const int32_t* seq_len, void* ws,
+                       dc_stream_t stream);
+
+/* optimizer.py:674-681: mean_gradient_norm (before/after), clip_grad_norm_(0.5), NaN guards, Adam.
+ *   seg_off i64 / seg_len i32 / seg_gate i32 [n_seg] (device): the named parameters inside the flat
+ *   buffer; seg_gate -1 = always has a gradient, 0..4 = only when head k acted, 5 = only if vf_coef>0;
+ *   m, v: Adam moments (flat); segsq f64[n_seg], ctl f32[2], seg_step i32[n_seg] (persistent step
+ *   counters), status i32[1] (0 ok, 1 NaN loss, 2 NaN grad norm: nothing updated) - all device;
+ *   norms_out f32[2] = unclipped, clipped mean gradient norm. */
+int dc_gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const int32_t* seg_gate, int n_seg,
+                          int max_seg_len, float* params, float* grads, float* m, float* v, double* segsq,
+                          const int32_t* head_on, const float* losses, float* norms_out, float* ctl,
+                          int32_t* seg_step, int32_t* status, float max_norm, float vf_coef, double lr, double beta1,
+                          double beta2, float eps, dc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
