@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""Benchmark of the PPO optimizer hot path (BASELINE.json metric: env-steps/sec through the PPO
+optimizer) on N MI355X of one node, one process per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one optimizer iteration over one batch of synthetic trajectories already resident in
+HBM: the rollout pass (no-grad forward for old log-probs/values + GAE scan, optimizer.py:328-430)
+followed by E = 4 full-batch epochs of train (optimizer.py:581-689; `--epochs` default of the
+reference, optimizer.py:781), each = forward + PPO loss + backward + (RCCL all-reduce if N > 1) +
+clip + Adam.  Default workload = BASELINE.json configs[1]: LSTM hidden=128, 64 trajectories x 256
+steps PER GPU (weak scaling).  Padded steps would count as steps as in the reference
+(optimizer.py:486); the throughput runs have none.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the launch stream in one
+extra, untimed iteration right after the timed region; `cpu_baseline` times the CPU oracle
+(oracle/, restatement of the reference - kind "port") on the host cores, rank 0, N = 1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from dotaclient_amd import synth                      # noqa: E402
+from dotaclient_amd.engine import Engine, pack_rollouts  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense fp32
+PEAK_HBM_GBS = 8000.0
+
+
+def fwd_flops_per_step(cell, hidden, layers):
+    """algorithmic forward FLOPs (2*MACs) per env-step."""
+    g = 3 if cell == 'gru' else 4
+    f = 768 + 122880 + 1310720 + 458752
+    inp = 256
+    for _ in range(layers):
+        f += 2 * g * hidden * (inp + hidden)
+        inp = hidden
+    return f + 2 * hidden * 154 + 10240
+
+
+def profile_report(lib):
+    n = 32
+    names = ctypes.create_string_buffer(64 * n)
+    launches = (ctypes.c_int64 * n)()
+    ms = (ctypes.c_double * n)()
+    fl = (ctypes.c_double * n)()
+    by = (ctypes.c_double * n)()
+    k = lib.dc_profile_report(names, launches, ms, fl, by, n)
+    out = []
+    for i in range(k):
+        nm = names.raw[64 * i:64 * (i + 1)].split(b'\0')[0].decode()
+        out.append({'kernel': nm, 'launches': int(launches[i]), 'total_ms': ms[i], 'flops': fl[i], 'bytes': by[i]})
+    return out
+
+
+def cpu_baseline(cell, hidden, layers, rollouts, seq_len, epochs, lr, ent, vf):
+    """Times the CPU oracle on the same synthetic workload: one rollout pass + `epochs` epochs."""
+    from oracle import ref_optimizer as RO
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    pol = RO.make_policy(synth.init_state_dict(7, cell, hidden, layers), cell, hidden, layers)
+    opt = torch.optim.Adam(pol.parameters(), lr=lr)
+    # warm-up on a small slice (first-call costs), untimed
+    warm = [c for r in rollouts[:2] for c in RO.rollout_pass(pol, r, seq_len)]
+    RO.train_step(pol, opt, warm, ent, vf)
+    t0 = time.time()
+    chunks = []
+    for r in rollouts:
+        chunks.extend(RO.rollout_pass(pol, r, seq_len))
+    t_roll = time.time() - t0
+    t1 = time.time()
+    for _ in range(epochs):
+        RO.train_step(pol, opt, chunks, ent, vf)
+    t_train = time.time() - t1
+    n_steps = len(chunks) * seq_len
+    total = t_roll + t_train
+    return {
+        'value': n_steps / total, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+        'sample': '1 iteration (rollout pass %.2fs + %d epochs %.2fs) of the same %dx%d workload, '
+                  'oracle/ref_optimizer.py on torch CPU fp32' % (t_roll, epochs, t_train, len(rollouts), seq_len),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--cell', default='lstm')
+    ap.add_argument('--hidden', type=int, default=128)
+    ap.add_argument('--layers', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=64, help='trajectories per GPU')
+    ap.add_argument('--seq-len', type=int, default=256)
+    ap.add_argument('--epochs', type=int, default=4)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node = --gpus'
+    dev = torch.device('cuda', local_rank if world > 1 else 0)
+    lr, ent, vf = 5e-5, 5e-4, 0.5
+    B, S, E = args.batch, args.seq_len, args.epochs
+
+    eng = Engine(args.cell, args.hidden, args.layers, dev)
+    eng.load_state_dict(synth.init_state_dict(7, args.cell, args.hidden, args.layers))
+    hook = None
+    if world > 1:
+        from dotaclient_amd.distributed import FlatGradAllReducer
+        hook = FlatGradAllReducer(eng)
+        hook.sync_parameters()
+    # every rank gets its own shard of trajectories (the reference's ranks pull from a shared queue)
+    rollouts = synth.make_rollouts(1000 + rank, [S] * B)
+    batch = pack_rollouts(rollouts, S, dev)
+
+    def step():
+        chunks = eng.rollout_pass(batch, S)
+        for _ in range(E):
+            eng.train_epoch(chunks, lr, ent, vf, grad_hook=hook)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    status = int(eng.status.item())
+    losses = eng.out.cpu().numpy()
+
+    # ---- roofline: one extra untimed iteration with per-launch HIP events --------------------------------
+    eng.lib.dc_profile_enable(1)
+    step()
+    torch.cuda.synchronize()
+    regions = profile_report(eng.lib)
+    eng.lib.dc_profile_enable(0)
+
+    if rank == 0:
+        n_steps = world * B * S * args.steps
+        value = n_steps / elapsed
+        ffwd = fwd_flops_per_step(args.cell, args.hidden, args.layers)
+        regions.sort(key=lambda r: -r['total_ms'])
+        kernels = []
+        for r in regions:
+            avg_us = r['total_ms'] * 1e3 / r['launches']
+            kernels.append({'kernel': r['kernel'], 'launches_per_step': r['launches'], 'avg_us': round(avg_us, 3),
+                            'ms_per_step': round(r['total_ms'], 3),
+                            'achieved_tflops': round(r['flops'] / (r['total_ms'] * 1e-3) / 1e12, 3)})
+        dom = regions[0]
+        achieved = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
+        roofline = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                    'avg_launch_us': round(dom['total_ms'] * 1e3 / dom['launches'], 3),
+                    'flops_per_launch': dom['flops'] / dom['launches'],
+                    'whole_step': {'flops_per_env_step': ffwd * (1 + 3 * E),
+                                   'achieved_tflops': round(value / world * ffwd * (1 + 3 * E) / 1e12, 3)},
+                    'kernels': kernels}
+        line = {
+            'metric': 'env-steps/sec through PPO optimizer', 'value': round(value, 1), 'unit': 'env-steps/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE.json configs[1]: 1v1-mid synthetic trajectories, %s hidden=%d x%d layer, '
+                                   'batch=%d trajectories x %d steps per GPU, %d epochs + rollout pass per step'
+                                   % (args.cell.upper(), args.hidden, args.layers, B, S, E),
+                       'cell': args.cell, 'hidden': args.hidden, 'layers': args.layers, 'batch_per_gpu': B,
+                       'seq_len': S, 'epochs': E, 'parallelism': 'dp%d' % world},
+            'roofline': roofline,
+            'nan_status': status, 'final_loss': float(losses[0]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.cell, args.hidden, args.layers, rollouts, S, E, lr, ent, vf)
+        else:
+            line['cpu_baseline'] = None
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -116,6 +116,35 @@ __global__ __launch_bounds__(256) void adam_update_kernel(AdamSegs sg, float* __
     }
 }
 
+// Data-parallel averaging (distributed.py:24-57): after the SUM all-reduce of the flat gradient bucket,
+// each parameter is divided by the number of ranks that had a gradient for it.  counts[0..4] = ranks
+// whose head k acted (all-reduced with the bucket), counts[5] = world size.  A rank whose own head was
+// inactive keeps "no gradient" for those parameters (its Adam skips them), like the reference, where
+// the reduced value is discarded on ranks with grad None (distributed.py:50-57).
+__global__ __launch_bounds__(256) void dp_scale_kernel(AdamSegs sg, float* __restrict__ grad,
+                                                       const float* __restrict__ counts, float vf_coef) {
+    const int seg = blockIdx.y;
+    const long long len = sg.seg_len[seg];
+    const long long c0 = (long long)blockIdx.x * ADAM_CHUNK;
+    if (c0 >= len) return;
+    const int g = sg.seg_gate[seg];
+    float cnt = counts[5];
+    if (g >= 0 && g < 5) cnt = counts[g];
+    if (cnt <= 0.f) return;
+    const float inv = 1.f / cnt;
+    const long long base = sg.seg_off[seg];
+    const long long c1 = min(len, c0 + ADAM_CHUNK);
+    for (long long i = base + c0 + threadIdx.x; i < base + c1; i += 256) grad[i] *= inv;
+}
+
+int dp_average_grads(const int64_t* seg_off, const int32_t* seg_len, const int32_t* seg_gate, int n_seg, int max_seg_len,
+                     float* grad, const float* counts, float vf_coef, hipStream_t s) {
+    AdamSegs sg{seg_off, seg_len, seg_gate, n_seg};
+    dim3 grid((max_seg_len + ADAM_CHUNK - 1) / ADAM_CHUNK, n_seg);
+    hipLaunchKernelGGL(dp_scale_kernel, grid, dim3(256), 0, s, sg, grad, counts, vf_coef);
+    return launch_check("dp_average_grads");
+}
+
 int gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const int32_t* seg_gate, int n_seg, int max_seg_len,
                        float* param, float* grad, float* m, float* v, double* segsq, const int32_t* head_on,
                        const float* losses, float* norms_out, float* ctl, int32_t* seg_step, int32_t* status,

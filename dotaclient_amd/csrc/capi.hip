@@ -95,4 +95,9 @@ int dc_gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const 
                                   (hipStream_t)stream);
 }
 
+int dc_dp_average_grads(const int64_t* seg_off, const int32_t* seg_len, const int32_t* seg_gate, int n_seg,
+                        int max_seg_len, float* grads, const float* counts, float vf_coef, dc_stream_t stream) {
+    return dc::dp_average_grads(seg_off, seg_len, seg_gate, n_seg, max_seg_len, grads, counts, vf_coef, (hipStream_t)stream);
+}
+
 }  // extern "C"

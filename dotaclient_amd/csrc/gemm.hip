@@ -282,6 +282,8 @@ int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int 
         a.atomic = 1;
         a.accumulate = 0;
     }
+    ProfScope prof(a_kmajor ? "gemm_f32_dW(TN,split-K)" : (b_kmajor ? "gemm_f32_dX(NN)" : "gemm_f32_fwd(NT)"),
+                   2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), stream);
     if (!a_kmajor && !b_kmajor) return dispatch_tile<false, false>(a, splits, stream);
     if (!a_kmajor && b_kmajor) return dispatch_tile<false, true>(a, splits, stream);
     if (a_kmajor && !b_kmajor) return dispatch_tile<true, false>(a, splits, stream);

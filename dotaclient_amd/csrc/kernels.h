@@ -25,6 +25,16 @@ struct RnnStepArgs {
     float* dgh;            // [rows][G*H] grad wrt (W_hh h + b_hh)   (GRU; LSTM: == dgx)
 };
 
+// prof.hip (inert unless dc_profile_enable(1))
+bool prof_enabled();
+int prof_begin(const char* name, double flops, double bytes, hipStream_t s);
+void prof_end(int handle, hipStream_t s);
+struct ProfScope {
+    int h; hipStream_t s;
+    ProfScope(const char* name, double flops, double bytes, hipStream_t st) : h(prof_begin(name, flops, bytes, st)), s(st) {}
+    ~ProfScope() { prof_end(h, s); }
+};
+
 // gae.hip
 int gae_scan(const float* rewards, const float* values, const int64_t* seq_off, const int32_t* seq_len, int n_seq,
              int max_len, double gamma, double lam, float* adv, float* ret, hipStream_t stream);
@@ -61,5 +71,8 @@ int gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const int
                        float* param, float* grad, float* m, float* v, double* segsq, const int32_t* head_on,
                        const float* losses, float* norms_out, float* ctl, int32_t* seg_step, int32_t* status,
                        float max_norm, float vf_coef, double lr, double beta1, double beta2, float eps, hipStream_t s);
+
+int dp_average_grads(const int64_t* seg_off, const int32_t* seg_len, const int32_t* seg_gate, int n_seg, int max_seg_len,
+                     float* grad, const float* counts, float vf_coef, hipStream_t s);
 
 }  // namespace dc

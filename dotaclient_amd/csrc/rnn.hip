@@ -246,6 +246,9 @@ int rnn_forward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     dim3 grid(a.H / 16, (a.n_seq + 15) / 16);
     for (int t = 0; t < max_len; ++t) {
         a.t = t;
+        const double G = cell == CELL_GRU ? 3 : 4;
+        ProfScope prof("rnn_fwd_step", 2.0 * a.n_seq * G * a.H * a.H,
+                       4.0 * (G * a.H * a.H + a.n_seq * a.H * (2.0 * G + 4.0)), s);
         if (cell == CELL_GRU) hipLaunchKernelGGL(rnn_fwd_step_kernel<CELL_GRU>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(rnn_fwd_step_kernel<CELL_LSTM>, grid, dim3(256), 0, s, a);
     }
@@ -257,6 +260,9 @@ int rnn_backward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     dim3 grid(a.H / 16, (a.n_seq + 15) / 16);
     for (int t = max_len - 1; t >= 0; --t) {
         a.t = t;
+        const double G = cell == CELL_GRU ? 3 : 4;
+        ProfScope prof("rnn_bwd_step", 2.0 * a.n_seq * G * a.H * a.H,
+                       4.0 * (G * a.H * a.H + a.n_seq * a.H * (3.0 * G + 6.0)), s);
         if (cell == CELL_GRU) hipLaunchKernelGGL(rnn_bwd_step_kernel<CELL_GRU>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(rnn_bwd_step_kernel<CELL_LSTM>, grid, dim3(256), 0, s, a);
     }

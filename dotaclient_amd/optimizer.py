@@ -1,0 +1,346 @@
+"""`DotaOptimizer` - drop-in for the experience-queue consumer of /root/reference/optimizer.py.
+
+Same constructor/CLI arguments (optimizer.py:207-209, 776-794), same method names and return shapes:
+
+    advantage_returns(rewards, values, gamma, lam)        optimizer.py:57-64
+    Sequence                                              optimizer.py:176-190
+    DotaOptimizer.get_rollout()                           optimizer.py:314-326   (kept: pickle off RMQ)
+    DotaOptimizer.experiences_from_rollout(data)          optimizer.py:328-430   -> HIP rollout pass
+    DotaOptimizer.train(experiences)                      optimizer.py:581-689   -> HIP fwd/loss/bwd/Adam
+    DotaOptimizer.run()                                   optimizer.py:436-579   (consumer loop + metrics)
+    DotaOptimizer.upload_model(version)                   optimizer.py:697-723
+
+The RabbitMQ / GCS / TensorBoard plumbing is outside the hot path: `MessageQueue`
+is imported lazily from pika when no queue object is injected, TensorBoard/GCS are used only if their
+modules are importable.  Everything arithmetic happens in libdotaclient_hip.so; there is no CPU path.
+"""
+import io
+import logging
+import os
+import pickle
+import re
+import time
+
+import numpy as np
+import torch
+
+from . import layout as L
+from . import ops
+from .engine import PackedBatch, pack_rollouts
+from .policy import Policy
+
+logger = logging.getLogger(__name__)
+REWARD_KEYS = ['enemy', 'win', 'xp', 'hp', 'kills', 'death', 'lh', 'denies', 'tower_hp', 'mana']  # policy.py:20
+
+
+def advantage_returns(rewards, values, gamma, lam):
+    """Same contract as optimizer.py:57-64: rewards/values are float32 (L+1,) arrays whose last entry is
+    the appended terminal 0 (optimizer.py:417-420); returns (advantages, returns) float32 (L,) numpy.
+    Runs the wavefront-scan HIP kernel (one sequence)."""
+    rewards = np.asarray(rewards, dtype=np.float32)
+    values = np.asarray(values, dtype=np.float32)
+    Lr = rewards.shape[0] - 1
+    if Lr <= 0:
+        return np.zeros(0, np.float32), np.zeros(0, np.float32)
+    if rewards[-1] != 0 or values[-1] != 0:
+        raise ValueError('advantage_returns expects the terminal 0 appended to rewards and values (optimizer.py:417-420)')
+    dev = torch.device('cuda:0')
+    rew10 = np.zeros((Lr, L.N_REWARDS), np.float32)
+    rew10[:, 0] = rewards[:-1]
+    adv, ret = ops.gae_scan(torch.from_numpy(rew10).to(dev), torch.from_numpy(values[:-1].copy()).to(dev),
+                            torch.zeros(1, dtype=torch.int64, device=dev),
+                            torch.tensor([Lr], dtype=torch.int32, device=dev), Lr, gamma, lam)
+    return adv.cpu().numpy(), ret.cpu().numpy()
+
+
+class Sequence:
+    """One seq_len chunk of a rollout (optimizer.py:176-190).  Thin handle into a PackedBatch: the
+    reference-shaped tensors are materialised lazily (tests / API users); `train` reads the packed
+    rows directly."""
+
+    def __init__(self, game_id, weight_version, team_id, batch, index, seq_len, hidden, cell_state=None):
+        self.game_id, self.weight_version, self.team_id = game_id, weight_version, team_id
+        self._batch, self._index, self._seq_len = batch, index, seq_len
+        self.hidden = hidden                      # (layers, 1, H)
+        self.cell_state = cell_state
+
+    def _rows(self):
+        lo = self._index * self._seq_len
+        return slice(lo, lo + self._seq_len)
+
+    def _split(self, flat, counts, shape_tail=None):
+        out, o = {}, 0
+        for k, c in counts.items():
+            out[k] = flat[:, o:o + c]
+            o += c
+        return out
+
+    @property
+    def observations(self):
+        obs = self._batch.obs[self._rows()]
+        out = {'env': obs[:, :L.ENV_FEATS]}
+        o = L.ENV_FEATS
+        for k, c in L.UNIT_COUNTS.items():
+            out[k] = obs[:, o:o + c * L.UNIT_FEATS].reshape(-1, c, L.UNIT_FEATS)
+            o += c * L.UNIT_FEATS
+        return out
+
+    @property
+    def actions(self):
+        return self._split(self._batch.act[self._rows()], L.HEAD_COUNTS)
+
+    @property
+    def masks(self):
+        return self._split(self._batch.mask[self._rows()], L.HEAD_COUNTS)
+
+    @property
+    def rewards(self):
+        return self._batch.rew[self._rows()].cpu().numpy()
+
+    @property
+    def values(self):
+        return self._batch.values[self._rows()].view(1, -1, 1)
+
+    @property
+    def advantages(self):
+        return self._batch.adv[self._rows()]
+
+    @property
+    def returns(self):
+        return self._batch.ret[self._rows()]
+
+    @property
+    def log_probs_sel(self):
+        lp = self._batch.old_logp[self._rows()]
+        act = self._batch.act[self._rows()]
+        out = {}
+        for i, (k, c) in enumerate(L.HEAD_COUNTS.items()):
+            sel = act[:, L.HEAD_OFFSETS[k]:L.HEAD_OFFSETS[k] + c].bool().any(dim=1)
+            out[k] = lp[sel, i]
+        return out
+
+
+class DotaOptimizer:
+    MODEL_FILENAME_FMT = "model_%09d.pt"
+    BUCKET_NAME = 'dotaservice'
+    MODEL_HISTOGRAM_FREQ = 128
+    MAX_GRAD_NORM = 0.5
+    SPEED_KEY = 'steps per s'
+
+    def __init__(self, rmq_host, rmq_port, epochs, min_seq_per_epoch, seq_len, learning_rate, checkpoint,
+                 pretrained_model, mq_prefetch_count, log_dir, entropy_coef, vf_coef, run_local,
+                 mq=None, cell='gru', hidden=256, layers=1, device='cuda:0'):
+        self.rmq_host, self.rmq_port = rmq_host, rmq_port
+        self.epochs, self.min_seq_per_epoch, self.seq_len = epochs, min_seq_per_epoch, seq_len
+        self.learning_rate, self.checkpoint = learning_rate, checkpoint
+        self.mq_prefetch_count, self.log_dir = mq_prefetch_count, log_dir
+        self.entropy_coef, self.vf_coef, self.run_local = entropy_coef, vf_coef, run_local
+        self.iteration_start = 1
+        self.iterations = 100000
+        self.model_upload_freq = 10
+        self.eventfile_refresh_freq = 100
+        self.e_clip = 0.1
+        self.writer = None
+        self.bucket = None
+        self.policy_base = Policy(cell, hidden, layers, device)
+        self.policy = self.policy_base
+        self.engine = self.policy_base.engine
+        self.device = self.engine.device
+
+        if self.checkpoint:
+            os.makedirs(self.log_dir, exist_ok=True)
+            latest = self.get_latest_model(prefix=self.log_dir)
+            if latest is not None:
+                pretrained_model = latest
+            if pretrained_model is not None:
+                self.iteration_start = self.iteration_from_model_filename(pretrained_model) + 1
+        if pretrained_model is not None:
+            self.policy_base.load_state_dict(torch.load(pretrained_model, map_location='cpu'), strict=False)
+
+        # data parallel: flat-bucket RCCL all-reduce instead of the reference's per-parameter gloo wrapper
+        self.grad_hook = None
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                torch.distributed.get_world_size() > 1:
+            from .distributed import FlatGradAllReducer
+            self.grad_hook = FlatGradAllReducer(self.engine)
+            self.grad_hook.sync_parameters()
+        self.policy_base.attach_grads()
+        self.time_last_it = time.time()
+
+        if mq is None:
+            from .mq import MessageQueue       # needs pika; only when talking to a real broker
+            mq = MessageQueue(host=rmq_host, port=rmq_port, prefetch_count=mq_prefetch_count,
+                              use_model_exchange=self.checkpoint)
+        self.mq = mq
+        self.mq.connect()
+        self.upload_model(version=self.iteration_start)
+
+    # ---- checkpoint helpers (optimizer.py:287-308) -------------------------------------------------
+    @staticmethod
+    def iteration_from_model_filename(filename):
+        return int(re.search(r'(\d+)(?=.pt)', filename).group(0))
+
+    def get_latest_model(self, prefix):
+        if not os.path.isdir(prefix):
+            return None
+        fns = sorted(os.path.join(prefix, f) for f in os.listdir(prefix) if f.endswith('.pt'))
+        return fns[-1] if fns else None
+
+    # ---- experience ingest ---------------------------------------------------------------------------
+    def get_rollout(self):
+        """optimizer.py:314-326."""
+        method, properties, body = self.mq.consume_xp()
+        data = pickle.loads(body)
+        subrewards = data['rewards'].sum(axis=0)
+        return data, subrewards, data['rewards'].shape[0], data['weight_version'], data['canvas']
+
+    def experiences_from_rollouts(self, rollouts):
+        """Batched form of optimizer.py:328-430: all rollouts go through ONE rollout pass (the hidden
+        state only couples chunks within a rollout).  Returns (list[Sequence], chunk PackedBatch)."""
+        batch = pack_rollouts(rollouts, self.seq_len, self.device)
+        chunks = self.engine.rollout_pass(batch, self.seq_len, gamma=0.98, lam=0.97)
+        seqs = []
+        lens = batch.seq_len.cpu().tolist()
+        i = 0
+        for data, Lr in zip(rollouts, lens):
+            for _ in range(Lr // self.seq_len):
+                h = chunks.h0[:, i:i + 1]
+                c = chunks.c0[:, i:i + 1] if chunks.c0 is not None else None
+                seqs.append(Sequence(data['game_id'], data['weight_version'], data['team_id'], chunks, i,
+                                     self.seq_len, h, c))
+                i += 1
+        return seqs, chunks
+
+    def experiences_from_rollout(self, data):
+        """optimizer.py:328-430 (one rollout)."""
+        return self.experiences_from_rollouts([data])[0]
+
+    def _gather(self, experiences):
+        """Packed chunk batch for a list of Sequences.  Sequences produced by one
+        experiences_from_rollouts call already share their batch; otherwise the rows are concatenated
+        on the device (plumbing, cached per experience list)."""
+        first = experiences[0]._batch
+        if all(e._batch is first for e in experiences) and len(experiences) == first.n_seq and \
+                all(e._index == i for i, e in enumerate(experiences)):
+            return first
+        key = (id(experiences), len(experiences))
+        if getattr(self, '_gather_key', None) == key:
+            return self._gather_val
+        S = self.seq_len
+        cat = lambda name: torch.cat([getattr(e._batch, name)[e._rows()] for e in experiences])
+        dev = self.device
+        b = len(experiences)
+        out = PackedBatch(cat('obs'), cat('act'), cat('mask'), cat('rew'),
+                          torch.arange(b, device=dev, dtype=torch.int64) * S,
+                          torch.full((b,), S, device=dev, dtype=torch.int32), S)
+        out.old_logp, out.values, out.adv, out.ret = cat('old_logp'), cat('values'), cat('adv'), cat('ret')
+        out.h0 = torch.cat([e.hidden for e in experiences], dim=1).contiguous()       # optimizer.py:591
+        out.c0 = torch.cat([e.cell_state for e in experiences], dim=1).contiguous() \
+            if experiences[0].cell_state is not None else None
+        self._gather_key, self._gather_val = key, out
+        return out
+
+    # ---- the optimizer step ----------------------------------------------------------------------------
+    def train(self, experiences):
+        """optimizer.py:581-689: one epoch on the full batch; returns (losses, entropies, grad_norms) as
+        dicts of 0-d tensors with the reference's keys (optimizer.py:682-689)."""
+        chunks = self._gather(experiences)
+        out, status = self.engine.train_epoch(chunks, self.learning_rate, self.entropy_coef, self.vf_coef,
+                                              e_clip=self.e_clip, grad_hook=self.grad_hook)
+        host = torch.cat([out[:11], status.to(torch.float32)]).cpu()      # the one sync of the epoch
+        st = int(host[11].item())
+        if st == 1:                                                         # optimizer.py:667-669
+            raise ValueError('loss={}, policy_loss={}, entropy_loss={}, value_loss={}'.format(*host[:4].tolist()))
+        if st == 2:                                                         # optimizer.py:678-679
+            raise ValueError('grad_norm={}'.format(host[9].item()))
+        losses = {'loss': host[0], 'policy_loss': host[1], 'entropy_loss': host[2], 'value_loss': host[3]}
+        entropies = {k: host[4 + i] for i, k in enumerate(L.OUTPUT_KEYS)}
+        return losses, entropies, {'unclipped': host[9], 'clipped': host[10]}
+
+    def mean_gradient_norm(self):
+        """optimizer.py:691-695 (metric helper on the exposed .grad views; torch plumbing)."""
+        return torch.stack([p.grad.norm(2) for p in self.policy_base.parameters() if p.grad is not None]).mean()
+
+    @staticmethod
+    def list_of_dicts_to_dict_of_lists(x):
+        return {k: torch.stack([d[k] for d in x]) for k in x[0]}
+
+    def run_iteration(self, it):
+        """Body of the reference's run() loop (optimizer.py:437-531); returns the metrics dict."""
+        experiences, rollouts, subrewards, rollout_lens, weight_ages = [], [], [], [], []
+        start_xp = time.time()
+        xp_waits = 0.0
+        n_seq = 0
+        while n_seq < self.min_seq_per_epoch:                               # optimizer.py:448-462
+            t0 = time.time()
+            rollout, rollout_subrewards, rollout_len, weight_version, canvas = self.get_rollout()
+            xp_waits += time.time() - t0
+            rollouts.append(rollout)
+            n_seq += (rollout_len + self.seq_len - 1) // self.seq_len
+            subrewards.append(rollout_subrewards)
+            rollout_lens.append(rollout_len)
+            weight_ages.append(it - weight_version)
+        experiences, _ = self.experiences_from_rollouts(rollouts)
+        time_xp = time.time() - start_xp
+
+        losses, entropies, grad_norms = [], [], []
+        start_opt = time.time()
+        for ep in range(self.epochs):                                       # optimizer.py:469-475
+            self.mq.process_data_events()
+            l, e, g = self.train(experiences=experiences)
+            losses.append(l); entropies.append(e); grad_norms.append(g)
+        time_opt = time.time() - start_opt
+        losses = self.list_of_dicts_to_dict_of_lists(losses)
+        entropies = self.list_of_dicts_to_dict_of_lists(entropies)
+        grad_norms = self.list_of_dicts_to_dict_of_lists(grad_norms)
+        n_steps = len(experiences) * self.seq_len                           # optimizer.py:486
+        sub = np.stack(subrewards) / n_steps * Policy.OBSERVATIONS_PER_SECOND
+        time_it = time.time() - self.time_last_it
+        self.time_last_it = time.time()
+        metrics = {
+            self.SPEED_KEY: n_steps / time_it,
+            'reward_per_sec/sum': sub.sum(),
+            'loss/sum': losses['loss'].mean(), 'loss/policy': losses['policy_loss'].mean(),
+            'loss/entropy': losses['entropy_loss'].mean(), 'loss/value': losses['value_loss'].mean(),
+            'entropy': torch.stack(list(entropies.values())).sum(dim=0).mean(),
+            'avg_rollout_len': float(np.mean(rollout_lens)), 'avg_weight_age': float(np.mean(weight_ages)),
+            'timing/it': time_it, 'timing/xp_total': time_xp, 'timing/xp_mq_wait': xp_waits,
+            'timing/optimizer': time_opt,
+        }
+        for k, v in entropies.items():
+            metrics['entropy/' + k] = v.mean()
+        for k, v in grad_norms.items():
+            metrics['grad_norm/' + k] = v.mean()
+        for k, v in zip(REWARD_KEYS, sub.sum(axis=0)):
+            metrics['reward_per_sec/' + k] = v
+        return metrics
+
+    def run(self):
+        for it in range(self.iteration_start, self.iterations):
+            metrics = self.run_iteration(it)
+            logger.info('iteration %d steps_per_s=%.2f loss=%.4f', it, metrics[self.SPEED_KEY], float(metrics['loss/sum']))
+            if self.checkpoint:
+                self._write_metrics(metrics, it)
+                self.upload_model(version=it)
+
+    def _write_metrics(self, metrics, it):
+        try:
+            from tensorboardX import SummaryWriter
+        except ImportError:
+            return
+        if self.writer is None or it % self.eventfile_refresh_freq == 0:
+            self.writer = SummaryWriter(log_dir=self.log_dir)
+        for name, metric in metrics.items():
+            self.writer.add_scalar(name, float(metric), it)
+
+    def upload_model(self, version):
+        """optimizer.py:697-723: rank 0 serialises state_dict() -> file + model exchange."""
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_rank() != 0:
+            return
+        buf = io.BytesIO()
+        torch.save({k: v.cpu() for k, v in self.engine.state_dict().items()}, buf)
+        blob = buf.getvalue()
+        if self.checkpoint:
+            with open(os.path.join(self.log_dir, self.MODEL_FILENAME_FMT % version), 'wb') as f:
+                f.write(blob)
+        self.mq.publish_model(msg=blob, hdr={'version': version})

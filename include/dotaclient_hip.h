@@ -136,6 +136,19 @@ int dc_gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const 
                           int32_t* seg_step, int32_t* status, float max_norm, float vf_coef, double lr, double beta1,
                           double beta2, float eps, dc_stream_t stream);
 
+/* Replaces the per-parameter averaging of DistributedDataParallelSparseParamCPU (distributed.py:24-57)
+ * AFTER the caller has SUM-all-reduced the flat gradient bucket (RCCL via torch.distributed): every
+ * parameter is divided by the number of ranks that had a gradient for it.
+ *   counts f32[6] (device): [k<5] = ranks whose head k acted in their shard, [5] = world size. */
+int dc_dp_average_grads(const int64_t* seg_off, const int32_t* seg_len, const int32_t* seg_gate, int n_seg,
+                        int max_seg_len, float* grads, const float* counts, float vf_coef, dc_stream_t stream);
+
+/* Measurement aid for bench.py (not part of the reference surface): when enabled, every GEMM call and
+ * every recurrent step launch is bracketed by two HIP events on the launch stream.  dc_profile_report
+ * synchronises, fills per-region sums (names: 64-byte slots) and returns the region count. */
+int dc_profile_enable(int on);
+int dc_profile_report(char* names, int64_t* launches, double* total_ms, double* flops, double* bytes, int max_regions);
+
 #ifdef __cplusplus
 }
 #endif

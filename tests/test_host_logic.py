@@ -1,0 +1,154 @@
+"""CPU: host-side logic that needs no GPU - packing, layout, the DP bucket protocol over gloo."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dotaclient_amd import layout as L
+from dotaclient_amd import synth
+from oracle import ref_optimizer as RO
+
+
+def test_flat_layout_is_dense_for_the_head_block_and_aligned():
+    for cell, h, layers in [('gru', 256, 1), ('lstm', 128, 1), ('lstm', 512, 2)]:
+        lay, total = L.flat_layout(cell, h, layers)
+        shapes = L.param_shapes(cell, h, layers)
+        assert set(lay) == set(shapes)
+        spans = sorted((o, o + n) for o, n, _ in lay.values())
+        for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+            assert a1 <= b0                       # no overlap
+        hw = ['affine_unit_attention', 'affine_head_enum', 'affine_move_x', 'affine_move_y', 'affine_head_ability', 'affine_value']
+        for suffix in ('.weight', '.bias'):
+            off = lay[hw[0] + suffix][0]
+            assert off % 4 == 0
+            for n in hw:
+                assert lay[n + suffix][0] == off   # contiguous [154,H] / [154] block
+                off += lay[n + suffix][1]
+        ref_total = {('gru', 256, 1): 765210, ('lstm', 128, 1): 548378, ('lstm', 512, 2): 4088090}[(cell, h, layers)]
+        assert sum(n for _, n, _ in lay.values()) == ref_total      # SURVEY.md 8(d) parameter counts
+
+
+def test_flatten_rollout_layout_and_actor_invariants():
+    r = synth.make_rollout(3, 37)
+    obs, act, msk, rew = synth.flatten_rollout(r)
+    assert obs.shape == (37, 483) and act.shape == (37, 65) and msk.shape == (37, 65) and rew.shape == (37, 10)
+    assert np.array_equal(obs[:, 3 + 12 * 6:3 + 12 * 7], r['observations']['allied_nonheroes'][:, 0].numpy())
+    assert np.array_equal(obs[:, 3 + 12 * 39:], r['observations']['enemy_towers'][:, 0].numpy())
+    # exactly one enum action, sub-head actions only inside their masks, unselected heads fully masked out
+    assert (act[:, :4].sum(1) == 1).all()
+    assert ((act & ~msk.astype(bool)) == 0).all()
+    e = act[:, :4].argmax(1)
+    assert (act[e != 2, 22:62] == 0).all() and (msk[e != 2, 22:62] == 0).all()
+    assert (act[e == 1, 4:13].sum(1) == 1).all() and (act[e == 1, 13:22].sum(1) == 1).all()
+
+
+def test_pack_rollouts_pads_to_seq_len_multiples():
+    from dotaclient_amd.engine import pack_rollouts
+    rollouts = synth.make_rollouts(4, [50, 16, 33])
+    b = pack_rollouts(rollouts, 16, torch.device('cpu'))          # packing itself is device-agnostic plumbing
+    assert b.seq_len.tolist() == [64, 16, 48] and b.seq_off.tolist() == [0, 64, 80] and b.rows == 128
+    assert torch.all(b.obs[50:64] == 0) and torch.all(b.mask[50:64] == 0) and torch.all(b.rew[113:128] == 0)
+    c = b.as_chunks(16)
+    assert c.n_seq == 8 and c.seq_off.tolist() == list(range(0, 128, 16))
+
+
+def test_product_path_refuses_cpu():
+    from dotaclient_amd import _lib
+    from dotaclient_amd.engine import Engine
+    with pytest.raises(_lib.DotaHipError):
+        Engine('gru', 256, 1, 'cpu')
+
+
+# ---- data parallel: flat bucket + has-grad counts over gloo, world_size 2 --------------------------------
+class _FakeLib:
+    """CPU stand-in for the scaling kernel only (the collective protocol is what is under test)."""
+
+    def __init__(self, eng):
+        self.eng = eng
+
+    def dc_dp_average_grads(self, seg_off, seg_len, seg_gate, n_seg, max_len, grads, counts, vf, stream):
+        e = self.eng
+        c = e.reducer.tail
+        for off, ln, gate in zip(e.seg_off.tolist(), e.seg_len.tolist(), e.seg_gate.tolist()):
+            cnt = c[gate].item() if 0 <= gate < 5 else c[5].item()
+            if cnt > 0:
+                e.grads[off:off + ln] /= cnt
+        return 0
+
+
+class _FakeEngine:
+    def __init__(self, head_on):
+        lay, total = L.flat_layout()
+        names = list(L.param_shapes().keys())
+        self.total, self.device = total, torch.device('cpu')
+        self.seg_names = names
+        self.seg_off = torch.tensor([lay[n][0] for n in names])
+        self.seg_len = torch.tensor([lay[n][1] for n in names], dtype=torch.int32)
+        gate = []
+        for n in names:
+            g = -1
+            for pre, k in (('affine_head_enum', 0), ('affine_move_x', 1), ('affine_move_y', 2),
+                           ('affine_unit_attention', 3), ('affine_unit_eth', 3), ('affine_head_ability', 4), ('affine_value', 5)):
+                if n.startswith(pre):
+                    g = k
+            gate.append(g)
+        self.seg_gate = torch.tensor(gate, dtype=torch.int32)
+        self.max_seg_len = int(self.seg_len.max())
+        self.params = torch.zeros(total)
+        self.grads = torch.zeros(total)
+        self.head_on = torch.tensor(head_on + [0, 0, 0], dtype=torch.int32)
+        self.lib = _FakeLib(self)
+        self.layout = lay
+
+
+def _dp_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from dotaclient_amd import distributed as D
+    D._lib.ptr = lambda t: t                         # no device pointers on CPU
+    D._lib.stream_ptr = lambda: None
+    D._lib.check = lambda code, what='': None
+    # rank 1 never used the ability head (index 4): its ability grads are "None"
+    eng = _FakeEngine([1, 1, 1, 1, 1 if rank == 0 else 0])
+    red = D.FlatGradAllReducer(eng)
+    eng.reducer = red
+    eng.params.fill_(float(rank + 1))
+    red.sync_parameters()
+    assert torch.all(eng.params == 1.0)              # broadcast from rank 0 (distributed.py:71-74)
+    g = torch.Generator().manual_seed(100 + rank)
+    local = torch.randn(eng.total, generator=g)
+    if rank == 1:
+        for nm in ('affine_head_ability.weight', 'affine_head_ability.bias'):
+            o, n, _ = eng.layout[nm]
+            local[o:o + n] = 0                       # no gradient on this rank
+    eng.grads.copy_(local)
+    red(eng)
+    torch.save({'local': local, 'out': eng.grads.clone()}, os.path.join(tmp, 'r%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+def test_dp_flat_bucket_matches_reference_semantics(tmp_path):
+    world, port = 2, 29500 + os.getpid() % 2000
+    mp.spawn(_dp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), 'r%d.pt' % r)) for r in range(world)]
+    lay, total = L.flat_layout()
+    names = list(L.param_shapes().keys())
+    # oracle: distributed.py:24-57 emulation - average over the ranks that have a grad
+    per_rank = []
+    for r in range(world):
+        gs = []
+        for n in names:
+            o, ln, _ = lay[n]
+            has = not (r == 1 and n.startswith('affine_head_ability'))
+            gs.append(res[r]['local'][o:o + ln].clone() if has else None)
+        per_rank.append(gs)
+    want = RO.dp_average_grads(per_rank)
+    for r in range(world):
+        for j, n in enumerate(names):
+            o, ln, _ = lay[n]
+            if want[r][j] is None:
+                continue                                # grad None in the reference: Adam skips it on this rank
+            assert torch.allclose(res[r]['out'][o:o + ln], want[r][j], rtol=1e-6, atol=1e-7), (r, n)
