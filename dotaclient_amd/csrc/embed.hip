@@ -35,10 +35,33 @@ __device__ __forceinline__ int unit_type_of_row(long long row, long long nr, lon
     return t;
 }
 
-// grid-stride over type-major rows; 256 threads = 2 rows x 128 channels per pass
+// Walks type-major rows [r0, r1) keeping (type, env-step n, local unit ul) incrementally (one 64-bit
+// division per block instead of one per row).
+struct RowCursor {
+    int t, U, ul;
+    long long n;
+    long long next_type_row;   // first row of type t+1
+    __device__ __forceinline__ void init(long long row, long long nr) {
+        long long local;
+        t = unit_type_of_row(row, nr, &local);
+        U = c_type_units[t];
+        n = local / U;
+        ul = (int)(local - n * U);
+        next_type_row = nr * c_type_cum[t + 1];
+    }
+    __device__ __forceinline__ void advance(long long new_row, long long nr) {
+        if (new_row >= next_type_row) { init(new_row, nr); return; }
+        if (++ul == U) { ul = 0; ++n; }
+    }
+    __device__ __forceinline__ const float* x(const float* obs) const {
+        return obs + n * OBS_DIM + 3 + (c_type_cum[t] + ul) * 12;
+    }
+};
+
+// 256 threads = 2 interleaved row streams x 128 channels; each block owns a contiguous range of rows
 __global__ __launch_bounds__(256) void unit_basic_fwd_kernel(const float* __restrict__ obs, const float* __restrict__ W1,
                                                              const float* __restrict__ b1, float* __restrict__ basic,
-                                                             long long nr) {
+                                                             long long nr, int rows_per_block) {
     const int c = threadIdx.x & 127;
     const int sub = threadIdx.x >> 7;
     float w[12];
@@ -46,17 +69,23 @@ __global__ __launch_bounds__(256) void unit_basic_fwd_kernel(const float* __rest
     for (int f = 0; f < 12; ++f) w[f] = W1[c * 12 + f];
     const float b = b1[c];
     const long long total = nr * 40;
-    for (long long row = (long long)blockIdx.x * 2 + sub; row < total; row += (long long)gridDim.x * 2) {
-        long long local;
-        const int t = unit_type_of_row(row, nr, &local);
-        const int U = c_type_units[t];
-        const long long n = local / U;
-        const int ul = (int)(local - n * U);
-        const float* x = obs + n * OBS_DIM + 3 + (c_type_cum[t] + ul) * 12;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(total, r0 + rows_per_block);
+    // the two halves of the block take the two halves of the range
+    const long long mid = r0 + ((r1 - r0 + 1) >> 1);
+    long long row = sub == 0 ? r0 : mid;
+    const long long end = sub == 0 ? mid : r1;
+    if (row >= end) return;
+    RowCursor cur;
+    cur.init(row, nr);
+    for (; row < end;) {
+        const float* x = cur.x(obs);
         float acc = b;
 #pragma unroll
         for (int f = 0; f < 12; ++f) acc = fmaf(x[f], w[f], acc);
         basic[row * EMB + c] = fmaxf(acc, 0.f);
+        ++row;
+        cur.advance(row, nr);
     }
 }
 
@@ -92,84 +121,161 @@ __global__ __launch_bounds__(256) void pool_env_fwd_kernel(const float* __restri
 }
 
 // demb[type-major row][c] = dtu[n][u] * q[n][c]  +  pool routing of dxcat[n][.]
-// also accumulates dW_env[128][3], db_env[128] (relu-masked by the stored env embedding)
+// Also accumulates, per block and then with one atomic per value: dW_env[128][3], db_env[128]
+// (relu-masked by the stored env embedding) and the six second-layer bias gradients db2[t][c] (column
+// sums of demb, which would otherwise need another 335 MB pass over it).
 __global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(
     const float* __restrict__ obs, const float* __restrict__ xcat, const float* __restrict__ dxcat,
     const float* __restrict__ dtu, const float* __restrict__ q, int ldq, const uint8_t* __restrict__ amax,
-    float* __restrict__ demb, float* __restrict__ dWenv, float* __restrict__ dbenv, long long nr) {
+    float* __restrict__ demb, float* __restrict__ partials, long long nr, int steps_per_block) {
+    constexpr int kU[6] = {1, 5, 16, 16, 1, 1};
+    constexpr int kCum[7] = {0, 1, 6, 22, 38, 39, 40};
     const int c = threadIdx.x & 127;
-    const int sub = threadIdx.x >> 7;
+    const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);   // wave-uniform: dtu loads go scalar
+    const long long n0 = (long long)blockIdx.x * steps_per_block;
+    const long long n1 = min(nr, n0 + steps_per_block);
     float gw0 = 0.f, gw1 = 0.f, gw2 = 0.f, gb = 0.f;
-    for (long long n = (long long)blockIdx.x * 2 + sub; n < nr; n += (long long)gridDim.x * 2) {
+    float gb2[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long long n = n0 + sub; n < n1; n += 2) {
         const float* dx = dxcat + n * XCAT;
         const float qc = q[n * ldq + c];
         const float* dt = dtu + n * 40;
+        float pool[6];
+        pool[0] = dx[1 * EMB + c];
+        pool[1] = dx[2 * EMB + c];
+        pool[2] = dx[3 * EMB + c];
+        pool[3] = dx[4 * EMB + c] + dx[6 * EMB + c];   // enh feeds slots 4 and 6 (policy.py:127)
+        pool[4] = dx[5 * EMB + c];
+        pool[5] = 0.f;                                 // eth is never pooled
+        int am[6] = {0, 0, 0, 0, 0, 0};
+        am[1] = amax[(n * 3 + 0) * EMB + c];
+        am[2] = amax[(n * 3 + 1) * EMB + c];
+        am[3] = amax[(n * 3 + 2) * EMB + c];
         // env embedding backward (policy.py:97)
         const float de = (xcat[n * XCAT + c] > 0.f) ? dx[c] : 0.f;
         const float* e = obs + n * OBS_DIM;
         gw0 = fmaf(de, e[0], gw0); gw1 = fmaf(de, e[1], gw1); gw2 = fmaf(de, e[2], gw2); gb += de;
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
-            const int U = c_type_units[t];
-            float pool_g;  // gradient arriving at this type's pooled slot(s)
-            if (t == 3) pool_g = dx[4 * EMB + c] + dx[6 * EMB + c];   // enh feeds slots 4 and 6
-            else if (t == 5) pool_g = 0.f;                             // eth is never pooled
-            else pool_g = dx[(1 + t) * EMB + c];
-            int am = 0;
-            if (t >= 1 && t <= 3) am = amax[(n * 3 + (t - 1)) * EMB + c];
-            float* p = demb + (nr * c_type_cum[t] + n * U) * EMB + c;
-            for (int u = 0; u < U; ++u) {
-                float g = dt[c_type_cum[t] + u] * qc;
-                if (u == am) g += pool_g;
-                p[(long long)u * EMB] = g;
+            float* p = demb + (nr * kCum[t] + n * kU[t]) * EMB + c;
+            float sum_dt = 0.f;
+#pragma unroll
+            for (int u = 0; u < kU[t]; ++u) {
+                const float d = dt[kCum[t] + u];
+                sum_dt += d;
+                float g = d * qc;
+                if (u == am[t]) g += pool[t];
+                p[u * EMB] = g;
             }
+            gb2[t] += sum_dt * qc + pool[t];           // column sum of this step's demb rows of type t
         }
     }
-    atomicAdd(&dWenv[c * 3 + 0], gw0);
-    atomicAdd(&dWenv[c * 3 + 1], gw1);
-    atomicAdd(&dWenv[c * 3 + 2], gw2);
-    atomicAdd(&dbenv[c], gb);
+    // per-block partials -> scratch[block][10][128] (contended atomics on 1280 addresses from thousands of
+    // blocks cost more than the kernel itself); combine the block's two halves through LDS first
+    __shared__ float sh[10][128];
+    if (sub == 1) {
+        sh[0][c] = gw0; sh[1][c] = gw1; sh[2][c] = gw2; sh[3][c] = gb;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) sh[4 + t][c] = gb2[t];
+    }
+    __syncthreads();
+    if (sub == 0) {
+        float* o = partials + (size_t)blockIdx.x * 1280;
+        o[0 * 128 + c] = gw0 + sh[0][c]; o[1 * 128 + c] = gw1 + sh[1][c]; o[2 * 128 + c] = gw2 + sh[2][c];
+        o[3 * 128 + c] = gb + sh[3][c];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) o[(4 + t) * 128 + c] = gb2[t] + sh[4 + t][c];
+    }
+}
+
+// stage 2: dWenv[c][f] / dbenv[c] / db2[t][c] += sum over blocks
+__global__ __launch_bounds__(256) void embed_scatter_reduce_kernel(const float* __restrict__ partials, int nblk,
+                                                                   float* __restrict__ dWenv, float* __restrict__ dbenv,
+                                                                   float* __restrict__ db2) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;   // 0..1279
+    if (idx >= 1280) return;
+    // blockIdx.y strides over the partial blocks: 32 atomics per output instead of thousands
+    float acc = 0.f;
+    for (int b = blockIdx.y; b < nblk; b += gridDim.y) acc += partials[(size_t)b * 1280 + idx];
+    const int k = idx >> 7, c = idx & 127;
+    if (k < 3) atomicAdd(&dWenv[c * 3 + k], acc);
+    else if (k == 3) atomicAdd(&dbenv[c], acc);
+    else atomicAdd(&db2[(k - 4) * EMB + c], acc);
 }
 
 // dW1[c][f] += sum_rows dbasic[row][c] * x[row][f];  db1[c] += sum_rows dbasic[row][c]
 // thread = (channel c, feature half h): 6 weight accumulators (+ bias on h == 0)
 __global__ __launch_bounds__(256) void unit_basic_bwd_kernel(const float* __restrict__ obs,
-                                                             const float* __restrict__ dbasic, float* __restrict__ dW1,
-                                                             float* __restrict__ db1, long long nr, int rows_per_block) {
+                                                             const float* __restrict__ dbasic,
+                                                             float* __restrict__ partials, long long nr,
+                                                             int rows_per_block) {
     const int c = threadIdx.x & 127;
     const int h = threadIdx.x >> 7;
     const long long total = nr * 40;
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = min(total, r0 + rows_per_block);
+    if (r0 >= r1) return;
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float accb = 0.f;
-    for (long long row = r0; row < r1; ++row) {
-        long long local;
-        const int t = unit_type_of_row(row, nr, &local);
-        const int U = c_type_units[t];
-        const long long n = local / U;
-        const int ul = (int)(local - n * U);
-        const float* x = obs + n * OBS_DIM + 3 + (c_type_cum[t] + ul) * 12 + h * 6;
+    RowCursor cur;
+    cur.init(r0, nr);
+    for (long long row = r0; row < r1;) {
+        const float* x = cur.x(obs) + h * 6;
         const float g = dbasic[row * EMB + c];
 #pragma unroll
         for (int f = 0; f < 6; ++f) acc[f] = fmaf(g, x[f], acc[f]);
         accb += g;
+        ++row;
+        cur.advance(row, nr);
     }
+    float* o = partials + (size_t)blockIdx.x * 1664;   // [13][128]: 12 features + bias
 #pragma unroll
-    for (int f = 0; f < 6; ++f) atomicAdd(&dW1[c * 12 + h * 6 + f], acc[f]);
-    if (h == 0) atomicAdd(&db1[c], accb);
+    for (int f = 0; f < 6; ++f) o[(h * 6 + f) * 128 + c] = acc[f];
+    if (h == 0) o[12 * 128 + c] = accb;
 }
 
-// out[j] += sum_rows X[row][j]   (bias gradients)
+__global__ __launch_bounds__(256) void unit_basic_reduce_kernel(const float* __restrict__ partials, int nblk,
+                                                                float* __restrict__ dW1, float* __restrict__ db1) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;   // 0..1663
+    if (idx >= 1664) return;
+    float acc = 0.f;
+    for (int b = blockIdx.y; b < nblk; b += gridDim.y) acc += partials[(size_t)b * 1664 + idx];
+    const int f = idx >> 7, c = idx & 127;
+    if (f < 12) atomicAdd(&dW1[c * 12 + f], acc);
+    else atomicAdd(&db1[c], acc);
+}
+
+// out[j] += sum_rows X[row][j]   (bias gradients).  blockDim = 256 = TX column lanes x TY row lanes.
+template <int TX>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int ld, long long rows, int cols,
                                                      float* __restrict__ out, int rows_per_block) {
+    constexpr int TY = 256 / TX;
+    __shared__ float sh[256];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const long long r0 = (long long)blockIdx.y * rows_per_block;
     const long long r1 = min(rows, r0 + rows_per_block);
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= cols) return;
+    const int j = blockIdx.x * TX + tx;
     float acc = 0.f;
-    for (long long r = r0; r < r1; ++r) acc += X[r * ld + j];
-    atomicAdd(&out[j], acc);
+    if (j < cols) {
+        long long r = r0 + ty;
+        for (; r + 7 * TY < r1; r += 8 * TY) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = X[(r + i * TY) * ld + j];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += v[i];
+        }
+        for (; r < r1; r += TY) acc += X[r * ld + j];
+    }
+    if (TY > 1) {
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        if (ty == 0) {
+#pragma unroll
+            for (int i = 1; i < TY; ++i) acc += sh[i * TX + tx];
+        }
+    }
+    if (ty == 0 && j < cols) atomicAdd(&out[j], acc);
 }
 
 static inline int grid_for(long long items, int per_block, int cap) {
@@ -180,7 +286,11 @@ static inline int grid_for(long long items, int per_block, int cap) {
 }
 
 int unit_basic_fwd(const float* obs, const float* W1, const float* b1, float* basic, long long nr, hipStream_t s) {
-    hipLaunchKernelGGL(unit_basic_fwd_kernel, dim3(grid_for(nr * 40, 2, 256 * 32)), dim3(256), 0, s, obs, W1, b1, basic, nr);
+    const long long total = nr * 40;
+    int rpb = (int)((total + 8191) / 8192);
+    if (rpb < 16) rpb = 16;
+    hipLaunchKernelGGL(unit_basic_fwd_kernel, dim3((unsigned)((total + rpb - 1) / rpb)), dim3(256), 0, s, obs, W1, b1, basic,
+                       nr, rpb);
     return launch_check("unit_basic_fwd");
 }
 
@@ -192,27 +302,36 @@ int pool_env_fwd(const float* obs, const float* emb, const float* Wenv, const fl
 }
 
 int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, const float* dtu, const float* q, int ldq,
-                      const uint8_t* amax, float* demb, float* dWenv, float* dbenv, long long nr, hipStream_t s) {
-    hipLaunchKernelGGL(embed_scatter_bwd_kernel, dim3(grid_for(nr, 2, 256 * 8)), dim3(256), 0, s, obs, xcat, dxcat, dtu, q,
-                       ldq, amax, demb, dWenv, dbenv, nr);
+                      const uint8_t* amax, float* demb, float* dWenv, float* dbenv, float* db2, float* scratch,
+                      long long nr, hipStream_t s) {
+    int spb = (int)((nr + 2047) / 2048);
+    if (spb < 4) spb = 4;
+    const int nblk = (int)((nr + spb - 1) / spb);        // <= 2048 -> <= 10.5 MB of scratch
+    hipLaunchKernelGGL(embed_scatter_bwd_kernel, dim3(nblk), dim3(256), 0, s, obs, xcat, dxcat, dtu, q, ldq, amax, demb,
+                       scratch, nr, spb);
+    hipLaunchKernelGGL(embed_scatter_reduce_kernel, dim3(5, 32), dim3(256), 0, s, scratch, nblk, dWenv, dbenv, db2);
     return launch_check("embed_scatter_bwd");
 }
 
-int unit_basic_bwd(const float* obs, const float* dbasic, float* dW1, float* db1, long long nr, hipStream_t s) {
+int unit_basic_bwd(const float* obs, const float* dbasic, float* dW1, float* db1, float* scratch, long long nr,
+                   hipStream_t s) {
     const long long total = nr * 40;
     int rpb = (int)((total + 2047) / 2048);
     if (rpb < 64) rpb = 64;
-    hipLaunchKernelGGL(unit_basic_bwd_kernel, dim3((unsigned)((total + rpb - 1) / rpb)), dim3(256), 0, s, obs, dbasic, dW1,
-                       db1, nr, rpb);
+    const int nblk = (int)((total + rpb - 1) / rpb);     // <= 2048 -> <= 13.6 MB of scratch
+    hipLaunchKernelGGL(unit_basic_bwd_kernel, dim3(nblk), dim3(256), 0, s, obs, dbasic, scratch, nr, rpb);
+    hipLaunchKernelGGL(unit_basic_reduce_kernel, dim3(7, 32), dim3(256), 0, s, scratch, nblk, dW1, db1);
     return launch_check("unit_basic_bwd");
 }
 
 int colsum(const float* X, int ld, long long rows, int cols, float* out, hipStream_t s) {
     if (rows <= 0 || cols <= 0) return 0;
-    int rpb = (int)((rows + 511) / 512);
-    if (rpb < 32) rpb = 32;
-    dim3 grid((cols + 255) / 256, (unsigned)((rows + rpb - 1) / rpb));
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, X, ld, rows, cols, out, rpb);
+    int rpb = (int)((rows + 1023) / 1024);
+    if (rpb < 64) rpb = 64;
+    const unsigned gy = (unsigned)((rows + rpb - 1) / rpb);
+    if (cols <= 64) hipLaunchKernelGGL(colsum_kernel<64>, dim3((cols + 63) / 64, gy), dim3(256), 0, s, X, ld, rows, cols, out, rpb);
+    else if (cols <= 128) hipLaunchKernelGGL(colsum_kernel<128>, dim3((cols + 127) / 128, gy), dim3(256), 0, s, X, ld, rows, cols, out, rpb);
+    else hipLaunchKernelGGL(colsum_kernel<256>, dim3((cols + 255) / 256, gy), dim3(256), 0, s, X, ld, rows, cols, out, rpb);
     return launch_check("colsum");
 }
 

@@ -33,8 +33,9 @@ struct GemmArgs {
     int lda, ldb, ldc, ldaux;
     int relu;        // apply max(0, .) (needs splits == 1)
     int accumulate;  // C += result (non-atomic read-modify-write; splits == 1)
-    int atomic;      // C += result with atomics (split-K)
+    int atomic;      // C += result with atomics (split-K without scratch)
     int k_per_split; // multiple of 32
+    float* slab;     // split-K with scratch: partial [split][M][N] slabs, reduced by splitk_reduce_kernel
 };
 
 enum { GEMM_BK = 32 };
@@ -202,6 +203,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
                 float v = acc[i][j][r] + bv;
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (p.aux != nullptr && !(p.aux[(size_t)row * p.ldaux + col] > 0.f)) v = 0.f;
+                if (p.slab != nullptr) {
+                    p.slab[((size_t)blockIdx.z * p.M + row) * p.N + col] = acc[i][j][r];
+                    continue;
+                }
                 float* c = p.C + (size_t)row * p.ldc + col;
                 if (p.atomic) atomicAdd(c, v);
                 else if (p.accumulate) *c += v;
@@ -210,6 +215,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         }
     }
 }
+
+// C[m][n] (+)= bias[n] + sum_z slab[z][m][n]   (second stage of split-K: far cheaper than one fp32 atomic
+// per partial element - an M x N x splits slab is a few MB, L2-resident)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int M,
+                                                            int N, int ldc, int splits, const float* __restrict__ bias,
+                                                            int accumulate) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)M * N) return;
+    const int m = (int)(idx / N), n = (int)(idx - (long long)m * N);
+    float acc = 0.f;
+    for (int z = 0; z < splits; ++z) acc += slab[(size_t)z * M * N + idx];
+    if (bias) acc += bias[n];
+    float* c = C + (size_t)m * ldc + n;
+    *c = accumulate ? *c + acc : acc;
+}
+
+static float* g_scratch = nullptr;
+static long long g_scratch_floats = 0;
+void gemm_set_scratch(float* p, long long floats) { g_scratch = p; g_scratch_floats = floats; }
 
 template <int BM, int BN, bool A_KM, bool B_KM>
 static int launch_gemm(const GemmArgs& a, int splits, hipStream_t stream) {
@@ -250,7 +274,7 @@ int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int 
     GemmArgs a;
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
-    a.relu = relu; a.accumulate = accumulate; a.atomic = 0;
+    a.relu = relu; a.accumulate = accumulate; a.atomic = 0; a.slab = nullptr;
     if (K <= 0) {
         set_error("gemm_f32: K <= 0", 1002);
         return 1002;
@@ -274,20 +298,32 @@ int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int 
             set_error("gemm_f32: relu/mask epilogue is incompatible with split-K", 1003);
             return 1003;
         }
-        if (!accumulate) {
-            // split-K accumulates with atomics: start from zero
-            hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, stream);
-            if (e != hipSuccess) { set_error("gemm_f32: memset", (int)e); return (int)e; }
+        if (g_scratch != nullptr && (long long)splits * M * N <= g_scratch_floats) {
+            a.slab = g_scratch;
+        } else {
+            if (!accumulate) {
+                // split-K accumulates with atomics: start from zero
+                hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, stream);
+                if (e != hipSuccess) { set_error("gemm_f32: memset", (int)e); return (int)e; }
+            }
+            a.atomic = 1;
+            a.accumulate = 0;
         }
-        a.atomic = 1;
-        a.accumulate = 0;
     }
     ProfScope prof(a_kmajor ? "gemm_f32_dW(TN,split-K)" : (b_kmajor ? "gemm_f32_dX(NN)" : "gemm_f32_fwd(NT)"),
                    2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), stream);
-    if (!a_kmajor && !b_kmajor) return dispatch_tile<false, false>(a, splits, stream);
-    if (!a_kmajor && b_kmajor) return dispatch_tile<false, true>(a, splits, stream);
-    if (a_kmajor && !b_kmajor) return dispatch_tile<true, false>(a, splits, stream);
-    return dispatch_tile<true, true>(a, splits, stream);
+    int rc;
+    if (!a_kmajor && !b_kmajor) rc = dispatch_tile<false, false>(a, splits, stream);
+    else if (!a_kmajor && b_kmajor) rc = dispatch_tile<false, true>(a, splits, stream);
+    else if (a_kmajor && !b_kmajor) rc = dispatch_tile<true, false>(a, splits, stream);
+    else rc = dispatch_tile<true, true>(a, splits, stream);
+    if (rc == 0 && a.slab != nullptr) {
+        const long long mn = (long long)M * N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, stream, a.slab, C, M, N,
+                           ldc, splits, bias, accumulate);
+        rc = launch_check("splitk_reduce");
+    }
+    return rc;
 }
 
 }  // namespace dc

@@ -42,13 +42,16 @@ int gae_scan(const float* rewards, const float* values, const int64_t* seq_off, 
 int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kmajor,
              int b_kmajor, const float* bias, int relu, const float* aux, int ldaux, int accumulate, int splits,
              hipStream_t stream);
+void gemm_set_scratch(float* p, long long floats);   // split-K slabs (nullptr -> atomics)
 // embed.hip
 int unit_basic_fwd(const float* obs, const float* W1, const float* b1, float* basic, long long nr, hipStream_t s);
 int pool_env_fwd(const float* obs, const float* emb, const float* Wenv, const float* benv, float* xcat, uint8_t* amax,
                  long long nr, hipStream_t s);
 int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, const float* dtu, const float* q, int ldq,
-                      const uint8_t* amax, float* demb, float* dWenv, float* dbenv, long long nr, hipStream_t s);
-int unit_basic_bwd(const float* obs, const float* dbasic, float* dW1, float* db1, long long nr, hipStream_t s);
+                      const uint8_t* amax, float* demb, float* dWenv, float* dbenv, float* db2, float* scratch,
+                      long long nr, hipStream_t s);
+int unit_basic_bwd(const float* obs, const float* dbasic, float* dW1, float* db1, float* scratch, long long nr,
+                   hipStream_t s);
 int colsum(const float* X, int ld, long long rows, int cols, float* out, hipStream_t s);
 // heads.hip
 int attn_logits(const float* headout, const float* emb, float* tu, long long nr, hipStream_t s);

@@ -13,7 +13,7 @@ namespace dc {
 
 static const int T_UNITS[6] = {1, 5, 16, 16, 1, 1};
 static const int T_CUM[7] = {0, 1, 6, 22, 38, 39, 40};
-enum { EMBW = 128, XCATW = 896, PREW = 256, HO_LD = 160, HO_N = 154 };
+enum { EMBW = 128, XCATW = 896, PREW = 256, HO_LD = 160, HO_N = 154, DC_SCRATCH_FLOATS = 8 << 20 };
 
 // parameter offsets (floats) inside the flat buffer, in the order of dc_param_index (header)
 struct Params {
@@ -50,6 +50,7 @@ int64_t workspace_layout(const dc_dims* d, int64_t* out) {
     put(DC_WS_DXCAT, NR * XCATW * 4);
     put(DC_WS_STATS, 64 * 8);
     put(DC_WS_WHHT, H * G * H * 4);
+    put(DC_WS_SCRATCH, (int64_t)DC_SCRATCH_FLOATS * 4);   // two-stage reductions / split-K slabs
     for (int l = 0; l < d->layers; ++l) {
         const int b = DC_WS_FIXED + l * DC_WS_PER_LAYER;
         put(b + DC_WSL_GATES, NR * G * H * 4);
@@ -76,7 +77,7 @@ struct Ws {
 static int check_dims(const dc_dims* d) {
     if (d->layers < 1 || d->layers > DC_MAX_LAYERS) { set_error("dims: layers out of range", 1020); return 1020; }
     if (d->cell != 0 && d->cell != 1) { set_error("dims: cell must be 0 (gru) or 1 (lstm)", 1021); return 1021; }
-    if (d->hidden % 64 != 0 || d->hidden <= 0) { set_error("dims: hidden must be a multiple of 64", 1022); return 1022; }
+    if (d->hidden != 64 && d->hidden != 128 && d->hidden != 256 && d->hidden != 512) { set_error("dims: hidden must be 64, 128, 256 or 512", 1022); return 1022; }
     if (d->rows * 40 * 128 >= (1LL << 31) * 8) { set_error("dims: too many rows for one call", 1023); return 1023; }
     return 0;
 }
@@ -147,6 +148,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     Ws w; w.base = (char*)ws_base; workspace_layout(d, w.off);
     Params P{params, poff};
     Grads Gd{grads, poff};
+    gemm_set_scratch(w.f(DC_WS_SCRATCH), DC_SCRATCH_FLOATS);
     const long long NR = d->rows;
     const int H = d->hidden, G = d->cell == 0 ? 3 : 4, B = d->n_seq, L = d->layers;
     const int TOP = L - 1;
@@ -196,18 +198,18 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     // max-pool routing + attention keys -> per-unit embedding gradients; env embedding weights
     DC_TRY(embed_scatter_bwd(obs, w.f(DC_WS_XCAT), w.f(DC_WS_DXCAT), w.f(DC_WS_DTU), w.f(DC_WS_HEADOUT), HO_LD,
                              reinterpret_cast<const uint8_t*>(w.base + w.off[DC_WS_AMAX]), w.f(DC_WS_DEMB),
-                             Gd.p(DC_P_ENV_W), Gd.p(DC_P_ENV_B), NR, s));
+                             Gd.p(DC_P_ENV_W), Gd.p(DC_P_ENV_B), Gd.p(DC_P_UNIT_B), w.f(DC_WS_SCRATCH), NR, s));
     for (int t = 0; t < 6; ++t) {
         const size_t ro = (size_t)NR * T_CUM[t] * EMBW;
         const int rows_t = (int)(NR * T_UNITS[t]);
         DC_TRY(gemm_f32(w.f(DC_WS_DEMB) + ro, w.f(DC_WS_BASIC) + ro, Gd.p(DC_P_UNIT_W) + (size_t)t * EMBW * EMBW, EMBW, EMBW,
                         rows_t, EMBW, EMBW, EMBW, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s));
-        DC_TRY(colsum(w.f(DC_WS_DEMB) + ro, EMBW, rows_t, EMBW, Gd.p(DC_P_UNIT_B) + t * EMBW, s));
         // dbasic (stored over the no-longer-needed emb buffer), relu-masked by basic
         DC_TRY(gemm_f32(w.f(DC_WS_DEMB) + ro, P.p(DC_P_UNIT_W) + (size_t)t * EMBW * EMBW, w.f(DC_WS_EMB) + ro, rows_t, EMBW,
                         EMBW, EMBW, EMBW, EMBW, 0, 1, nullptr, 0, w.f(DC_WS_BASIC) + ro, EMBW, 0, 1, s));
     }
-    DC_TRY(unit_basic_bwd(obs, w.f(DC_WS_EMB), Gd.p(DC_P_BASIC_W), Gd.p(DC_P_BASIC_B), NR, s));
+    DC_TRY(unit_basic_bwd(obs, w.f(DC_WS_EMB), Gd.p(DC_P_BASIC_W), Gd.p(DC_P_BASIC_B), w.f(DC_WS_SCRATCH), NR, s));
+    gemm_set_scratch(nullptr, 0);
     return 0;
 }
 

@@ -36,9 +36,11 @@ __device__ __forceinline__ void reduce_partials(float* red, const f32x4 (&acc)[G
 }
 
 // ---------------------------------------------------------------------------------------------------
-// forward step t
+// forward step t.  NCH = 16-wide K chunks per wave (H/64), compile-time so that every global load of
+// the launch - operand fragments AND the epilogue's gate inputs / previous state / biases - is issued
+// before the first MFMA: a step costs one memory round trip, not two.
 // ---------------------------------------------------------------------------------------------------
-template <int CELL>
+template <int CELL, int NCH>
 __global__ __launch_bounds__(256) void rnn_fwd_step_kernel(RnnStepArgs p) {
     constexpr int G = (CELL == CELL_GRU) ? 3 : 4;
     __shared__ float red[4 * G * 256];
@@ -47,64 +49,71 @@ __global__ __launch_bounds__(256) void rnn_fwd_step_kernel(RnnStepArgs p) {
     const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
     const int fi = lane & 15, fq = lane >> 4;
 
-    // A rows: sequence b0+fi at step t (inactive rows contribute zeros)
+    // ---- epilogue operands of this thread's (sequence, hidden unit): issue the loads now -------------
+    const int row_i = tid >> 4, col = tid & 15;
+    const int eb = b0 + row_i, j = j0 + col;
+    const int len = eb < p.n_seq ? p.seq_len[eb] : 0;
+    const bool e_on = t < len;
+    const size_t r = e_on ? (size_t)(p.seq_off[eb] + t) : 0;
+    float* gt = p.gates + r * (size_t)(G * H);
+    float gxv[G], bh[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { gxv[g] = e_on ? gt[g * H + j] : 0.f; bh[g] = p.bhh[g * H + j]; }
+    const float hp = e_on ? p.hprev[r * H + j] : 0.f;
+    float cp = 0.f;
+    if constexpr (CELL == CELL_LSTM) cp = e_on ? p.cprev[r * H + j] : 0.f;
+
+    // ---- operand fragments: A rows = sequence b0+fi at step t (inactive rows contribute zeros) -------
     const int ab = b0 + fi;
     const bool a_on = ab < p.n_seq && t < p.seq_len[ab];
-    const float* a_row = a_on ? p.hprev + (size_t)(p.seq_off[ab] + t) * H : nullptr;
-    const int kw = H / 4;  // K range of this wave
-    const int kbase = wave * kw + 4 * fq;
-
+    const float* a_row = p.hprev + (a_on ? (size_t)(p.seq_off[ab] + t) * H : 0);
+    const int kbase = wave * (NCH * 16) + 4 * fq;
+    float4 a[NCH], b[NCH][G];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        a[c] = a_on ? *reinterpret_cast<const float4*>(a_row + kbase + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            b[c][g] = *reinterpret_cast<const float4*>(p.Whh + (size_t)(g * H + j0 + fi) * H + kbase + 16 * c);
+    }
     f32x4 acc[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int kc = 0; kc < kw; kc += 16) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a_on) a = *reinterpret_cast<const float4*>(a_row + kbase + kc);
-        float4 b[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g)
-            b[g] = *reinterpret_cast<const float4*>(p.Whh + (size_t)(g * H + j0 + fi) * H + kbase + kc);
+    for (int c = 0; c < NCH; ++c) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[g].x, acc[g], 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[g].y, acc[g], 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[g].z, acc[g], 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[g].w, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].x, b[c][g].x, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].y, b[c][g].y, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].z, b[c][g].z, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].w, b[c][g].w, acc[g], 0, 0, 0);
         }
     }
     reduce_partials<G>(red, acc, wave, lane);
     __syncthreads();
+    if (!e_on) return;
 
-    const int row_i = tid >> 4, col = tid & 15;
-    const int b = b0 + row_i, j = j0 + col;
-    if (b >= p.n_seq) return;
-    const int len = p.seq_len[b];
-    if (t >= len) return;
-    const size_t r = (size_t)(p.seq_off[b] + t);
     float hh[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int e = row_i * 16 + col;
         hh[g] = (red[(0 * G + g) * 256 + e] + red[(1 * G + g) * 256 + e]) +
-                (red[(2 * G + g) * 256 + e] + red[(3 * G + g) * 256 + e]) + p.bhh[g * H + j];
+                (red[(2 * G + g) * 256 + e] + red[(3 * G + g) * 256 + e]) + bh[g];
     }
-    float* gt = p.gates + r * (size_t)(G * H);
-    const float hp = p.hprev[r * H + j];
     float hnew;
     if constexpr (CELL == CELL_GRU) {
-        const float rg = sigmoidf_(gt[j] + hh[0]);
-        const float zg = sigmoidf_(gt[H + j] + hh[1]);
-        const float ng = tanhf(gt[2 * H + j] + rg * hh[2]);
+        const float rg = sigmoidf_(gxv[0] + hh[0]);
+        const float zg = sigmoidf_(gxv[1] + hh[1]);
+        const float ng = tanhf(gxv[2] + rg * hh[2]);
         hnew = (1.f - zg) * ng + zg * hp;
         gt[j] = rg; gt[H + j] = zg; gt[2 * H + j] = ng;
         p.hn[r * H + j] = hh[2];
     } else {
-        const float ig = sigmoidf_(gt[j] + hh[0]);
-        const float fg = sigmoidf_(gt[H + j] + hh[1]);
-        const float gg = tanhf(gt[2 * H + j] + hh[2]);
-        const float og = sigmoidf_(gt[3 * H + j] + hh[3]);
-        const float cn = fg * p.cprev[r * H + j] + ig * gg;
+        const float ig = sigmoidf_(gxv[0] + hh[0]);
+        const float fg = sigmoidf_(gxv[1] + hh[1]);
+        const float gg = tanhf(gxv[2] + hh[2]);
+        const float og = sigmoidf_(gxv[3] + hh[3]);
+        const float cn = fg * cp + ig * gg;
         hnew = og * tanhf(cn);
         gt[j] = ig; gt[H + j] = fg; gt[2 * H + j] = gg; gt[3 * H + j] = og;
         p.cseq[r * H + j] = cn;
@@ -115,9 +124,10 @@ __global__ __launch_bounds__(256) void rnn_fwd_step_kernel(RnnStepArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// backward step t: dh_t (total) and the gate gradients of step t, consuming step t+1's gate gradients
+// backward step t: dh_t (total) and the gate gradients of step t, consuming step t+1's gate gradients.
+// NCH = 16-wide K chunks per wave (G*H/64).  Same prefetch discipline as the forward.
 // ---------------------------------------------------------------------------------------------------
-template <int CELL>
+template <int CELL, int NCH>
 __global__ __launch_bounds__(256) void rnn_bwd_step_kernel(RnnStepArgs p) {
     constexpr int G = (CELL == CELL_GRU) ? 3 : 4;
     __shared__ float red[4 * 256];
@@ -126,66 +136,83 @@ __global__ __launch_bounds__(256) void rnn_bwd_step_kernel(RnnStepArgs p) {
     const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
     const int fi = lane & 15, fq = lane >> 4;
 
-    // recurrent term: sum_k dgh[row(t+1)][k] * Whh[k][j]  (only for sequences that have a step t+1)
+    // ---- epilogue operands first ---------------------------------------------------------------------
+    const int row_i = tid >> 4, col = tid & 15;
+    const int eb = b0 + row_i, j = j0 + col;
+    const int len = eb < p.n_seq ? p.seq_len[eb] : 0;
+    const bool e_on = t < len;
+    const bool has_next = (t + 1) < len;
+    const size_t r = e_on ? (size_t)(p.seq_off[eb] + t) : 0;
+    const float* gt = p.gates + r * (size_t)GH;
+    float gv[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) gv[g] = e_on ? gt[g * H + j] : 0.f;
+    float dh = e_on ? p.dh[r * H + j] : 0.f;
+    float x0 = 0.f, x1 = 0.f, n0 = 0.f, n1 = 0.f;   // cell-specific extras
+    if constexpr (CELL == CELL_GRU) {
+        x0 = e_on ? p.hn[r * H + j] : 0.f;
+        x1 = e_on ? p.hprev[r * H + j] : 0.f;
+        if (has_next) { n0 = p.gates[(r + 1) * (size_t)GH + H + j]; n1 = p.dh[(r + 1) * H + j]; }
+    } else {
+        x0 = e_on ? p.cseq[r * H + j] : 0.f;
+        x1 = e_on ? p.cprev[r * H + j] : 0.f;
+        if (has_next) { n0 = p.gates[(r + 1) * (size_t)GH + H + j]; n1 = p.dc[(r + 1) * H + j]; }
+    }
+
+    // ---- recurrent term: sum_k dgh[row(t+1)][k] * Whh[k][j] (sequences that have a step t+1) ---------
     const int ab = b0 + fi;
     const bool a_on = ab < p.n_seq && (t + 1) < p.seq_len[ab];
-    const float* a_row = a_on ? p.dgh + (size_t)(p.seq_off[ab] + t + 1) * GH : nullptr;
+    const float* a_row = p.dgh + (a_on ? (size_t)(p.seq_off[ab] + t + 1) * GH : 0);
     const float* b_row = p.WhhT + (size_t)(j0 + fi) * GH;
-    const int kw = GH / 4;
-    const int kbase = wave * kw + 4 * fq;
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kc = 0; kc < kw; kc += 16) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a_on) a = *reinterpret_cast<const float4*>(a_row + kbase + kc);
-        const float4 b = *reinterpret_cast<const float4*>(b_row + kbase + kc);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    const int kbase = wave * (NCH * 16) + 4 * fq;
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int UN = NCH <= 8 ? NCH : (NCH % 8 == 0 ? 8 : 6);   // must divide NCH (3,6,12,24 | 4,8,16,32)
+    static_assert(NCH % UN == 0, "chunk unroll must divide the chunk count");
+#pragma unroll 1
+    for (int c0 = 0; c0 < NCH; c0 += UN) {
+        float4 a[UN], b[UN];
+#pragma unroll
+        for (int c = 0; c < UN; ++c) {
+            a[c] = a_on ? *reinterpret_cast<const float4*>(a_row + kbase + 16 * (c0 + c)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b[c] = *reinterpret_cast<const float4*>(b_row + kbase + 16 * (c0 + c));
+        }
+#pragma unroll
+        for (int c = 0; c < UN; ++c) {
+            // two independent accumulator chains hide the 40-cycle dependent-MFMA latency
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].x, b[c].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].y, b[c].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].z, b[c].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].w, b[c].w, acc1, 0, 0, 0);
+        }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
+    for (int q = 0; q < 4; ++q) red[wave * 256 + (4 * (lane >> 4) + q) * 16 + (lane & 15)] = acc0[q] + acc1[q];
     __syncthreads();
+    if (!e_on) return;
 
-    const int row_i = tid >> 4, col = tid & 15;
-    const int b = b0 + row_i, j = j0 + col;
-    if (b >= p.n_seq) return;
-    const int len = p.seq_len[b];
-    if (t >= len) return;
-    const size_t r = (size_t)(p.seq_off[b] + t);
     const int e = row_i * 16 + col;
-    float dh = p.dh[r * H + j];
-    const bool has_next = (t + 1) < len;
     if (has_next) dh += (red[e] + red[256 + e]) + (red[512 + e] + red[768 + e]);
-    const float* gt = p.gates + r * (size_t)GH;
     if constexpr (CELL == CELL_GRU) {
-        if (has_next) {
-            // direct path h_{t+1} = ... + z_{t+1} * h_t
-            const float zn = p.gates[(r + 1) * (size_t)GH + H + j];
-            dh += p.dh[(r + 1) * H + j] * zn;
-        }
+        if (has_next) dh += n1 * n0;                 // direct path h_{t+1} = ... + z_{t+1} * h_t
         p.dh[r * H + j] = dh;
-        const float rg = gt[j], zg = gt[H + j], ng = gt[2 * H + j];
-        const float hnv = p.hn[r * H + j];
-        const float hp = p.hprev[r * H + j];
+        const float rg = gv[0], zg = gv[1], ng = gv[2];
         const float dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
-        const float dz_pre = dh * (hp - ng) * zg * (1.f - zg);
-        const float dr_pre = dn_pre * hnv * rg * (1.f - rg);
+        const float dz_pre = dh * (x1 - ng) * zg * (1.f - zg);
+        const float dr_pre = dn_pre * x0 * rg * (1.f - rg);
         float* gx = p.dgx + r * (size_t)GH;
         float* gh = p.dgh + r * (size_t)GH;
         gx[j] = dr_pre; gx[H + j] = dz_pre; gx[2 * H + j] = dn_pre;
         gh[j] = dr_pre; gh[H + j] = dz_pre; gh[2 * H + j] = dn_pre * rg;
     } else {
         p.dh[r * H + j] = dh;
-        const float ig = gt[j], fg = gt[H + j], gg = gt[2 * H + j], og = gt[3 * H + j];
-        const float tc = tanhf(p.cseq[r * H + j]);
+        const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
+        const float tc = tanhf(x0);
         float dcv = dh * og * (1.f - tc * tc);
-        if (has_next) dcv += p.dc[(r + 1) * H + j] * p.gates[(r + 1) * (size_t)GH + H + j];
+        if (has_next) dcv += n1 * n0;                // dc_{t+1} * f_{t+1}
         p.dc[r * H + j] = dcv;
-        const float cp = p.cprev[r * H + j];
         float* gx = p.dgx + r * (size_t)GH;
         gx[j] = dcv * gg * ig * (1.f - ig);
-        gx[H + j] = dcv * cp * fg * (1.f - fg);
+        gx[H + j] = dcv * x1 * fg * (1.f - fg);
         gx[2 * H + j] = dcv * ig * (1.f - gg * gg);
         gx[3 * H + j] = dh * tc * og * (1.f - og);
     }
@@ -240,31 +267,59 @@ int rnn_final_state(const float* hseq, float* hT, const int64_t* seq_off, const 
     return launch_check("rnn_final_state");
 }
 
+template <int CELL>
+static bool launch_fwd(const RnnStepArgs& a, dim3 grid, hipStream_t s) {
+    switch (a.H / 64) {
+        case 1: hipLaunchKernelGGL((rnn_fwd_step_kernel<CELL, 1>), grid, dim3(256), 0, s, a); return true;
+        case 2: hipLaunchKernelGGL((rnn_fwd_step_kernel<CELL, 2>), grid, dim3(256), 0, s, a); return true;
+        case 4: hipLaunchKernelGGL((rnn_fwd_step_kernel<CELL, 4>), grid, dim3(256), 0, s, a); return true;
+        case 8: hipLaunchKernelGGL((rnn_fwd_step_kernel<CELL, 8>), grid, dim3(256), 0, s, a); return true;
+        default: return false;
+    }
+}
+template <int CELL>
+static bool launch_bwd(const RnnStepArgs& a, dim3 grid, hipStream_t s) {
+    constexpr int G = (CELL == CELL_GRU) ? 3 : 4;
+    switch (a.H / 64) {
+        case 1: hipLaunchKernelGGL((rnn_bwd_step_kernel<CELL, 1 * G>), grid, dim3(256), 0, s, a); return true;
+        case 2: hipLaunchKernelGGL((rnn_bwd_step_kernel<CELL, 2 * G>), grid, dim3(256), 0, s, a); return true;
+        case 4: hipLaunchKernelGGL((rnn_bwd_step_kernel<CELL, 4 * G>), grid, dim3(256), 0, s, a); return true;
+        case 8: hipLaunchKernelGGL((rnn_bwd_step_kernel<CELL, 8 * G>), grid, dim3(256), 0, s, a); return true;
+        default: return false;
+    }
+}
+
+static int check_h(int H) {
+    if (H == 64 || H == 128 || H == 256 || H == 512) return 0;
+    set_error("rnn: hidden size must be 64, 128, 256 or 512", 1010);
+    return 1010;
+}
+
 // all steps of one layer, forward.  max_len = max(seq_len) (host value).
 int rnn_forward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
-    if (a.H % 64 != 0) { set_error("rnn: hidden size must be a multiple of 64", 1010); return 1010; }
+    if (int e = check_h(a.H)) return e;
     dim3 grid(a.H / 16, (a.n_seq + 15) / 16);
     for (int t = 0; t < max_len; ++t) {
         a.t = t;
         const double G = cell == CELL_GRU ? 3 : 4;
         ProfScope prof("rnn_fwd_step", 2.0 * a.n_seq * G * a.H * a.H,
                        4.0 * (G * a.H * a.H + a.n_seq * a.H * (2.0 * G + 4.0)), s);
-        if (cell == CELL_GRU) hipLaunchKernelGGL(rnn_fwd_step_kernel<CELL_GRU>, grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(rnn_fwd_step_kernel<CELL_LSTM>, grid, dim3(256), 0, s, a);
+        if (cell == CELL_GRU) launch_fwd<CELL_GRU>(a, grid, s);
+        else launch_fwd<CELL_LSTM>(a, grid, s);
     }
     return launch_check("rnn_forward_layer");
 }
 
 int rnn_backward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
-    if (a.H % 64 != 0) { set_error("rnn: hidden size must be a multiple of 64", 1010); return 1010; }
+    if (int e = check_h(a.H)) return e;
     dim3 grid(a.H / 16, (a.n_seq + 15) / 16);
     for (int t = max_len - 1; t >= 0; --t) {
         a.t = t;
         const double G = cell == CELL_GRU ? 3 : 4;
         ProfScope prof("rnn_bwd_step", 2.0 * a.n_seq * G * a.H * a.H,
                        4.0 * (G * a.H * a.H + a.n_seq * a.H * (3.0 * G + 6.0)), s);
-        if (cell == CELL_GRU) hipLaunchKernelGGL(rnn_bwd_step_kernel<CELL_GRU>, grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(rnn_bwd_step_kernel<CELL_LSTM>, grid, dim3(256), 0, s, a);
+        if (cell == CELL_GRU) launch_bwd<CELL_GRU>(a, grid, s);
+        else launch_bwd<CELL_LSTM>(a, grid, s);
     }
     return launch_check("rnn_backward_layer");
 }

@@ -28,7 +28,7 @@ class DcDims(ctypes.Structure):
 
 
 WS_FIXED = ['BASIC', 'EMB', 'DEMB', 'XCAT', 'AMAX', 'PRE', 'HEADOUT', 'TU', 'DHEADOUT', 'DTU', 'DPRE', 'DXCAT',
-            'STATS', 'WHHT']
+            'STATS', 'WHHT', 'SCRATCH']
 WS_LAYER = ['GATES', 'HN', 'HSEQ', 'HPREV', 'CSEQ', 'CPREV', 'DGX', 'DGH', 'DC', 'DH']
 
 
