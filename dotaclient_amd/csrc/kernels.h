@@ -69,6 +69,10 @@ int rnn_final_state(const float* hseq, float* hT, const int64_t* seq_off, const 
                     hipStream_t s);
 int rnn_forward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s);
 int rnn_backward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s);
+// rnn_persist.hip (LSTM, H <= 128: all time steps in one launch, W_hh register-resident)
+bool lstm_persist_supported(int H);
+int lstm_forward_persist(RnnStepArgs a, int max_len, hipStream_t s);
+int lstm_backward_persist(RnnStepArgs a, int max_len, hipStream_t s);
 // adam.hip
 int gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const int32_t* seg_gate, int n_seg, int max_seg_len,
                        float* param, float* grad, float* m, float* v, double* segsq, const int32_t* head_on,

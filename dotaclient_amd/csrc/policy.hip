@@ -169,7 +169,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         a.seq_off = seq_off; a.seq_len = seq_len; a.n_seq = B; a.H = H;
         a.gates = w.fl(l, DC_WSL_GATES); a.hn = w.fl(l, DC_WSL_HN); a.hseq = w.fl(l, DC_WSL_HSEQ);
         a.hprev = w.fl(l, DC_WSL_HPREV); a.cseq = w.fl(l, DC_WSL_CSEQ); a.cprev = w.fl(l, DC_WSL_CPREV);
-        a.WhhT = w.f(DC_WS_WHHT); a.dh = w.fl(l, DC_WSL_DH); a.dc = w.fl(l, DC_WSL_DC);
+        a.Whh = P.p(pb + 1); a.WhhT = w.f(DC_WS_WHHT); a.dh = w.fl(l, DC_WSL_DH); a.dc = w.fl(l, DC_WSL_DC);
         a.dgx = w.fl(l, DC_WSL_DGX);
         a.dgh = d->cell == 0 ? w.fl(l, DC_WSL_DGH) : w.fl(l, DC_WSL_DGX);
         DC_TRY(rnn_backward_layer(d->cell, a, d->max_len, s));

@@ -19,6 +19,7 @@
 // Packed rows: sequence b occupies rows [seq_off[b], seq_off[b]+seq_len[b]); step t of sequence b is
 // row seq_off[b]+t.  hprev[row] holds h_{t-1} (h0 at the first row of a sequence), hseq[row] holds
 // h_t; the forward writes h_t to both hseq[row] and hprev[row+1].
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace dc {
@@ -296,8 +297,15 @@ static int check_h(int H) {
 }
 
 // all steps of one layer, forward.  max_len = max(seq_len) (host value).
+// DC_RNN_PERSIST=0 forces the launch-per-step kernels (A/B measurements)
+static bool persist_enabled() {
+    static const bool on = [] { const char* e = getenv("DC_RNN_PERSIST"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 int rnn_forward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     if (int e = check_h(a.H)) return e;
+    if (cell == CELL_LSTM && lstm_persist_supported(a.H) && persist_enabled()) return lstm_forward_persist(a, max_len, s);
     dim3 grid(a.H / 16, (a.n_seq + 15) / 16);
     for (int t = 0; t < max_len; ++t) {
         a.t = t;
@@ -312,6 +320,7 @@ int rnn_forward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
 
 int rnn_backward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     if (int e = check_h(a.H)) return e;
+    if (cell == CELL_LSTM && lstm_persist_supported(a.H) && persist_enabled()) return lstm_backward_persist(a, max_len, s);
     dim3 grid(a.H / 16, (a.n_seq + 15) / 16);
     for (int t = max_len - 1; t >= 0; --t) {
         a.t = t;
