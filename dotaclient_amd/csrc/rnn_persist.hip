@@ -22,6 +22,7 @@
 //             sequences 2*hi and 2*hi+1.  c_t of a cell lives in that lane's registers throughout.
 //   backward: lane accumulates dh_rec[seq][u] over gate columns [2H*hi, 2H*hi+2H), halves are summed
 //             across the wave halves, same cell ownership; dc_{t+1} and f_{t+1} stay in registers.
+#include <utility>
 #include "kernels.h"
 
 namespace dc {
@@ -37,6 +38,183 @@ struct PersistCfg {
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
+
+// Gate non-linearities on the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each): the
+// cell epilogue sits on the per-step critical path, and libm's range-reduced expf + IEEE division +
+// branchy tanhf cost several hundred dependent cycles there.  Absolute error ~1e-7, far inside the
+// 1e-4 parity bar (tests/test_gpu_parity.py).
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    // 2*sigmoid(2x) - 1; exp2 overflow to +inf gives rcp(inf) = 0 -> -1, underflow -> +1
+    return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.0f;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Hand-pipelined product phase.  hipcc (ROCm 7.2) sinks every LDS read to just before its first use
+// and waits for it at once (~100 exposed cycles per 16 MFMAs), and copies the weights it keeps in
+// AGPRs back to VGPRs with v_accvgpr_read + hazard nops before each MFMA.  So this phase is issued by
+// hand: a ring of RING float4 LDS reads stays in flight (each has RING-1 MFMA groups of cover, waited
+// for with a counted lgkmcnt), and the MFMAs take their B operand straight from AGPRs ("a"
+// constraint: MFMA A/B operands may be AGPRs on gfx950).  Every statement is asm volatile, so the
+// issue order - and with it the lgkmcnt arithmetic - is exactly the program order below; the compiler
+// emits no LDS/SMEM operation of its own between the first read and the last wait (checked in the
+// .s: the loop body has no s_load and no other ds_* before the epilogue).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_read16(float4& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+
+// forward group: one float4 of h (4 consecutive k) against this lane's two columns.
+// FIRST: accumulators start from the inline constant 0 (no VALU-written SrcC in front of an MFMA).
+// LAST : pads the MFMA -> VALU read hazard by hand (nothing after an asm is padded by the compiler).
+template <int WAIT, bool FIRST, bool LAST>
+__device__ __forceinline__ void fwd_mma_group(const float4& a, f32x4& a00, f32x4& a10, f32x4& a01, f32x4& a11,
+                                              float w00, float w10, float w01, float w11, float w02, float w12,
+                                              float w03, float w13) {
+    if constexpr (FIRST) {
+        asm volatile(
+            "s_waitcnt lgkmcnt(%16)\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, 0\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %1, %4, %9, 0\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %2, %5, %10, 0\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %3, %5, %11, 0\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %0, %6, %12, %0\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %1, %6, %13, %1\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %2, %7, %14, %2\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %3, %7, %15, %3"
+            : "=&v"(a00), "=&v"(a10), "=&v"(a01), "=&v"(a11)
+            : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "a"(w00), "a"(w10), "a"(w01), "a"(w11), "a"(w02), "a"(w12),
+              "a"(w03), "a"(w13), "i"(WAIT));
+    } else if constexpr (LAST) {
+        asm volatile(
+            "s_waitcnt lgkmcnt(%16)\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %1, %4, %9, %1\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %2, %5, %10, %2\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %3, %5, %11, %3\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %0, %6, %12, %0\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %1, %6, %13, %1\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %2, %7, %14, %2\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %3, %7, %15, %3\n\t"
+            "s_nop 7\n\ts_nop 7"
+            : "+v"(a00), "+v"(a10), "+v"(a01), "+v"(a11)
+            : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "a"(w00), "a"(w10), "a"(w01), "a"(w11), "a"(w02), "a"(w12),
+              "a"(w03), "a"(w13), "i"(WAIT));
+    } else {
+        asm volatile(
+            "s_waitcnt lgkmcnt(%16)\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %1, %4, %9, %1\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %2, %5, %10, %2\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %3, %5, %11, %3\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %0, %6, %12, %0\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %1, %6, %13, %1\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %2, %7, %14, %2\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %3, %7, %15, %3"
+            : "+v"(a00), "+v"(a10), "+v"(a01), "+v"(a11)
+            : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "a"(w00), "a"(w10), "a"(w01), "a"(w11), "a"(w02), "a"(w12),
+              "a"(w03), "a"(w13), "i"(WAIT));
+    }
+}
+
+template <int H>
+struct FwdProduct {
+    static constexpr int NG = H / 4;      // float4 groups
+    static constexpr int RING = 8;
+    template <int G>
+    static __device__ __forceinline__ void group(float4 (&av)[RING], f32x4 (&acc)[4], const float (&w0)[H],
+                                                 const float (&w1)[H], uint32_t addr) {
+        constexpr int outstanding = (NG - G < RING) ? (NG - G) : RING;   // reads in flight before this group
+        fwd_mma_group<outstanding - 1, G == 0, G == NG - 1>(av[G % RING], acc[0], acc[1], acc[2], acc[3], w0[4 * G],
+                                                            w1[4 * G], w0[4 * G + 1], w1[4 * G + 1], w0[4 * G + 2],
+                                                            w1[4 * G + 2], w0[4 * G + 3], w1[4 * G + 3]);
+        if constexpr (G + RING < NG) lds_read16<16 * (G + RING)>(av[G % RING], addr);
+    }
+    template <int... Gs>
+    static __device__ __forceinline__ void groups(float4 (&av)[RING], f32x4 (&acc)[4], const float (&w0)[H],
+                                                  const float (&w1)[H], uint32_t addr, std::integer_sequence<int, Gs...>) {
+        (group<Gs>(av, acc, w0, w1, addr), ...);
+    }
+    template <int... Rs>
+    static __device__ __forceinline__ void prologue(float4 (&av)[RING], uint32_t addr, std::integer_sequence<int, Rs...>) {
+        (lds_read16<16 * Rs>(av[Rs], addr), ...);
+    }
+    static __device__ __forceinline__ void run(f32x4 (&acc)[4], const float (&w0)[H], const float (&w1)[H], uint32_t addr) {
+        float4 av[RING];
+        prologue(av, addr, std::make_integer_sequence<int, RING>{});
+        groups(av, acc, w0, w1, addr, std::make_integer_sequence<int, NG>{});
+    }
+};
+
+// backward group: one float4 of gate gradients (4 consecutive k), one column, four accumulator chains.
+template <int WAIT, bool FIRST, bool LAST>
+__device__ __forceinline__ void bwd_mma_group(const float4& a, f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, float w0,
+                                              float w1, float w2, float w3) {
+    if constexpr (FIRST) {
+        asm volatile(
+            "s_waitcnt lgkmcnt(%12)\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, 0\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, 0\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %2, %6, %10, 0\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %3, %7, %11, 0"
+            : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+            : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "a"(w0), "a"(w1), "a"(w2), "a"(w3), "i"(WAIT));
+    } else if constexpr (LAST) {
+        asm volatile(
+            "s_waitcnt lgkmcnt(%12)\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %2, %6, %10, %2\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %3, %7, %11, %3\n\t"
+            "s_nop 7\n\ts_nop 7"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+            : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "a"(w0), "a"(w1), "a"(w2), "a"(w3), "i"(WAIT));
+    } else {
+        asm volatile(
+            "s_waitcnt lgkmcnt(%12)\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %2, %6, %10, %2\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %3, %7, %11, %3"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+            : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "a"(w0), "a"(w1), "a"(w2), "a"(w3), "i"(WAIT));
+    }
+}
+
+template <int KH>
+struct BwdProduct {
+    static constexpr int NG = KH / 4;
+    static constexpr int RING = 16;       // 4 MFMAs per group -> deeper ring for the same cover (lgkmcnt <= 15)
+    template <int G>
+    static __device__ __forceinline__ void group(float4 (&av)[RING], f32x4 (&acc)[4], const float (&w)[KH], uint32_t addr) {
+        constexpr int outstanding = (NG - G < RING) ? (NG - G) : RING;
+        bwd_mma_group<outstanding - 1, G == 0, G == NG - 1>(av[G % RING], acc[0], acc[1], acc[2], acc[3], w[4 * G],
+                                                            w[4 * G + 1], w[4 * G + 2], w[4 * G + 3]);
+        if constexpr (G + RING < NG) lds_read16<16 * (G + RING)>(av[G % RING], addr);
+    }
+    template <int... Gs>
+    static __device__ __forceinline__ void groups(float4 (&av)[RING], f32x4 (&acc)[4], const float (&w)[KH], uint32_t addr,
+                                                  std::integer_sequence<int, Gs...>) {
+        (group<Gs>(av, acc, w, addr), ...);
+    }
+    template <int... Rs>
+    static __device__ __forceinline__ void prologue(float4 (&av)[RING], uint32_t addr, std::integer_sequence<int, Rs...>) {
+        (lds_read16<16 * Rs>(av[Rs], addr), ...);
+    }
+    static __device__ __forceinline__ void run(f32x4 (&acc)[4], const float (&w)[KH], uint32_t addr) {
+        float4 av[RING];
+        prologue(av, addr, std::make_integer_sequence<int, RING>{});
+        groups(av, acc, w, addr, std::make_integer_sequence<int, NG>{});
+    }
+};
 
 // ---------------------------------------------------------------------------------------------------
 // forward.  gates[row][4H] holds W_ih x + b_ih on entry and the activated gates i,f,g,o on exit.
@@ -111,21 +289,9 @@ __global__ __launch_bounds__(PersistCfg<H>::THREADS, 1) void lstm_fwd_persist_ke
                 xn[cc][g] = (t + 1 < len[cc]) ? p.gates[(row0[cc] + t + 1) * (size_t)(4 * H) + g * H + u] : 0.f;
 
         // ---- recurrent product: rows = the 4 sequences, this lane's two columns ----------------------
-        const float4* hrow = reinterpret_cast<const float4*>(&h_lds[cur][lane & 3][0]);
-        f32x4 a00 = {0.f, 0.f, 0.f, 0.f}, a01 = a00, a10 = a00, a11 = a00;
-#pragma unroll
-        for (int k4 = 0; k4 < H / 4; ++k4) {
-            const float4 a = hrow[k4];
-            a00 = mfma4(a.x, w0[4 * k4 + 0], a00);
-            a10 = mfma4(a.x, w1[4 * k4 + 0], a10);
-            a01 = mfma4(a.y, w0[4 * k4 + 1], a01);
-            a11 = mfma4(a.y, w1[4 * k4 + 1], a11);
-            a00 = mfma4(a.z, w0[4 * k4 + 2], a00);
-            a10 = mfma4(a.z, w1[4 * k4 + 2], a10);
-            a01 = mfma4(a.w, w0[4 * k4 + 3], a01);
-            a11 = mfma4(a.w, w1[4 * k4 + 3], a11);
-        }
-        const f32x4 acc0 = a00 + a01, acc1 = a10 + a11;   // lanes hi=0: (i,f) of 4 sequences; hi=1: (g,o)
+        f32x4 pa[4];   // chains: [0] col0 even k, [1] col1 even k, [2] col0 odd k, [3] col1 odd k
+        FwdProduct<H>::run(pa, w0, w1, lds_addr(&h_lds[cur][lane & 3][0]));
+        const f32x4 acc0 = pa[0] + pa[2], acc1 = pa[1] + pa[3];   // lanes hi=0: (i,f) of 4 sequences; hi=1: (g,o)
 
         // ---- cross-half exchange: low lanes need g,o of sequences 0,1; high lanes i,f of 2,3 ---------
         float mine[2][2], recv[2][2];   // [m][cell]
@@ -143,12 +309,12 @@ __global__ __launch_bounds__(PersistCfg<H>::THREADS, 1) void lstm_fwd_persist_ke
             const float rg = hi ? mine[0][cc] : recv[0][cc];
             const float ro = hi ? mine[1][cc] : recv[1][cc];
             const bool on = t < len[cc];
-            const float ig = sigmoidf_(xc[cc][0] + (ri + bh[0]));
-            const float fg = sigmoidf_(xc[cc][1] + (rf + bh[1]));
-            const float gg = tanhf(xc[cc][2] + (rg + bh[2]));
-            const float og = sigmoidf_(xc[cc][3] + (ro + bh[3]));
+            const float ig = fast_sigmoid(xc[cc][0] + (ri + bh[0]));
+            const float fg = fast_sigmoid(xc[cc][1] + (rf + bh[1]));
+            const float gg = fast_tanh(xc[cc][2] + (rg + bh[2]));
+            const float og = fast_sigmoid(xc[cc][3] + (ro + bh[3]));
             const float cn = fg * c[cc] + ig * gg;
-            const float hn = og * tanhf(cn);
+            const float hn = og * fast_tanh(cn);
             h_lds[cur ^ 1][2 * hi + cc][u] = on ? hn : 0.f;
             if (on) {
                 c[cc] = cn;
@@ -231,17 +397,9 @@ __global__ __launch_bounds__(PersistCfg<H>::THREADS, 1) void lstm_bwd_persist_ke
         fetch(t - 1, gn, cn_, cpn, dhn);
 
         // ---- dh_rec[seq][u] = sum_k dgates_{t+1}[seq][k] * W_hh[k][u], this half's k range ------------
-        const float4* grow = reinterpret_cast<const float4*>(&g_lds[cur][lane & 3][KH * hi]);
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-#pragma unroll
-        for (int k4 = 0; k4 < KH / 4; ++k4) {
-            const float4 a = grow[k4];
-            a0 = mfma4(a.x, w[4 * k4 + 0], a0);
-            a1 = mfma4(a.y, w[4 * k4 + 1], a1);
-            a2 = mfma4(a.z, w[4 * k4 + 2], a2);
-            a3 = mfma4(a.w, w[4 * k4 + 3], a3);
-        }
-        const f32x4 acc = (a0 + a1) + (a2 + a3);
+        f32x4 pa[4];
+        BwdProduct<KH>::run(pa, w, lds_addr(&g_lds[cur][lane & 3][KH * hi]));
+        const f32x4 acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
         float rec[2];
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
@@ -256,7 +414,7 @@ __global__ __launch_bounds__(PersistCfg<H>::THREADS, 1) void lstm_bwd_persist_ke
             float dh = dhv[cc];
             if (has_next) dh += rec[cc];
             const float ig = gv[cc][0], fg = gv[cc][1], gg = gv[cc][2], og = gv[cc][3];
-            const float tc = tanhf(cv[cc]);
+            const float tc = fast_tanh(cv[cc]);
             float dcv = dh * og * (1.f - tc * tc);
             if (has_next) dcv += dc_next[cc] * f_next[cc];
             const float di = dcv * gg * ig * (1.f - ig);
