@@ -125,32 +125,44 @@ __device__ __forceinline__ void fwd_mma_group(const float4& a, f32x4& a00, f32x4
     }
 }
 
+// lanes 32..63 of `lo` <-> lanes 0..31 of `hi_` (v_permlane32_swap): afterwards
+//   lo  = [lo.low  | hi_.low ]      hi_ = [lo.high | hi_.high]
+__device__ __forceinline__ void half_swap(float& lo, float& hi_) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi_), false, false);
+    lo = __uint_as_float(r[0]);
+    hi_ = __uint_as_float(r[1]);
+}
+
 template <int H>
 struct FwdProduct {
     static constexpr int NG = H / 4;      // float4 groups
     static constexpr int RING = 8;
-    template <int G>
+    template <int G, class Slot>
     static __device__ __forceinline__ void group(float4 (&av)[RING], f32x4 (&acc)[4], const float (&w0)[H],
-                                                 const float (&w1)[H], uint32_t addr) {
+                                                 const float (&w1)[H], uint32_t addr, Slot& slot) {
         constexpr int outstanding = (NG - G < RING) ? (NG - G) : RING;   // reads in flight before this group
         fwd_mma_group<outstanding - 1, G == 0, G == NG - 1>(av[G % RING], acc[0], acc[1], acc[2], acc[3], w0[4 * G],
                                                             w1[4 * G], w0[4 * G + 1], w1[4 * G + 1], w0[4 * G + 2],
                                                             w1[4 * G + 2], w0[4 * G + 3], w1[4 * G + 3]);
         if constexpr (G + RING < NG) lds_read16<16 * (G + RING)>(av[G % RING], addr);
+        slot(std::integral_constant<int, G>{});   // off-critical-path work issued in the shadow of the MFMAs
     }
-    template <int... Gs>
+    template <class Slot, int... Gs>
     static __device__ __forceinline__ void groups(float4 (&av)[RING], f32x4 (&acc)[4], const float (&w0)[H],
-                                                  const float (&w1)[H], uint32_t addr, std::integer_sequence<int, Gs...>) {
-        (group<Gs>(av, acc, w0, w1, addr), ...);
+                                                  const float (&w1)[H], uint32_t addr, Slot& slot,
+                                                  std::integer_sequence<int, Gs...>) {
+        (group<Gs>(av, acc, w0, w1, addr, slot), ...);
     }
     template <int... Rs>
     static __device__ __forceinline__ void prologue(float4 (&av)[RING], uint32_t addr, std::integer_sequence<int, Rs...>) {
         (lds_read16<16 * Rs>(av[Rs], addr), ...);
     }
-    static __device__ __forceinline__ void run(f32x4 (&acc)[4], const float (&w0)[H], const float (&w1)[H], uint32_t addr) {
+    template <class Slot>
+    static __device__ __forceinline__ void run(f32x4 (&acc)[4], const float (&w0)[H], const float (&w1)[H], uint32_t addr,
+                                               Slot& slot) {
         float4 av[RING];
         prologue(av, addr, std::make_integer_sequence<int, RING>{});
-        groups(av, acc, w0, w1, addr, std::make_integer_sequence<int, NG>{});
+        groups(av, acc, w0, w1, addr, slot, std::make_integer_sequence<int, NG>{});
     }
 };
 
@@ -193,26 +205,29 @@ template <int KH>
 struct BwdProduct {
     static constexpr int NG = KH / 4;
     static constexpr int RING = 16;       // 4 MFMAs per group -> deeper ring for the same cover (lgkmcnt <= 15)
-    template <int G>
-    static __device__ __forceinline__ void group(float4 (&av)[RING], f32x4 (&acc)[4], const float (&w)[KH], uint32_t addr) {
+    template <int G, class Slot>
+    static __device__ __forceinline__ void group(float4 (&av)[RING], f32x4 (&acc)[4], const float (&w)[KH], uint32_t addr,
+                                                 Slot& slot) {
         constexpr int outstanding = (NG - G < RING) ? (NG - G) : RING;
         bwd_mma_group<outstanding - 1, G == 0, G == NG - 1>(av[G % RING], acc[0], acc[1], acc[2], acc[3], w[4 * G],
                                                             w[4 * G + 1], w[4 * G + 2], w[4 * G + 3]);
         if constexpr (G + RING < NG) lds_read16<16 * (G + RING)>(av[G % RING], addr);
+        slot(std::integral_constant<int, G>{});
     }
-    template <int... Gs>
+    template <class Slot, int... Gs>
     static __device__ __forceinline__ void groups(float4 (&av)[RING], f32x4 (&acc)[4], const float (&w)[KH], uint32_t addr,
-                                                  std::integer_sequence<int, Gs...>) {
-        (group<Gs>(av, acc, w, addr), ...);
+                                                  Slot& slot, std::integer_sequence<int, Gs...>) {
+        (group<Gs>(av, acc, w, addr, slot), ...);
     }
     template <int... Rs>
     static __device__ __forceinline__ void prologue(float4 (&av)[RING], uint32_t addr, std::integer_sequence<int, Rs...>) {
         (lds_read16<16 * Rs>(av[Rs], addr), ...);
     }
-    static __device__ __forceinline__ void run(f32x4 (&acc)[4], const float (&w)[KH], uint32_t addr) {
+    template <class Slot>
+    static __device__ __forceinline__ void run(f32x4 (&acc)[4], const float (&w)[KH], uint32_t addr, Slot& slot) {
         float4 av[RING];
         prologue(av, addr, std::make_integer_sequence<int, RING>{});
-        groups(av, acc, w, addr, std::make_integer_sequence<int, NG>{});
+        groups(av, acc, w, addr, slot, std::make_integer_sequence<int, NG>{});
     }
 };
 
@@ -220,6 +235,13 @@ struct BwdProduct {
 // forward.  gates[row][4H] holds W_ih x + b_ih on entry and the activated gates i,f,g,o on exit.
 // hprev/cprev[first row of a sequence] hold h0/c0 (rnn_seed_state); h_t, c_t go to hseq/cseq[row] and
 // to hprev/cprev[row+1] (the shifted copies the weight-gradient GEMM and the backward read).
+//
+// Per step the critical path is product -> exchange -> gate maths -> h to LDS -> barrier.  Everything
+// else - next step's gate pre-activation loads and the PREVIOUS step's global stores (results wait in
+// registers for one step) - is issued from the slots between the MFMA groups, where it costs nothing.
+// Loads of cells past their sequence end read a clamped (valid) row instead of branching.  Steps are
+// unrolled by two with ping-pong registers, so the prefetched values are never copied (a copy would
+// have to wait for the loads, and with them for every younger store, at the end of each step).
 // ---------------------------------------------------------------------------------------------------
 template <int H>
 __global__ __launch_bounds__(PersistCfg<H>::THREADS, 1) void lstm_fwd_persist_kernel(RnnStepArgs p) {
@@ -248,21 +270,23 @@ __global__ __launch_bounds__(PersistCfg<H>::THREADS, 1) void lstm_fwd_persist_ke
 
     // ---- this lane's two cells ----------------------------------------------------------------------
     int len[2];
-    size_t row0[2];
     float c[2];
+    float* gp[2];     // &gates[row0][u]
+    size_t so[2];     // offset of [row0][u] in the [rows][H] state arrays
     int tmax = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int b = b0 + q;
-        const int l = b < p.n_seq ? p.seq_len[b] : 0;
-        tmax = max(tmax, l);
+        tmax = max(tmax, b < p.n_seq ? p.seq_len[b] : 0);
     }
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
         const int b = b0 + 2 * hi + cc;
         len[cc] = b < p.n_seq ? p.seq_len[b] : 0;
-        row0[cc] = len[cc] > 0 ? (size_t)p.seq_off[b] : 0;
-        c[cc] = len[cc] > 0 ? p.cprev[row0[cc] * H + u] : 0.f;
+        const size_t row0 = len[cc] > 0 ? (size_t)p.seq_off[b] : 0;
+        gp[cc] = p.gates + row0 * (size_t)(4 * H) + u;
+        so[cc] = row0 * H + u;
+        c[cc] = len[cc] > 0 ? p.cprev[so[cc]] : 0.f;
     }
     // h0 -> LDS buffer 0
     for (int e = tid; e < 4 * H; e += C::THREADS) {
@@ -271,76 +295,109 @@ __global__ __launch_bounds__(PersistCfg<H>::THREADS, 1) void lstm_fwd_persist_ke
         const bool on = b < p.n_seq && p.seq_len[b] > 0;
         h_lds[0][q][j] = on ? p.hprev[(size_t)p.seq_off[b] * H + j] : 0.f;
     }
-    // gate pre-activations of step 0
+    // gate pre-activations of step 0 (clamped rows: always a valid address)
     float xc[2][4], xn[2][4];
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) xc[cc][g] = len[cc] > 0 ? p.gates[row0[cc] * (size_t)(4 * H) + g * H + u] : 0.f;
+        for (int g = 0; g < 4; ++g) xc[cc][g] = gp[cc][g * H];
+    // results of the previous step, stored one step late
+    float sv[2][6];   // i, f, g, o, c, h
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) sv[cc][q] = 0.f;
     __syncthreads();
 
-    for (int t = 0; t < tmax; ++t) {
-        const int cur = t & 1;
-        // prefetch next step's gate pre-activations (latency hidden behind the MFMAs)
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                xn[cc][g] = (t + 1 < len[cc]) ? p.gates[(row0[cc] + t + 1) * (size_t)(4 * H) + g * H + u] : 0.f;
+    // one step; xcur = this step's gate pre-activations, xnext receives the next step's
+    auto step = [&](const int t, float (&xcur)[2][4], float (&xnext)[2][4], auto CUR) {
+        constexpr int cur = decltype(CUR)::value;
+        // slot work: loads for step t+1 (first: they get the whole product phase to land), then the
+        // stores of step t-1
+        auto slot = [&](auto G) {
+            constexpr int g = decltype(G)::value;
+            constexpr int per = FwdProduct<H>::NG / 16 > 0 ? FwdProduct<H>::NG / 16 : 1;   // 16 items over NG slots
+            if constexpr (g % per == 0 && g / per < 16) {
+                constexpr int it = g / per;
+                if constexpr (it < 8) {
+                    constexpr int cc = it >> 2, gg = it & 3;
+                    const int tl = min(t + 1, max(len[cc] - 1, 0));
+                    xnext[cc][gg] = gp[cc][(size_t)tl * (4 * H) + gg * H];
+                } else {
+                    constexpr int q = it - 8;
+                    constexpr int cc = q >> 2, part = q & 3;
+                    const int tp = t - 1;
+                    if (tp >= 0 && tp < len[cc]) {
+                        if constexpr (part < 2) {
+                            float* gt = gp[cc] + (size_t)tp * (4 * H);
+                            gt[(2 * part) * H] = sv[cc][2 * part];
+                            gt[(2 * part + 1) * H] = sv[cc][2 * part + 1];
+                        } else if constexpr (part == 2) {
+                            p.cseq[so[cc] + (size_t)tp * H] = sv[cc][4];
+                            p.hseq[so[cc] + (size_t)tp * H] = sv[cc][5];
+                        } else {
+                            if (tp + 1 < len[cc]) {
+                                p.cprev[so[cc] + (size_t)(tp + 1) * H] = sv[cc][4];
+                                p.hprev[so[cc] + (size_t)(tp + 1) * H] = sv[cc][5];
+                            }
+                        }
+                    }
+                }
+            }
+        };
 
         // ---- recurrent product: rows = the 4 sequences, this lane's two columns ----------------------
         f32x4 pa[4];   // chains: [0] col0 even k, [1] col1 even k, [2] col0 odd k, [3] col1 odd k
-        FwdProduct<H>::run(pa, w0, w1, lds_addr(&h_lds[cur][lane & 3][0]));
-        const f32x4 acc0 = pa[0] + pa[2], acc1 = pa[1] + pa[3];   // lanes hi=0: (i,f) of 4 sequences; hi=1: (g,o)
+        FwdProduct<H>::run(pa, w0, w1, lds_addr(&h_lds[cur][lane & 3][0]), slot);
+        f32x4 acc0 = pa[0] + pa[2], acc1 = pa[1] + pa[3];   // lanes hi=0: (i,f) of 4 sequences; hi=1: (g,o)
 
-        // ---- cross-half exchange: low lanes need g,o of sequences 0,1; high lanes i,f of 2,3 ---------
-        float mine[2][2], recv[2][2];   // [m][cell]
+        // ---- cross-half exchange: afterwards every lane holds i,f,g,o of its own two cells ------------
+        float ri[2], rf[2], rg[2], ro[2];
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
-            mine[0][cc] = hi ? acc0[2 + cc] : acc0[cc];
-            mine[1][cc] = hi ? acc1[2 + cc] : acc1[cc];
-            recv[0][cc] = __shfl_xor(hi ? acc0[cc] : acc0[2 + cc], 32, 64);
-            recv[1][cc] = __shfl_xor(hi ? acc1[cc] : acc1[2 + cc], 32, 64);
+            float y0 = acc0[cc], x0 = acc0[2 + cc], y1 = acc1[cc], x1 = acc1[2 + cc];
+            half_swap(y0, x0);   // y0 = i of own cell, x0 = g of own cell
+            half_swap(y1, x1);   // y1 = f,             x1 = o
+            ri[cc] = y0; rg[cc] = x0; rf[cc] = y1; ro[cc] = x1;
         }
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
-            const float ri = hi ? recv[0][cc] : mine[0][cc];
-            const float rf = hi ? recv[1][cc] : mine[1][cc];
-            const float rg = hi ? mine[0][cc] : recv[0][cc];
-            const float ro = hi ? mine[1][cc] : recv[1][cc];
             const bool on = t < len[cc];
-            const float ig = fast_sigmoid(xc[cc][0] + (ri + bh[0]));
-            const float fg = fast_sigmoid(xc[cc][1] + (rf + bh[1]));
-            const float gg = fast_tanh(xc[cc][2] + (rg + bh[2]));
-            const float og = fast_sigmoid(xc[cc][3] + (ro + bh[3]));
+            const float ig = fast_sigmoid(xcur[cc][0] + (ri[cc] + bh[0]));
+            const float fg = fast_sigmoid(xcur[cc][1] + (rf[cc] + bh[1]));
+            const float gg = fast_tanh(xcur[cc][2] + (rg[cc] + bh[2]));
+            const float og = fast_sigmoid(xcur[cc][3] + (ro[cc] + bh[3]));
             const float cn = fg * c[cc] + ig * gg;
             const float hn = og * fast_tanh(cn);
             h_lds[cur ^ 1][2 * hi + cc][u] = on ? hn : 0.f;
-            if (on) {
-                c[cc] = cn;
-                const size_t r = row0[cc] + t;
-                float* gt = p.gates + r * (size_t)(4 * H);
-                gt[u] = ig; gt[H + u] = fg; gt[2 * H + u] = gg; gt[3 * H + u] = og;
-                p.cseq[r * H + u] = cn;
-                p.hseq[r * H + u] = hn;
-                if (t + 1 < len[cc]) {
-                    p.cprev[(r + 1) * H + u] = cn;
-                    p.hprev[(r + 1) * H + u] = hn;
-                }
-            }
+            c[cc] = on ? cn : c[cc];
+            sv[cc][0] = ig; sv[cc][1] = fg; sv[cc][2] = gg; sv[cc][3] = og; sv[cc][4] = cn; sv[cc][5] = hn;
         }
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) xc[cc][g] = xn[cc][g];
         __syncthreads();
+    };
+
+    for (int t = 0; t < tmax; t += 2) {
+        step(t, xc, xn, std::integral_constant<int, 0>{});
+        if (t + 1 < tmax) step(t + 1, xn, xc, std::integral_constant<int, 1>{});
+    }
+    // drain: the deferred stores of the last step
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+        const int tp = tmax - 1;
+        if (tp >= 0 && tp < len[cc]) {
+            float* gt = gp[cc] + (size_t)tp * (4 * H);
+            gt[0] = sv[cc][0]; gt[H] = sv[cc][1]; gt[2 * H] = sv[cc][2]; gt[3 * H] = sv[cc][3];
+            p.cseq[so[cc] + (size_t)tp * H] = sv[cc][4];
+            p.hseq[so[cc] + (size_t)tp * H] = sv[cc][5];
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // backward through time.  In: dh[row][H] = dL/dh_t from the layer above (heads), the forward's saved
 // gates / cseq / cprev.  Out: dgx[row][4H] = gradient w.r.t. the gate pre-activations (for an LSTM the
-// same tensor serves W_ih x + b_ih and W_hh h + b_hh).
+// same tensor serves W_ih x + b_ih and W_hh h + b_hh).  Same slot discipline as the forward: the
+// operands of step t-1 are loaded, and the gate gradients of step t+1 stored, between the MFMA groups.
 // ---------------------------------------------------------------------------------------------------
 template <int H>
 __global__ __launch_bounds__(PersistCfg<H>::THREADS, 1) void lstm_bwd_persist_kernel(RnnStepArgs p) {
@@ -358,7 +415,9 @@ __global__ __launch_bounds__(PersistCfg<H>::THREADS, 1) void lstm_bwd_persist_ke
     for (int kk = 0; kk < KH; ++kk) w[kk] = p.Whh[(size_t)(KH * hi + kk) * H + u];
 
     int len[2];
-    size_t row0[2];
+    const float* gp[2];
+    float* dgp[2];
+    size_t so[2];
     int tmax = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -369,74 +428,98 @@ __global__ __launch_bounds__(PersistCfg<H>::THREADS, 1) void lstm_bwd_persist_ke
     for (int cc = 0; cc < 2; ++cc) {
         const int b = b0 + 2 * hi + cc;
         len[cc] = b < p.n_seq ? p.seq_len[b] : 0;
-        row0[cc] = len[cc] > 0 ? (size_t)p.seq_off[b] : 0;
+        const size_t row0 = len[cc] > 0 ? (size_t)p.seq_off[b] : 0;
+        gp[cc] = p.gates + row0 * (size_t)(4 * H) + u;
+        dgp[cc] = p.dgx + row0 * (size_t)(4 * H) + u;
+        so[cc] = row0 * H + u;
     }
     for (int e = tid; e < 4 * C::GLD; e += C::THREADS) (&g_lds[0][0][0])[e] = 0.f;   // "step tmax" has no gradient
 
-    // per-cell carried state and the prefetched operands of the step about to be processed
+    // per-cell carried state, the operands of the step being processed, and the next ones in flight
     float dc_next[2] = {0.f, 0.f}, f_next[2] = {0.f, 0.f};
-    float gv[2][4], cv[2], cpv[2], dhv[2];      // current step
-    float gn[2][4], cn_[2], cpn[2], dhn[2];     // next (t-1)
-    auto fetch = [&](int t, float (&G)[2][4], float (&Cv)[2], float (&Cp)[2], float (&Dh)[2]) {
+    float cur_v[2][7], nxt_v[2][7];   // i, f, g, o, c, c_prev, dh
+    float sv[2][4];                   // gate gradients of the previous iteration (step t+1), stored one step late
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-            const bool on = t >= 0 && t < len[cc];
-            const size_t r = row0[cc] + (on ? t : 0);
+    for (int cc = 0; cc < 2; ++cc) {
+        const int tl = max(min(tmax - 1, len[cc] - 1), 0);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) G[cc][g] = on ? p.gates[r * (size_t)(4 * H) + g * H + u] : 0.f;
-            Cv[cc] = on ? p.cseq[r * H + u] : 0.f;
-            Cp[cc] = on ? p.cprev[r * H + u] : 0.f;
-            Dh[cc] = on ? p.dh[r * H + u] : 0.f;
-        }
-    };
-    fetch(tmax - 1, gv, cv, cpv, dhv);
+        for (int g = 0; g < 4; ++g) cur_v[cc][g] = gp[cc][(size_t)tl * (4 * H) + g * H];
+        cur_v[cc][4] = p.cseq[so[cc] + (size_t)tl * H];
+        cur_v[cc][5] = p.cprev[so[cc] + (size_t)tl * H];
+        cur_v[cc][6] = p.dh[so[cc] + (size_t)tl * H];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sv[cc][g] = 0.f;
+    }
     __syncthreads();
 
-    for (int t = tmax - 1; t >= 0; --t) {
-        const int cur = (tmax - 1 - t) & 1;
-        fetch(t - 1, gn, cn_, cpn, dhn);
+    auto step = [&](const int t, float (&cv)[2][7], float (&nv)[2][7], auto CUR) {
+        constexpr int cur = decltype(CUR)::value;
+        auto slot = [&](auto G) {
+            constexpr int g = decltype(G)::value;
+            constexpr int per = BwdProduct<KH>::NG / 32 > 0 ? BwdProduct<KH>::NG / 32 : 1;   // 22 items over NG slots
+            if constexpr (g % per == 0 && g / per < 22) {
+                constexpr int it = g / per;
+                if constexpr (it < 14) {
+                    constexpr int cc = it / 7, q = it % 7;
+                    const int tl = max(min(t - 1, len[cc] - 1), 0);
+                    if constexpr (q < 4) nv[cc][q] = gp[cc][(size_t)tl * (4 * H) + q * H];
+                    else if constexpr (q == 4) nv[cc][4] = p.cseq[so[cc] + (size_t)tl * H];
+                    else if constexpr (q == 5) nv[cc][5] = p.cprev[so[cc] + (size_t)tl * H];
+                    else nv[cc][6] = p.dh[so[cc] + (size_t)tl * H];
+                } else {
+                    constexpr int q = it - 14;
+                    constexpr int cc = q >> 2, gg = q & 3;
+                    const int tp = t + 1;
+                    if (tp < len[cc]) dgp[cc][(size_t)tp * (4 * H) + gg * H] = sv[cc][gg];
+                }
+            }
+        };
 
         // ---- dh_rec[seq][u] = sum_k dgates_{t+1}[seq][k] * W_hh[k][u], this half's k range ------------
         f32x4 pa[4];
-        BwdProduct<KH>::run(pa, w, lds_addr(&g_lds[cur][lane & 3][KH * hi]));
+        BwdProduct<KH>::run(pa, w, lds_addr(&g_lds[cur][lane & 3][KH * hi]), slot);
         const f32x4 acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
         float rec[2];
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
-            const float other = __shfl_xor(hi ? acc[cc] : acc[2 + cc], 32, 64);
-            rec[cc] = (hi ? acc[2 + cc] : acc[cc]) + other;
+            float y = acc[cc], x = acc[2 + cc];
+            half_swap(y, x);     // low lanes: own acc[cc] | partner's acc[cc]; high lanes: partner's acc[2+cc] | own
+            rec[cc] = y + x;
         }
 
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             const bool on = t < len[cc];
             const bool has_next = (t + 1) < len[cc];
-            float dh = dhv[cc];
+            float dh = cv[cc][6];
             if (has_next) dh += rec[cc];
-            const float ig = gv[cc][0], fg = gv[cc][1], gg = gv[cc][2], og = gv[cc][3];
-            const float tc = fast_tanh(cv[cc]);
+            const float ig = cv[cc][0], fg = cv[cc][1], gg = cv[cc][2], og = cv[cc][3];
+            const float tc = fast_tanh(cv[cc][4]);
             float dcv = dh * og * (1.f - tc * tc);
             if (has_next) dcv += dc_next[cc] * f_next[cc];
             const float di = dcv * gg * ig * (1.f - ig);
-            const float df = dcv * cpv[cc] * fg * (1.f - fg);
+            const float df = dcv * cv[cc][5] * fg * (1.f - fg);
             const float dg = dcv * ig * (1.f - gg * gg);
             const float dO = dh * tc * og * (1.f - og);
             float* gl = &g_lds[cur ^ 1][2 * hi + cc][0];
             gl[u] = on ? di : 0.f; gl[H + u] = on ? df : 0.f; gl[2 * H + u] = on ? dg : 0.f; gl[3 * H + u] = on ? dO : 0.f;
-            if (on) {
-                dc_next[cc] = dcv; f_next[cc] = fg;
-                float* gx = p.dgx + (row0[cc] + t) * (size_t)(4 * H);
-                gx[u] = di; gx[H + u] = df; gx[2 * H + u] = dg; gx[3 * H + u] = dO;
-            }
-        }
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) gv[cc][g] = gn[cc][g];
-            cv[cc] = cn_[cc]; cpv[cc] = cpn[cc]; dhv[cc] = dhn[cc];
+            sv[cc][0] = di; sv[cc][1] = df; sv[cc][2] = dg; sv[cc][3] = dO;
+            if (on) { dc_next[cc] = dcv; f_next[cc] = fg; }
         }
         __syncthreads();
+    };
+
+    for (int t = tmax - 1; t >= 0; t -= 2) {
+        step(t, cur_v, nxt_v, std::integral_constant<int, 0>{});
+        if (t - 1 >= 0) step(t - 1, nxt_v, cur_v, std::integral_constant<int, 1>{});
     }
+    // drain the deferred stores of step 0
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+        if (0 < len[cc]) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dgp[cc][g * H] = sv[cc][g];
+        }
 }
 
 bool lstm_persist_supported(int H) { return H == 64 || H == 128; }
