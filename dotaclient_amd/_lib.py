@@ -23,6 +23,7 @@ SIGNATURES = {
     'dc_gae_scan': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_dbl, c_dbl, c_ptr, c_ptr, c_ptr]),
     'dc_gemm_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                             c_ptr, c_int, c_ptr, c_int, c_int, c_int, c_ptr]),
+    'dc_gemm_set_scratch': (None, [c_ptr, c_i64]),
     'dc_dp_average_grads': (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_flt, c_ptr]),
     'dc_profile_enable': (c_int, [c_int]),
     'dc_profile_report': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int]),

@@ -48,6 +48,8 @@ int dc_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, i
                         splits, (hipStream_t)stream);
 }
 
+void dc_gemm_set_scratch(float* scratch, int64_t floats) { dc::gemm_set_scratch(scratch, (long long)floats); }
+
 int64_t dc_workspace_layout(const dc_dims* dims, int64_t* offsets) { return dc::workspace_layout(dims, offsets); }
 
 int dc_policy_forward(const dc_dims* dims, const float* params, const int64_t* poff_host, const float* obs,

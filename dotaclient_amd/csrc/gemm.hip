@@ -216,6 +216,180 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Fast path: full tiles only (M % BM == 0, N % BN == 0, every split's K range a multiple of 32,
+// 16-byte aligned operands) - which is every large product of the network; the kernel above stays as
+// the bounds-checked fallback for the 154-wide head projections.
+//
+// What differs from the fallback:
+//   * tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write): the next
+//     tile's DMA is issued before the MFMAs of the current tile and lands behind them; hipcc cannot sink
+//     it (it writes LDS) the way it sinks ordinary prefetch loads next to their consumers;
+//   * the DMA writes LDS lane-linearly (wave-uniform base + 16 B x lane), so a k-contiguous tile is the
+//     unpadded image [row][32] and bank conflicts are avoided by an XOR swizzle applied on the SOURCE
+//     side: the 16-byte slot p of row r holds k chunk p ^ ((r >> 1) & 7).  A fragment read of chunk c
+//     of row i then hits slot (i&1)*8 + (c ^ ((i>>1)&7)) of the 256-byte bank row - 16 distinct slots
+//     for the 16 rows of every ds_read_b128 lane group;
+//   * one ds_read_b128 feeds four MFMAs: lane (i = lane&31, q = lane>>5) reads k = 8j+4q .. 8j+4q+3
+//     of its row, i.e. MFMA step e of group j contracts k = 8j+e (q=0) and 8j+4+e (q=1).  Both
+//     operands use the same k permutation, so the sum over k is complete and exact;
+//   * k-major tiles ([k][rows], the operands of the weight-gradient products) are lane-linear as they
+//     are; their fragments are 4 conflict-free ds_read_b32;
+//   * epilogue variants are compile-time (EPI_*), no per-element branches.
+// ---------------------------------------------------------------------------------------------------
+enum { EPI_PLAIN = 0, EPI_RELU = 1, EPI_MASK = 2, EPI_ACC = 3, EPI_SLAB = 4, EPI_ATOMIC = 5 };
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BR, bool KM>
+struct FastTile {
+    static constexpr int LDS_FLOATS = GEMM_BK * BR;
+    static constexpr int NI = BR / 32;     // DMA instructions per wave per tile (each moves 1 KB)
+
+    // per-lane source offsets (floats, relative to the tile origin (r_base, k_base)) of this wave's NI
+    // DMA pieces; constant over the K loop
+    static __device__ __forceinline__ void src_offsets(size_t (&off)[NI], int ld, int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int n = wave * NI + i;   // piece index: LDS floats [n*256, n*256+256)
+            if constexpr (!KM) {
+                const int row = n * 8 + (lane >> 3), pos = lane & 7;
+                off[i] = (size_t)row * ld + 4 * (pos ^ ((row >> 1) & 7));
+            } else {
+                constexpr int V = BR / 4;              // 16-byte slots per k row
+                const int k = n * (64 / V) + lane / V, r4 = lane % V;
+                off[i] = (size_t)k * ld + 4 * r4;
+            }
+        }
+    }
+    static __device__ __forceinline__ void issue(const float* __restrict__ origin, const size_t (&off)[NI],
+                                                 float* __restrict__ S, int wave) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(origin + off[i]), (lptr_t)(S + (wave * NI + i) * 256), 16, 0, 0);
+    }
+    // the four k values (8j+4q+e, e = 0..3) of row r for this lane
+    static __device__ __forceinline__ float4 frag(const float* __restrict__ S, int r, int j, int q) {
+        if constexpr (!KM) {
+            return *reinterpret_cast<const float4*>(S + r * GEMM_BK + 4 * ((2 * j + q) ^ ((r >> 1) & 7)));
+        } else {
+            const float* s = S + (8 * j + 4 * q) * BR + r;
+            return make_float4(s[0], s[BR], s[2 * BR], s[3 * BR]);
+        }
+    }
+};
+
+template <int BM, int BN, bool A_KM, bool B_KM, int EPI>
+__global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs p) {
+    using LA = FastTile<BM, A_KM>;
+    using LB = FastTile<BN, B_KM>;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int A_FL = LA::LDS_FLOATS, B_FL = LB::LDS_FLOATS, STAGE_FL = A_FL + B_FL;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m_blk = blockIdx.y * BM, n_blk = blockIdx.x * BN;
+    const int k_begin = blockIdx.z * p.k_per_split;
+    const int k_end = min(p.K, k_begin + p.k_per_split);
+    const int nk = (k_end - k_begin) / GEMM_BK;
+    const int fr = lane & 31, fq = lane >> 5;
+    if (nk <= 0) return;   // host never launches an empty split
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    size_t offa[LA::NI], offb[LB::NI];
+    LA::src_offsets(offa, p.lda, wave, lane);
+    LB::src_offsets(offb, p.ldb, wave, lane);
+    // tile origins at k = k_begin; advancing one K step adds BK floats (k-contiguous) or BK rows (k-major)
+    const float* ga = A_KM ? p.A + (size_t)k_begin * p.lda + m_blk : p.A + (size_t)m_blk * p.lda + k_begin;
+    const float* gb = B_KM ? p.B + (size_t)k_begin * p.ldb + n_blk : p.B + (size_t)n_blk * p.ldb + k_begin;
+    const size_t sa = A_KM ? (size_t)GEMM_BK * p.lda : GEMM_BK;
+    const size_t sb = B_KM ? (size_t)GEMM_BK * p.ldb : GEMM_BK;
+
+    LA::issue(ga, offa, smem, wave);
+    LB::issue(gb, offb, smem + A_FL, wave);
+    __syncthreads();   // (hipcc drains the DMA - vmcnt(0) - in front of the barrier)
+
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {   // next tile's DMA lands in the other buffer while this one is multiplied
+            float* nxt = smem + ((kt + 1) & 1) * STAGE_FL;
+            ga += sa; gb += sb;
+            LA::issue(ga, offa, nxt, wave);
+            LB::issue(gb, offb, nxt + A_FL, wave);
+        }
+        const float* a_s = smem + (kt & 1) * STAGE_FL;
+        const float* b_s = a_s + A_FL;
+#pragma unroll
+        for (int j = 0; j < GEMM_BK / 8; ++j) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = LA::frag(a_s, wm * (BM / 2) + i * 32 + fr, j, fq);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) bf[i] = LB::frag(b_s, wn * (BN / 2) + i * 32 + fr, j, fq);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) {
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[jn].x, acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[jn].y, acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[jn].z, acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[jn].w, acc[i][jn], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n_blk + wn * (BN / 2) + j * 32 + fr;
+            const int row0 = m_blk + wm * (BM / 2) + i * 32 + 4 * fq;
+            if constexpr (EPI == EPI_SLAB) {
+                float* c = p.slab + ((size_t)blockIdx.z * p.M + row0) * p.N + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[(size_t)((r & 3) + 8 * (r >> 2)) * p.N] = acc[i][j][r];
+            } else {
+                float bv = 0.f;
+                if constexpr (EPI != EPI_ATOMIC) bv = p.bias != nullptr ? p.bias[col] : 0.f;
+                else bv = (p.bias != nullptr && blockIdx.z == 0) ? p.bias[col] : 0.f;
+                float* c = p.C + (size_t)row0 * p.ldc + col;
+                float mk[16];
+                if constexpr (EPI == EPI_MASK) {
+                    const float* ax = p.aux + (size_t)row0 * p.ldaux + col;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mk[r] = ax[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldaux];
+                }
+                if constexpr (EPI == EPI_ACC) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mk[r] = c[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] + bv;
+                    if constexpr (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+                    if constexpr (EPI == EPI_MASK) v = mk[r] > 0.f ? v : 0.f;
+                    if constexpr (EPI == EPI_ACC) v += mk[r];
+                    float* cr = c + (size_t)((r & 3) + 8 * (r >> 2)) * p.ldc;
+                    if constexpr (EPI == EPI_ATOMIC) atomicAdd(cr, v);
+                    else *cr = v;
+                }
+            }
+        }
+    }
+}
+
 // C[m][n] (+)= bias[n] + sum_z slab[z][m][n]   (second stage of split-K: far cheaper than one fp32 atomic
 // per partial element - an M x N x splits slab is a few MB, L2-resident)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int M,
@@ -263,6 +437,52 @@ static int dispatch_tile(const GemmArgs& a, int splits, hipStream_t stream) {
         if (tiles >= 128) return launch_gemm<128, 64, A_KM, B_KM>(a, splits, stream);
     }
     return launch_gemm<64, 64, A_KM, B_KM>(a, splits, stream);
+}
+
+
+template <int BM, int BN, bool A_KM, bool B_KM, int EPI>
+static int launch_fast(const GemmArgs& a, int splits, hipStream_t stream) {
+    constexpr int A_FL = FastTile<BM, A_KM>::LDS_FLOATS, B_FL = FastTile<BN, B_KM>::LDS_FLOATS;
+    const size_t lds = (size_t)(A_FL + B_FL) * 2 * sizeof(float);
+    static bool attr_done = false;
+    if (lds > 48 * 1024 && !attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_fast_kernel<BM, BN, A_KM, B_KM, EPI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("gemm: hipFuncSetAttribute", (int)e); return (int)e; }
+        attr_done = true;
+    }
+    dim3 grid(a.N / BN, a.M / BM, splits);
+    hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, A_KM, B_KM, EPI>), grid, dim3(256), lds, stream, a);
+    return launch_check("gemm_f32(fast)");
+}
+
+template <int BM, int BN, bool A_KM, bool B_KM>
+static int fast_epi(const GemmArgs& a, int splits, hipStream_t stream) {
+    if (a.slab != nullptr) return launch_fast<BM, BN, A_KM, B_KM, EPI_SLAB>(a, splits, stream);
+    if (a.atomic) return launch_fast<BM, BN, A_KM, B_KM, EPI_ATOMIC>(a, splits, stream);
+    if (a.aux != nullptr) return launch_fast<BM, BN, A_KM, B_KM, EPI_MASK>(a, splits, stream);
+    if (a.relu) return launch_fast<BM, BN, A_KM, B_KM, EPI_RELU>(a, splits, stream);
+    if (a.accumulate) return launch_fast<BM, BN, A_KM, B_KM, EPI_ACC>(a, splits, stream);
+    return launch_fast<BM, BN, A_KM, B_KM, EPI_PLAIN>(a, splits, stream);
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// returns -1 when the shape does not qualify for the fast path
+template <bool A_KM, bool B_KM>
+static int dispatch_fast(const GemmArgs& a, int splits, hipStream_t stream) {
+    if ((a.M & 63) || (a.N & 63) || (a.k_per_split % GEMM_BK) || (a.K % GEMM_BK) || (a.lda & 3) || (a.ldb & 3) ||
+        !aligned16(a.A) || !aligned16(a.B))
+        return -1;
+    if (a.relu && a.aux != nullptr) return -1;
+    const bool m128 = (a.M % 128) == 0, n128 = (a.N % 128) == 0;
+    // prefer the big tile while it still gives every CU two workgroups; otherwise shrink M first
+    const long t_big = (long)(a.M / 128) * (a.N / 128) * splits;
+    if (m128 && n128 && t_big >= 512) return fast_epi<128, 128, A_KM, B_KM>(a, splits, stream);
+    if (n128 && (long)(a.M / 64) * (a.N / 128) * splits >= 384) return fast_epi<64, 128, A_KM, B_KM>(a, splits, stream);
+    if (m128 && n128 && t_big >= 256) return fast_epi<128, 128, A_KM, B_KM>(a, splits, stream);
+    if (n128) return fast_epi<64, 128, A_KM, B_KM>(a, splits, stream);
+    return fast_epi<64, 64, A_KM, B_KM>(a, splits, stream);
 }
 
 // C[M,N] (op)= A*B.  splits <= 0 -> chosen automatically (split-K is used when the output tile
@@ -313,10 +533,16 @@ int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int 
     ProfScope prof(a_kmajor ? "gemm_f32_dW(TN,split-K)" : (b_kmajor ? "gemm_f32_dX(NN)" : "gemm_f32_fwd(NT)"),
                    2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), stream);
     int rc;
-    if (!a_kmajor && !b_kmajor) rc = dispatch_tile<false, false>(a, splits, stream);
-    else if (!a_kmajor && b_kmajor) rc = dispatch_tile<false, true>(a, splits, stream);
-    else if (a_kmajor && !b_kmajor) rc = dispatch_tile<true, false>(a, splits, stream);
-    else rc = dispatch_tile<true, true>(a, splits, stream);
+    if (!a_kmajor && !b_kmajor) rc = dispatch_fast<false, false>(a, splits, stream);
+    else if (!a_kmajor && b_kmajor) rc = dispatch_fast<false, true>(a, splits, stream);
+    else if (a_kmajor && !b_kmajor) rc = dispatch_fast<true, false>(a, splits, stream);
+    else rc = dispatch_fast<true, true>(a, splits, stream);
+    if (rc == -1) {
+        if (!a_kmajor && !b_kmajor) rc = dispatch_tile<false, false>(a, splits, stream);
+        else if (!a_kmajor && b_kmajor) rc = dispatch_tile<false, true>(a, splits, stream);
+        else if (a_kmajor && !b_kmajor) rc = dispatch_tile<true, false>(a, splits, stream);
+        else rc = dispatch_tile<true, true>(a, splits, stream);
+    }
     if (rc == 0 && a.slab != nullptr) {
         const long long mn = (long long)M * N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, stream, a.slab, C, M, N,

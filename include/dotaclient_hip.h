@@ -46,6 +46,11 @@ int dc_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, i
                 int a_kmajor, int b_kmajor, const float* bias, int relu, const float* aux, int ldaux,
                 int accumulate, int splits, dc_stream_t stream);
 
+/* Optional scratch for dc_gemm_f32's split-K (partial slabs reduced by a second kernel instead of fp32
+ * atomics).  floats = capacity; NULL/0 restores the atomic path.  Process-wide, not thread-safe;
+ * dc_policy_backward installs its own workspace slab for the duration of the call. */
+void dc_gemm_set_scratch(float* scratch, int64_t floats);
+
 /* ------------------------------------------------------------------------------------------------
  * Network + optimizer step.  Shapes: dc_dims; parameters: one flat fp32 buffer whose tensors are
  * addressed by an offset table `poff` (floats, host array, index = dc_param_index); scratch: one

@@ -1,0 +1,87 @@
+"""Times dc_gemm_f32 on the exact GEMM shapes of one PPO epoch (64x256 LSTM-128 by default) and, as a
+ceiling reference only, the same products through torch.matmul (rocBLAS fp32).  Scratch tool, not part
+of the bench contract.  Usage: python tools/gemm_bench.py [rows] [H]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dotaclient_amd import ops  # noqa: E402
+
+NR = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+G = 4
+dev = torch.device('cuda:0')
+
+
+def t_ms(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def case(name, M, N, K, a_km, b_km, relu=False, aux=False, bias=False, count=1):
+    # storage shapes
+    A = torch.randn((K, M) if a_km else (M, K), device=dev)
+    B = torch.randn((K, N) if b_km else (N, K), device=dev)
+    C = torch.empty(M, N, device=dev)
+    bz = torch.randn(N, device=dev) if bias else None
+    ax = torch.randn(M, N, device=dev) if aux else None
+    lda = M if a_km else K
+    ldb = N if b_km else K
+    f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, a_km, b_km, bias=bz, relu=relu, aux=ax, ldaux=N)
+    ms = t_ms(f)
+    Am = A.t() if a_km else A
+    Bm = B if b_km else B.t()
+    ref = Am @ Bm
+    if bias:
+        ref = ref + bz
+    if relu:
+        ref = ref.clamp_min(0)
+    if aux:
+        ref = torch.where(ax > 0, ref, torch.zeros_like(ref))
+    f()
+    err = ((C - ref).abs().max() / ref.abs().max()).item()
+    ms_ref = t_ms(lambda: torch.matmul(Am, Bm))
+    fl = 2.0 * M * N * K
+    print('%-22s M=%7d N=%4d K=%7d %s%s  ours %8.1f us %6.1f TF | rocblas %8.1f us %6.1f TF | x%d  err %.1e'
+          % (name, M, N, K, 'T' if a_km else 'N', 'N' if b_km else 'T', ms * 1e3, fl / ms / 1e9, ms_ref * 1e3,
+             fl / ms_ref / 1e9, count, err))
+    return ms * count
+
+
+SCRATCH = torch.empty(8 << 20, device=dev)
+ops._lib.load().dc_gemm_set_scratch(ops._lib.ptr(SCRATCH), SCRATCH.numel())
+tot = 0.0
+print('--- forward')
+for U in (1, 5, 16):
+    tot += case('F1 unit emb U=%d' % U, NR * U, 128, 128, False, False, bias=True, count=3 if U == 1 else (2 if U == 16 else 1))
+tot += case('F2 pre_rnn', NR, 256, 896, False, False, relu=True, bias=True)
+tot += case('F3 W_ih', NR, G * H, 256, False, False, bias=True)
+tot += case('F4 heads', NR, 154, H, False, False, bias=True)
+fwd = tot
+print('forward GEMMs: %.3f ms' % fwd)
+print('--- backward')
+tot = 0.0
+tot += case('B1 dH', NR, H, 154, False, True)
+tot += case('B2 dW_heads', 154, H, NR, True, True)
+tot += case('B4 dW_ih', G * H, 256, NR, True, True)
+tot += case('B5 dW_hh', G * H, H, NR, True, True)
+tot += case('B6 dpre', NR, 256, G * H, False, True, aux=True)
+tot += case('B7 dW_pre', 256, 896, NR, True, True)
+tot += case('B8 dxcat', NR, 896, 256, False, True)
+for U in (1, 5, 16):
+    c = 3 if U == 1 else (2 if U == 16 else 1)
+    tot += case('B9 dW_unit U=%d' % U, 128, 128, NR * U, True, True, count=c)
+    tot += case('B10 dbasic U=%d' % U, NR * U, 128, 128, False, True, aux=True, count=c)
+print('backward GEMMs: %.3f ms' % tot)
+print('per bench step (5 fwd + 4 bwd): %.3f ms' % (5 * fwd + 4 * tot))
