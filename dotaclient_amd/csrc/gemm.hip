@@ -248,19 +248,25 @@ struct FastTile {
     static constexpr int LDS_FLOATS = GEMM_BK * BR;
     static constexpr int NI = BR / 32;     // DMA instructions per wave per tile (each moves 1 KB)
 
-    // per-lane source offsets (floats, relative to the tile origin (r_base, k_base)) of this wave's NI
-    // DMA pieces; constant over the K loop
-    static __device__ __forceinline__ void src_offsets(size_t (&off)[NI], int ld, int wave, int lane) {
+    // per-lane source offsets (floats, relative to the operand at k = k_base) of this wave's NI DMA
+    // pieces; constant over the K loop.  EDGE: rows past the logical extent R re-read a valid row (their
+    // products only reach output rows/columns the epilogue never stores).
+    template <bool EDGE>
+    static __device__ __forceinline__ void src_offsets(size_t (&off)[NI], int ld, int r_base, int R, int wave, int lane) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int n = wave * NI + i;   // piece index: LDS floats [n*256, n*256+256)
             if constexpr (!KM) {
                 const int row = n * 8 + (lane >> 3), pos = lane & 7;
-                off[i] = (size_t)row * ld + 4 * (pos ^ ((row >> 1) & 7));
+                int rg = r_base + row;
+                if constexpr (EDGE) rg = min(rg, R - 1);
+                off[i] = (size_t)rg * ld + 4 * (pos ^ ((row >> 1) & 7));
             } else {
                 constexpr int V = BR / 4;              // 16-byte slots per k row
                 const int k = n * (64 / V) + lane / V, r4 = lane % V;
-                off[i] = (size_t)k * ld + 4 * r4;
+                int cg = r_base + 4 * r4;
+                if constexpr (EDGE) cg = min(cg, ld - 4);   // stay inside the physical row
+                off[i] = (size_t)k * ld + cg;
             }
         }
     }
@@ -281,7 +287,7 @@ struct FastTile {
     }
 };
 
-template <int BM, int BN, bool A_KM, bool B_KM, int EPI>
+template <int BM, int BN, bool A_KM, bool B_KM, int EPI, bool EDGE>
 __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs p) {
     using LA = FastTile<BM, A_KM>;
     using LB = FastTile<BN, B_KM>;
@@ -308,11 +314,11 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     size_t offa[LA::NI], offb[LB::NI];
-    LA::src_offsets(offa, p.lda, wave, lane);
-    LB::src_offsets(offb, p.ldb, wave, lane);
-    // tile origins at k = k_begin; advancing one K step adds BK floats (k-contiguous) or BK rows (k-major)
-    const float* ga = A_KM ? p.A + (size_t)k_begin * p.lda + m_blk : p.A + (size_t)m_blk * p.lda + k_begin;
-    const float* gb = B_KM ? p.B + (size_t)k_begin * p.ldb + n_blk : p.B + (size_t)n_blk * p.ldb + k_begin;
+    LA::template src_offsets<EDGE>(offa, p.lda, m_blk, p.M, wave, lane);
+    LB::template src_offsets<EDGE>(offb, p.ldb, n_blk, p.N, wave, lane);
+    // operand origins at k = k_begin; advancing one K step adds BK floats (k-contiguous) or BK rows (k-major)
+    const float* ga = A_KM ? p.A + (size_t)k_begin * p.lda : p.A + k_begin;
+    const float* gb = B_KM ? p.B + (size_t)k_begin * p.ldb : p.B + k_begin;
     const size_t sa = A_KM ? (size_t)GEMM_BK * p.lda : GEMM_BK;
     const size_t sb = B_KM ? (size_t)GEMM_BK * p.ldb : GEMM_BK;
 
@@ -356,10 +362,13 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs p) {
         for (int j = 0; j < TN; ++j) {
             const int col = n_blk + wn * (BN / 2) + j * 32 + fr;
             const int row0 = m_blk + wm * (BM / 2) + i * 32 + 4 * fq;
+            if constexpr (EDGE) { if (col >= p.N) continue; }
+            auto row_ok = [&](int r) { return !EDGE || row0 + (r & 3) + 8 * (r >> 2) < p.M; };
             if constexpr (EPI == EPI_SLAB) {
                 float* c = p.slab + ((size_t)blockIdx.z * p.M + row0) * p.N + col;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) c[(size_t)((r & 3) + 8 * (r >> 2)) * p.N] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r)
+                    if (row_ok(r)) c[(size_t)((r & 3) + 8 * (r >> 2)) * p.N] = acc[i][j][r];
             } else {
                 float bv = 0.f;
                 if constexpr (EPI != EPI_ATOMIC) bv = p.bias != nullptr ? p.bias[col] : 0.f;
@@ -369,11 +378,11 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs p) {
                 if constexpr (EPI == EPI_MASK) {
                     const float* ax = p.aux + (size_t)row0 * p.ldaux + col;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) mk[r] = ax[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldaux];
+                    for (int r = 0; r < 16; ++r) mk[r] = row_ok(r) ? ax[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldaux] : 0.f;
                 }
                 if constexpr (EPI == EPI_ACC) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) mk[r] = c[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc];
+                    for (int r = 0; r < 16; ++r) mk[r] = row_ok(r) ? c[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] : 0.f;
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -382,8 +391,10 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs p) {
                     if constexpr (EPI == EPI_MASK) v = mk[r] > 0.f ? v : 0.f;
                     if constexpr (EPI == EPI_ACC) v += mk[r];
                     float* cr = c + (size_t)((r & 3) + 8 * (r >> 2)) * p.ldc;
-                    if constexpr (EPI == EPI_ATOMIC) atomicAdd(cr, v);
-                    else *cr = v;
+                    if (row_ok(r)) {
+                        if constexpr (EPI == EPI_ATOMIC) atomicAdd(cr, v);
+                        else *cr = v;
+                    }
                 }
             }
         }
@@ -395,11 +406,27 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs p) {
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int M,
                                                             int N, int ldc, int splits, const float* __restrict__ bias,
                                                             int accumulate) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)M * N) return;
-    const int m = (int)(idx / N), n = (int)(idx - (long long)m * N);
+    // 64 consecutive outputs per block, the splits dealt round-robin to 4 thread groups (a 128x128
+    // product has only 16K outputs: one thread per output left most of the chip idle)
+    __shared__ float sh[256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long long mn = (long long)M * N;
+    const long long idx = (long long)blockIdx.x * 64 + tx;
     float acc = 0.f;
-    for (int z = 0; z < splits; ++z) acc += slab[(size_t)z * M * N + idx];
+    if (idx < mn) {
+        int z = ty;
+        for (; z + 12 < splits; z += 16) {
+            const float a0 = slab[(size_t)z * mn + idx], a1 = slab[(size_t)(z + 4) * mn + idx];
+            const float a2 = slab[(size_t)(z + 8) * mn + idx], a3 = slab[(size_t)(z + 12) * mn + idx];
+            acc += (a0 + a1) + (a2 + a3);
+        }
+        for (; z < splits; z += 4) acc += slab[(size_t)z * mn + idx];
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (ty != 0 || idx >= mn) return;
+    acc = (sh[tx] + sh[64 + tx]) + (sh[128 + tx] + sh[192 + tx]);
+    const int m = (int)(idx / N), n = (int)(idx - (long long)m * N);
     if (bias) acc += bias[n];
     float* c = C + (size_t)m * ldc + n;
     *c = accumulate ? *c + acc : acc;
@@ -440,30 +467,30 @@ static int dispatch_tile(const GemmArgs& a, int splits, hipStream_t stream) {
 }
 
 
-template <int BM, int BN, bool A_KM, bool B_KM, int EPI>
+template <int BM, int BN, bool A_KM, bool B_KM, int EPI, bool EDGE>
 static int launch_fast(const GemmArgs& a, int splits, hipStream_t stream) {
     constexpr int A_FL = FastTile<BM, A_KM>::LDS_FLOATS, B_FL = FastTile<BN, B_KM>::LDS_FLOATS;
     const size_t lds = (size_t)(A_FL + B_FL) * 2 * sizeof(float);
     static bool attr_done = false;
     if (lds > 48 * 1024 && !attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_fast_kernel<BM, BN, A_KM, B_KM, EPI>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_fast_kernel<BM, BN, A_KM, B_KM, EPI, EDGE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error("gemm: hipFuncSetAttribute", (int)e); return (int)e; }
         attr_done = true;
     }
-    dim3 grid(a.N / BN, a.M / BM, splits);
-    hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, A_KM, B_KM, EPI>), grid, dim3(256), lds, stream, a);
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits);
+    hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, A_KM, B_KM, EPI, EDGE>), grid, dim3(256), lds, stream, a);
     return launch_check("gemm_f32(fast)");
 }
 
-template <int BM, int BN, bool A_KM, bool B_KM>
+template <int BM, int BN, bool A_KM, bool B_KM, bool EDGE>
 static int fast_epi(const GemmArgs& a, int splits, hipStream_t stream) {
-    if (a.slab != nullptr) return launch_fast<BM, BN, A_KM, B_KM, EPI_SLAB>(a, splits, stream);
-    if (a.atomic) return launch_fast<BM, BN, A_KM, B_KM, EPI_ATOMIC>(a, splits, stream);
-    if (a.aux != nullptr) return launch_fast<BM, BN, A_KM, B_KM, EPI_MASK>(a, splits, stream);
-    if (a.relu) return launch_fast<BM, BN, A_KM, B_KM, EPI_RELU>(a, splits, stream);
-    if (a.accumulate) return launch_fast<BM, BN, A_KM, B_KM, EPI_ACC>(a, splits, stream);
-    return launch_fast<BM, BN, A_KM, B_KM, EPI_PLAIN>(a, splits, stream);
+    if (a.slab != nullptr) return launch_fast<BM, BN, A_KM, B_KM, EPI_SLAB, EDGE>(a, splits, stream);
+    if (a.atomic) return launch_fast<BM, BN, A_KM, B_KM, EPI_ATOMIC, EDGE>(a, splits, stream);
+    if (a.aux != nullptr) return launch_fast<BM, BN, A_KM, B_KM, EPI_MASK, EDGE>(a, splits, stream);
+    if (a.relu) return launch_fast<BM, BN, A_KM, B_KM, EPI_RELU, EDGE>(a, splits, stream);
+    if (a.accumulate) return launch_fast<BM, BN, A_KM, B_KM, EPI_ACC, EDGE>(a, splits, stream);
+    return launch_fast<BM, BN, A_KM, B_KM, EPI_PLAIN, EDGE>(a, splits, stream);
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -471,18 +498,23 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // returns -1 when the shape does not qualify for the fast path
 template <bool A_KM, bool B_KM>
 static int dispatch_fast(const GemmArgs& a, int splits, hipStream_t stream) {
-    if ((a.M & 63) || (a.N & 63) || (a.k_per_split % GEMM_BK) || (a.K % GEMM_BK) || (a.lda & 3) || (a.ldb & 3) ||
-        !aligned16(a.A) || !aligned16(a.B))
+    if ((a.k_per_split % GEMM_BK) || (a.K % GEMM_BK) || (a.lda & 3) || (a.ldb & 3) || !aligned16(a.A) || !aligned16(a.B))
         return -1;
     if (a.relu && a.aux != nullptr) return -1;
+    if ((a.M & 63) || (a.N & 63)) {
+        // ragged M/N (the 154-wide head projections): clamped source rows + masked stores, 64x64 tiles.
+        // k-major operands are read in 16-byte pieces up to their physical row width.
+        if ((A_KM && a.lda < 4) || (B_KM && a.ldb < 4)) return -1;
+        return fast_epi<64, 64, A_KM, B_KM, true>(a, splits, stream);
+    }
     const bool m128 = (a.M % 128) == 0, n128 = (a.N % 128) == 0;
     // prefer the big tile while it still gives every CU two workgroups; otherwise shrink M first
     const long t_big = (long)(a.M / 128) * (a.N / 128) * splits;
-    if (m128 && n128 && t_big >= 512) return fast_epi<128, 128, A_KM, B_KM>(a, splits, stream);
-    if (n128 && (long)(a.M / 64) * (a.N / 128) * splits >= 384) return fast_epi<64, 128, A_KM, B_KM>(a, splits, stream);
-    if (m128 && n128 && t_big >= 256) return fast_epi<128, 128, A_KM, B_KM>(a, splits, stream);
-    if (n128) return fast_epi<64, 128, A_KM, B_KM>(a, splits, stream);
-    return fast_epi<64, 64, A_KM, B_KM>(a, splits, stream);
+    if (m128 && n128 && t_big >= 512) return fast_epi<128, 128, A_KM, B_KM, false>(a, splits, stream);
+    if (n128 && (long)(a.M / 64) * (a.N / 128) * splits >= 384) return fast_epi<64, 128, A_KM, B_KM, false>(a, splits, stream);
+    if (m128 && n128 && t_big >= 256) return fast_epi<128, 128, A_KM, B_KM, false>(a, splits, stream);
+    if (n128) return fast_epi<64, 128, A_KM, B_KM, false>(a, splits, stream);
+    return fast_epi<64, 64, A_KM, B_KM, false>(a, splits, stream);
 }
 
 // C[M,N] (op)= A*B.  splits <= 0 -> chosen automatically (split-K is used when the output tile
@@ -545,7 +577,7 @@ int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int 
     }
     if (rc == 0 && a.slab != nullptr) {
         const long long mn = (long long)M * N;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, stream, a.slab, C, M, N,
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, stream, a.slab, C, M, N,
                            ldc, splits, bias, accumulate);
         rc = launch_check("splitk_reduce");
     }

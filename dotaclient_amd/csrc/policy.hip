@@ -51,6 +51,7 @@ int64_t workspace_layout(const dc_dims* d, int64_t* out) {
     put(DC_WS_STATS, 64 * 8);
     put(DC_WS_WHHT, H * G * H * 4);
     put(DC_WS_SCRATCH, (int64_t)DC_SCRATCH_FLOATS * 4);   // two-stage reductions / split-K slabs
+    put(DC_WS_HEADW_PAD, (int64_t)HO_LD * H * 4);          // head weights zero-padded to 160 rows (K of dH)
     for (int l = 0; l < d->layers; ++l) {
         const int b = DC_WS_FIXED + l * DC_WS_PER_LAYER;
         put(b + DC_WSL_GATES, NR * G * H * 4);
@@ -155,7 +156,15 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
 
     // heads (policy.py:144-155)
     DC_TRY(attn_bwd_q(w.f(DC_WS_DTU), w.f(DC_WS_EMB), w.f(DC_WS_DHEADOUT), NR, s));
-    DC_TRY(gemm_f32(w.f(DC_WS_DHEADOUT), P.p(DC_P_HEADS_W), w.fl(TOP, DC_WSL_DH), (int)NR, H, HO_N, HO_LD, H, H, 0, 1, nullptr,
+    // dH = dheadout[:, 0:160] * [W_heads; 0]: K padded to a multiple of 32 (dheadout's pad columns are
+    // zeroed by the loss kernel), so the product runs on the fast GEMM path
+    {
+        hipError_t e1 = hipMemcpyAsync(w.f(DC_WS_HEADW_PAD), P.p(DC_P_HEADS_W), (size_t)HO_N * H * sizeof(float),
+                                       hipMemcpyDeviceToDevice, s);
+        hipError_t e2 = hipMemsetAsync(w.f(DC_WS_HEADW_PAD) + (size_t)HO_N * H, 0, (size_t)(HO_LD - HO_N) * H * sizeof(float), s);
+        if (e1 != hipSuccess || e2 != hipSuccess) { set_error("policy_backward: head weight pad", (int)(e1 != hipSuccess ? e1 : e2)); return 1; }
+    }
+    DC_TRY(gemm_f32(w.f(DC_WS_DHEADOUT), w.f(DC_WS_HEADW_PAD), w.fl(TOP, DC_WSL_DH), (int)NR, H, HO_LD, HO_LD, H, H, 0, 1, nullptr,
                     0, nullptr, 0, 0, 1, s));
     DC_TRY(gemm_f32(w.f(DC_WS_DHEADOUT), w.fl(TOP, DC_WSL_HSEQ), Gd.p(DC_P_HEADS_W), HO_N, H, (int)NR, HO_LD, H, H, 1, 1,
                     nullptr, 0, nullptr, 0, 1, 0, s));

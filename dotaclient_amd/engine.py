@@ -28,7 +28,7 @@ class DcDims(ctypes.Structure):
 
 
 WS_FIXED = ['BASIC', 'EMB', 'DEMB', 'XCAT', 'AMAX', 'PRE', 'HEADOUT', 'TU', 'DHEADOUT', 'DTU', 'DPRE', 'DXCAT',
-            'STATS', 'WHHT', 'SCRATCH']
+            'STATS', 'WHHT', 'SCRATCH', 'HEADW_PAD']
 WS_LAYER = ['GATES', 'HN', 'HSEQ', 'HPREV', 'CSEQ', 'CPREV', 'DGX', 'DGH', 'DC', 'DH']
 
 

@@ -89,7 +89,7 @@ enum dc_param_index {
 /* workspace buffer ids (for dc_workspace_layout's offsets[]; bytes) */
 enum dc_ws_index {
     DC_WS_BASIC = 0, DC_WS_EMB, DC_WS_DEMB, DC_WS_XCAT, DC_WS_AMAX, DC_WS_PRE, DC_WS_HEADOUT, DC_WS_TU,
-    DC_WS_DHEADOUT, DC_WS_DTU, DC_WS_DPRE, DC_WS_DXCAT, DC_WS_STATS, DC_WS_WHHT, DC_WS_SCRATCH,
+    DC_WS_DHEADOUT, DC_WS_DTU, DC_WS_DPRE, DC_WS_DXCAT, DC_WS_STATS, DC_WS_WHHT, DC_WS_SCRATCH, DC_WS_HEADW_PAD,
     DC_WS_FIXED,            /* per-layer blocks follow */
     DC_WSL_GATES = 0, DC_WSL_HN, DC_WSL_HSEQ, DC_WSL_HPREV, DC_WSL_CSEQ, DC_WSL_CPREV, DC_WSL_DGX, DC_WSL_DGH,
     DC_WSL_DC, DC_WSL_DH,

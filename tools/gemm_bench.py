@@ -29,18 +29,18 @@ def t_ms(fn, iters=20):
     return s.elapsed_time(e) / iters
 
 
-def case(name, M, N, K, a_km, b_km, relu=False, aux=False, bias=False, count=1):
-    # storage shapes
-    A = torch.randn((K, M) if a_km else (M, K), device=dev)
+def case(name, M, N, K, a_km, b_km, relu=False, aux=False, bias=False, count=1, lda=None):
+    # storage shapes (lda > M: k-major A with padded rows, as the [rows][160] head-gradient buffer)
+    A = torch.randn((K, lda or M) if a_km else (M, K), device=dev)
     B = torch.randn((K, N) if b_km else (N, K), device=dev)
     C = torch.empty(M, N, device=dev)
     bz = torch.randn(N, device=dev) if bias else None
     ax = torch.randn(M, N, device=dev) if aux else None
-    lda = M if a_km else K
+    lda = (lda or M) if a_km else K
     ldb = N if b_km else K
     f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, a_km, b_km, bias=bz, relu=relu, aux=ax, ldaux=N)
     ms = t_ms(f)
-    Am = A.t() if a_km else A
+    Am = A[:, :M].t() if a_km else A
     Bm = B if b_km else B.t()
     ref = Am @ Bm
     if bias:
@@ -72,8 +72,8 @@ fwd = tot
 print('forward GEMMs: %.3f ms' % fwd)
 print('--- backward')
 tot = 0.0
-tot += case('B1 dH', NR, H, 154, False, True)
-tot += case('B2 dW_heads', 154, H, NR, True, True)
+tot += case('B1 dH (K pad 160)', NR, H, 160, False, True)
+tot += case('B2 dW_heads', 154, H, NR, True, True, lda=160)
 tot += case('B4 dW_ih', G * H, 256, NR, True, True)
 tot += case('B5 dW_hh', G * H, H, NR, True, True)
 tot += case('B6 dpre', NR, 256, G * H, False, True, aux=True)
