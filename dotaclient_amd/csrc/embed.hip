@@ -324,6 +324,11 @@ int unit_basic_bwd(const float* obs, const float* dbasic, float* dW1, float* db1
     return launch_check("unit_basic_bwd");
 }
 
+int unit_basic_reduce(const float* partials, int nblk, float* dW1, float* db1, hipStream_t s) {
+    hipLaunchKernelGGL(unit_basic_reduce_kernel, dim3(7, 32), dim3(256), 0, s, partials, nblk, dW1, db1);
+    return launch_check("unit_basic_reduce");
+}
+
 int colsum(const float* X, int ld, long long rows, int cols, float* out, hipStream_t s) {
     if (rows <= 0 || cols <= 0) return 0;
     int rpb = (int)((rows + 1023) / 1024);

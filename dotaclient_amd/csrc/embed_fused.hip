@@ -1,0 +1,426 @@
+// Fused per-unit embedding MLP: the 12 -> 128 first layer never touches HBM.
+//
+// Replaces /root/reference/policy.py:100-126 (forward) and the autograd products of
+// /root/reference/optimizer.py:672 for
+//     basic = relu(x W1^T + b1)          (affine_unit_basic_stats, shared by all unit types, K = 12)
+//     emb   = basic W2_t^T + b2_t        (affine_unit_{ah,eh,anh,enh,ath,eth}, K = 128)
+// The unfused path (embed.hip + gemm.hip) materialises `basic` (512 B per unit, 335 MB per 64x256
+// batch), reads it back in the forward GEMM, twice more in the backward, and writes + re-reads the
+// equally large d(basic).  Here the K = 12 layer is recomputed from the 48-byte unit record wherever
+// it is needed - 12 FMAs per element, a few percent of the MFMA work next to it:
+//   embed_fwd_fused : A tile (basic) generated on the VALU straight into the swizzled LDS image of the
+//                     fast GEMM, B tile (W2_t) by DMA, exact-fp32 MFMA, emb written once
+//   embed_bwd_dw2   : dW2_t = demb_t^T basic_t as a split-K product whose B operand is generated
+//   embed_bwd_dw1   : d(basic) = (demb_t W2_t) * [basic > 0] stays in the accumulators; the epilogue
+//                     folds it straight into dW1 / db1 (d(basic) is never stored)
+// `basic` is evaluated with the same fmaf chain everywhere, so the relu mask of the backward is bitwise
+// the forward's.  Requires rows % 128 == 0 (every type block then starts on a tile boundary); other
+// batches take the unfused path.
+#include "kernels.h"
+#include "gemm_tiles.h"
+
+namespace dc {
+
+enum { EF_OBS = 483, EF_EMB = 128, EF_TILE = 128 };
+
+struct EmbTypes {
+    long long row_begin[7];   // type-major row where type t starts (nr * cum[t])
+    int tile_begin[7];        // row_begin / 128
+    int wg_begin[7];          // embed_bwd_dw2: first workgroup of type t
+    int steps_per_wg;         // embed_bwd_dw2: K steps (32 rows) per workgroup
+};
+
+__device__ __forceinline__ int ef_type_of_tile(const EmbTypes& ty, int tile) {
+    int t = 0;
+#pragma unroll
+    for (int i = 1; i < 6; ++i)
+        if (tile >= ty.tile_begin[i]) t = i;
+    return t;
+}
+__device__ __forceinline__ int ef_units(int t) { return t == 1 ? 5 : ((t == 2 || t == 3) ? 16 : 1); }
+__device__ __forceinline__ int ef_cum(int t) { return t == 0 ? 0 : (t == 1 ? 1 : (t == 2 ? 6 : (t == 3 ? 22 : (t == 4 ? 38 : 39)))); }
+
+// 12-feature record of type-major row `local` (relative to its type block)
+__device__ __forceinline__ const float* ef_record(const float* __restrict__ obs, int t, long long local) {
+    const int U = ef_units(t);
+    const long long n = local / U;
+    const int u = (int)(local - n * U);
+    return obs + n * EF_OBS + 3 + (ef_cum(t) + u) * 12;
+}
+
+// the one definition of the first layer (same fmaf order in forward and backward)
+__device__ __forceinline__ float ef_basic(const float (&x)[12], const float (&w)[12], float b) {
+    float a = b;
+#pragma unroll
+    for (int f = 0; f < 12; ++f) a = fmaf(x[f], w[f], a);
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward: one 128-row tile per workgroup, all 128 output channels, K = 128 in 4 steps
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_fwd_fused_kernel(const float* __restrict__ obs, const float* __restrict__ W1,
+                                                              const float* __restrict__ b1, const float* __restrict__ W2,
+                                                              const float* __restrict__ b2, float* __restrict__ emb,
+                                                              EmbTypes ty) {
+    using LT = FastTile<128, false>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* w1s = smem;                 // [128][12]
+    float* b1s = smem + 1536;          // [128]
+    float* stage = smem + 1664;        // 2 x (A [128][32] | B [128][32])
+    constexpr int STAGE_FL = 2 * 4096;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fq = lane >> 5;
+    const int tile = blockIdx.x;
+    const int t = ef_type_of_tile(ty, tile);
+    const long long row0 = (long long)tile * EF_TILE;
+
+    // this thread generates row (tid >> 1), channels 16*(tid & 1) .. +15 of every 32-channel K step
+    const int grow = tid >> 1, gh = tid & 1;
+    float x[12];
+    {
+        const float* xp = ef_record(obs, t, row0 + grow - ty.row_begin[t]);
+#pragma unroll
+        for (int f = 0; f < 12; ++f) x[f] = xp[f];
+    }
+    for (int e = tid; e < 1664; e += 256) smem[e] = e < 1536 ? W1[e] : b1[e - 1536];
+
+    size_t offb[LT::NI];
+    LT::src_offsets<false>(offb, EF_EMB, 0, 128, wave, lane);
+    const float* gb = W2 + (size_t)t * EF_EMB * EF_EMB;
+    LT::issue(gb, offb, stage + 4096, wave);
+    __syncthreads();   // W1/b1 staged (and, harmlessly early, B(0) landed)
+
+    auto gen_a = [&](int kt, float* a_s) {
+        float* dst = a_s + grow * GEMM_BK;
+        const int key = (grow >> 1) & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int chunk = 4 * gh + i, c0 = 32 * kt + 4 * chunk;
+            const float4 bb = *reinterpret_cast<const float4*>(b1s + c0);
+            const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4* wp = reinterpret_cast<const float4*>(w1s + (c0 + e) * 12);
+                const float4 wa = wp[0], wb = wp[1], wc = wp[2];
+                const float w[12] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x, wc.y, wc.z, wc.w};
+                o[e] = fmaxf(ef_basic(x, w, bv[e]), 0.f);
+            }
+            *reinterpret_cast<float4*>(dst + 4 * (chunk ^ key)) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    };
+    gen_a(0, stage);
+    __syncthreads();
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        float* cur = stage + (kt & 1) * STAGE_FL;
+        if (kt < 3) {
+            float* nxt = stage + ((kt + 1) & 1) * STAGE_FL;
+            LT::issue(gb + (kt + 1) * GEMM_BK, offb, nxt + 4096, wave);
+            gen_a(kt + 1, nxt);
+        }
+        mma_kstep<LT, LT, 2, 2>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc);
+        __syncthreads();
+    }
+
+    const float* b2t = b2 + t * EF_EMB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wn * 64 + j * 32 + fr;
+            const float bv = b2t[col];
+            float* c = emb + (size_t)(row0 + wm * 64 + i * 32 + 4 * fq) * EF_EMB + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[(size_t)((r & 3) + 8 * (r >> 2)) * EF_EMB] = acc[i][j][r] + bv;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward 1: dW2_t = demb_t^T basic_t.  Workgroup = (type, range of 32-row K steps), full 128x128
+// output -> slab[workgroup][128][128] (reduced per type by splitk_reduce).  A = demb rows by DMA
+// (k-major), B = basic generated k-major: thread (channel c, row half) with W1[c] in registers and the
+// unit records read through wave-uniform addresses.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restrict__ obs, const float* __restrict__ demb,
+                                                            const float* __restrict__ W1, const float* __restrict__ b1,
+                                                            float* __restrict__ slab, EmbTypes ty) {
+    using LT = FastTile<128, true>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x (A [32][128] | B [32][128])
+    constexpr int STAGE_FL = 2 * 4096;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fq = lane >> 5;
+    const int wg = blockIdx.x;
+    int t = 0;
+#pragma unroll
+    for (int i = 1; i < 6; ++i)
+        if (wg >= ty.wg_begin[i]) t = i;
+    const long long steps_t = (ty.row_begin[t + 1] - ty.row_begin[t]) / GEMM_BK;
+    const long long s0 = (long long)(wg - ty.wg_begin[t]) * ty.steps_per_wg;
+    const int ns = (int)min((long long)ty.steps_per_wg, steps_t - s0);
+
+    const int gc = tid & 127;
+    const int ghalf = __builtin_amdgcn_readfirstlane(tid >> 7);
+    float w[12];
+#pragma unroll
+    for (int f = 0; f < 12; ++f) w[f] = W1[gc * 12 + f];
+    const float bias = b1[gc];
+
+    size_t offa[LT::NI];
+    LT::src_offsets<false>(offa, EF_EMB, 0, 128, wave, lane);
+    const float* ga = demb + (size_t)(ty.row_begin[t] + s0 * GEMM_BK) * EF_EMB;
+
+    auto gen_b = [&](int s, float* b_s) {
+        const long long local = (s0 + s) * GEMM_BK + 16 * ghalf;   // wave-uniform
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const float* xp = ef_record(obs, t, local + i);
+            float x[12];
+#pragma unroll
+            for (int f = 0; f < 12; ++f) x[f] = xp[f];
+            b_s[(16 * ghalf + i) * 128 + gc] = fmaxf(ef_basic(x, w, bias), 0.f);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (ns > 0) {
+        LT::issue(ga, offa, smem, wave);
+        gen_b(0, smem + 4096);
+    }
+    __syncthreads();
+    for (int s = 0; s < ns; ++s) {
+        float* cur = smem + (s & 1) * STAGE_FL;
+        if (s + 1 < ns) {
+            float* nxt = smem + ((s + 1) & 1) * STAGE_FL;
+            LT::issue(ga + (size_t)(s + 1) * GEMM_BK * EF_EMB, offa, nxt, wave);
+            gen_b(s + 1, nxt + 4096);
+        }
+        mma_kstep<LT, LT, 2, 2>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc);
+        __syncthreads();
+    }
+    float* out = slab + (size_t)wg * EF_EMB * EF_EMB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float* c = out + (size_t)(wm * 64 + i * 32 + 4 * fq) * EF_EMB + wn * 64 + j * 32 + fr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[(size_t)((r & 3) + 8 * (r >> 2)) * EF_EMB] = acc[i][j][r];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward 2: d(basic) = (demb_t W2_t) * [basic > 0] -> dW1 / db1, d(basic) never stored.
+// Persistent workgroups stride over the 128-row tiles; main loop = the NN fast GEMM (A = demb rows by
+// DMA, B = W2_t k-major by DMA); the epilogue recomputes basic for the mask and accumulates
+// dW1[c][f] += g x[f], db1[c] += g in registers across tiles.  Output: partials[workgroup][13][128]
+// (12 features + bias), summed by unit_basic_reduce (embed.hip).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void embed_bwd_dw1_kernel(const float* __restrict__ obs, const float* __restrict__ demb,
+                                                            const float* __restrict__ W1, const float* __restrict__ b1,
+                                                            const float* __restrict__ W2, float* __restrict__ partials,
+                                                            EmbTypes ty, int n_tiles) {
+    using LA = FastTile<128, false>;
+    using LB = FastTile<128, true>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;              // [128][12] unit records of the tile
+    float* stage = smem + 1536;    // 2 x (A [128][32] | B [32][128])
+    constexpr int STAGE_FL = 2 * 4096;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fq = lane >> 5;
+
+    float w[2][12], bias[2], dw[2][12], db[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = wn * 64 + j * 32 + fr;
+#pragma unroll
+        for (int f = 0; f < 12; ++f) { w[j][f] = W1[c * 12 + f]; dw[j][f] = 0.f; }
+        bias[j] = b1[c];
+        db[j] = 0.f;
+    }
+    size_t offa[LA::NI], offb[LB::NI];
+    LA::src_offsets<false>(offa, EF_EMB, 0, 128, wave, lane);
+    LB::src_offsets<false>(offb, EF_EMB, 0, 128, wave, lane);
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int t = ef_type_of_tile(ty, tile);
+        const long long row0 = (long long)tile * EF_TILE;
+        const float* ga = demb + (size_t)row0 * EF_EMB;
+        const float* gb = W2 + (size_t)t * EF_EMB * EF_EMB;
+        __syncthreads();   // previous tile's epilogue is done with xs / the stage buffers
+        for (int e = tid; e < 1536; e += 256) {
+            const int r = e / 12, f = e - r * 12;
+            xs[e] = ef_record(obs, t, row0 + r - ty.row_begin[t])[f];
+        }
+        LA::issue(ga, offa, stage, wave);
+        LB::issue(gb, offb, stage + 4096, wave);
+        __syncthreads();
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            float* cur = stage + (kt & 1) * STAGE_FL;
+            if (kt < 3) {
+                float* nxt = stage + ((kt + 1) & 1) * STAGE_FL;
+                LA::issue(ga + (kt + 1) * GEMM_BK, offa, nxt, wave);
+                LB::issue(gb + (size_t)(kt + 1) * GEMM_BK * EF_EMB, offb, nxt + 4096, wave);
+            }
+            mma_kstep<LA, LB, 2, 2>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc);
+            __syncthreads();
+        }
+        // epilogue: rows of this lane = wm*64 + i*32 + 4*fq + (r&3) + 8*(r>>2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 64 + i * 32 + 4 * fq + (r & 3) + 8 * (r >> 2);
+                const float4* xp = reinterpret_cast<const float4*>(xs + rl * 12);
+                const float4 xa = xp[0], xb = xp[1], xc = xp[2];
+                const float x[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float g = ef_basic(x, w[j], bias[j]) > 0.f ? acc[i][j][r] : 0.f;
+#pragma unroll
+                    for (int f = 0; f < 12; ++f) dw[j][f] = fmaf(g, x[f], dw[j][f]);
+                    db[j] += g;
+                }
+            }
+        }
+    }
+    // combine the 4 partial sums per column (2 lane halves x 2 row waves) through LDS
+    __syncthreads();
+    float* red = smem;   // [4][13][128]
+    {
+        const int slot = wm * 2 + fq;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = wn * 64 + j * 32 + fr;
+#pragma unroll
+            for (int f = 0; f < 12; ++f) red[(slot * 13 + f) * 128 + c] = dw[j][f];
+            red[(slot * 13 + 12) * 128 + c] = db[j];
+        }
+    }
+    __syncthreads();
+    float* o = partials + (size_t)blockIdx.x * 1664;
+    for (int e = tid; e < 1664; e += 256) o[e] = (red[e] + red[1664 + e]) + (red[2 * 1664 + e] + red[3 * 1664 + e]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+static const int H_UNITS[6] = {1, 5, 16, 16, 1, 1};
+static const int H_CUM[7] = {0, 1, 6, 22, 38, 39, 40};
+
+bool embed_fused_supported(long long nr) { return nr > 0 && nr % 128 == 0; }
+
+static EmbTypes make_types(long long nr, int* total_wg) {
+    EmbTypes ty;
+    for (int t = 0; t <= 6; ++t) {
+        ty.row_begin[t] = nr * H_CUM[t];
+        ty.tile_begin[t] = (int)(ty.row_begin[t] / EF_TILE);
+    }
+    const long long total_steps = nr * 40 / GEMM_BK;
+    int spw = (int)((total_steps + 447) / 448);
+    if (spw < 4) spw = 4;
+    ty.steps_per_wg = spw;
+    int wg = 0;
+    for (int t = 0; t < 6; ++t) {
+        ty.wg_begin[t] = wg;
+        const long long st = nr * H_UNITS[t] / GEMM_BK;
+        wg += (int)((st + spw - 1) / spw);
+    }
+    ty.wg_begin[6] = wg;
+    *total_wg = wg;
+    return ty;
+}
+
+template <class K>
+static int set_lds(K kernel, size_t bytes, bool* done) {
+    if (*done) return 0;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { set_error("embed_fused: hipFuncSetAttribute", (int)e); return (int)e; }
+    *done = true;
+    return 0;
+}
+
+int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const float* W2, const float* b2, float* emb,
+                    long long nr, hipStream_t s) {
+    int nwg;
+    const EmbTypes ty = make_types(nr, &nwg);
+    const size_t lds = (size_t)(1664 + 4 * 4096) * sizeof(float);
+    static bool attr = false;
+    if (int e = set_lds(embed_fwd_fused_kernel, lds, &attr)) return e;
+    const int tiles = (int)(nr * 40 / EF_TILE);
+    ProfScope prof("embed_fwd_fused", 2.0 * nr * 40 * 128 * (128 + 12), 4.0 * nr * 40 * (12 + 128), s);
+    hipLaunchKernelGGL(embed_fwd_fused_kernel, dim3(tiles), dim3(256), lds, s, obs, W1, b1, W2, b2, emb, ty);
+    return launch_check("embed_fwd_fused");
+}
+
+// dW2 [6][128][128] (overwritten), dW1 [128][12] / db1 [128] (accumulated into, like unit_basic_bwd);
+// scratch: >= max(total_wg * 16384, 512 * 1664) floats
+int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const float* b1, const float* W2, float* dW2,
+                    float* dW1, float* db1, float* scratch, long long scratch_floats, long long nr, hipStream_t s) {
+    int nwg;
+    const EmbTypes ty = make_types(nr, &nwg);
+    if ((long long)nwg * EF_EMB * EF_EMB > scratch_floats || 512LL * 1664 > scratch_floats) {
+        set_error("embed_bwd_fused: scratch too small", 1040);
+        return 1040;
+    }
+    {
+        const size_t lds = (size_t)(4 * 4096) * sizeof(float);
+        static bool attr = false;
+        if (int e = set_lds(embed_bwd_dw2_kernel, lds, &attr)) return e;
+        {
+            ProfScope prof("embed_bwd_dw2", 2.0 * nr * 40 * 128 * (128 + 12), 4.0 * nr * 40 * (12 + 128), s);
+            hipLaunchKernelGGL(embed_bwd_dw2_kernel, dim3(nwg), dim3(256), lds, s, obs, demb, W1, b1, scratch, ty);
+        }
+        if (int e = launch_check("embed_bwd_dw2")) return e;
+        for (int t = 0; t < 6; ++t) {
+            const int cnt = ty.wg_begin[t + 1] - ty.wg_begin[t];
+            if (int e = splitk_reduce(scratch + (size_t)ty.wg_begin[t] * EF_EMB * EF_EMB, dW2 + (size_t)t * EF_EMB * EF_EMB, EF_EMB,
+                                      EF_EMB, EF_EMB, cnt, s))
+                return e;
+        }
+    }
+    {
+        const size_t lds = (size_t)(1536 + 4 * 4096) * sizeof(float);
+        static bool attr = false;
+        if (int e = set_lds(embed_bwd_dw1_kernel, lds, &attr)) return e;
+        const int tiles = (int)(nr * 40 / EF_TILE);
+        const int grid = tiles < 512 ? tiles : 512;
+        {
+            ProfScope prof("embed_bwd_dw1", 2.0 * nr * 40 * 128 * (128 + 24), 4.0 * nr * 40 * (12 + 128), s);
+            hipLaunchKernelGGL(embed_bwd_dw1_kernel, dim3(grid), dim3(256), lds, s, obs, demb, W1, b1, W2, scratch, ty, tiles);
+        }
+        if (int e = launch_check("embed_bwd_dw1")) return e;
+        if (int e = unit_basic_reduce(scratch, grid, dW1, db1, s)) return e;
+    }
+    return 0;
+}
+
+}  // namespace dc

@@ -20,6 +20,7 @@
 // k-major tiles sit as [k][rows] (fragment reads are lane-consecutive, staging is ds_write_b128).
 // Split-K (gridDim.z) accumulates with fp32 global atomics into a caller-zeroed / live C.
 #include "kernels.h"
+#include "gemm_tiles.h"
 
 namespace dc {
 
@@ -38,7 +39,6 @@ struct GemmArgs {
     float* slab;     // split-K with scratch: partial [split][M][N] slabs, reduced by splitk_reduce_kernel
 };
 
-enum { GEMM_BK = 32 };
 
 template <int BR, bool KM>
 struct TileLoader {
@@ -240,53 +240,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 // ---------------------------------------------------------------------------------------------------
 enum { EPI_PLAIN = 0, EPI_RELU = 1, EPI_MASK = 2, EPI_ACC = 3, EPI_SLAB = 4, EPI_ATOMIC = 5 };
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-template <int BR, bool KM>
-struct FastTile {
-    static constexpr int LDS_FLOATS = GEMM_BK * BR;
-    static constexpr int NI = BR / 32;     // DMA instructions per wave per tile (each moves 1 KB)
-
-    // per-lane source offsets (floats, relative to the operand at k = k_base) of this wave's NI DMA
-    // pieces; constant over the K loop.  EDGE: rows past the logical extent R re-read a valid row (their
-    // products only reach output rows/columns the epilogue never stores).
-    template <bool EDGE>
-    static __device__ __forceinline__ void src_offsets(size_t (&off)[NI], int ld, int r_base, int R, int wave, int lane) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int n = wave * NI + i;   // piece index: LDS floats [n*256, n*256+256)
-            if constexpr (!KM) {
-                const int row = n * 8 + (lane >> 3), pos = lane & 7;
-                int rg = r_base + row;
-                if constexpr (EDGE) rg = min(rg, R - 1);
-                off[i] = (size_t)rg * ld + 4 * (pos ^ ((row >> 1) & 7));
-            } else {
-                constexpr int V = BR / 4;              // 16-byte slots per k row
-                const int k = n * (64 / V) + lane / V, r4 = lane % V;
-                int cg = r_base + 4 * r4;
-                if constexpr (EDGE) cg = min(cg, ld - 4);   // stay inside the physical row
-                off[i] = (size_t)k * ld + cg;
-            }
-        }
-    }
-    static __device__ __forceinline__ void issue(const float* __restrict__ origin, const size_t (&off)[NI],
-                                                 float* __restrict__ S, int wave) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(origin + off[i]), (lptr_t)(S + (wave * NI + i) * 256), 16, 0, 0);
-    }
-    // the four k values (8j+4q+e, e = 0..3) of row r for this lane
-    static __device__ __forceinline__ float4 frag(const float* __restrict__ S, int r, int j, int q) {
-        if constexpr (!KM) {
-            return *reinterpret_cast<const float4*>(S + r * GEMM_BK + 4 * ((2 * j + q) ^ ((r >> 1) & 7)));
-        } else {
-            const float* s = S + (8 * j + 4 * q) * BR + r;
-            return make_float4(s[0], s[BR], s[2 * BR], s[3 * BR]);
-        }
-    }
-};
-
 template <int BM, int BN, bool A_KM, bool B_KM, int EPI, bool EDGE>
 __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs p) {
     using LA = FastTile<BM, A_KM>;
@@ -335,23 +288,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs p) {
         }
         const float* a_s = smem + (kt & 1) * STAGE_FL;
         const float* b_s = a_s + A_FL;
-#pragma unroll
-        for (int j = 0; j < GEMM_BK / 8; ++j) {
-            float4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = LA::frag(a_s, wm * (BM / 2) + i * 32 + fr, j, fq);
-#pragma unroll
-            for (int i = 0; i < TN; ++i) bf[i] = LB::frag(b_s, wn * (BN / 2) + i * 32 + fr, j, fq);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int jn = 0; jn < TN; ++jn) {
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[jn].x, acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[jn].y, acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[jn].z, acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[jn].w, acc[i][jn], 0, 0, 0);
-                }
-        }
+        mma_kstep<LA, LB, TM, TN>(a_s, b_s, wm * (BM / 2), wn * (BN / 2), fr, fq, acc);
         __syncthreads();
     }
 
@@ -430,6 +367,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     if (bias) acc += bias[n];
     float* c = C + (size_t)m * ldc + n;
     *c = accumulate ? *c + acc : acc;
+}
+
+int splitk_reduce(const float* slab, float* C, int M, int N, int ldc, int splits, hipStream_t s) {
+    const long long mn = (long long)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, s, slab, C, M, N, ldc, splits,
+                       (const float*)nullptr, 0);
+    return launch_check("splitk_reduce");
 }
 
 static float* g_scratch = nullptr;

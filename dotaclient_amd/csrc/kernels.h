@@ -43,6 +43,7 @@ int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int 
              int b_kmajor, const float* bias, int relu, const float* aux, int ldaux, int accumulate, int splits,
              hipStream_t stream);
 void gemm_set_scratch(float* p, long long floats);   // split-K slabs (nullptr -> atomics)
+int splitk_reduce(const float* slab, float* C, int M, int N, int ldc, int splits, hipStream_t s);   // C = sum_z slab[z]
 // embed.hip
 int unit_basic_fwd(const float* obs, const float* W1, const float* b1, float* basic, long long nr, hipStream_t s);
 int pool_env_fwd(const float* obs, const float* emb, const float* Wenv, const float* benv, float* xcat, uint8_t* amax,
@@ -53,6 +54,13 @@ int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, c
 int unit_basic_bwd(const float* obs, const float* dbasic, float* dW1, float* db1, float* scratch, long long nr,
                    hipStream_t s);
 int colsum(const float* X, int ld, long long rows, int cols, float* out, hipStream_t s);
+int unit_basic_reduce(const float* partials, int nblk, float* dW1, float* db1, hipStream_t s);   // partials [nblk][13][128]
+// embed_fused.hip (rows % 128 == 0: first embedding layer recomputed on chip, `basic` never stored)
+bool embed_fused_supported(long long nr);
+int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const float* W2, const float* b2, float* emb,
+                    long long nr, hipStream_t s);
+int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const float* b1, const float* W2, float* dW2,
+                    float* dW1, float* db1, float* scratch, long long scratch_floats, long long nr, hipStream_t s);
 // heads.hip
 int attn_logits(const float* headout, const float* emb, float* tu, long long nr, hipStream_t s);
 int attn_bwd_q(const float* dtu, const float* emb, float* dheadout, long long nr, hipStream_t s);

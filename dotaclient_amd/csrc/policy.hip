@@ -95,13 +95,18 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
     const long long NR = d->rows;
     const int H = d->hidden, G = d->cell == 0 ? 3 : 4, B = d->n_seq;
 
-    // per-unit embedding MLP (policy.py:100-126): layer 1 on VALU, layer 2 as six dense GEMMs
-    DC_TRY(unit_basic_fwd(obs, P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), w.f(DC_WS_BASIC), NR, s));
-    for (int t = 0; t < 6; ++t) {
-        const size_t ro = (size_t)NR * T_CUM[t] * EMBW;
-        DC_TRY(gemm_f32(w.f(DC_WS_BASIC) + ro, P.p(DC_P_UNIT_W) + (size_t)t * EMBW * EMBW, w.f(DC_WS_EMB) + ro,
-                        (int)(NR * T_UNITS[t]), EMBW, EMBW, EMBW, EMBW, EMBW, 0, 0, P.p(DC_P_UNIT_B) + t * EMBW, 0, nullptr, 0,
-                        0, 1, s));
+    // per-unit embedding MLP (policy.py:100-126).  Fused (rows % 128 == 0): layer 1 recomputed on chip inside
+    // the layer-2 product; otherwise layer 1 on VALU into `basic`, layer 2 as six dense GEMMs
+    if (embed_fused_supported(NR)) {
+        DC_TRY(embed_fwd_fused(obs, P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), P.p(DC_P_UNIT_W), P.p(DC_P_UNIT_B), w.f(DC_WS_EMB), NR, s));
+    } else {
+        DC_TRY(unit_basic_fwd(obs, P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), w.f(DC_WS_BASIC), NR, s));
+        for (int t = 0; t < 6; ++t) {
+            const size_t ro = (size_t)NR * T_CUM[t] * EMBW;
+            DC_TRY(gemm_f32(w.f(DC_WS_BASIC) + ro, P.p(DC_P_UNIT_W) + (size_t)t * EMBW * EMBW, w.f(DC_WS_EMB) + ro,
+                            (int)(NR * T_UNITS[t]), EMBW, EMBW, EMBW, EMBW, EMBW, 0, 0, P.p(DC_P_UNIT_B) + t * EMBW, 0, nullptr, 0,
+                            0, 1, s));
+        }
     }
     // env embedding + max-pools -> xcat (policy.py:97,102-136)
     DC_TRY(pool_env_fwd(obs, w.f(DC_WS_EMB), P.p(DC_P_ENV_W), P.p(DC_P_ENV_B), w.f(DC_WS_XCAT),
@@ -208,16 +213,23 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     DC_TRY(embed_scatter_bwd(obs, w.f(DC_WS_XCAT), w.f(DC_WS_DXCAT), w.f(DC_WS_DTU), w.f(DC_WS_HEADOUT), HO_LD,
                              reinterpret_cast<const uint8_t*>(w.base + w.off[DC_WS_AMAX]), w.f(DC_WS_DEMB),
                              Gd.p(DC_P_ENV_W), Gd.p(DC_P_ENV_B), Gd.p(DC_P_UNIT_B), w.f(DC_WS_SCRATCH), NR, s));
-    for (int t = 0; t < 6; ++t) {
-        const size_t ro = (size_t)NR * T_CUM[t] * EMBW;
-        const int rows_t = (int)(NR * T_UNITS[t]);
-        DC_TRY(gemm_f32(w.f(DC_WS_DEMB) + ro, w.f(DC_WS_BASIC) + ro, Gd.p(DC_P_UNIT_W) + (size_t)t * EMBW * EMBW, EMBW, EMBW,
-                        rows_t, EMBW, EMBW, EMBW, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s));
-        // dbasic (stored over the no-longer-needed emb buffer), relu-masked by basic
-        DC_TRY(gemm_f32(w.f(DC_WS_DEMB) + ro, P.p(DC_P_UNIT_W) + (size_t)t * EMBW * EMBW, w.f(DC_WS_EMB) + ro, rows_t, EMBW,
-                        EMBW, EMBW, EMBW, EMBW, 0, 1, nullptr, 0, w.f(DC_WS_BASIC) + ro, EMBW, 0, 1, s));
+    if (embed_fused_supported(NR)) {
+        // dW2 (split-K with the first layer regenerated as B operand) and dW1/db1 (d(basic) kept in the
+        // accumulators) - neither `basic` nor d(basic) exists in HBM on this path
+        DC_TRY(embed_bwd_fused(obs, w.f(DC_WS_DEMB), P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), P.p(DC_P_UNIT_W), Gd.p(DC_P_UNIT_W),
+                               Gd.p(DC_P_BASIC_W), Gd.p(DC_P_BASIC_B), w.f(DC_WS_SCRATCH), DC_SCRATCH_FLOATS, NR, s));
+    } else {
+        for (int t = 0; t < 6; ++t) {
+            const size_t ro = (size_t)NR * T_CUM[t] * EMBW;
+            const int rows_t = (int)(NR * T_UNITS[t]);
+            DC_TRY(gemm_f32(w.f(DC_WS_DEMB) + ro, w.f(DC_WS_BASIC) + ro, Gd.p(DC_P_UNIT_W) + (size_t)t * EMBW * EMBW, EMBW, EMBW,
+                            rows_t, EMBW, EMBW, EMBW, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s));
+            // dbasic (stored over the no-longer-needed emb buffer), relu-masked by basic
+            DC_TRY(gemm_f32(w.f(DC_WS_DEMB) + ro, P.p(DC_P_UNIT_W) + (size_t)t * EMBW * EMBW, w.f(DC_WS_EMB) + ro, rows_t, EMBW,
+                            EMBW, EMBW, EMBW, EMBW, 0, 1, nullptr, 0, w.f(DC_WS_BASIC) + ro, EMBW, 0, 1, s));
+        }
+        DC_TRY(unit_basic_bwd(obs, w.f(DC_WS_EMB), Gd.p(DC_P_BASIC_W), Gd.p(DC_P_BASIC_B), w.f(DC_WS_SCRATCH), NR, s));
     }
-    DC_TRY(unit_basic_bwd(obs, w.f(DC_WS_EMB), Gd.p(DC_P_BASIC_W), Gd.p(DC_P_BASIC_B), w.f(DC_WS_SCRATCH), NR, s));
     gemm_set_scratch(nullptr, 0);
     return 0;
 }
