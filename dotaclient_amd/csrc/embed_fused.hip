@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restr
                                                             const float* __restrict__ W1, const float* __restrict__ b1,
                                                             float* __restrict__ slab, EmbTypes ty) {
     using LT = FastTile<128, true>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x (A [32][128] | B [32][128])
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x (A [32][128] | B [32][128]) | unit records [2][384]
     constexpr int STAGE_FL = 2 * 4096;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -183,14 +183,20 @@ __global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restr
     LT::src_offsets<false>(offa, EF_EMB, 0, 128, wave, lane);
     const float* ga = demb + (size_t)(ty.row_begin[t] + s0 * GEMM_BK) * EF_EMB;
 
-    auto gen_b = [&](int s, float* b_s) {
-        const long long local = (s0 + s) * GEMM_BK + 16 * ghalf;   // wave-uniform
+    // unit records of a K step (32 rows x 12 floats) are staged in LDS two steps ahead: element e of the
+    // step = (row e/12, feature e%12); 384 elements over 256 threads
+    float* xs = smem + 2 * STAGE_FL;   // [2][384]
+    auto rec_ptr = [&](int s, int e) {
+        const int r = e / 12, f = e - r * 12;
+        return ef_record(obs, t, (s0 + min(s, ns - 1)) * GEMM_BK + r) + f;   // clamped: always a valid step
+    };
+    const int e0 = tid, e1 = 256 + (tid & 127);   // second element only for tid < 128
+    auto gen_b = [&](const float* xrow, float* b_s) {
 #pragma unroll 4
         for (int i = 0; i < 16; ++i) {
-            const float* xp = ef_record(obs, t, local + i);
-            float x[12];
-#pragma unroll
-            for (int f = 0; f < 12; ++f) x[f] = xp[f];
+            const float4* xp = reinterpret_cast<const float4*>(xrow + (16 * ghalf + i) * 12);   // wave-uniform: broadcast
+            const float4 xa = xp[0], xb = xp[1], xc = xp[2];
+            const float x[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
             b_s[(16 * ghalf + i) * 128 + gc] = fmaxf(ef_basic(x, w, bias), 0.f);
         }
     };
@@ -203,19 +209,26 @@ __global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (ns > 0) {
-        LT::issue(ga, offa, smem, wave);
-        gen_b(0, smem + 4096);
-    }
+    xs[e0] = *rec_ptr(0, e0);
+    xs[384 + e0] = *rec_ptr(1, e0);
+    if (tid < 128) { xs[e1] = *rec_ptr(0, e1); xs[384 + e1] = *rec_ptr(1, e1); }
+    LT::issue(ga, offa, smem, wave);
+    __syncthreads();
+    gen_b(xs, smem + 4096);
     __syncthreads();
     for (int s = 0; s < ns; ++s) {
         float* cur = smem + (s & 1) * STAGE_FL;
+        const float xn0 = *rec_ptr(s + 2, e0);                       // lands behind the MFMAs
+        const float xn1 = tid < 128 ? *rec_ptr(s + 2, e1) : 0.f;
         if (s + 1 < ns) {
             float* nxt = smem + ((s + 1) & 1) * STAGE_FL;
             LT::issue(ga + (size_t)(s + 1) * GEMM_BK * EF_EMB, offa, nxt, wave);
-            gen_b(s + 1, nxt + 4096);
+            gen_b(xs + ((s + 1) & 1) * 384, nxt + 4096);
         }
         mma_kstep<LT, LT, 2, 2>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc);
+        // records of step s were consumed by gen_b in the previous iteration: their slot takes step s+2
+        xs[(s & 1) * 384 + e0] = xn0;
+        if (tid < 128) xs[(s & 1) * 384 + e1] = xn1;
         __syncthreads();
     }
     float* out = slab + (size_t)wg * EF_EMB * EF_EMB;
@@ -392,7 +405,7 @@ int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const 
         return 1040;
     }
     {
-        const size_t lds = (size_t)(4 * 4096) * sizeof(float);
+        const size_t lds = (size_t)(4 * 4096 + 768) * sizeof(float);
         static bool attr = false;
         if (int e = set_lds(embed_bwd_dw2_kernel, lds, &attr)) return e;
         {
