@@ -23,6 +23,7 @@ struct RnnStepArgs {
     float* dc;             // [rows][H]  LSTM: total dL/dc_t
     float* dgx;            // [rows][G*H] grad wrt (W_ih x + b_ih)
     float* dgh;            // [rows][G*H] grad wrt (W_hh h + b_hh)   (GRU; LSTM: == dgx)
+    long long* dbg;        // DC_LSTM_TIMING=1: phase cycle sums of workgroup 0 (else nullptr)
 };
 
 // prof.hip (inert unless dc_profile_enable(1))

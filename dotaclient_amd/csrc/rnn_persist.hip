@@ -22,6 +22,8 @@
 //             sequences 2*hi and 2*hi+1.  c_t of a cell lives in that lane's registers throughout.
 //   backward: lane accumulates dh_rec[seq][u] over gate columns [2H*hi, 2H*hi+2H), halves are summed
 //             across the wave halves, same cell ownership; dc_{t+1} and f_{t+1} stay in registers.
+#include <stdio.h>
+#include <stdlib.h>
 #include <utility>
 #include "kernels.h"
 
@@ -53,15 +55,24 @@ __device__ __forceinline__ float fast_tanh(float x) {
 
 
 // ---------------------------------------------------------------------------------------------------
-// Hand-pipelined product phase.  hipcc (ROCm 7.2) sinks every LDS read to just before its first use
-// and waits for it at once (~100 exposed cycles per 16 MFMAs), and copies the weights it keeps in
-// AGPRs back to VGPRs with v_accvgpr_read + hazard nops before each MFMA.  So this phase is issued by
-// hand: a ring of RING float4 LDS reads stays in flight (each has RING-1 MFMA groups of cover, waited
-// for with a counted lgkmcnt), and the MFMAs take their B operand straight from AGPRs ("a"
-// constraint: MFMA A/B operands may be AGPRs on gfx950).  Every statement is asm volatile, so the
-// issue order - and with it the lgkmcnt arithmetic - is exactly the program order below; the compiler
-// emits no LDS/SMEM operation of its own between the first read and the last wait (checked in the
-// .s: the loop body has no s_load and no other ds_* before the epilogue).
+// Hand-issued product phase.
+//
+// A operand by BROADCAST: all 16 blocks of the 4x4x1 MFMA need the same four rows (sequences), so the
+// instruction's block broadcast (cbsz:4 abid:b = "every block takes its A from block b", verified on
+// gfx950 by tools/ubench/mfma_bcast.hip) lets ONE register carry 16 different k: lane 4b+i of register
+// j holds state[i][16j+b], and the 16 MFMAs abid = 0..15 walk k = 16j .. 16j+15.  The whole A operand
+// of a step is then H/16 (forward) or 2H/16 (backward) registers = 2 resp. 4 ds_read_b128 per lane
+// (state kept in LDS in that permuted order) instead of one read per 4 k.
+// B operand straight from AGPRs ("a" constraint: MFMA A/B operands may be AGPRs on gfx950) - hipcc
+// itself copies AGPR-resident weights back to VGPRs with v_accvgpr_read + hazard nops per MFMA.
+//
+// Issue budget (tools/ubench/mfma4x4.hip): the MFMA issues every 8.55 cycles whatever the register
+// files and chain count, and with one wave per SIMD every OTHER instruction placed between two MFMAs
+// costs ~5 cycles of its own - nothing hides behind a 2-pass MFMA.  The product phase therefore carries
+// the bare minimum: the 2-4 LDS reads, and one memory instruction per hook for next step's operands and
+// the previous step's results (32-bit byte offsets from uniform bases, no branches).
+// Every statement is asm volatile: issue order = program order, and the compiler emits no LDS/SMEM
+// operation of its own between the reads and their waits.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
@@ -71,58 +82,40 @@ template <int OFF>
 __device__ __forceinline__ void lds_read16(float4& dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
 }
-
-// forward group: one float4 of h (4 consecutive k) against this lane's two columns.
-// FIRST: accumulators start from the inline constant 0 (no VALU-written SrcC in front of an MFMA).
-// LAST : pads the MFMA -> VALU read hazard by hand (nothing after an asm is padded by the compiler).
-template <int WAIT, bool FIRST, bool LAST>
-__device__ __forceinline__ void fwd_mma_group(const float4& a, f32x4& a00, f32x4& a10, f32x4& a01, f32x4& a11,
-                                              float w00, float w10, float w01, float w11, float w02, float w12,
-                                              float w03, float w13) {
-    if constexpr (FIRST) {
-        asm volatile(
-            "s_waitcnt lgkmcnt(%16)\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, 0\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %1, %4, %9, 0\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %2, %5, %10, 0\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %3, %5, %11, 0\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %0, %6, %12, %0\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %1, %6, %13, %1\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %2, %7, %14, %2\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %3, %7, %15, %3"
-            : "=&v"(a00), "=&v"(a10), "=&v"(a01), "=&v"(a11)
-            : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "a"(w00), "a"(w10), "a"(w01), "a"(w11), "a"(w02), "a"(w12),
-              "a"(w03), "a"(w13), "i"(WAIT));
-    } else if constexpr (LAST) {
-        asm volatile(
-            "s_waitcnt lgkmcnt(%16)\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %1, %4, %9, %1\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %2, %5, %10, %2\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %3, %5, %11, %3\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %0, %6, %12, %0\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %1, %6, %13, %1\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %2, %7, %14, %2\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %3, %7, %15, %3\n\t"
-            "s_nop 7\n\ts_nop 7"
-            : "+v"(a00), "+v"(a10), "+v"(a01), "+v"(a11)
-            : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "a"(w00), "a"(w10), "a"(w01), "a"(w11), "a"(w02), "a"(w12),
-              "a"(w03), "a"(w13), "i"(WAIT));
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N));
+}
+// c0 (+)= bcast_b(a) * w0 ; c1 (+)= bcast_b(a) * w1.  ZERO: start from the inline constant 0.
+template <bool ZERO, int ABID>
+__device__ __forceinline__ void mfma_pair_same(f32x4& c0, f32x4& c1, float a, float w0, float w1) {
+    if constexpr (ZERO) {
+        asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %2, %3, 0 cbsz:4 abid:%5\n\tv_mfma_f32_4x4x1_16b_f32 %1, %2, %4, 0 cbsz:4 abid:%5"
+                     : "=&v"(c0), "=&v"(c1)
+                     : "v"(a), "a"(w0), "a"(w1), "i"(ABID));
     } else {
-        asm volatile(
-            "s_waitcnt lgkmcnt(%16)\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %1, %4, %9, %1\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %2, %5, %10, %2\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %3, %5, %11, %3\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %0, %6, %12, %0\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %1, %6, %13, %1\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %2, %7, %14, %2\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %3, %7, %15, %3"
-            : "+v"(a00), "+v"(a10), "+v"(a01), "+v"(a11)
-            : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "a"(w00), "a"(w10), "a"(w01), "a"(w11), "a"(w02), "a"(w12),
-              "a"(w03), "a"(w13), "i"(WAIT));
+        asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %2, %3, %0 cbsz:4 abid:%5\n\tv_mfma_f32_4x4x1_16b_f32 %1, %2, %4, %1 cbsz:4 abid:%5"
+                     : "+v"(c0), "+v"(c1)
+                     : "v"(a), "a"(w0), "a"(w1), "i"(ABID));
     }
+}
+// c0 (+)= bcast_b0(a) * w0 ; c1 (+)= bcast_b1(a) * w1   (two consecutive k of one column)
+// cbsz:3 = broadcast inside each group of 8 blocks (= each wave half): the halves keep different A
+template <bool ZERO, int ABID0, int ABID1>
+__device__ __forceinline__ void mfma_pair_seq(f32x4& c0, f32x4& c1, float a, float w0, float w1) {
+    if constexpr (ZERO) {
+        asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %2, %3, 0 cbsz:3 abid:%5\n\tv_mfma_f32_4x4x1_16b_f32 %1, %2, %4, 0 cbsz:3 abid:%6"
+                     : "=&v"(c0), "=&v"(c1)
+                     : "v"(a), "a"(w0), "a"(w1), "i"(ABID0), "i"(ABID1));
+    } else {
+        asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %2, %3, %0 cbsz:3 abid:%5\n\tv_mfma_f32_4x4x1_16b_f32 %1, %2, %4, %1 cbsz:3 abid:%6"
+                     : "+v"(c0), "+v"(c1)
+                     : "v"(a), "a"(w0), "a"(w1), "i"(ABID0), "i"(ABID1));
+    }
+}
+// MFMA -> VALU read hazard, padded by hand (nothing after an asm is padded by the compiler)
+__device__ __forceinline__ void mfma_tail_pad(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
 // lanes 32..63 of `lo` <-> lanes 0..31 of `hi_` (v_permlane32_swap): afterwards
@@ -133,103 +126,112 @@ __device__ __forceinline__ void half_swap(float& lo, float& hi_) {
     hi_ = __uint_as_float(r[1]);
 }
 
+// register j of the A operand = component (j & 3) of LDS read (j >> 2).  Components are named at the use
+// site (a sub-register reference, no instruction): copying them earlier would read the destination of a
+// ds_read the compiler does not know is still in flight.
+template <int J, int N>
+__device__ __forceinline__ const float& a_reg(const float4 (&r)[N]) {
+    if constexpr ((J & 3) == 0) return r[J >> 2].x;
+    else if constexpr ((J & 3) == 1) return r[J >> 2].y;
+    else if constexpr ((J & 3) == 2) return r[J >> 2].z;
+    else return r[J >> 2].w;
+}
+
+// position of state[seq][k] inside a broadcast-ordered LDS row set: lane 4b+i reads the NJ floats
+// [i][b][0..NJ) contiguously; k = 16j + b.  ROW = floats per sequence row (>= 16*NJ, padded).
+template <int NJ, int ROW>
+__device__ __forceinline__ int bcast_pos(int seq, int k) { return seq * ROW + (k & 15) * NJ + (k >> 4); }
+
 template <int H>
 struct FwdProduct {
-    static constexpr int NG = H / 4;      // float4 groups
-    static constexpr int RING = 8;
-    template <int G, class Slot>
-    static __device__ __forceinline__ void group(float4 (&av)[RING], f32x4 (&acc)[4], const float (&w0)[H],
-                                                 const float (&w1)[H], uint32_t addr, Slot& slot) {
-        constexpr int outstanding = (NG - G < RING) ? (NG - G) : RING;   // reads in flight before this group
-        fwd_mma_group<outstanding - 1, G == 0, G == NG - 1>(av[G % RING], acc[0], acc[1], acc[2], acc[3], w0[4 * G],
-                                                            w1[4 * G], w0[4 * G + 1], w1[4 * G + 1], w0[4 * G + 2],
-                                                            w1[4 * G + 2], w0[4 * G + 3], w1[4 * G + 3]);
-        if constexpr (G + RING < NG) lds_read16<16 * (G + RING)>(av[G % RING], addr);
-        slot(std::integral_constant<int, G>{});   // off-critical-path work issued in the shadow of the MFMAs
+    static constexpr int NJ = H / 16;        // A registers per step
+    static constexpr int HOOKS = H / 2;      // one hook per MFMA quad (2 k x 2 columns)
+    template <int K2, class Hook>            // k = 2*K2, 2*K2+1
+    static __device__ __forceinline__ void quad(const float4 (&r)[NJ / 4], f32x4 (&acc)[4], const float (&w0)[H],
+                                                const float (&w1)[H], Hook& hook) {
+        constexpr int k = 2 * K2;
+        if constexpr (k == 0) wait_lgkm<NJ / 4 - 1>();
+        if constexpr (NJ == 8 && k == 64) wait_lgkm<0>();
+        mfma_pair_same<k == 0, k & 15>(acc[0], acc[1], a_reg<(k >> 4)>(r), w0[k], w1[k]);
+        mfma_pair_same<k == 0, (k + 1) & 15>(acc[2], acc[3], a_reg<((k + 1) >> 4)>(r), w0[k + 1], w1[k + 1]);
+        hook(std::integral_constant<int, K2>{});
     }
-    template <class Slot, int... Gs>
-    static __device__ __forceinline__ void groups(float4 (&av)[RING], f32x4 (&acc)[4], const float (&w0)[H],
-                                                  const float (&w1)[H], uint32_t addr, Slot& slot,
-                                                  std::integer_sequence<int, Gs...>) {
-        (group<Gs>(av, acc, w0, w1, addr, slot), ...);
+    template <class Hook, int... Ks>
+    static __device__ __forceinline__ void quads(const float4 (&r)[NJ / 4], f32x4 (&acc)[4], const float (&w0)[H],
+                                                 const float (&w1)[H], Hook& hook, std::integer_sequence<int, Ks...>) {
+        (quad<Ks>(r, acc, w0, w1, hook), ...);
     }
-    template <int... Rs>
-    static __device__ __forceinline__ void prologue(float4 (&av)[RING], uint32_t addr, std::integer_sequence<int, Rs...>) {
-        (lds_read16<16 * Rs>(av[Rs], addr), ...);
-    }
-    template <class Slot>
+    // acc: chains [0] col0 even k, [1] col1 even k, [2] col0 odd k, [3] col1 odd k
+    template <class Hook>
     static __device__ __forceinline__ void run(f32x4 (&acc)[4], const float (&w0)[H], const float (&w1)[H], uint32_t addr,
-                                               Slot& slot) {
-        float4 av[RING];
-        prologue(av, addr, std::make_integer_sequence<int, RING>{});
-        groups(av, acc, w0, w1, addr, slot, std::make_integer_sequence<int, NG>{});
+                                               Hook& hook) {
+        float4 r[NJ / 4];
+        lds_read16<0>(r[0], addr);
+        if constexpr (NJ == 8) lds_read16<16>(r[1], addr);
+        quads(r, acc, w0, w1, hook, std::make_integer_sequence<int, H / 2>{});
+        mfma_tail_pad(acc[0], acc[1], acc[2], acc[3]);
     }
 };
-
-// backward group: one float4 of gate gradients (4 consecutive k), one column, four accumulator chains.
-template <int WAIT, bool FIRST, bool LAST>
-__device__ __forceinline__ void bwd_mma_group(const float4& a, f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, float w0,
-                                              float w1, float w2, float w3) {
-    if constexpr (FIRST) {
-        asm volatile(
-            "s_waitcnt lgkmcnt(%12)\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, 0\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, 0\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %2, %6, %10, 0\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %3, %7, %11, 0"
-            : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
-            : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "a"(w0), "a"(w1), "a"(w2), "a"(w3), "i"(WAIT));
-    } else if constexpr (LAST) {
-        asm volatile(
-            "s_waitcnt lgkmcnt(%12)\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %2, %6, %10, %2\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %3, %7, %11, %3\n\t"
-            "s_nop 7\n\ts_nop 7"
-            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
-            : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "a"(w0), "a"(w1), "a"(w2), "a"(w3), "i"(WAIT));
-    } else {
-        asm volatile(
-            "s_waitcnt lgkmcnt(%12)\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %1, %5, %9, %1\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %2, %6, %10, %2\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %3, %7, %11, %3"
-            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
-            : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "a"(w0), "a"(w1), "a"(w2), "a"(w3), "i"(WAIT));
-    }
-}
 
 template <int KH>
 struct BwdProduct {
-    static constexpr int NG = KH / 4;
-    static constexpr int RING = 16;       // 4 MFMAs per group -> deeper ring for the same cover (lgkmcnt <= 15)
-    template <int G, class Slot>
-    static __device__ __forceinline__ void group(float4 (&av)[RING], f32x4 (&acc)[4], const float (&w)[KH], uint32_t addr,
-                                                 Slot& slot) {
-        constexpr int outstanding = (NG - G < RING) ? (NG - G) : RING;
-        bwd_mma_group<outstanding - 1, G == 0, G == NG - 1>(av[G % RING], acc[0], acc[1], acc[2], acc[3], w[4 * G],
-                                                            w[4 * G + 1], w[4 * G + 2], w[4 * G + 3]);
-        if constexpr (G + RING < NG) lds_read16<16 * (G + RING)>(av[G % RING], addr);
-        slot(std::integral_constant<int, G>{});
+    // the two wave halves contract different k ranges, so the broadcast stays inside a half (cbsz:3):
+    // lane 4b'+i (b' = 0..7 within the half) of register j holds dgates[i][half*KH + 8j + b']
+    static constexpr int NJ = KH / 8;        // A registers per step
+    static constexpr int NR = NJ / 4;        // ds_read_b128 per step
+    static constexpr int HOOKS = KH / 4;     // one hook per MFMA quad (4 consecutive k)
+    template <int K4, class Hook>
+    static __device__ __forceinline__ void quad(const float4 (&r)[NR], f32x4 (&acc)[4], const float (&w)[KH], Hook& hook) {
+        constexpr int k = 4 * K4;
+        if constexpr (k % 32 == 0) wait_lgkm<NR - 1 - k / 32>();
+        mfma_pair_seq<k == 0, k & 7, (k + 1) & 7>(acc[0], acc[1], a_reg<(k >> 3)>(r), w[k], w[k + 1]);
+        mfma_pair_seq<k == 0, (k + 2) & 7, (k + 3) & 7>(acc[2], acc[3], a_reg<(k >> 3)>(r), w[k + 2], w[k + 3]);
+        hook(std::integral_constant<int, K4>{});
     }
-    template <class Slot, int... Gs>
-    static __device__ __forceinline__ void groups(float4 (&av)[RING], f32x4 (&acc)[4], const float (&w)[KH], uint32_t addr,
-                                                  Slot& slot, std::integer_sequence<int, Gs...>) {
-        (group<Gs>(av, acc, w, addr, slot), ...);
+    template <class Hook, int... Ks>
+    static __device__ __forceinline__ void quads(const float4 (&r)[NR], f32x4 (&acc)[4], const float (&w)[KH], Hook& hook,
+                                                 std::integer_sequence<int, Ks...>) {
+        (quad<Ks>(r, acc, w, hook), ...);
     }
     template <int... Rs>
-    static __device__ __forceinline__ void prologue(float4 (&av)[RING], uint32_t addr, std::integer_sequence<int, Rs...>) {
-        (lds_read16<16 * Rs>(av[Rs], addr), ...);
+    static __device__ __forceinline__ void reads(float4 (&r)[NR], uint32_t addr, std::integer_sequence<int, Rs...>) {
+        (lds_read16<16 * Rs>(r[Rs], addr), ...);
     }
-    template <class Slot>
-    static __device__ __forceinline__ void run(f32x4 (&acc)[4], const float (&w)[KH], uint32_t addr, Slot& slot) {
-        float4 av[RING];
-        prologue(av, addr, std::make_integer_sequence<int, RING>{});
-        groups(av, acc, w, addr, slot, std::make_integer_sequence<int, NG>{});
+    template <class Hook>
+    static __device__ __forceinline__ void run(f32x4 (&acc)[4], const float (&w)[KH], uint32_t addr, Hook& hook) {
+        float4 r[NR];
+        reads(r, addr, std::make_integer_sequence<int, NR>{});
+        quads(r, acc, w, hook, std::make_integer_sequence<int, KH / 4>{});
+        mfma_tail_pad(acc[0], acc[1], acc[2], acc[3]);
+    }
+    // position of gate column `col` (0..2*KH) inside a sequence row of the LDS image
+    static __device__ __forceinline__ int pos(int col) {
+        const int half = col / KH, kk = col - half * KH;
+        return half * KH + (kk & 7) * NJ + (kk >> 3);
     }
 };
+
+// The four sequence slots of a workgroup.  A slot whose sequence does not exist (ragged last
+// workgroup) or is empty duplicates the workgroup's first real sequence: it then computes and stores
+// bit-identical values to the same addresses, and no part of the step needs an "is this cell real"
+// branch.  Returns false if the workgroup has nothing to do.
+__device__ __forceinline__ bool map_slots(const RnnStepArgs& p, int b0, int (&bmap)[4], int& tmax) {
+    int first = -1;
+    tmax = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int b = b0 + q;
+        const int l = b < p.n_seq ? p.seq_len[b] : 0;
+        if (l > 0 && first < 0) first = b;
+        tmax = max(tmax, l);
+        bmap[q] = l > 0 ? b : -1;
+    }
+    if (first < 0) return false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (bmap[q] < 0) bmap[q] = first;
+    return true;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // forward.  gates[row][4H] holds W_ih x + b_ih on entry and the activated gates i,f,g,o on exit.
@@ -237,20 +239,22 @@ struct BwdProduct {
 // to hprev/cprev[row+1] (the shifted copies the weight-gradient GEMM and the backward read).
 //
 // Per step the critical path is product -> exchange -> gate maths -> h to LDS -> barrier.  Everything
-// else - next step's gate pre-activation loads and the PREVIOUS step's global stores (results wait in
-// registers for one step) - is issued from the slots between the MFMA groups, where it costs nothing.
-// Loads of cells past their sequence end read a clamped (valid) row instead of branching.  Steps are
-// unrolled by two with ping-pong registers, so the prefetched values are never copied (a copy would
-// have to wait for the loads, and with them for every younger store, at the end of each step).
+// else is issued from the hooks between MFMA pairs: the loads of next step's gate pre-activations and
+// the stores of the PREVIOUS step's results, which wait in registers for one step.  A cell past its
+// sequence end keeps re-storing its last results to the same rows (idempotent) and re-loading its last
+// row - no branches anywhere in the step.  Steps are unrolled by two with ping-pong registers, so the
+// prefetched values are never copied.
 // ---------------------------------------------------------------------------------------------------
-template <int H>
+template <int H, bool TIMING = false, int HOOKMODE = 0>   // HOOKMODE (timing experiments only): 1 no hook work, 2 loads only, 3 stores only
 __global__ __launch_bounds__(PersistCfg<H>::THREADS, 1) void lstm_fwd_persist_kernel(RnnStepArgs p) {
+    long long tm0 = 0, tm_prod = 0, tm_gate = 0, tm_bar = 0;   // TIMING: s_memtime phase sums (shader cycles)
     using C = PersistCfg<H>;
     __shared__ __attribute__((aligned(16))) float h_lds[2][4][C::HLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5;
     const int u = 32 * wave + (lane & 31);
-    const int b0 = blockIdx.x * 4;
+    int bmap[4], tmax;
+    if (!map_slots(p, blockIdx.x * 4, bmap, tmax)) return;
 
     // ---- weights: column (2*hi + m)*H + u of W_hh, all k, for m = 0,1 ------------------------------
     float w0[H], w1[H];
@@ -268,87 +272,88 @@ __global__ __launch_bounds__(PersistCfg<H>::THREADS, 1) void lstm_fwd_persist_ke
 #pragma unroll
     for (int g = 0; g < 4; ++g) bh[g] = p.bhh[g * H + u];
 
-    // ---- this lane's two cells ----------------------------------------------------------------------
+    // ---- this lane's two cells: sequences slot 2*hi and 2*hi+1 --------------------------------------
     int len[2];
     float c[2];
-    float* gp[2];     // &gates[row0][u]
-    size_t so[2];     // offset of [row0][u] in the [rows][H] state arrays
-    int tmax = 0;
+    unsigned goff[2], soff[2];          // element offsets of the CURRENT row: gates[row][u], state[row][u]
+    unsigned st_g[2], st_s[2], st_p[2]; // rows the deferred stores go to (frozen once the cell is done)
+    float sv[2][6], svp[2][2];          // deferred: i,f,g,o,c,h of the last finished step / c,h for row+1
+    auto init_cell = [&](auto CC) {
+        constexpr int cc = decltype(CC)::value;
+        const int b = hi ? bmap[2 + cc] : bmap[cc];
+        len[cc] = p.seq_len[b];
+        const unsigned row0 = (unsigned)p.seq_off[b];
+        goff[cc] = row0 * (4 * H) + u;
+        soff[cc] = row0 * H + u;
+        c[cc] = p.cprev[soff[cc]];
+        st_g[cc] = goff[cc]; st_s[cc] = soff[cc]; st_p[cc] = soff[cc];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int b = b0 + q;
-        tmax = max(tmax, b < p.n_seq ? p.seq_len[b] : 0);
-    }
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
-        const int b = b0 + 2 * hi + cc;
-        len[cc] = b < p.n_seq ? p.seq_len[b] : 0;
-        const size_t row0 = len[cc] > 0 ? (size_t)p.seq_off[b] : 0;
-        gp[cc] = p.gates + row0 * (size_t)(4 * H) + u;
-        so[cc] = row0 * H + u;
-        c[cc] = len[cc] > 0 ? p.cprev[so[cc]] : 0.f;
-    }
+        for (int q = 0; q < 6; ++q) sv[cc][q] = 0.f;      // step 0 "stores" these over rows it rewrites at step 1
+        svp[cc][0] = c[cc];                               // row 0 of cprev/hprev keeps c0/h0
+        svp[cc][1] = p.hprev[soff[cc]];
+    };
+    init_cell(std::integral_constant<int, 0>{});
+    init_cell(std::integral_constant<int, 1>{});
     // h0 -> LDS buffer 0
     for (int e = tid; e < 4 * H; e += C::THREADS) {
         const int q = e / H, j = e - q * H;
-        const int b = b0 + q;
-        const bool on = b < p.n_seq && p.seq_len[b] > 0;
-        h_lds[0][q][j] = on ? p.hprev[(size_t)p.seq_off[b] * H + j] : 0.f;
+        const int bq = q == 0 ? bmap[0] : (q == 1 ? bmap[1] : (q == 2 ? bmap[2] : bmap[3]));   // static indices: no scratch
+        (&h_lds[0][0][0])[bcast_pos<H / 16, C::HLD>(q, j)] = p.hprev[(size_t)p.seq_off[bq] * H + j];
     }
-    // gate pre-activations of step 0 (clamped rows: always a valid address)
     float xc[2][4], xn[2][4];
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) xc[cc][g] = gp[cc][g * H];
-    // results of the previous step, stored one step late
-    float sv[2][6];   // i, f, g, o, c, h
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-        for (int q = 0; q < 6; ++q) sv[cc][q] = 0.f;
+    for (int g = 0; g < 4; ++g) { xc[0][g] = p.gates[goff[0] + g * H]; xc[1][g] = p.gates[goff[1] + g * H]; }
     __syncthreads();
 
     // one step; xcur = this step's gate pre-activations, xnext receives the next step's
-    auto step = [&](const int t, float (&xcur)[2][4], float (&xnext)[2][4], auto CUR) {
+    // UNI: all four slots have the workgroup's full length (the training case: equal chunks) - every
+    // "is this cell still running" select folds away
+    auto step = [&](const int t, float (&xcur)[2][4], float (&xnext)[2][4], auto CUR, auto UNI_) {
         constexpr int cur = decltype(CUR)::value;
-        // slot work: loads for step t+1 (first: they get the whole product phase to land), then the
-        // stores of step t-1
-        auto slot = [&](auto G) {
-            constexpr int g = decltype(G)::value;
-            constexpr int per = FwdProduct<H>::NG / 16 > 0 ? FwdProduct<H>::NG / 16 : 1;   // 16 items over NG slots
-            if constexpr (g % per == 0 && g / per < 16) {
-                constexpr int it = g / per;
-                if constexpr (it < 8) {
-                    constexpr int cc = it >> 2, gg = it & 3;
-                    const int tl = min(t + 1, max(len[cc] - 1, 0));
-                    xnext[cc][gg] = gp[cc][(size_t)tl * (4 * H) + gg * H];
+        constexpr bool UNI = decltype(UNI_)::value;
+        // (indices of the per-cell integer state are compile-time constants everywhere - cells are visited
+        // through integral_constant, not loops: hipcc leaves loop-indexed copies of them in scratch)
+        const bool on1_0 = UNI ? t + 1 < tmax : t + 1 < len[0], on1_1 = UNI ? t + 1 < tmax : t + 1 < len[1];
+        const unsigned gnx[2] = {goff[0] + (on1_0 ? 4 * H : 0), goff[1] + (on1_1 ? 4 * H : 0)};
+        // all addresses of the step up front (they issue while the first LDS read is in flight); the
+        // hooks are then bare memory instructions with immediate offsets
+        const float* const lp[2] = {p.gates + gnx[0], p.gates + gnx[1]};
+        float* const gs[2] = {p.gates + st_g[0], p.gates + st_g[1]};
+        float* const cs[2] = {p.cseq + st_s[0], p.cseq + st_s[1]};
+        float* const hs[2] = {p.hseq + st_s[0], p.hseq + st_s[1]};
+        float* const cp[2] = {p.cprev + st_p[0], p.cprev + st_p[1]};
+        float* const hp[2] = {p.hprev + st_p[0], p.hprev + st_p[1]};
+        auto hook = [&](auto K) {
+            constexpr int k = decltype(K)::value;
+            constexpr int SP = FwdProduct<H>::HOOKS >= 52 ? 2 : 1;   // 25 items, one per SP hooks
+            if constexpr (k % SP == 0 && k / SP < 25) {
+                constexpr int it = k / SP;
+                if constexpr (it == 0) {
+                } else if constexpr (it <= 8) {
+                    constexpr int cc = (it - 1) >> 2, gg = (it - 1) & 3;
+                    if constexpr (HOOKMODE == 0 || HOOKMODE == 2) xnext[cc][gg] = lp[cc][gg * H];
+                    else xnext[cc][gg] = 0.f;
+                } else if constexpr (HOOKMODE == 1 || HOOKMODE == 2) {
+                } else if constexpr (it <= 16) {
+                    constexpr int cc = (it - 9) >> 2, gg = (it - 9) & 3;
+                    gs[cc][gg * H] = sv[cc][gg];
+                } else if constexpr (it <= 18) {
+                    *cs[it - 17] = sv[it - 17][4];
+                } else if constexpr (it <= 20) {
+                    *hs[it - 19] = sv[it - 19][5];
+                } else if constexpr (it <= 22) {
+                    *cp[it - 21] = svp[it - 21][0];
                 } else {
-                    constexpr int q = it - 8;
-                    constexpr int cc = q >> 2, part = q & 3;
-                    const int tp = t - 1;
-                    if (tp >= 0 && tp < len[cc]) {
-                        if constexpr (part < 2) {
-                            float* gt = gp[cc] + (size_t)tp * (4 * H);
-                            gt[(2 * part) * H] = sv[cc][2 * part];
-                            gt[(2 * part + 1) * H] = sv[cc][2 * part + 1];
-                        } else if constexpr (part == 2) {
-                            p.cseq[so[cc] + (size_t)tp * H] = sv[cc][4];
-                            p.hseq[so[cc] + (size_t)tp * H] = sv[cc][5];
-                        } else {
-                            if (tp + 1 < len[cc]) {
-                                p.cprev[so[cc] + (size_t)(tp + 1) * H] = sv[cc][4];
-                                p.hprev[so[cc] + (size_t)(tp + 1) * H] = sv[cc][5];
-                            }
-                        }
-                    }
+                    *hp[it - 23] = svp[it - 23][1];
                 }
             }
         };
 
         // ---- recurrent product: rows = the 4 sequences, this lane's two columns ----------------------
-        f32x4 pa[4];   // chains: [0] col0 even k, [1] col1 even k, [2] col0 odd k, [3] col1 odd k
-        FwdProduct<H>::run(pa, w0, w1, lds_addr(&h_lds[cur][lane & 3][0]), slot);
+        f32x4 pa[4];
+        if constexpr (TIMING) tm0 = __builtin_amdgcn_s_memtime();
+        FwdProduct<H>::run(pa, w0, w1, lds_addr(&h_lds[cur][lane & 3][(lane >> 2) * (H / 16)]), hook);
+        if constexpr (TIMING) { const long long x = __builtin_amdgcn_s_memtime(); tm_prod += x - tm0; tm0 = x; }
         f32x4 acc0 = pa[0] + pa[2], acc1 = pa[1] + pa[3];   // lanes hi=0: (i,f) of 4 sequences; hi=1: (g,o)
 
         // ---- cross-half exchange: afterwards every lane holds i,f,g,o of its own two cells ------------
@@ -360,44 +365,72 @@ __global__ __launch_bounds__(PersistCfg<H>::THREADS, 1) void lstm_fwd_persist_ke
             half_swap(y1, x1);   // y1 = f,             x1 = o
             ri[cc] = y0; rg[cc] = x0; rf[cc] = y1; ro[cc] = x1;
         }
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-            const bool on = t < len[cc];
+        auto cell = [&](auto CC, const bool on1c) {
+            constexpr int cc = decltype(CC)::value;
+            const bool on = UNI ? true : t < len[cc];
             const float ig = fast_sigmoid(xcur[cc][0] + (ri[cc] + bh[0]));
             const float fg = fast_sigmoid(xcur[cc][1] + (rf[cc] + bh[1]));
             const float gg = fast_tanh(xcur[cc][2] + (rg[cc] + bh[2]));
             const float og = fast_sigmoid(xcur[cc][3] + (ro[cc] + bh[3]));
             const float cn = fg * c[cc] + ig * gg;
             const float hn = og * fast_tanh(cn);
-            h_lds[cur ^ 1][2 * hi + cc][u] = on ? hn : 0.f;
+            (&h_lds[cur ^ 1][0][0])[bcast_pos<H / 16, C::HLD>(2 * hi + cc, u)] = on ? hn : 0.f;
             c[cc] = on ? cn : c[cc];
-            sv[cc][0] = ig; sv[cc][1] = fg; sv[cc][2] = gg; sv[cc][3] = og; sv[cc][4] = cn; sv[cc][5] = hn;
-        }
+            // results of an active step replace the deferred ones; a finished cell keeps its last set
+            sv[cc][0] = on ? ig : sv[cc][0]; sv[cc][1] = on ? fg : sv[cc][1]; sv[cc][2] = on ? gg : sv[cc][2];
+            sv[cc][3] = on ? og : sv[cc][3]; sv[cc][4] = on ? cn : sv[cc][4]; sv[cc][5] = on ? hn : sv[cc][5];
+            st_g[cc] = on ? goff[cc] : st_g[cc];
+            st_s[cc] = on ? soff[cc] : st_s[cc];
+            svp[cc][0] = on1c ? cn : svp[cc][0];
+            svp[cc][1] = on1c ? hn : svp[cc][1];
+            st_p[cc] = on1c ? soff[cc] + H : st_p[cc];
+            goff[cc] = gnx[cc];
+            soff[cc] += on1c ? H : 0;
+        };
+        cell(std::integral_constant<int, 0>{}, on1_0);
+        cell(std::integral_constant<int, 1>{}, on1_1);
+        if constexpr (TIMING) { const long long x = __builtin_amdgcn_s_memtime(); tm_gate += x - tm0; tm0 = x; }
         __syncthreads();
+        if constexpr (TIMING) { const long long x = __builtin_amdgcn_s_memtime(); tm_bar += x - tm0; }
     };
 
-    for (int t = 0; t < tmax; t += 2) {
-        step(t, xc, xn, std::integral_constant<int, 0>{});
-        if (t + 1 < tmax) step(t + 1, xn, xc, std::integral_constant<int, 1>{});
+    const bool uni = p.seq_len[bmap[0]] == tmax && p.seq_len[bmap[1]] == tmax && p.seq_len[bmap[2]] == tmax &&
+                     p.seq_len[bmap[3]] == tmax;
+    if (uni) {
+        for (int t = 0; t < tmax; t += 2) {
+            step(t, xc, xn, std::integral_constant<int, 0>{}, std::true_type{});
+            if (t + 1 < tmax) step(t + 1, xn, xc, std::integral_constant<int, 1>{}, std::true_type{});
+        }
+    } else {
+        for (int t = 0; t < tmax; t += 2) {
+            step(t, xc, xn, std::integral_constant<int, 0>{}, std::false_type{});
+            if (t + 1 < tmax) step(t + 1, xn, xc, std::integral_constant<int, 1>{}, std::false_type{});
+        }
     }
     // drain: the deferred stores of the last step
+    auto drain = [&](auto CC) {
+        constexpr int cc = decltype(CC)::value;
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
-        const int tp = tmax - 1;
-        if (tp >= 0 && tp < len[cc]) {
-            float* gt = gp[cc] + (size_t)tp * (4 * H);
-            gt[0] = sv[cc][0]; gt[H] = sv[cc][1]; gt[2 * H] = sv[cc][2]; gt[3 * H] = sv[cc][3];
-            p.cseq[so[cc] + (size_t)tp * H] = sv[cc][4];
-            p.hseq[so[cc] + (size_t)tp * H] = sv[cc][5];
-        }
+        for (int g = 0; g < 4; ++g) p.gates[st_g[cc] + g * H] = sv[cc][g];
+        p.cseq[st_s[cc]] = sv[cc][4];
+        p.hseq[st_s[cc]] = sv[cc][5];
+        p.cprev[st_p[cc]] = svp[cc][0];
+        p.hprev[st_p[cc]] = svp[cc][1];
+    };
+    drain(std::integral_constant<int, 0>{});
+    drain(std::integral_constant<int, 1>{});
+    if constexpr (TIMING) {
+        if (tid == 0 && blockIdx.x == 0 && p.dbg != nullptr) { p.dbg[0] = tm_prod; p.dbg[1] = tm_gate; p.dbg[2] = tm_bar; p.dbg[3] = tmax; }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // backward through time.  In: dh[row][H] = dL/dh_t from the layer above (heads), the forward's saved
 // gates / cseq / cprev.  Out: dgx[row][4H] = gradient w.r.t. the gate pre-activations (for an LSTM the
-// same tensor serves W_ih x + b_ih and W_hh h + b_hh).  Same slot discipline as the forward: the
-// operands of step t-1 are loaded, and the gate gradients of step t+1 stored, between the MFMA groups.
+// same tensor serves W_ih x + b_ih and W_hh h + b_hh).  Same hook discipline as the forward: the
+// operands of step t-1 are loaded, and the gate gradients of step t+1 stored, between the MFMA pairs.
+// A cell whose sequence is shorter than the workgroup's longest idles at its last row until the sweep
+// reaches it (stores there are overwritten by its first real step).
 // ---------------------------------------------------------------------------------------------------
 template <int H>
 __global__ __launch_bounds__(PersistCfg<H>::THREADS, 1) void lstm_bwd_persist_kernel(RnnStepArgs p) {
@@ -407,7 +440,8 @@ __global__ __launch_bounds__(PersistCfg<H>::THREADS, 1) void lstm_bwd_persist_ke
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5;
     const int u = 32 * wave + (lane & 31);
-    const int b0 = blockIdx.x * 4;
+    int bmap[4], tmax;
+    if (!map_slots(p, blockIdx.x * 4, bmap, tmax)) return;
 
     // ---- weights: W_hh[KH*hi + kk][u], kk = 0..KH-1 --------------------------------------------------
     float w[KH];
@@ -415,69 +449,62 @@ __global__ __launch_bounds__(PersistCfg<H>::THREADS, 1) void lstm_bwd_persist_ke
     for (int kk = 0; kk < KH; ++kk) w[kk] = p.Whh[(size_t)(KH * hi + kk) * H + u];
 
     int len[2];
-    const float* gp[2];
-    float* dgp[2];
-    size_t so[2];
-    int tmax = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int b = b0 + q;
-        tmax = max(tmax, b < p.n_seq ? p.seq_len[b] : 0);
-    }
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
-        const int b = b0 + 2 * hi + cc;
-        len[cc] = b < p.n_seq ? p.seq_len[b] : 0;
-        const size_t row0 = len[cc] > 0 ? (size_t)p.seq_off[b] : 0;
-        gp[cc] = p.gates + row0 * (size_t)(4 * H) + u;
-        dgp[cc] = p.dgx + row0 * (size_t)(4 * H) + u;
-        so[cc] = row0 * H + u;
-    }
-    for (int e = tid; e < 4 * C::GLD; e += C::THREADS) (&g_lds[0][0][0])[e] = 0.f;   // "step tmax" has no gradient
-
-    // per-cell carried state, the operands of the step being processed, and the next ones in flight
+    unsigned goff[2], soff[2], st_g[2];
     float dc_next[2] = {0.f, 0.f}, f_next[2] = {0.f, 0.f};
     float cur_v[2][7], nxt_v[2][7];   // i, f, g, o, c, c_prev, dh
-    float sv[2][4];                   // gate gradients of the previous iteration (step t+1), stored one step late
+    float sv[2][4];                   // gate gradients of the last finished step, stored one step late
+    auto init_cell = [&](auto CC) {
+        constexpr int cc = decltype(CC)::value;
+        const int b = hi ? bmap[2 + cc] : bmap[cc];
+        len[cc] = p.seq_len[b];
+        const unsigned row = (unsigned)p.seq_off[b] + (unsigned)min(tmax - 1, len[cc] - 1);
+        goff[cc] = row * (4 * H) + u;
+        soff[cc] = row * H + u;
+        st_g[cc] = goff[cc];
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
-        const int tl = max(min(tmax - 1, len[cc] - 1), 0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) cur_v[cc][g] = gp[cc][(size_t)tl * (4 * H) + g * H];
-        cur_v[cc][4] = p.cseq[so[cc] + (size_t)tl * H];
-        cur_v[cc][5] = p.cprev[so[cc] + (size_t)tl * H];
-        cur_v[cc][6] = p.dh[so[cc] + (size_t)tl * H];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) sv[cc][g] = 0.f;
-    }
+        for (int g = 0; g < 4; ++g) { cur_v[cc][g] = p.gates[goff[cc] + g * H]; sv[cc][g] = 0.f; }
+        cur_v[cc][4] = p.cseq[soff[cc]];
+        cur_v[cc][5] = p.cprev[soff[cc]];
+        cur_v[cc][6] = p.dh[soff[cc]];
+    };
+    init_cell(std::integral_constant<int, 0>{});
+    init_cell(std::integral_constant<int, 1>{});
+    for (int e = tid; e < 4 * C::GLD; e += C::THREADS) (&g_lds[0][0][0])[e] = 0.f;   // "step tmax" has no gradient
     __syncthreads();
 
-    auto step = [&](const int t, float (&cv)[2][7], float (&nv)[2][7], auto CUR) {
+    auto step = [&](const int t, float (&cv)[2][7], float (&nv)[2][7], auto CUR, auto UNI_) {
         constexpr int cur = decltype(CUR)::value;
-        auto slot = [&](auto G) {
-            constexpr int g = decltype(G)::value;
-            constexpr int per = BwdProduct<KH>::NG / 32 > 0 ? BwdProduct<KH>::NG / 32 : 1;   // 22 items over NG slots
-            if constexpr (g % per == 0 && g / per < 22) {
-                constexpr int it = g / per;
-                if constexpr (it < 14) {
-                    constexpr int cc = it / 7, q = it % 7;
-                    const int tl = max(min(t - 1, len[cc] - 1), 0);
-                    if constexpr (q < 4) nv[cc][q] = gp[cc][(size_t)tl * (4 * H) + q * H];
-                    else if constexpr (q == 4) nv[cc][4] = p.cseq[so[cc] + (size_t)tl * H];
-                    else if constexpr (q == 5) nv[cc][5] = p.cprev[so[cc] + (size_t)tl * H];
-                    else nv[cc][6] = p.dh[so[cc] + (size_t)tl * H];
+        constexpr bool UNI = decltype(UNI_)::value;
+        const bool dec0 = UNI ? t > 0 : (t < len[0] && t > 0), dec1 = UNI ? t > 0 : (t < len[1] && t > 0);   // row below is next
+        const unsigned gnx[2] = {goff[0] - (dec0 ? 4 * H : 0), goff[1] - (dec1 ? 4 * H : 0)};
+        const unsigned snx[2] = {soff[0] - (dec0 ? H : 0), soff[1] - (dec1 ? H : 0)};
+        const float* const lg[2] = {p.gates + gnx[0], p.gates + gnx[1]};
+        const float* const lc[2] = {p.cseq + snx[0], p.cseq + snx[1]};
+        const float* const lcp[2] = {p.cprev + snx[0], p.cprev + snx[1]};
+        const float* const ldh[2] = {p.dh + snx[0], p.dh + snx[1]};
+        float* const gs[2] = {p.dgx + st_g[0], p.dgx + st_g[1]};
+        auto hook = [&](auto K) {
+            constexpr int k = decltype(K)::value;
+            constexpr int SP = BwdProduct<KH>::HOOKS >= 48 ? 2 : 1;   // 23 items
+            if constexpr (k % SP == 0 && k / SP < 23) {
+                constexpr int it = k / SP;
+                if constexpr (it == 0) {
+                } else if constexpr (it <= 14) {
+                    constexpr int cc = (it - 1) / 7, q = (it - 1) % 7;
+                    if constexpr (q < 4) nv[cc][q] = lg[cc][q * H];
+                    else if constexpr (q == 4) nv[cc][4] = *lc[cc];
+                    else if constexpr (q == 5) nv[cc][5] = *lcp[cc];
+                    else nv[cc][6] = *ldh[cc];
                 } else {
-                    constexpr int q = it - 14;
-                    constexpr int cc = q >> 2, gg = q & 3;
-                    const int tp = t + 1;
-                    if (tp < len[cc]) dgp[cc][(size_t)tp * (4 * H) + gg * H] = sv[cc][gg];
+                    constexpr int cc = (it - 15) >> 2, gg = (it - 15) & 3;
+                    gs[cc][gg * H] = sv[cc][gg];
                 }
             }
         };
 
         // ---- dh_rec[seq][u] = sum_k dgates_{t+1}[seq][k] * W_hh[k][u], this half's k range ------------
         f32x4 pa[4];
-        BwdProduct<KH>::run(pa, w, lds_addr(&g_lds[cur][lane & 3][KH * hi]), slot);
+        BwdProduct<KH>::run(pa, w, lds_addr(&g_lds[cur][lane & 3][KH * hi + ((lane >> 2) & 7) * BwdProduct<KH>::NJ]), hook);
         const f32x4 acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
         float rec[2];
 #pragma unroll
@@ -487,39 +514,54 @@ __global__ __launch_bounds__(PersistCfg<H>::THREADS, 1) void lstm_bwd_persist_ke
             rec[cc] = y + x;
         }
 
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-            const bool on = t < len[cc];
-            const bool has_next = (t + 1) < len[cc];
+        auto cell = [&](auto CC) {
+            constexpr int cc = decltype(CC)::value;
+            const bool on = UNI ? true : t < len[cc];
+            const bool has_next = UNI ? (t + 1) < tmax : (t + 1) < len[cc];
             float dh = cv[cc][6];
-            if (has_next) dh += rec[cc];
+            dh += has_next ? rec[cc] : 0.f;
             const float ig = cv[cc][0], fg = cv[cc][1], gg = cv[cc][2], og = cv[cc][3];
             const float tc = fast_tanh(cv[cc][4]);
             float dcv = dh * og * (1.f - tc * tc);
-            if (has_next) dcv += dc_next[cc] * f_next[cc];
+            dcv += has_next ? dc_next[cc] * f_next[cc] : 0.f;
             const float di = dcv * gg * ig * (1.f - ig);
             const float df = dcv * cv[cc][5] * fg * (1.f - fg);
             const float dg = dcv * ig * (1.f - gg * gg);
             const float dO = dh * tc * og * (1.f - og);
+            // gate column g*H+u -> wave half (col / KH), position inside that half's broadcast-ordered block
             float* gl = &g_lds[cur ^ 1][2 * hi + cc][0];
-            gl[u] = on ? di : 0.f; gl[H + u] = on ? df : 0.f; gl[2 * H + u] = on ? dg : 0.f; gl[3 * H + u] = on ? dO : 0.f;
-            sv[cc][0] = di; sv[cc][1] = df; sv[cc][2] = dg; sv[cc][3] = dO;
-            if (on) { dc_next[cc] = dcv; f_next[cc] = fg; }
-        }
+            auto gpos = [&](int col) { return BwdProduct<KH>::pos(col); };
+            gl[gpos(u)] = on ? di : 0.f; gl[gpos(H + u)] = on ? df : 0.f;
+            gl[gpos(2 * H + u)] = on ? dg : 0.f; gl[gpos(3 * H + u)] = on ? dO : 0.f;
+            sv[cc][0] = on ? di : sv[cc][0]; sv[cc][1] = on ? df : sv[cc][1];
+            sv[cc][2] = on ? dg : sv[cc][2]; sv[cc][3] = on ? dO : sv[cc][3];
+            st_g[cc] = on ? goff[cc] : st_g[cc];
+            dc_next[cc] = on ? dcv : dc_next[cc];
+            f_next[cc] = on ? fg : f_next[cc];
+            goff[cc] = gnx[cc];
+            soff[cc] = snx[cc];
+        };
+        cell(std::integral_constant<int, 0>{});
+        cell(std::integral_constant<int, 1>{});
         __syncthreads();
     };
 
-    for (int t = tmax - 1; t >= 0; t -= 2) {
-        step(t, cur_v, nxt_v, std::integral_constant<int, 0>{});
-        if (t - 1 >= 0) step(t - 1, nxt_v, cur_v, std::integral_constant<int, 1>{});
+    const bool uni = p.seq_len[bmap[0]] == tmax && p.seq_len[bmap[1]] == tmax && p.seq_len[bmap[2]] == tmax &&
+                     p.seq_len[bmap[3]] == tmax;
+    if (uni) {
+        for (int t = tmax - 1; t >= 0; t -= 2) {
+            step(t, cur_v, nxt_v, std::integral_constant<int, 0>{}, std::true_type{});
+            if (t - 1 >= 0) step(t - 1, nxt_v, cur_v, std::integral_constant<int, 1>{}, std::true_type{});
+        }
+    } else {
+        for (int t = tmax - 1; t >= 0; t -= 2) {
+            step(t, cur_v, nxt_v, std::integral_constant<int, 0>{}, std::false_type{});
+            if (t - 1 >= 0) step(t - 1, nxt_v, cur_v, std::integral_constant<int, 1>{}, std::false_type{});
+        }
     }
     // drain the deferred stores of step 0
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
-        if (0 < len[cc]) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) dgp[cc][g * H] = sv[cc][g];
-        }
+    for (int g = 0; g < 4; ++g) { p.dgx[st_g[0] + g * H] = sv[0][g]; p.dgx[st_g[1] + g * H] = sv[1][g]; }
 }
 
 bool lstm_persist_supported(int H) { return H == 64 || H == 128; }
@@ -528,6 +570,22 @@ int lstm_forward_persist(RnnStepArgs a, int max_len, hipStream_t s) {
     const dim3 grid((a.n_seq + 3) / 4);
     ProfScope prof("lstm_fwd_persist", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len,
                    4.0 * a.n_seq * max_len * a.H * (2.0 * 4 + 4.0), s);
+    static long long* dbg = nullptr;
+    static const bool timing = [] { const char* e = getenv("DC_LSTM_TIMING"); return e && e[0] == '1'; }();
+    if (timing && a.H == 128) {   // debugging aid: per-phase cycle counts of workgroup 0, printed per launch
+        if (!dbg) (void)hipMalloc(&dbg, 64);
+        a.dbg = dbg;
+        static const int mode = [] { const char* e = getenv("DC_LSTM_HOOKMODE"); return e ? atoi(e) : 0; }();
+        if (mode == 1) hipLaunchKernelGGL((lstm_fwd_persist_kernel<128, true, 1>), grid, dim3(PersistCfg<128>::THREADS), 0, s, a);
+        else if (mode == 2) hipLaunchKernelGGL((lstm_fwd_persist_kernel<128, true, 2>), grid, dim3(PersistCfg<128>::THREADS), 0, s, a);
+        else if (mode == 3) hipLaunchKernelGGL((lstm_fwd_persist_kernel<128, true, 3>), grid, dim3(PersistCfg<128>::THREADS), 0, s, a);
+        else hipLaunchKernelGGL((lstm_fwd_persist_kernel<128, true>), grid, dim3(PersistCfg<128>::THREADS), 0, s, a);
+        long long h[4];
+        (void)hipMemcpy(h, dbg, 32, hipMemcpyDeviceToHost);
+        fprintf(stderr, "lstm_fwd timing: steps %lld  product %.0f  gates %.0f  barrier %.0f cycles/step\n", h[3],
+                (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3]);
+        return launch_check("lstm_forward_persist");
+    }
     if (a.H == 128) hipLaunchKernelGGL((lstm_fwd_persist_kernel<128>), grid, dim3(PersistCfg<128>::THREADS), 0, s, a);
     else if (a.H == 64) hipLaunchKernelGGL((lstm_fwd_persist_kernel<64>), grid, dim3(PersistCfg<64>::THREADS), 0, s, a);
     else { set_error("lstm_forward_persist: unsupported hidden size", 1011); return 1011; }
