@@ -63,6 +63,21 @@ def profile_report(lib):
     return out
 
 
+def pmc_traffic(path, kernel, workload_key):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (FETCH_SIZE x2 on gfx950 +
+    WRITE_SIZE, separate passes - MI355X_MICROARCH.md); None when the summary is missing, was taken on a
+    different workload, or does not hold the kernel."""
+    try:
+        with open(path) as f:
+            j = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if j.get('meta', {}).get('workload') not in (None, workload_key):
+        return None
+    k = j.get('kernels', {}).get(kernel + '_kernel')
+    return int(k['bytes']) if k else None
+
+
 def cpu_baseline(cell, hidden, layers, rollouts, seq_len, epochs, lr, ent, vf):
     """Times the CPU oracle (kind "port") on the same synthetic workload: one rollout pass + `epochs`
     epochs = one bench step.  Thread count: the best of a short sweep (torch CPU ops of this size get
@@ -112,6 +127,9 @@ def main():
     ap.add_argument('--seq-len', type=int, default=256)
     ap.add_argument('--epochs', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'pmc_traffic_latest.json'),
+                    help='per-kernel HBM bytes from the rocprofv3 PMC passes (tools/gpu_round.sh + tools/pmc_traffic.py); '
+                         'PMC counters cannot be read from inside the process, so `traffic` is taken from this file')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -186,7 +204,10 @@ def main():
         dom = regions[0]
         achieved = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
         roofline = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                    'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    'traffic': pmc_traffic(args.traffic_json, dom['kernel'], '%s-%d-%dx%d' % (args.cell, args.hidden, B, S)),
+                    'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, %s)' % os.path.relpath(args.traffic_json, REPO),
+                    'algorithmic_bytes_per_launch': dom['bytes'] / dom['launches'],
                     'avg_launch_us': round(dom['total_ms'] * 1e3 / dom['launches'], 3),
                     'flops_per_launch': dom['flops'] / dom['launches'],
                     'whole_step': {'flops_per_env_step': ffwd * (1 + 3 * E),

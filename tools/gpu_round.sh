@@ -1,0 +1,29 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, bench line, rocprofv3 kernel stats, HBM-traffic PMC passes.
+# Usage (from the repo root on the GPU box): bash tools/gpu_round.sh <tag> [skip_tests]
+TAG=${1:-vX}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+REPO=$(pwd)
+if [ -z "$2" ]; then
+  timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1
+  echo "pytest exit $?" >> $OUT/pytest_gpu.log
+  tail -3 $OUT/pytest_gpu.log
+fi
+timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+tail -c 1500 $OUT/bench.json
+# kernel-trace + stats of the same command (short: no CPU baseline inside the traced run)
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/$OUT/prof -o trace -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $REPO/$OUT/prof_bench.log 2>&1
+# PMC passes, each on its own (no trace domains besides kernel-trace)
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $REPO/$OUT/pmc_fetch -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $REPO/$OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $REPO/$OUT/pmc_write -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $REPO/$OUT/pmc_write.log 2>&1
+cd $REPO
+DB=$(find $OUT/prof -name '*.db' | head -1)
+[ -n "$DB" ] && python tools/rocpd_stats.py $DB $OUT/kernel_stats.csv
+python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json lstm-128-64x256 2>&1 | tail -15
+# keep the merge-back small: drop raw traces
+find $OUT/prof -name '*.db' -size +20M -delete
+find $OUT -name '*kernel_trace.csv' -size +20M -delete
+ls -la $OUT
