@@ -82,6 +82,11 @@ int rnn_backward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s);
 bool lstm_persist_supported(int H);
 int lstm_forward_persist(RnnStepArgs a, int max_len, hipStream_t s);
 int lstm_backward_persist(RnnStepArgs a, int max_len, hipStream_t s);
+// rnn_persist_valu.hip (same contract, one sequence per workgroup on the packed-f32 VALU: the low-latency
+// variant for batches of <= 2 sequences per CU; lstm_*_persist dispatch to it)
+bool lstm_persist_use_valu(int n_seq);
+int lstm_forward_valu(RnnStepArgs a, hipStream_t s);
+int lstm_backward_valu(RnnStepArgs a, hipStream_t s);
 // adam.hip
 int gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const int32_t* seg_gate, int n_seg, int max_seg_len,
                        float* param, float* grad, float* m, float* v, double* segsq, const int32_t* head_on,
