@@ -50,36 +50,42 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(AdamSegs sg, const flo
     if (threadIdx.x == 0) atomicAdd(&segsq[seg], (sh[0] + sh[1]) + (sh[2] + sh[3]));
 }
 
-// ctl[0] = clip coefficient, ctl[1] = ok flag (1.0 = apply the update)
-__global__ void clip_finalize_kernel(AdamSegs sg, const double* __restrict__ segsq, const int32_t* __restrict__ head_on,
-                                     const float* __restrict__ losses, float* __restrict__ norms_out,
-                                     float* __restrict__ ctl, int32_t* __restrict__ seg_step,
-                                     int32_t* __restrict__ status, float max_norm, float vf_coef) {
-    if (threadIdx.x != 0) return;
-    double sum_norm = 0.0, tot_sq = 0.0;
-    int n_act = 0;
-    for (int s = 0; s < sg.n_seg; ++s) {
+// ctl[0] = clip coefficient, ctl[1] = ok flag (1.0 = apply the update).  One wave: lane s owns segment s
+// (34 named parameters; the loop covers more), sums in the segment order of the reference via wave_sum.
+__global__ __launch_bounds__(64) void clip_finalize_kernel(AdamSegs sg, const double* __restrict__ segsq,
+                                                           const int32_t* __restrict__ head_on,
+                                                           const float* __restrict__ losses, float* __restrict__ norms_out,
+                                                           float* __restrict__ ctl, int32_t* __restrict__ seg_step,
+                                                           int32_t* __restrict__ status, float max_norm, float vf_coef) {
+    const int lane = threadIdx.x;
+    double sum_norm = 0.0, tot_sq = 0.0, n_act = 0.0;
+    for (int s = lane; s < sg.n_seg; s += 64) {
         if (!seg_active(sg, s, head_on, vf_coef)) continue;
         const float nrm = (float)sqrt(segsq[s]);
         sum_norm += (double)nrm;
         tot_sq += (double)nrm * (double)nrm;
-        ++n_act;
+        n_act += 1.0;
     }
-    const float unclipped = (float)(sum_norm / (double)n_act);
+    sum_norm = wave_sum(sum_norm);
+    tot_sq = wave_sum(tot_sq);
+    n_act = wave_sum(n_act);
+    const float unclipped = (float)(sum_norm / n_act);
     const float total = (float)sqrt(tot_sq);
     float coef = max_norm / (total + 1e-6f);
     if (coef > 1.f) coef = 1.f;
-    norms_out[0] = unclipped;
-    norms_out[1] = unclipped * coef;   // every per-parameter norm scales by the same coefficient
     const bool loss_nan = losses[0] != losses[0];
     const bool norm_nan = unclipped != unclipped;
     int st = 0;
     if (loss_nan) st = 1; else if (norm_nan) st = 2;
-    *status = st;
-    ctl[0] = coef;
-    ctl[1] = st == 0 ? 1.f : 0.f;
+    if (lane == 0) {
+        norms_out[0] = unclipped;
+        norms_out[1] = unclipped * coef;   // every per-parameter norm scales by the same coefficient
+        *status = st;
+        ctl[0] = coef;
+        ctl[1] = st == 0 ? 1.f : 0.f;
+    }
     if (st == 0)
-        for (int s = 0; s < sg.n_seg; ++s)
+        for (int s = lane; s < sg.n_seg; s += 64)
             if (seg_active(sg, s, head_on, vf_coef)) seg_step[s] += 1;
 }
 
@@ -95,11 +101,18 @@ __global__ __launch_bounds__(256) void adam_update_kernel(AdamSegs sg, float* __
     if (ctl[1] == 0.f) return;                                   // NaN guard tripped: leave everything alone
     if (!seg_active(sg, seg, head_on, vf_coef)) return;          // grad is None in the reference
     const float coef = ctl[0];
-    const int step = seg_step[seg];                              // already incremented for this update
-    const double bc1 = 1.0 - pow(beta1, (double)step);
-    const double bc2 = 1.0 - pow(beta2, (double)step);
-    const float step_size = (float)(lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
+    // bias corrections: two double pow() - once per block, not once per thread
+    __shared__ float sh_bc[2];
+    if (threadIdx.x == 0) {
+        const int step = seg_step[seg];                          // already incremented for this update
+        const double bc1 = 1.0 - pow(beta1, (double)step);
+        const double bc2 = 1.0 - pow(beta2, (double)step);
+        sh_bc[0] = (float)(lr / bc1);
+        sh_bc[1] = (float)sqrt(bc2);
+    }
+    __syncthreads();
+    const float step_size = sh_bc[0];
+    const float bc2_sqrt = sh_bc[1];
     const float w1 = (float)(1.0 - beta1), b2 = (float)beta2, w2 = (float)(1.0 - beta2);
     const long long base = sg.seg_off[seg];
     const long long c1 = min(len, c0 + ADAM_CHUNK);

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void unit_basic_fwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void pool_env_fwd_kernel(const float* __restrict__ obs, const float* __restrict__ emb,
                                                            const float* __restrict__ Wenv, const float* __restrict__ benv,
                                                            float* __restrict__ xcat, uint8_t* __restrict__ amax,
-                                                           long long nr) {
+                                                           long long nr, int residual) {
+    // residual != 0: embed_fwd_fused's epilogue already pooled every type except eh (t = 1)
     const int c = threadIdx.x & 127;
     const int sub = threadIdx.x >> 7;
     const float w0 = Wenv[c * 3 + 0], w1 = Wenv[c * 3 + 1], w2 = Wenv[c * 3 + 2], be = benv[c];
@@ -101,6 +102,19 @@ __global__ __launch_bounds__(256) void pool_env_fwd_kernel(const float* __restri
         const float* e = obs + n * OBS_DIM;
         float* xo = xcat + n * XCAT;
         xo[c] = fmaxf(fmaf(e[2], w2, fmaf(e[1], w1, fmaf(e[0], w0, be))), 0.f);  // policy.py:97
+        if (residual) {
+            const float* p = emb + (nr * c_type_cum[1] + n * 5) * EMB + c;
+            float m = p[0];
+            int am = 0;
+#pragma unroll
+            for (int u = 1; u < 5; ++u) {
+                const float v = p[(long long)u * EMB];
+                if (v > m) { m = v; am = u; }
+            }
+            amax[(n * 3 + 0) * EMB + c] = (uint8_t)am;
+            xo[2 * EMB + c] = m;
+            continue;
+        }
         float enh_max = 0.f;
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
@@ -295,9 +309,9 @@ int unit_basic_fwd(const float* obs, const float* W1, const float* b1, float* ba
 }
 
 int pool_env_fwd(const float* obs, const float* emb, const float* Wenv, const float* benv, float* xcat, uint8_t* amax,
-                 long long nr, hipStream_t s) {
+                 long long nr, int residual, hipStream_t s) {
     hipLaunchKernelGGL(pool_env_fwd_kernel, dim3(grid_for(nr, 2, 256 * 16)), dim3(256), 0, s, obs, emb, Wenv, benv, xcat,
-                       amax, nr);
+                       amax, nr, residual);
     return launch_check("pool_env_fwd");
 }
 

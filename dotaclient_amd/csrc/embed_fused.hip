@@ -62,6 +62,7 @@ __device__ __forceinline__ float ef_basic(const float (&x)[12], const float (&w)
 __global__ __launch_bounds__(256) void embed_fwd_fused_kernel(const float* __restrict__ obs, const float* __restrict__ W1,
                                                               const float* __restrict__ b1, const float* __restrict__ W2,
                                                               const float* __restrict__ b2, float* __restrict__ emb,
+                                                              float* __restrict__ xcat, uint8_t* __restrict__ amax,
                                                               EmbTypes ty) {
     using LT = FastTile<128, false>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -135,7 +136,14 @@ __global__ __launch_bounds__(256) void embed_fwd_fused_kernel(const float* __res
         __syncthreads();
     }
 
+    // Epilogue: emb = acc + b2, and the max-pool over the units of an env-step (policy.py:102-127) straight from
+    // the accumulators - the 335 MB re-read of emb by a separate pooling kernel is gone.  A 32x32 accumulator
+    // tile holds rows 8*(r>>2) + 4*fq + (r&3): the 16 units of a step (types anh/enh, U = 16, tiles start on
+    // step boundaries) are 8 registers of this lane + 8 of lane^32.  "First maximum wins" like torch.max.
+    // Types with one unit (ah, ath) copy through; eh (U = 5, steps straddle tiles) and the env embedding are
+    // left to pool_env_fwd's residual pass; eth is never pooled (policy.py:127 pools enh twice instead).
     const float* b2t = b2 + t * EF_EMB;
+    const long long lrow0 = row0 - ty.row_begin[t];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -143,8 +151,41 @@ __global__ __launch_bounds__(256) void embed_fwd_fused_kernel(const float* __res
             const int col = wn * 64 + j * 32 + fr;
             const float bv = b2t[col];
             float* c = emb + (size_t)(row0 + wm * 64 + i * 32 + 4 * fq) * EF_EMB + col;
+            float v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c[(size_t)((r & 3) + 8 * (r >> 2)) * EF_EMB] = acc[i][j][r] + bv;
+            for (int r = 0; r < 16; ++r) {
+                v[r] = acc[i][j][r] + bv;
+                c[(size_t)((r & 3) + 8 * (r >> 2)) * EF_EMB] = v[r];
+            }
+            if (xcat == nullptr) continue;
+            const long long lr = lrow0 + wm * 64 + i * 32;           // type-local row of this tile's row 0
+            if (t == 2 || t == 3) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {                         // rows 16h..16h+15 = one env-step
+                    float m = v[8 * h];
+                    int am = 4 * fq;
+#pragma unroll
+                    for (int rr = 1; rr < 8; ++rr) {
+                        const float x = v[8 * h + rr];
+                        const int u = (rr & 3) + 8 * (rr >> 2) + 4 * fq;
+                        if (x > m) { m = x; am = u; }
+                    }
+                    const float pm = __shfl_xor(m, 32, 64);
+                    const int pam = __shfl_xor(am, 32, 64);
+                    if (pm > m || (pm == m && pam < am)) { m = pm; am = pam; }
+                    if (fq == h) {
+                        const long long n = (lr >> 4) + h;
+                        float* xo = xcat + n * 896;
+                        xo[(1 + t) * EF_EMB + col] = m;
+                        if (t == 3) xo[6 * EF_EMB + col] = m;         // policy.py:127: the "eth" slot holds the enh max
+                        amax[(n * 3 + (t - 1)) * EF_EMB + col] = (uint8_t)am;
+                    }
+                }
+            } else if (t == 0 || t == 4) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    xcat[(lr + (r & 3) + 8 * (r >> 2) + 4 * fq) * 896 + (1 + t) * EF_EMB + col] = v[r];
+            }
         }
 }
 
@@ -382,7 +423,7 @@ static int set_lds(K kernel, size_t bytes, bool* done) {
 }
 
 int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const float* W2, const float* b2, float* emb,
-                    long long nr, hipStream_t s) {
+                    float* xcat, uint8_t* amax, long long nr, hipStream_t s) {
     int nwg;
     const EmbTypes ty = make_types(nr, &nwg);
     const size_t lds = (size_t)(1664 + 4 * 4096) * sizeof(float);
@@ -390,7 +431,7 @@ int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const fl
     if (int e = set_lds(embed_fwd_fused_kernel, lds, &attr)) return e;
     const int tiles = (int)(nr * 40 / EF_TILE);
     ProfScope prof("embed_fwd_fused", 2.0 * nr * 40 * 128 * (128 + 12), 4.0 * nr * 40 * (12 + 128), s);
-    hipLaunchKernelGGL(embed_fwd_fused_kernel, dim3(tiles), dim3(256), lds, s, obs, W1, b1, W2, b2, emb, ty);
+    hipLaunchKernelGGL(embed_fwd_fused_kernel, dim3(tiles), dim3(256), lds, s, obs, W1, b1, W2, b2, emb, xcat, amax, ty);
     return launch_check("embed_fwd_fused");
 }
 
@@ -413,12 +454,7 @@ int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const 
             hipLaunchKernelGGL(embed_bwd_dw2_kernel, dim3(nwg), dim3(256), lds, s, obs, demb, W1, b1, scratch, ty);
         }
         if (int e = launch_check("embed_bwd_dw2")) return e;
-        for (int t = 0; t < 6; ++t) {
-            const int cnt = ty.wg_begin[t + 1] - ty.wg_begin[t];
-            if (int e = splitk_reduce(scratch + (size_t)ty.wg_begin[t] * EF_EMB * EF_EMB, dW2 + (size_t)t * EF_EMB * EF_EMB, EF_EMB,
-                                      EF_EMB, EF_EMB, cnt, s))
-                return e;
-        }
+        if (int e = splitk_reduce_grouped(scratch, dW2, EF_EMB, EF_EMB, 6, ty.wg_begin, s)) return e;   // one launch, six types
     }
     {
         const size_t lds = (size_t)(1536 + 4 * 4096) * sizeof(float);

@@ -369,6 +369,41 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *c = accumulate ? *c + acc : acc;
 }
 
+// grouped form: group g (blockIdx.y) owns slabs [begin[g], begin[g+1]) and writes C + g*M*N (dense M x N)
+struct SplitkGroups { int begin[9]; };
+__global__ __launch_bounds__(256) void splitk_reduce_grouped_kernel(const float* __restrict__ slab, float* __restrict__ C,
+                                                                    int mn, SplitkGroups gr) {
+    __shared__ float sh[256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int g = blockIdx.y;
+    const int idx = blockIdx.x * 64 + tx;
+    const float* sl = slab + (size_t)gr.begin[g] * mn;
+    const int splits = gr.begin[g + 1] - gr.begin[g];
+    float acc = 0.f;
+    if (idx < mn) {
+        int z = ty;
+        for (; z + 12 < splits; z += 16) {
+            const float a0 = sl[(size_t)z * mn + idx], a1 = sl[(size_t)(z + 4) * mn + idx];
+            const float a2 = sl[(size_t)(z + 8) * mn + idx], a3 = sl[(size_t)(z + 12) * mn + idx];
+            acc += (a0 + a1) + (a2 + a3);
+        }
+        for (; z < splits; z += 4) acc += sl[(size_t)z * mn + idx];
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (ty != 0 || idx >= mn) return;
+    C[(size_t)g * mn + idx] = (sh[tx] + sh[64 + tx]) + (sh[128 + tx] + sh[192 + tx]);
+}
+
+int splitk_reduce_grouped(const float* slab, float* C, int M, int N, int n_groups, const int* begin, hipStream_t s) {
+    if (n_groups > 8) { set_error("splitk_reduce_grouped: more than 8 groups", 1050); return 1050; }
+    SplitkGroups gr;
+    for (int i = 0; i <= n_groups; ++i) gr.begin[i] = begin[i];
+    const int mn = M * N;
+    hipLaunchKernelGGL(splitk_reduce_grouped_kernel, dim3((unsigned)((mn + 63) / 64), n_groups), dim3(256), 0, s, slab, C, mn, gr);
+    return launch_check("splitk_reduce_grouped");
+}
+
 int splitk_reduce(const float* slab, float* C, int M, int N, int ldc, int splits, hipStream_t s) {
     const long long mn = (long long)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, s, slab, C, M, N, ldc, splits,

@@ -45,10 +45,12 @@ int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int 
              hipStream_t stream);
 void gemm_set_scratch(float* p, long long floats);   // split-K slabs (nullptr -> atomics)
 int splitk_reduce(const float* slab, float* C, int M, int N, int ldc, int splits, hipStream_t s);   // C = sum_z slab[z]
+// n_groups (<= 8) independent reductions in one launch: C[g] (dense M x N) = sum of slabs [begin[g], begin[g+1])
+int splitk_reduce_grouped(const float* slab, float* C, int M, int N, int n_groups, const int* begin, hipStream_t s);
 // embed.hip
 int unit_basic_fwd(const float* obs, const float* W1, const float* b1, float* basic, long long nr, hipStream_t s);
 int pool_env_fwd(const float* obs, const float* emb, const float* Wenv, const float* benv, float* xcat, uint8_t* amax,
-                 long long nr, hipStream_t s);
+                 long long nr, int residual, hipStream_t s);
 int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, const float* dtu, const float* q, int ldq,
                       const uint8_t* amax, float* demb, float* dWenv, float* dbenv, float* db2, float* scratch,
                       long long nr, hipStream_t s);
@@ -58,8 +60,10 @@ int colsum(const float* X, int ld, long long rows, int cols, float* out, hipStre
 int unit_basic_reduce(const float* partials, int nblk, float* dW1, float* db1, hipStream_t s);   // partials [nblk][13][128]
 // embed_fused.hip (rows % 128 == 0: first embedding layer recomputed on chip, `basic` never stored)
 bool embed_fused_supported(long long nr);
+// xcat/amax != nullptr: the max-pools of the one-unit and 16-unit types are produced by the epilogue (then call
+// pool_env_fwd with residual = 1 for the env embedding and the 5-unit type only)
 int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const float* W2, const float* b2, float* emb,
-                    long long nr, hipStream_t s);
+                    float* xcat, uint8_t* amax, long long nr, hipStream_t s);
 int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const float* b1, const float* W2, float* dW2,
                     float* dW1, float* db1, float* scratch, long long scratch_floats, long long nr, hipStream_t s);
 // heads.hip

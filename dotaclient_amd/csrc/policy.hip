@@ -97,8 +97,11 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
 
     // per-unit embedding MLP (policy.py:100-126).  Fused (rows % 128 == 0): layer 1 recomputed on chip inside
     // the layer-2 product; otherwise layer 1 on VALU into `basic`, layer 2 as six dense GEMMs
-    if (embed_fused_supported(NR)) {
-        DC_TRY(embed_fwd_fused(obs, P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), P.p(DC_P_UNIT_W), P.p(DC_P_UNIT_B), w.f(DC_WS_EMB), NR, s));
+    uint8_t* amax = reinterpret_cast<uint8_t*>(w.base + w.off[DC_WS_AMAX]);
+    const bool fused = embed_fused_supported(NR);
+    if (fused) {
+        DC_TRY(embed_fwd_fused(obs, P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), P.p(DC_P_UNIT_W), P.p(DC_P_UNIT_B), w.f(DC_WS_EMB),
+                               w.f(DC_WS_XCAT), amax, NR, s));
     } else {
         DC_TRY(unit_basic_fwd(obs, P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), w.f(DC_WS_BASIC), NR, s));
         for (int t = 0; t < 6; ++t) {
@@ -109,8 +112,8 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
         }
     }
     // env embedding + max-pools -> xcat (policy.py:97,102-136)
-    DC_TRY(pool_env_fwd(obs, w.f(DC_WS_EMB), P.p(DC_P_ENV_W), P.p(DC_P_ENV_B), w.f(DC_WS_XCAT),
-                        reinterpret_cast<uint8_t*>(w.base + w.off[DC_WS_AMAX]), NR, s));
+    // (fused: only the env embedding and the 5-unit type are left to do - the GEMM epilogue pooled the rest)
+    DC_TRY(pool_env_fwd(obs, w.f(DC_WS_EMB), P.p(DC_P_ENV_W), P.p(DC_P_ENV_B), w.f(DC_WS_XCAT), amax, NR, fused ? 1 : 0, s));
     // pre-rnn projection (policy.py:138)
     DC_TRY(gemm_f32(w.f(DC_WS_XCAT), P.p(DC_P_PRE_W), w.f(DC_WS_PRE), (int)NR, PREW, XCATW, XCATW, XCATW, PREW, 0, 0,
                     P.p(DC_P_PRE_B), 1, nullptr, 0, 0, 1, s));
