@@ -7,15 +7,21 @@
 // The unfused path (embed.hip + gemm.hip) materialises `basic` (512 B per unit, 335 MB per 64x256
 // batch), reads it back in the forward GEMM, twice more in the backward, and writes + re-reads the
 // equally large d(basic).  Here the K = 12 layer is recomputed from the 48-byte unit record wherever
-// it is needed - 12 FMAs per element, a few percent of the MFMA work next to it:
-//   embed_fwd_fused : A tile (basic) generated on the VALU straight into the swizzled LDS image of the
-//                     fast GEMM, B tile (W2_t) by DMA, exact-fp32 MFMA, emb written once
+// it is needed, ON THE MATRIX CORES: a 32x32 block of `basic` is six v_mfma_f32_32x32x2_f32 whose
+// operands are one register per lane each (the records; W1 stays in registers for the whole kernel) -
+// +9 % MFMA work instead of 192 VALU FMAs and 48 LDS reads per thread per K step, which used to take
+// as long as the 64 MFMAs of the step they fed.
+//   embed_fwd_fused : A tile (basic) generated into the swizzled LDS image of the fast GEMM, B tile
+//                     (W2_t) by DMA, exact-fp32 MFMA, emb written once, the max-pools of the 1- and
+//                     16-unit types taken from the accumulators
 //   embed_bwd_dw2   : dW2_t = demb_t^T basic_t as a split-K product whose B operand is generated
-//   embed_bwd_dw1   : d(basic) = (demb_t W2_t) * [basic > 0] stays in the accumulators; the epilogue
-//                     folds it straight into dW1 / db1 (d(basic) is never stored)
-// `basic` is evaluated with the same fmaf chain everywhere, so the relu mask of the backward is bitwise
-// the forward's.  Requires rows % 128 == 0 (every type block then starts on a tile boundary); other
+//   embed_bwd_dw1   : d(basic) = (demb_t W2_t) * [basic > 0] stays in the accumulators (the mask is
+//                     regenerated in the accumulators' own layout); the epilogue folds it straight into
+//                     dW1 / db1 (d(basic) is never stored)
+// `basic` is evaluated the same way everywhere - six v_mfma_f32_32x32x2_f32 over the feature pairs (an
+// exact k-ordered fmaf chain) plus b1 - so the relu mask of the backward is bitwise the forward's.  Requires rows % 128 == 0 (every type block then starts on a tile boundary); other
 // batches take the unfused path.
+#include <utility>
 #include "kernels.h"
 #include "gemm_tiles.h"
 
@@ -40,12 +46,15 @@ __device__ __forceinline__ int ef_type_of_tile(const EmbTypes& ty, int tile) {
 __device__ __forceinline__ int ef_units(int t) { return t == 1 ? 5 : ((t == 2 || t == 3) ? 16 : 1); }
 __device__ __forceinline__ int ef_cum(int t) { return t == 0 ? 0 : (t == 1 ? 1 : (t == 2 ? 6 : (t == 3 ? 22 : (t == 4 ? 38 : 39)))); }
 
-// 12-feature record of type-major row `local` (relative to its type block)
-__device__ __forceinline__ const float* ef_record(const float* __restrict__ obs, int t, long long local) {
-    const int U = ef_units(t);
-    const long long n = local / U;
-    const int u = (int)(local - n * U);
-    return obs + n * EF_OBS + 3 + (ef_cum(t) + u) * 12;
+// 12-feature record of type-major row `local` (relative to its type block; < 2^31: policy.hip check_dims).
+// The unit counts are 1, 5 and 16: shift / multiply-high instead of a 64-bit division per record.
+__device__ __forceinline__ const float* ef_record(const float* __restrict__ obs, int t, long long local_) {
+    const unsigned local = (unsigned)local_;
+    unsigned n, u;
+    if (t == 2 || t == 3) { n = local >> 4; u = local & 15u; }
+    else if (t == 1) { n = __umulhi(local, 0xCCCCCCCDu) >> 2; u = local - 5u * n; }
+    else { n = local; u = 0u; }
+    return obs + (size_t)n * EF_OBS + 3 + (ef_cum(t) + (int)u) * 12;
 }
 
 // the one definition of the first layer (same fmaf order in forward and backward)
@@ -66,9 +75,7 @@ __global__ __launch_bounds__(256) void embed_fwd_fused_kernel(const float* __res
                                                               EmbTypes ty) {
     using LT = FastTile<128, false>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* w1s = smem;                 // [128][12]
-    float* b1s = smem + 1536;          // [128]
-    float* stage = smem + 1664;        // 2 x (A [128][32] | B [128][32])
+    float* stage = smem;               // 2 x (A [128][32] | B [128][32])
     constexpr int STAGE_FL = 2 * 4096;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -78,42 +85,51 @@ __global__ __launch_bounds__(256) void embed_fwd_fused_kernel(const float* __res
     const int t = ef_type_of_tile(ty, tile);
     const long long row0 = (long long)tile * EF_TILE;
 
-    // this thread generates row (tid >> 1), channels 16*(tid & 1) .. +15 of every 32-channel K step
-    const int grow = tid >> 1, gh = tid & 1;
-    float x[12];
+    // The first layer (K = 12) is itself a matrix product and runs on the matrix cores: per K step of the
+    // second layer, wave w produces basic[rows 32w..32w+31][channels 32kt..32kt+31] with six
+    // v_mfma_f32_32x32x2_f32 (A = unit records, B = W1 rows, both one register per lane per instruction and
+    // loaded ONCE: the records per tile, W1 per kernel), adds b1, applies the relu and writes the 16
+    // accumulator values into the swizzled A image of the second product.  The previous VALU generator
+    // (192 FMAs + 48 LDS reads of W1 per thread per K step, the reads waited for one by one) took as long
+    // as the 64 MFMAs of the K step it fed.
+    //   A operand of MFMA kk: lane (fr, fq) = x[row 32w + fr][feature 2kk + fq]
+    //   B operand          : lane (fr, fq) = W1[channel 32kt + fr][feature 2kk + fq]
+    //   D                  : lane (fr, fq), register r = basic[row 32w + 8(r>>2) + 4fq + (r&3)][channel 32kt + fr]
+    float xa[6], wb[4][6], b1v[4];
     {
-        const float* xp = ef_record(obs, t, row0 + grow - ty.row_begin[t]);
+        const float* xp = ef_record(obs, t, row0 + 32 * wave + fr - ty.row_begin[t]);
 #pragma unroll
-        for (int f = 0; f < 12; ++f) x[f] = xp[f];
+        for (int kk = 0; kk < 6; ++kk) xa[kk] = xp[2 * kk + fq];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk) wb[kt][kk] = W1[(32 * kt + fr) * 12 + 2 * kk + fq];
+            b1v[kt] = b1[32 * kt + fr];
+        }
     }
-    for (int e = tid; e < 1664; e += 256) smem[e] = e < 1536 ? W1[e] : b1[e - 1536];
+    int aoff[16];   // LDS float index of D register r inside an A stage (row-major [128][32], 16-byte chunks XOR-swizzled)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = 32 * wave + 8 * (r >> 2) + 4 * fq + (r & 3);
+        aoff[r] = row * GEMM_BK + 4 * ((fr >> 2) ^ ((row >> 1) & 7)) + (fr & 3);
+    }
 
     size_t offb[LT::NI];
     LT::src_offsets<false>(offb, EF_EMB, 0, 128, wave, lane);
     const float* gb = W2 + (size_t)t * EF_EMB * EF_EMB;
     LT::issue(gb, offb, stage + 4096, wave);
-    __syncthreads();   // W1/b1 staged (and, harmlessly early, B(0) landed)
 
-    auto gen_a = [&](int kt, float* a_s) {
-        float* dst = a_s + grow * GEMM_BK;
-        const int key = (grow >> 1) & 7;
+    auto gen_a = [&](auto KT, float* a_s) {
+        constexpr int kt = decltype(KT)::value;
+        f32x16 g;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int chunk = 4 * gh + i, c0 = 32 * kt + 4 * chunk;
-            const float4 bb = *reinterpret_cast<const float4*>(b1s + c0);
-            const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
-            float o[4];
+        for (int r = 0; r < 16; ++r) g[r] = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float4* wp = reinterpret_cast<const float4*>(w1s + (c0 + e) * 12);
-                const float4 wa = wp[0], wb = wp[1], wc = wp[2];
-                const float w[12] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x, wc.y, wc.z, wc.w};
-                o[e] = fmaxf(ef_basic(x, w, bv[e]), 0.f);
-            }
-            *reinterpret_cast<float4*>(dst + 4 * (chunk ^ key)) = make_float4(o[0], o[1], o[2], o[3]);
-        }
+        for (int kk = 0; kk < 6; ++kk) g = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[kk], wb[kt][kk], g, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a_s[aoff[r]] = fmaxf(g[r] + b1v[kt], 0.f);
     };
-    gen_a(0, stage);
+    gen_a(std::integral_constant<int, 0>{}, stage);
     __syncthreads();
 
     f32x16 acc[2][2];
@@ -130,7 +146,9 @@ __global__ __launch_bounds__(256) void embed_fwd_fused_kernel(const float* __res
         if (kt < 3) {
             float* nxt = stage + ((kt + 1) & 1) * STAGE_FL;
             LT::issue(gb + (kt + 1) * GEMM_BK, offb, nxt + 4096, wave);
-            gen_a(kt + 1, nxt);
+            if (kt == 0) gen_a(std::integral_constant<int, 1>{}, nxt);
+            else if (kt == 1) gen_a(std::integral_constant<int, 2>{}, nxt);
+            else gen_a(std::integral_constant<int, 3>{}, nxt);
         }
         mma_kstep<LT, LT, 2, 2>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc);
         __syncthreads();
@@ -199,7 +217,7 @@ __global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restr
                                                             const float* __restrict__ W1, const float* __restrict__ b1,
                                                             float* __restrict__ slab, EmbTypes ty) {
     using LT = FastTile<128, true>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x (A [32][128] | B [32][128]) | unit records [2][384]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x (A [32][128] | B [32][128])
     constexpr int STAGE_FL = 2 * 4096;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -213,33 +231,35 @@ __global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restr
     const long long s0 = (long long)(wg - ty.wg_begin[t]) * ty.steps_per_wg;
     const int ns = (int)min((long long)ty.steps_per_wg, steps_t - s0);
 
-    const int gc = tid & 127;
-    const int ghalf = __builtin_amdgcn_readfirstlane(tid >> 7);
-    float w[12];
+    // B operand (basic, k-major [32 rows][128 channels]) on the matrix cores, like the forward: wave w makes
+    // channels 32w..32w+31 of the K step's 32 rows with six MFMAs.  B of those = W1 (six registers for the whole
+    // kernel); A = the step's unit records, one register per MFMA, loaded two steps ahead straight from HBM/L2
+    // (each wave its own copy - 1.5 KB per step).
+    float wb[6];
 #pragma unroll
-    for (int f = 0; f < 12; ++f) w[f] = W1[gc * 12 + f];
-    const float bias = b1[gc];
+    for (int kk = 0; kk < 6; ++kk) wb[kk] = W1[(32 * wave + fr) * 12 + 2 * kk + fq];
+    const float b1v = b1[32 * wave + fr];
+    int boff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) boff[r] = (8 * (r >> 2) + 4 * fq + (r & 3)) * 128 + 32 * wave + fr;
 
     size_t offa[LT::NI];
     LT::src_offsets<false>(offa, EF_EMB, 0, 128, wave, lane);
     const float* ga = demb + (size_t)(ty.row_begin[t] + s0 * GEMM_BK) * EF_EMB;
 
-    // unit records of a K step (32 rows x 12 floats) are staged in LDS two steps ahead: element e of the
-    // step = (row e/12, feature e%12); 384 elements over 256 threads
-    float* xs = smem + 2 * STAGE_FL;   // [2][384]
-    auto rec_ptr = [&](int s, int e) {
-        const int r = e / 12, f = e - r * 12;
-        return ef_record(obs, t, (s0 + min(s, ns - 1)) * GEMM_BK + r) + f;   // clamped: always a valid step
+    auto load_x = [&](int s, float (&x)[6]) {
+        const float* xp = ef_record(obs, t, (s0 + min(s, ns - 1)) * GEMM_BK + fr) + fq;   // clamped: always a valid step
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) x[kk] = xp[2 * kk];
     };
-    const int e0 = tid, e1 = 256 + (tid & 127);   // second element only for tid < 128
-    auto gen_b = [&](const float* xrow, float* b_s) {
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const float4* xp = reinterpret_cast<const float4*>(xrow + (16 * ghalf + i) * 12);   // wave-uniform: broadcast
-            const float4 xa = xp[0], xb = xp[1], xc = xp[2];
-            const float x[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
-            b_s[(16 * ghalf + i) * 128 + gc] = fmaxf(ef_basic(x, w, bias), 0.f);
-        }
+    auto gen_b = [&](const float (&x)[6], float* b_s) {
+        f32x16 g;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) g = __builtin_amdgcn_mfma_f32_32x32x2f32(x[kk], wb[kk], g, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b_s[boff[r]] = fmaxf(g[r] + b1v, 0.f);
     };
 
     f32x16 acc[2][2];
@@ -250,27 +270,30 @@ __global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    xs[e0] = *rec_ptr(0, e0);
-    xs[384 + e0] = *rec_ptr(1, e0);
-    if (tid < 128) { xs[e1] = *rec_ptr(0, e1); xs[384 + e1] = *rec_ptr(1, e1); }
+    float x0[6], x1[6];
+    load_x(0, x0);
+    load_x(1, x1);
     LT::issue(ga, offa, smem, wave);
+    gen_b(x0, smem + 4096);
     __syncthreads();
-    gen_b(xs, smem + 4096);
-    __syncthreads();
-    for (int s = 0; s < ns; ++s) {
+    // steps unrolled by two with ping-pong record registers: x1 feeds gen_b(s+1) while x0 receives step s+2
+    auto step = [&](int s, float (&xnext)[6], float (&xfill)[6]) {
         float* cur = smem + (s & 1) * STAGE_FL;
-        const float xn0 = *rec_ptr(s + 2, e0);                       // lands behind the MFMAs
-        const float xn1 = tid < 128 ? *rec_ptr(s + 2, e1) : 0.f;
+        // The barrier at the end of a step waits for the A DMA (vmcnt retires in order), hence for every load
+        // of the step: the record loads go FIRST, so that they complete behind the 64 MFMAs.
+        load_x(s + 2, xfill);
+        __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < ns) {
             float* nxt = smem + ((s + 1) & 1) * STAGE_FL;
             LT::issue(ga + (size_t)(s + 1) * GEMM_BK * EF_EMB, offa, nxt, wave);
-            gen_b(xs + ((s + 1) & 1) * 384, nxt + 4096);
+            gen_b(xnext, nxt + 4096);
         }
         mma_kstep<LT, LT, 2, 2>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc);
-        // records of step s were consumed by gen_b in the previous iteration: their slot takes step s+2
-        xs[(s & 1) * 384 + e0] = xn0;
-        if (tid < 128) xs[(s & 1) * 384 + e1] = xn1;
         __syncthreads();
+    };
+    for (int s = 0; s < ns; s += 2) {
+        step(s, x1, x0);
+        if (s + 1 < ns) step(s + 1, x0, x1);
     }
     float* out = slab + (size_t)wg * EF_EMB * EF_EMB;
 #pragma unroll
@@ -304,12 +327,16 @@ __global__ __launch_bounds__(256, 2) void embed_bwd_dw1_kernel(const float* __re
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fq = lane >> 5;
 
-    float w[2][12], bias[2], dw[2][12], db[2];
+    // relu mask: basic is re-evaluated on the matrix cores in the accumulators' own layout (six MFMAs per 32x32
+    // tile: A = unit records from xs, B = W1 in twelve registers for the whole kernel) - bitwise the forward's
+    float wb[2][6], bias[2], dw[2][12], db[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int c = wn * 64 + j * 32 + fr;
 #pragma unroll
-        for (int f = 0; f < 12; ++f) { w[j][f] = W1[c * 12 + f]; dw[j][f] = 0.f; }
+        for (int kk = 0; kk < 6; ++kk) wb[j][kk] = W1[c * 12 + 2 * kk + fq];
+#pragma unroll
+        for (int f = 0; f < 12; ++f) dw[j][f] = 0.f;
         bias[j] = b1[c];
         db[j] = 0.f;
     }
@@ -352,6 +379,20 @@ __global__ __launch_bounds__(256, 2) void embed_bwd_dw1_kernel(const float* __re
         // epilogue: rows of this lane = wm*64 + i*32 + 4*fq + (r&3) + 8*(r>>2)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            f32x16 bs[2];
+            {
+                const float* xr = xs + (wm * 64 + i * 32 + fr) * 12 + fq;
+                float xa[6];
+#pragma unroll
+                for (int kk = 0; kk < 6; ++kk) xa[kk] = xr[2 * kk];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) bs[j][r] = 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < 6; ++kk) bs[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[kk], wb[j][kk], bs[j], 0, 0, 0);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = wm * 64 + i * 32 + 4 * fq + (r & 3) + 8 * (r >> 2);
@@ -360,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void embed_bwd_dw1_kernel(const float* __re
                 const float x[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const float g = ef_basic(x, w[j], bias[j]) > 0.f ? acc[i][j][r] : 0.f;
+                    const float g = (bs[j][r] + bias[j]) > 0.f ? acc[i][j][r] : 0.f;
 #pragma unroll
                     for (int f = 0; f < 12; ++f) dw[j][f] = fmaf(g, x[f], dw[j][f]);
                     db[j] += g;
@@ -426,7 +467,7 @@ int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const fl
                     float* xcat, uint8_t* amax, long long nr, hipStream_t s) {
     int nwg;
     const EmbTypes ty = make_types(nr, &nwg);
-    const size_t lds = (size_t)(1664 + 4 * 4096) * sizeof(float);
+    const size_t lds = (size_t)(4 * 4096) * sizeof(float);
     static bool attr = false;
     if (int e = set_lds(embed_fwd_fused_kernel, lds, &attr)) return e;
     const int tiles = (int)(nr * 40 / EF_TILE);
@@ -446,7 +487,7 @@ int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const 
         return 1040;
     }
     {
-        const size_t lds = (size_t)(4 * 4096 + 768) * sizeof(float);
+        const size_t lds = (size_t)(4 * 4096) * sizeof(float);
         static bool attr = false;
         if (int e = set_lds(embed_bwd_dw2_kernel, lds, &attr)) return e;
         {
