@@ -21,6 +21,8 @@
 // `basic` is evaluated the same way everywhere - six v_mfma_f32_32x32x2_f32 over the feature pairs (an
 // exact k-ordered fmaf chain) plus b1 - so the relu mask of the backward is bitwise the forward's.  Requires rows % 128 == 0 (every type block then starts on a tile boundary); other
 // batches take the unfused path.
+#include <stdio.h>
+#include <stdlib.h>
 #include <utility>
 #include "kernels.h"
 #include "gemm_tiles.h"
@@ -66,13 +68,29 @@ __device__ __forceinline__ float ef_basic(const float (&x)[12], const float (&w)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// forward: one 128-row tile per workgroup, all 128 output channels, K = 128 in 4 steps
+// forward: persistent workgroups stride over the 128-row tiles (all 128 output channels, K = 128 in 4
+// steps of 32).  Phase stamps (s_memtime, DC_EF_TIMING=1) of the one-tile-per-workgroup version showed the
+// K loop at 43 % of a tile's life: 26 % went to a prologue that re-loaded W1 and waited for the unit
+// records, 31 % to the epilogue.  Hence the two points below.  What remains (measured per tile and wave, in
+// cycles): K loop 26.8 k for 17.9 k of MFMA issue, epilogue 15.6 k - of which the 64 KB of emb stores cost
+// 10 k plus 7 k of the OTHER resident workgroup's K loop (without the stores: 20.2 k / 8.5 k).  Staggering
+// the workgroups in time (per CU or across the chip) changes nothing: the CU's store path is the limit,
+// and the way past it is not to materialise emb at all ("next").
+//   * W1 / b1 live in registers for the whole kernel; the NEXT tile's records are loaded during the
+//     current K loop, and its step-0 operands (generated A, DMA'd B) are produced during the current
+//     tile's last K step, in the stage buffer that step does not use - the K steps of consecutive tiles
+//     form one continuous pipeline;
+//   * the epilogue transposes the accumulators through the other (free) stage buffer and writes emb
+//     with 16-byte stores, 256 contiguous bytes per 16 lanes.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void embed_fwd_fused_kernel(const float* __restrict__ obs, const float* __restrict__ W1,
-                                                              const float* __restrict__ b1, const float* __restrict__ W2,
-                                                              const float* __restrict__ b2, float* __restrict__ emb,
-                                                              float* __restrict__ xcat, uint8_t* __restrict__ amax,
-                                                              EmbTypes ty) {
+template <bool TIMING>   // TIMING (DC_EF_TIMING=1): s_memtime phase sums of wave 0 of every workgroup -> dbg[wg][4]
+__global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __restrict__ obs, const float* __restrict__ W1,
+                                                                 const float* __restrict__ b1, const float* __restrict__ W2,
+                                                                 const float* __restrict__ b2, float* __restrict__ emb,
+                                                                 float* __restrict__ xcat, uint8_t* __restrict__ amax,
+                                                                 EmbTypes ty, int n_tiles, long long* __restrict__ dbg) {
+    long long tm_k = 0, tm_e = 0, tm_b = 0, tm0 = 0, tm_start = 0;
+    if constexpr (TIMING) tm_start = __builtin_amdgcn_s_memtime();
     using LT = FastTile<128, false>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* stage = smem;               // 2 x (A [128][32] | B [128][32])
@@ -81,31 +99,21 @@ __global__ __launch_bounds__(256) void embed_fwd_fused_kernel(const float* __res
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fq = lane >> 5;
-    const int tile = blockIdx.x;
-    const int t = ef_type_of_tile(ty, tile);
-    const long long row0 = (long long)tile * EF_TILE;
 
     // The first layer (K = 12) is itself a matrix product and runs on the matrix cores: per K step of the
     // second layer, wave w produces basic[rows 32w..32w+31][channels 32kt..32kt+31] with six
-    // v_mfma_f32_32x32x2_f32 (A = unit records, B = W1 rows, both one register per lane per instruction and
-    // loaded ONCE: the records per tile, W1 per kernel), adds b1, applies the relu and writes the 16
-    // accumulator values into the swizzled A image of the second product.  The previous VALU generator
-    // (192 FMAs + 48 LDS reads of W1 per thread per K step, the reads waited for one by one) took as long
-    // as the 64 MFMAs of the K step it fed.
+    // v_mfma_f32_32x32x2_f32 (A = unit records, B = W1 rows, both one register per lane per instruction),
+    // adds b1, applies the relu and writes the 16 accumulator values into the swizzled A image of the
+    // second product.
     //   A operand of MFMA kk: lane (fr, fq) = x[row 32w + fr][feature 2kk + fq]
     //   B operand          : lane (fr, fq) = W1[channel 32kt + fr][feature 2kk + fq]
     //   D                  : lane (fr, fq), register r = basic[row 32w + 8(r>>2) + 4fq + (r&3)][channel 32kt + fr]
-    float xa[6], wb[4][6], b1v[4];
-    {
-        const float* xp = ef_record(obs, t, row0 + 32 * wave + fr - ty.row_begin[t]);
+    float wb[4][6], b1v[4];
 #pragma unroll
-        for (int kk = 0; kk < 6; ++kk) xa[kk] = xp[2 * kk + fq];
+    for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-            for (int kk = 0; kk < 6; ++kk) wb[kt][kk] = W1[(32 * kt + fr) * 12 + 2 * kk + fq];
-            b1v[kt] = b1[32 * kt + fr];
-        }
+        for (int kk = 0; kk < 6; ++kk) wb[kt][kk] = W1[(32 * kt + fr) * 12 + 2 * kk + fq];
+        b1v[kt] = b1[32 * kt + fr];
     }
     int aoff[16];   // LDS float index of D register r inside an A stage (row-major [128][32], 16-byte chunks XOR-swizzled)
 #pragma unroll
@@ -113,98 +121,155 @@ __global__ __launch_bounds__(256) void embed_fwd_fused_kernel(const float* __res
         const int row = 32 * wave + 8 * (r >> 2) + 4 * fq + (r & 3);
         aoff[r] = row * GEMM_BK + 4 * ((fr >> 2) ^ ((row >> 1) & 7)) + (fr & 3);
     }
-
     size_t offb[LT::NI];
     LT::src_offsets<false>(offb, EF_EMB, 0, 128, wave, lane);
-    const float* gb = W2 + (size_t)t * EF_EMB * EF_EMB;
-    LT::issue(gb, offb, stage + 4096, wave);
 
-    auto gen_a = [&](auto KT, float* a_s) {
+    auto load_x = [&](int tile, float (&x)[6]) {
+        const int tl = min(tile, n_tiles - 1);                      // past the end: a valid tile, never used
+        const int tt = ef_type_of_tile(ty, tl);
+        const float* xp = ef_record(obs, tt, (long long)tl * EF_TILE + 32 * wave + fr - ty.row_begin[tt]) + fq;
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) x[kk] = xp[2 * kk];
+    };
+    auto gen_a = [&](auto KT, const float (&x)[6], float* a_s) {
         constexpr int kt = decltype(KT)::value;
         f32x16 g;
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[r] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < 6; ++kk) g = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[kk], wb[kt][kk], g, 0, 0, 0);
+        for (int kk = 0; kk < 6; ++kk) g = __builtin_amdgcn_mfma_f32_32x32x2f32(x[kk], wb[kt][kk], g, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) a_s[aoff[r]] = fmaxf(g[r] + b1v[kt], 0.f);
     };
-    gen_a(std::integral_constant<int, 0>{}, stage);
+
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    float xa[6], xn[6];
+    load_x(tile, xa);
+    {   // step-0 operands of the first tile
+        const int t0 = ef_type_of_tile(ty, tile);
+        LT::issue(W2 + (size_t)t0 * EF_EMB * EF_EMB, offb, stage + 4096, wave);
+        gen_a(std::integral_constant<int, 0>{}, xa, stage);
+    }
     __syncthreads();
 
-    f32x16 acc[2][2];
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int t = ef_type_of_tile(ty, tile);
+        const long long row0 = (long long)tile * EF_TILE;
+        const float* gb = W2 + (size_t)t * EF_EMB * EF_EMB;
+        const int ntile = tile + gridDim.x;
+        const bool more = ntile < n_tiles;
+        load_x(ntile, xn);              // lands behind the K loop
+        const float b2v[2] = {b2[t * EF_EMB + wn * 64 + fr], b2[t * EF_EMB + wn * 64 + 32 + fr]};   // epilogue operands: likewise
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (TIMING) tm0 = __builtin_amdgcn_s_memtime();
+
+        f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-        float* cur = stage + (kt & 1) * STAGE_FL;
-        if (kt < 3) {
+        for (int kt = 0; kt < 4; ++kt) {
+            float* cur = stage + (kt & 1) * STAGE_FL;
             float* nxt = stage + ((kt + 1) & 1) * STAGE_FL;
-            LT::issue(gb + (kt + 1) * GEMM_BK, offb, nxt + 4096, wave);
-            if (kt == 0) gen_a(std::integral_constant<int, 1>{}, nxt);
-            else if (kt == 1) gen_a(std::integral_constant<int, 2>{}, nxt);
-            else gen_a(std::integral_constant<int, 3>{}, nxt);
+            if (kt < 3) {
+                LT::issue(gb + (kt + 1) * GEMM_BK, offb, nxt + 4096, wave);
+                if (kt == 0) gen_a(std::integral_constant<int, 1>{}, xa, nxt);
+                else if (kt == 1) gen_a(std::integral_constant<int, 2>{}, xa, nxt);
+                else gen_a(std::integral_constant<int, 3>{}, xa, nxt);
+            } else if (more) {          // the next tile's step 0, into the buffer step 3 does not read
+                const int t1 = ef_type_of_tile(ty, ntile);
+                LT::issue(W2 + (size_t)t1 * EF_EMB * EF_EMB, offb, nxt + 4096, wave);
+                gen_a(std::integral_constant<int, 0>{}, xn, nxt);
+            }
+            mma_kstep<LT, LT, 2, 2>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc);
+            __syncthreads();
         }
-        mma_kstep<LT, LT, 2, 2>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc);
-        __syncthreads();
-    }
 
-    // Epilogue: emb = acc + b2, and the max-pool over the units of an env-step (policy.py:102-127) straight from
-    // the accumulators - the 335 MB re-read of emb by a separate pooling kernel is gone.  A 32x32 accumulator
-    // tile holds rows 8*(r>>2) + 4*fq + (r&3): the 16 units of a step (types anh/enh, U = 16, tiles start on
-    // step boundaries) are 8 registers of this lane + 8 of lane^32.  "First maximum wins" like torch.max.
-    // Types with one unit (ah, ath) copy through; eh (U = 5, steps straddle tiles) and the env embedding are
-    // left to pool_env_fwd's residual pass; eth is never pooled (policy.py:127 pools enh twice instead).
-    const float* b2t = b2 + t * EF_EMB;
-    const long long lrow0 = row0 - ty.row_begin[t];
+        // ---- epilogue.  emb = acc + b2; the max-pool over the units of an env-step (policy.py:102-127) is
+        // taken straight from the accumulators (no 335 MB re-read of emb by a pooling kernel).  A 32x32
+        // accumulator tile holds rows 8*(r>>2) + 4*fq + (r&3): the 16 units of a step (types anh/enh, U = 16,
+        // tiles start on step boundaries) are 8 registers of this lane + 8 of lane^32.  "First maximum wins"
+        // like torch.max.  Types with one unit (ah, ath) copy through; eh (U = 5, steps straddle tiles) and
+        // the env embedding are left to pool_env_fwd's residual pass; eth is never pooled (policy.py:127
+        // pools enh twice instead).
+        // emb itself goes through LDS (stage buffer 1: step 3 is done with it, the next tile's step 0 sits in
+        // buffer 0): each wave transposes its 64x64 block in two 32-row halves of 8 KB and stores 16 bytes
+        // per lane, 256 contiguous bytes per 16 lanes.
+        if constexpr (TIMING) { const long long x = __builtin_amdgcn_s_memtime(); tm_k += x - tm0; tm0 = x; }
+        const long long lrow0 = row0 - ty.row_begin[t];
+        float* tr = stage + STAGE_FL + wave * 2048;     // [32][64]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = wn * 64 + j * 32 + fr;
-            const float bv = b2t[col];
-            float* c = emb + (size_t)(row0 + wm * 64 + i * 32 + 4 * fq) * EF_EMB + col;
-            float v[16];
+            for (int j = 0; j < 2; ++j) {
+                const int col = wn * 64 + j * 32 + fr;
+                const float bv = b2v[j];
+                float v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                v[r] = acc[i][j][r] + bv;
-                c[(size_t)((r & 3) + 8 * (r >> 2)) * EF_EMB] = v[r];
-            }
-            if (xcat == nullptr) continue;
-            const long long lr = lrow0 + wm * 64 + i * 32;           // type-local row of this tile's row 0
-            if (t == 2 || t == 3) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {                         // rows 16h..16h+15 = one env-step
-                    float m = v[8 * h];
-                    int am = 4 * fq;
-#pragma unroll
-                    for (int rr = 1; rr < 8; ++rr) {
-                        const float x = v[8 * h + rr];
-                        const int u = (rr & 3) + 8 * (rr >> 2) + 4 * fq;
-                        if (x > m) { m = x; am = u; }
-                    }
-                    const float pm = __shfl_xor(m, 32, 64);
-                    const int pam = __shfl_xor(am, 32, 64);
-                    if (pm > m || (pm == m && pam < am)) { m = pm; am = pam; }
-                    if (fq == h) {
-                        const long long n = (lr >> 4) + h;
-                        float* xo = xcat + n * 896;
-                        xo[(1 + t) * EF_EMB + col] = m;
-                        if (t == 3) xo[6 * EF_EMB + col] = m;         // policy.py:127: the "eth" slot holds the enh max
-                        amax[(n * 3 + (t - 1)) * EF_EMB + col] = (uint8_t)am;
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    v[r] = acc[i][j][r] + bv;
+                    tr[(8 * (r >> 2) + 4 * fq + (r & 3)) * 64 + j * 32 + fr] = v[r];
                 }
-            } else if (t == 0 || t == 4) {
+                if (xcat == nullptr) continue;
+                const long long lr = lrow0 + wm * 64 + i * 32;           // type-local row of this tile's row 0
+                if (t == 2 || t == 3) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    xcat[(lr + (r & 3) + 8 * (r >> 2) + 4 * fq) * 896 + (1 + t) * EF_EMB + col] = v[r];
+                    for (int h = 0; h < 2; ++h) {                         // rows 16h..16h+15 = one env-step
+                        float m = v[8 * h];
+                        int am = 4 * fq;
+#pragma unroll
+                        for (int rr = 1; rr < 8; ++rr) {
+                            const float x = v[8 * h + rr];
+                            const int u = (rr & 3) + 8 * (rr >> 2) + 4 * fq;
+                            if (x > m) { m = x; am = u; }
+                        }
+                        // partner lane^32 through v_permlane32_swap (VALU; a ds_bpermute costs an LDS round trip):
+                        // swap(x, x) = {[x.low | x.low], [x.high | x.high]} -> the other half's value is r[1 - fq]
+                        const auto sm = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                        const auto sa = __builtin_amdgcn_permlane32_swap((unsigned)am, (unsigned)am, false, false);
+                        const float pm = __uint_as_float(fq ? sm[0] : sm[1]);
+                        const int pam = (int)(fq ? sa[0] : sa[1]);
+                        if (pm > m || (pm == m && pam < am)) { m = pm; am = pam; }
+                        if (fq == h) {
+                            const long long n = (lr >> 4) + h;
+                            float* xo = xcat + n * 896;
+                            xo[(1 + t) * EF_EMB + col] = m;
+                            if (t == 3) xo[6 * EF_EMB + col] = m;         // policy.py:127: the "eth" slot holds the enh max
+                            amax[(n * 3 + (t - 1)) * EF_EMB + col] = (uint8_t)am;
+                        }
+                    }
+                } else if (t == 0 || t == 4) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        xcat[(lr + (r & 3) + 8 * (r >> 2) + 4 * fq) * 896 + (1 + t) * EF_EMB + col] = v[r];
+                }
+            }
+            // rows 4*it + lane/16 of the half, 16 bytes at column 4*(lane%16): one wave, LDS ops in order
+            float* eo = emb + (size_t)(row0 + wm * 64 + i * 32) * EF_EMB + wn * 64;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int rr = 4 * it + (lane >> 4), c4 = lane & 15;
+                const float4 q = *reinterpret_cast<const float4*>(tr + rr * 64 + 4 * c4);
+                *reinterpret_cast<float4*>(eo + (size_t)rr * EF_EMB + 4 * c4) = q;
             }
         }
+        if constexpr (TIMING) { const long long x = __builtin_amdgcn_s_memtime(); tm_e += x - tm0; tm0 = x; }
+        __syncthreads();            // buffer 1 is free again for step 1 of the next tile
+        if constexpr (TIMING) { const long long x = __builtin_amdgcn_s_memtime(); tm_b += x - tm0; }
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) xa[kk] = xn[kk];
+    }
+    if constexpr (TIMING) {
+        if (tid == 0) {
+            dbg[blockIdx.x * 4 + 0] = tm_k; dbg[blockIdx.x * 4 + 1] = tm_e; dbg[blockIdx.x * 4 + 2] = tm_b;
+            dbg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime() - tm_start;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -469,10 +534,28 @@ int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const fl
     const EmbTypes ty = make_types(nr, &nwg);
     const size_t lds = (size_t)(4 * 4096) * sizeof(float);
     static bool attr = false;
-    if (int e = set_lds(embed_fwd_fused_kernel, lds, &attr)) return e;
+    if (int e = set_lds(embed_fwd_fused_kernel<false>, lds, &attr)) return e;
     const int tiles = (int)(nr * 40 / EF_TILE);
+    const int grid = tiles < 512 ? tiles : 512;      // two resident workgroups per CU
     ProfScope prof("embed_fwd_fused", 2.0 * nr * 40 * 128 * (128 + 12), 4.0 * nr * 40 * (12 + 128), s);
-    hipLaunchKernelGGL(embed_fwd_fused_kernel, dim3(tiles), dim3(256), lds, s, obs, W1, b1, W2, b2, emb, xcat, amax, ty);
+    static const bool timing = [] { const char* e = getenv("DC_EF_TIMING"); return e && e[0] == '1'; }();
+    if (timing) {   // debugging aid: mean per-tile phase cycles (wave 0 of each workgroup), printed per launch
+        static bool attr2 = false;
+        if (int e = set_lds(embed_fwd_fused_kernel<true>, lds, &attr2)) return e;
+        static long long* dbg = nullptr;
+        if (!dbg) (void)hipMalloc(&dbg, 512 * 4 * sizeof(long long));
+        hipLaunchKernelGGL(embed_fwd_fused_kernel<true>, dim3(grid), dim3(256), lds, s, obs, W1, b1, W2, b2, emb, xcat, amax, ty, tiles, dbg);
+        long long h[512 * 4];
+        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        double ph[4] = {0, 0, 0, 0};
+        for (int b = 0; b < grid; ++b)
+            for (int i = 0; i < 4; ++i) ph[i] += (double)h[b * 4 + i];
+        fprintf(stderr, "embed_fwd timing (cycles per tile, mean over %d workgroups): k-loop %.0f  epilogue %.0f  end barrier %.0f | workgroup life %.0f (%d tiles)\n",
+                grid, ph[0] / tiles, ph[1] / tiles, ph[2] / tiles, ph[3] / grid, tiles / grid);
+        return launch_check("embed_fwd_fused");
+    }
+    hipLaunchKernelGGL(embed_fwd_fused_kernel<false>, dim3(grid), dim3(256), lds, s, obs, W1, b1, W2, b2, emb, xcat, amax, ty, tiles,
+                       (long long*)nullptr);
     return launch_check("embed_fwd_fused");
 }
 

@@ -69,15 +69,14 @@ __device__ __forceinline__ void mma_kstep(const float* __restrict__ a_s, const f
         for (int i = 0; i < TM; ++i) af[i] = LA::frag(a_s, a_row0 + i * 32 + fr, j, fq);
 #pragma unroll
         for (int i = 0; i < TN; ++i) bf[i] = LB::frag(b_s, b_row0 + i * 32 + fr, j, fq);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn) {
-                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[jn].x, acc[i][jn], 0, 0, 0);
-                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[jn].y, acc[i][jn], 0, 0, 0);
-                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[jn].z, acc[i][jn], 0, 0, 0);
-                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[jn].w, acc[i][jn], 0, 0, 0);
-            }
+        // element-major order: the TM x TN accumulators take turns, so consecutive MFMAs never chain on the
+        // same accumulator (each sees TM*TN - 1 independent issues before its own next update)
+#define DC_MMA_E(E)                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                          \
+            _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                                   \
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].E, bf[jn].E, acc[i][jn], 0, 0, 0);
+        DC_MMA_E(x) DC_MMA_E(y) DC_MMA_E(z) DC_MMA_E(w)
+#undef DC_MMA_E
     }
 }
 
