@@ -19,11 +19,14 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/$OUT/prof -o trace -- pyth
 # PMC passes, each on its own (no trace domains besides kernel-trace)
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $REPO/$OUT/pmc_fetch -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $REPO/$OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $REPO/$OUT/pmc_write -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $REPO/$OUT/pmc_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $REPO/$OUT/pmc_sq -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $REPO/$OUT/pmc_sq.log 2>&1
 cd $REPO
+python tools/pmc_sq.py $OUT/pmc_sq $OUT/pmc_sq.json > $OUT/pmc_sq.txt 2>&1
 DB=$(find $OUT/prof -name '*.db' | head -1)
 [ -n "$DB" ] && python tools/rocpd_stats.py $DB $OUT/kernel_stats.csv
 python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json lstm-128-64x256 2>&1 | tail -15
 # keep the merge-back small: drop raw traces
 find $OUT/prof -name '*.db' -size +20M -delete
 find $OUT -name '*kernel_trace.csv' -size +20M -delete
+find $OUT -name '*counter_collection.csv' -size +20M -delete
 ls -la $OUT
