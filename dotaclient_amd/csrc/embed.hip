@@ -310,6 +310,7 @@ int unit_basic_fwd(const float* obs, const float* W1, const float* b1, float* ba
 
 int pool_env_fwd(const float* obs, const float* emb, const float* Wenv, const float* benv, float* xcat, uint8_t* amax,
                  long long nr, int residual, hipStream_t s) {
+    ProfScope prof("pool_env_fwd", 0.0, 4.0 * nr * ((residual ? 5 : 40) * 128 + 896), s);
     hipLaunchKernelGGL(pool_env_fwd_kernel, dim3(grid_for(nr, 2, 256 * 16)), dim3(256), 0, s, obs, emb, Wenv, benv, xcat,
                        amax, nr, residual);
     return launch_check("pool_env_fwd");
@@ -321,6 +322,7 @@ int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, c
     int spb = (int)((nr + 2047) / 2048);
     if (spb < 4) spb = 4;
     const int nblk = (int)((nr + spb - 1) / spb);        // <= 2048 -> <= 10.5 MB of scratch
+    ProfScope prof("embed_scatter_bwd(+reduce)", 2.0 * nr * 40 * 128, 4.0 * nr * (40 * 128 + 896 * 2 + 128 + 40), s);
     hipLaunchKernelGGL(embed_scatter_bwd_kernel, dim3(nblk), dim3(256), 0, s, obs, xcat, dxcat, dtu, q, ldq, amax, demb,
                        scratch, nr, spb);
     hipLaunchKernelGGL(embed_scatter_reduce_kernel, dim3(5, 32), dim3(256), 0, s, scratch, nblk, dWenv, dbenv, db2);

@@ -166,92 +166,173 @@ struct LossArgs {
     float e_clip, entropy_coef, vf_coef, adv_eps;
 };
 
-// One thread per (env-step, head): loss partial sums + d(loss)/d(logits); the head-0 thread also does
-// the value term.  Partial sums are reduced per block and accumulated in double.
+// 16 lanes (one DPP row) per env-step: lane j owns the act/mask columns j, j+16, j+32, j+48 (and lane 0 column
+// 64) of the step's 65, whatever head they belong to; per-head soft-max sums, entropies, the selected column and
+// its gradient seed are row all-reduces (four v_add_f32_dpp / v_min_u32_dpp each).  The previous one-thread-per-
+// (step, head) form walked up to 40 logits three times in a serial loop while the other heads' lanes idled
+// (66 us per launch; this one is bound by its ~1 KB per step of traffic).  Same arithmetic per element:
+// no max-subtraction (policy.py:172), tie/clamp gradient rules of torch.min / clamp, batch sums in f64.
+template <int CTRL>
+__device__ __forceinline__ float row_dpp(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int row_dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ float row_sum16(float x) {      // all 16 lanes of the row get the sum
+    x += row_dpp<0x128>(x); x += row_dpp<0x124>(x); x += row_dpp<0x122>(x); x += row_dpp<0x121>(x);   // row_ror 8,4,2,1
+    return x;
+}
+__device__ __forceinline__ int row_sum16_i(int x) {
+    x += row_dpp_i<0x128>(x); x += row_dpp_i<0x124>(x); x += row_dpp_i<0x122>(x); x += row_dpp_i<0x121>(x);
+    return x;
+}
+__device__ __forceinline__ int row_min16_i(int x) {
+    x = min(x, row_dpp_i<0x128>(x)); x = min(x, row_dpp_i<0x124>(x)); x = min(x, row_dpp_i<0x122>(x)); x = min(x, row_dpp_i<0x121>(x));
+    return x;
+}
+__device__ __forceinline__ int head_of_col(int c) { return c < 4 ? 0 : (c < 13 ? 1 : (c < 22 ? 2 : (c < 62 ? 3 : 4))); }
+
 __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    double pol = 0.0, ent = 0.0, val = 0.0;
-    int k = 0;
-    const bool on = idx < p.nr * 5;
-    if (on) {
-        const long long n = idx / 5;
-        k = (int)(idx - n * 5);
+    __shared__ float sh_norm[2];
+    __shared__ double sh[4][11];
+    if (threadIdx.x == 0) {
         const double N = (double)p.nr;
         const double mean = p.stats[ST_ADV_SUM] / N;
-        // torch.std: unbiased (N-1); optimizer.py:588
-        double var = (p.stats[ST_ADV_SQ] - N * mean * mean) / (N - 1.0);
+        double var = (p.stats[ST_ADV_SQ] - N * mean * mean) / (N - 1.0);   // torch.std: unbiased (N-1); optimizer.py:588
         if (var < 0.0) var = 0.0;
-        const float A = (float)(((double)p.adv[n] - mean) / (sqrt(var) + (double)p.adv_eps));
-        const double nsel = p.stats[ST_NSEL + k];
-        const float* ho = p.headout + n * HO_LD;
-        const float* tun = p.tu + n * NUNITS;
-        const int o = c_head_off[k], C = c_head_off[k + 1] - o;
-        const uint8_t* m = p.mask + n * ACT + o;
-        const uint8_t* a = p.act + n * ACT + o;
-        float se = 0.f;
-        int ai = -1, many = 0;
-        for (int c = 0; c < C; ++c) {
-            if (m[c]) { se += expf(head_logit(ho, tun, k, c)); many = 1; }
-            if (a[c] && ai < 0) ai = c;
+        sh_norm[0] = (float)mean;
+        sh_norm[1] = (float)(sqrt(var) + (double)p.adv_eps);
+    }
+    __syncthreads();
+    const int j = threadIdx.x & 15;
+    const long long n = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool on = n < p.nr;
+    const long long nn = on ? n : p.nr - 1;     // idle rows of the last block recompute a valid step and store nothing
+    double pol[5] = {0, 0, 0, 0, 0}, ent[5] = {0, 0, 0, 0, 0}, val = 0.0;
+
+    const float* ho = p.headout + nn * HO_LD;
+    const float* tun = p.tu + nn * NUNITS;
+    const uint8_t* mrow = p.mask + nn * ACT;
+    const uint8_t* arow = p.act + nn * ACT;
+    // (double) like the reference's fp32 tensor op on a float64-free path: A is an fp32 value
+    const float A = (float)(((double)p.adv[nn] - (double)sh_norm[0]) / (double)sh_norm[1]);
+
+    float z[5], e[5];
+    bool mk[5];
+    int cand[5];
+    int cnt_packed = 0;
+    float se_c[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    int amin_c[5] = {127, 127, 127, 127, 127};
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        const int c = j + 16 * m;
+        const bool valid = c < ACT;
+        const int cc = valid ? c : 0;
+        const int k = head_of_col(cc);
+        z[m] = k == 3 ? tun[cc - 22] : ho[(k == 4 ? 88 : 128) + cc];
+        mk[m] = valid && mrow[cc] != 0;
+        const bool ac = valid && arow[cc] != 0;
+        e[m] = mk[m] ? expf(z[m]) : 0.f;
+        cand[m] = ac ? c : 127;
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk) {
+            se_c[kk] += (valid && k == kk) ? e[m] : 0.f;
+            amin_c[kk] = (valid && k == kk) ? min(amin_c[kk], cand[m]) : amin_c[kk];
         }
-        const float lse = logf(se);
-        // entropy of this row over the masked entries (optimizer.py:643-646)
-        float Hrow = 0.f;
-        if (many) {
-            for (int c = 0; c < C; ++c)
-                if (m[c]) {
-                    const float lp = head_logit(ho, tun, k, c) - lse;
-                    Hrow -= expf(lp) * lp;
-                }
-        }
-        // clipped-ratio surrogate for the selected action (optimizer.py:633-641)
-        float g_lp = 0.f;  // d(total loss)/d(logp_sel)
-        if (ai >= 0 && nsel > 0.0) {
-            const float lp = head_logit(ho, tun, k, ai) - lse;
-            const float ratio = expf(lp - p.old_logp[n * 5 + k]);
+        cnt_packed += mk[m] ? (1 << (6 * k)) : 0;
+    }
+    float lse[5], nselv[5];
+    int amin[5];
+    const int cnt = row_sum16_i(cnt_packed);
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) {
+        lse[kk] = logf(row_sum16(se_c[kk]));
+        amin[kk] = row_min16_i(amin_c[kk]);
+        nselv[kk] = (float)p.stats[ST_NSEL + kk];
+    }
+    // log-probs of this lane's columns, entropy terms, the selected action's surrogate
+    float lp[5], pc[5];
+    float h_c[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, glp_c[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        const int c = j + 16 * m;
+        const bool valid = c < ACT;
+        const int k = head_of_col(valid ? c : 0);
+        float lsek = lse[4];
+        lsek = k == 3 ? lse[3] : lsek; lsek = k == 2 ? lse[2] : lsek; lsek = k == 1 ? lse[1] : lsek; lsek = k == 0 ? lse[0] : lsek;
+        lp[m] = z[m] - lsek;
+        pc[m] = mk[m] ? expf(lp[m]) : 0.f;
+        const float ht = mk[m] ? pc[m] * lp[m] : 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk) h_c[kk] -= (valid && k == kk) ? ht : 0.f;
+        // owner of the head's selected action (lowest set column)
+        int amk = amin[4];
+        amk = k == 3 ? amin[3] : amk; amk = k == 2 ? amin[2] : amk; amk = k == 1 ? amin[1] : amk; amk = k == 0 ? amin[0] : amk;
+        float nsk = nselv[4];
+        nsk = k == 3 ? nselv[3] : nsk; nsk = k == 2 ? nselv[2] : nsk; nsk = k == 1 ? nselv[1] : nsk; nsk = k == 0 ? nselv[0] : nsk;
+        if (valid && c == amk && nsk > 0.f) {     // at most one column per head in the whole row
+            const float ratio = expf(lp[m] - p.old_logp[nn * 5 + k]);
             const float s1 = ratio * A;
             const float rc = fminf(fmaxf(ratio, 1.f - p.e_clip), 1.f + p.e_clip);
             const float s2 = rc * A;
-            pol = -(double)fminf(s1, s2);
+            const double polv = -(double)fminf(s1, s2);
             // d min(s1,s2)/d ratio: torch splits ties evenly; clamp passes gradient inside [lo,hi]
             const bool inr = (ratio >= 1.f - p.e_clip) && (ratio <= 1.f + p.e_clip);
             float w1, w2;
             if (s1 < s2) { w1 = 1.f; w2 = 0.f; } else if (s1 > s2) { w1 = 0.f; w2 = 1.f; } else { w1 = 0.5f; w2 = 0.5f; }
             const float dmin_dr = A * (w1 + (inr ? w2 : 0.f));
-            g_lp = (float)(-(double)dmin_dr * (double)ratio / (5.0 * nsel));
-        }
-        const float g_ent = (nsel > 0.0 && p.entropy_coef > 0.f) ? (float)((double)p.entropy_coef / nsel) : 0.f;
-        if (nsel > 0.0 && many) ent = (double)Hrow;
-        // d loss / d logit_c = g_lp * (delta_{c,a} - [mask_c] p_c) + g_ent * [mask_c] p_c (logp_c + Hrow)
-        for (int c = 0; c < C; ++c) {
-            float g = 0.f;
-            if (m[c]) {
-                const float lp = head_logit(ho, tun, k, c) - lse;
-                const float pc = expf(lp);
-                g = -g_lp * pc + g_ent * pc * (lp + Hrow);
-            }
-            if (c == ai) g += g_lp;
-            const int col = head_grad_col(k, c);
-            if (col >= 0) p.dheadout[n * HO_LD + col] = g;
-            else p.dtu[n * NUNITS + c] = g;
-        }
-        if (k == 0) {
-            const float v = ho[HO_VALUE];
-            const float d = p.ret[n] - v;
-            val = (double)d * (double)d;
-            // value_loss = vf_coef * 0.5 * mean((R - V)^2)  (optimizer.py:658-661)
-            p.dheadout[n * HO_LD + HO_VALUE] = (p.vf_coef > 0.f) ? (float)((double)p.vf_coef * (double)(v - p.ret[n]) / N) : 0.f;
+            const float g = (float)(-(double)dmin_dr * (double)ratio / (5.0 * (double)nsk));
 #pragma unroll
-            for (int c = HO_VALUE + 1; c < HO_LD; ++c) p.dheadout[n * HO_LD + c] = 0.f;
+            for (int kk = 0; kk < 5; ++kk) {
+                glp_c[kk] += k == kk ? g : 0.f;
+                if (on) pol[kk] += k == kk ? polv : 0.0;
+            }
         }
     }
+    float Hrow[5], glp[5], gent[5];
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) {
+        Hrow[kk] = row_sum16(h_c[kk]);
+        glp[kk] = row_sum16(glp_c[kk]);
+        const bool many = ((cnt >> (6 * kk)) & 63) != 0;
+        if (!many) Hrow[kk] = 0.f;
+        gent[kk] = (nselv[kk] > 0.f && p.entropy_coef > 0.f) ? (float)((double)p.entropy_coef / (double)nselv[kk]) : 0.f;
+        if (on && j == 0 && nselv[kk] > 0.f && many) ent[kk] = (double)Hrow[kk];
+    }
+    // d loss / d logit_c = g_lp * (delta_{c,a} - [mask_c] p_c) + g_ent * [mask_c] p_c (logp_c + Hrow)
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        const int c = j + 16 * m;
+        if (c < ACT && on) {
+            const int k = head_of_col(c);
+            float gl = glp[4], ge = gent[4], hr = Hrow[4];
+            int amk = amin[4];
+#pragma unroll
+            for (int kk = 3; kk >= 0; --kk) {
+                gl = k == kk ? glp[kk] : gl; ge = k == kk ? gent[kk] : ge; hr = k == kk ? Hrow[kk] : hr; amk = k == kk ? amin[kk] : amk;
+            }
+            float g = mk[m] ? (-gl * pc[m] + ge * pc[m] * (lp[m] + hr)) : 0.f;
+            if (c == amk) g += gl;
+            if (k == 3) p.dtu[n * NUNITS + (c - 22)] = g;
+            else p.dheadout[n * HO_LD + (k == 4 ? 88 : 128) + c] = g;
+        }
+    }
+    if (on && j == 0) {
+        const double N = (double)p.nr;
+        const float v = ho[HO_VALUE];
+        const float d = p.ret[n] - v;
+        val = (double)d * (double)d;
+        // value_loss = vf_coef * 0.5 * mean((R - V)^2)  (optimizer.py:658-661)
+        p.dheadout[n * HO_LD + HO_VALUE] = (p.vf_coef > 0.f) ? (float)((double)p.vf_coef * (double)(v - p.ret[n]) / N) : 0.f;
+#pragma unroll
+        for (int c = HO_VALUE + 1; c < HO_LD; ++c) p.dheadout[n * HO_LD + c] = 0.f;
+    }
     // block reduction: 5 policy sums + 5 entropy sums + value sum
-    __shared__ double sh[4][11];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int kk = 0; kk < 5; ++kk) {
-        const double a = wave_sum((on && k == kk) ? pol : 0.0);
-        const double b = wave_sum((on && k == kk) ? ent : 0.0);
+        const double a = wave_sum(pol[kk]);
+        const double b = wave_sum(ent[kk]);
         if (lane == 0) { sh[wave][kk] = a; sh[wave][5 + kk] = b; }
     }
     const double vs = wave_sum(val);
@@ -296,11 +377,13 @@ static inline int grid1d(long long items, int per_block, int cap) {
 }
 
 int attn_logits(const float* headout, const float* emb, float* tu, long long nr, hipStream_t s) {
+    ProfScope prof("attn_logits", 2.0 * nr * 40 * 128, 4.0 * nr * (40 * 128 + 128 + 40), s);
     hipLaunchKernelGGL(attn_logits_kernel, dim3(grid1d(nr, 4, 256 * 16)), dim3(256), 0, s, headout, emb, tu, nr);
     return launch_check("attn_logits");
 }
 
 int attn_bwd_q(const float* dtu, const float* emb, float* dheadout, long long nr, hipStream_t s) {
+    ProfScope prof("attn_bwd_q", 2.0 * nr * 40 * 128, 4.0 * nr * (40 * 128 + 128 + 40), s);
     hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(grid1d(nr, 2, 256 * 16)), dim3(256), 0, s, dtu, emb, dheadout, nr);
     return launch_check("attn_bwd_q");
 }
@@ -315,6 +398,7 @@ int select_logp(const float* headout, const float* tu, const uint8_t* act, const
 int ppo_loss_fwd_bwd(const float* headout, const float* tu, const uint8_t* act, const uint8_t* mask, const float* old_logp,
                      const float* adv, const float* ret, double* stats, float* dheadout, float* dtu, float* losses_out,
                      int32_t* head_on, long long nr, float e_clip, float entropy_coef, float vf_coef, hipStream_t s) {
+    ProfScope prof("ppo_loss(stats+loss+finalize)", 0.0, (double)nr * (4.0 * (26 + 40 + 5 + 2) + 2.0 * 65 + 4.0 * (32 + 40)), s);
     hipError_t e = hipMemsetAsync(stats, 0, ST_COUNT * sizeof(double), s);
     if (e != hipSuccess) { set_error("ppo_loss: memset", (int)e); return (int)e; }
     hipLaunchKernelGGL(batch_stats_kernel, dim3(grid1d(nr, 256, 1024)), dim3(256), 0, s, adv, act, stats, nr);
@@ -323,7 +407,7 @@ int ppo_loss_fwd_bwd(const float* headout, const float* tu, const uint8_t* act, 
     a.stats = stats; a.dheadout = dheadout; a.dtu = dtu; a.nr = nr;
     a.e_clip = e_clip; a.entropy_coef = entropy_coef; a.vf_coef = vf_coef;
     a.adv_eps = 1.1920928955078125e-07f;   // np.finfo(np.float32).eps, optimizer.py:38
-    hipLaunchKernelGGL(ppo_loss_kernel, dim3((unsigned)((nr * 5 + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3((unsigned)((nr + 15) / 16)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, stats, losses_out, head_on, nr, entropy_coef, vf_coef);
     return launch_check("ppo_loss_fwd_bwd");
 }

@@ -80,6 +80,7 @@ int rnn_seed_state(const float* h0, float* hprev, const int64_t* seq_off, const 
                    hipStream_t s);
 int rnn_final_state(const float* hseq, float* hT, const int64_t* seq_off, const int32_t* seq_len, int n_seq, int H,
                     hipStream_t s);
+bool rnn_uses_persistent(int cell, int H);   // register-resident LSTM kernels: W_hh^T is not needed
 int rnn_forward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s);
 int rnn_backward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s);
 // rnn_persist.hip (LSTM, H <= 128: all time steps in one launch, W_hh register-resident)

@@ -181,7 +181,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     // recurrent core, top layer first
     for (int l = TOP; l >= 0; --l) {
         const int pb = DC_P_RNN0 + 4 * l;
-        DC_TRY(transpose(P.p(pb + 1), w.f(DC_WS_WHHT), G * H, H, s));
+        if (!rnn_uses_persistent(d->cell, H)) DC_TRY(transpose(P.p(pb + 1), w.f(DC_WS_WHHT), G * H, H, s));
         RnnStepArgs a{};
         a.seq_off = seq_off; a.seq_len = seq_len; a.n_seq = B; a.H = H;
         a.gates = w.fl(l, DC_WSL_GATES); a.hn = w.fl(l, DC_WSL_HN); a.hseq = w.fl(l, DC_WSL_HSEQ);
@@ -196,7 +196,12 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         DC_TRY(gemm_f32(a.dgx, xin, Gd.p(pb + 0), G * H, in, (int)NR, G * H, in, in, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s));
         DC_TRY(gemm_f32(a.dgh, a.hprev, Gd.p(pb + 1), G * H, H, (int)NR, G * H, H, H, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s));
         DC_TRY(colsum(a.dgx, G * H, NR, G * H, Gd.p(pb + 2), s));
-        DC_TRY(colsum(a.dgh, G * H, NR, G * H, Gd.p(pb + 3), s));
+        if (d->cell == 1) {   // LSTM: dgh is dgx, so d(b_hh) = d(b_ih) - copy 2 KB instead of a second 33 MB column sum
+            hipError_t ec = hipMemcpyAsync(Gd.p(pb + 3), Gd.p(pb + 2), (size_t)G * H * sizeof(float), hipMemcpyDeviceToDevice, s);
+            if (ec != hipSuccess) { set_error("policy_backward: bias gradient copy", (int)ec); return (int)ec; }
+        } else {
+            DC_TRY(colsum(a.dgh, G * H, NR, G * H, Gd.p(pb + 3), s));
+        }
         if (l > 0) {
             DC_TRY(gemm_f32(a.dgx, P.p(pb + 0), w.fl(l - 1, DC_WSL_DH), (int)NR, H, G * H, G * H, H, H, 0, 1, nullptr, 0, nullptr,
                             0, 0, 1, s));

@@ -298,10 +298,14 @@ static int check_h(int H) {
 
 // all steps of one layer, forward.  max_len = max(seq_len) (host value).
 // DC_RNN_PERSIST=0 forces the launch-per-step kernels (A/B measurements)
+bool rnn_uses_persistent(int cell, int H);
 static bool persist_enabled() {
     static const bool on = [] { const char* e = getenv("DC_RNN_PERSIST"); return !(e && e[0] == '0'); }();
     return on;
 }
+
+// true when the layer runs on the register-resident LSTM kernels (which read W_hh directly: no W_hh^T needed)
+bool rnn_uses_persistent(int cell, int H) { return cell == CELL_LSTM && lstm_persist_supported(H) && persist_enabled(); }
 
 int rnn_forward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     if (int e = check_h(a.H)) return e;

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Shortest GPU-box visit: one short bench line (no CPU baseline) and its per-region table.  Usage: bash tools/gpu_bench_only.sh <tag> [bench args]
+TAG=${1:-b}; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/bench.err
+python - <<PY
+import json
+try:
+    j = json.load(open('$OUT/bench.json'))
+    print(j['value'], 'env-steps/s', j['ms_per_step'], 'ms/step')
+    tot = 0
+    for k in j['roofline']['kernels']:
+        print('%-30s n=%3d avg=%8.1f us  %6.3f ms  %6.1f TF' % (k['kernel'], k['launches_per_step'], k['avg_us'], k['ms_per_step'], k['achieved_tflops'])); tot += k['ms_per_step']
+    print('profiled regions: %.3f ms' % tot)
+except Exception as e:
+    print('bench failed', e); print(open('$OUT/bench.err').read()[-2000:])
+PY
