@@ -67,6 +67,10 @@ static float* ws_f(const dc_dims* dims, const void* ws, int idx) {
 int dc_select_logp(const dc_dims* dims, const void* ws, const uint8_t* act, const uint8_t* mask, float* logp_sel,
                    float* values, int32_t* argmax, dc_stream_t stream) {
     if (dims->rows <= 0) return 0;
+    if (dims->flags & DC_DIMS_LAZY_TU)
+        if (int e = dc::attn_logits_masked(ws_f(dims, ws, DC_WS_HEADOUT), ws_f(dims, ws, DC_WS_EMB), mask, ws_f(dims, ws, DC_WS_TU),
+                                           dims->rows, (hipStream_t)stream))
+            return e;
     return dc::select_logp(ws_f(dims, ws, DC_WS_HEADOUT), ws_f(dims, ws, DC_WS_TU), act, mask, logp_sel, values, argmax,
                            dims->rows, (hipStream_t)stream);
 }
@@ -75,6 +79,10 @@ int dc_ppo_loss_fwd_bwd(const dc_dims* dims, void* ws, const uint8_t* act, const
                         const float* adv, const float* ret, float* losses_out, int32_t* head_on, float e_clip,
                         float entropy_coef, float vf_coef, dc_stream_t stream) {
     if (dims->rows <= 0) { dc::set_error("ppo_loss: empty batch", 1030); return 1030; }
+    if (dims->flags & DC_DIMS_LAZY_TU)
+        if (int e = dc::attn_logits_masked(ws_f(dims, ws, DC_WS_HEADOUT), ws_f(dims, ws, DC_WS_EMB), mask, ws_f(dims, ws, DC_WS_TU),
+                                           dims->rows, (hipStream_t)stream))
+            return e;
     return dc::ppo_loss_fwd_bwd(ws_f(dims, ws, DC_WS_HEADOUT), ws_f(dims, ws, DC_WS_TU), act, mask, old_logp, adv, ret,
                                 reinterpret_cast<double*>(ws_f(dims, ws, DC_WS_STATS)), ws_f(dims, ws, DC_WS_DHEADOUT),
                                 ws_f(dims, ws, DC_WS_DTU), losses_out, head_on, dims->rows, e_clip, entropy_coef, vf_coef,

@@ -48,18 +48,64 @@ __global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restric
     }
 }
 
-// dq[n][c] = sum_u dtu[n][u] * emb[n][u][c]  -> dheadout[n][0..127]; 128 threads per env-step
+// type-major row of unit u (0..39) of env-step n
+__device__ __forceinline__ long long unit_row(long long nr, long long n, int u) {
+    int t = 0;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) if (u >= c_t_cum[i]) t = i;
+    return nr * c_t_cum[t] + n * c_t_units[t] + (u - c_t_cum[t]);
+}
+
+// Mask-aware form (DC_DIMS_LAZY_TU): only units whose target_unit mask byte is set are read - the actors' masks
+// (agent.py:666-671) leave the head empty unless the step's action type targets a unit, so most steps cost 40
+// bytes instead of 20 KB.  One wave per env-step: the 40 mask bytes become a ballot, each 16-lane quarter of the
+// wave takes every fourth set bit.
+__global__ __launch_bounds__(256) void attn_logits_masked_kernel(const float* __restrict__ headout, const float* __restrict__ emb,
+                                                                 const uint8_t* __restrict__ mask, float* __restrict__ tu,
+                                                                 long long nr) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 4, l16 = lane & 15;
+    for (long long n = (long long)blockIdx.x * 4 + wave; n < nr; n += (long long)gridDim.x * 4) {
+        const bool set = lane < NUNITS && mask[n * ACT + 22 + lane] != 0;
+        unsigned long long bits = __ballot(set);
+        if (lane < NUNITS && !set) tu[n * NUNITS + lane] = 0.f;
+        if (bits == 0ull) continue;
+        const float4* qp = reinterpret_cast<const float4*>(headout + n * HO_LD);
+        const float4 q0 = qp[l16], q1 = qp[16 + l16];
+        while (bits) {
+            // this quarter's unit: the sub-th lowest set bit (wave-uniform loop, quarter-uniform choice)
+            unsigned long long b = bits;
+            for (int i = 0; i < sub; ++i) b &= b - 1;
+            const bool have = b != 0ull;
+            const int u = have ? __builtin_ctzll(b) : 0;
+            if (have) {
+                const float4* ep = reinterpret_cast<const float4*>(emb + unit_row(nr, n, u) * EMBW);
+                const float4 e0 = ep[l16], e1 = ep[16 + l16];
+                float s = q0.x * e0.x + q0.y * e0.y + q0.z * e0.z + q0.w * e0.w + q1.x * e1.x + q1.y * e1.y + q1.z * e1.z +
+                          q1.w * e1.w;
+                s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+                if (l16 == 0) tu[n * NUNITS + u] = s;
+            }
+            bits &= bits - 1; bits &= bits - 1; bits &= bits - 1; bits &= bits - 1;   // drop the four lowest set bits
+        }
+    }
+}
+
+// dq[n][c] = sum_u dtu[n][u] * emb[n][u][c]  -> dheadout[n][0..127]; 128 threads (two waves) per env-step.
+// Only units with a non-zero gradient are read: dtu is zero outside the masked-in units of the steps whose
+// target_unit head is live (most steps have none and cost 160 bytes instead of 20 KB).
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ dtu, const float* __restrict__ emb,
                                                          float* __restrict__ dheadout, long long nr) {
-    const int c = threadIdx.x & 127, sub = threadIdx.x >> 7;
+    const int c = threadIdx.x & 127, sub = threadIdx.x >> 7, lane = threadIdx.x & 63;
     for (long long n = (long long)blockIdx.x * 2 + sub; n < nr; n += (long long)gridDim.x * 2) {
         const float* dt = dtu + n * NUNITS;
+        const float mine = lane < NUNITS ? dt[lane] : 0.f;
+        unsigned long long bits = __ballot(mine != 0.f);        // the same in both waves of the step
         float acc = 0.f;
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            const int U = c_t_units[t];
-            const float* p = emb + (nr * c_t_cum[t] + n * U) * EMBW + c;
-            for (int u = 0; u < U; ++u) acc = fmaf(dt[c_t_cum[t] + u], p[(long long)u * EMBW], acc);
+        while (bits) {
+            const int u = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            acc = fmaf(dt[u], emb[unit_row(nr, n, u) * EMBW + c], acc);
         }
         dheadout[n * HO_LD + c] = acc;
     }
@@ -380,6 +426,12 @@ int attn_logits(const float* headout, const float* emb, float* tu, long long nr,
     ProfScope prof("attn_logits", 2.0 * nr * 40 * 128, 4.0 * nr * (40 * 128 + 128 + 40), s);
     hipLaunchKernelGGL(attn_logits_kernel, dim3(grid1d(nr, 4, 256 * 16)), dim3(256), 0, s, headout, emb, tu, nr);
     return launch_check("attn_logits");
+}
+
+int attn_logits_masked(const float* headout, const float* emb, const uint8_t* mask, float* tu, long long nr, hipStream_t s) {
+    ProfScope prof("attn_logits", 2.0 * nr * 40 * 128, 4.0 * nr * (40 * 128 + 128 + 40), s);
+    hipLaunchKernelGGL(attn_logits_masked_kernel, dim3(grid1d(nr, 4, 256 * 16)), dim3(256), 0, s, headout, emb, mask, tu, nr);
+    return launch_check("attn_logits_masked");
 }
 
 int attn_bwd_q(const float* dtu, const float* emb, float* dheadout, long long nr, hipStream_t s) {

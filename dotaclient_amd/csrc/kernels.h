@@ -68,6 +68,8 @@ int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const 
                     float* dW1, float* db1, float* scratch, long long scratch_floats, long long nr, hipStream_t s);
 // heads.hip
 int attn_logits(const float* headout, const float* emb, float* tu, long long nr, hipStream_t s);
+// target-unit logits of the units whose mask byte (mask[n][22 + u]) is set; 0 elsewhere
+int attn_logits_masked(const float* headout, const float* emb, const uint8_t* mask, float* tu, long long nr, hipStream_t s);
 int attn_bwd_q(const float* dtu, const float* emb, float* dheadout, long long nr, hipStream_t s);
 int select_logp(const float* headout, const float* tu, const uint8_t* act, const uint8_t* mask, float* logp_sel,
                 float* values, int32_t* argmax, long long nr, hipStream_t s);

@@ -142,7 +142,8 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
     // all head projections as one GEMM (policy.py:144-155), then the attention logits (policy.py:152)
     DC_TRY(gemm_f32(x, P.p(DC_P_HEADS_W), w.f(DC_WS_HEADOUT), (int)NR, HO_N, H, H, H, HO_LD, 0, 0, P.p(DC_P_HEADS_B), 0,
                     nullptr, 0, 0, 1, s));
-    DC_TRY(attn_logits(w.f(DC_WS_HEADOUT), w.f(DC_WS_EMB), w.f(DC_WS_TU), NR, s));
+    // (DC_DIMS_LAZY_TU: left to dc_select_logp / dc_ppo_loss_fwd_bwd, which know which units are unmasked)
+    if (!(d->flags & DC_DIMS_LAZY_TU)) DC_TRY(attn_logits(w.f(DC_WS_HEADOUT), w.f(DC_WS_EMB), w.f(DC_WS_TU), NR, s));
     return 0;
 }
 

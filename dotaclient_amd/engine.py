@@ -23,9 +23,11 @@ ADAM_EPS = 1e-8
 
 class DcDims(ctypes.Structure):
     _fields_ = [('cell', ctypes.c_int32), ('hidden', ctypes.c_int32), ('layers', ctypes.c_int32),
-                ('n_seq', ctypes.c_int32), ('max_len', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('n_seq', ctypes.c_int32), ('max_len', ctypes.c_int32), ('flags', ctypes.c_int32),
                 ('rows', ctypes.c_int64)]
 
+
+DC_DIMS_LAZY_TU = 1     # include/dotaclient_hip.h
 
 WS_FIXED = ['BASIC', 'EMB', 'DEMB', 'XCAT', 'AMAX', 'PRE', 'HEADOUT', 'TU', 'DHEADOUT', 'DTU', 'DPRE', 'DXCAT',
             'STATS', 'WHHT', 'SCRATCH', 'HEADW_PAD']
@@ -142,8 +144,11 @@ class Engine:
         return {n: self.param_view(n).detach().clone() for n in L.param_shapes(self.cell, self.hidden, self.layers)}
 
     # ---- workspace -------------------------------------------------------------------------------
-    def dims(self, batch):
-        return DcDims(CELL_ID[self.cell], self.hidden, self.layers, batch.n_seq, batch.max_len, 0, batch.rows)
+    def dims(self, batch, lazy_tu=False):
+        """lazy_tu: DC_DIMS_LAZY_TU - the target-unit logits are produced by select_logp / loss for the unmasked
+        units only (the optimizer's passes); False gives DC_WS_TU for every unit (Policy.forward)."""
+        return DcDims(CELL_ID[self.cell], self.hidden, self.layers, batch.n_seq, batch.max_len,
+                      DC_DIMS_LAZY_TU if lazy_tu else 0, batch.rows)
 
     def _workspace(self, d):
         n = len(WS_FIXED) + len(WS_LAYER) * self.layers
@@ -167,8 +172,8 @@ class Engine:
         return self._ws[offs[idx]:nxt].view(dtype)
 
     # ---- C-ABI calls -----------------------------------------------------------------------------
-    def forward(self, batch, h0=None, c0=None, want_final=False):
-        d = self.dims(batch)
+    def forward(self, batch, h0=None, c0=None, want_final=False, lazy_tu=False):
+        d = self.dims(batch, lazy_tu)
         ws = self._workspace(d)
         hT = cT = None
         if want_final:
@@ -216,7 +221,7 @@ class Engine:
         """optimizer.py:328-430 for all rollouts of `batch` at once: no-grad forward with the hidden state
         carried across a rollout's chunks, old log-probs, values, GAE.  Returns the chunk view."""
         from . import ops
-        d, _, _ = self.forward(batch)
+        d, _, _ = self.forward(batch, lazy_tu=True)
         batch.old_logp, batch.values, batch.argmax = self.select_logp(d, batch)
         batch.adv, batch.ret = ops.gae_scan(batch.rew, batch.values, batch.seq_off, batch.seq_len, batch.max_len,
                                             gamma, lam)
@@ -246,7 +251,7 @@ class Engine:
     def train_epoch(self, chunks, lr, entropy_coef, vf_coef, e_clip=0.1, grad_hook=None):
         """optimizer.py:581-689: one full-batch epoch.  Returns the device tensor `out`
         (0 loss, 1 policy, 2 entropy, 3 value, 4..8 entropies, 9 unclipped, 10 clipped) and status."""
-        d, _, _ = self.forward(chunks, chunks.h0, chunks.c0)
+        d, _, _ = self.forward(chunks, chunks.h0, chunks.c0, lazy_tu=True)
         self.loss(d, chunks, e_clip, entropy_coef, vf_coef)
         self.backward(d, chunks)
         if grad_hook is not None:

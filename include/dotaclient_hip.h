@@ -65,9 +65,16 @@ typedef struct dc_dims {
     int32_t layers;   /* 1..DC_MAX_LAYERS */
     int32_t n_seq;    /* B: sequences (trajectory chunks) in the batch */
     int32_t max_len;  /* max(seq_len) */
-    int32_t reserved;
+    int32_t flags;    /* DC_DIMS_* bits; 0 = plain */
     int64_t rows;     /* total env-steps = sum(seq_len) */
 } dc_dims;
+
+/* dc_dims.flags.  DC_DIMS_LAZY_TU: dc_policy_forward does NOT run the dense target-unit attention
+ * (policy.py:152, 20 KB of embeddings per env-step); dc_select_logp / dc_ppo_loss_fwd_bwd - the consumers,
+ * which hold the action masks - compute the logits of the UNMASKED units only (all others are written as 0;
+ * masked_softmax, policy.py:169-178, never lets them reach a result).  Set by the optimizer's two passes;
+ * leave clear when the caller wants DC_WS_TU for every unit (Policy.forward). */
+#define DC_DIMS_LAZY_TU 1
 
 /* index into poff[]; policy.py:54-75 names in comments */
 enum dc_param_index {
