@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void pool_env_fwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(
     const float* __restrict__ obs, const float* __restrict__ xcat, const float* __restrict__ dxcat,
     const float* __restrict__ dtu, const float* __restrict__ q, int ldq, const uint8_t* __restrict__ amax,
-    float* __restrict__ demb, float* __restrict__ partials, long long nr, int steps_per_block) {
+    float* __restrict__ demb, float* __restrict__ partials, long long nr, int steps_per_block, int skip16) {
     constexpr int kU[6] = {1, 5, 16, 16, 1, 1};
     constexpr int kCum[7] = {0, 1, 6, 22, 38, 39, 40};
     const int c = threadIdx.x & 127;
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(
         gw0 = fmaf(de, e[0], gw0); gw1 = fmaf(de, e[1], gw1); gw2 = fmaf(de, e[2], gw2); gb += de;
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
+            if (skip16 && (t == 2 || t == 3)) continue;     // handled by embed_bwd_pool16 without materialising d(emb)
             float* p = demb + (nr * kCum[t] + n * kU[t]) * EMB + c;
             float sum_dt = 0.f;
 #pragma unroll
@@ -318,13 +319,13 @@ int pool_env_fwd(const float* obs, const float* emb, const float* Wenv, const fl
 
 int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, const float* dtu, const float* q, int ldq,
                       const uint8_t* amax, float* demb, float* dWenv, float* dbenv, float* db2, float* scratch,
-                      long long nr, hipStream_t s) {
+                      long long nr, int skip16, hipStream_t s) {
     int spb = (int)((nr + 2047) / 2048);
     if (spb < 4) spb = 4;
     const int nblk = (int)((nr + spb - 1) / spb);        // <= 2048 -> <= 10.5 MB of scratch
     ProfScope prof("embed_scatter_bwd(+reduce)", 2.0 * nr * 40 * 128, 4.0 * nr * (40 * 128 + 896 * 2 + 128 + 40), s);
     hipLaunchKernelGGL(embed_scatter_bwd_kernel, dim3(nblk), dim3(256), 0, s, obs, xcat, dxcat, dtu, q, ldq, amax, demb,
-                       scratch, nr, spb);
+                       scratch, nr, spb, skip16);
     hipLaunchKernelGGL(embed_scatter_reduce_kernel, dim3(5, 32), dim3(256), 0, s, scratch, nblk, dWenv, dbenv, db2);
     return launch_check("embed_scatter_bwd");
 }

@@ -36,6 +36,8 @@ struct EmbTypes {
     int tile_begin[7];        // row_begin / 128
     int wg_begin[7];          // embed_bwd_dw2: first workgroup of type t
     int steps_per_wg;         // embed_bwd_dw2: K steps (32 rows) per workgroup
+    int sparse16;             // backward: the two 16-unit types are handled by embed_bwd_pool16 (embed_sparse.hip);
+                              // their dW2 slab ranges [wg_begin[2], wg_begin[4]) are written by that kernel
 };
 
 __device__ __forceinline__ int ef_type_of_tile(const EmbTypes& ty, int tile) {
@@ -292,6 +294,7 @@ __global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restr
 #pragma unroll
     for (int i = 1; i < 6; ++i)
         if (wg >= ty.wg_begin[i]) t = i;
+    if (ty.sparse16 && (t == 2 || t == 3)) return;      // slab written by embed_bwd_pool16
     const long long steps_t = (ty.row_begin[t + 1] - ty.row_begin[t]) / GEMM_BK;
     const long long s0 = (long long)(wg - ty.wg_begin[t]) * ty.steps_per_wg;
     const int ns = (int)min((long long)ty.steps_per_wg, steps_t - s0);
@@ -409,7 +412,10 @@ __global__ __launch_bounds__(256, 2) void embed_bwd_dw1_kernel(const float* __re
     LA::src_offsets<false>(offa, EF_EMB, 0, 128, wave, lane);
     LB::src_offsets<false>(offb, EF_EMB, 0, 128, wave, lane);
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // sparse16: only the tiles of the four small types; virtual tile v -> the v-th tile outside [tile_begin[2], tile_begin[4])
+    const int skip_lo = ty.sparse16 ? ty.tile_begin[2] : n_tiles, skip_n = ty.sparse16 ? ty.tile_begin[4] - ty.tile_begin[2] : 0;
+    for (int vt = blockIdx.x; vt < n_tiles - skip_n; vt += gridDim.x) {
+        const int tile = vt < skip_lo ? vt : vt + skip_n;
         const int t = ef_type_of_tile(ty, tile);
         const long long row0 = (long long)tile * EF_TILE;
         const float* ga = demb + (size_t)row0 * EF_EMB;
@@ -498,19 +504,24 @@ static const int H_CUM[7] = {0, 1, 6, 22, 38, 39, 40};
 
 bool embed_fused_supported(long long nr) { return nr > 0 && nr % 128 == 0; }
 
-static EmbTypes make_types(long long nr, int* total_wg) {
+enum { SPARSE_WG_PER_TYPE = 128 };   // embed_bwd_pool16: one workgroup per CU over the two 16-unit types
+
+static EmbTypes make_types(long long nr, int* total_wg, bool sparse16 = false) {
     EmbTypes ty;
+    ty.sparse16 = sparse16 ? 1 : 0;
     for (int t = 0; t <= 6; ++t) {
         ty.row_begin[t] = nr * H_CUM[t];
         ty.tile_begin[t] = (int)(ty.row_begin[t] / EF_TILE);
     }
-    const long long total_steps = nr * 40 / GEMM_BK;
+    // dense split-K workgroups: 448 over the types that take the dense path (sparse16: the 8 units of the small types)
+    const long long total_steps = nr * (sparse16 ? 8 : 40) / GEMM_BK;
     int spw = (int)((total_steps + 447) / 448);
     if (spw < 4) spw = 4;
     ty.steps_per_wg = spw;
     int wg = 0;
     for (int t = 0; t < 6; ++t) {
         ty.wg_begin[t] = wg;
+        if (sparse16 && (t == 2 || t == 3)) { wg += SPARSE_WG_PER_TYPE; continue; }
         const long long st = nr * H_UNITS[t] / GEMM_BK;
         wg += (int)((st + spw - 1) / spw);
     }
@@ -561,20 +572,35 @@ int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const fl
 
 // dW2 [6][128][128] (overwritten), dW1 [128][12] / db1 [128] (accumulated into, like unit_basic_bwd);
 // scratch: >= max(total_wg * 16384, 512 * 1664) floats
+// dW2 [6][128][128] (overwritten), dW1 [128][12] / db1 [128] (accumulated into, like unit_basic_bwd).
+// sp != nullptr: the two 16-unit types go through embed_bwd_pool16 (their d(emb) rows need not exist in `demb`, and
+// their second-layer bias gradients are ACCUMULATED into sp->db2 [6][128]); the four small types stay dense.
+// scratch: >= (dense + sparse workgroups) * 16384 + sparse partials floats
 int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const float* b1, const float* W2, float* dW2,
-                    float* dW1, float* db1, float* scratch, long long scratch_floats, long long nr, hipStream_t s) {
+                    float* dW1, float* db1, float* scratch, long long scratch_floats, long long nr, const EmbSparseIn* sp,
+                    hipStream_t s) {
     int nwg;
-    const EmbTypes ty = make_types(nr, &nwg);
-    if ((long long)nwg * EF_EMB * EF_EMB > scratch_floats || 512LL * 1664 > scratch_floats) {
+    const bool sparse16 = sp != nullptr;
+    const EmbTypes ty = make_types(nr, &nwg, sparse16);
+    const long long sp_floats = sparse16 ? 2LL * SPARSE_WG_PER_TYPE * (1664 + 128) : 0;
+    if ((long long)nwg * EF_EMB * EF_EMB + sp_floats > scratch_floats || 512LL * 1664 + sp_floats > scratch_floats) {
         set_error("embed_bwd_fused: scratch too small", 1040);
         return 1040;
+    }
+    float* part1 = scratch + scratch_floats - sp_floats;                 // sparse dW1/db1 partials, then db2 partials
+    float* part2 = part1 + 2LL * SPARSE_WG_PER_TYPE * 1664;
+    if (sparse16) {
+        if (int e = embed_bwd_pool16(obs, sp->dxcat, sp->amax, sp->dtu, sp->q, sp->ldq, W1, b1, W2,
+                                     scratch + (size_t)ty.wg_begin[2] * EF_EMB * EF_EMB, part1, part2, sp->prep, nr, SPARSE_WG_PER_TYPE, s))
+            return e;
     }
     {
         const size_t lds = (size_t)(4 * 4096) * sizeof(float);
         static bool attr = false;
         if (int e = set_lds(embed_bwd_dw2_kernel, lds, &attr)) return e;
         {
-            ProfScope prof("embed_bwd_dw2", 2.0 * nr * 40 * 128 * (128 + 12), 4.0 * nr * 40 * (12 + 128), s);
+            const double units = sparse16 ? 8 : 40;
+            ProfScope prof("embed_bwd_dw2", 2.0 * nr * units * 128 * (128 + 12), 4.0 * nr * units * (12 + 128), s);
             hipLaunchKernelGGL(embed_bwd_dw2_kernel, dim3(nwg), dim3(256), lds, s, obs, demb, W1, b1, scratch, ty);
         }
         if (int e = launch_check("embed_bwd_dw2")) return e;
@@ -585,13 +611,21 @@ int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const 
         static bool attr = false;
         if (int e = set_lds(embed_bwd_dw1_kernel, lds, &attr)) return e;
         const int tiles = (int)(nr * 40 / EF_TILE);
-        const int grid = tiles < 512 ? tiles : 512;
+        const int dense_tiles = sparse16 ? tiles - (ty.tile_begin[4] - ty.tile_begin[2]) : tiles;
+        const int grid = dense_tiles < 512 ? dense_tiles : 512;
         {
-            ProfScope prof("embed_bwd_dw1", 2.0 * nr * 40 * 128 * (128 + 24), 4.0 * nr * 40 * (12 + 128), s);
+            const double units = sparse16 ? 8 : 40;
+            ProfScope prof("embed_bwd_dw1", 2.0 * nr * units * 128 * (128 + 24), 4.0 * nr * units * (12 + 128), s);
             hipLaunchKernelGGL(embed_bwd_dw1_kernel, dim3(grid), dim3(256), lds, s, obs, demb, W1, b1, W2, scratch, ty, tiles);
         }
         if (int e = launch_check("embed_bwd_dw1")) return e;
         if (int e = unit_basic_reduce(scratch, grid, dW1, db1, s)) return e;
+    }
+    if (sparse16) {
+        if (int e = unit_basic_reduce(part1, 2 * SPARSE_WG_PER_TYPE, dW1, db1, s)) return e;
+        for (int t = 2; t < 4; ++t)
+            if (int e = colsum(part2 + (size_t)(t - 2) * SPARSE_WG_PER_TYPE * 128, 128, SPARSE_WG_PER_TYPE, 128, sp->db2 + t * 128, s))
+                return e;
     }
     return 0;
 }

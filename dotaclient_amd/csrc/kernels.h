@@ -51,9 +51,10 @@ int splitk_reduce_grouped(const float* slab, float* C, int M, int N, int n_group
 int unit_basic_fwd(const float* obs, const float* W1, const float* b1, float* basic, long long nr, hipStream_t s);
 int pool_env_fwd(const float* obs, const float* emb, const float* Wenv, const float* benv, float* xcat, uint8_t* amax,
                  long long nr, int residual, hipStream_t s);
+// skip16: the two 16-unit types are left out (no d(emb) rows written, no db2 contribution): embed_bwd_pool16 has them
 int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, const float* dtu, const float* q, int ldq,
                       const uint8_t* amax, float* demb, float* dWenv, float* dbenv, float* db2, float* scratch,
-                      long long nr, hipStream_t s);
+                      long long nr, int skip16, hipStream_t s);
 int unit_basic_bwd(const float* obs, const float* dbasic, float* dW1, float* db1, float* scratch, long long nr,
                    hipStream_t s);
 int colsum(const float* X, int ld, long long rows, int cols, float* out, hipStream_t s);
@@ -64,8 +65,16 @@ bool embed_fused_supported(long long nr);
 // pool_env_fwd with residual = 1 for the env embedding and the 5-unit type only)
 int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const float* W2, const float* b2, float* emb,
                     float* xcat, uint8_t* amax, long long nr, hipStream_t s);
+// inputs of the sparse max-pool backward of the two 16-unit types (embed_sparse.hip); db2 [6][128] is accumulated into
+// (prep: 2 * nr * 320 floats of scratch - the d(emb) rows of the two types, which the sparse path never writes)
+struct EmbSparseIn { const float* dxcat; const uint8_t* amax; const float* dtu; const float* q; int ldq; float* db2; float* prep; };
 int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const float* b1, const float* W2, float* dW2,
-                    float* dW1, float* db1, float* scratch, long long scratch_floats, long long nr, hipStream_t s);
+                    float* dW1, float* db1, float* scratch, long long scratch_floats, long long nr, const EmbSparseIn* sp,
+                    hipStream_t s);
+// embed_sparse.hip
+int embed_bwd_pool16(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq,
+                     const float* W1, const float* b1, const float* W2, float* slab, float* part1, float* part2, float* prep,
+                     long long nr, int wg_per_type, hipStream_t s);
 // heads.hip
 int attn_logits(const float* headout, const float* emb, float* tu, long long nr, hipStream_t s);
 // target-unit logits of the units whose mask byte (mask[n][22 + u]) is set; 0 elsewhere

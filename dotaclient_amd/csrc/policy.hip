@@ -7,13 +7,14 @@
 // workspace_layout() below (sizes depend only on dc_dims), so a whole epoch can be replayed as a
 // hipGraph by the caller.
 #include "../../include/dotaclient_hip.h"
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace dc {
 
 static const int T_UNITS[6] = {1, 5, 16, 16, 1, 1};
 static const int T_CUM[7] = {0, 1, 6, 22, 38, 39, 40};
-enum { EMBW = 128, XCATW = 896, PREW = 256, HO_LD = 160, HO_N = 154, DC_SCRATCH_FLOATS = 8 << 20 };
+enum { EMBW = 128, XCATW = 896, PREW = 256, HO_LD = 160, HO_N = 154, DC_SCRATCH_FLOATS = 16 << 20 };
 
 // parameter offsets (floats) inside the flat buffer, in the order of dc_param_index (header)
 struct Params {
@@ -84,6 +85,15 @@ static int check_dims(const dc_dims* d) {
 }
 
 #define DC_TRY(x) do { int _e = (x); if (_e) return _e; } while (0)
+
+// DC_EMBED_SPARSE=1 routes the two 16-unit types through the sparse max-pool backward (embed_sparse.hip).  Off by
+// default: at the bench batch it is on par with the dense MFMA kernels (378 us vs 385 us for those types) - it does a
+// sixteenth of the MACs but pays ~10 instructions per 512-byte LDS row; see DESIGN.md "next".  Read per call: the GPU
+// tests run both paths in one process.
+static bool embed_sparse_enabled() {
+    const char* e = getenv("DC_EMBED_SPARSE");
+    return e && e[0] == '1';
+}
 
 int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, const float* obs, const float* h0,
                    const float* c0, const int64_t* seq_off, const int32_t* seq_len, void* ws_base, float* hT, float* cT,
@@ -219,14 +229,24 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
                     0, nullptr, 0, 0, 1, s));
 
     // max-pool routing + attention keys -> per-unit embedding gradients; env embedding weights
-    DC_TRY(embed_scatter_bwd(obs, w.f(DC_WS_XCAT), w.f(DC_WS_DXCAT), w.f(DC_WS_DTU), w.f(DC_WS_HEADOUT), HO_LD,
-                             reinterpret_cast<const uint8_t*>(w.base + w.off[DC_WS_AMAX]), w.f(DC_WS_DEMB),
-                             Gd.p(DC_P_ENV_W), Gd.p(DC_P_ENV_B), Gd.p(DC_P_UNIT_B), w.f(DC_WS_SCRATCH), NR, s));
-    if (embed_fused_supported(NR)) {
+    // Fused path, DC_EMBED_SPARSE=1: the two 16-unit types (32 of the 40 units) take the sparse max-pool backward
+    // (embed_sparse.hip: a sixteenth of the dense MACs, no d(emb) in HBM); default: the dense kernels for all types.
+    const bool fusedb = embed_fused_supported(NR);
+    const bool sparse16 = fusedb && embed_sparse_enabled();
+    const uint8_t* amaxp = reinterpret_cast<const uint8_t*>(w.base + w.off[DC_WS_AMAX]);
+    DC_TRY(embed_scatter_bwd(obs, w.f(DC_WS_XCAT), w.f(DC_WS_DXCAT), w.f(DC_WS_DTU), w.f(DC_WS_HEADOUT), HO_LD, amaxp,
+                             w.f(DC_WS_DEMB), Gd.p(DC_P_ENV_W), Gd.p(DC_P_ENV_B), Gd.p(DC_P_UNIT_B), w.f(DC_WS_SCRATCH), NR,
+                             sparse16 ? 1 : 0, s));
+    if (fusedb) {
         // dW2 (split-K with the first layer regenerated as B operand) and dW1/db1 (d(basic) kept in the
         // accumulators) - neither `basic` nor d(basic) exists in HBM on this path
+        // the channel lists of the sparse path live in the d(emb) rows of the two 16-unit types (2 * 16 * 128 floats per
+        // step, never written on that path; the lists take 2 * 320)
+        const EmbSparseIn sp{w.f(DC_WS_DXCAT), amaxp, w.f(DC_WS_DTU), w.f(DC_WS_HEADOUT), HO_LD, Gd.p(DC_P_UNIT_B),
+                             w.f(DC_WS_DEMB) + (size_t)NR * T_CUM[2] * EMBW};
         DC_TRY(embed_bwd_fused(obs, w.f(DC_WS_DEMB), P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), P.p(DC_P_UNIT_W), Gd.p(DC_P_UNIT_W),
-                               Gd.p(DC_P_BASIC_W), Gd.p(DC_P_BASIC_B), w.f(DC_WS_SCRATCH), DC_SCRATCH_FLOATS, NR, s));
+                               Gd.p(DC_P_BASIC_W), Gd.p(DC_P_BASIC_B), w.f(DC_WS_SCRATCH), DC_SCRATCH_FLOATS, NR,
+                               sparse16 ? &sp : nullptr, s));
     } else {
         for (int t = 0; t < 6; ++t) {
             const size_t ro = (size_t)NR * T_CUM[t] * EMBW;

@@ -147,3 +147,31 @@ def test_lstm_persist_variants_agree(monkeypatch, S, lens):
                          eng.grads.cpu().numpy().copy())
     for a, b in zip(outs['mfma'], outs['valu']):
         assert util.scaled_err(a, b) < 2e-5, util.scaled_err(a, b)
+
+
+@pytest.mark.parametrize('lens', [[128] * 4, [256] * 6, [384, 128, 256]])
+def test_sparse_pool_backward_matches_dense(monkeypatch, lens):
+    # fused embedding path (rows % 128 == 0): the sparse max-pool backward of the two 16-unit types
+    # (embed_sparse.hip) against the dense MFMA kernels on the same batch - gradients and post-step parameters
+    from dotaclient_amd.engine import Engine, pack_rollouts
+    dev = torch.device('cuda:0')
+    outs = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('DC_EMBED_SPARSE', mode)
+        eng = Engine('lstm', 128, 1, dev)
+        eng.load_state_dict(synth.init_state_dict(7, 'lstm', 128, 1))
+        rollouts = synth.make_rollouts(91, lens)
+        batch = pack_rollouts(rollouts, 128, dev)
+        chunks = eng.rollout_pass(batch, 128)
+        res, status = eng.train_epoch(chunks, 5e-5, 5e-4, 0.5)
+        assert int(status.item()) == 0
+        g = {n: eng.param_view(n, eng.grads).cpu().numpy().copy() for n in
+             ('affine_unit_basic_stats.weight', 'affine_unit_basic_stats.bias', 'affine_unit_anh.weight',
+              'affine_unit_enh.weight', 'affine_unit_anh.bias', 'affine_unit_enh.bias', 'affine_unit_eh.weight',
+              'affine_unit_ah.bias', 'affine_env.weight')}
+        outs[mode] = (g, res.cpu().numpy().copy(), eng.params.cpu().numpy().copy())
+    for n in outs['0'][0]:
+        a, b = outs['1'][0][n], outs['0'][0][n]
+        assert util.scaled_err(a, b) < 2e-5, (n, util.scaled_err(a, b))
+    assert util.scaled_err(outs['1'][1][:11], outs['0'][1][:11]) < 2e-5
+    assert util.scaled_err(outs['1'][2], outs['0'][2]) < 2e-5
