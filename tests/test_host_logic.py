@@ -55,6 +55,25 @@ def test_pack_rollouts_pads_to_seq_len_multiples():
     assert c.n_seq == 8 and c.seq_off.tolist() == list(range(0, 128, 16))
 
 
+def test_pack_rollouts_matches_flatten_and_reuses_staging():
+    # the direct-to-staging ingest against the per-rollout flattening, twice (the staging buffers are reused, a shorter
+    # rollout in the same slot must not inherit rows of the previous batch)
+    from dotaclient_amd.engine import pack_rollouts
+    for seed, lens in [(5, [40, 64, 7]), (6, [33, 50, 16]), (7, [40, 64, 7])]:
+        rollouts = synth.make_rollouts(seed, lens)
+        b = pack_rollouts(rollouts, 16, torch.device('cpu'))
+        r0 = 0
+        for d, T in zip(rollouts, lens):
+            o, a, m, r = synth.flatten_rollout(d)
+            lp = (T + 15) // 16 * 16
+            assert np.array_equal(b.obs[r0:r0 + T].numpy(), o) and np.array_equal(b.act[r0:r0 + T].numpy(), a)
+            assert np.array_equal(b.mask[r0:r0 + T].numpy(), m) and np.array_equal(b.rew[r0:r0 + T].numpy(), r)
+            for x in (b.obs, b.act, b.mask, b.rew):
+                assert torch.all(x[r0 + T:r0 + lp] == 0)
+            r0 += lp
+        assert b.rows == r0
+
+
 def test_product_path_refuses_cpu():
     from dotaclient_amd import _lib
     from dotaclient_amd.engine import Engine
