@@ -46,6 +46,8 @@ class PackedBatch:
         # filled by the rollout pass
         self.old_logp = self.values = self.adv = self.ret = self.argmax = None
         self.h0 = self.c0 = None
+        self._chunk_meta = {}
+        self.is_first = self.prev_row = None
 
     def as_chunks(self, seq_len):
         """Same rows viewed as B = rows/seq_len sequences of seq_len steps (rollouts are stored padded to a
@@ -53,9 +55,15 @@ class PackedBatch:
         assert self.rows % seq_len == 0
         b = self.rows // seq_len
         dev = self.obs.device
-        out = PackedBatch(self.obs, self.act, self.mask, self.rew,
-                          torch.arange(b, device=dev, dtype=torch.int64) * seq_len,
-                          torch.full((b,), seq_len, device=dev, dtype=torch.int32), seq_len)
+        # layout metadata of the chunk view (depends on the batch's shape only): built once per batch
+        meta = self._chunk_meta.get(seq_len)
+        if meta is None:
+            starts = torch.arange(b, device=dev, dtype=torch.int64) * seq_len
+            meta = {'starts': starts, 'lens': torch.full((b,), seq_len, device=dev, dtype=torch.int32),
+                    'is_first': torch.isin(starts, self.seq_off), 'prev_row': (starts - 1).clamp(min=0)}
+            self._chunk_meta[seq_len] = meta
+        out = PackedBatch(self.obs, self.act, self.mask, self.rew, meta['starts'], meta['lens'], seq_len)
+        out.is_first, out.prev_row = meta['is_first'], meta['prev_row']
         out.old_logp, out.values, out.adv, out.ret, out.argmax = self.old_logp, self.values, self.adv, self.ret, self.argmax
         return out
 
@@ -284,9 +292,7 @@ class Engine:
         chunks = batch.as_chunks(seq_len)
         # initial state of every chunk = state after the previous chunk of the same rollout (detached,
         # optimizer.py:384,408), zeros for a rollout's first chunk (policy.py:77-78)
-        starts = chunks.seq_off
-        is_first = torch.isin(starts, batch.seq_off)
-        prev_row = (starts - 1).clamp(min=0)
+        is_first, prev_row = chunks.is_first, chunks.prev_row
         H = self.hidden
         h0 = []
         c0 = []
