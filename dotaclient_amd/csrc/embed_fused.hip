@@ -74,10 +74,14 @@ __device__ __forceinline__ float ef_basic(const float (&x)[12], const float (&w)
 // steps of 32).  Phase stamps (s_memtime, DC_EF_TIMING=1) of the one-tile-per-workgroup version showed the
 // K loop at 43 % of a tile's life: 26 % went to a prologue that re-loaded W1 and waited for the unit
 // records, 31 % to the epilogue.  Hence the two points below.  What remains (measured per tile and wave, in
-// cycles): K loop 26.8 k for 17.9 k of MFMA issue, epilogue 15.6 k - of which the 64 KB of emb stores cost
-// 10 k plus 7 k of the OTHER resident workgroup's K loop (without the stores: 20.2 k / 8.5 k).  Staggering
-// the workgroups in time (per CU or across the chip) changes nothing: the CU's store path is the limit,
-// and the way past it is not to materialise emb at all ("next").
+// cycles): K loop 26.8 k for 17.9 k of MFMA issue, epilogue 15.6 k.  Experiments: with the emb stores removed
+// altogether 20.2 k / 8.5 k; storing only the rows the attention can read (a quarter of the bytes, WRITE_SIZE
+// 382 -> 127 MB), skipping the store instructions of unneeded rows, non-temporal stores, or staggering the
+// workgroups in time (per CU or across the chip) change NOTHING - so the cost is neither store bytes nor store
+// issue but having stores in flight: every K step's barrier waits vmcnt(0) for its LDS-DMA, vmcnt retires in
+// order, and the previous epilogue's stores sit in front.  The fix is structural (issue the next tile's DMA
+// before the epilogue's stores so that the barrier can wait vmcnt(#stores), which needs a separate LDS transpose
+// buffer), or not materialising emb at all ("next").
 //   * W1 / b1 live in registers for the whole kernel; the NEXT tile's records are loaded during the
 //     current K loop, and its step-0 operands (generated A, DMA'd B) are produced during the current
 //     tile's last K step, in the stage buffer that step does not use - the K steps of consecutive tiles
