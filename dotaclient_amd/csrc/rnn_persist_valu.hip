@@ -32,6 +32,7 @@
 //             lands output 16*wave + (lane >> 2) in all four lanes of its quad.
 // The index logic of both trees is checked on the CPU by tests/test_host_logic.py (numpy emulation of
 // the lane permutations) and on the GPU against the MFMA variant and the oracle.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <utility>
@@ -101,8 +102,12 @@ constexpr int PF = 4;   // global loads run this many steps ahead (L2/MALL laten
 // forward.  gates[row][4H]: W_ih x + b_ih on entry, activated i,f,g,o on exit; hprev/cprev[first row] =
 // h0/c0; h_t, c_t -> hseq/cseq[row] and hprev/cprev[row+1] (exactly lstm_fwd_persist_kernel's contract).
 // ---------------------------------------------------------------------------------------------------
-template <int H>
+template <int H, bool TIMING = false>   // TIMING (DC_LSTM_TIMING=1): s_memtime phase sums of wave 3 of workgroup 0 -> p.dbg
 __global__ __launch_bounds__(4 * H) void lstm_fwd_valu_kernel(RnnStepArgs p) {
+    long long tm[4] = {0, 0, 0, 0}, tm0 = 0;
+    auto stamp = [&](int i) {
+        if constexpr (TIMING) { const long long x = __builtin_amdgcn_s_memtime(); tm[i] += x - tm0; tm0 = x; }
+    };
     constexpr int KPL = H / 16;   // k per lane
     constexpr int NRD = KPL / 4;  // ds_read_b128 per step
     __shared__ __attribute__((aligned(16))) float h_lds[2][H];
@@ -155,6 +160,7 @@ __global__ __launch_bounds__(4 * H) void lstm_fwd_valu_kernel(RnnStepArgs p) {
             hv[2 * i] = __builtin_shufflevector(v, v, 0, 1);
             hv[2 * i + 1] = __builtin_shufflevector(v, v, 2, 3);
         }
+        stamp(0);      // barrier release .. h slice in registers
         f32x2 acc[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) acc[m] = pk_mul_bcast0(wp[m][0], hv[0]);
@@ -168,6 +174,7 @@ __global__ __launch_bounds__(4 * H) void lstm_fwd_valu_kernel(RnnStepArgs p) {
         float a[16];
 #pragma unroll
         for (int m = 0; m < 8; ++m) { a[2 * m] = acc[m].x; a[2 * m + 1] = acc[m].y; }
+        stamp(1);      // packed FMAs
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) a[cc] += dpp<DPP_ROR8>(a[8 + cc]);
 #pragma unroll
@@ -188,9 +195,12 @@ __global__ __launch_bounds__(4 * H) void lstm_fwd_valu_kernel(RnnStepArgs p) {
         // value to the same address as lanes 0,1 - no divergent branch around a memory instruction
         float* const dst = (q >= 2 && t + 1 < len) ? sB : sA;
         dst[(size_t)t * H] = (q & 1) ? cn : hn;
+        stamp(2);      // reduce + cell + stores
         __syncthreads();
+        stamp(3);      // barrier
     };
     int t = 0;
+    if constexpr (TIMING) tm0 = __builtin_amdgcn_s_memtime();
     for (; t + PF <= len; t += PF) {
         float xn[PF];
 #pragma unroll
@@ -212,6 +222,9 @@ __global__ __launch_bounds__(4 * H) void lstm_fwd_valu_kernel(RnnStepArgs p) {
             step(t + 1, xc[1]);
             if (t + 2 < len) step(t + 2, xc[2]);
         }
+    }
+    if constexpr (TIMING) {
+        if (blockIdx.x == 0 && tid == 192 && p.dbg != nullptr) { for (int i = 0; i < 4; ++i) p.dbg[i] = tm[i]; p.dbg[4] = len; }
     }
 }
 
@@ -353,6 +366,19 @@ bool lstm_persist_use_valu(int n_seq) {
 }
 
 int lstm_forward_valu(RnnStepArgs a, hipStream_t s) {
+    static const bool timing = [] { const char* e = getenv("DC_LSTM_TIMING"); return e && e[0] == '1'; }();
+    if (timing && a.H == 128) {   // debugging aid: per-step phase cycles of one wave, printed per launch
+        static long long* dbg = nullptr;
+        if (!dbg) (void)hipMalloc(&dbg, 64);
+        a.dbg = dbg;
+        hipLaunchKernelGGL((lstm_fwd_valu_kernel<128, true>), dim3(a.n_seq), dim3(512), 0, s, a);
+        long long h[5];
+        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        const double st = (double)h[4];
+        fprintf(stderr, "lstm_fwd_valu timing (cycles per step, %lld steps): h read %.0f  packed FMAs %.0f  reduce+cell+stores %.0f  barrier %.0f\n",
+                h[4], h[0] / st, h[1] / st, h[2] / st, h[3] / st);
+        return launch_check("lstm_forward_valu");
+    }
     if (a.H == 128) hipLaunchKernelGGL((lstm_fwd_valu_kernel<128>), dim3(a.n_seq), dim3(512), 0, s, a);
     else if (a.H == 64) hipLaunchKernelGGL((lstm_fwd_valu_kernel<64>), dim3(a.n_seq), dim3(256), 0, s, a);
     else { set_error("lstm_forward_valu: unsupported hidden size", 1011); return 1011; }
