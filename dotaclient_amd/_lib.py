@@ -48,6 +48,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch first: both link libamdhip64.  If this library is loaded before torch, the process ends up with two HIP
+    # runtimes (the system one behind this library, torch's bundled one behind torch) and every launch from here
+    # fails with hipErrorNoDevice - seen with __graft_entry__.build() followed by smoke() in one interpreter.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise DotaHipError('libdotaclient_hip.so not found at %s - run `python -m dotaclient_amd.build` '
                            '(or __graft_entry__.build()); there is no CPU fallback' % LIB_PATH)

@@ -31,6 +31,11 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
 
 }  // namespace dc
 
+// hipGetLastError() is sticky per thread and shared with every other user of the HIP runtime in the process (PyTorch
+// probes devices and pointer attributes and may leave e.g. hipErrorNoDevice / hipErrorInvalidValue behind): clear it
+// on entry, so that launch_check reports only what THIS call enqueued.
+#define DC_ENTER() (void)hipGetLastError()
+
 extern "C" {
 
 int dc_abi_version(void) { return 1; }
@@ -38,12 +43,14 @@ const char* dc_last_error(void) { return dc::g_err; }
 
 int dc_gae_scan(const float* rewards, const float* values, const int64_t* seq_off, const int32_t* seq_len,
                 int n_seq, int max_len, double gamma, double lam, float* adv, float* ret, dc_stream_t stream) {
+    DC_ENTER();
     return dc::gae_scan(rewards, values, seq_off, seq_len, n_seq, max_len, gamma, lam, adv, ret, (hipStream_t)stream);
 }
 
 int dc_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                 int a_kmajor, int b_kmajor, const float* bias, int relu, const float* aux, int ldaux,
                 int accumulate, int splits, dc_stream_t stream) {
+    DC_ENTER();
     return dc::gemm_f32(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, bias, relu, aux, ldaux, accumulate,
                         splits, (hipStream_t)stream);
 }
@@ -55,6 +62,7 @@ int64_t dc_workspace_layout(const dc_dims* dims, int64_t* offsets) { return dc::
 int dc_policy_forward(const dc_dims* dims, const float* params, const int64_t* poff_host, const float* obs,
                       const float* h0, const float* c0, const int64_t* seq_off, const int32_t* seq_len, void* ws,
                       float* hT, float* cT, dc_stream_t stream) {
+    DC_ENTER();
     return dc::policy_forward(dims, params, poff_host, obs, h0, c0, seq_off, seq_len, ws, hT, cT, (hipStream_t)stream);
 }
 
@@ -66,6 +74,7 @@ static float* ws_f(const dc_dims* dims, const void* ws, int idx) {
 
 int dc_select_logp(const dc_dims* dims, const void* ws, const uint8_t* act, const uint8_t* mask, float* logp_sel,
                    float* values, int32_t* argmax, dc_stream_t stream) {
+    DC_ENTER();
     if (dims->rows <= 0) return 0;
     if (dims->flags & DC_DIMS_LAZY_TU)
         if (int e = dc::attn_logits_masked(ws_f(dims, ws, DC_WS_HEADOUT), ws_f(dims, ws, DC_WS_EMB), mask, ws_f(dims, ws, DC_WS_TU),
@@ -78,6 +87,7 @@ int dc_select_logp(const dc_dims* dims, const void* ws, const uint8_t* act, cons
 int dc_ppo_loss_fwd_bwd(const dc_dims* dims, void* ws, const uint8_t* act, const uint8_t* mask, const float* old_logp,
                         const float* adv, const float* ret, float* losses_out, int32_t* head_on, float e_clip,
                         float entropy_coef, float vf_coef, dc_stream_t stream) {
+    DC_ENTER();
     if (dims->rows <= 0) { dc::set_error("ppo_loss: empty batch", 1030); return 1030; }
     if (dims->flags & DC_DIMS_LAZY_TU)
         if (int e = dc::attn_logits_masked(ws_f(dims, ws, DC_WS_HEADOUT), ws_f(dims, ws, DC_WS_EMB), mask, ws_f(dims, ws, DC_WS_TU),
@@ -92,6 +102,7 @@ int dc_ppo_loss_fwd_bwd(const dc_dims* dims, void* ws, const uint8_t* act, const
 int dc_policy_backward(const dc_dims* dims, const float* params, const int64_t* poff_host, float* grads,
                        int64_t total_floats, const float* obs, const int64_t* seq_off, const int32_t* seq_len, void* ws,
                        dc_stream_t stream) {
+    DC_ENTER();
     return dc::policy_backward(dims, params, poff_host, grads, total_floats, obs, seq_off, seq_len, ws, (hipStream_t)stream);
 }
 
@@ -100,6 +111,7 @@ int dc_gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const 
                           const int32_t* head_on, const float* losses, float* norms_out, float* ctl,
                           int32_t* seg_step, int32_t* status, float max_norm, float vf_coef, double lr, double beta1,
                           double beta2, float eps, dc_stream_t stream) {
+    DC_ENTER();
     return dc::gradnorm_clip_adam(seg_off, seg_len, seg_gate, n_seg, max_seg_len, params, grads, m, v, segsq, head_on,
                                   losses, norms_out, ctl, seg_step, status, max_norm, vf_coef, lr, beta1, beta2, eps,
                                   (hipStream_t)stream);
@@ -107,6 +119,7 @@ int dc_gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const 
 
 int dc_dp_average_grads(const int64_t* seg_off, const int32_t* seg_len, const int32_t* seg_gate, int n_seg,
                         int max_seg_len, float* grads, const float* counts, float vf_coef, dc_stream_t stream) {
+    DC_ENTER();
     return dc::dp_average_grads(seg_off, seg_len, seg_gate, n_seg, max_seg_len, grads, counts, vf_coef, (hipStream_t)stream);
 }
 
