@@ -61,14 +61,6 @@ __device__ __forceinline__ const float* ef_record(const float* __restrict__ obs,
     return obs + (size_t)n * EF_OBS + 3 + (ef_cum(t) + (int)u) * 12;
 }
 
-// the one definition of the first layer (same fmaf order in forward and backward)
-__device__ __forceinline__ float ef_basic(const float (&x)[12], const float (&w)[12], float b) {
-    float a = b;
-#pragma unroll
-    for (int f = 0; f < 12; ++f) a = fmaf(x[f], w[f], a);
-    return a;
-}
-
 // ---------------------------------------------------------------------------------------------------
 // forward: persistent workgroups stride over the 128-row tiles (all 128 output channels, K = 128 in 4
 // steps of 32).  Phase stamps (s_memtime, DC_EF_TIMING=1) of the one-tile-per-workgroup version showed the
@@ -77,11 +69,11 @@ __device__ __forceinline__ float ef_basic(const float (&x)[12], const float (&w)
 // cycles): K loop 26.8 k for 17.9 k of MFMA issue, epilogue 15.6 k.  Experiments: with the emb stores removed
 // altogether 20.2 k / 8.5 k; storing only the rows the attention can read (a quarter of the bytes, WRITE_SIZE
 // 382 -> 127 MB), skipping the store instructions of unneeded rows, non-temporal stores, or staggering the
-// workgroups in time (per CU or across the chip) change NOTHING - so the cost is neither store bytes nor store
-// issue but having stores in flight: every K step's barrier waits vmcnt(0) for its LDS-DMA, vmcnt retires in
-// order, and the previous epilogue's stores sit in front.  The fix is structural (issue the next tile's DMA
-// before the epilogue's stores so that the barrier can wait vmcnt(#stores), which needs a separate LDS transpose
-// buffer), or not materialising emb at all ("next").
+// workgroups in time (per CU or across the chip) change NOTHING; an explicit s_waitcnt vmcnt(0) behind the epilogue
+// costs only ~500 cycles (the stores are acknowledged quickly) and leaves the K loop at 27 k.  So it is neither
+// store bytes, nor store issue, nor store latency in front of the DMA barriers - the mechanism by which the
+// presence of the emb stores costs ~7 k cycles in each phase is NOT understood yet; the robust way around it is
+// not to materialise emb at all ("next").
 //   * W1 / b1 live in registers for the whole kernel; the NEXT tile's records are loaded during the
 //     current K loop, and its step-0 operands (generated A, DMA'd B) are produced during the current
 //     tile's last K step, in the stage buffer that step does not use - the K steps of consecutive tiles

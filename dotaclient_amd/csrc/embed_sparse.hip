@@ -59,7 +59,7 @@ enum {
     L_W1 = L_RS + 256,                 // [128][12] W1 (48 registers per thread would not fit next to the accumulators)
     L_TOTAL = L_W1 + 128 * 12
 };
-enum { SP_COMPUTE = 512, SP_SLOTS = 12 };   // compute threads; channels of a unit handled in straight-line code
+enum { SP_SLOTS = 12 };   // channels of a unit handled in straight-line code (a unit holds 8 on average); the rest in a loop
 
 __device__ __forceinline__ f32x2 mk2(float a, float b) { f32x2 r; r.x = a; r.y = b; return r; }
 

@@ -64,10 +64,7 @@ template <int CTRL>
 __device__ __forceinline__ float dpp(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float sigmoid_hw(float x) {   // v_exp_f32 / v_rcp_f32, ~1 ulp each (see rnn_persist.hip)
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
-}
-__device__ __forceinline__ float tanh_hw(float x) {
+__device__ __forceinline__ float tanh_hw(float x) {   // v_exp_f32 / v_rcp_f32, ~1 ulp each (see rnn_persist.hip)
     return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.0f;
 }
 // lanes 32..63 of a <-> lanes 0..31 of b; the sum is then, in the low half, a(l) + a(l+32) and, in the high
