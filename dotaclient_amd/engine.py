@@ -110,6 +110,8 @@ def pack_rollouts(rollouts, seq_len, device):
     ([rows,483] f32 observations, [rows,65] u8 actions and masks, [rows,10] f32 sub-rewards; reused across
     iterations) - no per-rollout temporaries, no concatenation - followed by one asynchronous H2D copy per field
     (four per batch instead of the reference's 17 per chunk)."""
+    if len(rollouts) == 0:
+        raise ValueError('pack_rollouts: no rollouts')
     lens = [(int(d['rewards'].shape[0]) + seq_len - 1) // seq_len * seq_len for d in rollouts]
     rows = int(sum(lens))
     dev = torch.device(device)

@@ -175,3 +175,31 @@ def test_sparse_pool_backward_matches_dense(monkeypatch, lens):
         assert util.scaled_err(a, b) < 2e-5, (n, util.scaled_err(a, b))
     assert util.scaled_err(outs['1'][1][:11], outs['0'][1][:11]) < 2e-5
     assert util.scaled_err(outs['1'][2], outs['0'][2]) < 2e-5
+
+
+def test_full_size_batch_is_invariant_to_trajectory_order():
+    # BASELINE.json-sized batch (96 trajectories x 256 steps, fused embedding path, persistent LSTM) - too large for the
+    # oracle in a test, so a size-independent property instead: the optimizer step is a sum over trajectories, hence
+    # permuting them must leave the losses, the gradient norms and the post-step parameters unchanged (up to fp32
+    # summation order) and must permute the per-step values / advantages with them
+    from dotaclient_amd.engine import Engine, pack_rollouts
+    dev = torch.device('cuda:0')
+    B, S = 96, 256
+    rollouts = synth.make_rollouts(2024, [S] * B)
+    perm = np.random.Generator(np.random.PCG64(5)).permutation(B)
+    outs = []
+    for order in (np.arange(B), perm):
+        eng = Engine('lstm', 128, 1, dev)
+        eng.load_state_dict(synth.init_state_dict(7, 'lstm', 128, 1))
+        batch = pack_rollouts([rollouts[i] for i in order], S, dev)
+        chunks = eng.rollout_pass(batch, S)
+        res, status = eng.train_epoch(chunks, 5e-5, 5e-4, 0.5)
+        assert int(status.item()) == 0
+        r = res.cpu().numpy().astype(np.float64)
+        assert np.all(np.isfinite(r[:11]))
+        outs.append((r[:11], batch.values.view(B, S).cpu().numpy(), batch.adv.view(B, S).cpu().numpy(),
+                     eng.params.cpu().numpy().copy()))
+    (r0, v0, a0, p0), (r1, v1, a1, p1) = outs
+    assert util.rel_err(r1, r0) < 2e-5, (r0, r1)
+    assert np.array_equal(v1, v0[perm]) and np.array_equal(a1, a0[perm])      # per-trajectory work is order-independent
+    assert util.scaled_err(p1, p0) < 1e-6

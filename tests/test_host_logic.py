@@ -74,6 +74,12 @@ def test_pack_rollouts_matches_flatten_and_reuses_staging():
         assert b.rows == r0
 
 
+def test_pack_rollouts_rejects_an_empty_batch():
+    from dotaclient_amd.engine import pack_rollouts
+    with pytest.raises(ValueError):
+        pack_rollouts([], 16, torch.device('cpu'))
+
+
 def test_product_path_refuses_cpu():
     from dotaclient_amd import _lib
     from dotaclient_amd.engine import Engine
