@@ -177,3 +177,91 @@ def test_dp_flat_bucket_matches_reference_semantics(tmp_path):
             if want[r][j] is None:
                 continue                                # grad None in the reference: Adam skips it on this rank
             assert torch.allclose(res[r]['out'][o:o + ln], want[r][j], rtol=1e-6, atol=1e-7), (r, n)
+
+
+# ---- lane-permutation logic of the one-sequence-per-workgroup LSTM kernels (rnn_persist_valu.hip) ------------------
+# numpy emulation of the reduce-scatter trees: which register of which lane holds which column, and the DPP /
+# permlane-swap data movement.  The kernels compute the same index expressions; a mistake there shows up here as a
+# wrong matrix-vector product (the GPU tests then check the real instructions against the oracle).
+def _half_mirror16(l):
+    return (l & 8) | (7 - (l & 7))
+
+
+def _colmap(l, r):
+    if r & 8: l ^= 8
+    if r & 4: l = _half_mirror16(l)
+    if r & 2: l ^= 2
+    if r & 1: l ^= 1
+    return l
+
+
+def _row_dpp(vals, kind):
+    src = {'ror8': lambda i: (i + 8) % 16, 'hm': _half_mirror16, 'x2': lambda i: i ^ 2, 'x1': lambda i: i ^ 1}[kind]
+    return np.array([vals[src(i)] for i in range(16)])
+
+
+@pytest.mark.parametrize('H', [64, 128])
+def test_lstm_valu_forward_reduce_scatter_tree(H):
+    rng = np.random.default_rng(H)
+    kpl = H // 16
+    W, h = rng.standard_normal((4 * H, H)), rng.standard_normal(H)
+    got = np.zeros(4 * H)
+    for jg in range(H // 4):
+        a = np.zeros((16, 16))                       # [row lane kg][register]
+        for kg in range(16):
+            for r in range(16):
+                c = _colmap(kg, r)
+                col = (c & 3) * H + 4 * jg + (c >> 2)
+                ks = [(kk >> 2) * 64 + 4 * kg + (kk & 3) for kk in range(kpl)]
+                a[kg, r] = W[col, ks] @ h[ks]
+        for c in range(8): a[:, c] += _row_dpp(a[:, 8 + c].copy(), 'ror8')
+        for c in range(4): a[:, c] += _row_dpp(a[:, 4 + c].copy(), 'hm')
+        for c in range(2): a[:, c] += _row_dpp(a[:, 2 + c].copy(), 'x2')
+        a[:, 0] += _row_dpp(a[:, 1].copy(), 'x1')
+        for kg in range(16):
+            tid = jg * 16 + kg
+            got[(tid & 3) * H + (tid >> 2)] = a[kg, 0]          # thread tid ends with gate tid & 3 of unit tid >> 2
+    assert np.allclose(got, W @ h, atol=1e-12)
+
+
+@pytest.mark.parametrize('H', [64, 128])
+def test_lstm_valu_backward_reduce_scatter_tree(H):
+    rng = np.random.default_rng(H + 1)
+    kpl = H // 16
+    W, dg = rng.standard_normal((4 * H, H)), rng.standard_normal(4 * H)
+    lds = np.zeros(4 * H)
+    for u in range(H):
+        for q in range(4): lds[4 * u + q] = dg[q * H + u]       # LDS position 4*unit + gate
+    got = np.zeros(H)
+    for wave in range(H // 16):
+        a = np.zeros((64, 16))
+        for l in range(64):
+            Q = (l >> 2) & 3
+            for r in range(16):
+                uo = 16 * wave + ((r & 12) | ((r & 3) ^ Q))
+                for kk in range(kpl):
+                    pos = (kk >> 2) * 256 + 4 * l + (kk & 3)
+                    a[l, r] += W[(pos & 3) * H + (pos >> 2), uo] * lds[pos]
+        s8 = np.zeros((64, 8))
+        for c in range(8):                                        # v_permlane32_swap(a[c], a[8+c]) then add
+            x, y = a[:, c].copy(), a[:, 8 + c].copy()
+            nx, ny = x.copy(), y.copy()
+            nx[32:], ny[:32] = y[:32], x[32:]
+            s8[:, c] = nx + ny
+        s4 = np.zeros((64, 4))
+        for c in range(4):                                        # v_permlane16_swap: odd rows of x <-> even rows of y
+            x, y = s8[:, c].copy(), s8[:, 4 + c].copy()
+            nx, ny = x.copy(), y.copy()
+            for row in (1, 3):
+                nx[16 * row:16 * row + 16] = y[16 * (row - 1):16 * row]
+                ny[16 * (row - 1):16 * row] = x[16 * row:16 * row + 16]
+            s4[:, c] = nx + ny
+        for row in range(4):
+            tr = s4[16 * row:16 * row + 16]
+            for c in range(2): tr[:, c] += _row_dpp(tr[:, 2 + c].copy(), 'ror8')
+            tr[:, 0] += _row_dpp(tr[:, 1].copy(), 'hm')
+            tr[:, 0] += _row_dpp(tr[:, 0].copy(), 'x1')
+            tr[:, 0] += _row_dpp(tr[:, 0].copy(), 'x2')
+        for l in range(64):
+            got[(64 * wave + l) >> 2] = s4[l, 0]                  # all four lanes of a quad hold the unit's sum
+    assert np.allclose(got, dg @ W, atol=1e-12)
