@@ -22,6 +22,7 @@
 //   slab[wg][128][128] (splitk_reduce_grouped), part1[wg][13][128] (unit_basic_reduce), part2[wg][128] (colsum).
 #include <stdio.h>
 #include <stdlib.h>
+#include <utility>
 #include "kernels.h"
 
 namespace dc {
@@ -41,12 +42,15 @@ struct SparseArgs {
     float* prep;      // [2][nr][SP_PREP]: per step and type {d, W2-row byte offset} sorted by arg-max unit [144] | {first, count} [16]
 };
 
-// LDS carve-up (floats)
+// LDS carve-up (floats).  A workgroup runs NS = 2 independent step streams in lock step (one barrier per iteration):
+// twice the independent work per wave between barriers - the per-row chains (broadcast -> address -> LDS -> FMA) are
+// latency-bound with two waves per SIMD, so the second stream is nearly free.
 enum {
-    L_W2 = 0,                          // [128][132] W2_t rows
-    L_BAS = L_W2 + 128 * SP_LD,        // 2 x [16][132] basic of a step (written one iteration ahead)
-    L_RED = L_BAS + 2 * 16 * SP_LD,    // [2][16][128] partials of R and s
-    L_STG = L_RED + 2 * 16 * 128,      // 3 x staging block: the inputs of a step, prepared by the loader wave
+    NS = 2,
+    L_W2 = 0,                               // [128][128] W2_t rows
+    L_BAS = L_W2 + 128 * SP_LD,             // 2 x NS x [16][128] basic of a step (written one iteration ahead)
+    L_RED = L_BAS + 2 * NS * 16 * SP_LD,    // NS x [2][8][128] per-wave partials of R and s
+    L_STG = L_RED + NS * 2 * 8 * 128,       // 3 x NS staging blocks: the inputs of a step
     STG_Q = 0,                         //   q[128]
     STG_PB = 128,                      //   per channel {d, byte offset of basic row a(c)}          [128] x 8 B
     STG_LIST = 384,                    //   channels sorted by arg-max unit: {d, byte offset of W2 row c}, [128 + 16] x 8 B
@@ -55,13 +59,30 @@ enum {
     STG_FLAG = 736,                    //   1 if any dtu != 0
     STG_X = 752,                       //   unit records [16][12]
     STG_SIZE = 944,
-    L_RS = L_STG + 3 * STG_SIZE,       // R[128] | s[128]
-    L_W1 = L_RS + 256,                 // [128][12] W1 (48 registers per thread would not fit next to the accumulators)
+    L_RS = L_STG + 3 * NS * STG_SIZE,       // NS x (R[128] | s[128])
+    L_W1 = L_RS + NS * 256,                 // [128][12] W1
     L_TOTAL = L_W1 + 128 * 12
 };
 enum { SP_SLOTS = 12 };   // channels of a unit handled in straight-line code (a unit holds 8 on average); the rest in a loop
 
 __device__ __forceinline__ f32x2 mk2(float a, float b) { f32x2 r; r.x = a; r.y = b; return r; }
+
+// entry J (0..15) of a gather16 vector in every lane: each 16-lane DPP row holds the sixteen entries, row_newbcast:J
+// copies lane J of every row to the whole row - one VALU instruction (foldable into its consumer), no SGPR round trip
+template <int J>
+__device__ __forceinline__ int bcast16_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, true); }
+template <int J>
+__device__ __forceinline__ float bcast16_f(float v) { return __int_as_float(bcast16_i<J>(__float_as_int(v))); }
+
+template <class F, int... Js>
+__device__ __forceinline__ void for_consts(F&& f, std::integer_sequence<int, Js...>) { (f(std::integral_constant<int, Js>{}), ...); }
+
+// acc += row * d with d wave-uniform: the scalar goes in as an SGPR pair (d, 0) whose low dword feeds both halves
+// (op_sel_hi) - no v_mov pair per row to splat it into vector registers
+__device__ __forceinline__ void pk_fma_s(f32x2& acc, f32x2 row, float d_uniform) {
+    const unsigned long long dd = (unsigned long long)__float_as_uint(d_uniform);
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(row), "s"(dd));
+}
 
 }  // namespace
 
@@ -108,13 +129,14 @@ __global__ __launch_bounds__(256) void embed_pool16_prepare_kernel(SparseArgs p)
     }
 }
 
-// Pass 2.  Workgroup = one type x a contiguous range of env-steps, one step per iteration, one barrier per step.
+// Pass 2.  Workgroup = one type x a contiguous range of env-steps, split into two streams that advance one step per
+// iteration each (one barrier per iteration).
 // Wave w owns units w and w + 8 and the dW2 rows of channels w + 8i (i < 16); lane l owns k = 2l, 2l + 1 - so every
 // row of W2 / basic a wave touches is read by its 64 lanes as 512 contiguous bytes, and WHICH row is wave-uniform: the
 // {value, row offset} entries are fetched sixteen at a time (one 8-byte LDS read by sixteen lanes) and broadcast with
 // v_readlane into scalar registers.  One LDS round trip per row instead of two dependent ones, no divergent loops.
-//   iteration n: every thread hands its (at most four) prefetched values of step n+1 to staging[(n+1) % 3] and issues the
-//   loads of step n+2  -- barrier --  phase A of step n+1 (basic -> bas[(n+1) & 1]), phases B, C, (live), D of step n.
+//   iteration i: every thread hands its prefetched values of iteration i+1 to staging[(i+1) % 3] and issues the loads of
+//   iteration i+2  -- barrier --  phase A of iteration i+1 (basic -> bas[(i+1) & 1]), phases B, C, (live), D of iteration i.
 template <bool TIMING>   // TIMING (DC_SP_TIMING=1): s_memtime phase sums of wave 3 of workgroup 0 -> p.dbg[8]
 __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs p) {
     long long tm[6] = {0, 0, 0, 0, 0, 0}, tm0 = 0;
@@ -151,42 +173,57 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
         for (int f = 0; f < 12; ++f) dW1a[e][f] = 0.f;
     }
 
+    // ---- two step streams: stream s covers steps [nb[s], ne[s]); iteration i works on step nb[s] + i of both ----------
+    const long long half = (n1 - n0 + 1) / 2;
+    const long long nb[NS] = {n0, n0 + half}, ne[NS] = {min(n1, n0 + half), n1};
+    const long long iters = half;
+
     // ---- loader roles: tid < 128 channel tid (d, q, arg-max) | 128..143 dtu | 144..335 record floats | 336..495 prepared list
-    float st_0 = 0.f, st_1 = 0.f;
-    int st_a = 0;
-    auto stage_load = [&](long long n) {
-        if (n >= n1) return;
-        if (tid < 128) {
-            const float* dx = p.dxcat + n * SP_XCAT;
-            st_0 = t == 2 ? dx[3 * 128 + tid] : dx[4 * 128 + tid] + dx[6 * 128 + tid];   // policy.py:127: enh feeds two slots
-            st_1 = p.q[n * p.ldq + tid];
-            st_a = p.amax[(n * 3 + (t - 1)) * 128 + tid];
-        } else if (tid < 144) {
-            st_0 = p.dtu[n * 40 + cum + (tid - 128)];
-        } else if (tid < 336) {
-            st_0 = p.obs[n * SP_OBS + 3 + cum * 12 + (tid - 144)];
-        } else if (tid < 496) {
-            const float2 v = *reinterpret_cast<const float2*>(prep_t + (size_t)n * SP_PREP + 2 * (tid - 336));
-            st_0 = v.x; st_1 = v.y;
+    float st_0[NS] = {0.f, 0.f}, st_1[NS] = {0.f, 0.f};
+    int st_a[NS] = {0, 0};
+    auto stage_load = [&](long long i) {
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) {
+            const long long n = nb[s2] + i;
+            if (n >= ne[s2]) continue;
+            if (tid < 128) {
+                const float* dx = p.dxcat + n * SP_XCAT;
+                st_0[s2] = t == 2 ? dx[3 * 128 + tid] : dx[4 * 128 + tid] + dx[6 * 128 + tid];   // policy.py:127: enh feeds two slots
+                st_1[s2] = p.q[n * p.ldq + tid];
+                st_a[s2] = p.amax[(n * 3 + (t - 1)) * 128 + tid];
+            } else if (tid < 144) {
+                st_0[s2] = p.dtu[n * 40 + cum + (tid - 128)];
+            } else if (tid < 336) {
+                st_0[s2] = p.obs[n * SP_OBS + 3 + cum * 12 + (tid - 144)];
+            } else if (tid < 496) {
+                const float2 v = *reinterpret_cast<const float2*>(prep_t + (size_t)n * SP_PREP + 2 * (tid - 336));
+                st_0[s2] = v.x; st_1[s2] = v.y;
+            }
         }
     };
-    auto hand_over = [&](long long n) {           // registers -> staging[(n - n0) % 3]
-        if (n >= n1) return;
-        float* stg = smem + L_STG + (int)((n - n0) % 3) * STG_SIZE;
-        if (tid < 128) {
-            stg[STG_Q + tid] = st_1;
-            *reinterpret_cast<float2*>(stg + STG_PB + 2 * tid) = make_float2(st_0, __int_as_float(st_a * SP_LD * 4));
-        } else if (tid < 144) {        // lanes 0..15 of wave 2
-            stg[STG_DT + (tid - 128)] = st_0;
-            float sum = st_0;
+    auto stg_of = [&](long long i, int s2) { return smem + L_STG + ((int)(i % 3) * NS + s2) * STG_SIZE; };
+    auto hand_over = [&](long long i) {           // registers -> staging[i % 3][stream]
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
-            const unsigned long long nz = __ballot(st_0 != 0.f) & 0xffffull;
-            if (tid == 128) { stg[STG_DT + 16] = sum; reinterpret_cast<int*>(stg)[STG_FLAG] = nz != 0ull; }
-        } else if (tid < 336) {
-            stg[STG_X + (tid - 144)] = st_0;
-        } else if (tid < 496) {        // LIST [288] and SC [32] are contiguous in the prepared block and in staging
-            *reinterpret_cast<float2*>(stg + STG_LIST + 2 * (tid - 336)) = make_float2(st_0, st_1);
+        for (int s2 = 0; s2 < NS; ++s2) {
+            if (nb[s2] + i >= ne[s2]) continue;
+            float* stg = stg_of(i, s2);
+            if (tid < 128) {
+                stg[STG_Q + tid] = st_1[s2];
+                *reinterpret_cast<float2*>(stg + STG_PB + 2 * tid) = make_float2(st_0[s2], __int_as_float(st_a[s2] * SP_LD * 4));
+            } else if (tid < 144) {        // lanes 0..15 of wave 2
+                stg[STG_DT + (tid - 128)] = st_0[s2];
+                float sum = st_0[s2];          // the sixteen lanes are one DPP row: rotate-and-add, no LDS round trips
+                sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x128, 0xf, 0xf, true));
+                sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x124, 0xf, 0xf, true));
+                sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x122, 0xf, 0xf, true));
+                sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x121, 0xf, 0xf, true));
+                const unsigned long long nz = __ballot(st_0[s2] != 0.f) & 0xffffull;
+                if (tid == 128) { stg[STG_DT + 16] = sum; reinterpret_cast<int*>(stg)[STG_FLAG] = nz != 0ull; }
+            } else if (tid < 336) {
+                stg[STG_X + (tid - 144)] = st_0[s2];
+            } else if (tid < 496) {        // LIST [288] and SC [32] are contiguous in the prepared block and in staging
+                *reinterpret_cast<float2*>(stg + STG_LIST + 2 * (tid - 336)) = make_float2(st_0[s2], st_1[s2]);
+            }
         }
     };
     // sixteen {value, offset} entries starting at `first`, stride `stride` entries -> lanes 0..15 of (val, off)
@@ -195,11 +232,8 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
         val = e.x;
         off = __float_as_int(e.y);
     };
-    auto bcast_f = [&](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
-    auto phase_a = [&](long long n) {             // basic[u][k0..k0+1] of step n, u = w and w + 8 -> bas[(n - n0) & 1]
-        if (n >= n1) return;
-        const float* stg = smem + L_STG + (int)((n - n0) % 3) * STG_SIZE;
-        float* bas = smem + L_BAS + (int)((n - n0) & 1) * 16 * SP_LD;
+    auto bas_of = [&](long long i, int s2) { return smem + L_BAS + ((int)(i & 1) * NS + s2) * 16 * SP_LD; };
+    auto phase_a = [&](long long i) {             // basic[u][k0..k0+1] of iteration i's steps, u = w and w + 8
         // W1 rows k0, k0 + 1 (24 floats); the k-ordered fmaf chain of the MFMA-generated first layer (embed_fused.hip),
         // bias last: bitwise the forward's value, hence its relu mask
         const float4* wp = reinterpret_cast<const float4*>(smem + L_W1 + k0 * 12);
@@ -207,130 +241,172 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
 #pragma unroll
         for (int v = 0; v < 6; ++v) { const float4 q4 = wp[v]; w1[4 * v] = q4.x; w1[4 * v + 1] = q4.y; w1[4 * v + 2] = q4.z; w1[4 * v + 3] = q4.w; }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int u = w + 8 * h;
-            const float4* xp = reinterpret_cast<const float4*>(stg + STG_X + u * 12);     // wave-uniform address
-            const float4 xa = xp[0], xb = xp[1], xc = xp[2];
-            const float x[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
-            float a0 = x[0] * w1[0], a1 = x[0] * w1[12];
+        for (int s2 = 0; s2 < NS; ++s2) {
+            if (nb[s2] + i >= ne[s2]) continue;
+            const float* stg = stg_of(i, s2);
+            float* bas = bas_of(i, s2);
 #pragma unroll
-            for (int f = 1; f < 12; ++f) { a0 = fmaf(x[f], w1[f], a0); a1 = fmaf(x[f], w1[12 + f], a1); }
-            *reinterpret_cast<float2*>(bas + u * SP_LD + k0) = make_float2(fmaxf(a0 + b1r.x, 0.f), fmaxf(a1 + b1r.y, 0.f));
+            for (int h = 0; h < 2; ++h) {
+                const int u = w + 8 * h;
+                const float4* xp = reinterpret_cast<const float4*>(stg + STG_X + u * 12);     // wave-uniform address
+                const float4 xa = xp[0], xb = xp[1], xc = xp[2];
+                const float x[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
+                float a0 = x[0] * w1[0], a1 = x[0] * w1[12];
+#pragma unroll
+                for (int f = 1; f < 12; ++f) { a0 = fmaf(x[f], w1[f], a0); a1 = fmaf(x[f], w1[12 + f], a1); }
+                *reinterpret_cast<float2*>(bas + u * SP_LD + k0) = make_float2(fmaxf(a0 + b1r.x, 0.f), fmaxf(a1 + b1r.y, 0.f));
+            }
         }
     };
 
-    stage_load(n0);
-    hand_over(n0);
-    stage_load(n0 + 1);
+    stage_load(0);
+    hand_over(0);
+    stage_load(1);
     __syncthreads();          // W2 / W1 / staging[0]
-    phase_a(n0);
+    phase_a(0);
 
     const char* w2b = reinterpret_cast<const char*>(smem + L_W2 + k0);     // + W2-row byte offset
-    for (long long n = n0; n < n1; ++n) {
+    for (long long i = 0; i < iters; ++i) {
         if constexpr (TIMING) tm0 = __builtin_amdgcn_s_memtime();
-        hand_over(n + 1);
-        stage_load(n + 2);
+        hand_over(i + 1);
+        stage_load(i + 2);
         stamp(0);
         __syncthreads();
         stamp(1);
-        const float* stg = smem + L_STG + (int)((n - n0) % 3) * STG_SIZE;
-        const bool live = reinterpret_cast<const int*>(stg)[STG_FLAG] != 0;    // workgroup-uniform
-        phase_a(n + 1);
-        const char* basb = reinterpret_cast<const char*>(smem + L_BAS + (int)((n - n0) & 1) * 16 * SP_LD + k0);
-        f32x2 basic[2];
+        phase_a(i + 1);
+        const float* stg[NS];
+        const char* basb[NS];
+        bool on[NS], live[NS];
+        f32x2 basic[NS][2], db[NS][2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) basic[h] = *reinterpret_cast<const f32x2*>(basb + (w + 8 * h) * SP_LD * 4);
-        // ---- phase B: dW2[c][k] += d[c] * basic[a(c)][k], c = w + 8 i ----------------------------------
-        {
-            float dvec; int ovec;
-            gather16(stg + STG_PB, w, 8, dvec, ovec);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float d = bcast_f(dvec, i);
-                const int off = __builtin_amdgcn_readlane(ovec, i);
-                const f32x2 r = *reinterpret_cast<const f32x2*>(basb + off);
-                D[i] = __builtin_elementwise_fma(mk2(d, d), r, D[i]);
-            }
+        for (int s2 = 0; s2 < NS; ++s2) {
+            on[s2] = nb[s2] + i < ne[s2];                                         // workgroup-uniform
+            stg[s2] = stg_of(i, s2);
+            basb[s2] = reinterpret_cast<const char*>(bas_of(i, s2) + k0);
+            live[s2] = on[s2] && reinterpret_cast<const int*>(stg[s2])[STG_FLAG] != 0;
+            db[s2][0] = mk2(0.f, 0.f); db[s2][1] = mk2(0.f, 0.f);
+            basic[s2][0] = mk2(0.f, 0.f); basic[s2][1] = mk2(0.f, 0.f);
         }
-        stamp(2);
-        // ---- phase C: dbasic[u][k] = sum over the unit's channels of d[c] * W2[c][k], u = w, w + 8 --------
-        f32x2 db[2] = {mk2(0.f, 0.f), mk2(0.f, 0.f)};
-        {
+        // ---- phase B: dW2[c][k] += d[c] * basic[a(c)][k], c = w + 8 i;  phase C: dbasic[u][k] = sum over the unit's
+        // channels of d[c] * W2[c][k], u = w, w + 8 - for both streams
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) {
+            if (!on[s2]) continue;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) basic[s2][h] = *reinterpret_cast<const f32x2*>(basb[s2] + (w + 8 * h) * SP_LD * 4);
+            {
+                float dvec; int ovec;
+                gather16(stg[s2] + STG_PB, w, 8, dvec, ovec);
+                const char* bb = basb[s2];
+                for_consts([&](auto CC) {
+                    constexpr int C = decltype(CC)::value;
+                    const f32x2 r = *reinterpret_cast<const f32x2*>(bb + bcast16_i<C>(ovec));
+                    const float d = bcast16_f<C>(dvec);
+                    D[C].x = fmaf(d, r.x, D[C].x);
+                    D[C].y = fmaf(d, r.y, D[C].y);
+                }, std::make_integer_sequence<int, 16>{});
+            }
             float scv; int scc;
-            gather16(stg + STG_SC, 0, 1, scv, scc);          // lane u: {first entry, count} of unit u
+            gather16(stg[s2] + STG_SC, 0, 1, scv, scc);          // lane u: {first entry, count} of unit u
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int first = __builtin_amdgcn_readlane(__float_as_int(scv), w + 8 * h);
                 const int cnt = __builtin_amdgcn_readlane(scc, w + 8 * h);
                 float dvec; int ovec;
-                gather16(stg + STG_LIST, first, 1, dvec, ovec);
-#pragma unroll
-                for (int j = 0; j < SP_SLOTS; ++j) {
-                    const float dj = bcast_f(dvec, j);
-                    const int off = __builtin_amdgcn_readlane(ovec, j);
-                    const float d = j < cnt ? dj : 0.f;       // past the unit's segment: the next unit's entry, weight 0
-                    const f32x2 wv = *reinterpret_cast<const f32x2*>(w2b + off);
-                    db[h] = __builtin_elementwise_fma(mk2(d, d), wv, db[h]);
-                }
+                gather16(stg[s2] + STG_LIST, first, 1, dvec, ovec);
+                dvec = (lane & 15) < cnt ? dvec : 0.f;        // past the unit's segment: the next unit's entries, weight 0
+                f32x2& dbh = db[s2][h];
+                auto slot = [&](auto JC) {
+                    constexpr int J = decltype(JC)::value;
+                    const f32x2 wv = *reinterpret_cast<const f32x2*>(w2b + bcast16_i<J>(ovec));
+                    const float d = bcast16_f<J>(dvec);
+                    dbh.x = fmaf(d, wv.x, dbh.x);
+                    dbh.y = fmaf(d, wv.y, dbh.y);
+                };
+                for_consts(slot, std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>{});         // a unit holds 8 channels on average
+                if (cnt > 8) for_consts(slot, std::integer_sequence<int, 8, 9, 10, 11>{});      // wave-uniform
                 for (int j = SP_SLOTS; j < cnt; ++j) {        // wave-uniform trip count
-                    const float2 e = *reinterpret_cast<const float2*>(stg + STG_LIST + 2 * (first + j));
+                    const float2 e = *reinterpret_cast<const float2*>(stg[s2] + STG_LIST + 2 * (first + j));
                     const f32x2 wv = *reinterpret_cast<const f32x2*>(w2b + __float_as_int(e.y));
-                    db[h] = __builtin_elementwise_fma(mk2(e.x, e.x), wv, db[h]);
+                    db[s2][h] = __builtin_elementwise_fma(mk2(e.x, e.x), wv, db[s2][h]);
                 }
             }
         }
+        stamp(2);
         stamp(3);
-        if (live) {
+        if (live[0] || live[1]) {
             // rank-one attention terms: d(emb)[u][c] += dtu[u] q[c]
             //   dbasic[u][k] += dtu[u] * R[k],  R[k] = sum_c q[c] W2[c][k]
             //   dW2[c][k]    += q[c] * s[k],    s[k] = sum_u dtu[u] basic[u][k]
-            const float dt0 = stg[STG_DT + w], dt1 = stg[STG_DT + w + 8];
-            const float qvec = stg[STG_Q + w + 8 * (lane & 15)];       // lane i: q of channel w + 8 i
-            float* red = smem + L_RED;
-            f32x2 r = mk2(0.f, 0.f);
+            float dt0[NS] = {0.f, 0.f}, dt1[NS] = {0.f, 0.f}, qvec[NS] = {0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float qc = bcast_f(qvec, i);
-                const f32x2 wv = *reinterpret_cast<const f32x2*>(w2b + (w + 8 * i) * SP_LD * 4);
-                r = __builtin_elementwise_fma(mk2(qc, qc), wv, r);
+            for (int s2 = 0; s2 < NS; ++s2) {
+                if (!live[s2]) continue;
+                dt0[s2] = stg[s2][STG_DT + w]; dt1[s2] = stg[s2][STG_DT + w + 8];
+                qvec[s2] = stg[s2][STG_Q + w + 8 * (lane & 15)];       // lane c: q of channel w + 8 c
+                float* red = smem + L_RED + s2 * 2048;
+                f32x2 r = mk2(0.f, 0.f);
+                const float qv16 = qvec[s2];
+                for_consts([&](auto CC) {
+                    constexpr int C = decltype(CC)::value;
+                    const float qc = bcast16_f<C>(qv16);
+                    const f32x2 wv = *reinterpret_cast<const f32x2*>(w2b + (w + 8 * C) * SP_LD * 4);
+                    r.x = fmaf(qc, wv.x, r.x);
+                    r.y = fmaf(qc, wv.y, r.y);
+                }, std::make_integer_sequence<int, 16>{});
+                *reinterpret_cast<f32x2*>(red + w * 128 + k0) = r;
+                *reinterpret_cast<f32x2*>(red + 1024 + w * 128 + k0) =
+                    mk2(dt0[s2], dt0[s2]) * basic[s2][0] + mk2(dt1[s2], dt1[s2]) * basic[s2][1];
             }
-            *reinterpret_cast<f32x2*>(red + w * 128 + k0) = r;
-            *reinterpret_cast<f32x2*>(red + 2048 + w * 128 + k0) = mk2(dt0, dt0) * basic[0] + mk2(dt1, dt1) * basic[1];
             __syncthreads();
-            if (tid < 256) {         // R[k] (tid < 128) and s[k] (128 <= tid < 256): sums over the 8 waves, fixed order
-                const float* src = red + (tid >> 7) * 2048 + (tid & 127);
-                float acc = 0.f;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc += src[u * 128];
-                smem[L_RS + tid] = acc;
+            for (int s2 = 0; s2 < NS; ++s2) {
+                if (!live[s2]) continue;
+                if (tid < 256) {     // R[k] (tid < 128) and s[k] (128 <= tid < 256): sums over the 8 waves, fixed order
+                    const float* src = smem + L_RED + s2 * 2048 + (tid >> 7) * 1024 + (tid & 127);
+                    float acc = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += src[u * 128];
+                    smem[L_RS + s2 * 256 + tid] = acc;
+                }
             }
             __syncthreads();
-            const f32x2 R = *reinterpret_cast<const f32x2*>(smem + L_RS + k0);
-            const f32x2 S = *reinterpret_cast<const f32x2*>(smem + L_RS + 128 + k0);
-            db[0] = __builtin_elementwise_fma(mk2(dt0, dt0), R, db[0]);
-            db[1] = __builtin_elementwise_fma(mk2(dt1, dt1), R, db[1]);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float qc = bcast_f(qvec, i);
-                D[i] = __builtin_elementwise_fma(mk2(qc, qc), S, D[i]);
+            for (int s2 = 0; s2 < NS; ++s2) {
+                if (!live[s2]) continue;
+                const f32x2 R = *reinterpret_cast<const f32x2*>(smem + L_RS + s2 * 256 + k0);
+                const f32x2 S = *reinterpret_cast<const f32x2*>(smem + L_RS + s2 * 256 + 128 + k0);
+                db[s2][0] = __builtin_elementwise_fma(mk2(dt0[s2], dt0[s2]), R, db[s2][0]);
+                db[s2][1] = __builtin_elementwise_fma(mk2(dt1[s2], dt1[s2]), R, db[s2][1]);
+                const float qv16 = qvec[s2];
+                for_consts([&](auto CC) {
+                    constexpr int C = decltype(CC)::value;
+                    const float qc = bcast16_f<C>(qv16);
+                    D[C].x = fmaf(qc, S.x, D[C].x);
+                    D[C].y = fmaf(qc, S.y, D[C].y);
+                }, std::make_integer_sequence<int, 16>{});
             }
         }
         stamp(4);
         // ---- phase D: through the relu into dW1 / db1; second-layer bias gradient -----------------------
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float4* xp = reinterpret_cast<const float4*>(stg + STG_X + (w + 8 * h) * 12);
-            const float4 xa = xp[0], xb = xp[1], xc = xp[2];
-            const float x[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
-            const float dbm[2] = {basic[h].x > 0.f ? db[h].x : 0.f, basic[h].y > 0.f ? db[h].y : 0.f};
+        for (int s2 = 0; s2 < NS; ++s2) {
+            if (!on[s2]) continue;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
+            for (int h = 0; h < 2; ++h) {
+                const float4* xp = reinterpret_cast<const float4*>(stg[s2] + STG_X + (w + 8 * h) * 12);
+                const float4 xa = xp[0], xb = xp[1], xc = xp[2];
+                const float x[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
+                const float dbm[2] = {basic[s2][h].x > 0.f ? db[s2][h].x : 0.f, basic[s2][h].y > 0.f ? db[s2][h].y : 0.f};
 #pragma unroll
-                for (int f = 0; f < 12; ++f) dW1a[e][f] = fmaf(dbm[e], x[f], dW1a[e][f]);
-                db1a[e] += dbm[e];
+                for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                    for (int f = 0; f < 12; ++f) dW1a[e][f] = fmaf(dbm[e], x[f], dW1a[e][f]);
+                    db1a[e] += dbm[e];
+                }
             }
+            if (tid < 128) db2a += stg[s2][STG_PB + 2 * tid] + (live[s2] ? stg[s2][STG_Q + tid] * stg[s2][STG_DT + 16] : 0.f);   // column sum of d(emb)
         }
-        if (tid < 128) db2a += stg[STG_PB + 2 * tid] + (live ? stg[STG_Q + tid] * stg[STG_DT + 16] : 0.f);   // column sum of d(emb)
         stamp(5);
     }
 

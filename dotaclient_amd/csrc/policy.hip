@@ -86,13 +86,12 @@ static int check_dims(const dc_dims* d) {
 
 #define DC_TRY(x) do { int _e = (x); if (_e) return _e; } while (0)
 
-// DC_EMBED_SPARSE=1 routes the two 16-unit types through the sparse max-pool backward (embed_sparse.hip).  Off by
-// default: at the bench batch it is on par with the dense MFMA kernels (378 us vs 385 us for those types) - it does a
-// sixteenth of the MACs but pays ~10 instructions per 512-byte LDS row; see DESIGN.md "next".  Read per call: the GPU
-// tests run both paths in one process.
+// The two 16-unit types go through the sparse max-pool backward (embed_sparse.hip: a sixteenth of the MACs, no d(emb)
+// in HBM; 290 us against 385 us for the dense MFMA kernels on the same units at the bench batch).  DC_EMBED_SPARSE=0
+// forces the dense kernels for every type.  Read per call: the GPU tests run both paths in one process.
 static bool embed_sparse_enabled() {
     const char* e = getenv("DC_EMBED_SPARSE");
-    return e && e[0] == '1';
+    return !(e && e[0] == '0');
 }
 
 int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, const float* obs, const float* h0,
@@ -229,8 +228,8 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
                     0, nullptr, 0, 0, 1, s));
 
     // max-pool routing + attention keys -> per-unit embedding gradients; env embedding weights
-    // Fused path, DC_EMBED_SPARSE=1: the two 16-unit types (32 of the 40 units) take the sparse max-pool backward
-    // (embed_sparse.hip: a sixteenth of the dense MACs, no d(emb) in HBM); default: the dense kernels for all types.
+    // Fused path: the two 16-unit types (32 of the 40 units) take the sparse max-pool backward (embed_sparse.hip);
+    // DC_EMBED_SPARSE=0: the dense kernels for all types.
     const bool fusedb = embed_fused_supported(NR);
     const bool sparse16 = fusedb && embed_sparse_enabled();
     const uint8_t* amaxp = reinterpret_cast<const uint8_t*>(w.base + w.off[DC_WS_AMAX]);
