@@ -216,7 +216,13 @@ def main():
                             'achieved_tflops': round(r['flops'] / (r['total_ms'] * 1e-3) / 1e12, 3)})
         dom = regions[0]
         achieved = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
-        roofline = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS,
+        # every region on this list is priced against the dense f32 rate of the chip, 157.3 TF: it is both the f32 MFMA
+        # peak (the GEMM-shaped kernels) and the packed-f32 VALU peak (the sparse max-pool backward and the recurrent
+        # kernels, whose algorithmic flop counts are the sparse / per-sequence ones)
+        notes = {'embed_bwd_pool16': 'f32 VALU kernel (gathers of 512-byte W2 / basic rows scaled per channel): 1/16 of the '
+                                     'dense MACs; its own limits are VALU issue and LDS bandwidth, not the matrix pipes',
+                 'lstm_fwd_persist': 'recurrence, serial in time: latency-bound', 'lstm_bwd_persist': 'recurrence, serial in time: latency-bound'}
+        roofline = {'bound': 'mfma', 'bound_note': notes.get(dom['kernel'], 'f32 MFMA (v_mfma_f32_32x32x2_f32)'), 'kernel': dom['kernel'], 'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                     'traffic': pmc_traffic(args.traffic_json, dom['kernel'], '%s-%d-%dx%d' % (args.cell, args.hidden, B, S)),
                     'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, %s)' % os.path.relpath(args.traffic_json, REPO),
