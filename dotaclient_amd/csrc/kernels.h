@@ -103,6 +103,11 @@ int lstm_backward_persist(RnnStepArgs a, int max_len, hipStream_t s);
 bool lstm_persist_use_valu(int n_seq);
 int lstm_forward_valu(RnnStepArgs a, hipStream_t s);
 int lstm_backward_valu(RnnStepArgs a, hipStream_t s);
+// rnn_team.hip (GRU / LSTM with H = 256: all time steps in one launch, a sequence's W_hh spread over the registers
+// of four workgroups that exchange the state every step)
+bool rnn_team_supported(int cell, int H, int n_seq);
+int rnn_team_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s);
+int rnn_team_backward(int cell, RnnStepArgs a, int max_len, hipStream_t s);
 // adam.hip
 int gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const int32_t* seg_gate, int n_seg, int max_seg_len,
                        float* param, float* grad, float* m, float* v, double* segsq, const int32_t* head_on,

@@ -310,6 +310,7 @@ bool rnn_uses_persistent(int cell, int H) { return cell == CELL_LSTM && lstm_per
 int rnn_forward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     if (int e = check_h(a.H)) return e;
     if (cell == CELL_LSTM && lstm_persist_supported(a.H) && persist_enabled()) return lstm_forward_persist(a, max_len, s);
+    if (persist_enabled() && rnn_team_supported(cell, a.H, a.n_seq)) return rnn_team_forward(cell, a, max_len, s);
     dim3 grid(a.H / 16, (a.n_seq + 15) / 16);
     for (int t = 0; t < max_len; ++t) {
         a.t = t;
@@ -325,6 +326,7 @@ int rnn_forward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
 int rnn_backward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     if (int e = check_h(a.H)) return e;
     if (cell == CELL_LSTM && lstm_persist_supported(a.H) && persist_enabled()) return lstm_backward_persist(a, max_len, s);
+    if (persist_enabled() && rnn_team_supported(cell, a.H, a.n_seq)) return rnn_team_backward(cell, a, max_len, s);
     dim3 grid(a.H / 16, (a.n_seq + 15) / 16);
     for (int t = max_len - 1; t >= 0; --t) {
         a.t = t;

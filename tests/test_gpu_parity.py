@@ -149,6 +149,32 @@ def test_lstm_persist_variants_agree(monkeypatch, S, lens):
         assert util.scaled_err(a, b) < 2e-5, util.scaled_err(a, b)
 
 
+@pytest.mark.parametrize('cell', ['gru', 'lstm'])
+@pytest.mark.parametrize('S,lens', [(256, [256] * 6), (7, [21, 7, 13, 30, 1, 44]), (5, [350]), (16, [50, 64, 33])])
+def test_rnn_team_kernels_agree_with_per_step(monkeypatch, cell, S, lens):
+    # H = 256 (the reference's GRU, the LSTM-256 configs): the four-workgroups-per-sequence persistent kernels
+    # (rnn_team.hip) against the launch-per-step kernels on the same batch.  6 / 17 / 70 / 11 chunk sequences: fewer
+    # teams than 8 (plain block -> team map), 16 teams with one sequence left over, more sequences than the 64 teams
+    # (a team walks through two sequences: tag / ring continuity across the boundary), every remainder of the
+    # 4-step groups.  The two differ only in summation order.
+    from dotaclient_amd.engine import Engine, pack_rollouts
+    dev = torch.device('cuda:0')
+    outs = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('DC_RNN_TEAM', mode)
+        eng = Engine(cell, 256, 1, dev)
+        eng.load_state_dict(synth.init_state_dict(7, cell, 256, 1))
+        rollouts = synth.make_rollouts(78, lens)
+        batch = pack_rollouts(rollouts, S, dev)
+        chunks = eng.rollout_pass(batch, S)
+        res, status = eng.train_epoch(chunks, 5e-5, 5e-4, 0.5)
+        assert int(status.item()) == 0
+        outs[mode] = (batch.values.cpu().numpy().copy(), batch.adv.cpu().numpy().copy(), res.cpu().numpy().copy(),
+                      eng.grads.cpu().numpy().copy())
+    for a, b in zip(outs['0'], outs['1']):
+        assert util.scaled_err(a, b) < 2e-5, util.scaled_err(a, b)
+
+
 @pytest.mark.parametrize('lens', [[128] * 4, [256] * 6, [384, 128, 256]])
 def test_sparse_pool_backward_matches_dense(monkeypatch, lens):
     # fused embedding path (rows % 128 == 0): the sparse max-pool backward of the two 16-unit types

@@ -265,3 +265,83 @@ def test_lstm_valu_backward_reduce_scatter_tree(H):
         for l in range(64):
             got[(64 * wave + l) >> 2] = s4[l, 0]                  # all four lanes of a quad hold the unit's sum
     assert np.allclose(got, dg @ W, atol=1e-12)
+
+
+# ---- the four-workgroup team kernels for H = 256 (rnn_team.hip): same emulation, plus the split over members ---------
+def _swap32_sum(x, y):
+    nx, ny = x.copy(), y.copy()
+    nx[32:], ny[:32] = y[:32], x[32:]
+    return nx + ny
+
+
+def _swap16_sum(x, y):
+    nx, ny = x.copy(), y.copy()
+    for row in (1, 3):
+        nx[16 * row:16 * row + 16] = y[16 * (row - 1):16 * row]
+        ny[16 * (row - 1):16 * row] = x[16 * row:16 * row + 16]
+    return nx + ny
+
+
+@pytest.mark.parametrize('G', [3, 4])
+def test_rnn_team_forward_tree(G):
+    H, US = 256, 64
+    rng = np.random.default_rng(G)
+    W, h = rng.standard_normal((G * H, H)), rng.standard_normal(H)
+    got = np.full(G * H, np.nan)
+    for member in range(4):
+        U0 = member * US
+        for row in range(32):
+            a = np.zeros((16, 8))
+            for kg in range(16):
+                for r in range(8):
+                    c = _colmap(kg, r) & 7
+                    gate, unit = c & 3, U0 + 2 * row + (c >> 2)
+                    ks = [(kk >> 2) * 64 + 4 * kg + (kk & 3) for kk in range(16)]
+                    a[kg, r] = W[gate * H + unit, ks] @ h[ks] if gate < G else 0.0
+            for c in range(4): a[:, c] += _row_dpp(a[:, 4 + c].copy(), 'hm')
+            for c in range(2): a[:, c] += _row_dpp(a[:, 2 + c].copy(), 'x2')
+            a[:, 0] += _row_dpp(a[:, 1].copy(), 'x1')
+            a[:, 0] += _row_dpp(a[:, 0].copy(), 'ror8')
+            for kg in range(16):
+                tid = row * 16 + kg
+                q, u = tid & 3, U0 + 2 * row + ((tid >> 2) & 1)      # both "dup" halves of the row hold the same column
+                if q < G:
+                    assert np.isnan(got[q * H + u]) or got[q * H + u] == a[kg, 0]
+                    got[q * H + u] = a[kg, 0]
+    assert np.allclose(got, W @ h, atol=1e-12)
+
+
+@pytest.mark.parametrize('G', [3, 4])
+def test_rnn_team_backward_tree(G):
+    H, US = 256, 64
+    rng = np.random.default_rng(10 + G)
+    W, dg = rng.standard_normal((G * H, H)), rng.standard_normal(G * H)
+    lds = np.zeros(4 * H)                                            # position 4*unit + gate slot (slot 3 of the GRU: 0)
+    for u in range(H):
+        for q in range(G): lds[4 * u + q] = dg[q * H + u]
+    got = np.zeros(H)
+    for member in range(4):
+        U0 = member * US
+        for wave in range(8):
+            a = np.zeros((64, 8))
+            for l in range(64):
+                b3 = (l >> 3) & 1
+                for r in range(8):
+                    uo = U0 + 8 * wave + ((r & 6) | ((r & 1) ^ b3))
+                    for kk in range(16):
+                        pos = (kk >> 2) * 256 + 4 * l + (kk & 3)
+                        gate, unit = pos & 3, pos >> 2
+                        if gate < G: a[l, r] += W[gate * H + unit, uo] * lds[pos]
+            s4 = np.stack([_swap32_sum(a[:, c], a[:, 4 + c]) for c in range(4)], axis=1)
+            s2 = np.stack([_swap16_sum(s4[:, c], s4[:, 2 + c]) for c in range(2)], axis=1)
+            for row in range(4):
+                tr = s2[16 * row:16 * row + 16]
+                tr[:, 0] += _row_dpp(tr[:, 1].copy(), 'ror8')
+                tr[:, 0] += _row_dpp(tr[:, 0].copy(), 'hm')
+                tr[:, 0] += _row_dpp(tr[:, 0].copy(), 'x1')
+                tr[:, 0] += _row_dpp(tr[:, 0].copy(), 'x2')
+            for l in range(64):
+                u = U0 + 8 * wave + (l >> 3)
+                assert l & 7 == 0 or np.isclose(got[u], s2[l, 0])    # all eight lanes of a group agree
+                got[u] = s2[l, 0]
+    assert np.allclose(got, dg @ W, atol=1e-12)
