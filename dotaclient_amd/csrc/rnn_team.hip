@@ -45,9 +45,8 @@
 namespace dc {
 namespace {
 
-enum { TEAM_H = 256, TEAM_US = 64, TEAM_M = 4, TEAM_SLOTS = 4, TEAM_MAX = 64 };
+enum { TEAM_H = 256, TEAM_US = 64, TEAM_M = 4, TEAM_SLOTS = 4, TEAM_MAX = 64, TEAM_NS_MAX = 4 };
 enum { CELL_GRU = 0, CELL_LSTM = 1 };
-constexpr int PF = 4;
 constexpr int SPIN_LIMIT = 1 << 21;   // polls (~0.5-1 us each) before a member gives up
 
 typedef unsigned long long u64;
@@ -56,9 +55,8 @@ __device__ __forceinline__ u64 granule_load(const u64* p) { return __hip_atomic_
 __device__ __forceinline__ void granule_store(u64* p, float v, unsigned tag) {
     __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// spins until the granule carries `tag`; false on timeout
-__device__ __forceinline__ bool granule_wait(const u64* p, unsigned tag, float& v) {
-    u64 g = granule_load(p);
+// spins until the granule carries `tag`; false on timeout.  g = a first read of the granule (possibly issued long ago)
+__device__ __forceinline__ bool granule_wait(u64 g, const u64* p, unsigned tag, float& v) {
     int n = 0;
     while ((unsigned)(g >> 32) != tag) {
         if (++n > SPIN_LIMIT) return false;
@@ -89,12 +87,19 @@ __device__ __forceinline__ void team_of_block(int n_teams, int& team, int& membe
 // forward.  Same contract as the per-step kernels of rnn.hip: gates[row][G*H] = W_ih x + b_ih on entry,
 // activated gates on exit; hprev/cprev[first row] = h0/c0; h_t (c_t) -> hseq (cseq)[row] and
 // hprev (cprev)[row+1]; GRU: hn[row] = W_hn h + b_hn.
+// NS = sequences a team works on concurrently ("streams", round-robin one step each): a step is ~0.45 us of
+// work and ~1 us of waiting for the peers' granules, so with more sequences than teams the wait of one
+// stream is filled with the work of the others.  Stream s of team T owns sequences T*NS + s + k*NS*teams.
 // ---------------------------------------------------------------------------------------------------
-template <int CELL>
+template <int CELL, int NS, bool TIMING = false>   // TIMING (DC_TEAM_TIMING=1): s_memtime phase sums of wave 0 of block 0 -> p.dbg
 __global__ __launch_bounds__(512) void rnn_team_fwd_kernel(RnnStepArgs p, u64* __restrict__ xbuf, int n_teams) {
     constexpr int H = TEAM_H, G = CELL == CELL_GRU ? 3 : 4, GH = G * H;
     constexpr int KPL = 16, NRD = 4;
-    __shared__ __attribute__((aligned(16))) float h_lds[2][H];
+    long long tm[6] = {0, 0, 0, 0, 0, 0}, tm0 = 0;
+    auto stamp = [&](int i) {
+        if constexpr (TIMING) { const long long x = __builtin_amdgcn_s_memtime(); tm[i] += x - tm0; tm0 = x; }
+    };
+    __shared__ __attribute__((aligned(16))) float h_lds[NS][2][H];
     __shared__ int dead;
     const int tid = threadIdx.x;
     const int kg = tid & 15, row = tid >> 4;
@@ -103,7 +108,6 @@ __global__ __launch_bounds__(512) void rnn_team_fwd_kernel(RnnStepArgs p, u64* _
     team_of_block(n_teams, team, member);
     const int U0 = member * TEAM_US;
     const int u = U0 + 2 * row + ((tid >> 2) & 1);
-    u64* const xb = xbuf + (size_t)team * (TEAM_SLOTS * H);
 
     // ---- weights: pair m = registers 2m, 2m+1; element kk <-> k = 64*(kk>>2) + 4*kg + (kk&3) ----------
     f32x2 wp[4][KPL];
@@ -130,118 +134,194 @@ __global__ __launch_bounds__(512) void rnn_team_fwd_kernel(RnnStepArgs p, u64* _
     const float am = (CELL == CELL_LSTM && is_t) ? 2.f : 1.f, aa = (CELL == CELL_LSTM && is_t) ? -1.f : 0.f;
     if (tid == 0) dead = 0;
 
-    unsigned tag = 0;   // tag of the previous step's output (team-wide running counter)
-    for (int b = team; b < p.n_seq; b += n_teams) {
-        const int len = p.seq_len[b];
-        if (len <= 0) continue;
-        const size_t row0 = (size_t)p.seq_off[b];
-        float* const gp = p.gates + row0 * GH + gq * H + u;
-        float st = CELL == CELL_LSTM ? p.cprev[row0 * H + u] : p.hprev[row0 * H + u];   // c_{t-1} (LSTM) / h_{t-1} (GRU) of this unit
-        __syncthreads();                                           // the previous sequence's last reads of h_lds
-        if (tid < H) h_lds[0][tid] = p.hprev[row0 * H + tid];
-        float xc[PF];
-#pragma unroll
-        for (int j = 0; j < PF; ++j) xc[j] = gp[(size_t)min(j, len - 1) * GH];
-        asm volatile("" : "+v"(xc[0]), "+v"(xc[1]), "+v"(xc[2]), "+v"(xc[3]) : : "memory");
-
-        auto step = [&](const int t, const float x) -> bool {
-            const int par = t & 1;
-            if (t > 0 && tid < H - TEAM_US) {                       // the other members' h_{t-1}
-                const int idx = (U0 + TEAM_US + tid) & (H - 1);
-                float v = 0.f;
-                if (!granule_wait(xb + (tag & 3) * H + idx, tag, v)) dead = 1;
-                h_lds[par][idx] = v;
+    // ---- per-stream state (every loop over s is unrolled: registers / SGPRs) ---------------------------------
+    int sq[NS], len[NS], tt[NS];
+    size_t row0[NS];
+    unsigned tag[NS];      // tag of the stream's previous step output (running counter, continues across sequences)
+    bool on[NS];
+    float st[NS];          // c_{t-1} (LSTM) / h_{t-1} (GRU) of this lane's unit
+    float x0[NS], x1[NS];  // gate pre-activations of steps t, t+1 (loaded two steps ahead)
+    const int pidx = (U0 + TEAM_US + tid) & (H - 1);   // the granule lanes 0..191 collect
+    u64 pre = 0;           // early first read of a stream's granule (see step)
+    int pre_owner = -1;
+    auto gate_ptr = [&](int s) { return p.gates + row0[s] * GH + gq * H + u; };
+    auto open = [&](int s) {   // next non-empty sequence of stream s, or retire the stream
+        for (;;) {
+            sq[s] += NS * n_teams;
+            if (sq[s] >= p.n_seq) { on[s] = false; return; }
+            len[s] = p.seq_len[sq[s]];
+            if (len[s] > 0) break;
+        }
+        row0[s] = (size_t)p.seq_off[sq[s]];
+        tt[s] = 0;
+        st[s] = CELL == CELL_LSTM ? p.cprev[row0[s] * H + u] : p.hprev[row0[s] * H + u];
+        const float* gp = gate_ptr(s);
+        x0[s] = gp[0];
+        x1[s] = gp[(size_t)min(1, len[s] - 1) * GH];
+        __syncthreads();                                           // the previous sequence's last reads of h_lds[s]
+        if (tid < H) h_lds[s][0][tid] = p.hprev[row0[s] * H + tid];
+        // wait for these loads inside this (rare) path: otherwise the wait lands after the join with the path that
+        // opens nothing, as a vmcnt(0) behind that path's freshly issued stores
+        asm volatile("" : "+v"(x0[s]), "+v"(x1[s]), "+v"(st[s]) : : "memory");
+    };
+    // outputs of a step: one store per lane plus the granules
+    float* pend_ptr = nullptr; float pend_val = 0.f, pend_h = 0.f; bool pend_on = false, pending = false;
+    u64* pend_gr = nullptr; unsigned pend_tag = 0;
+    auto flush = [&]() {
+        if (!pending) return;
+        if (dup == 0 && q == 0) granule_store(pend_gr, pend_h, pend_tag);
+        if (pend_on) *pend_ptr = pend_val;
+        pending = false;
+    };
+    auto step = [&](int s) -> bool {
+        stamp(0);      // between step calls (loop control, open)
+        const int t = tt[s], par = t & 1;
+        u64* const xb = xbuf + (size_t)(team * NS + s) * (TEAM_SLOTS * H);
+        float* const gp = gate_ptr(s);
+        const float x = x0[s];
+        auto next_operands = [&]() {
+            x0[s] = x1[s];
+            x1[s] = gp[(size_t)min(t + 2, len[s] - 1) * GH];
+        };
+        // several streams: issued first, waited for with the early granule read at the end of the arithmetic (the hot path
+        // of the poll below has no wait of its own).  One stream: after the poll, whose vmcnt(0) must not include it.
+        if constexpr (NS > 1) next_operands();
+        if (t > 0 && tid < H - TEAM_US) {                           // the other members' h_{t-1}
+            const u64* gptr = xb + (tag[s] & 3) * H + pidx;
+            float v = 0.f;
+            u64 g = pre;
+            if (pre_owner != s) {   // no early read for this step: read now, and wait for it inside this branch (a wait after
+                g = granule_load(gptr);                            // the join would be a vmcnt(0) behind the last stores)
+                asm volatile("" : "+v"(g) : : "memory");
             }
-            __syncthreads();
-            const float* hl = &h_lds[par][4 * kg];
-            f32x2 hv[KPL / 2];
-#pragma unroll
-            for (int i = 0; i < NRD; ++i) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(hl + 64 * i);
-                hv[2 * i] = __builtin_shufflevector(v, v, 0, 1);
-                hv[2 * i + 1] = __builtin_shufflevector(v, v, 2, 3);
+            if constexpr (TIMING) {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(g) : : "memory");
+                stamp(1);                                          // first read back
+                if ((unsigned)(g >> 32) != tag[s]) tm[5] += 1;     // ... and it was stale
             }
-            const int is_dead = dead;
-            f32x2 acc[4];
+            if (!granule_wait(g, gptr, tag[s], v)) dead = 1;
+            h_lds[s][par][pidx] = v;
+        }
+        stamp(2);      // spinning
+        pre_owner = -1;
+        __syncthreads();
+        stamp(3);      // barrier
+        if (NS > 1) {
+            // first read of the NEXT stream's granules now, so that its round trip (~0.7 us even when the data is
+            // there) runs under this step's arithmetic; that stream's step starts from the value read here
+            const int n = (s + 1) % NS;
+            if (on[n] && tt[n] > 0) {
+                if (tid < H - TEAM_US) pre = granule_load(xbuf + (size_t)(team * NS + n) * (TEAM_SLOTS * H) + (tag[n] & 3) * H + pidx);
+                pre_owner = n;
+            }
+        }
+        if constexpr (NS == 1) next_operands();
+        const float* hl = &h_lds[s][par][4 * kg];
+        f32x2 hv[KPL / 2];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = pk_mul_bcast0(wp[m][0], hv[0]);
+        for (int i = 0; i < NRD; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(hl + 64 * i);
+            hv[2 * i] = __builtin_shufflevector(v, v, 0, 1);
+            hv[2 * i + 1] = __builtin_shufflevector(v, v, 2, 3);
+        }
+        const int is_dead = dead;
+        f32x2 acc[4];
 #pragma unroll
-            for (int kk = 1; kk < KPL; ++kk)
+        for (int m = 0; m < 4; ++m) acc[m] = pk_mul_bcast0(wp[m][0], hv[0]);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    if (kk & 1) pk_fma_bcast<1>(acc[m], wp[m][kk], hv[kk >> 1]);
-                    else pk_fma_bcast<0>(acc[m], wp[m][kk], hv[kk >> 1]);
-                }
-            float a[8];
+        for (int kk = 1; kk < KPL; ++kk)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) { a[2 * m] = acc[m].x; a[2 * m + 1] = acc[m].y; }
+            for (int m = 0; m < 4; ++m) {
+                if (kk & 1) pk_fma_bcast<1>(acc[m], wp[m][kk], hv[kk >> 1]);
+                else pk_fma_bcast<0>(acc[m], wp[m][kk], hv[kk >> 1]);
+            }
+        float a[8];
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) a[cc] += dpp<DPP_HALF_MIRROR>(a[4 + cc]);
+        for (int m = 0; m < 4; ++m) { a[2 * m] = acc[m].x; a[2 * m + 1] = acc[m].y; }
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc) a[cc] += dpp<DPP_XOR2>(a[2 + cc]);
-            a[0] += dpp<DPP_XOR1>(a[1]);
-            a[0] += dpp<DPP_ROR8>(a[0]);
-            const float ah = a[0] + bq;                            // W_hh h + b_hh of this lane's gate
-            const size_t r = (size_t)t;
-            float hn;
-            if constexpr (CELL == CELL_LSTM) {
-                const float act = __builtin_fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(sc * (ah + x))), am, aa);
-                const float ig = dpp<DPP_Q0>(act), fg = dpp<DPP_Q1>(act), gg = dpp<DPP_Q2>(act), og = dpp<DPP_Q3>(act);
-                const float cn = fg * st + ig * gg;
-                hn = og * tanh_hw(cn);
-                st = cn;
-                if (dup == 0) gp[r * GH] = act;
-                else {
-                    // q 0,1: h_t, c_t -> hseq/cseq[row]; q 2,3: -> hprev/cprev[row+1] (last step: the same value again)
-                    float* base = (q & 1) ? ((q >= 2 && t + 1 < len) ? p.cprev + H : p.cseq) : ((q >= 2 && t + 1 < len) ? p.hprev + H : p.hseq);
-                    base[(row0 + r) * H + u] = (q & 1) ? cn : hn;
-                }
+        for (int cc = 0; cc < 4; ++cc) a[cc] += dpp<DPP_HALF_MIRROR>(a[4 + cc]);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) a[cc] += dpp<DPP_XOR2>(a[2 + cc]);
+        a[0] += dpp<DPP_XOR1>(a[1]);
+        a[0] += dpp<DPP_ROR8>(a[0]);
+        const float ah = a[0] + bq;                                // W_hh h + b_hh of this lane's gate
+        const size_t r = row0[s] + t;
+        const bool more = t + 1 < len[s];
+        float hn;
+        // every lane has (at most) ONE output store per step: dup 0 the activated gate (GRU slot 3: hn), dup 1 the states
+        float* o_ptr;
+        float o_val;
+        bool o_on = true;
+        if constexpr (CELL == CELL_LSTM) {
+            const float act = __builtin_fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(sc * (ah + x))), am, aa);
+            const float ig = dpp<DPP_Q0>(act), fg = dpp<DPP_Q1>(act), gg = dpp<DPP_Q2>(act), og = dpp<DPP_Q3>(act);
+            const float cn = fg * st[s] + ig * gg;
+            hn = og * tanh_hw(cn);
+            st[s] = cn;
+            // dup 1: q 0,1: h_t, c_t -> hseq/cseq[row]; q 2,3: -> hprev/cprev[row+1] (last step: the same value again)
+            float* base = (q & 1) ? ((q >= 2 && more) ? p.cprev + H : p.cseq) : ((q >= 2 && more) ? p.hprev + H : p.hseq);
+            o_ptr = dup == 0 ? gp + (size_t)t * GH : base + r * H + u;
+            o_val = dup == 0 ? act : ((q & 1) ? cn : hn);
+        } else {
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(sc * (ah + x)));   // r, z lanes
+            const float rg = dpp<DPP_Q0>(sg);
+            const float ng = tanh_hw(x + rg * ah);                                                  // n lane
+            const float act = is_t ? ng : sg;
+            const float zg = dpp<DPP_Q1>(act), nn = dpp<DPP_Q2>(act), hnv = dpp<DPP_Q2>(ah);
+            hn = (1.f - zg) * nn + zg * st[s];
+            st[s] = hn;
+            if (dup == 0) {
+                o_ptr = q < 3 ? gp + (size_t)t * GH : p.hn + r * H + u;
+                o_val = q < 3 ? act : hnv;
             } else {
-                const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(sc * (ah + x)));   // r, z lanes
-                const float rg = dpp<DPP_Q0>(s);
-                const float ng = tanh_hw(x + rg * ah);                                                  // n lane
-                const float act = is_t ? ng : s;
-                const float zg = dpp<DPP_Q1>(act), nn = dpp<DPP_Q2>(act), hnv = dpp<DPP_Q2>(ah);
-                hn = (1.f - zg) * nn + zg * st;
-                st = hn;
-                if (dup == 0) {
-                    if (q < 3) gp[r * GH] = act;
-                    else p.hn[(row0 + r) * H + u] = hnv;
-                } else if (q == 0) {
-                    p.hseq[(row0 + r) * H + u] = hn;
-                } else if (q == 1 && t + 1 < len) {
-                    p.hprev[(row0 + r + 1) * H + u] = hn;
-                }
-            }
-            ++tag;
-            if (dup == 0 && q == 0) {
-                granule_store(xb + (tag & 3) * H + u, hn, tag);
-                h_lds[par ^ 1][u] = hn;
-            }
-            return is_dead == 0;
-        };
-        auto poison = [&](int t) {   // a peer never answered: make the failure visible downstream
-            if (tid < TEAM_US) p.hseq[(row0 + t) * H + U0 + tid] = __builtin_nanf("");
-        };
-        int t = 0;
-        bool ok = true;
-        for (; ok && t + PF <= len; t += PF) {
-            float xn[PF];
-#pragma unroll
-            for (int j = 0; j < PF; ++j) xn[j] = gp[(size_t)min(t + PF + j, len - 1) * GH];
-            ok = step(t, xc[0]) && step(t + 1, xc[1]) && step(t + 2, xc[2]) && step(t + 3, xc[3]);
-#pragma unroll
-            for (int j = 0; j < PF; ++j) xc[j] = xn[j];
-            asm volatile("" : "+v"(xc[0]), "+v"(xc[1]), "+v"(xc[2]), "+v"(xc[3]) : : "memory");
-        }
-        if (ok && t < len) {
-            ok = step(t, xc[0]);
-            if (ok && t + 1 < len) {
-                ok = step(t + 1, xc[1]);
-                if (ok && t + 2 < len) ok = step(t + 2, xc[2]);
+                o_ptr = (q == 0 ? p.hseq : p.hprev + H) + r * H + u;
+                o_val = hn;
+                o_on = q == 0 || (q == 1 && more);
             }
         }
-        if (!ok) { poison(min(t, len - 1)); return; }
+        ++tag[s];
+        if (dup == 0 && q == 0) h_lds[s][par ^ 1][u] = hn;
+        pend_ptr = o_ptr; pend_val = o_val; pend_on = o_on;
+        pend_gr = xb + (tag[s] & 3) * H + u; pend_h = hn; pend_tag = tag[s];
+        pending = true;
+        // Several streams: the loads of this step call (next operands, the next stream's granules) are waited for HERE,
+        // with a step's arithmetic behind them and before this step's stores are issued.  Left to the compiler the wait
+        // lands at the loop back-edge (register rotation of x0/x1) as a vmcnt(0) behind the stores: their acknowledgement
+        // latency in every step call (measured: 480-700 cycles).  One stream: the poll is the critical path and the
+        // publish must not wait for anything.
+        if constexpr (NS > 1) asm volatile("" : "+v"(x1[s]), "+v"(pre) : : "memory");
+        // (holding the stores back until after the next step call's poll was measured and is slower: the later publish
+        // costs the peers more than it saves)
+        flush();
+        stamp(4);      // arithmetic + stores
+        return is_dead == 0;
+    };
+
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        sq[s] = team * NS + s - NS * n_teams; tag[s] = 0; on[s] = true; len[s] = 0; tt[s] = 0; row0[s] = 0;
+        st[s] = x0[s] = x1[s] = 0.f;
+        open(s);
+    }
+    if constexpr (TIMING) tm0 = __builtin_amdgcn_s_memtime();
+    bool failed = false;
+    size_t fail_row = 0;
+    for (bool any = true; any && !failed;) {
+        any = false;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (!on[s] || failed) continue;
+            const size_t r_now = row0[s] + tt[s];
+            if (!step(s)) { failed = true; fail_row = r_now; continue; }
+            if (++tt[s] == len[s]) open(s);
+            any |= on[s];
+        }
+    }
+    flush();
+    // a peer never answered: make the failure visible downstream
+    if (failed && tid < TEAM_US) p.hseq[fail_row * H + U0 + tid] = __builtin_nanf("");
+    if constexpr (TIMING) {
+        if (blockIdx.x == 0 && tid == 0 && p.dbg != nullptr) for (int i = 0; i < 6; ++i) p.dbg[i] = tm[i];
     }
 }
 
@@ -249,11 +329,11 @@ __global__ __launch_bounds__(512) void rnn_team_fwd_kernel(RnnStepArgs p, u64* _
 // backward through time.  In: dh[row][H] (from above), the forward's activated gates, cseq/cprev (LSTM)
 // or hn/hprev (GRU).  Out: dgx[row][G*H] and, GRU, dgh[row][G*H] (the n gate's differs by the factor r).
 // ---------------------------------------------------------------------------------------------------
-template <int CELL>
+template <int CELL, int NS>
 __global__ __launch_bounds__(512) void rnn_team_bwd_kernel(RnnStepArgs p, u64* __restrict__ xbuf, int n_teams) {
     constexpr int H = TEAM_H, G = CELL == CELL_GRU ? 3 : 4, GH = G * H, NG = 4 * H;   // NG: granules / LDS positions per step
     constexpr int KPL = 16, NRD = 4;
-    __shared__ __attribute__((aligned(16))) float g_lds[2][NG];   // position 4*unit + gate slot
+    __shared__ __attribute__((aligned(16))) float g_lds[NS][2][NG];   // position 4*unit + gate slot
     __shared__ int dead;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 3, dup = (lane >> 2) & 1, b3 = (lane >> 3) & 1;
@@ -261,7 +341,6 @@ __global__ __launch_bounds__(512) void rnn_team_bwd_kernel(RnnStepArgs p, u64* _
     team_of_block(n_teams, team, member);
     const int U0 = member * TEAM_US;
     const int u = U0 + 8 * wave + (lane >> 3);
-    u64* const xb = xbuf + (size_t)team * (TEAM_SLOTS * NG);
 
     // ---- weights.  Register r <-> output U0 + 8*wave + ((r & 6) | ((r & 1) ^ b3)); element kk <-> LDS position
     // 256*(kk>>2) + 4*lane + (kk&3) = gate slot (kk&3) of unit 64*(kk>>2) + lane.
@@ -283,146 +362,181 @@ __global__ __launch_bounds__(512) void rnn_team_bwd_kernel(RnnStepArgs p, u64* _
     }
     const int gq = q < G ? q : G - 1;
     const bool is_q0 = q == 0, is_q1 = q == 1, is_q2 = q == 2, is_q3 = q == 3;
+    // LSTM: q0 c_t, q1 c_{t-1}, q2 dh (q3: dh again, unused).  GRU: q0 hn, q1 h_{t-1}, q2 dh.
+    const float* const sh_base = CELL == CELL_LSTM ? (q == 0 ? p.cseq : (q == 1 ? p.cprev : p.dh)) : (q == 0 ? p.hn : (q == 1 ? p.hprev : p.dh));
     if (tid == 0) dead = 0;
 
-    unsigned tag = 0;
-    for (int b = team; b < p.n_seq; b += n_teams) {
-        const int len = p.seq_len[b];
-        if (len <= 0) continue;
-        const size_t row0 = (size_t)p.seq_off[b];
-        const float* const gp = p.gates + row0 * GH + gq * H + u;
-        // LSTM: q0 c_t, q1 c_{t-1}, q2 dh (q3: dh again, unused).  GRU: q0 hn, q1 h_{t-1}, q2 dh.
-        const float* const shp = (CELL == CELL_LSTM ? (q == 0 ? p.cseq : (q == 1 ? p.cprev : p.dh))
-                                                    : (q == 0 ? p.hn : (q == 1 ? p.hprev : p.dh))) + row0 * H + u;
-        float aoc[PF], shc[PF];
-#pragma unroll
-        for (int j = 0; j < PF; ++j) {
-            const size_t r = (size_t)max(len - 1 - j, 0);
-            aoc[j] = gp[r * GH];
-            shc[j] = shp[r * H];
+    int sq[NS], len[NS], ii[NS];   // ii: step index from the end, t = len - 1 - ii
+    size_t row0[NS];
+    unsigned tag[NS];
+    bool on[NS];
+    float carry[NS], gate_next[NS];      // LSTM: dc_{t+1}, f_{t+1};  GRU: dh_{t+1}, z_{t+1}
+    float a0[NS], a1[NS], s0[NS], s1[NS];   // own gate activation / state operand of steps ii, ii+1
+    // the 768 granules of the other members: every lane collects one, lanes 0..255 a second
+    const int i0 = (4 * U0 + 4 * TEAM_US + tid) & (NG - 1), i1 = (4 * U0 + 4 * TEAM_US + 512 + tid) & (NG - 1);
+    u64 pre0 = 0, pre1 = 0;
+    int pre_owner = -1;
+    auto open = [&](int s) {
+        for (;;) {
+            sq[s] += NS * n_teams;
+            if (sq[s] >= p.n_seq) { on[s] = false; return; }
+            len[s] = p.seq_len[sq[s]];
+            if (len[s] > 0) break;
         }
-        asm volatile("" : "+v"(aoc[0]), "+v"(aoc[1]), "+v"(aoc[2]), "+v"(aoc[3]), "+v"(shc[0]), "+v"(shc[1]), "+v"(shc[2]),
-                     "+v"(shc[3]) : : "memory");
-        float carry = 0.f, gate_next = 0.f;   // LSTM: dc_{t+1}, f_{t+1};  GRU: dh_{t+1}, z_{t+1}
-        __syncthreads();
-        g_lds[0][tid] = 0.f; g_lds[0][512 + tid] = 0.f;            // "step len" has no gate gradient
-        // (the barrier of the first step orders these writes)
-
-        auto step = [&](const int i, const float a_own, const float shv) -> bool {
-            const int t = len - 1 - i, cur = i & 1;
-            if (i > 0) {                                           // the other members' gate gradients of step t+1
-                const int i0 = (4 * U0 + 4 * TEAM_US + tid) & (NG - 1);
-                float v0 = 0.f, v1 = 0.f;
-                const u64* base = xb + (tag & 3) * NG;
-                bool ok = granule_wait(base + i0, tag, v0);
-                g_lds[cur][i0] = v0;
-                if (tid < 256) {
-                    const int i1 = (4 * U0 + 4 * TEAM_US + 512 + tid) & (NG - 1);
-                    ok = granule_wait(base + i1, tag, v1) && ok;
-                    g_lds[cur][i1] = v1;
-                }
-                if (!ok) dead = 1;
-            }
-            __syncthreads();
-            const float* gl = &g_lds[cur][4 * lane];
-            f32x2 dv[KPL / 2];
-#pragma unroll
-            for (int j = 0; j < NRD; ++j) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(gl + 256 * j);
-                dv[2 * j] = __builtin_shufflevector(v, v, 0, 1);
-                dv[2 * j + 1] = __builtin_shufflevector(v, v, 2, 3);
-            }
-            const int is_dead = dead;
-            f32x2 acc[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = pk_mul_bcast0(wp[m][0], dv[0]);
-#pragma unroll
-            for (int kk = 1; kk < KPL; ++kk)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    if (kk & 1) pk_fma_bcast<1>(acc[m], wp[m][kk], dv[kk >> 1]);
-                    else pk_fma_bcast<0>(acc[m], wp[m][kk], dv[kk >> 1]);
-                }
-            float a[8];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) { a[2 * m] = acc[m].x; a[2 * m + 1] = acc[m].y; }
-            float s4[4], s2[2];
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) s4[cc] = swap32_sum(a[cc], a[4 + cc]);
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) s2[cc] = swap16_sum(s4[cc], s4[2 + cc]);
-            float rec = s2[0] + dpp<DPP_ROR8>(s2[1]);
-            rec += dpp<DPP_HALF_MIRROR>(rec);
-            rec += dpp<DPP_XOR1>(rec);
-            rec += dpp<DPP_XOR2>(rec);            // dh_rec[u]: zero at the sequence's last step (g_lds starts zeroed)
-            float d, dh_out;
-            if constexpr (CELL == CELL_LSTM) {
-                const float ig = dpp<DPP_Q0>(a_own), fg = dpp<DPP_Q1>(a_own), gg = dpp<DPP_Q2>(a_own), og = dpp<DPP_Q3>(a_own);
-                const float cs = dpp<DPP_Q0>(shv), cp = dpp<DPP_Q1>(shv), dhx = dpp<DPP_Q2>(shv);
-                const float dh = dhx + rec;
-                const float tc = tanh_hw(cs);
-                const float dcv = dh * og * (1.f - tc * tc) + carry * gate_next;
-                const float M = is_q3 ? dh * tc : dcv;
-                float X = is_q2 ? ig : 1.f;
-                X = is_q1 ? cp : X;
-                X = is_q0 ? gg : X;
-                const float D = __builtin_fmaf(-a_own, a_own, is_q2 ? 1.f : a_own);
-                d = M * X * D;
-                dh_out = d;
-                carry = dcv;
-                gate_next = fg;
-                if (dup == 0) p.dgx[(row0 + t) * GH + q * H + u] = d;
-            } else {
-                const float rg = dpp<DPP_Q0>(a_own), zg = dpp<DPP_Q1>(a_own), ng = dpp<DPP_Q2>(a_own);
-                const float hnv = dpp<DPP_Q0>(shv), hpv = dpp<DPP_Q1>(shv), dhx = dpp<DPP_Q2>(shv);
-                const float dh = dhx + rec + carry * gate_next;
-                const float dn = dh * (1.f - zg) * (1.f - ng * ng);
-                const float dz = dh * (hpv - ng) * zg * (1.f - zg);
-                const float dr = dn * hnv * rg * (1.f - rg);
-                d = is_q0 ? dr : (is_q1 ? dz : (is_q2 ? dn : 0.f));
-                dh_out = is_q2 ? dn * rg : d;
-                carry = dh;
-                gate_next = zg;
-                if (q < 3) {
-                    if (dup == 0) p.dgx[(row0 + t) * GH + q * H + u] = d;
-                    else p.dgh[(row0 + t) * GH + q * H + u] = dh_out;
-                }
-            }
-            ++tag;
-            if (dup == 0) {
-                granule_store(xb + (tag & 3) * NG + 4 * u + q, dh_out, tag);
-                g_lds[cur ^ 1][4 * u + q] = dh_out;
-            }
-            return is_dead == 0;
+        row0[s] = (size_t)p.seq_off[sq[s]];
+        ii[s] = 0;
+        carry[s] = 0.f; gate_next[s] = 0.f;
+        const float* gp = p.gates + row0[s] * GH + gq * H + u;
+        const float* shp = sh_base + row0[s] * H + u;
+        const size_t r0 = (size_t)(len[s] - 1), r1 = (size_t)max(len[s] - 2, 0);
+        a0[s] = gp[r0 * GH]; s0[s] = shp[r0 * H];
+        a1[s] = gp[r1 * GH]; s1[s] = shp[r1 * H];
+        __syncthreads();                                           // the previous sequence's last reads of g_lds[s]
+        g_lds[s][0][tid] = 0.f; g_lds[s][0][512 + tid] = 0.f;      // "step len" has no gate gradient
+        asm volatile("" : "+v"(a0[s]), "+v"(a1[s]), "+v"(s0[s]), "+v"(s1[s]) : : "memory");   // (see the forward)
+    };
+    float* pend_ptr = nullptr; float pend_val = 0.f, pend_d = 0.f; bool pend_on = false, pending = false;
+    u64* pend_gr = nullptr; unsigned pend_tag = 0;
+    auto flush = [&]() {
+        if (!pending) return;
+        if (dup == 0) granule_store(pend_gr, pend_d, pend_tag);
+        if (pend_on) *pend_ptr = pend_val;
+        pending = false;
+    };
+    auto step = [&](int s) -> bool {
+        const int i = ii[s], t = len[s] - 1 - i, cur = i & 1;
+        u64* const xb = xbuf + (size_t)(team * NS + s) * (TEAM_SLOTS * NG);
+        const float a_own = a0[s], shv = s0[s];
+        auto next_operands = [&]() {   // operands of step i + 2
+            const size_t r2 = (size_t)max(t - 2, 0);
+            a0[s] = a1[s]; s0[s] = s1[s];
+            a1[s] = p.gates[(row0[s] + r2) * GH + gq * H + u];
+            s1[s] = sh_base[(row0[s] + r2) * H + u];
         };
-        int i = 0;   // step index from the end: t = len - 1 - i
-        bool ok = true;
-        for (; ok && i + PF <= len; i += PF) {
-            float aon[PF], shn[PF];
-#pragma unroll
-            for (int j = 0; j < PF; ++j) {
-                const size_t r = (size_t)max(len - 1 - i - PF - j, 0);
-                aon[j] = gp[r * GH];
-                shn[j] = shp[r * H];
+        if constexpr (NS > 1) next_operands();   // (placement: see the forward)
+        if (i > 0) {                                               // the other members' gate gradients of step t+1
+            float v0 = 0.f, v1 = 0.f;
+            const u64* base = xb + (tag[s] & 3) * NG;
+            u64 g0 = pre0, g1 = pre1;
+            if (pre_owner != s) {   // (see the forward)
+                g0 = granule_load(base + i0);
+                if (tid < 256) g1 = granule_load(base + i1);
+                asm volatile("" : "+v"(g0), "+v"(g1) : : "memory");
             }
-            ok = step(i, aoc[0], shc[0]) && step(i + 1, aoc[1], shc[1]) && step(i + 2, aoc[2], shc[2]) && step(i + 3, aoc[3], shc[3]);
-#pragma unroll
-            for (int j = 0; j < PF; ++j) { aoc[j] = aon[j]; shc[j] = shn[j]; }
-            asm volatile("" : "+v"(aoc[0]), "+v"(aoc[1]), "+v"(aoc[2]), "+v"(aoc[3]), "+v"(shc[0]), "+v"(shc[1]), "+v"(shc[2]),
-                         "+v"(shc[3]) : : "memory");
+            bool ok = granule_wait(g0, base + i0, tag[s], v0);
+            g_lds[s][cur][i0] = v0;
+            if (tid < 256) {
+                ok = granule_wait(g1, base + i1, tag[s], v1) && ok;
+                g_lds[s][cur][i1] = v1;
+            }
+            if (!ok) dead = 1;
         }
-        if (ok && i < len) {
-            ok = step(i, aoc[0], shc[0]);
-            if (ok && i + 1 < len) {
-                ok = step(i + 1, aoc[1], shc[1]);
-                if (ok && i + 2 < len) ok = step(i + 2, aoc[2], shc[2]);
+        pre_owner = -1;
+        __syncthreads();
+        if (NS > 1) {   // early first read of the next stream's granules (see the forward)
+            const int n = (s + 1) % NS;
+            if (on[n] && ii[n] > 0) {
+                const u64* nb = xbuf + (size_t)(team * NS + n) * (TEAM_SLOTS * NG) + (tag[n] & 3) * NG;
+                pre0 = granule_load(nb + i0);
+                if (tid < 256) pre1 = granule_load(nb + i1);
+                pre_owner = n;
             }
         }
-        if (!ok) {
-            if (tid < TEAM_US) p.dgx[(row0 + max(len - 1 - i, 0)) * GH + U0 + tid] = __builtin_nanf("");
-            return;
+        if constexpr (NS == 1) next_operands();
+        const float* gl = &g_lds[s][cur][4 * lane];
+        f32x2 dv[KPL / 2];
+#pragma unroll
+        for (int j = 0; j < NRD; ++j) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(gl + 256 * j);
+            dv[2 * j] = __builtin_shufflevector(v, v, 0, 1);
+            dv[2 * j + 1] = __builtin_shufflevector(v, v, 2, 3);
+        }
+        const int is_dead = dead;
+        f32x2 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = pk_mul_bcast0(wp[m][0], dv[0]);
+#pragma unroll
+        for (int kk = 1; kk < KPL; ++kk)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (kk & 1) pk_fma_bcast<1>(acc[m], wp[m][kk], dv[kk >> 1]);
+                else pk_fma_bcast<0>(acc[m], wp[m][kk], dv[kk >> 1]);
+            }
+        float a[8];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { a[2 * m] = acc[m].x; a[2 * m + 1] = acc[m].y; }
+        float s4[4], s2[2];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) s4[cc] = swap32_sum(a[cc], a[4 + cc]);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) s2[cc] = swap16_sum(s4[cc], s4[2 + cc]);
+        float rec = s2[0] + dpp<DPP_ROR8>(s2[1]);
+        rec += dpp<DPP_HALF_MIRROR>(rec);
+        rec += dpp<DPP_XOR1>(rec);
+        rec += dpp<DPP_XOR2>(rec);            // dh_rec[u]: zero at the sequence's last step (g_lds starts zeroed)
+        const size_t r = row0[s] + t;
+        float d, dh_out;
+        float* o_ptr; float o_val; bool o_on;      // the lane's one output store of the step
+        if constexpr (CELL == CELL_LSTM) {
+            const float ig = dpp<DPP_Q0>(a_own), fg = dpp<DPP_Q1>(a_own), gg = dpp<DPP_Q2>(a_own), og = dpp<DPP_Q3>(a_own);
+            const float cs = dpp<DPP_Q0>(shv), cp = dpp<DPP_Q1>(shv), dhx = dpp<DPP_Q2>(shv);
+            const float dh = dhx + rec;
+            const float tc = tanh_hw(cs);
+            const float dcv = dh * og * (1.f - tc * tc) + carry[s] * gate_next[s];
+            const float M = is_q3 ? dh * tc : dcv;
+            float X = is_q2 ? ig : 1.f;
+            X = is_q1 ? cp : X;
+            X = is_q0 ? gg : X;
+            const float D = __builtin_fmaf(-a_own, a_own, is_q2 ? 1.f : a_own);
+            d = M * X * D;
+            dh_out = d;
+            carry[s] = dcv;
+            gate_next[s] = fg;
+            o_ptr = p.dgx + r * GH + q * H + u; o_val = d; o_on = dup == 0;
+        } else {
+            const float rg = dpp<DPP_Q0>(a_own), zg = dpp<DPP_Q1>(a_own), ng = dpp<DPP_Q2>(a_own);
+            const float hnv = dpp<DPP_Q0>(shv), hpv = dpp<DPP_Q1>(shv), dhx = dpp<DPP_Q2>(shv);
+            const float dh = dhx + rec + carry[s] * gate_next[s];
+            const float dn = dh * (1.f - zg) * (1.f - ng * ng);
+            const float dz = dh * (hpv - ng) * zg * (1.f - zg);
+            const float dr = dn * hnv * rg * (1.f - rg);
+            d = is_q0 ? dr : (is_q1 ? dz : (is_q2 ? dn : 0.f));
+            dh_out = is_q2 ? dn * rg : d;
+            carry[s] = dh;
+            gate_next[s] = zg;
+            o_ptr = (dup == 0 ? p.dgx : p.dgh) + r * GH + gq * H + u; o_val = dup == 0 ? d : dh_out; o_on = q < 3;
+        }
+        ++tag[s];
+        if (dup == 0) g_lds[s][cur ^ 1][4 * u + q] = dh_out;
+        if constexpr (NS > 1) asm volatile("" : "+v"(a1[s]), "+v"(s1[s]), "+v"(pre0), "+v"(pre1) : : "memory");   // (see the forward)
+        pend_ptr = o_ptr; pend_val = o_val; pend_on = o_on;
+        pend_gr = xb + (tag[s] & 3) * NG + 4 * u + q; pend_d = dh_out; pend_tag = tag[s];
+        pending = true;
+        flush();
+        return is_dead == 0;
+    };
+
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        sq[s] = team * NS + s - NS * n_teams; tag[s] = 0; on[s] = true; len[s] = 0; ii[s] = 0; row0[s] = 0;
+        carry[s] = gate_next[s] = a0[s] = a1[s] = s0[s] = s1[s] = 0.f;
+        open(s);
+    }
+    bool failed = false;
+    size_t fail_row = 0;
+    for (bool any = true; any && !failed;) {
+        any = false;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (!on[s] || failed) continue;
+            const size_t r_now = row0[s] + (len[s] - 1 - ii[s]);
+            if (!step(s)) { failed = true; fail_row = r_now; continue; }
+            if (++ii[s] == len[s]) open(s);
+            any |= on[s];
         }
     }
+    flush();
+    if (failed && tid < TEAM_US) p.dgx[fail_row * GH + U0 + tid] = __builtin_nanf("");
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -433,7 +547,7 @@ namespace {
 // exchange ring of the largest case (backward: 4H granules per slot), allocated once
 u64* team_xbuf() {
     static u64* buf = nullptr;
-    if (!buf && hipMalloc(&buf, (size_t)TEAM_MAX * TEAM_SLOTS * 4 * TEAM_H * sizeof(u64)) != hipSuccess) buf = nullptr;
+    if (!buf && hipMalloc(&buf, (size_t)TEAM_MAX * TEAM_NS_MAX * TEAM_SLOTS * 4 * TEAM_H * sizeof(u64)) != hipSuccess) buf = nullptr;
     return buf;
 }
 
@@ -457,39 +571,79 @@ int team_count(int n_seq) {
     return t;
 }
 
+// sequences a team keeps in flight: as many as it has to walk through anyway, up to four (a step is ~1/3 work,
+// ~2/3 waiting for the peers).  DC_RNN_TEAM_NS = 1 | 2 | 4 forces a count (A/B measurements, tests).
+int team_streams(int n_seq, int nt) {
+    const char* e = getenv("DC_RNN_TEAM_NS");
+    if (e && (e[0] == '1' || e[0] == '2' || e[0] == '4') && e[1] == 0) return e[0] - '0';
+    const int per = (n_seq + nt - 1) / nt;
+    return per >= 3 ? 4 : (per == 2 ? 2 : 1);
+}
+
+template <int CELL>
+void launch_team_fwd(int ns, int nt, const RnnStepArgs& a, u64* xb, hipStream_t s) {
+    const dim3 grid(nt * TEAM_M), block(512);
+    if (ns == 4) hipLaunchKernelGGL((rnn_team_fwd_kernel<CELL, 4>), grid, block, 0, s, a, xb, nt);
+    else if (ns == 2) hipLaunchKernelGGL((rnn_team_fwd_kernel<CELL, 2>), grid, block, 0, s, a, xb, nt);
+    else hipLaunchKernelGGL((rnn_team_fwd_kernel<CELL, 1>), grid, block, 0, s, a, xb, nt);
+}
+template <int CELL>
+void launch_team_bwd(int ns, int nt, const RnnStepArgs& a, u64* xb, hipStream_t s) {
+    const dim3 grid(nt * TEAM_M), block(512);
+    if (ns == 4) hipLaunchKernelGGL((rnn_team_bwd_kernel<CELL, 4>), grid, block, 0, s, a, xb, nt);
+    else if (ns == 2) hipLaunchKernelGGL((rnn_team_bwd_kernel<CELL, 2>), grid, block, 0, s, a, xb, nt);
+    else hipLaunchKernelGGL((rnn_team_bwd_kernel<CELL, 1>), grid, block, 0, s, a, xb, nt);
+}
+
 }  // namespace
 
 // DC_RNN_TEAM=0 forces the launch-per-step kernels (A/B measurements, parity tests of both)
 bool rnn_team_supported(int cell, int H, int n_seq) {
     const char* e = getenv("DC_RNN_TEAM");
     const bool on = !(e && e[0] == '0');
-    // above ~6 sequences per team the serial walk through a team's sequences loses to the batched per-step launches
-    return on && H == TEAM_H && (cell == CELL_GRU || cell == CELL_LSTM) && n_seq <= 6 * TEAM_MAX && team_capacity() >= 1;
+    // measured at LSTM-256, 256 steps: 64 sequences 0.39 vs 2.2 ms per pass, 256: 0.86 vs 2.4 ms, 1024: 3.4 vs 3.8 ms - beyond
+    // that the batched per-step launches (MFMA, all sequences at once) win again
+    return on && H == TEAM_H && (cell == CELL_GRU || cell == CELL_LSTM) && n_seq <= 12 * TEAM_MAX && team_capacity() >= 1;
 }
 
 int rnn_team_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     u64* xb = team_xbuf();
     if (!xb) { set_error("rnn_team_forward: exchange buffer allocation failed", 1012); return 1012; }
-    const int nt = team_count(a.n_seq);
+    const int nt = team_count(a.n_seq), ns = team_streams(a.n_seq, nt);
     const double G = cell == CELL_GRU ? 3 : 4;
     ProfScope prof(cell == CELL_GRU ? "gru_fwd_team" : "lstm_fwd_team", 2.0 * a.n_seq * G * a.H * a.H * max_len,
                    4.0 * a.n_seq * max_len * a.H * (2.0 * G + 4.0), s);
-    if (hipMemsetAsync(xb, 0, (size_t)nt * TEAM_SLOTS * TEAM_H * sizeof(u64), s) != hipSuccess) return launch_check("rnn_team_forward memset");
-    if (cell == CELL_GRU) hipLaunchKernelGGL((rnn_team_fwd_kernel<CELL_GRU>), dim3(nt * TEAM_M), dim3(512), 0, s, a, xb, nt);
-    else hipLaunchKernelGGL((rnn_team_fwd_kernel<CELL_LSTM>), dim3(nt * TEAM_M), dim3(512), 0, s, a, xb, nt);
+    if (hipMemsetAsync(xb, 0, (size_t)nt * ns * TEAM_SLOTS * TEAM_H * sizeof(u64), s) != hipSuccess) return launch_check("rnn_team_forward memset");
+    static const bool timing = [] { const char* e = getenv("DC_TEAM_TIMING"); return e && e[0] == '1'; }();
+    if (timing && cell == CELL_LSTM && (ns == 1 || ns == 4)) {   // debugging aid: phase cycles of one wave, printed per launch
+        static long long* dbg = nullptr;
+        if (!dbg) (void)hipMalloc(&dbg, 64);
+        a.dbg = dbg;
+        if (ns == 1) hipLaunchKernelGGL((rnn_team_fwd_kernel<CELL_LSTM, 1, true>), dim3(nt * TEAM_M), dim3(512), 0, s, a, xb, nt);
+        else hipLaunchKernelGGL((rnn_team_fwd_kernel<CELL_LSTM, 4, true>), dim3(nt * TEAM_M), dim3(512), 0, s, a, xb, nt);
+        long long h[6];
+        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        const double calls = (double)((a.n_seq + nt - 1) / nt) * max_len;   // step calls of one team (uniform lengths)
+        fprintf(stderr, "rnn_team_fwd timing (NS=%d, cycles per step call, %.0f calls): between %.0f  first read %.0f  spin %.0f  barrier %.0f  "
+                        "arithmetic+stores %.0f  stale first reads %.2f\n", ns, calls, h[0] / calls, h[1] / calls, h[2] / calls, h[3] / calls,
+                h[4] / calls, h[5] / calls);
+        return launch_check("rnn_team_forward");
+    }
+    if (cell == CELL_GRU) launch_team_fwd<CELL_GRU>(ns, nt, a, xb, s);
+    else launch_team_fwd<CELL_LSTM>(ns, nt, a, xb, s);
     return launch_check("rnn_team_forward");
 }
 
 int rnn_team_backward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     u64* xb = team_xbuf();
     if (!xb) { set_error("rnn_team_backward: exchange buffer allocation failed", 1012); return 1012; }
-    const int nt = team_count(a.n_seq);
+    const int nt = team_count(a.n_seq), ns = team_streams(a.n_seq, nt);
     const double G = cell == CELL_GRU ? 3 : 4;
     ProfScope prof(cell == CELL_GRU ? "gru_bwd_team" : "lstm_bwd_team", 2.0 * a.n_seq * G * a.H * a.H * max_len,
                    4.0 * a.n_seq * max_len * a.H * (3.0 * G + 6.0), s);
-    if (hipMemsetAsync(xb, 0, (size_t)nt * TEAM_SLOTS * 4 * TEAM_H * sizeof(u64), s) != hipSuccess) return launch_check("rnn_team_backward memset");
-    if (cell == CELL_GRU) hipLaunchKernelGGL((rnn_team_bwd_kernel<CELL_GRU>), dim3(nt * TEAM_M), dim3(512), 0, s, a, xb, nt);
-    else hipLaunchKernelGGL((rnn_team_bwd_kernel<CELL_LSTM>), dim3(nt * TEAM_M), dim3(512), 0, s, a, xb, nt);
+    if (hipMemsetAsync(xb, 0, (size_t)nt * ns * TEAM_SLOTS * 4 * TEAM_H * sizeof(u64), s) != hipSuccess) return launch_check("rnn_team_backward memset");
+    if (cell == CELL_GRU) launch_team_bwd<CELL_GRU>(ns, nt, a, xb, s);
+    else launch_team_bwd<CELL_LSTM>(ns, nt, a, xb, s);
     return launch_check("rnn_team_backward");
 }
 

@@ -150,18 +150,21 @@ def test_lstm_persist_variants_agree(monkeypatch, S, lens):
 
 
 @pytest.mark.parametrize('cell', ['gru', 'lstm'])
-@pytest.mark.parametrize('S,lens', [(256, [256] * 6), (7, [21, 7, 13, 30, 1, 44]), (5, [350]), (16, [50, 64, 33])])
+@pytest.mark.parametrize('S,lens', [(256, [256] * 6), (7, [21, 7, 13, 30, 1, 44]), (5, [350]), (16, [50, 64, 33]), (3, [1200, 2])])
 def test_rnn_team_kernels_agree_with_per_step(monkeypatch, cell, S, lens):
     # H = 256 (the reference's GRU, the LSTM-256 configs): the four-workgroups-per-sequence persistent kernels
-    # (rnn_team.hip) against the launch-per-step kernels on the same batch.  6 / 17 / 70 / 11 chunk sequences: fewer
-    # teams than 8 (plain block -> team map), 16 teams with one sequence left over, more sequences than the 64 teams
-    # (a team walks through two sequences: tag / ring continuity across the boundary), every remainder of the
-    # 4-step groups.  The two differ only in summation order.
+    # (rnn_team.hip) against the launch-per-step kernels on the same batch.  6 / 17 / 70 / 11 / 401 chunk sequences:
+    # fewer teams than 8 (plain block -> team map), 16 teams with one sequence left over, more sequences than the 64
+    # teams (two streams per team, then four with several sequences per stream: tag / ring continuity across sequence
+    # boundaries, streams that retire early), every remainder of the step groups.  Each case also with the stream
+    # count forced to 1, 2 and 4.  All differ only in summation order.
     from dotaclient_amd.engine import Engine, pack_rollouts
     dev = torch.device('cuda:0')
     outs = {}
-    for mode in ('0', '1'):
+    for mode, ns in (('0', None), ('1', None), ('1', '1'), ('1', '2'), ('1', '4')):
         monkeypatch.setenv('DC_RNN_TEAM', mode)
+        if ns is None: monkeypatch.delenv('DC_RNN_TEAM_NS', raising=False)
+        else: monkeypatch.setenv('DC_RNN_TEAM_NS', ns)
         eng = Engine(cell, 256, 1, dev)
         eng.load_state_dict(synth.init_state_dict(7, cell, 256, 1))
         rollouts = synth.make_rollouts(78, lens)
@@ -169,10 +172,11 @@ def test_rnn_team_kernels_agree_with_per_step(monkeypatch, cell, S, lens):
         chunks = eng.rollout_pass(batch, S)
         res, status = eng.train_epoch(chunks, 5e-5, 5e-4, 0.5)
         assert int(status.item()) == 0
-        outs[mode] = (batch.values.cpu().numpy().copy(), batch.adv.cpu().numpy().copy(), res.cpu().numpy().copy(),
-                      eng.grads.cpu().numpy().copy())
-    for a, b in zip(outs['0'], outs['1']):
-        assert util.scaled_err(a, b) < 2e-5, util.scaled_err(a, b)
+        outs[(mode, ns)] = (batch.values.cpu().numpy().copy(), batch.adv.cpu().numpy().copy(), res.cpu().numpy().copy(),
+                            eng.grads.cpu().numpy().copy())
+    for key in outs:
+        for a, b in zip(outs[('0', None)], outs[key]):
+            assert util.scaled_err(a, b) < 2e-5, (key, util.scaled_err(a, b))
 
 
 @pytest.mark.parametrize('lens', [[128] * 4, [256] * 6, [384, 128, 256]])
