@@ -21,7 +21,7 @@ static std::vector<hipEvent_t> g_pool;
 static hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
     hipEvent_t e;
-    hipEventCreate(&e);
+    (void)hipEventCreate(&e);
     return e;
 }
 
@@ -33,14 +33,14 @@ int prof_begin(const char* name, double flops, double bytes, hipStream_t s) {
     for (size_t i = 0; i < g_names.size(); ++i) if (g_names[i] == name) { id = (int)i; break; }
     if (id < 0) { g_names.push_back(name); id = (int)g_names.size() - 1; }
     ProfRec r{get_event(), get_event(), flops, bytes, id};
-    hipEventRecord(r.a, s);
+    (void)hipEventRecord(r.a, s);
     g_recs.push_back(r);
     return (int)g_recs.size() - 1;
 }
 
 void prof_end(int h, hipStream_t s) {
     if (h < 0 || !g_prof_on) return;
-    hipEventRecord(g_recs[h].b, s);
+    (void)hipEventRecord(g_recs[h].b, s);
 }
 
 }  // namespace dc
@@ -60,9 +60,9 @@ int dc_profile_report(char* names, int64_t* launches, double* total_ms, double* 
     std::vector<int64_t> cnt(n, 0);
     std::vector<double> ms(n, 0.0), fl(n, 0.0), by(n, 0.0);
     for (auto& r : g_recs) {
-        hipEventSynchronize(r.b);
+        (void)hipEventSynchronize(r.b);
         float t = 0.f;
-        hipEventElapsedTime(&t, r.a, r.b);
+        (void)hipEventElapsedTime(&t, r.a, r.b);
         cnt[r.name_id] += 1; ms[r.name_id] += t; fl[r.name_id] += r.flops; by[r.name_id] += r.bytes;
         g_pool.push_back(r.a); g_pool.push_back(r.b);
     }

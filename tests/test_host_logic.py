@@ -345,3 +345,88 @@ def test_rnn_team_backward_tree(G):
                 assert l & 7 == 0 or np.isclose(got[u], s2[l, 0])    # all eight lanes of a group agree
                 got[u] = s2[l, 0]
     assert np.allclose(got, dg @ W, atol=1e-12)
+
+
+# ---- the team kernels' exchange protocol (rnn_team.hip): tagged granules in a ring of four slots ---------------------
+# A model of what the four members of a team do, run under random interleavings: a member's stream publishes its
+# step output with tag T (running counter over the sequences it walks through) into slot T & 3 and, at every step
+# but a sequence's first, waits for the peers' granules of tag T-1.  Claims checked: nobody overwrites a granule a
+# peer still needs (the slot's old tag T-4 has been consumed by all peers or never will be read), a reader never finds a
+# tag NEWER than the one it waits for (it would wait forever), and every schedule terminates.
+def _run_team_model(rng, ns, seq_lens, members=4, slots=4):
+    # stream s owns sequences s, s + ns, ... (one team); program of a member: round-robin over its live streams
+    streams = [[l for l in seq_lens[s::ns] if l > 0] for s in range(ns)]
+    ring = [[[0] * members for _ in range(slots)] for _ in range(ns)]           # ring[s][slot][member] = tag
+    consumed = [[[0] * members for _ in range(members)] for _ in range(ns)]     # consumed[s][reader][writer] = last tag read
+
+    def member_program(m):
+        state = [{'seq': 0, 't': 0, 'tag': 0} for _ in range(ns)]
+        live = [bool(streams[s]) for s in range(ns)]
+        while any(live):
+            for s in range(ns):
+                if not live[s]: continue
+                st = state[s]
+                if st['t'] > 0:                                     # poll the peers' previous step
+                    want = st['tag']
+                    for w in range(members):
+                        if w == m: continue
+                        while True:
+                            have = ring[s][want % slots][w]
+                            assert have <= want, 'granule overwritten before it was read'
+                            if have == want: break
+                            yield                                    # spin
+                        consumed[s][m][w] = want
+                yield                                                # arithmetic (any delay)
+                st['tag'] += 1
+                T = st['tag']
+                old = ring[s][T % slots][m]
+                # the granule being replaced: every peer has moved past it, or it was a sequence's last step (never read)
+                for r in range(members):
+                    if r != m and old > 0: assert consumed[s][r][m] >= old or old in last_tags[s], (old, consumed[s][r][m])
+                ring[s][T % slots][m] = T
+                st['t'] += 1
+                if st['t'] == streams[s][st['seq']]:
+                    st['seq'] += 1; st['t'] = 0
+                    if st['seq'] == len(streams[s]): live[s] = False
+                yield
+
+    last_tags = []
+    for s in range(ns):
+        acc, ends = 0, set()
+        for l in streams[s]:
+            acc += l; ends.add(acc)
+        last_tags.append(ends)
+    progs = [member_program(m) for m in range(members)]
+    alive = list(range(members))
+    steps = 0
+    while alive:
+        m = alive[rng.integers(len(alive))] if rng.random() < 0.7 else alive[0]   # mostly random, sometimes starve the others
+        try:
+            next(progs[m])
+        except StopIteration:
+            alive.remove(m)
+        steps += 1
+        assert steps < 2_000_000, 'schedule does not terminate'
+
+
+@pytest.mark.parametrize('ns', [1, 2, 4])
+def test_rnn_team_ring_protocol_is_safe_under_any_interleaving(ns):
+    rng = np.random.default_rng(100 + ns)
+    for trial in range(12):
+        n = int(rng.integers(1, 9))
+        lens = [int(x) for x in rng.choice([1, 1, 2, 3, 4, 5, 7, 9, 16], size=n)]
+        _run_team_model(rng, ns, lens)
+
+
+def test_rnn_team_ring_model_detects_a_ring_that_is_too_small():
+    # the model has teeth: with two slots a fast member overwrites a granule a slow peer still waits for
+    rng = np.random.default_rng(5)
+    failures = 0
+    for trial in range(20):
+        n = int(rng.integers(2, 9))
+        lens = [int(x) for x in rng.choice([3, 4, 5, 7, 9, 16], size=n)]
+        try:
+            _run_team_model(rng, 2, lens, slots=2)
+        except AssertionError:
+            failures += 1
+    assert failures > 0
