@@ -74,7 +74,9 @@ def pmc_traffic(path, kernel, workload_key):
         return None
     if j.get('meta', {}).get('workload') not in (None, workload_key):
         return None
-    k = j.get('kernels', {}).get(kernel + '_kernel')
+    region_kernels = {'gru_fwd_team': 'rnn_team_fwd', 'lstm_fwd_team': 'rnn_team_fwd', 'gru_bwd_team': 'rnn_team_bwd',
+                      'lstm_bwd_team': 'rnn_team_bwd', 'lstm_fwd_persist': 'lstm_fwd_valu', 'lstm_bwd_persist': 'lstm_bwd_valu'}
+    k = j.get('kernels', {}).get(region_kernels.get(kernel, kernel) + '_kernel')
     return int(k['bytes']) if k else None
 
 
@@ -222,6 +224,9 @@ def main():
         notes = {'embed_bwd_pool16': 'f32 VALU kernel (gathers of 512-byte W2 / basic rows scaled per channel): 1/16 of the '
                                      'dense MACs; its own limits are VALU issue and LDS bandwidth, not the matrix pipes',
                  'lstm_fwd_persist': 'recurrence, serial in time: latency-bound', 'lstm_bwd_persist': 'recurrence, serial in time: latency-bound'}
+        for k in ('gru_fwd_team', 'gru_bwd_team', 'lstm_fwd_team', 'lstm_bwd_team'):
+            notes[k] = ('recurrence, serial in time, a sequence spread over four CUs: bound by the per-step hand-off latency '
+                        'between them (rnn_team.hip), not by arithmetic')
         roofline = {'bound': 'mfma', 'bound_note': notes.get(dom['kernel'], 'f32 MFMA (v_mfma_f32_32x32x2_f32)'), 'kernel': dom['kernel'], 'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                     'traffic': pmc_traffic(args.traffic_json, dom['kernel'], '%s-%d-%dx%d' % (args.cell, args.hidden, B, S)),

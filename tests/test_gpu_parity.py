@@ -102,7 +102,8 @@ def test_hip_matches_reference_golden(case):
         assert np.array_equal(out['ep%d_steps' % ep] > 0, g['ep%d_has_grad' % ep])
 
 
-@pytest.mark.parametrize('cell,hidden,layers', [('lstm', 128, 1), ('lstm', 256, 1), ('gru', 128, 1), ('lstm', 128, 2)])
+@pytest.mark.parametrize('cell,hidden,layers', [('lstm', 128, 1), ('lstm', 256, 1), ('gru', 128, 1), ('lstm', 128, 2), ('lstm', 256, 2),
+                                                ('lstm', 512, 2)])
 def test_hip_matches_oracle_other_cells(cell, hidden, layers):
     # no reference implementation exists for these: the oracle restatement is the bar
     g, rollouts = util.load_case('ragged_s16')
@@ -207,20 +208,22 @@ def test_sparse_pool_backward_matches_dense(monkeypatch, lens):
     assert util.scaled_err(outs['1'][2], outs['0'][2]) < 2e-5
 
 
-def test_full_size_batch_is_invariant_to_trajectory_order():
-    # BASELINE.json-sized batch (96 trajectories x 256 steps, fused embedding path, persistent LSTM) - too large for the
-    # oracle in a test, so a size-independent property instead: the optimizer step is a sum over trajectories, hence
-    # permuting them must leave the losses, the gradient norms and the post-step parameters unchanged (up to fp32
+@pytest.mark.parametrize('cell,hidden,B', [('lstm', 128, 96), ('gru', 256, 96), ('lstm', 256, 200)])
+def test_full_size_batch_is_invariant_to_trajectory_order(cell, hidden, B):
+    # BASELINE.json-sized batches (96 / 200 trajectories x 256 steps, fused embedding path; persistent LSTM-128, the
+    # reference's GRU-256 and LSTM-256 on the team kernels with two and four sequences in flight per team) - too large
+    # for the oracle in a test, so a size-independent property instead: the optimizer step is a sum over trajectories,
+    # hence permuting them must leave the losses, the gradient norms and the post-step parameters unchanged (up to fp32
     # summation order) and must permute the per-step values / advantages with them
     from dotaclient_amd.engine import Engine, pack_rollouts
     dev = torch.device('cuda:0')
-    B, S = 96, 256
+    S = 256
     rollouts = synth.make_rollouts(2024, [S] * B)
     perm = np.random.Generator(np.random.PCG64(5)).permutation(B)
     outs = []
     for order in (np.arange(B), perm):
-        eng = Engine('lstm', 128, 1, dev)
-        eng.load_state_dict(synth.init_state_dict(7, 'lstm', 128, 1))
+        eng = Engine(cell, hidden, 1, dev)
+        eng.load_state_dict(synth.init_state_dict(7, cell, hidden, 1))
         batch = pack_rollouts([rollouts[i] for i in order], S, dev)
         chunks = eng.rollout_pass(batch, S)
         res, status = eng.train_epoch(chunks, 5e-5, 5e-4, 0.5)
