@@ -173,6 +173,30 @@ def main():
         torch.cuda.synchronize()
         ingest_ms = (time.perf_counter() - t0) / 3 * 1e3
 
+    # model publish (optimizer.py:697-716, once per iteration): flat snapshot D2H + host views vs per-tensor .cpu() copies;
+    # reported beside the headline, not inside it
+    publish_ms = None
+    if rank == 0:
+        import io
+
+        def pub_flat():
+            i = eng.start_param_snapshot()
+            buf = io.BytesIO()
+            torch.save(eng.snapshot_state_dict(i), buf)
+
+        def pub_per_tensor():
+            buf = io.BytesIO()
+            torch.save({k: v.cpu() for k, v in eng.state_dict().items()}, buf)
+
+        publish_ms = {}
+        for name, fn in (('flat_snapshot', pub_flat), ('per_tensor_copies', pub_per_tensor)):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                fn()
+            publish_ms[name] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+
     def step():
         chunks = eng.rollout_pass(batch, S)
         for _ in range(E):
@@ -253,6 +277,10 @@ def main():
                        'env_steps_per_s_with_ingest_serialised': round(B * S / (elapsed / args.steps + ingest_ms * 1e-3), 1),
                        'note': 'wire-format dicts -> page-locked staging -> HBM (engine.pack_rollouts), one host thread; '
                                'not part of `value`'},
+            'publish': {'ms_per_publish': publish_ms,
+                        'note': 'model publish once per iteration (optimizer.py:697-716): D2H + torch.save of the 34-tensor state_dict; '
+                                'flat_snapshot = one asynchronous copy of the flat buffer into page-locked memory (Engine.start_param_snapshot), '
+                                'per_tensor_copies = the reference\'s form; not part of `value`'},
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.cell, args.hidden, args.layers, rollouts, S, E, lr, ent, vf)

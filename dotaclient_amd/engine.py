@@ -209,6 +209,45 @@ class Engine:
     def state_dict(self):
         return {n: self.param_view(n).detach().clone() for n in L.param_shapes(self.cell, self.hidden, self.layers)}
 
+    # ---- model publish (optimizer.py:697-716: state_dict -> torch.save -> model exchange, every iteration) ----------
+    def start_param_snapshot(self):
+        """Enqueues ONE device -> host copy of the flat parameter buffer into a page-locked buffer on a side stream,
+        ordered after everything already enqueued on the current stream (the last optimizer step) and returning at
+        once: the copy runs beside whatever the caller enqueues next.  The reference's publish does 34 synchronous
+        per-tensor `.cpu()` copies instead.  Double-buffered: a snapshot stays valid until the one after the next starts."""
+        if not hasattr(self, '_snap'):
+            self._snap = {'host': [torch.empty(self.total, dtype=torch.float32).pin_memory() for _ in range(2)],
+                          'stream': torch.cuda.Stream(device=self.device), 'done': [None, None], 'cur': 1}
+        sn = self._snap
+        sn['cur'] ^= 1
+        i = sn['cur']
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(sn['stream']):
+            sn['stream'].wait_event(ready)
+            sn['host'][i].copy_(self.params, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(sn['stream'])
+        sn['done'][i] = done
+        return i
+
+    def snapshot_state_dict(self, which=None):
+        """The last (or the given) snapshot as the reference's wire format: the 34 names / shapes / dtypes of
+        `Policy.state_dict()` (optimizer.py:706, loaded with strict=True by the actors, agent.py:186,315), as host
+        tensors that own their memory (the snapshot buffer is reused two publishes later).  Blocks only on that
+        snapshot's copy."""
+        sn = getattr(self, '_snap', None)
+        if sn is None or sn['done'][sn['cur'] if which is None else which] is None:
+            raise _lib.DotaHipError('snapshot_state_dict: no snapshot started')
+        i = sn['cur'] if which is None else which
+        sn['done'][i].synchronize()
+        host = sn['host'][i]
+        out = {}
+        for n in L.param_shapes(self.cell, self.hidden, self.layers):
+            off, numel, shape = self.layout[n]
+            out[n] = host[off:off + numel].view(shape).clone()
+        return out
+
     # ---- workspace -------------------------------------------------------------------------------
     def dims(self, batch, lazy_tu=False):
         """lazy_tu: DC_DIMS_LAZY_TU - the target-unit logits are produced by select_logp / loss for the unmasked

@@ -141,6 +141,7 @@ class DotaOptimizer:
         self.eventfile_refresh_freq = 100
         self.e_clip = 0.1
         self.writer = None
+        self._snapshot = None
         self.bucket = None
         self.policy_base = Policy(cell, hidden, layers, device)
         self.policy = self.policy_base
@@ -289,6 +290,8 @@ class DotaOptimizer:
             self.mq.process_data_events()
             l, e, g = self.train(experiences=experiences)
             losses.append(l); entropies.append(e); grad_norms.append(g)
+        if self.checkpoint:
+            self._snapshot = self.engine.start_param_snapshot()            # D2H for the publish, beside the metric reads below
         time_opt = time.time() - start_opt
         losses = self.list_of_dicts_to_dict_of_lists(losses)
         entropies = self.list_of_dicts_to_dict_of_lists(entropies)
@@ -337,8 +340,13 @@ class DotaOptimizer:
         """optimizer.py:697-723: rank 0 serialises state_dict() -> file + model exchange."""
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_rank() != 0:
             return
+        # one D2H copy of the flat parameter buffer (started right after the last epoch was enqueued, run_iteration) instead
+        # of 34 synchronous per-tensor copies; same names / shapes / dtypes on the wire
+        if self._snapshot is None:
+            self._snapshot = self.engine.start_param_snapshot()
         buf = io.BytesIO()
-        torch.save({k: v.cpu() for k, v in self.engine.state_dict().items()}, buf)
+        torch.save(self.engine.snapshot_state_dict(self._snapshot), buf)
+        self._snapshot = None
         blob = buf.getvalue()
         if self.checkpoint:
             with open(os.path.join(self.log_dir, self.MODEL_FILENAME_FMT % version), 'wb') as f:

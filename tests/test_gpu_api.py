@@ -125,3 +125,34 @@ def test_run_iteration_and_nan_guard(tmp_path):
     with pytest.raises(ValueError):
         opt.train(experiences=seqs)
     assert torch.equal(before, opt.engine.params)
+
+
+def test_model_publish_is_the_reference_wire_format(tmp_path):
+    # optimizer.py:697-716: every iteration rank 0 serialises state_dict() and publishes it; the actors load it with
+    # strict=True (agent.py:186,315).  Here: ONE asynchronous D2H copy of the flat parameter buffer (started when the
+    # last epoch is enqueued) instead of 34 per-tensor copies - same names, shapes, dtypes and values on the wire.
+    import io
+    g, rollouts = util.load_case('ragged_s16')
+    opt = make_opt(rollouts, g, tmp_path)
+    opt.checkpoint = True
+    opt.min_seq_per_epoch = 11
+    opt.run_iteration(1)
+    assert opt._snapshot is not None                         # the copy was started inside run_iteration
+    want = {k: v.cpu() for k, v in opt.engine.state_dict().items()}
+    blobs = []
+    opt.mq.publish_model = lambda msg, hdr: blobs.append((hdr, msg))
+    opt.upload_model(version=1)
+    (hdr, blob), = blobs
+    assert hdr == {'version': 1}
+    sd = torch.load(io.BytesIO(blob))
+    assert list(sd.keys()) == list(L.param_shapes().keys())
+    for k, v in sd.items():
+        assert v.dtype == torch.float32 and v.device.type == 'cpu' and torch.equal(v, want[k]), k
+    RO.make_policy(sd).load_state_dict(sd, strict=True)      # what an actor does with it
+    # a later optimizer step must not leak into a snapshot that was already taken (double buffering)
+    i = opt.engine.start_param_snapshot()
+    before = {k: v.clone() for k, v in opt.engine.snapshot_state_dict(i).items()}
+    opt.engine.params.add_(1.0)
+    opt.engine.start_param_snapshot()
+    for k, v in opt.engine.snapshot_state_dict(i).items():
+        assert torch.equal(v, before[k])
