@@ -188,14 +188,15 @@ def main():
             buf = io.BytesIO()
             torch.save({k: v.cpu() for k, v in eng.state_dict().items()}, buf)
 
-        publish_ms = {}
-        for name, fn in (('flat_snapshot', pub_flat), ('per_tensor_copies', pub_per_tensor)):
-            fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(5):
+        samples = {'flat_snapshot': [], 'per_tensor_copies': []}
+        for it in range(17):                      # interleaved, median: single samples of host-side work scatter by 10x
+            for name, fn in (('flat_snapshot', pub_flat), ('per_tensor_copies', pub_per_tensor)):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
                 fn()
-            publish_ms[name] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+                if it >= 2:
+                    samples[name].append((time.perf_counter() - t0) * 1e3)
+        publish_ms = {k: round(float(np.median(v)), 3) for k, v in samples.items()}
 
     def step():
         chunks = eng.rollout_pass(batch, S)

@@ -25,6 +25,7 @@ SIGNATURES = {
                             c_ptr, c_int, c_ptr, c_int, c_int, c_int, c_ptr]),
     'dc_gemm_set_scratch': (None, [c_ptr, c_i64]),
     'dc_dp_average_grads': (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_flt, c_ptr]),
+    'dc_pack_rows': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int]),
     'dc_profile_enable': (c_int, [c_int]),
     'dc_profile_report': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int]),
     'dc_workspace_layout': (c_i64, [c_ptr, c_ptr]),

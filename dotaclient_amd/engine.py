@@ -8,6 +8,7 @@ Mirrors what the reference does implicitly through torch objects:
   Engine.train_epoch        <->  train                             (optimizer.py:581-689)
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -101,6 +102,10 @@ class _Staging:
         return st
 
 
+PACK_THREADS = int(os.environ.get('DC_PACK_THREADS', '8'))
+_TORCH_OF = {np.float32: torch.float32, np.uint8: torch.uint8}
+
+
 def pack_rollouts(rollouts, seq_len, device):
     """Wire-format rollout dicts (optimizer.py:314-326) -> PackedBatch with one sequence per rollout, each
     zero-padded to a multiple of seq_len (optimizer.py:343-382).
@@ -108,8 +113,9 @@ def pack_rollouts(rollouts, seq_len, device):
     Replaces the per-key slicing + `.to(device)` of optimizer.py:353-365.  Every key of every
     rollout is copied ONCE, straight into its column block of one page-locked staging buffer per field
     ([rows,483] f32 observations, [rows,65] u8 actions and masks, [rows,10] f32 sub-rewards; reused across
-    iterations) - no per-rollout temporaries, no concatenation - followed by one asynchronous H2D copy per field
-    (four per batch instead of the reference's 17 per chunk)."""
+    iterations) - no per-rollout temporaries, no concatenation; the ~17 copies per rollout are one native call for the
+    whole batch (`dc_pack_rows`, a few host threads) - followed by one asynchronous H2D copy per field (four per batch
+    instead of the reference's 17 per chunk)."""
     if len(rollouts) == 0:
         raise ValueError('pack_rollouts: no rollouts')
     lens = [(int(d['rewards'].shape[0]) + seq_len - 1) // seq_len * seq_len for d in rollouts]
@@ -117,30 +123,53 @@ def pack_rollouts(rollouts, seq_len, device):
     dev = torch.device(device)
     pin = dev.type == 'cuda'
     st = _Staging.get(rows, pin)
-    obs_n, act_n, msk_n, rew_n = st.views
-    r0 = 0
-    for d, lp in zip(rollouts, lens):
-        T = int(d['rewards'].shape[0])
-        o = d['observations']
-        obs_n[r0:r0 + T, :L.ENV_FEATS] = _as_np(o['env'])
-        c = L.ENV_FEATS
-        for key, cnt in L.UNIT_COUNTS.items():
-            w = cnt * L.UNIT_FEATS
-            obs_n[r0:r0 + T, c:c + w] = _as_np(o[key]).reshape(T, w)
-            c += w
-        for key in L.OUTPUT_KEYS:
-            h0, hc = L.HEAD_OFFSETS[key], L.HEAD_COUNTS[key]
-            act_n[r0:r0 + T, h0:h0 + hc] = _as_np(d['actions'][key])
-            msk_n[r0:r0 + T, h0:h0 + hc] = _as_np(d['masks'][key])
-        rew_n[r0:r0 + T] = _as_np(d['rewards'])
-        if lp > T:      # the zero pad of optimizer.py:367-382 (the buffers are reused: clear just these rows)
-            obs_n[r0 + T:r0 + lp] = 0
-            act_n[r0 + T:r0 + lp] = 0
-            msk_n[r0 + T:r0 + lp] = 0
-            rew_n[r0 + T:r0 + lp] = 0
-        r0 += lp
     lens_n = np.asarray(lens, dtype=np.int64)
     off = np.concatenate([[0], np.cumsum(lens_n)[:-1]]).astype(np.int64)
+
+    # five numbers (src, dst, rows, row_bytes, dst_stride) per key per rollout, executed by dc_pack_rows in one call
+    keep, items = [], []
+
+    def ptr_of(x, dtype, width):
+        if type(x) is torch.Tensor and x.dtype is _TORCH_OF[dtype] and x.numel() == T * width and x.is_contiguous():
+            return x.data_ptr()                                   # the usual case (agent.py:406-416): no numpy detour
+        a = _as_np(x)
+        if a.dtype != dtype or not a.flags['C_CONTIGUOUS']:
+            if a.dtype == np.bool_ and dtype == np.uint8:
+                a = a.view(np.uint8) if a.flags['C_CONTIGUOUS'] else np.ascontiguousarray(a).view(np.uint8)
+            else:
+                a = np.ascontiguousarray(a, dtype=dtype)
+            keep.append(a)
+        if a.size != T * width:
+            raise ValueError('pack_rollouts: a %d-step rollout holds an array of %d elements where %d x %d were expected'
+                             % (T, a.size, T, width))
+        return a.__array_interface__['data'][0]
+
+    obs_p, act_p, msk_p, rew_p = st.obs.data_ptr(), st.act.data_ptr(), st.msk.data_ptr(), st.rew.data_ptr()
+    OBS_B, ACT_B, REW_B = 4 * L.OBS_DIM, L.ACT_DIM, 40
+    obs_cols = [('env', 0, L.ENV_FEATS)]
+    c = L.ENV_FEATS
+    for key, cnt in L.UNIT_COUNTS.items():
+        obs_cols.append((key, c, cnt * L.UNIT_FEATS))
+        c += cnt * L.UNIT_FEATS
+    for i, d in enumerate(rollouts):
+        T, lp, r0 = int(d['rewards'].shape[0]), lens[i], int(off[i])
+        o, acts, msks = d['observations'], d['actions'], d['masks']
+        for key, c0, w in obs_cols:
+            items += (ptr_of(o[key], np.float32, w), obs_p + r0 * OBS_B + 4 * c0, T, 4 * w, OBS_B)
+        for key in L.OUTPUT_KEYS:
+            h0, hc = L.HEAD_OFFSETS[key], L.HEAD_COUNTS[key]
+            items += (ptr_of(acts[key], np.uint8, hc), act_p + r0 * ACT_B + h0, T, hc, ACT_B)
+            items += (ptr_of(msks[key], np.uint8, hc), msk_p + r0 * ACT_B + h0, T, hc, ACT_B)
+        items += (ptr_of(d['rewards'], np.float32, 10), rew_p + r0 * REW_B, T, REW_B, REW_B)
+        if lp > T:      # the zero pad of optimizer.py:367-382 (the buffers are reused: clear just these rows)
+            n = lp - T
+            items += (0, obs_p + (r0 + T) * OBS_B, n, OBS_B, OBS_B)
+            items += (0, act_p + (r0 + T) * ACT_B, n, ACT_B, ACT_B)
+            items += (0, msk_p + (r0 + T) * ACT_B, n, ACT_B, ACT_B)
+            items += (0, rew_p + (r0 + T) * REW_B, n, REW_B, REW_B)
+    tab = np.ascontiguousarray(np.array(items, dtype=np.int64).reshape(-1, 5).T)          # [5, n_items] (items: flat list)
+    col = lambda k: ctypes.c_void_p(tab[k].ctypes.data)
+    _lib.check(_lib.load().dc_pack_rows(col(0), col(1), col(2), col(3), col(4), tab.shape[1], PACK_THREADS), 'dc_pack_rows')
     to = lambda x: x.to(dev, non_blocking=True) if pin else x.clone()
     batch = PackedBatch(to(st.obs), to(st.act), to(st.msk), to(st.rew), torch.from_numpy(off).to(dev),
                         torch.from_numpy(lens_n.astype(np.int32)).to(dev), int(lens_n.max()))

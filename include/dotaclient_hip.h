@@ -155,6 +155,13 @@ int dc_gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const 
 int dc_dp_average_grads(const int64_t* seg_off, const int32_t* seg_len, const int32_t* seg_gate, int n_seg,
                         int max_seg_len, float* grads, const float* counts, float vf_coef, dc_stream_t stream);
 
+/* Host-side ingest (no device work): a list of 2-D copies src[i] (rows[i] x row_bytes[i], contiguous; 0 = write
+ * zeros) -> dst[i] (row stride dst_stride[i] bytes), executed by up to n_threads host threads.  Fills the page-locked
+ * staging buffers of a batch from the wire-format arrays of its rollouts in one call - replaces the per-key slicing
+ * of optimizer.py:353-365 (one interpreter-level copy per key per chunk).  Pointers are passed as int64. */
+int dc_pack_rows(const int64_t* src, const int64_t* dst, const int64_t* rows, const int64_t* row_bytes,
+                 const int64_t* dst_stride, int64_t n_items, int n_threads);
+
 /* Measurement aid for bench.py (not part of the reference surface): when enabled, every GEMM call and
  * every recurrent step launch is bracketed by two HIP events on the launch stream.  dc_profile_report
  * synchronises, fills per-region sums (names: 64-byte slots) and returns the region count. */
