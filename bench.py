@@ -276,7 +276,7 @@ def main():
             'nan_status': status, 'final_loss': float(losses[0]),
             'ingest': {'pack_h2d_ms_per_batch': round(ingest_ms, 3),
                        'env_steps_per_s_with_ingest_serialised': round(B * S / (elapsed / args.steps + ingest_ms * 1e-3), 1),
-                       'note': 'wire-format dicts -> page-locked staging -> HBM (engine.pack_rollouts), one host thread; '
+                       'note': 'wire-format dicts -> page-locked staging (dc_pack_rows, DC_PACK_THREADS host threads) -> HBM (engine.pack_rollouts); '
                                'not part of `value`'},
             'publish': {'ms_per_publish': publish_ms,
                         'note': 'model publish once per iteration (optimizer.py:697-716): D2H + torch.save of the 34-tensor state_dict; '
