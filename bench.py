@@ -240,7 +240,21 @@ def main():
             avg_us = r['total_ms'] * 1e3 / r['launches']
             kernels.append({'kernel': r['kernel'], 'launches_per_step': r['launches'], 'avg_us': round(avg_us, 3),
                             'ms_per_step': round(r['total_ms'], 3),
-                            'achieved_tflops': round(r['flops'] / (r['total_ms'] * 1e-3) / 1e12, 3)})
+                            'achieved_tflops': round(r['flops'] / (r['total_ms'] * 1e-3) / 1e12, 3),
+                            # algorithmic bytes / time; HBM peak 8 TB/s (MI355X_MICROARCH.md) - the yardstick of the streaming kernels
+                            'achieved_gbs': round(r['bytes'] / (r['total_ms'] * 1e-3) / 1e9, 1)})
+        # the HBM-bound side (GAE / loss / Adam / pooling stream their operands once): largest by time
+        hbm_names = ('pool_env_fwd', 'embed_scatter_bwd(+reduce)', 'ppo_loss(stats+loss+finalize)', 'gradnorm_clip_adam', 'attn_logits',
+                     'attn_bwd_q', 'gae_scan', 'select_logp')
+        hbm = [r for r in regions if r['kernel'] in hbm_names]
+        roofline_hbm = None
+        if hbm:
+            hd = hbm[0]
+            gbs = hd['bytes'] / (hd['total_ms'] * 1e-3) / 1e9
+            roofline_hbm = {'bound': 'hbm', 'kernel': hd['kernel'], 'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                            'frac': round(gbs / 8000.0, 4), 'avg_launch_us': round(hd['total_ms'] * 1e3 / hd['launches'], 3),
+                            'algorithmic_bytes_per_launch': hd['bytes'] / hd['launches'],
+                            'traffic': pmc_traffic(args.traffic_json, hd['kernel'].split('(')[0], '%s-%d-%dx%d' % (args.cell, args.hidden, B, S))}
         dom = regions[0]
         achieved = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
         # every region on this list is priced against the dense f32 rate of the chip, 157.3 TF: it is both the f32 MFMA
@@ -273,6 +287,7 @@ def main():
                        'cell': args.cell, 'hidden': args.hidden, 'layers': args.layers, 'batch_per_gpu': B,
                        'seq_len': S, 'epochs': E, 'parallelism': 'dp%d' % world},
             'roofline': roofline,
+            'roofline_hbm': roofline_hbm,
             'nan_status': status, 'final_loss': float(losses[0]),
             'ingest': {'pack_h2d_ms_per_batch': round(ingest_ms, 3),
                        'env_steps_per_s_with_ingest_serialised': round(B * S / (elapsed / args.steps + ingest_ms * 1e-3), 1),

@@ -134,6 +134,8 @@ int gae_scan(const float* rewards, const float* values, const int64_t* seq_off, 
     // The reference keeps gamma and lam as python doubles: gamma*lam is a double product
     // (optimizer.py:61), lfilter runs in double with the double gamma (optimizer.py:63), and only the
     // TD residuals use float32(gamma) (numpy scalar-times-float32-array arithmetic, optimizer.py:60).
+    // algorithmic bytes: 10 sub-rewards + value read, advantage + return written per env-step (44 + 8 B)
+    ProfScope prof("gae_scan", 0.0, 52.0 * n_seq * max_len, stream);
     hipLaunchKernelGGL(gae_scan_kernel, dim3(n_seq), dim3(64), lds_bytes, stream, rewards, values, seq_off,
                        seq_len, (float)gamma, gamma, gamma * lam, adv, ret);
     return launch_check("gae_scan");

@@ -514,7 +514,15 @@ int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int 
         const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
         splits = 1;
         if (tiles < 256 && K >= 2048 && !relu && aux == nullptr) {
-            long want = (512 + tiles - 1) / tiles;
+            // workgroups the dispatch below will launch per split (64 x 128 tiles when N allows, else 64 x 64)
+            const bool wide = !(M & 63) && !(N & 127);
+            const long wgs = (long)((M + 63) / 64) * (wide ? N / 128 : (N + 63) / 64);
+            // one workgroup per CU in a single round is the sweet spot (tools/gemm_split_sweep.py: dW_pre 256 x 896 takes
+            // 80 us at 224-252 or 448-504 workgroups, 112 us at 280 - a second, nearly empty round); two per CU when one
+            // round would leave a quarter of the chip idle
+            long want = 256 / wgs;
+            if (want < 1) want = 1;
+            if (wgs * want < 192) want = 512 / wgs;
             long maxs = K / 512;
             splits = (int)(want < maxs ? want : maxs);
             if (splits < 1) splits = 1;

@@ -442,6 +442,7 @@ int attn_bwd_q(const float* dtu, const float* emb, float* dheadout, long long nr
 
 int select_logp(const float* headout, const float* tu, const uint8_t* act, const uint8_t* mask, float* logp_sel,
                 float* values, int32_t* argmax, long long nr, hipStream_t s) {
+    ProfScope prof("select_logp", 0.0, (double)nr * (4.0 * (26 + 40) + 2.0 * 65 + 4.0 * (5 + 1 + 5)), s);
     hipLaunchKernelGGL(select_logp_kernel, dim3((unsigned)((nr * 5 + 255) / 256)), dim3(256), 0, s, headout, tu, act, mask,
                        logp_sel, values, argmax, nr);
     return launch_check("select_logp");
