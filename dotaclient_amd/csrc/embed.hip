@@ -323,7 +323,10 @@ int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, c
     int spb = (int)((nr + 2047) / 2048);
     if (spb < 4) spb = 4;
     const int nblk = (int)((nr + spb - 1) / spb);        // <= 2048 -> <= 10.5 MB of scratch
-    ProfScope prof("embed_scatter_bwd(+reduce)", 2.0 * nr * 40 * 128, 4.0 * nr * (40 * 128 + 896 * 2 + 128 + 40), s);
+    // algorithmic bytes: d(emb) rows written for the units this pass owns (8 of 40 with skip16), xcat / dxcat rows, the
+    // attention query, the target-unit gradients
+    const double units = skip16 ? 8.0 : 40.0;
+    ProfScope prof("embed_scatter_bwd(+reduce)", 2.0 * nr * units * 128, 4.0 * nr * (units * 128 + 896 * 2 + 128 + 40), s);
     hipLaunchKernelGGL(embed_scatter_bwd_kernel, dim3(nblk), dim3(256), 0, s, obs, xcat, dxcat, dtu, q, ldq, amax, demb,
                        scratch, nr, spb, skip16);
     hipLaunchKernelGGL(embed_scatter_reduce_kernel, dim3(5, 32), dim3(256), 0, s, scratch, nblk, dWenv, dbenv, db2);
