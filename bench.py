@@ -129,6 +129,8 @@ def main():
     ap.add_argument('--seq-len', type=int, default=256)
     ap.add_argument('--epochs', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-host-extras', action='store_true',
+                    help='skip the ingest / publish timings (hundreds of small copies that would pollute a kernel trace)')
     ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'pmc_traffic_latest.json'),
                     help='per-kernel HBM bytes from the rocprofv3 PMC passes (tools/gpu_round.sh + tools/pmc_traffic.py); '
                          'PMC counters cannot be read from inside the process, so `traffic` is taken from this file')
@@ -163,7 +165,7 @@ def main():
     # host -> device ingest of one batch (pack_rollouts: page-locked staging + 4 H2D copies), steady state; reported
     # beside the headline, never inside it (inputs are resident in HBM when the timed region starts)
     ingest_ms = None
-    if rank == 0:
+    if rank == 0 and not args.no_host_extras:
         for _ in range(2):
             pack_rollouts(rollouts, S, dev)
         torch.cuda.synchronize()
@@ -176,7 +178,7 @@ def main():
     # model publish (optimizer.py:697-716, once per iteration): flat snapshot D2H + host views vs per-tensor .cpu() copies;
     # reported beside the headline, not inside it
     publish_ms = None
-    if rank == 0:
+    if rank == 0 and not args.no_host_extras:
         import io
 
         def pub_flat():
@@ -290,7 +292,8 @@ def main():
             'roofline': roofline,
             'roofline_hbm': roofline_hbm,
             'nan_status': status, 'final_loss': float(losses[0]),
-            'ingest': {'pack_h2d_ms_per_batch': round(ingest_ms, 3),
+            'ingest': None if ingest_ms is None else {
+                       'pack_h2d_ms_per_batch': round(ingest_ms, 3),
                        'env_steps_per_s_with_ingest_serialised': round(B * S / (elapsed / args.steps + ingest_ms * 1e-3), 1),
                        'note': 'wire-format dicts -> page-locked staging (dc_pack_rows, DC_PACK_THREADS host threads) -> HBM (engine.pack_rollouts); '
                                'not part of `value`'},

@@ -344,6 +344,34 @@ int unit_basic_bwd(const float* obs, const float* dbasic, float* dW1, float* db1
     return launch_check("unit_basic_bwd");
 }
 
+// The tail of the fused embedding backward in one launch: dW1/db1 += the dense kernel's partials [na][13][128] and the
+// sparse kernel's [nb][13][128]; db2 of the two 16-unit types += the sparse kernel's [2][n2][128] bias partials.
+__global__ __launch_bounds__(256) void embed_tail_reduce_kernel(const float* __restrict__ pa, int na, const float* __restrict__ pb,
+                                                                int nb, float* __restrict__ dW1, float* __restrict__ db1,
+                                                                const float* __restrict__ p2, int n2, float* __restrict__ db2) {
+    if (blockIdx.x == 7) {                              // bias gradients of types 2, 3: thread = (type, channel)
+        const int t = threadIdx.x >> 7, c = threadIdx.x & 127;
+        float acc = 0.f;
+        for (int b = blockIdx.y; b < n2; b += gridDim.y) acc += p2[((size_t)t * n2 + b) * 128 + c];
+        atomicAdd(&db2[t * 128 + c], acc);
+        return;
+    }
+    const int idx = blockIdx.x * 256 + threadIdx.x;   // 0..1663
+    if (idx >= 1664) return;
+    float acc = 0.f;
+    for (int b = blockIdx.y; b < na; b += gridDim.y) acc += pa[(size_t)b * 1664 + idx];
+    for (int b = blockIdx.y; b < nb; b += gridDim.y) acc += pb[(size_t)b * 1664 + idx];
+    const int f = idx >> 7, c = idx & 127;
+    if (f < 12) atomicAdd(&dW1[c * 12 + f], acc);
+    else atomicAdd(&db1[c], acc);
+}
+
+int embed_tail_reduce(const float* pa, int na, const float* pb, int nb, float* dW1, float* db1, const float* p2, int n2,
+                      float* db2, hipStream_t s) {
+    hipLaunchKernelGGL(embed_tail_reduce_kernel, dim3(8, 32), dim3(256), 0, s, pa, na, pb, nb, dW1, db1, p2, n2, db2);
+    return launch_check("embed_tail_reduce");
+}
+
 int unit_basic_reduce(const float* partials, int nblk, float* dW1, float* db1, hipStream_t s) {
     hipLaunchKernelGGL(unit_basic_reduce_kernel, dim3(7, 32), dim3(256), 0, s, partials, nblk, dW1, db1);
     return launch_check("unit_basic_reduce");

@@ -615,15 +615,10 @@ int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const 
             hipLaunchKernelGGL(embed_bwd_dw1_kernel, dim3(grid), dim3(256), lds, s, obs, demb, W1, b1, W2, scratch, ty, tiles);
         }
         if (int e = launch_check("embed_bwd_dw1")) return e;
-        if (int e = unit_basic_reduce(scratch, grid, dW1, db1, s)) return e;
+        // one launch: dW1/db1 from the dense and the sparse partials, db2 of types 2, 3 from the sparse bias partials
+        if (sparse16) return embed_tail_reduce(scratch, grid, part1, 2 * SPARSE_WG_PER_TYPE, dW1, db1, part2, SPARSE_WG_PER_TYPE, sp->db2 + 2 * 128, s);
+        return unit_basic_reduce(scratch, grid, dW1, db1, s);
     }
-    if (sparse16) {
-        if (int e = unit_basic_reduce(part1, 2 * SPARSE_WG_PER_TYPE, dW1, db1, s)) return e;
-        for (int t = 2; t < 4; ++t)
-            if (int e = colsum(part2 + (size_t)(t - 2) * SPARSE_WG_PER_TYPE * 128, 128, SPARSE_WG_PER_TYPE, 128, sp->db2 + t * 128, s))
-                return e;
-    }
-    return 0;
 }
 
 }  // namespace dc

@@ -17,6 +17,8 @@ struct RnnStepArgs {
     float* hprev;          // [rows][H]
     float* cseq;           // [rows][H]   LSTM
     float* cprev;          // [rows][H]   LSTM
+    const float* h0;       // [n_seq][H] initial state of this layer (nullptr = zeros); rnn_forward_layer seeds hprev/cprev[first row]
+    const float* c0;       // [n_seq][H] LSTM
     // backward
     const float* WhhT;     // [H][G*H]
     float* dh;             // [rows][H]  in: dL/dh_t from above, out: total dL/dh_t
@@ -57,6 +59,8 @@ int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, c
                       long long nr, int skip16, hipStream_t s);
 int unit_basic_bwd(const float* obs, const float* dbasic, float* dW1, float* db1, float* scratch, long long nr,
                    hipStream_t s);
+int embed_tail_reduce(const float* pa, int na, const float* pb, int nb, float* dW1, float* db1, const float* p2, int n2,
+                      float* db2, hipStream_t s);
 int colsum(const float* X, int ld, long long rows, int cols, float* out, hipStream_t s);
 int unit_basic_reduce(const float* partials, int nblk, float* dW1, float* db1, hipStream_t s);   // partials [nblk][13][128]
 // embed_fused.hip (rows % 128 == 0: first embedding layer recomputed on chip, `basic` never stored)

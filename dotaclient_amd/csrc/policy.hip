@@ -133,10 +133,9 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
         const int pb = DC_P_RNN0 + 4 * l;
         DC_TRY(gemm_f32(x, P.p(pb + 0), w.fl(l, DC_WSL_GATES), (int)NR, G * H, in, in, in, G * H, 0, 0, P.p(pb + 2), 0, nullptr,
                         0, 0, 1, s));
-        DC_TRY(rnn_seed_state(h0 ? h0 + (size_t)l * B * H : nullptr, w.fl(l, DC_WSL_HPREV), seq_off, seq_len, B, H, s));
-        if (d->cell == 1)
-            DC_TRY(rnn_seed_state(c0 ? c0 + (size_t)l * B * H : nullptr, w.fl(l, DC_WSL_CPREV), seq_off, seq_len, B, H, s));
         RnnStepArgs a{};
+        a.h0 = h0 ? h0 + (size_t)l * B * H : nullptr;
+        a.c0 = (c0 && d->cell == 1) ? c0 + (size_t)l * B * H : nullptr;
         a.seq_off = seq_off; a.seq_len = seq_len; a.n_seq = B; a.H = H;
         a.Whh = P.p(pb + 1); a.bhh = P.p(pb + 3);
         a.gates = w.fl(l, DC_WSL_GATES); a.hn = w.fl(l, DC_WSL_HN); a.hseq = w.fl(l, DC_WSL_HSEQ);
@@ -154,6 +153,13 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
     // (DC_DIMS_LAZY_TU: left to dc_select_logp / dc_ppo_loss_fwd_bwd, which know which units are unmasked)
     if (!(d->flags & DC_DIMS_LAZY_TU)) DC_TRY(attn_logits(w.f(DC_WS_HEADOUT), w.f(DC_WS_EMB), w.f(DC_WS_TU), NR, s));
     return 0;
+}
+
+// dst[0..n_total) (float4 units) = src[0..n_src) followed by zeros: the head weights [154][H] padded to [160][H]
+__global__ __launch_bounds__(256) void copy_zero_pad_kernel(const float* __restrict__ src, float* __restrict__ dst, int n_src, int n_total) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_total) return;
+    reinterpret_cast<float4*>(dst)[i] = i < n_src ? reinterpret_cast<const float4*>(src)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // Consumes DHEADOUT[:,128:154] and DTU (written by ppo_loss_fwd_bwd) and everything policy_forward
@@ -176,12 +182,9 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     DC_TRY(attn_bwd_q(w.f(DC_WS_DTU), w.f(DC_WS_EMB), w.f(DC_WS_DHEADOUT), NR, s));
     // dH = dheadout[:, 0:160] * [W_heads; 0]: K padded to a multiple of 32 (dheadout's pad columns are
     // zeroed by the loss kernel), so the product runs on the fast GEMM path
-    {
-        hipError_t e1 = hipMemcpyAsync(w.f(DC_WS_HEADW_PAD), P.p(DC_P_HEADS_W), (size_t)HO_N * H * sizeof(float),
-                                       hipMemcpyDeviceToDevice, s);
-        hipError_t e2 = hipMemsetAsync(w.f(DC_WS_HEADW_PAD) + (size_t)HO_N * H, 0, (size_t)(HO_LD - HO_N) * H * sizeof(float), s);
-        if (e1 != hipSuccess || e2 != hipSuccess) { set_error("policy_backward: head weight pad", (int)(e1 != hipSuccess ? e1 : e2)); return 1; }
-    }
+    hipLaunchKernelGGL(copy_zero_pad_kernel, dim3((HO_LD * H / 4 + 255) / 256), dim3(256), 0, s, P.p(DC_P_HEADS_W), w.f(DC_WS_HEADW_PAD),
+                       HO_N * H / 4, HO_LD * H / 4);   // one launch instead of a copy and a memset
+    DC_TRY(launch_check("policy_backward: head weight pad"));
     DC_TRY(gemm_f32(w.f(DC_WS_DHEADOUT), w.f(DC_WS_HEADW_PAD), w.fl(TOP, DC_WSL_DH), (int)NR, H, HO_LD, HO_LD, H, H, 0, 1, nullptr,
                     0, nullptr, 0, 0, 1, s));
     DC_TRY(gemm_f32(w.f(DC_WS_DHEADOUT), w.fl(TOP, DC_WSL_HSEQ), Gd.p(DC_P_HEADS_W), HO_N, H, (int)NR, HO_LD, H, H, 1, 1,

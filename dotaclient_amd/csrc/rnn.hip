@@ -309,8 +309,19 @@ bool rnn_uses_persistent(int cell, int H) { return cell == CELL_LSTM && lstm_per
 
 int rnn_forward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     if (int e = check_h(a.H)) return e;
-    if (cell == CELL_LSTM && lstm_persist_supported(a.H) && persist_enabled()) return lstm_forward_persist(a, max_len, s);
-    if (persist_enabled() && rnn_team_supported(cell, a.H, a.n_seq)) return rnn_team_forward(cell, a, max_len, s);
+    // hprev/cprev[first row of a sequence] = h0/c0 (zeros when absent).  The one-sequence-per-workgroup LSTM kernels
+    // and the team kernels read h0/c0 themselves and write those rows (two launches less per pass); the others are
+    // seeded here.
+    const bool lstm_persist = cell == CELL_LSTM && lstm_persist_supported(a.H) && persist_enabled();
+    const bool team = !lstm_persist && persist_enabled() && rnn_team_supported(cell, a.H, a.n_seq);
+    const bool self_seeding = (lstm_persist && lstm_persist_use_valu(a.n_seq)) || team;
+    if (!self_seeding) {
+        if (int e = rnn_seed_state(a.h0, a.hprev, a.seq_off, a.seq_len, a.n_seq, a.H, s)) return e;
+        if (cell == CELL_LSTM)
+            if (int e = rnn_seed_state(a.c0, a.cprev, a.seq_off, a.seq_len, a.n_seq, a.H, s)) return e;
+    }
+    if (lstm_persist) return lstm_forward_persist(a, max_len, s);
+    if (team) return rnn_team_forward(cell, a, max_len, s);
     dim3 grid(a.H / 16, (a.n_seq + 15) / 16);
     for (int t = 0; t < max_len; ++t) {
         a.t = t;

@@ -47,8 +47,8 @@ constexpr int PF = 4;   // global loads run this many steps ahead (L2/MALL laten
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
-// forward.  gates[row][4H]: W_ih x + b_ih on entry, activated i,f,g,o on exit; hprev/cprev[first row] =
-// h0/c0; h_t, c_t -> hseq/cseq[row] and hprev/cprev[row+1] (exactly lstm_fwd_persist_kernel's contract).
+// forward.  gates[row][4H]: W_ih x + b_ih on entry, activated i,f,g,o on exit; hprev/cprev[first row] <-
+// h0/c0 (written here); h_t, c_t -> hseq/cseq[row] and hprev/cprev[row+1] (exactly lstm_fwd_persist_kernel's contract).
 // ---------------------------------------------------------------------------------------------------
 template <int H, bool TIMING = false>   // TIMING (DC_LSTM_TIMING=1): s_memtime phase sums of wave 3 of workgroup 0 -> p.dbg
 __global__ __launch_bounds__(4 * H) void lstm_fwd_valu_kernel(RnnStepArgs p) {
@@ -86,8 +86,15 @@ __global__ __launch_bounds__(4 * H) void lstm_fwd_valu_kernel(RnnStepArgs p) {
     const bool is_g = q == 2;                                     // the tanh gate
     const float sc = is_g ? -2.8853900817779268f : -1.4426950408889634f;
     const float am = is_g ? 2.f : 1.f, aa = is_g ? -1.f : 0.f;   // act = am * rcp(1 + exp2(sc * x)) + aa
-    float c = p.cprev[row0 * H + u];
-    if (tid < H) h_lds[0][tid] = p.hprev[row0 * H + tid];
+    // initial state: read from h0/c0 (zeros when absent) and written to the first row's hprev/cprev, where the backward and
+    // the dW_hh product expect it
+    float c = p.c0 ? p.c0[(size_t)b * H + u] : 0.f;
+    if (q == 0) p.cprev[row0 * H + u] = c;
+    if (tid < H) {
+        const float h = p.h0 ? p.h0[(size_t)b * H + tid] : 0.f;
+        h_lds[0][tid] = h;
+        p.hprev[row0 * H + tid] = h;
+    }
     float* const gp = p.gates + row0 * (4 * H) + q * H + u;      // this lane's gate column, row 0
     float* const sA = ((q & 1) ? p.cseq : p.hseq) + row0 * H + u;
     float* const sB = ((q & 1) ? p.cprev : p.hprev) + row0 * H + u + H;

@@ -154,12 +154,24 @@ __global__ __launch_bounds__(512) void rnn_team_fwd_kernel(RnnStepArgs p, u64* _
         }
         row0[s] = (size_t)p.seq_off[sq[s]];
         tt[s] = 0;
-        st[s] = CELL == CELL_LSTM ? p.cprev[row0[s] * H + u] : p.hprev[row0[s] * H + u];
+        // initial state from h0/c0 (zeros when absent); every member writes its own 64 units of the first row's
+        // hprev/cprev, where the backward and the dW_hh product expect it
+        const size_t sb = (size_t)sq[s] * H;
+        if constexpr (CELL == CELL_LSTM) {
+            st[s] = p.c0 ? p.c0[sb + u] : 0.f;
+            if (dup == 0 && q == 0) p.cprev[row0[s] * H + u] = st[s];
+        } else {
+            st[s] = p.h0 ? p.h0[sb + u] : 0.f;
+        }
         const float* gp = gate_ptr(s);
         x0[s] = gp[0];
         x1[s] = gp[(size_t)min(1, len[s] - 1) * GH];
         __syncthreads();                                           // the previous sequence's last reads of h_lds[s]
-        if (tid < H) h_lds[s][0][tid] = p.hprev[row0[s] * H + tid];
+        if (tid < H) {
+            const float h = p.h0 ? p.h0[sb + tid] : 0.f;
+            h_lds[s][0][tid] = h;
+            if (tid >= U0 && tid < U0 + TEAM_US) p.hprev[row0[s] * H + tid] = h;
+        }
         // wait for these loads inside this (rare) path: otherwise the wait lands after the join with the path that
         // opens nothing, as a vmcnt(0) behind that path's freshly issued stores
         asm volatile("" : "+v"(x0[s]), "+v"(x1[s]), "+v"(st[s]) : : "memory");
