@@ -139,15 +139,21 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # Test aid (never set by the driver): DC_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and uses gloo, so that the whole
+    # multi-rank flow of this script (broadcast, flat-bucket all-reduce, barriers, max over ranks, rank-0 JSON) can be
+    # exercised on a one-GPU box; RCCL refuses two ranks on one device.
+    one_device = os.environ.get('DC_BENCH_ONE_DEVICE') == '1'
+    dev_index = 0 if (one_device or world == 1) else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
-    else:
-        torch.cuda.set_device(0)
+        if one_device:
+            dist.init_process_group(backend='gloo')
+        else:
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', dev_index))
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node = --gpus'
-    dev = torch.device('cuda', local_rank if world > 1 else 0)
+    dev = torch.device('cuda', dev_index)
     lr, ent, vf = 5e-5, 5e-4, 0.5
     B, S, E = args.batch, args.seq_len, args.epochs
 
