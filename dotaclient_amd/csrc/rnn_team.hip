@@ -91,6 +91,10 @@ __device__ __forceinline__ void team_of_block(int n_teams, int& team, int& membe
 // work and ~1 us of waiting for the peers' granules, so with more sequences than teams the wait of one
 // stream is filled with the work of the others.  Stream s of team T owns sequences T*NS + s + k*NS*teams.
 // ---------------------------------------------------------------------------------------------------
+// early granule read of a lone stream right behind its publish (see the end of step): measured SLOWER (forward 305 -> 386 us
+// per 256 steps): the peers publish at the same moment, a read issued now mostly comes back stale and costs a second round trip
+constexpr bool EARLY1 = false;
+
 template <int CELL, int NS, bool TIMING = false>   // TIMING (DC_TEAM_TIMING=1): s_memtime phase sums of wave 0 of block 0 -> p.dbg
 __global__ __launch_bounds__(512) void rnn_team_fwd_kernel(RnnStepArgs p, u64* __restrict__ xbuf, int n_teams) {
     constexpr int H = TEAM_H, G = CELL == CELL_GRU ? 3 : 4, GH = G * H;
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(512) void rnn_team_fwd_kernel(RnnStepArgs p, u64* _
             h_lds[s][par][pidx] = v;
         }
         stamp(2);      // spinning
-        pre_owner = -1;
+        if constexpr (!(NS == 1 && EARLY1)) pre_owner = -1;
         __syncthreads();
         stamp(3);      // barrier
         if (NS > 1) {
@@ -305,6 +309,12 @@ __global__ __launch_bounds__(512) void rnn_team_fwd_kernel(RnnStepArgs p, u64* _
         // (holding the stores back until after the next step call's poll was measured and is slower: the later publish
         // costs the peers more than it saves)
         flush();
+        if constexpr (NS == 1 && EARLY1) {
+            // one stream: a first read of the peers' granules of THIS step right behind the publish, so that its round trip
+            // overlaps the wait for the store acknowledgements at the loop back-edge instead of following it
+            if (more && tid < H - TEAM_US) pre = granule_load(xb + (tag[s] & 3) * H + pidx);
+            pre_owner = more ? s : -1;
+        }
         stamp(4);      // arithmetic + stores
         return is_dead == 0;
     };
