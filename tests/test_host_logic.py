@@ -74,6 +74,63 @@ def test_pack_rollouts_matches_flatten_and_reuses_staging():
         assert b.rows == r0
 
 
+def test_pack_rollouts_accepts_what_the_wire_may_carry():
+    # the actors send torch tensors (agent.py:406-416); numpy arrays, bool masks (the oracle's form), non-contiguous
+    # views and float64 observations must come out the same bytes - dc_pack_rows only sees contiguous f32 / u8
+    from dotaclient_amd.engine import pack_rollouts
+    base = synth.make_rollouts(21, [40, 64, 7, 300])
+    want = pack_rollouts(base, 16, torch.device('cpu'))
+    odd = []
+    for i, d in enumerate(base):
+        e = {'observations': dict(d['observations']), 'actions': dict(d['actions']), 'masks': dict(d['masks']),
+             'rewards': d['rewards']}
+        if i == 0:
+            e['masks'] = {k: v.bool() for k, v in d['masks'].items()}
+            e['actions'] = {k: v.numpy().astype(bool) for k, v in d['actions'].items()}
+        if i == 1:
+            e['observations'] = {k: v.double() for k, v in d['observations'].items()}
+            e['rewards'] = np.asfortranarray(d['rewards'])
+        if i == 2:
+            e['observations'] = {k: torch.stack([v, v], 1)[:, 0] for k, v in d['observations'].items()}     # strided views
+        if i == 3:
+            e['observations'] = {k: v.numpy() for k, v in d['observations'].items()}
+            e['rewards'] = torch.from_numpy(np.ascontiguousarray(d['rewards']))
+        odd.append(e)
+    got = pack_rollouts(odd, 16, torch.device('cpu'))
+    for a, b in ((want.obs, got.obs), (want.act, got.act), (want.mask, got.mask), (want.rew, got.rew)):
+        assert torch.equal(a, b)
+    bad = dict(base[0]); bad['rewards'] = base[0]['rewards'][:-1]       # a key with one step less than the others
+    with pytest.raises(ValueError):
+        pack_rollouts([bad], 16, torch.device('cpu'))
+
+
+def test_dc_pack_rows_threads_and_bad_items():
+    import ctypes
+    from dotaclient_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    n, rows, w, stride = 200, 256, 192, 1932
+    src = [rng.integers(0, 255, size=(rows, w), dtype=np.uint8) for _ in range(n)]
+    dst = np.zeros((n, rows, stride), dtype=np.uint8)
+    tab = np.zeros((5, n + 1), dtype=np.int64)
+    for i in range(n):
+        tab[:, i] = (src[i].ctypes.data, dst[i].ctypes.data + 7 * (i % 5), rows, w, stride)
+    pad = np.full((64, 40), 9, dtype=np.uint8)
+    tab[:, n] = (0, pad.ctypes.data, 64, 40, 40)                        # zero-fill item
+    col = lambda k: ctypes.c_void_p(tab[k].ctypes.data)
+    for threads in (1, 3, 8, 64):
+        dst[:] = 0; pad[:] = 9
+        assert lib.dc_pack_rows(col(0), col(1), col(2), col(3), col(4), n + 1, threads) == 0
+        for i in range(0, n, 17):
+            o = 7 * (i % 5)
+            assert np.array_equal(dst[i].reshape(-1)[o:o + rows * stride - stride + w].reshape(-1)[:w], src[i][0])
+            assert np.array_equal(np.lib.stride_tricks.as_strided(dst[i].reshape(-1)[o:], (rows, w), (stride, 1)), src[i])
+        assert not pad.any()
+    tab[4, 0] = w - 1                                                   # destination stride smaller than the row
+    assert lib.dc_pack_rows(col(0), col(1), col(2), col(3), col(4), n + 1, 4) != 0
+    assert b'dc_pack_rows' in lib.dc_last_error()
+
+
 def test_pack_rollouts_rejects_an_empty_batch():
     from dotaclient_amd.engine import pack_rollouts
     with pytest.raises(ValueError):
