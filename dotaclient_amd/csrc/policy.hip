@@ -167,8 +167,13 @@ __global__ __launch_bounds__(256) void copy_zero_pad_kernel(const float* __restr
 int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, float* grads, int64_t total_floats,
                     const float* obs, const int64_t* seq_off, const int32_t* seq_len, void* ws_base, hipStream_t s) {
     DC_TRY(check_dims(d));
-    hipError_t e = hipMemsetAsync(grads, 0, (size_t)total_floats * sizeof(float), s);
-    if (e != hipSuccess) { set_error("policy_backward: memset", (int)e); return (int)e; }
+    // DC_DIMS_BWD_UPPER / DC_DIMS_BWD_EMBED: the two halves as separate calls (header); neither bit: both
+    const bool do_upper = !(d->flags & DC_DIMS_BWD_EMBED) || (d->flags & DC_DIMS_BWD_UPPER);
+    const bool do_embed = !(d->flags & DC_DIMS_BWD_UPPER) || (d->flags & DC_DIMS_BWD_EMBED);
+    if (do_upper) {
+        hipError_t e = hipMemsetAsync(grads, 0, (size_t)total_floats * sizeof(float), s);
+        if (e != hipSuccess) { set_error("policy_backward: memset", (int)e); return (int)e; }
+    }
     if (d->rows <= 0 || d->n_seq <= 0) return 0;
     Ws w; w.base = (char*)ws_base; workspace_layout(d, w.off);
     Params P{params, poff};
@@ -178,6 +183,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     const int H = d->hidden, G = d->cell == 0 ? 3 : 4, B = d->n_seq, L = d->layers;
     const int TOP = L - 1;
 
+    if (do_upper) {
     // heads (policy.py:144-155)
     DC_TRY(attn_bwd_q(w.f(DC_WS_DTU), w.f(DC_WS_EMB), w.f(DC_WS_DHEADOUT), NR, s));
     // dH = dheadout[:, 0:160] * [W_heads; 0]: K padded to a multiple of 32 (dheadout's pad columns are
@@ -229,6 +235,8 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     DC_TRY(colsum(w.f(DC_WS_DPRE), PREW, NR, PREW, Gd.p(DC_P_PRE_B), s));
     DC_TRY(gemm_f32(w.f(DC_WS_DPRE), P.p(DC_P_PRE_W), w.f(DC_WS_DXCAT), (int)NR, XCATW, PREW, PREW, XCATW, XCATW, 0, 1, nullptr,
                     0, nullptr, 0, 0, 1, s));
+    }   // do_upper
+    if (!do_embed) { gemm_set_scratch(nullptr, 0); return 0; }
 
     // max-pool routing + attention keys -> per-unit embedding gradients; env embedding weights
     // Fused path: the two 16-unit types (32 of the 40 units) take the sparse max-pool backward (embed_sparse.hip);

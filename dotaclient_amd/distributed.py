@@ -21,9 +21,18 @@ def is_distributed():
 
 
 class FlatGradAllReducer:
-    def __init__(self, engine, group=None):
+    """overlap (default: environment DC_DP_OVERLAP == '1'; off unless asked for - it has only been exercised with two
+    gloo ranks so far, tools/gpu_two_ranks.sh): the bucket is reduced in two collectives.  The gradients of every
+    parameter from affine_pre_rnn on (82 % of the bucket, final once the first half of the backward is enqueued) plus
+    the head flags go first, asynchronously, while the embedding backward runs; the embedding gradients follow.  Same
+    sums, same averaging."""
+
+    def __init__(self, engine, group=None, overlap=None):
+        import os
         self.engine = engine
         self.group = group
+        self.overlap = (os.environ.get('DC_DP_OVERLAP') == '1') if overlap is None else bool(overlap)
+        self._work = None
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         dev = engine.device
         # bucket = [flat grads | 5 head flags | world] so that one collective carries everything
@@ -36,13 +45,35 @@ class FlatGradAllReducer:
         if self.world > 1:
             dist.broadcast(self.engine.params, src=0, group=self.group)
 
+    def _set_tail(self, engine):
+        self.tail[:5] = engine.head_on[:5].to(torch.float32)
+        self.tail[5] = 1.0
+
+    def start_upper(self, engine):
+        """After the first half of the backward (Engine.backward(.., DC_DIMS_BWD_UPPER)) has been enqueued."""
+        if self.world <= 1:
+            return
+        self._set_tail(engine)
+        self._work = dist.all_reduce(self.bucket[engine.embed_floats:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self, engine):
+        """After the second half: reduce the embedding gradients, join the first collective, average."""
+        if self.world <= 1:
+            return
+        dist.all_reduce(self.bucket[:engine.embed_floats], op=dist.ReduceOp.SUM, group=self.group)
+        self._work.wait()
+        self._work = None
+        self._average(engine)
+
     def __call__(self, engine):
         """grad_hook for Engine.train_epoch: runs between backward and the Adam step."""
         if self.world <= 1:
             return
-        self.tail[:5] = engine.head_on[:5].to(torch.float32)
-        self.tail[5] = 1.0
+        self._set_tail(engine)
         dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
+        self._average(engine)
+
+    def _average(self, engine):
         _lib.check(engine.lib.dc_dp_average_grads(
             _lib.ptr(engine.seg_off), _lib.ptr(engine.seg_len), _lib.ptr(engine.seg_gate), len(engine.seg_names),
             engine.max_seg_len, _lib.ptr(engine.grads), _lib.ptr(self.tail), 0.0, _lib.stream_ptr()),

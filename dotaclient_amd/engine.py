@@ -29,6 +29,8 @@ class DcDims(ctypes.Structure):
 
 
 DC_DIMS_LAZY_TU = 1     # include/dotaclient_hip.h
+DC_DIMS_BWD_UPPER = 2   # dc_policy_backward: heads .. pre-rnn projection only (zeroes the gradient buffer first)
+DC_DIMS_BWD_EMBED = 4   # dc_policy_backward: the embedding parameters only (after UPPER)
 
 WS_FIXED = ['BASIC', 'EMB', 'DEMB', 'XCAT', 'AMAX', 'PRE', 'HEADOUT', 'TU', 'DHEADOUT', 'DTU', 'DPRE', 'DXCAT',
             'STATS', 'WHHT', 'SCRATCH', 'HEADW_PAD']
@@ -222,6 +224,8 @@ class Engine:
         self.ctl = torch.zeros(2, dtype=torch.float32, device=dev)
         self.head_on = torch.zeros(8, dtype=torch.int32, device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        # flat offset of the first parameter that is not part of the unit / env embeddings (they come first in the layout)
+        self.embed_floats = self.layout['affine_pre_rnn.weight'][0]
         self._ws = None
         self._ws_off = None
         self._ws_dims_key = None
@@ -336,7 +340,12 @@ class Engine:
                                                 float(entropy_coef), float(vf_coef), _lib.stream_ptr()),
                    'dc_ppo_loss_fwd_bwd')
 
-    def backward(self, d, batch):
+    def backward(self, d, batch, part=0):
+        """part: 0 = the whole backward; DC_DIMS_BWD_UPPER / DC_DIMS_BWD_EMBED = its two halves as separate calls (the
+        gradients of every parameter from affine_pre_rnn on are final after UPPER: a data-parallel caller starts their
+        all-reduce there, Engine.train_epoch)."""
+        if part:
+            d = DcDims(d.cell, d.hidden, d.layers, d.n_seq, d.max_len, d.flags | part, d.rows)
         _lib.check(self.lib.dc_policy_backward(ctypes.byref(d), _lib.ptr(self.params), self.poff, _lib.ptr(self.grads),
                                                self.total, _lib.ptr(batch.obs), _lib.ptr(batch.seq_off),
                                                _lib.ptr(batch.seq_len), _lib.ptr(self._ws), _lib.stream_ptr()),
@@ -385,8 +394,16 @@ class Engine:
         (0 loss, 1 policy, 2 entropy, 3 value, 4..8 entropies, 9 unclipped, 10 clipped) and status."""
         d, _, _ = self.forward(chunks, chunks.h0, chunks.c0, lazy_tu=True)
         self.loss(d, chunks, e_clip, entropy_coef, vf_coef)
-        self.backward(d, chunks)
-        if grad_hook is not None:
-            grad_hook(self)
+        if grad_hook is not None and getattr(grad_hook, 'overlap', False):
+            # data-parallel with overlap: the all-reduce of everything but the embedding gradients (82 % of the bucket)
+            # runs beside the embedding backward
+            self.backward(d, chunks, DC_DIMS_BWD_UPPER)
+            grad_hook.start_upper(self)
+            self.backward(d, chunks, DC_DIMS_BWD_EMBED)
+            grad_hook.finish(self)
+        else:
+            self.backward(d, chunks)
+            if grad_hook is not None:
+                grad_hook(self)
         self.adam(lr, vf_coef)
         return self.out, self.status

@@ -75,6 +75,14 @@ typedef struct dc_dims {
  * masked_softmax, policy.py:169-178, never lets them reach a result).  Set by the optimizer's two passes;
  * leave clear when the caller wants DC_WS_TU for every unit (Policy.forward). */
 #define DC_DIMS_LAZY_TU 1
+/* dc_policy_backward in two calls, so that a data-parallel caller can start the all-reduce of the first part's
+ * gradients while the second part runs (distributed.py:29-57 reduces after the whole backward):
+ *   DC_DIMS_BWD_UPPER : zero the gradient buffer, then heads, recurrent core, pre-rnn projection - every parameter from
+ *                       affine_pre_rnn on; leaves d(xcat) and the attention gradients in the workspace;
+ *   DC_DIMS_BWD_EMBED : the unit / env embedding parameters from that workspace state (call after UPPER, same arguments).
+ * Neither bit set: both parts, one call. */
+#define DC_DIMS_BWD_UPPER 2
+#define DC_DIMS_BWD_EMBED 4
 
 /* index into poff[]; policy.py:54-75 names in comments */
 enum dc_param_index {

@@ -184,9 +184,10 @@ class _FakeEngine:
         self.head_on = torch.tensor(head_on + [0, 0, 0], dtype=torch.int32)
         self.lib = _FakeLib(self)
         self.layout = lay
+        self.embed_floats = lay['affine_pre_rnn.weight'][0]
 
 
-def _dp_worker(rank, world, port, tmp):
+def _dp_worker(rank, world, port, tmp, overlap):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from dotaclient_amd import distributed as D
@@ -195,7 +196,7 @@ def _dp_worker(rank, world, port, tmp):
     D._lib.check = lambda code, what='': None
     # rank 1 never used the ability head (index 4): its ability grads are "None"
     eng = _FakeEngine([1, 1, 1, 1, 1 if rank == 0 else 0])
-    red = D.FlatGradAllReducer(eng)
+    red = D.FlatGradAllReducer(eng, overlap=overlap)
     eng.reducer = red
     eng.params.fill_(float(rank + 1))
     red.sync_parameters()
@@ -207,14 +208,19 @@ def _dp_worker(rank, world, port, tmp):
             o, n, _ = eng.layout[nm]
             local[o:o + n] = 0                       # no gradient on this rank
     eng.grads.copy_(local)
-    red(eng)
+    if overlap:                                       # the two-collective form Engine.train_epoch drives
+        red.start_upper(eng)
+        red.finish(eng)
+    else:
+        red(eng)
     torch.save({'local': local, 'out': eng.grads.clone()}, os.path.join(tmp, 'r%d.pt' % rank))
     dist.destroy_process_group()
 
 
-def test_dp_flat_bucket_matches_reference_semantics(tmp_path):
-    world, port = 2, 29500 + os.getpid() % 2000
-    mp.spawn(_dp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize('overlap', [False, True])
+def test_dp_flat_bucket_matches_reference_semantics(tmp_path, overlap):
+    world, port = 2, 29500 + (os.getpid() + int(overlap)) % 2000
+    mp.spawn(_dp_worker, args=(world, port, str(tmp_path), overlap), nprocs=world, join=True)
     res = [torch.load(os.path.join(str(tmp_path), 'r%d.pt' % r)) for r in range(world)]
     lay, total = L.flat_layout()
     names = list(L.param_shapes().keys())
