@@ -285,14 +285,19 @@ def main():
                     'whole_step': {'flops_per_env_step': ffwd * (1 + 3 * E),
                                    'achieved_tflops': round(value / world * ffwd * (1 + 3 * E) / 1e12, 3)},
                     'kernels': kernels}
+        key = (args.cell, args.hidden, args.layers, B, S)
+        which = {('lstm', 128, 1, 64, 256): 'BASELINE.json configs[1] (1v1-mid, the configuration the metric is quoted on)',
+                 ('lstm', 256, 1, 256, 256): 'BASELINE.json configs[2] (5v5: 256 trajectories, LSTM-256)',
+                 ('gru', 256, 1, 64, 256): "configs[1]'s batch with the reference's own cell (GRU-256, policy.py:66)"}.get(
+                     key, 'other configuration (not a BASELINE.json bench line)')
         line = {
             'metric': 'env-steps/sec through PPO optimizer', 'value': round(value, 1), 'unit': 'env-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE.json configs[1]: 1v1-mid synthetic trajectories, %s hidden=%d x%d layer, '
+            'config': {'workload': '%s: synthetic trajectories, %s hidden=%d x%d layer, '
                                    'batch=%d trajectories x %d steps per GPU, %d epochs + rollout pass per step'
-                                   % (args.cell.upper(), args.hidden, args.layers, B, S, E),
+                                   % (which, args.cell.upper(), args.hidden, args.layers, B, S, E),
                        'cell': args.cell, 'hidden': args.hidden, 'layers': args.layers, 'batch_per_gpu': B,
                        'seq_len': S, 'epochs': E, 'parallelism': 'dp%d' % world},
             'roofline': roofline,
