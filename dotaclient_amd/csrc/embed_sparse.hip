@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void embed_pool16_prepare_kernel(SparseArgs p)
 // v_readlane into scalar registers.  One LDS round trip per row instead of two dependent ones, no divergent loops.
 //   iteration i: every thread hands its prefetched values of iteration i+1 to staging[(i+1) % 3] and issues the loads of
 //   iteration i+2  -- barrier --  phase A of iteration i+1 (basic -> bas[(i+1) & 1]), phases B, C, (live), D of iteration i.
-template <bool TIMING>   // TIMING (DC_SP_TIMING=1): s_memtime phase sums of wave 3 of workgroup 0 -> p.dbg[8]
+template <bool TIMING>   // TIMING (DC_SP_TIMING=1): s_memtime phase sums of every wave of workgroup 0 -> p.dbg[8][6]
 __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs p) {
     long long tm[6] = {0, 0, 0, 0, 0, 0}, tm0 = 0;
     auto stamp = [&](int i) {
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
     }
 
     if constexpr (TIMING) {
-        if (blockIdx.x == 0 && tid == 192) for (int i = 0; i < 6; ++i) p.dbg[i] = tm[i];
+        if (blockIdx.x == 0 && (tid & 63) == 0) for (int i = 0; i < 6; ++i) p.dbg[(tid >> 6) * 6 + i] = tm[i];   // every wave's sums
     }
     // ---- results --------------------------------------------------------------------------------------
     {
@@ -463,14 +463,15 @@ int embed_bwd_pool16(const float* obs, const float* dxcat, const uint8_t* amax, 
     static const bool timing = [] { const char* e = getenv("DC_SP_TIMING"); return e && e[0] == '1'; }();
     if (timing) {   // debugging aid: per-step phase cycles of one wave, printed per launch
         static long long* dbg = nullptr;
-        if (!dbg) (void)hipMalloc(&dbg, 64);
+        if (!dbg) (void)hipMalloc(&dbg, 8 * 6 * sizeof(long long));
         a.dbg = dbg;
         hipLaunchKernelGGL(embed_bwd_pool16_kernel<true>, dim3(2 * wg_per_type), dim3(SP_THREADS), lds, s, a);
-        long long h[6];
+        long long h[8][6];
         (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
         const double st = (double)a.steps_per_wg;
-        fprintf(stderr, "embed_bwd_pool16 timing (cycles per step): handover+A %.0f  barrier %.0f  B %.0f  C %.0f  live %.0f  D %.0f\n",
-                h[0] / st, h[1] / st, h[2] / st, h[3] / st, h[4] / st, h[5] / st);
+        for (int wv = 0; wv < 8; ++wv)
+            fprintf(stderr, "embed_bwd_pool16 timing, wave %d (cycles per step): handover+A %.0f  barrier %.0f  B+C %.0f  live %.0f  D %.0f\n", wv,
+                    h[wv][0] / st, h[wv][1] / st, (h[wv][2] + h[wv][3]) / st, h[wv][4] / st, h[wv][5] / st);
         return launch_check("embed_bwd_pool16");
     }
     hipLaunchKernelGGL(embed_bwd_pool16_kernel<false>, dim3(2 * wg_per_type), dim3(SP_THREADS), lds, s, a);
