@@ -316,12 +316,15 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
                 gather16(stg[s2] + STG_LIST, first, 1, dvec, ovec);
                 dvec = (lane & 15) < cnt ? dvec : 0.f;        // past the unit's segment: the next unit's entries, weight 0
                 f32x2& dbh = db[s2][h];
+                f32x2 dbo = mk2(0.f, 0.f);       // odd slots: a second chain (a unit's 8-12 dependent packed FMAs are the
+                                                 // longest serial chain of the step; order of the sum stays fixed)
                 auto slot = [&](auto JC) {
                     constexpr int J = decltype(JC)::value;
                     const f32x2 wv = *reinterpret_cast<const f32x2*>(w2b + bcast16_i<J>(ovec));
                     const float d = bcast16_f<J>(dvec);
-                    dbh.x = fmaf(d, wv.x, dbh.x);
-                    dbh.y = fmaf(d, wv.y, dbh.y);
+                    f32x2& acc = (J & 1) ? dbo : dbh;
+                    acc.x = fmaf(d, wv.x, acc.x);
+                    acc.y = fmaf(d, wv.y, acc.y);
                 };
                 for_consts(slot, std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>{});         // a unit holds 8 channels on average
                 if (cnt > 8) for_consts(slot, std::integer_sequence<int, 8, 9, 10, 11>{});      // wave-uniform
@@ -330,6 +333,7 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
                     const f32x2 wv = *reinterpret_cast<const f32x2*>(w2b + __float_as_int(e.y));
                     db[s2][h] = __builtin_elementwise_fma(mk2(e.x, e.x), wv, db[s2][h]);
                 }
+                db[s2][h] += dbo;
             }
         }
         stamp(2);
