@@ -7,7 +7,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libdotaclient_hip.so')
+LIB_PATH = os.environ.get('DC_LIB') or os.path.join(HERE, 'libdotaclient_hip.so')   # DC_LIB: an A/B build (build.py)
 
 c_f32p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p

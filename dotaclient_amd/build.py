@@ -11,10 +11,13 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-OBJ = os.path.join(CSRC, '_obj')
-LIB = os.path.join(HERE, 'libdotaclient_hip.so')
+# A/B builds: DC_BUILD_VARIANT=name (+ DC_BUILD_FLAGS='-DX ...') produces libdotaclient_hip_name.so next to the regular
+# library (own object directory); run with DC_LIB=<that file> to load it (dotaclient_amd/_lib.py).
+VARIANT = os.environ.get('DC_BUILD_VARIANT', '')
+OBJ = os.path.join(CSRC, '_obj' + ('_' + VARIANT if VARIANT else ''))
+LIB = os.path.join(HERE, 'libdotaclient_hip%s.so' % ('_' + VARIANT if VARIANT else ''))
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'] + os.environ.get('DC_BUILD_FLAGS', '').split()
 
 
 def _sources():

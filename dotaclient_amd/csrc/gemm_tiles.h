@@ -75,7 +75,14 @@ __device__ __forceinline__ void mma_kstep(const float* __restrict__ a_s, const f
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                          \
             _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                                   \
                 acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].E, bf[jn].E, acc[i][jn], 0, 0, 0);
+#ifdef DC_MMA_SETPRIO
+        __builtin_amdgcn_s_setprio(1);      // experiment (A/B build): the wave inside its MFMA burst wins issue arbitration -
+                                            // measured 2-7 % SLOWER on every MFMA kernel of the step
+#endif
         DC_MMA_E(x) DC_MMA_E(y) DC_MMA_E(z) DC_MMA_E(w)
+#ifdef DC_MMA_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #undef DC_MMA_E
     }
 }
