@@ -231,6 +231,18 @@ def main():
     status = int(eng.status.item())
     losses = eng.out.cpu().numpy()
 
+    # ---- split of a step ("also report per-epoch train-only steps/s"): one extra untimed iteration with
+    # events on the launch stream around the rollout pass and around the E epochs
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev[0].record()
+    chunks_x = eng.rollout_pass(batch, S)
+    ev[1].record()
+    for _ in range(E):
+        eng.train_epoch(chunks_x, lr, ent, vf, grad_hook=hook)
+    ev[2].record()
+    torch.cuda.synchronize()
+    rollout_ms, epochs_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+
     # ---- roofline: one extra untimed iteration with per-launch HIP events --------------------------------
     eng.lib.dc_profile_enable(1)
     step()
@@ -300,6 +312,10 @@ def main():
                                    % (which, args.cell.upper(), args.hidden, args.layers, B, S, E),
                        'cell': args.cell, 'hidden': args.hidden, 'layers': args.layers, 'batch_per_gpu': B,
                        'seq_len': S, 'epochs': E, 'parallelism': 'dp%d' % world},
+            'phases': {'rollout_pass_ms': round(rollout_ms, 3), 'epoch_ms': round(epochs_ms / E, 3),
+                       'train_only_env_steps_per_s_per_gpu': round(B * S / (epochs_ms / E * 1e-3), 1),
+                       'note': 'one untimed iteration on rank 0: no-grad forward + old log-probs + GAE, then the mean of the %d '
+                               'full-batch epochs (forward, loss, backward, clip + Adam); train-only = B*S / epoch time' % E},
             'roofline': roofline,
             'roofline_hbm': roofline_hbm,
             'nan_status': status, 'final_loss': float(losses[0]),
