@@ -295,7 +295,9 @@ def main():
                     'avg_launch_us': round(dom['total_ms'] * 1e3 / dom['launches'], 3),
                     'flops_per_launch': dom['flops'] / dom['launches'],
                     'whole_step': {'flops_per_env_step': ffwd * (1 + 3 * E),
-                                   'achieved_tflops': round(value / world * ffwd * (1 + 3 * E) / 1e12, 3)},
+                                   'achieved_tflops': round(value / world * ffwd * (1 + 3 * E) / 1e12, 3),
+                                   # steps/s x F_iter / peak, per GPU, dense (reference) flop count
+                                   'frac_of_f32_peak': round(value / world * ffwd * (1 + 3 * E) / 1e12 / 157.3, 4)},
                     'kernels': kernels}
         key = (args.cell, args.hidden, args.layers, B, S)
         which = {('lstm', 128, 1, 64, 256): 'BASELINE.json configs[1] (1v1-mid, the configuration the metric is quoted on)',
