@@ -37,6 +37,10 @@ struct GemmArgs {
     int atomic;      // C += result with atomics (split-K without scratch)
     int k_per_split; // multiple of 32
     float* slab;     // split-K with scratch: partial [split][M][N] slabs, reduced by splitk_reduce_kernel
+    // two B operands side by side (gemm_f32_tn_pair): columns >= n_split come from B2 (n_split: multiple of the column
+    // tile, 0 = off)
+    const float* B2;
+    int ldb2, n_split;
 };
 
 
@@ -268,12 +272,18 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs p) {
 
     size_t offa[LA::NI], offb[LB::NI];
     LA::template src_offsets<EDGE>(offa, p.lda, m_blk, p.M, wave, lane);
-    LB::template src_offsets<EDGE>(offb, p.ldb, n_blk, p.N, wave, lane);
+    // B of this column tile: the second operand of a pair behind n_split (workgroup-uniform)
+    const bool second = p.n_split > 0 && n_blk >= p.n_split;
+    const float* Bp = second ? p.B2 : p.B;
+    const int ldb = second ? p.ldb2 : p.ldb;
+    const int nb_blk = second ? n_blk - p.n_split : n_blk;
+    const int nb_ext = p.n_split > 0 ? (second ? p.N - p.n_split : p.n_split) : p.N;
+    LB::template src_offsets<EDGE>(offb, ldb, nb_blk, nb_ext, wave, lane);
     // operand origins at k = k_begin; advancing one K step adds BK floats (k-contiguous) or BK rows (k-major)
     const float* ga = A_KM ? p.A + (size_t)k_begin * p.lda : p.A + k_begin;
-    const float* gb = B_KM ? p.B + (size_t)k_begin * p.ldb : p.B + k_begin;
+    const float* gb = B_KM ? Bp + (size_t)k_begin * ldb : Bp + k_begin;
     const size_t sa = A_KM ? (size_t)GEMM_BK * p.lda : GEMM_BK;
-    const size_t sb = B_KM ? (size_t)GEMM_BK * p.ldb : GEMM_BK;
+    const size_t sb = B_KM ? (size_t)GEMM_BK * ldb : GEMM_BK;
 
     LA::issue(ga, offa, smem, wave);
     LB::issue(gb, offb, smem + A_FL, wave);
@@ -342,7 +352,8 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs p) {
 // per partial element - an M x N x splits slab is a few MB, L2-resident)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int M,
                                                             int N, int ldc, int splits, const float* __restrict__ bias,
-                                                            int accumulate) {
+                                                            int accumulate, float* __restrict__ C2 = nullptr, int ldc2 = 0,
+                                                            int n_split = 0) {
     // 64 consecutive outputs per block, the splits dealt round-robin to 4 thread groups (a 128x128
     // product has only 16K outputs: one thread per output left most of the chip idle)
     __shared__ float sh[256];
@@ -365,7 +376,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     acc = (sh[tx] + sh[64 + tx]) + (sh[128 + tx] + sh[192 + tx]);
     const int m = (int)(idx / N), n = (int)(idx - (long long)m * N);
     if (bias) acc += bias[n];
-    float* c = C + (size_t)m * ldc + n;
+    float* c = (n_split > 0 && n >= n_split) ? C2 + (size_t)m * ldc2 + (n - n_split) : C + (size_t)m * ldc + n;
     *c = accumulate ? *c + acc : acc;
 }
 
@@ -506,6 +517,7 @@ int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int 
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
     a.relu = relu; a.accumulate = accumulate; a.atomic = 0; a.slab = nullptr;
+    a.B2 = nullptr; a.ldb2 = 0; a.n_split = 0;
     if (K <= 0) {
         set_error("gemm_f32: K <= 0", 1002);
         return 1002;
@@ -569,6 +581,45 @@ int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int 
         rc = launch_check("splitk_reduce");
     }
     return rc;
+}
+
+// [C1 | C2] = A^T [B1 | B2] in ONE split-K launch: A [K][M] k-major (lda), B1 [K][N1], B2 [K][N2] k-major, C1 [M][N1],
+// C2 [M][N2] accumulated into (like the callers' gemm_f32(.., accumulate = 1)).  The two weight-gradient products of a recurrent layer (dW_ih = dgates^T x, dW_hh = dgates^T h_prev)
+// share their A operand; as one product they are one launch of ~256 workgroups and one reduction instead of two each.
+// Falls back to two gemm_f32 calls when the shapes do not fit (N1, N2 multiples of 128, M of 64, scratch large enough).
+int gemm_f32_tn_pair(const float* A, int lda, const float* B1, int ldb1, int N1, const float* B2, int ldb2, int N2, float* C1,
+                     int ldc1, float* C2, int ldc2, int M, int K, hipStream_t stream) {
+    const int N = N1 + N2;
+    const long wgs = (long)(M / 64) * (N / 128);
+    long want = wgs > 0 ? 256 / wgs : 1;
+    if (want < 1) want = 1;
+    if (wgs * want < 192 && wgs > 0) want = 512 / wgs;
+    const long maxs = K / 512;
+    int splits = (int)(want < maxs ? want : maxs);
+    bool ok = (M % 64) == 0 && (N1 % 128) == 0 && (N2 % 128) == 0 && (K % GEMM_BK) == 0 && splits >= 2 && g_scratch != nullptr &&
+              !(lda & 3) && !(ldb1 & 3) && !(ldb2 & 3) && aligned16(A) && aligned16(B1) && aligned16(B2);
+    int kper = 0;
+    if (ok) {
+        kper = (K + splits - 1) / splits;
+        kper = (kper + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+        splits = (K + kper - 1) / kper;
+        ok = (long long)splits * M * N <= g_scratch_floats;
+    }
+    if (!ok) {
+        if (int e = gemm_f32(A, B1, C1, M, N1, K, lda, ldb1, ldc1, 1, 1, nullptr, 0, nullptr, 0, 1, 0, stream)) return e;
+        return gemm_f32(A, B2, C2, M, N2, K, lda, ldb2, ldc2, 1, 1, nullptr, 0, nullptr, 0, 1, 0, stream);
+    }
+    GemmArgs a;
+    a.A = A; a.B = B1; a.C = C1; a.bias = nullptr; a.aux = nullptr;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb1; a.ldc = ldc1; a.ldaux = 0;
+    a.relu = 0; a.accumulate = 0; a.atomic = 0; a.k_per_split = kper; a.slab = g_scratch;
+    a.B2 = B2; a.ldb2 = ldb2; a.n_split = N1;
+    ProfScope prof("gemm_f32_dW(TN,split-K)", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), stream);
+    if (int e = launch_fast<64, 128, true, true, EPI_SLAB, false>(a, splits, stream)) return e;
+    const long long mn = (long long)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, stream, a.slab, C1, M, N, ldc1, splits,
+                       (const float*)nullptr, 1, C2, ldc2, N1);
+    return launch_check("gemm_f32_tn_pair");
 }
 
 }  // namespace dc

@@ -45,6 +45,8 @@ int gae_scan(const float* rewards, const float* values, const int64_t* seq_off, 
 int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kmajor,
              int b_kmajor, const float* bias, int relu, const float* aux, int ldaux, int accumulate, int splits,
              hipStream_t stream);
+int gemm_f32_tn_pair(const float* A, int lda, const float* B1, int ldb1, int N1, const float* B2, int ldb2, int N2, float* C1,
+                     int ldc1, float* C2, int ldc2, int M, int K, hipStream_t stream);   // [C1 | C2] = A^T [B1 | B2], one launch
 void gemm_set_scratch(float* p, long long floats);   // split-K slabs (nullptr -> atomics)
 int splitk_reduce(const float* slab, float* C, int M, int N, int ldc, int splits, hipStream_t s);   // C = sum_z slab[z]
 // n_groups (<= 8) independent reductions in one launch: C[g] (dense M x N) = sum of slabs [begin[g], begin[g+1])

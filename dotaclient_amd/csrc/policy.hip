@@ -212,8 +212,12 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         const float* xin = l == 0 ? w.f(DC_WS_PRE) : w.fl(l - 1, DC_WSL_HSEQ);
         const int in = l == 0 ? PREW : H;
         // dW_ih = dgx^T x ; dW_hh = dgh^T h_prev ; biases = column sums
-        DC_TRY(gemm_f32(a.dgx, xin, Gd.p(pb + 0), G * H, in, (int)NR, G * H, in, in, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s));
-        DC_TRY(gemm_f32(a.dgh, a.hprev, Gd.p(pb + 1), G * H, H, (int)NR, G * H, H, H, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s));
+        if (a.dgh == a.dgx) {   // LSTM: both products contract the same gate gradients - one launch
+            DC_TRY(gemm_f32_tn_pair(a.dgx, G * H, xin, in, in, a.hprev, H, H, Gd.p(pb + 0), in, Gd.p(pb + 1), H, G * H, (int)NR, s));
+        } else {
+            DC_TRY(gemm_f32(a.dgx, xin, Gd.p(pb + 0), G * H, in, (int)NR, G * H, in, in, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s));
+            DC_TRY(gemm_f32(a.dgh, a.hprev, Gd.p(pb + 1), G * H, H, (int)NR, G * H, H, H, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s));
+        }
         DC_TRY(colsum(a.dgx, G * H, NR, G * H, Gd.p(pb + 2), s));
         if (d->cell == 1) {   // LSTM: dgh is dgx, so d(b_hh) = d(b_ih) - copy 2 KB instead of a second 33 MB column sum
             hipError_t ec = hipMemcpyAsync(Gd.p(pb + 3), Gd.p(pb + 2), (size_t)G * H * sizeof(float), hipMemcpyDeviceToDevice, s);
