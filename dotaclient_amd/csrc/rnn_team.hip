@@ -599,7 +599,9 @@ __global__ __launch_bounds__(512) void rnn_team_bwd_kernel(RnnStepArgs p, u64* _
 // ---------------------------------------------------------------------------------------------------
 namespace {
 
-// exchange ring of the largest case (backward: 4H granules per slot), allocated once
+// exchange ring of the largest case (backward: 4H granules per slot), allocated once per process: team launches are
+// expected on ONE stream at a time (the optimizer is single-threaded, one process per GPU - optimizer.py:726-733); two
+// launches overlapping on different streams would share it
 u64* team_xbuf() {
     static u64* buf = nullptr;
     if (!buf && hipMalloc(&buf, ((size_t)TEAM_MAX * TEAM_M + (size_t)TEAM_MAX * TEAM_NS_MAX * TEAM_SLOTS * 4 * TEAM_H) * sizeof(u64)) != hipSuccess) buf = nullptr;
