@@ -9,13 +9,20 @@ One "step" = one optimizer iteration over one batch of synthetic trajectories al
 HBM: the rollout pass (no-grad forward for old log-probs/values + GAE scan, optimizer.py:328-430)
 followed by E = 4 full-batch epochs of train (optimizer.py:581-689; `--epochs` default of the
 reference, optimizer.py:781), each = forward + PPO loss + backward + (RCCL all-reduce if N > 1) +
-clip + Adam.  Default workload = BASELINE.json configs[1]: LSTM hidden=128, 64 trajectories x 256
-steps PER GPU (weak scaling).  Padded steps would count as steps as in the reference
-(optimizer.py:486); the throughput runs have none.
+clip + Adam.  Default workload = the 5v5 LSTM-256 family of BASELINE.json: N = 1 runs configs[2] (LSTM
+hidden=256, 256 trajectories x 256 steps on the one GPU), N > 1 runs configs[3]'s geometry (128 trajectories x
+256 steps PER GPU = 1024 x 256 at DP=8, RCCL all-reduce of the flat gradient bucket every epoch; weak scaling:
+the per-GPU shard is fixed for every N > 1, and the N = 1 line also carries the one-GPU rate of that 128-trajectory
+shard as `weak_scaling_unit` so that a scaling efficiency can be formed from like with like).  configs[1]
+(LSTM-128, 64 x 256) and the reference's own GRU-256 on the same batch are measured as `secondary` lines at N = 1.
+Padded steps would count as steps as in the reference (optimizer.py:486); the throughput runs have none.
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the launch stream in one
 extra, untimed iteration right after the timed region; `cpu_baseline` times the CPU oracle
-(oracle/, restatement of the reference - kind "port") on the host cores, rank 0, N = 1 only.
+(oracle/, restatement of the reference - kind "port") on the host cores, rank 0, N = 1 only, on one full step of the
+same workload - and the same oracle run is the checker of `parity`: advantages, returns, old log-probs, the losses /
+entropies / gradient norms of all E epochs and the post-step parameters of the HIP path's first iteration (from the
+same initial weights) against the oracle's, masked argmax indices bit-exact (BASELINE.json north_star: 1e-4).
 """
 import argparse
 import ctypes
@@ -80,41 +87,194 @@ def pmc_traffic(path, kernel, workload_key):
     return int(k['bytes']) if k else None
 
 
+def _tensor_samples(t, stride=251):
+    return t.detach().flatten()[::stride][:1000].float().cpu().numpy().copy()
+
+
+def hip_parity_iteration(eng, batch, S, E, lr, ent, vf, hook=None):
+    """The HIP path's FIRST iteration (from the freshly loaded weights), with everything `parity` compares read back."""
+    from dotaclient_amd import layout as L
+    chunks = eng.rollout_pass(batch, S)
+    out = {'advantages': batch.adv.cpu().numpy(), 'returns': batch.ret.cpu().numpy(), 'values': batch.values.cpu().numpy(),
+           'argmax': batch.argmax.cpu().numpy()}
+    act = batch.act.cpu().numpy()
+    lp = batch.old_logp.cpu().numpy()
+    for k, name in enumerate(L.OUTPUT_KEYS):
+        o = L.HEAD_OFFSETS[name]
+        out['old_logp_' + name] = lp[act[:, o:o + L.HEAD_COUNTS[name]].any(axis=1), k]
+    per_epoch = []
+    for _ in range(E):
+        res, status = eng.train_epoch(chunks, lr, ent, vf, grad_hook=hook)
+        per_epoch.append(res.cpu().numpy().astype(np.float64)[:11])
+    out['epochs'] = np.stack(per_epoch)
+    names = list(L.param_shapes(eng.cell, eng.hidden, eng.layers).keys())
+    out['param_samples'] = np.concatenate([_tensor_samples(eng.param_view(n)) for n in names])
+    return out
+
+
 def cpu_baseline(cell, hidden, layers, rollouts, seq_len, epochs, lr, ent, vf):
     """Times the CPU oracle (kind "port") on the same synthetic workload: one rollout pass + `epochs`
-    epochs = one bench step.  Thread count: the best of a short sweep (torch CPU ops of this size get
-    slower, not faster, when spread over all 256 host threads of the GPU box)."""
+    epochs = one bench step, and returns what that run computed (the checker side of `parity`).  Thread count: the best
+    of a short sweep (torch CPU ops of this size get slower, not faster, when spread over all 256 host threads of the
+    GPU box)."""
     from oracle import ref_optimizer as RO
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     sd = synth.init_state_dict(7, cell, hidden, layers)
 
-    def one_iteration(rs, n_ep):
+    def one_iteration(rs, n_ep, keep=False):
         pol = RO.make_policy(sd, cell, hidden, layers)
         opt = torch.optim.Adam(pol.parameters(), lr=lr)
         t0 = time.time()
         chunks = [c for r in rs for c in RO.rollout_pass(pol, r, seq_len)]
         t1 = time.time()
+        ref = None
+        if keep:                                       # read-outs of the rollout pass: outside the timed spans
+            ref = {'advantages': torch.stack([c.advantages for c in chunks]).numpy().ravel(),
+                   'returns': torch.stack([c.returns for c in chunks]).numpy().ravel(),
+                   'values': torch.stack([c.values for c in chunks]).numpy().ravel(),
+                   'argmax': RO.masked_argmax(pol, chunks).numpy().reshape(-1, 5)}
+            for k in RO.HEADS:
+                ref['old_logp_' + k] = torch.cat([c.old_logp[k] for c in chunks]).numpy()
+        t_train = 0.0
+        per_epoch = []
         for _ in range(n_ep):
-            RO.train_step(pol, opt, chunks, ent, vf)
-        return t1 - t0, time.time() - t1, len(chunks)
+            t2 = time.time()
+            parts, entr, norms = RO.train_step(pol, opt, chunks, ent, vf)
+            t_train += time.time() - t2
+            per_epoch.append([float(parts[k]) for k in ('loss', 'policy_loss', 'entropy_loss', 'value_loss')] +
+                             [float(entr[k]) for k in RO.HEADS] + [float(norms['unclipped']), float(norms['clipped'])])
+        if keep:
+            ref['epochs'] = np.array(per_epoch, dtype=np.float64)
+            ref['param_samples'] = np.concatenate([_tensor_samples(p) for _, p in pol.named_parameters()])
+        return t1 - t0, t_train, len(chunks), ref
 
     cands = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 8)})
     best, best_t = cands[0], None
     for t in cands:                                   # short sweep on 4 trajectories, 1 epoch
         torch.set_num_threads(t)
         one_iteration(rollouts[:2], 1)                # warm-up
-        a, b, _ = one_iteration(rollouts[:4], 1)
+        a, b, _, _ = one_iteration(rollouts[:4], 1)
         if best_t is None or a + b < best_t:
             best, best_t = t, a + b
     torch.set_num_threads(best)
-    t_roll, t_train, n_chunks = one_iteration(rollouts, epochs)
+    t_roll, t_train, n_chunks, ref = one_iteration(rollouts, epochs, keep=True)
     n_steps = n_chunks * seq_len
     return {
         'value': round(n_steps / (t_roll + t_train), 1), 'unit': 'env-steps/s', 'cores': best, 'kind': 'port',
-        'sample': '1 full bench step (rollout pass %.2fs + %d epochs %.2fs) of the same %dx%d workload; '
-                  'oracle/ref_optimizer.py, torch CPU fp32, %d of %d host threads (best of sweep %s)'
+        'sample': '1 full bench step (rollout pass %.2fs + %d epochs %.2fs) of the same %dx%d workload, run once (a repeat '
+                  'moves it by about +-10 %%); oracle/ref_optimizer.py, torch CPU fp32, %d of %d host threads (best of sweep %s)'
                   % (t_roll, epochs, t_train, len(rollouts), seq_len, best, ncpu, cands),
-    }
+    }, ref
+
+
+def parity_report(got, ref, tol=1e-4):
+    """HIP path vs oracle on the bench workload itself.  Vectors: max |a-b| / max |b|; per-epoch scalars: relative, a loss
+    component measured against max(|component|, 1 % of |loss|) (the same yardsticks as tests/test_gpu_parity.py)."""
+    def scaled(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30)) if a.size else 0.0
+    rep = {}
+    for k in ['advantages', 'returns', 'values', 'param_samples'] + [k for k in ref if k.startswith('old_logp_')]:
+        rep[k] = scaled(got[k], ref[k])
+    ge, re_ = got['epochs'], ref['epochs']
+    den = np.abs(re_) + 1e-30
+    den[:, :4] = np.maximum(den[:, :4], 0.01 * np.abs(re_[:, :1]))
+    err = np.abs(ge - re_) / den
+    rep['losses'] = float(err[:, :4].max())
+    rep['entropies'] = float(err[:, 4:9].max())
+    rep['grad_norms'] = float(err[:, 9:11].max())
+    worst = max(rep.values())
+    argmax_equal = bool(np.array_equal(got['argmax'], ref['argmax'].astype(got['argmax'].dtype)))
+    return {'checker': 'oracle/ref_optimizer.py on the same %d env-steps, first iteration from the same initial weights, all %d epochs'
+                       % (ref['advantages'].size, re_.shape[0]),
+            'parity_rel_err': worst, 'tolerance': tol, 'argmax_bit_exact': argmax_equal,
+            'ok': bool(worst < tol and argmax_equal), 'per_quantity': {k: float('%.3g' % v) for k, v in rep.items()},
+            'final_epoch_losses_hip': [float(x) for x in ge[-1, :4]], 'final_epoch_losses_oracle': [float(x) for x in re_[-1, :4]]}
+
+
+# what bounds each timed region (the rates in `kernels` are priced against that resource's peak)
+REGION_BOUND = {
+    'embed_fwd_fused': 'mfma', 'embed_bwd_dw2': 'mfma', 'embed_bwd_dw1': 'mfma', 'gemm_f32_fwd(NT)': 'mfma', 'gemm_f32_dX(NN)': 'mfma',
+    'gemm_f32_dW(TN,split-K)': 'mfma',
+    'embed_bwd_pool16': 'valu',
+    'lstm_fwd_persist': 'latency', 'lstm_bwd_persist': 'latency', 'gru_fwd_team': 'latency', 'gru_bwd_team': 'latency',
+    'lstm_fwd_team': 'latency', 'lstm_bwd_team': 'latency', 'rnn_fwd_steps': 'latency', 'rnn_bwd_steps': 'latency',
+    'pool_env_fwd': 'hbm', 'embed_scatter_bwd(+reduce)': 'hbm', 'ppo_loss(stats+loss+finalize)': 'hbm', 'gradnorm_clip_adam': 'hbm',
+    'gae_scan': 'hbm', 'select_logp': 'hbm', 'attn_logits': 'hbm', 'attn_bwd_q': 'hbm', 'colsum': 'hbm',
+}
+BOUND_NOTES = {
+    'mfma': 'f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32): priced against the dense f32 matrix peak',
+    'valu': 'packed-f32 VALU kernel (per-channel-scaled gathers of 512-byte W2 / basic rows; 1/16 of the dense MACs): priced against '
+            'the f32 VALU peak, which equals the f32 MFMA peak (157.3 TF at 2.4 GHz); what limits it is VALU issue and LDS '
+            'bandwidth at 2 waves/SIMD, not the matrix pipes',
+    'latency': 'recurrence, serial in time: bound by the per-step dependency chain (and, for the H=256 team kernels, the hand-off '
+               'between the four CUs that share a sequence), not by arithmetic or HBM',
+    'hbm': 'streams its operands once: priced against the 8 TB/s HBM peak',
+}
+MASK_DEPENDENT_BYTES = ('attn_logits', 'attn_bwd_q')   # mask-aware: bytes moved depend on the masks; the host-side figure is the dense form
+
+
+def run_workload(cell, hidden, layers, B, S, E, steps, warmup, dev, rank, world, hook_factory=None, want_parity=False,
+                 want_profile=False):
+    """Builds an engine + a resident batch, runs warmup + `steps` timed iterations; returns a dict of raw results."""
+    lr, ent, vf = 5e-5, 5e-4, 0.5
+    eng = Engine(cell, hidden, layers, dev)
+    eng.load_state_dict(synth.init_state_dict(7, cell, hidden, layers))
+    hook = hook_factory(eng) if hook_factory is not None else None
+    if hook is not None:
+        hook.sync_parameters()
+    # every rank gets its own shard of trajectories (the reference's ranks pull from a shared queue)
+    rollouts = synth.make_rollouts(1000 + rank, [S] * B)
+    batch = pack_rollouts(rollouts, S, dev)
+    res = {'eng': eng, 'rollouts': rollouts, 'batch': batch, 'hook': hook, 'lr': lr, 'ent': ent, 'vf': vf}
+    if want_parity:
+        res['first_iteration'] = hip_parity_iteration(eng, batch, S, E, lr, ent, vf, hook)
+
+    def step():
+        chunks = eng.rollout_pass(batch, S)
+        for _ in range(E):
+            eng.train_epoch(chunks, lr, ent, vf, grad_hook=hook)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    res['elapsed'] = elapsed
+    res['status'] = int(eng.status.item())
+    res['losses'] = eng.out.cpu().numpy()
+    res['step'] = step
+    if want_profile:
+        # split of a step (SURVEY.md 8(d): "also report per-epoch train-only steps/s"): one extra untimed iteration with
+        # events on the launch stream around the rollout pass and around the E epochs
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        chunks_x = eng.rollout_pass(batch, S)
+        ev[1].record()
+        for _ in range(E):
+            eng.train_epoch(chunks_x, lr, ent, vf, grad_hook=hook)
+        ev[2].record()
+        torch.cuda.synchronize()
+        res['rollout_ms'], res['epochs_ms'] = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+        # roofline: one extra untimed iteration with per-launch HIP events
+        eng.lib.dc_profile_enable(1)
+        step()
+        torch.cuda.synchronize()
+        res['regions'] = profile_report(eng.lib)
+        eng.lib.dc_profile_enable(0)
+    return res
 
 
 def main():
@@ -123,12 +283,14 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--cell', default='lstm')
-    ap.add_argument('--hidden', type=int, default=128)
+    ap.add_argument('--hidden', type=int, default=256)
     ap.add_argument('--layers', type=int, default=1)
-    ap.add_argument('--batch', type=int, default=64, help='trajectories per GPU')
+    ap.add_argument('--batch', type=int, default=0,
+                    help='trajectories per GPU; 0 = BASELINE.json: 256 at N = 1 (configs[2]), 128 at N > 1 (configs[3]: 1024 at DP=8)')
     ap.add_argument('--seq-len', type=int, default=256)
     ap.add_argument('--epochs', type=int, default=4)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true', help='also skips `parity` (the oracle run is its checker)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the configs[1] / GRU-256 / weak-scaling-unit side measurements')
     ap.add_argument('--no-host-extras', action='store_true',
                     help='skip the ingest / publish timings (hundreds of small copies that would pollute a kernel trace)')
     ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'pmc_traffic_latest.json'),
@@ -154,19 +316,20 @@ def main():
             dist.init_process_group(backend='nccl', device_id=torch.device('cuda', dev_index))
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node = --gpus'
     dev = torch.device('cuda', dev_index)
-    lr, ent, vf = 5e-5, 5e-4, 0.5
-    B, S, E = args.batch, args.seq_len, args.epochs
+    S, E = args.seq_len, args.epochs
+    default_family = (args.cell, args.hidden, args.layers, S) == ('lstm', 256, 1, 256) and args.batch == 0
+    B = args.batch if args.batch > 0 else (256 if world == 1 else 128)
 
-    eng = Engine(args.cell, args.hidden, args.layers, dev)
-    eng.load_state_dict(synth.init_state_dict(7, args.cell, args.hidden, args.layers))
-    hook = None
+    hook_factory = None
     if world > 1:
         from dotaclient_amd.distributed import FlatGradAllReducer
-        hook = FlatGradAllReducer(eng)
-        hook.sync_parameters()
-    # every rank gets its own shard of trajectories (the reference's ranks pull from a shared queue)
-    rollouts = synth.make_rollouts(1000 + rank, [S] * B)
-    batch = pack_rollouts(rollouts, S, dev)
+        hook_factory = FlatGradAllReducer
+    main_run = run_workload(args.cell, args.hidden, args.layers, B, S, E, args.steps, args.warmup, dev, rank, world, hook_factory,
+                            want_parity=(world == 1 and rank == 0 and not args.no_cpu_baseline), want_profile=True)
+    eng, rollouts, batch = main_run['eng'], main_run['rollouts'], main_run['batch']
+    elapsed, status, losses, regions = main_run['elapsed'], main_run['status'], main_run['losses'], main_run['regions']
+    rollout_ms, epochs_ms = main_run['rollout_ms'], main_run['epochs_ms']
+    lr, ent, vf = main_run['lr'], main_run['ent'], main_run['vf']
 
     # host -> device ingest of one batch (pack_rollouts: page-locked staging + 4 H2D copies), steady state; reported
     # beside the headline, never inside it (inputs are resident in HBM when the timed region starts)
@@ -206,103 +369,82 @@ def main():
                     samples[name].append((time.perf_counter() - t0) * 1e3)
         publish_ms = {k: round(float(np.median(v)), 3) for k, v in samples.items()}
 
-    def step():
-        chunks = eng.rollout_pass(batch, S)
-        for _ in range(E):
-            eng.train_epoch(chunks, lr, ent, vf, grad_hook=hook)
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    status = int(eng.status.item())
-    losses = eng.out.cpu().numpy()
-
-    # ---- split of a step ("also report per-epoch train-only steps/s"): one extra untimed iteration with
-    # events on the launch stream around the rollout pass and around the E epochs
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    ev[0].record()
-    chunks_x = eng.rollout_pass(batch, S)
-    ev[1].record()
-    for _ in range(E):
-        eng.train_epoch(chunks_x, lr, ent, vf, grad_hook=hook)
-    ev[2].record()
-    torch.cuda.synchronize()
-    rollout_ms, epochs_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
-
-    # ---- roofline: one extra untimed iteration with per-launch HIP events --------------------------------
-    eng.lib.dc_profile_enable(1)
-    step()
-    torch.cuda.synchronize()
-    regions = profile_report(eng.lib)
-    eng.lib.dc_profile_enable(0)
+    # ---- side measurements at N = 1: the other BASELINE.json single-GPU configurations and the weak-scaling unit --------
+    secondary = None
+    if world == 1 and default_family and not args.no_secondary:
+        secondary = {}
+        for key, (c, h, b, what) in {
+                'weak_scaling_unit': ('lstm', 256, 128, "configs[3]'s per-GPU shard (128 trajectories x 256 steps, LSTM-256) on ONE GPU, "
+                                                        'no all-reduce: the N = 1 reference point for the N > 1 lines of this script'),
+                'configs[1]': ('lstm', 128, 64, 'BASELINE.json configs[1]: 1v1-mid, LSTM-128, 64 trajectories x 256 steps'),
+                'reference_gru256_64x256': ('gru', 256, 64, "configs[1]'s batch on the reference's own cell (GRU-256, policy.py:66)")}.items():
+            main_run['eng'] = None
+            r = run_workload(c, h, 1, b, S, E, args.steps, args.warmup, dev, rank, world)
+            secondary[key] = {'workload': what, 'value': round(b * S * args.steps / r['elapsed'], 1), 'unit': 'env-steps/s',
+                              'ms_per_step': round(r['elapsed'] / args.steps * 1e3, 3), 'nan_status': r['status']}
+            del r
+            torch.cuda.empty_cache()
 
     if rank == 0:
         n_steps = world * B * S * args.steps
         value = n_steps / elapsed
         ffwd = fwd_flops_per_step(args.cell, args.hidden, args.layers)
+        workload_key = '%s-%d-%dx%d' % (args.cell, args.hidden, B, S)
         regions.sort(key=lambda r: -r['total_ms'])
         kernels = []
         for r in regions:
             avg_us = r['total_ms'] * 1e3 / r['launches']
-            kernels.append({'kernel': r['kernel'], 'launches_per_step': r['launches'], 'avg_us': round(avg_us, 3),
-                            'ms_per_step': round(r['total_ms'], 3),
-                            'achieved_tflops': round(r['flops'] / (r['total_ms'] * 1e-3) / 1e12, 3),
-                            # algorithmic bytes / time; HBM peak 8 TB/s (MI355X_MICROARCH.md) - the yardstick of the streaming kernels
-                            'achieved_gbs': round(r['bytes'] / (r['total_ms'] * 1e-3) / 1e9, 1)})
+            bound = REGION_BOUND.get(r['kernel'], 'mfma' if r['flops'] > 0 else 'hbm')
+            k = {'kernel': r['kernel'], 'bound': bound, 'launches_per_step': r['launches'], 'avg_us': round(avg_us, 3),
+                 'ms_per_step': round(r['total_ms'], 3)}
+            if bound == 'hbm':
+                if r['kernel'] in MASK_DEPENDENT_BYTES:
+                    k['achieved_gbs'] = None
+                    k['note'] = 'mask-aware: reads only the unmasked units, the byte count depends on the masks (dense form: %.0f MB per launch)' \
+                                % (r['bytes'] / r['launches'] / 1e6)
+                else:
+                    gbs = r['bytes'] / (r['total_ms'] * 1e-3) / 1e9
+                    k['achieved_gbs'] = round(gbs, 1)
+                    k['frac_of_hbm_peak'] = round(gbs / PEAK_HBM_GBS, 4)
+            else:
+                tf = r['flops'] / (r['total_ms'] * 1e-3) / 1e12
+                k['achieved_tflops'] = round(tf, 3)
+                k['frac_of_f32_peak'] = round(tf / PEAK_F32_MFMA_TFLOPS, 4)
+            k['traffic'] = pmc_traffic(args.traffic_json, r['kernel'].split('(')[0], workload_key)
+            kernels.append(k)
         # the HBM-bound side (GAE / loss / Adam / pooling stream their operands once): largest by time
-        # (the mask-aware attention kernels are left out: their byte count depends on the masks, the host-side figure is the dense one)
-        hbm_names = ('pool_env_fwd', 'embed_scatter_bwd(+reduce)', 'ppo_loss(stats+loss+finalize)', 'gradnorm_clip_adam', 'gae_scan',
-                     'select_logp')
-        hbm = [r for r in regions if r['kernel'] in hbm_names]
+        hbm = [r for r in regions if REGION_BOUND.get(r['kernel']) == 'hbm' and r['kernel'] not in MASK_DEPENDENT_BYTES]
         roofline_hbm = None
         if hbm:
             hd = hbm[0]
             gbs = hd['bytes'] / (hd['total_ms'] * 1e-3) / 1e9
-            roofline_hbm = {'bound': 'hbm', 'kernel': hd['kernel'], 'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s',
-                            'frac': round(gbs / 8000.0, 4), 'avg_launch_us': round(hd['total_ms'] * 1e3 / hd['launches'], 3),
+            roofline_hbm = {'bound': 'hbm', 'kernel': hd['kernel'], 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                            'frac': round(gbs / PEAK_HBM_GBS, 4), 'avg_launch_us': round(hd['total_ms'] * 1e3 / hd['launches'], 3),
                             'algorithmic_bytes_per_launch': hd['bytes'] / hd['launches'],
-                            'traffic': pmc_traffic(args.traffic_json, hd['kernel'].split('(')[0], '%s-%d-%dx%d' % (args.cell, args.hidden, B, S))}
+                            'traffic': pmc_traffic(args.traffic_json, hd['kernel'].split('(')[0], workload_key)}
         dom = regions[0]
+        dom_bound = REGION_BOUND.get(dom['kernel'], 'mfma')
         achieved = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
-        # every region on this list is priced against the dense f32 rate of the chip, 157.3 TF: it is both the f32 MFMA
-        # peak (the GEMM-shaped kernels) and the packed-f32 VALU peak (the sparse max-pool backward and the recurrent
-        # kernels, whose algorithmic flop counts are the sparse / per-sequence ones)
-        notes = {'embed_bwd_pool16': 'f32 VALU kernel (gathers of 512-byte W2 / basic rows scaled per channel): 1/16 of the '
-                                     'dense MACs; its own limits are VALU issue and LDS bandwidth, not the matrix pipes',
-                 'lstm_fwd_persist': 'recurrence, serial in time: latency-bound', 'lstm_bwd_persist': 'recurrence, serial in time: latency-bound'}
-        for k in ('gru_fwd_team', 'gru_bwd_team', 'lstm_fwd_team', 'lstm_bwd_team'):
-            notes[k] = ('recurrence, serial in time, a sequence spread over four CUs: bound by the per-step hand-off latency '
-                        'between them (rnn_team.hip), not by arithmetic')
-        roofline = {'bound': 'mfma', 'bound_note': notes.get(dom['kernel'], 'f32 MFMA (v_mfma_f32_32x32x2_f32)'), 'kernel': dom['kernel'], 'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS,
+        roofline = {'bound': dom_bound, 'bound_note': BOUND_NOTES[dom_bound], 'kernel': dom['kernel'],
+                    'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                    'traffic': pmc_traffic(args.traffic_json, dom['kernel'], '%s-%d-%dx%d' % (args.cell, args.hidden, B, S)),
+                    'traffic': pmc_traffic(args.traffic_json, dom['kernel'], workload_key),
                     'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, %s)' % os.path.relpath(args.traffic_json, REPO),
                     'algorithmic_bytes_per_launch': dom['bytes'] / dom['launches'],
                     'avg_launch_us': round(dom['total_ms'] * 1e3 / dom['launches'], 3),
                     'flops_per_launch': dom['flops'] / dom['launches'],
-                    'whole_step': {'flops_per_env_step': ffwd * (1 + 3 * E),
-                                   'achieved_tflops': round(value / world * ffwd * (1 + 3 * E) / 1e12, 3),
-                                   # steps/s x F_iter / peak, per GPU, dense (reference) flop count
-                                   'frac_of_f32_peak': round(value / world * ffwd * (1 + 3 * E) / 1e12 / 157.3, 4)},
+                    'whole_step': {'flops_per_env_step_dense': ffwd * (1 + 3 * E),
+                                   'effective_tflops_dense_count': round(value / world * ffwd * (1 + 3 * E) / 1e12, 3),
+                                   'note': 'steps/s x the reference\'s DENSE flop count (SURVEY.md 8(d)); the sparse max-pool backward '
+                                           'executes 1/16 of the dense MACs of the 16-unit types, so this is an effective rate, not pipe '
+                                           'utilisation - per-kernel utilisation is in `kernels`'},
                     'kernels': kernels}
-        key = (args.cell, args.hidden, args.layers, B, S)
-        which = {('lstm', 128, 1, 64, 256): 'BASELINE.json configs[1] (1v1-mid, the configuration the metric is quoted on)',
-                 ('lstm', 256, 1, 256, 256): 'BASELINE.json configs[2] (5v5: 256 trajectories, LSTM-256)',
-                 ('gru', 256, 1, 64, 256): "configs[1]'s batch with the reference's own cell (GRU-256, policy.py:66)"}.get(
+        key = (args.cell, args.hidden, args.layers, B, S, world > 1)
+        which = {('lstm', 256, 1, 256, 256, False): 'BASELINE.json configs[2] (5v5 synthetic, LSTM hidden=256, batch=256x256 steps, 1xMI355X)',
+                 ('lstm', 256, 1, 128, 256, True): "BASELINE.json configs[3] geometry (5v5 synthetic, LSTM hidden=256, 128 trajectories x 256 "
+                                                   'steps per GPU = 1024x256 at DP=8, RCCL gradient all-reduce every epoch)',
+                 ('lstm', 128, 1, 64, 256, False): 'BASELINE.json configs[1] (1v1-mid, LSTM hidden=128, batch=64x256 steps)',
+                 ('gru', 256, 1, 64, 256, False): "configs[1]'s batch with the reference's own cell (GRU-256, policy.py:66)"}.get(
                      key, 'other configuration (not a BASELINE.json bench line)')
         line = {
             'metric': 'env-steps/sec through PPO optimizer', 'value': round(value, 1), 'unit': 'env-steps/s',
@@ -321,6 +463,7 @@ def main():
             'roofline': roofline,
             'roofline_hbm': roofline_hbm,
             'nan_status': status, 'final_loss': float(losses[0]),
+            'secondary': secondary,
             'ingest': None if ingest_ms is None else {
                        'pack_h2d_ms_per_batch': round(ingest_ms, 3),
                        'env_steps_per_s_with_ingest_serialised': round(B * S / (elapsed / args.steps + ingest_ms * 1e-3), 1),
@@ -332,10 +475,15 @@ def main():
                                 'per_tensor_copies = the reference\'s form; not part of `value`'},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(args.cell, args.hidden, args.layers, rollouts, S, E, lr, ent, vf)
+            line['cpu_baseline'], ref = cpu_baseline(args.cell, args.hidden, args.layers, rollouts, S, E, lr, ent, vf)
+            line['parity'] = parity_report(main_run['first_iteration'], ref)
         else:
             line['cpu_baseline'] = None
+            line['parity'] = None
         print(json.dumps(line))
+        if line['parity'] is not None and not line['parity']['ok']:
+            sys.stderr.write('bench.py: PARITY FAILED against the oracle: %s\n' % json.dumps(line['parity']))
+            sys.exit(3)
     if world > 1:
         torch.distributed.destroy_process_group()
 

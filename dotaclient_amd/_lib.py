@@ -21,6 +21,8 @@ SIGNATURES = {
     'dc_abi_version': (c_int, []),
     'dc_last_error': (ctypes.c_char_p, []),
     'dc_gae_scan': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_dbl, c_dbl, c_ptr, c_ptr, c_ptr]),
+    'dc_discount': (c_int, [c_ptr, c_int, c_dbl, c_ptr, c_ptr]),
+    'dc_advantage_returns': (c_int, [c_ptr, c_ptr, c_int, c_dbl, c_dbl, c_ptr, c_ptr, c_ptr]),
     'dc_gemm_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                             c_ptr, c_int, c_ptr, c_int, c_int, c_int, c_ptr]),
     'dc_gemm_set_scratch': (None, [c_ptr, c_i64]),

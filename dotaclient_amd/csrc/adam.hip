@@ -144,10 +144,9 @@ __global__ __launch_bounds__(256) void dp_scale_kernel(AdamSegs sg, float* __res
     float cnt = counts[5];
     if (g >= 0 && g < 5) cnt = counts[g];
     if (cnt <= 0.f) return;
-    const float inv = 1.f / cnt;
     const long long base = sg.seg_off[seg];
     const long long c1 = min(len, c0 + ADAM_CHUNK);
-    for (long long i = base + c0 + threadIdx.x; i < base + c1; i += 256) grad[i] *= inv;
+    for (long long i = base + c0 + threadIdx.x; i < base + c1; i += 256) grad[i] = grad[i] / cnt;   // grad_data /= has_grad_count (distributed.py:57)
 }
 
 int dp_average_grads(const int64_t* seg_off, const int32_t* seg_len, const int32_t* seg_gate, int n_seg, int max_seg_len,

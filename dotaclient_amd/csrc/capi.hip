@@ -47,6 +47,17 @@ int dc_gae_scan(const float* rewards, const float* values, const int64_t* seq_of
     return dc::gae_scan(rewards, values, seq_off, seq_len, n_seq, max_len, gamma, lam, adv, ret, (hipStream_t)stream);
 }
 
+int dc_discount(const float* x, int n, double gamma, float* y, dc_stream_t stream) {
+    DC_ENTER();
+    return dc::discount(x, n, gamma, y, (hipStream_t)stream);
+}
+
+int dc_advantage_returns(const float* rewards, const float* values, int L, double gamma, double lam, float* adv, float* ret,
+                         dc_stream_t stream) {
+    DC_ENTER();
+    return dc::advantage_returns(rewards, values, L, gamma, lam, adv, ret, (hipStream_t)stream);
+}
+
 int dc_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                 int a_kmajor, int b_kmajor, const float* bias, int relu, const float* aux, int ldaux,
                 int accumulate, int splits, dc_stream_t stream) {

@@ -44,6 +44,36 @@ __device__ __forceinline__ Affine compose(const Affine& outer, const Affine& inn
     return r;
 }
 
+// y[t] = x[t] + g * y[t+1] over s[0..L) in place (float32 in, float64 accumulate, float32 out), y[L] = carry_term:
+// lane-local chunk -> affine map (reverse time), wavefront suffix scan of the 64 maps, replay of the chunk with the
+// exact carry-in.  Called by all 64 lanes of ONE wavefront; s lives in LDS and was written by this wavefront.
+__device__ __forceinline__ void suffix_scan_replay(float* s, int L, int lane, double g, double carry_term) {
+    const int chunk = (L + 63) / 64;
+    const int lo = min(lane * chunk, L);
+    const int hi = min(lo + chunk, L);
+    Affine m = {1.0, 0.0};
+    for (int t = hi - 1; t >= lo; --t) {
+        m.b = (double)s[t] + g * m.b;
+        m.a *= g;
+    }
+    // suffix scan over lanes: after it, lane i holds the map of chunks i..63
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        Affine n;
+        n.a = __shfl_down(m.a, o, 64); n.b = __shfl_down(m.b, o, 64);
+        if (lane + o < 64) m = compose(m, n);
+    }
+    // carry into lane i = value at the first step of lane i+1's suffix
+    const double na = __shfl_down(m.a, 1, 64), nb = __shfl_down(m.b, 1, 64);
+    double c = (lane == 63) ? carry_term : (carry_term == 0.0 ? nb : nb + na * carry_term);
+    // replay the chunk with the exact carry: one rounding per multiply and per add, like the C loop inside lfilter
+    for (int t = hi - 1; t >= lo; --t) {
+        const double p = g * c;
+        c = (double)s[t] + p;
+        s[t] = (float)c;
+    }
+}
+
 __global__ __launch_bounds__(64) void gae_scan_kernel(const float* __restrict__ rewards,   // [rows,10]
                                                       const float* __restrict__ values,    // [rows]
                                                       const int64_t* __restrict__ seq_off, // [n_seq]
@@ -76,41 +106,9 @@ __global__ __launch_bounds__(64) void gae_scan_kernel(const float* __restrict__ 
     }
     __syncthreads();
 
-    // pass 2: lane-local chunk -> affine map (reverse time)
-    const int chunk = (L + 63) / 64;
-    const int lo = min(lane * chunk, L);
-    const int hi = min(lo + chunk, L);
-    Affine ma = {1.0, 0.0}, mr = {1.0, 0.0};
-    for (int t = hi - 1; t >= lo; --t) {
-        ma.b = (double)s_delta[t] + gl_d * ma.b;
-        ma.a *= gl_d;
-        mr.b = (double)s_rsum[t] + gamma_d * mr.b;
-        mr.a *= gamma_d;
-    }
-    // suffix scan over lanes: after it, lane i holds the map of chunks i..63 (terminal carry 0)
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        Affine na, nr;
-        na.a = __shfl_down(ma.a, o, 64); na.b = __shfl_down(ma.b, o, 64);
-        nr.a = __shfl_down(mr.a, o, 64); nr.b = __shfl_down(mr.b, o, 64);
-        if (lane + o < 64) {
-            ma = compose(ma, na);
-            mr = compose(mr, nr);
-        }
-    }
-    // carry into lane i = value at the first step of lane i+1's suffix = b of lane i+1
-    double ca = __shfl_down(ma.b, 1, 64);
-    double cr = __shfl_down(mr.b, 1, 64);
-    if (lane == 63) { ca = 0.0; cr = 0.0; }
-    // pass 3: replay the chunk with the exact carry
-    for (int t = hi - 1; t >= lo; --t) {
-        // one rounding per multiply and per add, like the C loop inside lfilter (no fma contraction)
-        const double pa = gl_d * ca, pr = gamma_d * cr;
-        ca = (double)s_delta[t] + pa;
-        cr = (double)s_rsum[t] + pr;
-        s_delta[t] = (float)ca;
-        s_rsum[t] = (float)cr;
-    }
+    // passes 2 + 3: the two reverse recurrences (terminal carry 0: the appended zeros of optimizer.py:417-420)
+    suffix_scan_replay(s_delta, L, lane, gl_d, 0.0);
+    suffix_scan_replay(s_rsum, L, lane, gamma_d, 0.0);
     __syncthreads();
     for (int t = lane; t < L; t += 64) {
         adv[base + t] = s_delta[t];
@@ -139,6 +137,72 @@ int gae_scan(const float* rewards, const float* values, const int64_t* seq_off, 
     hipLaunchKernelGGL(gae_scan_kernel, dim3(n_seq), dim3(64), lds_bytes, stream, rewards, values, seq_off,
                        seq_len, (float)gamma, gamma, gamma * lam, adv, ret);
     return launch_check("gae_scan");
+}
+
+// optimizer.py:53-54 `discount` for one vector: y[t] = x[t] + gamma * y[t+1], y[n] = 0 (float64 accumulate).
+__global__ __launch_bounds__(64) void discount_kernel(const float* __restrict__ x, int n, double g, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    for (int t = lane; t < n; t += 64) lds[t] = x[t];
+    __syncthreads();
+    suffix_scan_replay(lds, n, lane, g, 0.0);
+    __syncthreads();
+    for (int t = lane; t < n; t += 64) y[t] = lds[t];
+}
+
+// optimizer.py:57-64 `advantage_returns` for one rollout with ANY terminal entries: rewards / values are the (L+1)-long
+// vectors of the reference (already summed over the sub-rewards; entry L is whatever the caller appended):
+//   deltas = rewards[:-1] + gamma * values[1:] - values[:-1]   (float32)
+//   adv    = discount(deltas, gamma * lam)
+//   ret    = discount(rewards, gamma)[:-1]                      -> the scan over L entries enters with y[L] = rewards[L]
+__global__ __launch_bounds__(64) void advantage_returns_kernel(const float* __restrict__ rewards, const float* __restrict__ values,
+                                                               int L, float gamma, double gamma_d, double gl_d,
+                                                               float* __restrict__ adv, float* __restrict__ ret) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    float* s_delta = lds;
+    float* s_r = lds + L;
+    for (int t = lane; t < L; t += 64) {
+        const float r = rewards[t];
+        const float gv = gamma * values[t + 1];
+        s_delta[t] = (r + gv) - values[t];
+        s_r[t] = r;
+    }
+    __syncthreads();
+    suffix_scan_replay(s_delta, L, lane, gl_d, 0.0);
+    suffix_scan_replay(s_r, L, lane, gamma_d, (double)rewards[L]);
+    __syncthreads();
+    for (int t = lane; t < L; t += 64) {
+        adv[t] = s_delta[t];
+        ret[t] = s_r[t];
+    }
+}
+
+static int scan_lds_attr(const void* fn, size_t lds_bytes, const char* what) {
+    if (lds_bytes > 160 * 1024) { set_error(what, 1001); return 1001; }
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) { set_error("gae: hipFuncSetAttribute", (int)e); return (int)e; }
+    }
+    return 0;
+}
+
+int discount(const float* x, int n, double gamma, float* y, hipStream_t stream) {
+    if (n <= 0) return 0;
+    const size_t lds_bytes = (size_t)n * sizeof(float);
+    if (int e = scan_lds_attr((const void*)discount_kernel, lds_bytes, "discount: vector longer than 40960 entries is not supported")) return e;
+    hipLaunchKernelGGL(discount_kernel, dim3(1), dim3(64), lds_bytes, stream, x, n, gamma, y);
+    return launch_check("discount");
+}
+
+int advantage_returns(const float* rewards, const float* values, int L, double gamma, double lam, float* adv, float* ret,
+                      hipStream_t stream) {
+    if (L <= 0) return 0;
+    const size_t lds_bytes = (size_t)L * 2 * sizeof(float);
+    if (int e = scan_lds_attr((const void*)advantage_returns_kernel, lds_bytes, "advantage_returns: rollout longer than 20480 steps is not supported")) return e;
+    hipLaunchKernelGGL(advantage_returns_kernel, dim3(1), dim3(64), lds_bytes, stream, rewards, values, L, (float)gamma, gamma,
+                       gamma * lam, adv, ret);
+    return launch_check("advantage_returns");
 }
 
 }  // namespace dc

@@ -41,6 +41,9 @@ struct ProfScope {
 // gae.hip
 int gae_scan(const float* rewards, const float* values, const int64_t* seq_off, const int32_t* seq_len, int n_seq,
              int max_len, double gamma, double lam, float* adv, float* ret, hipStream_t stream);
+int discount(const float* x, int n, double gamma, float* y, hipStream_t stream);
+int advantage_returns(const float* rewards, const float* values, int L, double gamma, double lam, float* adv, float* ret,
+                      hipStream_t stream);
 // gemm.hip
 int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kmajor,
              int b_kmajor, const float* bias, int relu, const float* aux, int ldaux, int accumulate, int splits,

@@ -77,30 +77,37 @@ def _as_np(x):
 
 
 class _Staging:
-    """Page-locked host buffers of one batch shape, reused across iterations (a fresh 32 MB allocation costs more in
-    page faults than filling it).  Two sets alternate; a set is handed out again only after the H2D copies that read
-    it have completed (event recorded behind them)."""
-    _pool = {}
+    """Page-locked host buffers for one batch, reused across iterations (a fresh 32 MB allocation costs more in page
+    faults than filling it).  ONE double-buffered pair per process, sized to the largest batch seen so far and grown
+    geometrically (the consumer loop adds whole rollouts until min_seq_per_epoch is reached, so the row count changes
+    almost every iteration: a pair per exact size would pin host memory without bound); a batch uses the leading
+    `rows` of each buffer.  A set is handed out again only after the H2D copies that read it have completed (event
+    recorded behind them); the old set is released when a larger one replaces it."""
+    _sets = {}        # pin -> [set, set]
+    _next = {}
 
-    def __init__(self, rows, pin):
+    def __init__(self, capacity, pin):
         mk = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=pin)
-        self.obs = mk((rows, L.OBS_DIM), torch.float32)
-        self.act = mk((rows, L.ACT_DIM), torch.uint8)
-        self.msk = mk((rows, L.ACT_DIM), torch.uint8)
-        self.rew = mk((rows, 10), torch.float32)
-        self.views = (self.obs.numpy(), self.act.numpy(), self.msk.numpy(), self.rew.numpy())
+        self.capacity = capacity
+        self.obs = mk((capacity, L.OBS_DIM), torch.float32)
+        self.act = mk((capacity, L.ACT_DIM), torch.uint8)
+        self.msk = mk((capacity, L.ACT_DIM), torch.uint8)
+        self.rew = mk((capacity, 10), torch.float32)
         self.event = None
 
     @classmethod
     def get(cls, rows, pin):
-        sets = cls._pool.setdefault((rows, pin), {'sets': [], 'next': 0})
-        if len(sets['sets']) < 2:
-            sets['sets'].append(cls(rows, pin))
-            return sets['sets'][-1]
-        st = sets['sets'][sets['next']]
-        sets['next'] ^= 1
-        if st.event is not None:
+        sets = cls._sets.setdefault(pin, [None, None])
+        i = cls._next.get(pin, 0)
+        cls._next[pin] = i ^ 1
+        st = sets[i]
+        if st is not None and st.event is not None:
             st.event.synchronize()
+            st.event = None
+        if st is None or st.capacity < rows:
+            cap = rows if st is None else max(rows, st.capacity + st.capacity // 2)
+            sets[i] = st = None               # release the old pinned buffers before allocating the larger ones
+            sets[i] = st = cls(cap, pin)
         return st
 
 
@@ -172,7 +179,7 @@ def pack_rollouts(rollouts, seq_len, device):
     tab = np.ascontiguousarray(np.array(items, dtype=np.int64).reshape(-1, 5).T)          # [5, n_items] (items: flat list)
     col = lambda k: ctypes.c_void_p(tab[k].ctypes.data)
     _lib.check(_lib.load().dc_pack_rows(col(0), col(1), col(2), col(3), col(4), tab.shape[1], PACK_THREADS), 'dc_pack_rows')
-    to = lambda x: x.to(dev, non_blocking=True) if pin else x.clone()
+    to = lambda x: x[:rows].to(dev, non_blocking=True) if pin else x[:rows].clone()
     batch = PackedBatch(to(st.obs), to(st.act), to(st.msk), to(st.rew), torch.from_numpy(off).to(dev),
                         torch.from_numpy(lens_n.astype(np.int32)).to(dev), int(lens_n.max()))
     if pin:

@@ -35,6 +35,30 @@ def gae_scan(rewards, values, seq_off, seq_len, max_len, gamma=0.98, lam=0.97, a
     return adv, ret
 
 
+def discount(x, gamma, y=None):
+    """x [n] f32 (GPU) -> y[t] = x[t] + gamma * y[t+1] (optimizer.py:53-54)."""
+    lib = _lib.load()
+    _chk(x, torch.float32, 'x')
+    if y is None:
+        y = torch.empty_like(x)
+    _lib.check(lib.dc_discount(_lib.ptr(x), x.numel(), float(gamma), _lib.ptr(y), _lib.stream_ptr()), 'dc_discount')
+    return y
+
+
+def advantage_returns(rewards, values, gamma, lam):
+    """rewards, values [L+1] f32 (GPU; any terminal entries) -> (adv, ret) [L] f32 (optimizer.py:57-64)."""
+    lib = _lib.load()
+    _chk(rewards, torch.float32, 'rewards'); _chk(values, torch.float32, 'values')
+    n = rewards.numel() - 1
+    if values.numel() != n + 1:
+        raise ValueError('advantage_returns: rewards and values must have the same length')
+    adv = torch.empty(max(n, 0), dtype=torch.float32, device=values.device)
+    ret = torch.empty_like(adv)
+    _lib.check(lib.dc_advantage_returns(_lib.ptr(rewards), _lib.ptr(values), n, float(gamma), float(lam), _lib.ptr(adv),
+                                        _lib.ptr(ret), _lib.stream_ptr()), 'dc_advantage_returns')
+    return adv, ret
+
+
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, bias=None, relu=False, aux=None,
          ldaux=0, accumulate=False, splits=0):
     lib = _lib.load()

@@ -10,15 +10,16 @@ Same constructor/CLI arguments (optimizer.py:207-209, 776-794), same method name
     DotaOptimizer.run()                                   optimizer.py:436-579   (consumer loop + metrics)
     DotaOptimizer.upload_model(version)                   optimizer.py:697-723
 
-The RabbitMQ / GCS / TensorBoard plumbing is outside the hot path: `MessageQueue`
-is imported lazily from pika when no queue object is injected, TensorBoard/GCS are used only if their
-modules are importable.  Everything arithmetic happens in libdotaclient_hip.so; there is no CPU path.
+The RabbitMQ / GCS / TensorBoard / checkpoint-directory plumbing (optimizer.py:67-174, 231-266, 287-308, 534-579) is
+outside the hot path and is NOT re-implemented here: the caller injects the reference's own
+`MessageQueue` object (`mq=`; INTEGRATION.md, option A keeps the reference's class), and metrics go to an optional
+`metrics_sink(metrics, iteration)` callable (the reference's TensorBoard writer, or nothing).  Everything arithmetic
+happens in libdotaclient_hip.so; there is no CPU path.
 """
 import io
 import logging
 import os
 import pickle
-import re
 import time
 
 import numpy as np
@@ -33,23 +34,30 @@ logger = logging.getLogger(__name__)
 REWARD_KEYS = ['enemy', 'win', 'xp', 'hp', 'kills', 'death', 'lh', 'denies', 'tower_hp', 'mana']  # policy.py:20
 
 
+def _to_dev_f32(x):
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float32))).to('cuda:0')
+
+
+def discount(x, gamma):
+    """Same contract as optimizer.py:53-54: float32 (n,) in, float32 (n,) numpy out (float64 accumulate inside, like the
+    reference's lfilter).  One wavefront-scan HIP launch."""
+    x = np.asarray(x, dtype=np.float32)
+    if x.shape[0] == 0:
+        return np.zeros(0, np.float32)
+    return ops.discount(_to_dev_f32(x), gamma).cpu().numpy()
+
+
 def advantage_returns(rewards, values, gamma, lam):
-    """Same contract as optimizer.py:57-64: rewards/values are float32 (L+1,) arrays whose last entry is
-    the appended terminal 0 (optimizer.py:417-420); returns (advantages, returns) float32 (L,) numpy.
-    Runs the wavefront-scan HIP kernel (one sequence)."""
+    """Same contract as optimizer.py:57-64: rewards/values are float32 (L+1,) arrays - the reference's caller appends a
+    terminal 0 to each (optimizer.py:417-420), but like the reference function any terminal reward / bootstrap value
+    is accepted; returns (advantages, returns) float32 (L,) numpy.  One wavefront-scan HIP launch."""
     rewards = np.asarray(rewards, dtype=np.float32)
     values = np.asarray(values, dtype=np.float32)
-    Lr = rewards.shape[0] - 1
-    if Lr <= 0:
+    if rewards.shape != values.shape or rewards.ndim != 1:
+        raise ValueError('advantage_returns: rewards and values must be 1-D and of equal length')
+    if rewards.shape[0] <= 1:
         return np.zeros(0, np.float32), np.zeros(0, np.float32)
-    if rewards[-1] != 0 or values[-1] != 0:
-        raise ValueError('advantage_returns expects the terminal 0 appended to rewards and values (optimizer.py:417-420)')
-    dev = torch.device('cuda:0')
-    rew10 = np.zeros((Lr, L.N_REWARDS), np.float32)
-    rew10[:, 0] = rewards[:-1]
-    adv, ret = ops.gae_scan(torch.from_numpy(rew10).to(dev), torch.from_numpy(values[:-1].copy()).to(dev),
-                            torch.zeros(1, dtype=torch.int64, device=dev),
-                            torch.tensor([Lr], dtype=torch.int32, device=dev), Lr, gamma, lam)
+    adv, ret = ops.advantage_returns(_to_dev_f32(rewards), _to_dev_f32(values), gamma, lam)
     return adv.cpu().numpy(), ret.cpu().numpy()
 
 
@@ -129,7 +137,7 @@ class DotaOptimizer:
 
     def __init__(self, rmq_host, rmq_port, epochs, min_seq_per_epoch, seq_len, learning_rate, checkpoint,
                  pretrained_model, mq_prefetch_count, log_dir, entropy_coef, vf_coef, run_local,
-                 mq=None, cell='gru', hidden=256, layers=1, device='cuda:0'):
+                 mq=None, metrics_sink=None, cell='gru', hidden=256, layers=1, device='cuda:0'):
         self.rmq_host, self.rmq_port = rmq_host, rmq_port
         self.epochs, self.min_seq_per_epoch, self.seq_len = epochs, min_seq_per_epoch, seq_len
         self.learning_rate, self.checkpoint = learning_rate, checkpoint
@@ -140,7 +148,6 @@ class DotaOptimizer:
         self.model_upload_freq = 10
         self.eventfile_refresh_freq = 100
         self.e_clip = 0.1
-        self.writer = None
         self._snapshot = None
         self.bucket = None
         self.policy_base = Policy(cell, hidden, layers, device)
@@ -148,14 +155,7 @@ class DotaOptimizer:
         self.engine = self.policy_base.engine
         self.device = self.engine.device
 
-        if self.checkpoint:
-            os.makedirs(self.log_dir, exist_ok=True)
-            latest = self.get_latest_model(prefix=self.log_dir)
-            if latest is not None:
-                pretrained_model = latest
-            if pretrained_model is not None:
-                self.iteration_start = self.iteration_from_model_filename(pretrained_model) + 1
-        if pretrained_model is not None:
+        if pretrained_model is not None:                                    # optimizer.py:264-267 (a local file)
             self.policy_base.load_state_dict(torch.load(pretrained_model, map_location='cpu'), strict=False)
 
         # data parallel: flat-bucket RCCL all-reduce instead of the reference's per-parameter gloo wrapper
@@ -169,23 +169,13 @@ class DotaOptimizer:
         self.time_last_it = time.time()
 
         if mq is None:
-            from .mq import MessageQueue       # needs pika; only when talking to a real broker
-            mq = MessageQueue(host=rmq_host, port=rmq_port, prefetch_count=mq_prefetch_count,
-                              use_model_exchange=self.checkpoint)
+            raise ValueError('DotaOptimizer needs the experience / model queue object: pass the reference\'s own '
+                             'MessageQueue(host, port, prefetch_count, use_model_exchange) as mq= (optimizer.py:67-174; '
+                             'the broker client is outside the hot path and is not re-implemented, INTEGRATION.md)')
         self.mq = mq
+        self.metrics_sink = metrics_sink
         self.mq.connect()
         self.upload_model(version=self.iteration_start)
-
-    # ---- checkpoint helpers (optimizer.py:287-308) -------------------------------------------------
-    @staticmethod
-    def iteration_from_model_filename(filename):
-        return int(re.search(r'(\d+)(?=.pt)', filename).group(0))
-
-    def get_latest_model(self, prefix):
-        if not os.path.isdir(prefix):
-            return None
-        fns = sorted(os.path.join(prefix, f) for f in os.listdir(prefix) if f.endswith('.pt'))
-        return fns[-1] if fns else None
 
     # ---- experience ingest ---------------------------------------------------------------------------
     def get_rollout(self):
@@ -224,7 +214,9 @@ class DotaOptimizer:
         if all(e._batch is first for e in experiences) and len(experiences) == first.n_seq and \
                 all(e._index == i for i, e in enumerate(experiences)):
             return first
-        key = (id(experiences), len(experiences))
+        # cache of the last gathered list, keyed on its CONTENT (which chunk of which batch, in order); the key's batches
+        # are kept alive with it, so an id() can never be recycled while the entry exists
+        key = tuple((id(e._batch), e._index) for e in experiences)
         if getattr(self, '_gather_key', None) == key:
             return self._gather_val
         S = self.seq_len
@@ -239,6 +231,7 @@ class DotaOptimizer:
         out.c0 = torch.cat([e.cell_state for e in experiences], dim=1).contiguous() \
             if experiences[0].cell_state is not None else None
         self._gather_key, self._gather_val = key, out
+        self._gather_refs = list({id(e._batch): e._batch for e in experiences}.values())
         return out
 
     # ---- the optimizer step ----------------------------------------------------------------------------
@@ -322,19 +315,10 @@ class DotaOptimizer:
         for it in range(self.iteration_start, self.iterations):
             metrics = self.run_iteration(it)
             logger.info('iteration %d steps_per_s=%.2f loss=%.4f', it, metrics[self.SPEED_KEY], float(metrics['loss/sum']))
+            if self.metrics_sink is not None:
+                self.metrics_sink(metrics, it)
             if self.checkpoint:
-                self._write_metrics(metrics, it)
                 self.upload_model(version=it)
-
-    def _write_metrics(self, metrics, it):
-        try:
-            from tensorboardX import SummaryWriter
-        except ImportError:
-            return
-        if self.writer is None or it % self.eventfile_refresh_freq == 0:
-            self.writer = SummaryWriter(log_dir=self.log_dir)
-        for name, metric in metrics.items():
-            self.writer.add_scalar(name, float(metric), it)
 
     def upload_model(self, version):
         """optimizer.py:697-723: rank 0 serialises state_dict() -> file + model exchange."""

@@ -38,6 +38,18 @@ const char* dc_last_error(void);
 int dc_gae_scan(const float* rewards, const float* values, const int64_t* seq_off, const int32_t* seq_len,
                 int n_seq, int max_len, double gamma, double lam, float* adv, float* ret, dc_stream_t stream);
 
+/* Replaces optimizer.py:53-54 `discount(x, gamma)` for one vector: y[t] = x[t] + gamma * y[t+1] (the reversed
+ * scipy lfilter([1],[1,-gamma]) of the reference: float32 in, float64 accumulate, float32 out).
+ *   x, y [n] f32 (device; y may alias x); n <= 40960. */
+int dc_discount(const float* x, int n, double gamma, float* y, dc_stream_t stream);
+
+/* Replaces optimizer.py:57-64 `advantage_returns(rewards, values, gamma, lam)` for ONE rollout, with the reference's
+ * own argument shapes: rewards, values [L+1] f32 (entry L is whatever the caller appended - the reference's run()
+ * appends 0, optimizer.py:417-420, but the function itself accepts any terminal reward / bootstrap value);
+ * adv, ret [L] f32 out.  L <= 20480. */
+int dc_advantage_returns(const float* rewards, const float* values, int L, double gamma, double lam, float* adv,
+                         float* ret, dc_stream_t stream);
+
 /* fp32 MFMA GEMM building block (every nn.Linear of policy.py:54-75 and its autograd products).
  *   C[M,N] (op)= A[M,K] * B[K,N] (+ bias[N]) ; a_kmajor: A stored [K][lda] else [M][lda];
  *   b_kmajor: B stored [K][ldb] else [N][ldb]; relu: max(0,.); aux/ldaux: zero where aux<=0;

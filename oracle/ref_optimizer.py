@@ -203,6 +203,33 @@ def dp_average_grads(per_rank_grads):
     return out
 
 
+def dp_train_step(policies, optimizers, shards, entropy_coef, vf_coef, e_clip=0.1, max_grad_norm=0.5):
+    """One epoch of N data-parallel ranks emulated in one process: every rank runs optimizer.py:581-672 on ITS shard
+    (own advantage normalisation, own loss means), the gradients are exchanged as distributed.py:24-57 does
+    (dp_average_grads), then every rank finishes optimizer.py:674-681 (norm metric, clip, Adam) on what it holds.
+    Returns one (parts, entropies, norms) triple per rank.  Pinned against the reference's own wrapper run under two
+    gloo ranks (tests/golden/dp2_s16.npz)."""
+    parts_all, ent_all = [], []
+    for pol, opt, chunks in zip(policies, optimizers, shards):
+        loss, parts, ent, _, _ = ppo_loss(pol, chunks, entropy_coef, vf_coef, e_clip)
+        opt.zero_grad()
+        loss.backward()
+        parts_all.append(parts); ent_all.append(ent)
+    avg = dp_average_grads([[p.grad for p in pol.parameters()] for pol in policies])
+    out = []
+    for r, (pol, opt) in enumerate(zip(policies, optimizers)):
+        params = list(pol.parameters())
+        for p, g in zip(params, avg[r]):
+            p.grad = g
+        unclipped = mean_gradient_norm(params)
+        torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
+        clipped = mean_gradient_norm(params)
+        opt.step()
+        detach = lambda d: {k: v.detach() for k, v in d.items()}
+        out.append((detach(parts_all[r]), detach(ent_all[r]), {'unclipped': unclipped, 'clipped': clipped}))
+    return out
+
+
 def make_policy(state_dict, cell='gru', hidden=256, layers=1):
     p = RefPolicy(cell, hidden, layers)
     p.load_state_dict(state_dict, strict=True)

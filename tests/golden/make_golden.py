@@ -132,6 +132,84 @@ def run_case(ref_optimizer, ref_policy, name, lengths, seq_len, epochs, lr, entr
           '%.1f KB' % (os.path.getsize(path) / 1024))
 
 
+# ---- data parallel: the reference's own wrapper (distributed.py:16-79) under two gloo ranks ---------------------------
+DP_SHARDS = [dict(lengths=[48, 64], data_seed=131, forbid_enum=()),
+             dict(lengths=[40, 32], data_seed=132, forbid_enum=(3,))]      # rank 1 never uses the ability head
+DP_CFG = dict(seq_len=16, epochs=2, lr=1e-3, entropy_coef=5e-4, vf_coef=0.5)
+
+
+def _dp_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    ref_optimizer, ref_policy = import_reference()
+    import distributed as ref_distributed
+    torch.set_num_threads(4)
+    torch.manual_seed(0)
+    opt = ref_optimizer.DotaOptimizer.__new__(ref_optimizer.DotaOptimizer)
+    opt.policy_base = ref_policy.Policy()
+    sd = synth.init_state_dict(seed=7)
+    if rank != 0:                     # sync_parameters (distributed.py:71-74) must overwrite this with rank 0's weights
+        sd = {k: v + 0.01 for k, v in sd.items()}
+    opt.policy_base.load_state_dict(sd, strict=True)
+    wrapper = ref_distributed.DistributedDataParallelSparseParamCPU(opt.policy_base)   # optimizer.py:269-270
+    opt.seq_len, opt.e_clip = DP_CFG['seq_len'], 0.1
+    opt.entropy_coef, opt.vf_coef = DP_CFG['entropy_coef'], DP_CFG['vf_coef']
+    opt.optimizer = torch.optim.Adam(wrapper.parameters(), lr=DP_CFG['lr'])
+    sh = DP_SHARDS[rank]
+    rollouts = synth.make_rollouts(sh['data_seed'], sh['lengths'], forbid_enum=sh['forbid_enum'])
+    # the rollout pass goes to policy_base: the wrapper has no init_hidden / sequence (the reference's own bug at
+    # optimizer.py:340,385 - SURVEY.md 8(c))
+    opt.policy = opt.policy_base
+    experiences = []
+    with torch.no_grad():
+        for r in rollouts:
+            experiences.extend(opt.experiences_from_rollout(data=boolify(r)))
+    opt.policy = wrapper
+    out = {'advantages': torch.stack([e.advantages for e in experiences]).numpy(),
+           'returns': torch.stack([e.returns for e in experiences]).numpy()}
+    for ep in range(DP_CFG['epochs']):
+        losses, entropies, norms = opt.train(experiences=experiences)
+        out['ep%d_losses' % ep] = np.array([float(losses[k]) for k in ('loss', 'policy_loss', 'entropy_loss', 'value_loss')], np.float64)
+        out['ep%d_entropies' % ep] = np.array([float(entropies[k]) for k in ref_policy.Policy.OUTPUT_KEYS], np.float64)
+        out['ep%d_grad_norms' % ep] = np.array([float(norms['unclipped']), float(norms['clipped'])], np.float64)
+        gs, gv, ps, pv, hg = [], [], [], [], []
+        for n, p in opt.policy_base.named_parameters():
+            hg.append(p.grad is not None)
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            s_, v_ = tensor_summary(g); gs.append(s_); gv.append(v_)
+            s_, v_ = tensor_summary(p); ps.append(s_); pv.append(v_)
+        out['ep%d_grad_summary' % ep] = np.stack(gs)
+        out['ep%d_grad_samples' % ep] = np.concatenate(gv)
+        out['ep%d_param_summary' % ep] = np.stack(ps)
+        out['ep%d_param_samples' % ep] = np.concatenate(pv)
+        out['ep%d_has_grad' % ep] = np.array(hg)
+    out['param_names'] = np.array([n for n, _ in opt.policy_base.named_parameters()])
+    np.savez(os.path.join(tmp, 'rank%d.npz' % rank), **out)
+    dist.destroy_process_group()
+
+
+def run_dp_case(name):
+    import tempfile
+    import torch.multiprocessing as mp
+    world = len(DP_SHARDS)
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_dp_worker, args=(world, 29400 + os.getpid() % 500, tmp), nprocs=world, join=True)
+        out = {'world': np.array(world), 'seq_len': np.array(DP_CFG['seq_len']), 'epochs': np.array(DP_CFG['epochs']),
+               'lr': np.array(DP_CFG['lr']), 'entropy_coef': np.array(DP_CFG['entropy_coef']), 'vf_coef': np.array(DP_CFG['vf_coef'])}
+        for r in range(world):
+            sh = DP_SHARDS[r]
+            out['r%d_lengths' % r] = np.array(sh['lengths'])
+            out['r%d_data_seed' % r] = np.array(sh['data_seed'])
+            out['r%d_forbid_enum' % r] = np.array(list(sh['forbid_enum']), dtype=np.int64)
+            for k, v in np.load(os.path.join(tmp, 'rank%d.npz' % r)).items():
+                out['r%d_%s' % (r, k)] = v
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(name, {k: out[k] for k in ('r0_ep0_losses', 'r1_ep0_losses', 'r0_ep0_has_grad', 'r1_ep0_has_grad')},
+          '%.1f KB' % (os.path.getsize(path) / 1024))
+
+
 def main():
     ref_optimizer, ref_policy = import_reference()
     torch.set_num_threads(8)
@@ -142,7 +220,16 @@ def main():
     r = (0.3 * rng.standard_normal(1025)).astype(np.float32); r[-1] = 0
     v = rng.standard_normal(1025).astype(np.float32); v[-1] = 0
     adv2, ret2 = ref_optimizer.advantage_returns(r, v, 0.98, 0.97)
-    np.savez_compressed(os.path.join(HERE, 'gae_kat.npz'), adv=adv, ret=ret, r2=r, v2=v, adv2=adv2, ret2=ret2)
+    # non-zero terminal reward / bootstrap value (the function accepts any (L+1)-vectors, optimizer.py:57-64) and
+    # `discount` on its own (optimizer.py:53-54)
+    r3 = (0.3 * rng.standard_normal(778)).astype(np.float32)
+    v3 = rng.standard_normal(778).astype(np.float32)
+    adv3, ret3 = ref_optimizer.advantage_returns(r3, v3, 0.98, 0.97)
+    x4 = rng.standard_normal(3001).astype(np.float32)
+    disc4 = ref_optimizer.discount(x4, 0.98).astype(np.float32)
+    disc4b = ref_optimizer.discount(x4[:65], 0.98 * 0.97).astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, 'gae_kat.npz'), adv=adv, ret=ret, r2=r, v2=v, adv2=adv2, ret2=ret2,
+                        r3=r3, v3=v3, adv3=adv3, ret3=ret3, x4=x4, disc4=disc4, disc4b=disc4b)
     print('gae_kat', adv, ret)
 
     common = dict(entropy_coef=5e-4, vf_coef=0.5)
@@ -151,6 +238,14 @@ def main():
     run_case(ref_optimizer, ref_policy, 'cfg1_4x128', [128, 128, 128, 128], 128, 1, 5e-5, data_seed=125, **common)
     run_case(ref_optimizer, ref_policy, 'emptyhead_s16', [40, 32], 16, 2, 5e-5, data_seed=126,
              forbid_enum=(3,), **common)
+    # the loss-coefficient branches of optimizer.py:652-663 (entropy_coef == 0 / vf_coef == 0: the term is a constant 0
+    # and - for the value head - affine_value gets no gradient at all)
+    run_case(ref_optimizer, ref_policy, 'noent_s16', [50, 64, 33], 16, 2, 5e-5, data_seed=123, entropy_coef=0.0, vf_coef=0.5)
+    run_case(ref_optimizer, ref_policy, 'novf_s16', [50, 64, 33], 16, 2, 5e-5, data_seed=123, entropy_coef=5e-4, vf_coef=0.0)
+    # BASELINE.json configs[1]'s batch (64 trajectories x 256 steps) on the reference's own network (GRU-256): the real
+    # reference at a bench-sized batch, one epoch
+    run_case(ref_optimizer, ref_policy, 'cfg2_gru_64x256', [256] * 64, 256, 1, 5e-5, data_seed=1000, **common)
+    run_dp_case('dp2_s16')
 
 
 if __name__ == '__main__':

@@ -80,6 +80,31 @@ def test_policy_forward_matches_oracle():
     assert lg['target_unit'].shape == (1, 24, 40) and v.shape == (1, 24, 1) and h.shape == (1, 1, 256)
 
 
+@pytest.mark.parametrize('cell,hidden', [('gru', 256), ('lstm', 128)])
+def test_policy_single_step_matches_oracle(cell, hidden):
+    # the actor-side entry point (policy.py:80-84, agent.py:652): B = 1, S = 1, hidden state carried by the caller
+    from dotaclient_amd.policy import Policy
+    sd = synth.init_state_dict(7, cell, hidden, 1)
+    pol = Policy(cell, hidden, 1)
+    pol.load_state_dict(sd)
+    ref = RO.make_policy(sd, cell, hidden, 1)
+    r = synth.make_rollouts(12, [6])[0]
+    hid = pol.init_hidden()
+    rhid = ref.init_hidden(1)
+    for t in range(6):
+        obs_t = {k: r['observations'][k][t] for k in L.INPUT_KEYS}
+        lg, v, hid = pol.single(**{k: x.cuda() for k, x in obs_t.items()}, hidden=hid)
+        with torch.no_grad():
+            rl, rv, rhid = ref({k: x[None, None] for k, x in obs_t.items()}, rhid)
+        for k in L.OUTPUT_KEYS:
+            assert lg[k].shape == rl[k].shape == (1, 1, L.HEAD_COUNTS[k])
+            assert util.scaled_err(lg[k].cpu().numpy(), rl[k].numpy()) < 1e-5, (t, k)
+        assert v.shape == (1, 1, 1) and util.scaled_err(v.cpu().numpy(), rv.numpy()) < 1e-5
+        h_got = hid if cell == 'gru' else hid[0]
+        h_ref = rhid if cell == 'gru' else rhid[0]
+        assert h_got.shape == (1, 1, hidden) and util.scaled_err(h_got.cpu().numpy(), h_ref.numpy()) < 1e-5
+
+
 @pytest.mark.parametrize('case', ['ragged_s16', 'clip_s16'])
 def test_optimizer_surface_matches_golden(case, tmp_path):
     g, rollouts = util.load_case(case)

@@ -55,6 +55,29 @@ def test_gae_scan_golden_vector():
     assert np.array_equal(adv.cpu().numpy(), g['adv2']) and np.array_equal(ret.cpu().numpy(), g['ret2'])
 
 
+def test_discount_and_advantage_returns_any_terminals():
+    # optimizer.py:53-64 with the reference's own signatures: non-zero terminal reward / bootstrap value, `discount` on its
+    # own - bit-exact against vectors produced by the real reference (gae_kat.npz) and against the oracle on other lengths
+    from dotaclient_amd.optimizer import advantage_returns, discount
+    _dev()
+    g = np.load(util.GOLDEN + '/gae_kat.npz')
+    adv, ret = advantage_returns(g['r3'], g['v3'], 0.98, 0.97)
+    assert adv.dtype == np.float32 and adv.shape == (g['r3'].size - 1,)
+    assert np.array_equal(adv, g['adv3']) and np.array_equal(ret, g['ret3'])
+    assert np.array_equal(discount(g['x4'], 0.98), g['disc4'])
+    assert np.array_equal(discount(g['x4'][:65], 0.98 * 0.97), g['disc4b'])
+    rng = np.random.Generator(np.random.PCG64(11))
+    for n in (2, 3, 64, 65, 129, 1000, 20001):
+        r = (0.3 * rng.standard_normal(n)).astype(np.float32)
+        v = rng.standard_normal(n).astype(np.float32)
+        a, t = advantage_returns(r, v, 0.98, 0.97)
+        ea, et = RO.advantage_returns(r, v, 0.98, 0.97)
+        assert np.array_equal(a, ea) and np.array_equal(t, et), n
+        assert np.array_equal(discount(r, 0.9), RO.discount(r, 0.9)), n
+    assert advantage_returns(np.zeros(1, np.float32), np.zeros(1, np.float32), 0.98, 0.97)[0].shape == (0,)
+    assert discount(np.zeros(0, np.float32), 0.98).shape == (0,)
+
+
 @pytest.mark.parametrize('akm,bkm', [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize('M,N,K', [(64, 64, 32), (200, 154, 256), (1000, 256, 896), (130, 70, 154), (768, 256, 5000),
                                    (33, 12, 7), (2048, 768, 256)])

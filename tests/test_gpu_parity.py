@@ -92,8 +92,11 @@ def compare(out, ref, n_ep, names_ref, tol=TOL):
         assert util.rel_err(pn, rpn) < tol
 
 
-@pytest.mark.parametrize('case', util.CASES)
+@pytest.mark.parametrize('case', util.CASES + util.BIG_CASES)
 def test_hip_matches_reference_golden(case):
+    # incl. the entropy_coef == 0 / vf_coef == 0 branches (optimizer.py:652-663: affine_value then has no gradient and is
+    # not stepped) and cfg2_gru_64x256 = the REAL reference on BASELINE.json configs[1]'s batch (64 trajectories x 256
+    # steps, GRU-256): default kernel selection - team kernels, fused embedding forward, sparse max-pool backward
     g, rollouts = util.load_case(case)
     out, eng = run_hip(g, rollouts)
     compare(out, g, int(g['epochs']), g['param_names'])
@@ -111,6 +114,23 @@ def test_hip_matches_oracle_other_cells(cell, hidden, layers):
     out, _ = run_hip(g, rollouts, cell, hidden, layers, epochs=2)
     ref.pop('hidden', None); out.pop('hidden', None)
     compare(out, ref, 2, ref['param_names'])
+
+
+@pytest.mark.parametrize('cell,hidden,B', [('lstm', 128, 64), ('lstm', 256, 256)])
+def test_hip_matches_oracle_at_baseline_configs(cell, hidden, B):
+    # BASELINE.json configs[1] (LSTM-128, 64 x 256) and configs[2] (LSTM-256, 256 x 256) - the very batches bench.py
+    # times (same seed) - against the oracle run live (about 4 s / 25 s of CPU), one epoch, with the DEFAULT kernel
+    # selection: persistent VALU LSTM / team kernels with four sequences in flight, fused embedding forward, sparse
+    # max-pool backward over many tiles.  Advantages, returns, values, old log-probs, losses, entropies, gradient norms,
+    # clipped gradients, post-step parameters < 1e-4; masked argmax bit-exact.
+    S = 256
+    g = {'seq_len': S, 'lr': 5e-5, 'entropy_coef': 5e-4, 'vf_coef': 0.5, 'epochs': 1}
+    rollouts = synth.make_rollouts(1000, [S] * B)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref, _, _ = util.oracle_run(g, rollouts, cell, hidden, 1, epochs=1)
+    out, _ = run_hip(g, rollouts, cell, hidden, 1, epochs=1)
+    out.pop('hidden', None)
+    compare(out, ref, 1, ref['param_names'])
 
 
 @pytest.mark.parametrize('variant', ['mfma', 'valu'])

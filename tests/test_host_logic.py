@@ -74,6 +74,52 @@ def test_pack_rollouts_matches_flatten_and_reuses_staging():
         assert b.rows == r0
 
 
+def test_staging_is_one_growing_pair_not_one_per_batch_size():
+    # the consumer loop's row count changes almost every iteration: the page-locked staging must not accumulate a pair of
+    # buffers per distinct size - one double-buffered pair, grown geometrically, a batch uses its leading rows
+    from dotaclient_amd import engine as E
+    dev = torch.device('cpu')
+    E._Staging._sets.pop(False, None)
+    caps = []
+    for seed, lens in enumerate([[16], [48, 16], [32], [200, 40], [64], [16, 16, 16], [500], [16]]):
+        rollouts = synth.make_rollouts(40 + seed, lens)
+        b = E.pack_rollouts(rollouts, 16, dev)
+        assert b.rows == sum((t + 15) // 16 * 16 for t in lens) and b.obs.shape[0] == b.rows
+        o, a, m, r = synth.flatten_rollout(rollouts[0])
+        assert np.array_equal(b.obs[:lens[0]].numpy(), o) and np.array_equal(b.mask[:lens[0]].numpy(), m)
+        sets = E._Staging._sets[False]
+        assert len(sets) == 2
+        caps.append(sorted(st.capacity for st in sets if st is not None))
+    assert max(caps[-1]) >= 512 and len(E._Staging._sets) == 1          # still exactly one pair
+    assert all(c >= p for p, c in zip(caps[1:-1:2], caps[3::2]))          # capacities only ever grow
+
+
+def test_gather_cache_is_keyed_on_content_not_on_list_identity():
+    # a cache keyed on id(list) returns the PREVIOUS iteration's batch when CPython recycles the address of a
+    # freed same-length list.  _gather's key is the (batch, chunk index) sequence, and the keyed batches are kept alive.
+    from dotaclient_amd.optimizer import DotaOptimizer, Sequence
+    from dotaclient_amd.engine import PackedBatch
+
+    def fake_batch(fill):
+        t = lambda w, dt=torch.float32: torch.full((32, w), fill, dtype=dt)
+        b = PackedBatch(t(483), t(65, torch.uint8), t(65, torch.uint8), t(10), torch.tensor([0, 16]), torch.tensor([16, 16], dtype=torch.int32), 16)
+        b.old_logp, b.values, b.adv, b.ret = t(5), t(1)[:, 0], t(1)[:, 0], t(1)[:, 0]
+        return b
+
+    opt = DotaOptimizer.__new__(DotaOptimizer)
+    opt.seq_len, opt.device = 16, torch.device('cpu')
+    h = torch.zeros(1, 1, 256)
+    outs = []
+    for fill in (1.0, 2.0, 3.0):                    # a fresh same-length list each "iteration", the old one freed
+        b = fake_batch(fill)
+        exps = [Sequence('g', 1, 2, b, 1, 16, h), Sequence('g', 1, 2, b, 0, 16, h)]     # reordered: takes the slow path
+        outs.append(float(opt._gather(exps).obs[0, 0]))
+        again = opt._gather(list(exps))              # same content, another list object: served from the cache
+        assert again is opt._gather_val
+        del exps, b
+    assert outs == [1.0, 2.0, 3.0]
+
+
 def test_pack_rollouts_accepts_what_the_wire_may_carry():
     # the actors send torch tensors (agent.py:406-416); numpy arrays, bool masks (the oracle's form), non-contiguous
     # views and float64 observations must come out the same bytes - dc_pack_rows only sees contiguous f32 / u8

@@ -20,7 +20,36 @@ def test_gae_golden_bit_exact():
     assert np.array_equal(adv, g['adv2']) and np.array_equal(ret, g['ret2'])
 
 
-@pytest.mark.parametrize('case', util.CASES)
+def test_gae_golden_nonzero_terminals_and_discount():
+    # optimizer.py:53-64 accept any vectors: terminal reward / bootstrap value != 0, and discount on its own
+    g = np.load(util.GOLDEN + '/gae_kat.npz')
+    adv, ret = RO.advantage_returns(g['r3'], g['v3'], 0.98, 0.97)
+    assert g['r3'][-1] != 0 and g['v3'][-1] != 0
+    assert np.array_equal(adv, g['adv3']) and np.array_equal(ret, g['ret3'])
+    assert np.array_equal(RO.discount(g['x4'], 0.98), g['disc4'])
+    assert np.array_equal(RO.discount(g['x4'][:65], 0.98 * 0.97), g['disc4b'])
+
+
+def test_oracle_dp_emulation_matches_reference_wrapper():
+    # the N-rank emulation (RO.dp_train_step / dp_average_grads) against the reference's own
+    # DistributedDataParallelSparseParamCPU (distributed.py:16-79) run under two gloo ranks by make_golden.py; rank 1
+    # never uses the ability head, so its has-grad count is 1 and rank 1 keeps grad = None for it
+    g, shards = util.load_dp_case()
+    out = util.oracle_dp_run(g, shards)
+    for r in range(int(g['world'])):
+        for key in ('advantages', 'returns'):
+            assert util.scaled_err(out['r%d_%s' % (r, key)], g['r%d_%s' % (r, key)]) < 1e-5
+        for ep in range(int(g['epochs'])):
+            pre = 'r%d_ep%d_' % (r, ep)
+            for key in ('losses', 'entropies', 'grad_norms'):
+                assert util.rel_err(out[pre + key], g[pre + key]) < 2e-5, (pre + key, out[pre + key], g[pre + key])
+            assert np.array_equal(out[pre + 'has_grad'], g[pre + 'has_grad'])
+            assert util.scaled_err(out[pre + 'grad_samples'], g[pre + 'grad_samples']) < 1e-4
+            assert util.scaled_err(out[pre + 'param_samples'], g[pre + 'param_samples']) < 1e-5
+    assert not g['r1_ep0_has_grad'].all() and g['r0_ep0_has_grad'].all()
+
+
+@pytest.mark.parametrize('case', util.CASES + util.BIG_CASES)
 def test_oracle_matches_reference(case):
     g, rollouts = util.load_case(case)
     out, _, _ = util.oracle_run(g, rollouts)

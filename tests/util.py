@@ -8,7 +8,8 @@ from dotaclient_amd import synth
 from oracle import ref_optimizer as RO
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CASES = ['ragged_s16', 'clip_s16', 'cfg1_4x128', 'emptyhead_s16']
+CASES = ['ragged_s16', 'clip_s16', 'cfg1_4x128', 'emptyhead_s16', 'noent_s16', 'novf_s16']
+BIG_CASES = ['cfg2_gru_64x256']        # the real reference at a BASELINE.json batch (64 trajectories x 256 steps), 1 epoch
 SAMPLE_STRIDE = 251
 
 
@@ -74,3 +75,41 @@ def oracle_run(g, rollouts, cell='gru', hidden=256, layers=1, epochs=None):
         out['ep%d_has_grad' % ep] = np.array(hg)
     out['param_names'] = np.array([n for n, _ in pol.named_parameters()])
     return out, pol, chunks
+
+
+def load_dp_case(name='dp2_s16'):
+    """Fixture of the reference's own DP wrapper under gloo (make_golden.py::run_dp_case): returns the fixture and the
+    per-rank rollouts."""
+    g = dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
+    shards = [synth.make_rollouts(int(g['r%d_data_seed' % r]), [int(x) for x in g['r%d_lengths' % r]],
+                                  forbid_enum=tuple(int(x) for x in g['r%d_forbid_enum' % r])) for r in range(int(g['world']))]
+    return g, shards
+
+
+def oracle_dp_run(g, shards):
+    """The oracle's N-rank emulation (RO.dp_train_step) on a DP fixture's inputs; dict shaped like the fixture."""
+    world, S = int(g['world']), int(g['seq_len'])
+    sd = synth.init_state_dict(7)
+    pols = [RO.make_policy(sd) for _ in range(world)]
+    opts = [torch.optim.Adam(p.parameters(), lr=float(g['lr'])) for p in pols]
+    chunk_shards = [[c for r in sh for c in RO.rollout_pass(pol, r, S)] for pol, sh in zip(pols, shards)]
+    out = {}
+    for r in range(world):
+        out['r%d_advantages' % r] = torch.stack([c.advantages for c in chunk_shards[r]]).numpy()
+        out['r%d_returns' % r] = torch.stack([c.returns for c in chunk_shards[r]]).numpy()
+    for ep in range(int(g['epochs'])):
+        res = RO.dp_train_step(pols, opts, chunk_shards, float(g['entropy_coef']), float(g['vf_coef']))
+        for r, (parts, ent, norms) in enumerate(res):
+            pre = 'r%d_ep%d_' % (r, ep)
+            out[pre + 'losses'] = np.array([float(parts[k]) for k in ('loss', 'policy_loss', 'entropy_loss', 'value_loss')])
+            out[pre + 'entropies'] = np.array([float(ent[k]) for k in RO.HEADS])
+            out[pre + 'grad_norms'] = np.array([float(norms['unclipped']), float(norms['clipped'])])
+            gv, pv, hg = [], [], []
+            for n, p in pols[r].named_parameters():
+                hg.append(p.grad is not None)
+                gr = p.grad if p.grad is not None else torch.zeros_like(p)
+                gv.append(tensor_summary(gr)[1]); pv.append(tensor_summary(p)[1])
+            out[pre + 'grad_samples'] = np.concatenate(gv)
+            out[pre + 'param_samples'] = np.concatenate(pv)
+            out[pre + 'has_grad'] = np.array(hg)
+    return out

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box visit: parity tests, bench line, rocprofv3 kernel stats, HBM-traffic PMC passes.
-# Usage (from the repo root on the GPU box): [BENCH_ARGS='--cell gru --hidden 256' WORKLOAD=gru-256-64x256] bash tools/gpu_round.sh <tag> [skip_tests]
+# Usage (from the repo root on the GPU box; default workload = bench.py's default, BASELINE.json configs[2]): [BENCH_ARGS='--cell gru --hidden 256 --batch 64' WORKLOAD=gru-256-64x256] bash tools/gpu_round.sh <tag> [skip_tests]
 TAG=${1:-vX}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -11,16 +11,16 @@ if [ -z "$2" ]; then
   echo "pytest exit $?" >> $OUT/pytest_gpu.log
   tail -3 $OUT/pytest_gpu.log
 fi
-WORKLOAD=${WORKLOAD:-lstm-128-64x256}
+WORKLOAD=${WORKLOAD:-lstm-256-256x256}
 timeout 600 python bench.py $BENCH_ARGS > $OUT/bench.json 2> $OUT/bench.err
 tail -c 1500 $OUT/bench.json
 # kernel-trace + stats of the same command (short: no CPU baseline inside the traced run)
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/$OUT/prof -o trace -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-extras $BENCH_ARGS > $REPO/$OUT/prof_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/$OUT/prof -o trace -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-host-extras $BENCH_ARGS > $REPO/$OUT/prof_bench.log 2>&1
 # PMC passes, each on its own (no trace domains besides kernel-trace)
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $REPO/$OUT/pmc_fetch -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-extras $BENCH_ARGS > $REPO/$OUT/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $REPO/$OUT/pmc_write -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-extras $BENCH_ARGS > $REPO/$OUT/pmc_write.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $REPO/$OUT/pmc_sq -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-extras $BENCH_ARGS > $REPO/$OUT/pmc_sq.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $REPO/$OUT/pmc_fetch -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-host-extras $BENCH_ARGS > $REPO/$OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $REPO/$OUT/pmc_write -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-host-extras $BENCH_ARGS > $REPO/$OUT/pmc_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $REPO/$OUT/pmc_sq -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-host-extras $BENCH_ARGS > $REPO/$OUT/pmc_sq.log 2>&1
 cd $REPO
 python tools/pmc_sq.py $OUT/pmc_sq $OUT/pmc_sq.json > $OUT/pmc_sq.txt 2>&1
 DB=$(find $OUT/prof -name '*.db' | head -1)
