@@ -211,6 +211,8 @@ BOUND_NOTES = {
                'between the four CUs that share a sequence), not by arithmetic or HBM',
     'hbm': 'streams its operands once: priced against the 8 TB/s HBM peak',
 }
+KERNEL_FLAGS = 0      # --kernel-flags: DC_DIMS_* kernel-selection overrides for A/B runs (include/dotaclient_hip.h)
+USE_GRAPHS = False    # --epoch-graph: replay every epoch as one hipGraph launch (Engine.train_epoch(graph=True))
 MASK_DEPENDENT_BYTES = ('attn_logits', 'attn_bwd_q')   # mask-aware: bytes moved depend on the masks; the host-side figure is the dense form
 
 
@@ -219,6 +221,8 @@ def run_workload(cell, hidden, layers, B, S, E, steps, warmup, dev, rank, world,
     """Builds an engine + a resident batch, runs warmup + `steps` timed iterations; returns a dict of raw results."""
     lr, ent, vf = 5e-5, 5e-4, 0.5
     eng = Engine(cell, hidden, layers, dev)
+    eng.kernel_flags = KERNEL_FLAGS
+    eng.use_graphs = USE_GRAPHS
     eng.load_state_dict(synth.init_state_dict(7, cell, hidden, layers))
     hook = hook_factory(eng) if hook_factory is not None else None
     if hook is not None:
@@ -293,10 +297,17 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip the configs[1] / GRU-256 / weak-scaling-unit side measurements')
     ap.add_argument('--no-host-extras', action='store_true',
                     help='skip the ingest / publish timings (hundreds of small copies that would pollute a kernel trace)')
+    ap.add_argument('--kernel-flags', type=int, default=0, help='DC_DIMS_* kernel-selection overrides (A/B measurements)')
+    ap.add_argument('--epoch-graph', type=int, default=-1,
+                    help='1: replay each epoch as ONE hipGraph launch, 0: eager launches; default: eager for the timed line, and the '
+                         'other mode is timed beside it (`epoch_graph` in the JSON)')
     ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'pmc_traffic_latest.json'),
                     help='per-kernel HBM bytes from the rocprofv3 PMC passes (tools/gpu_round.sh + tools/pmc_traffic.py); '
                          'PMC counters cannot be read from inside the process, so `traffic` is taken from this file')
     args = ap.parse_args()
+    global KERNEL_FLAGS, USE_GRAPHS
+    KERNEL_FLAGS = args.kernel_flags
+    USE_GRAPHS = args.epoch_graph == 1
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -369,6 +380,19 @@ def main():
                     samples[name].append((time.perf_counter() - t0) * 1e3)
         publish_ms = {k: round(float(np.median(v)), 3) for k, v in samples.items()}
 
+    # ---- the same workload with each epoch replayed as one hipGraph launch (or eagerly, if the timed line used graphs) -----
+    epoch_graph = None
+    if world == 1 and args.epoch_graph == -1 and not args.no_secondary:
+        USE_GRAPHS = True
+        r = run_workload(args.cell, args.hidden, args.layers, B, S, E, args.steps, args.warmup, dev, rank, world)
+        USE_GRAPHS = False
+        epoch_graph = {'eager_ms_per_step': round(elapsed / args.steps * 1e3, 3), 'graph_replay_ms_per_step': round(r['elapsed'] / args.steps * 1e3, 3),
+                       'timed_line_uses': 'eager',
+                       'note': 'Engine.train_epoch(graph=True): the ~45 launches / memsets / copies of an epoch captured once and replayed as '
+                               'ONE hipGraph launch (the rollout pass stays eager); same kernels, same order'}
+        del r
+        torch.cuda.empty_cache()
+
     # ---- side measurements at N = 1: the other BASELINE.json single-GPU configurations and the weak-scaling unit --------
     secondary = None
     if world == 1 and default_family and not args.no_secondary:
@@ -378,7 +402,6 @@ def main():
                                                         'no all-reduce: the N = 1 reference point for the N > 1 lines of this script'),
                 'configs[1]': ('lstm', 128, 64, 'BASELINE.json configs[1]: 1v1-mid, LSTM-128, 64 trajectories x 256 steps'),
                 'reference_gru256_64x256': ('gru', 256, 64, "configs[1]'s batch on the reference's own cell (GRU-256, policy.py:66)")}.items():
-            main_run['eng'] = None
             r = run_workload(c, h, 1, b, S, E, args.steps, args.warmup, dev, rank, world)
             secondary[key] = {'workload': what, 'value': round(b * S * args.steps / r['elapsed'], 1), 'unit': 'env-steps/s',
                               'ms_per_step': round(r['elapsed'] / args.steps * 1e3, 3), 'nan_status': r['status']}
@@ -464,6 +487,7 @@ def main():
             'roofline_hbm': roofline_hbm,
             'nan_status': status, 'final_loss': float(losses[0]),
             'secondary': secondary,
+            'epoch_graph': epoch_graph,
             'ingest': None if ingest_ms is None else {
                        'pack_h2d_ms_per_batch': round(ingest_ms, 3),
                        'env_steps_per_s_with_ingest_serialised': round(B * S / (elapsed / args.steps + ingest_ms * 1e-3), 1),

@@ -24,14 +24,14 @@ SIGNATURES = {
     'dc_discount': (c_int, [c_ptr, c_int, c_dbl, c_ptr, c_ptr]),
     'dc_advantage_returns': (c_int, [c_ptr, c_ptr, c_int, c_dbl, c_dbl, c_ptr, c_ptr, c_ptr]),
     'dc_gemm_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                            c_ptr, c_int, c_ptr, c_int, c_int, c_int, c_ptr]),
-    'dc_gemm_set_scratch': (None, [c_ptr, c_i64]),
+                            c_ptr, c_int, c_ptr, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
     'dc_dp_average_grads': (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_flt, c_ptr]),
     'dc_pack_rows': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int]),
     'dc_profile_enable': (c_int, [c_int]),
     'dc_profile_report': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int]),
     'dc_workspace_layout': (c_i64, [c_ptr, c_ptr]),
     'dc_policy_forward': (c_int, [c_ptr] * 12),
+    'dc_chunk_initial_state': (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr]),
     'dc_select_logp': (c_int, [c_ptr] * 8),
     'dc_ppo_loss_fwd_bwd': (c_int, [c_ptr] * 9 + [c_flt, c_flt, c_flt, c_ptr]),
     'dc_policy_backward': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),

@@ -60,13 +60,11 @@ int dc_advantage_returns(const float* rewards, const float* values, int L, doubl
 
 int dc_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                 int a_kmajor, int b_kmajor, const float* bias, int relu, const float* aux, int ldaux,
-                int accumulate, int splits, dc_stream_t stream) {
+                int accumulate, int splits, float* scratch, int64_t scratch_floats, dc_stream_t stream) {
     DC_ENTER();
     return dc::gemm_f32(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, bias, relu, aux, ldaux, accumulate,
-                        splits, (hipStream_t)stream);
+                        splits, (hipStream_t)stream, dc::GemmScratch{scratch, (long long)scratch_floats});
 }
-
-void dc_gemm_set_scratch(float* scratch, int64_t floats) { dc::gemm_set_scratch(scratch, (long long)floats); }
 
 int64_t dc_workspace_layout(const dc_dims* dims, int64_t* offsets) { return dc::workspace_layout(dims, offsets); }
 
@@ -81,6 +79,23 @@ static float* ws_f(const dc_dims* dims, const void* ws, int idx) {
     int64_t off[DC_WS_FIXED + DC_WS_PER_LAYER * DC_MAX_LAYERS];
     dc::workspace_layout(dims, off);
     return reinterpret_cast<float*>((char*)ws + off[idx]);
+}
+
+int dc_chunk_initial_state(const dc_dims* dims, const void* ws, const int64_t* prev_row, int n_chunks, float* h0, float* c0,
+                           dc_stream_t stream) {
+    DC_ENTER();
+    if (dims->layers < 1 || dims->layers > DC_MAX_LAYERS) { dc::set_error("chunk_initial_state: layers out of range", 1020); return 1020; }
+    for (int l = 0; l < dims->layers; ++l) {
+        const int b = DC_WS_FIXED + l * DC_WS_PER_LAYER;
+        if (int e = dc::rnn_gather_state(ws_f(dims, ws, b + DC_WSL_HSEQ), prev_row, h0 + (size_t)l * n_chunks * dims->hidden, n_chunks,
+                                         dims->hidden, (hipStream_t)stream))
+            return e;
+        if (dims->cell == 1 && c0 != nullptr)
+            if (int e = dc::rnn_gather_state(ws_f(dims, ws, b + DC_WSL_CSEQ), prev_row, c0 + (size_t)l * n_chunks * dims->hidden, n_chunks,
+                                             dims->hidden, (hipStream_t)stream))
+                return e;
+    }
+    return 0;
 }
 
 int dc_select_logp(const dc_dims* dims, const void* ws, const uint8_t* act, const uint8_t* mask, float* logp_sel,

@@ -4,6 +4,15 @@
 #include <stdint.h>
 
 #define DC_WAVE 64
+// Developer builds only (python -m dotaclient_amd.build with DC_BUILD_VARIANT=timing DC_BUILD_FLAGS=-DDC_DEV_TIMING=1): the
+// phase-cycle instrumentation of the persistent kernels (extra kernel instantiations, a blocking read-back and a line on
+// stderr per launch).  The shipped library compiles it out; nothing on the call path reads the environment.
+#ifndef DC_DEV_TIMING
+#define DC_DEV_TIMING 0
+#endif
+#ifndef DC_DEV_HOOKMODE
+#define DC_DEV_HOOKMODE 0
+#endif
 
 namespace dc {
 

@@ -545,7 +545,7 @@ int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const fl
     const int tiles = (int)(nr * 40 / EF_TILE);
     const int grid = tiles < 512 ? tiles : 512;      // two resident workgroups per CU
     ProfScope prof("embed_fwd_fused", 2.0 * nr * 40 * 128 * (128 + 12), 4.0 * nr * 40 * (12 + 128), s);
-    static const bool timing = [] { const char* e = getenv("DC_EF_TIMING"); return e && e[0] == '1'; }();
+    constexpr bool timing = DC_DEV_TIMING != 0;
     if (timing) {   // debugging aid: mean per-tile phase cycles (wave 0 of each workgroup), printed per launch
         static bool attr2 = false;
         if (int e = set_lds(embed_fwd_fused_kernel<true>, lds, &attr2)) return e;

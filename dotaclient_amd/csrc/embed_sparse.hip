@@ -464,7 +464,7 @@ int embed_bwd_pool16(const float* obs, const float* dxcat, const uint8_t* amax, 
     // algorithmic work: basic + dW1 fold 2 x 16 x 128 x 12 MACs, the two gathers 2 x 128 x 128 MACs per step and type
     ProfScope prof("embed_bwd_pool16", 2.0 * 2.0 * nr * (2.0 * 16 * 128 * 12 + 2.0 * 128 * 128),
                    4.0 * 2.0 * nr * (16 * 12 + 3 * 128 + 16 + 32), s);
-    static const bool timing = [] { const char* e = getenv("DC_SP_TIMING"); return e && e[0] == '1'; }();
+    constexpr bool timing = DC_DEV_TIMING != 0;
     if (timing) {   // debugging aid: per-step phase cycles of one wave, printed per launch
         static long long* dbg = nullptr;
         if (!dbg) (void)hipMalloc(&dbg, 8 * 6 * sizeof(long long));

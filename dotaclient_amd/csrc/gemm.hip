@@ -422,10 +422,6 @@ int splitk_reduce(const float* slab, float* C, int M, int N, int ldc, int splits
     return launch_check("splitk_reduce");
 }
 
-static float* g_scratch = nullptr;
-static long long g_scratch_floats = 0;
-void gemm_set_scratch(float* p, long long floats) { g_scratch = p; g_scratch_floats = floats; }
-
 template <int BM, int BN, bool A_KM, bool B_KM>
 static int launch_gemm(const GemmArgs& a, int splits, hipStream_t stream) {
     using LA = TileLoader<BM, A_KM>;
@@ -511,7 +507,7 @@ static int dispatch_fast(const GemmArgs& a, int splits, hipStream_t stream) {
 // grid alone cannot fill 256 CUs, i.e. for the weight-gradient products with K = rows).
 int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
              int a_kmajor, int b_kmajor, const float* bias, int relu, const float* aux, int ldaux,
-             int accumulate, int splits, hipStream_t stream) {
+             int accumulate, int splits, hipStream_t stream, GemmScratch sc) {
     if (M <= 0 || N <= 0) return 0;
     GemmArgs a;
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux;
@@ -549,8 +545,8 @@ int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int 
             set_error("gemm_f32: relu/mask epilogue is incompatible with split-K", 1003);
             return 1003;
         }
-        if (g_scratch != nullptr && (long long)splits * M * N <= g_scratch_floats) {
-            a.slab = g_scratch;
+        if (sc.p != nullptr && (long long)splits * M * N <= sc.floats) {
+            a.slab = sc.p;
         } else {
             if (!accumulate) {
                 // split-K accumulates with atomics: start from zero
@@ -588,7 +584,7 @@ int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int 
 // share their A operand; as one product they are one launch of ~256 workgroups and one reduction instead of two each.
 // Falls back to two gemm_f32 calls when the shapes do not fit (N1, N2 multiples of 128, M of 64, scratch large enough).
 int gemm_f32_tn_pair(const float* A, int lda, const float* B1, int ldb1, int N1, const float* B2, int ldb2, int N2, float* C1,
-                     int ldc1, float* C2, int ldc2, int M, int K, hipStream_t stream) {
+                     int ldc1, float* C2, int ldc2, int M, int K, hipStream_t stream, GemmScratch sc) {
     const int N = N1 + N2;
     const long wgs = (long)(M / 64) * (N / 128);
     long want = wgs > 0 ? 256 / wgs : 1;
@@ -596,23 +592,23 @@ int gemm_f32_tn_pair(const float* A, int lda, const float* B1, int ldb1, int N1,
     if (wgs * want < 192 && wgs > 0) want = 512 / wgs;
     const long maxs = K / 512;
     int splits = (int)(want < maxs ? want : maxs);
-    bool ok = (M % 64) == 0 && (N1 % 128) == 0 && (N2 % 128) == 0 && (K % GEMM_BK) == 0 && splits >= 2 && g_scratch != nullptr &&
+    bool ok = (M % 64) == 0 && (N1 % 128) == 0 && (N2 % 128) == 0 && (K % GEMM_BK) == 0 && splits >= 2 && sc.p != nullptr &&
               !(lda & 3) && !(ldb1 & 3) && !(ldb2 & 3) && aligned16(A) && aligned16(B1) && aligned16(B2);
     int kper = 0;
     if (ok) {
         kper = (K + splits - 1) / splits;
         kper = (kper + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
         splits = (K + kper - 1) / kper;
-        ok = (long long)splits * M * N <= g_scratch_floats;
+        ok = (long long)splits * M * N <= sc.floats;
     }
     if (!ok) {
-        if (int e = gemm_f32(A, B1, C1, M, N1, K, lda, ldb1, ldc1, 1, 1, nullptr, 0, nullptr, 0, 1, 0, stream)) return e;
-        return gemm_f32(A, B2, C2, M, N2, K, lda, ldb2, ldc2, 1, 1, nullptr, 0, nullptr, 0, 1, 0, stream);
+        if (int e = gemm_f32(A, B1, C1, M, N1, K, lda, ldb1, ldc1, 1, 1, nullptr, 0, nullptr, 0, 1, 0, stream, sc)) return e;
+        return gemm_f32(A, B2, C2, M, N2, K, lda, ldb2, ldc2, 1, 1, nullptr, 0, nullptr, 0, 1, 0, stream, sc);
     }
     GemmArgs a;
     a.A = A; a.B = B1; a.C = C1; a.bias = nullptr; a.aux = nullptr;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb1; a.ldc = ldc1; a.ldaux = 0;
-    a.relu = 0; a.accumulate = 0; a.atomic = 0; a.k_per_split = kper; a.slab = g_scratch;
+    a.relu = 0; a.accumulate = 0; a.atomic = 0; a.k_per_split = kper; a.slab = sc.p;
     a.B2 = B2; a.ldb2 = ldb2; a.n_split = N1;
     ProfScope prof("gemm_f32_dW(TN,split-K)", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), stream);
     if (int e = launch_fast<64, 128, true, true, EPI_SLAB, false>(a, splits, stream)) return e;

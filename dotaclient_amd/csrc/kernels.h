@@ -1,5 +1,6 @@
 // Internal prototypes shared by the translation units of libdotaclient_hip.so.
 #pragma once
+#include "../../include/dotaclient_hip.h"   // dc_dims, DC_DIMS_* flags, workspace ids
 #include "common.h"
 
 namespace dc {
@@ -8,6 +9,8 @@ struct RnnStepArgs {
     const int64_t* seq_off;
     const int32_t* seq_len;
     int n_seq, H, t;
+    int flags;             // dc_dims.flags (DC_DIMS_* kernel-selection overrides)
+    void* xbuf;            // DC_WS_TEAM_XBUF: exchange ring of the H = 256 team kernels (caller workspace)
     // forward
     const float* Whh;      // [G*H][H]
     const float* bhh;      // [G*H]
@@ -45,12 +48,14 @@ int discount(const float* x, int n, double gamma, float* y, hipStream_t stream);
 int advantage_returns(const float* rewards, const float* values, int L, double gamma, double lam, float* adv, float* ret,
                       hipStream_t stream);
 // gemm.hip
+// split-K partial slabs of ONE call (reduced by a second kernel); p == nullptr -> fp32 atomics.  Passed per call: the
+// library keeps no scratch pointer of its own (two callers on two streams never share one)
+struct GemmScratch { float* p = nullptr; long long floats = 0; };
 int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kmajor,
              int b_kmajor, const float* bias, int relu, const float* aux, int ldaux, int accumulate, int splits,
-             hipStream_t stream);
+             hipStream_t stream, GemmScratch sc = GemmScratch());
 int gemm_f32_tn_pair(const float* A, int lda, const float* B1, int ldb1, int N1, const float* B2, int ldb2, int N2, float* C1,
-                     int ldc1, float* C2, int ldc2, int M, int K, hipStream_t stream);   // [C1 | C2] = A^T [B1 | B2], one launch
-void gemm_set_scratch(float* p, long long floats);   // split-K slabs (nullptr -> atomics)
+                     int ldc1, float* C2, int ldc2, int M, int K, hipStream_t stream, GemmScratch sc);   // [C1 | C2] = A^T [B1 | B2], one launch
 int splitk_reduce(const float* slab, float* C, int M, int N, int ldc, int splits, hipStream_t s);   // C = sum_z slab[z]
 // n_groups (<= 8) independent reductions in one launch: C[g] (dense M x N) = sum of slabs [begin[g], begin[g+1])
 int splitk_reduce_grouped(const float* slab, float* C, int M, int N, int n_groups, const int* begin, hipStream_t s);
@@ -100,7 +105,8 @@ int rnn_seed_state(const float* h0, float* hprev, const int64_t* seq_off, const 
                    hipStream_t s);
 int rnn_final_state(const float* hseq, float* hT, const int64_t* seq_off, const int32_t* seq_len, int n_seq, int H,
                     hipStream_t s);
-bool rnn_uses_persistent(int cell, int H);   // register-resident LSTM kernels: W_hh^T is not needed
+int rnn_gather_state(const float* seq, const int64_t* prev_row, float* out, int n, int H, hipStream_t s);
+bool rnn_uses_persistent(int cell, int H, int flags);   // register-resident LSTM kernels: W_hh^T is not needed
 int rnn_forward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s);
 int rnn_backward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s);
 // rnn_persist.hip (LSTM, H <= 128: all time steps in one launch, W_hh register-resident)
@@ -109,12 +115,13 @@ int lstm_forward_persist(RnnStepArgs a, int max_len, hipStream_t s);
 int lstm_backward_persist(RnnStepArgs a, int max_len, hipStream_t s);
 // rnn_persist_valu.hip (same contract, one sequence per workgroup on the packed-f32 VALU: the low-latency
 // variant for batches of <= 2 sequences per CU; lstm_*_persist dispatch to it)
-bool lstm_persist_use_valu(int n_seq);
+bool lstm_persist_use_valu(int n_seq, int flags);
 int lstm_forward_valu(RnnStepArgs a, hipStream_t s);
 int lstm_backward_valu(RnnStepArgs a, hipStream_t s);
 // rnn_team.hip (GRU / LSTM with H = 256: all time steps in one launch, a sequence's W_hh spread over the registers
 // of four workgroups that exchange the state every step)
-bool rnn_team_supported(int cell, int H, int n_seq);
+bool rnn_team_supported(int cell, int H, int n_seq, int flags);
+long long rnn_team_xbuf_bytes();   // size of DC_WS_TEAM_XBUF
 int rnn_team_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s);
 int rnn_team_backward(int cell, RnnStepArgs a, int max_len, hipStream_t s);
 // adam.hip

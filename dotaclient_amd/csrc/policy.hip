@@ -53,6 +53,7 @@ int64_t workspace_layout(const dc_dims* d, int64_t* out) {
     put(DC_WS_WHHT, H * G * H * 4);
     put(DC_WS_SCRATCH, (int64_t)DC_SCRATCH_FLOATS * 4);   // two-stage reductions / split-K slabs
     put(DC_WS_HEADW_PAD, (int64_t)HO_LD * H * 4);          // head weights zero-padded to 160 rows (K of dH)
+    put(DC_WS_TEAM_XBUF, H == 256 ? rnn_team_xbuf_bytes() : 0);   // exchange ring of the H = 256 team kernels (rnn_team.hip)
     for (int l = 0; l < d->layers; ++l) {
         const int b = DC_WS_FIXED + l * DC_WS_PER_LAYER;
         put(b + DC_WSL_GATES, NR * G * H * 4);
@@ -87,12 +88,9 @@ static int check_dims(const dc_dims* d) {
 #define DC_TRY(x) do { int _e = (x); if (_e) return _e; } while (0)
 
 // The two 16-unit types go through the sparse max-pool backward (embed_sparse.hip: a sixteenth of the MACs, no d(emb)
-// in HBM; 290 us against 385 us for the dense MFMA kernels on the same units at the bench batch).  DC_EMBED_SPARSE=0
-// forces the dense kernels for every type.  Read per call: the GPU tests run both paths in one process.
-static bool embed_sparse_enabled() {
-    const char* e = getenv("DC_EMBED_SPARSE");
-    return !(e && e[0] == '0');
-}
+// in HBM; 290 us against 385 us for the dense MFMA kernels on the same units at the bench batch).  DC_DIMS_DENSE_POOL_BWD
+// forces the dense kernels for every type (per call: the GPU tests run both paths in one process).
+static bool embed_sparse_enabled(const dc_dims* d) { return !(d->flags & DC_DIMS_DENSE_POOL_BWD); }
 
 int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, const float* obs, const float* h0,
                    const float* c0, const int64_t* seq_off, const int32_t* seq_len, void* ws_base, float* hT, float* cT,
@@ -137,6 +135,7 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
         a.h0 = h0 ? h0 + (size_t)l * B * H : nullptr;
         a.c0 = (c0 && d->cell == 1) ? c0 + (size_t)l * B * H : nullptr;
         a.seq_off = seq_off; a.seq_len = seq_len; a.n_seq = B; a.H = H;
+        a.flags = d->flags; a.xbuf = w.base + w.off[DC_WS_TEAM_XBUF];
         a.Whh = P.p(pb + 1); a.bhh = P.p(pb + 3);
         a.gates = w.fl(l, DC_WSL_GATES); a.hn = w.fl(l, DC_WSL_HN); a.hseq = w.fl(l, DC_WSL_HSEQ);
         a.hprev = w.fl(l, DC_WSL_HPREV); a.cseq = w.fl(l, DC_WSL_CSEQ); a.cprev = w.fl(l, DC_WSL_CPREV);
@@ -178,7 +177,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     Ws w; w.base = (char*)ws_base; workspace_layout(d, w.off);
     Params P{params, poff};
     Grads Gd{grads, poff};
-    gemm_set_scratch(w.f(DC_WS_SCRATCH), DC_SCRATCH_FLOATS);
+    const GemmScratch sc{w.f(DC_WS_SCRATCH), DC_SCRATCH_FLOATS};   // split-K slabs of this call's weight-gradient products
     const long long NR = d->rows;
     const int H = d->hidden, G = d->cell == 0 ? 3 : 4, B = d->n_seq, L = d->layers;
     const int TOP = L - 1;
@@ -194,15 +193,16 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     DC_TRY(gemm_f32(w.f(DC_WS_DHEADOUT), w.f(DC_WS_HEADW_PAD), w.fl(TOP, DC_WSL_DH), (int)NR, H, HO_LD, HO_LD, H, H, 0, 1, nullptr,
                     0, nullptr, 0, 0, 1, s));
     DC_TRY(gemm_f32(w.f(DC_WS_DHEADOUT), w.fl(TOP, DC_WSL_HSEQ), Gd.p(DC_P_HEADS_W), HO_N, H, (int)NR, HO_LD, H, H, 1, 1,
-                    nullptr, 0, nullptr, 0, 1, 0, s));
+                    nullptr, 0, nullptr, 0, 1, 0, s, sc));
     DC_TRY(colsum(w.f(DC_WS_DHEADOUT), HO_LD, NR, HO_N, Gd.p(DC_P_HEADS_B), s));
 
     // recurrent core, top layer first
     for (int l = TOP; l >= 0; --l) {
         const int pb = DC_P_RNN0 + 4 * l;
-        if (!rnn_uses_persistent(d->cell, H)) DC_TRY(transpose(P.p(pb + 1), w.f(DC_WS_WHHT), G * H, H, s));
+        if (!rnn_uses_persistent(d->cell, H, d->flags)) DC_TRY(transpose(P.p(pb + 1), w.f(DC_WS_WHHT), G * H, H, s));
         RnnStepArgs a{};
         a.seq_off = seq_off; a.seq_len = seq_len; a.n_seq = B; a.H = H;
+        a.flags = d->flags; a.xbuf = w.base + w.off[DC_WS_TEAM_XBUF];
         a.gates = w.fl(l, DC_WSL_GATES); a.hn = w.fl(l, DC_WSL_HN); a.hseq = w.fl(l, DC_WSL_HSEQ);
         a.hprev = w.fl(l, DC_WSL_HPREV); a.cseq = w.fl(l, DC_WSL_CSEQ); a.cprev = w.fl(l, DC_WSL_CPREV);
         a.Whh = P.p(pb + 1); a.WhhT = w.f(DC_WS_WHHT); a.dh = w.fl(l, DC_WSL_DH); a.dc = w.fl(l, DC_WSL_DC);
@@ -213,10 +213,10 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         const int in = l == 0 ? PREW : H;
         // dW_ih = dgx^T x ; dW_hh = dgh^T h_prev ; biases = column sums
         if (a.dgh == a.dgx) {   // LSTM: both products contract the same gate gradients - one launch
-            DC_TRY(gemm_f32_tn_pair(a.dgx, G * H, xin, in, in, a.hprev, H, H, Gd.p(pb + 0), in, Gd.p(pb + 1), H, G * H, (int)NR, s));
+            DC_TRY(gemm_f32_tn_pair(a.dgx, G * H, xin, in, in, a.hprev, H, H, Gd.p(pb + 0), in, Gd.p(pb + 1), H, G * H, (int)NR, s, sc));
         } else {
-            DC_TRY(gemm_f32(a.dgx, xin, Gd.p(pb + 0), G * H, in, (int)NR, G * H, in, in, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s));
-            DC_TRY(gemm_f32(a.dgh, a.hprev, Gd.p(pb + 1), G * H, H, (int)NR, G * H, H, H, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s));
+            DC_TRY(gemm_f32(a.dgx, xin, Gd.p(pb + 0), G * H, in, (int)NR, G * H, in, in, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s, sc));
+            DC_TRY(gemm_f32(a.dgh, a.hprev, Gd.p(pb + 1), G * H, H, (int)NR, G * H, H, H, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s, sc));
         }
         DC_TRY(colsum(a.dgx, G * H, NR, G * H, Gd.p(pb + 2), s));
         if (d->cell == 1) {   // LSTM: dgh is dgx, so d(b_hh) = d(b_ih) - copy 2 KB instead of a second 33 MB column sum
@@ -235,18 +235,18 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         }
     }
     DC_TRY(gemm_f32(w.f(DC_WS_DPRE), w.f(DC_WS_XCAT), Gd.p(DC_P_PRE_W), PREW, XCATW, (int)NR, PREW, XCATW, XCATW, 1, 1, nullptr,
-                    0, nullptr, 0, 1, 0, s));
+                    0, nullptr, 0, 1, 0, s, sc));
     DC_TRY(colsum(w.f(DC_WS_DPRE), PREW, NR, PREW, Gd.p(DC_P_PRE_B), s));
     DC_TRY(gemm_f32(w.f(DC_WS_DPRE), P.p(DC_P_PRE_W), w.f(DC_WS_DXCAT), (int)NR, XCATW, PREW, PREW, XCATW, XCATW, 0, 1, nullptr,
                     0, nullptr, 0, 0, 1, s));
     }   // do_upper
-    if (!do_embed) { gemm_set_scratch(nullptr, 0); return 0; }
+    if (!do_embed) return 0;
 
     // max-pool routing + attention keys -> per-unit embedding gradients; env embedding weights
     // Fused path: the two 16-unit types (32 of the 40 units) take the sparse max-pool backward (embed_sparse.hip);
-    // DC_EMBED_SPARSE=0: the dense kernels for all types.
+    // DC_DIMS_DENSE_POOL_BWD: the dense kernels for all types.
     const bool fusedb = embed_fused_supported(NR);
-    const bool sparse16 = fusedb && embed_sparse_enabled();
+    const bool sparse16 = fusedb && embed_sparse_enabled(d);
     const uint8_t* amaxp = reinterpret_cast<const uint8_t*>(w.base + w.off[DC_WS_AMAX]);
     DC_TRY(embed_scatter_bwd(obs, w.f(DC_WS_XCAT), w.f(DC_WS_DXCAT), w.f(DC_WS_DTU), w.f(DC_WS_HEADOUT), HO_LD, amaxp,
                              w.f(DC_WS_DEMB), Gd.p(DC_P_ENV_W), Gd.p(DC_P_ENV_B), Gd.p(DC_P_UNIT_B), w.f(DC_WS_SCRATCH), NR,
@@ -266,14 +266,13 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
             const size_t ro = (size_t)NR * T_CUM[t] * EMBW;
             const int rows_t = (int)(NR * T_UNITS[t]);
             DC_TRY(gemm_f32(w.f(DC_WS_DEMB) + ro, w.f(DC_WS_BASIC) + ro, Gd.p(DC_P_UNIT_W) + (size_t)t * EMBW * EMBW, EMBW, EMBW,
-                            rows_t, EMBW, EMBW, EMBW, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s));
+                            rows_t, EMBW, EMBW, EMBW, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s, sc));
             // dbasic (stored over the no-longer-needed emb buffer), relu-masked by basic
             DC_TRY(gemm_f32(w.f(DC_WS_DEMB) + ro, P.p(DC_P_UNIT_W) + (size_t)t * EMBW * EMBW, w.f(DC_WS_EMB) + ro, rows_t, EMBW,
                             EMBW, EMBW, EMBW, EMBW, 0, 1, nullptr, 0, w.f(DC_WS_BASIC) + ro, EMBW, 0, 1, s));
         }
         DC_TRY(unit_basic_bwd(obs, w.f(DC_WS_EMB), Gd.p(DC_P_BASIC_W), Gd.p(DC_P_BASIC_B), w.f(DC_WS_SCRATCH), NR, s));
     }
-    gemm_set_scratch(nullptr, 0);
     return 0;
 }
 

@@ -268,6 +268,24 @@ int rnn_final_state(const float* hseq, float* hT, const int64_t* seq_off, const 
     return launch_check("rnn_final_state");
 }
 
+// out[b][:] = seq[prev_row[b]][:] (zeros when prev_row[b] < 0): the initial state of chunk b = the state after the last
+// step of the previous chunk of the same rollout (optimizer.py:384,408), zeros for a rollout's first chunk (policy.py:77-78)
+__global__ __launch_bounds__(128) void gather_state_kernel(const float* __restrict__ seq, const int64_t* __restrict__ prev_row,
+                                                           float* __restrict__ out, int H) {
+    const int b = blockIdx.x;
+    const int64_t r = prev_row[b];
+    for (int j = threadIdx.x * 4; j < H; j += 128 * 4) {
+        const float4 v = r >= 0 ? *reinterpret_cast<const float4*>(seq + r * H + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(out + (size_t)b * H + j) = v;
+    }
+}
+
+int rnn_gather_state(const float* seq, const int64_t* prev_row, float* out, int n, int H, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(gather_state_kernel, dim3(n), dim3(128), 0, s, seq, prev_row, out, H);
+    return launch_check("rnn_gather_state");
+}
+
 template <int CELL>
 static bool launch_fwd(const RnnStepArgs& a, dim3 grid, hipStream_t s) {
     switch (a.H / 64) {
@@ -297,24 +315,20 @@ static int check_h(int H) {
 }
 
 // all steps of one layer, forward.  max_len = max(seq_len) (host value).
-// DC_RNN_PERSIST=0 forces the launch-per-step kernels (A/B measurements)
-bool rnn_uses_persistent(int cell, int H);
-static bool persist_enabled() {
-    static const bool on = [] { const char* e = getenv("DC_RNN_PERSIST"); return !(e && e[0] == '0'); }();
-    return on;
-}
+// DC_DIMS_RNN_PER_STEP forces the launch-per-step kernels (A/B measurements, parity tests of both)
+static bool persist_enabled(int flags) { return !(flags & DC_DIMS_RNN_PER_STEP); }
 
 // true when the layer runs on the register-resident LSTM kernels (which read W_hh directly: no W_hh^T needed)
-bool rnn_uses_persistent(int cell, int H) { return cell == CELL_LSTM && lstm_persist_supported(H) && persist_enabled(); }
+bool rnn_uses_persistent(int cell, int H, int flags) { return cell == CELL_LSTM && lstm_persist_supported(H) && persist_enabled(flags); }
 
 int rnn_forward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     if (int e = check_h(a.H)) return e;
     // hprev/cprev[first row of a sequence] = h0/c0 (zeros when absent).  The one-sequence-per-workgroup LSTM kernels
     // and the team kernels read h0/c0 themselves and write those rows (two launches less per pass); the others are
     // seeded here.
-    const bool lstm_persist = cell == CELL_LSTM && lstm_persist_supported(a.H) && persist_enabled();
-    const bool team = !lstm_persist && persist_enabled() && rnn_team_supported(cell, a.H, a.n_seq);
-    const bool self_seeding = (lstm_persist && lstm_persist_use_valu(a.n_seq)) || team;
+    const bool lstm_persist = cell == CELL_LSTM && lstm_persist_supported(a.H) && persist_enabled(a.flags);
+    const bool team = !lstm_persist && persist_enabled(a.flags) && rnn_team_supported(cell, a.H, a.n_seq, a.flags);
+    const bool self_seeding = (lstm_persist && lstm_persist_use_valu(a.n_seq, a.flags)) || team;
     if (!self_seeding) {
         if (int e = rnn_seed_state(a.h0, a.hprev, a.seq_off, a.seq_len, a.n_seq, a.H, s)) return e;
         if (cell == CELL_LSTM)
@@ -336,8 +350,8 @@ int rnn_forward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
 
 int rnn_backward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     if (int e = check_h(a.H)) return e;
-    if (cell == CELL_LSTM && lstm_persist_supported(a.H) && persist_enabled()) return lstm_backward_persist(a, max_len, s);
-    if (persist_enabled() && rnn_team_supported(cell, a.H, a.n_seq)) return rnn_team_backward(cell, a, max_len, s);
+    if (cell == CELL_LSTM && lstm_persist_supported(a.H) && persist_enabled(a.flags)) return lstm_backward_persist(a, max_len, s);
+    if (persist_enabled(a.flags) && rnn_team_supported(cell, a.H, a.n_seq, a.flags)) return rnn_team_backward(cell, a, max_len, s);
     dim3 grid(a.H / 16, (a.n_seq + 15) / 16);
     for (int t = max_len - 1; t >= 0; --t) {
         a.t = t;

@@ -570,13 +570,13 @@ int lstm_forward_persist(RnnStepArgs a, int max_len, hipStream_t s) {
     const dim3 grid((a.n_seq + 3) / 4);
     ProfScope prof("lstm_fwd_persist", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len,
                    4.0 * a.n_seq * max_len * a.H * (2.0 * 4 + 4.0), s);
-    if (lstm_persist_use_valu(a.n_seq)) return lstm_forward_valu(a, s);
+    if (lstm_persist_use_valu(a.n_seq, a.flags)) return lstm_forward_valu(a, s);
     static long long* dbg = nullptr;
-    static const bool timing = [] { const char* e = getenv("DC_LSTM_TIMING"); return e && e[0] == '1'; }();
+    constexpr bool timing = DC_DEV_TIMING != 0;
     if (timing && a.H == 128) {   // debugging aid: per-phase cycle counts of workgroup 0, printed per launch
         if (!dbg) (void)hipMalloc(&dbg, 64);
         a.dbg = dbg;
-        static const int mode = [] { const char* e = getenv("DC_LSTM_HOOKMODE"); return e ? atoi(e) : 0; }();
+        constexpr int mode = DC_DEV_HOOKMODE;
         if (mode == 1) hipLaunchKernelGGL((lstm_fwd_persist_kernel<128, true, 1>), grid, dim3(PersistCfg<128>::THREADS), 0, s, a);
         else if (mode == 2) hipLaunchKernelGGL((lstm_fwd_persist_kernel<128, true, 2>), grid, dim3(PersistCfg<128>::THREADS), 0, s, a);
         else if (mode == 3) hipLaunchKernelGGL((lstm_fwd_persist_kernel<128, true, 3>), grid, dim3(PersistCfg<128>::THREADS), 0, s, a);
@@ -597,7 +597,7 @@ int lstm_backward_persist(RnnStepArgs a, int max_len, hipStream_t s) {
     const dim3 grid((a.n_seq + 3) / 4);
     ProfScope prof("lstm_bwd_persist", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len,
                    4.0 * a.n_seq * max_len * a.H * (2.0 * 4 + 3.0), s);
-    if (lstm_persist_use_valu(a.n_seq)) return lstm_backward_valu(a, s);
+    if (lstm_persist_use_valu(a.n_seq, a.flags)) return lstm_backward_valu(a, s);
     if (a.H == 128) hipLaunchKernelGGL((lstm_bwd_persist_kernel<128>), grid, dim3(PersistCfg<128>::THREADS), 0, s, a);
     else if (a.H == 64) hipLaunchKernelGGL((lstm_bwd_persist_kernel<64>), grid, dim3(PersistCfg<64>::THREADS), 0, s, a);
     else { set_error("lstm_backward_persist: unsupported hidden size", 1011); return 1011; }

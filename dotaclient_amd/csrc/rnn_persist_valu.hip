@@ -312,16 +312,15 @@ __global__ __launch_bounds__(4 * H) void lstm_bwd_valu_kernel(RnnStepArgs p) {
     }
 }
 
-// DC_LSTM_PERSIST = mfma | valu forces a variant (A/B measurements, parity tests of both); default: by size
-bool lstm_persist_use_valu(int n_seq) {
-    const char* e = getenv("DC_LSTM_PERSIST");
-    if (e && !strcmp(e, "mfma")) return false;
-    if (e && !strcmp(e, "valu")) return true;
+// DC_DIMS_LSTM_MFMA / DC_DIMS_LSTM_VALU force a variant (A/B measurements, parity tests of both); default: by size
+bool lstm_persist_use_valu(int n_seq, int flags) {
+    if (flags & DC_DIMS_LSTM_MFMA) return false;
+    if (flags & DC_DIMS_LSTM_VALU) return true;
     return n_seq <= 512;   // <= 2 sequences per CU: one-sequence workgroups; above, the 4-sequence MFMA packing
 }
 
 int lstm_forward_valu(RnnStepArgs a, hipStream_t s) {
-    static const bool timing = [] { const char* e = getenv("DC_LSTM_TIMING"); return e && e[0] == '1'; }();
+    constexpr bool timing = DC_DEV_TIMING != 0;
     if (timing && a.H == 128) {   // debugging aid: per-step phase cycles of one wave, printed per launch
         static long long* dbg = nullptr;
         if (!dbg) (void)hipMalloc(&dbg, 64);

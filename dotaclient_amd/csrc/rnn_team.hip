@@ -24,8 +24,9 @@
 // do share an XCD (hence an L2), publish with L2-scope stores instead of write-through ones (a lone sequence's step:
 // 1.19 -> 0.97 us); any other placement keeps the device-scope stores.  Every spin is bounded; a member that gives up
 // poisons its outputs with NaN (the loss turns NaN and the optimizer raises, optimizer.py:667) instead of
-// hanging the GPU.  All 4 x teams workgroups must be resident at once: the host sizes the grid from the
-// CU count (one 512-thread workgroup with ~180 registers per lane per CU).
+// hanging the GPU.  The grid does NOT have to be resident at once: roles are taken by ticket when a workgroup starts
+// (team_claim_role), so a team only ever waits for workgroups that are running; the host still sizes the grid from
+// the CU count (one 512-thread workgroup with ~180 registers per lane per CU) because that is the fastest shape.
 //
 // Lane roles (512 threads).  Both kernels end a step with gate q = lane & 3 of one hidden unit in every
 // DPP quad, each (unit, gate) held by two lanes ("dup" 0/1, which share the stores).
@@ -74,18 +75,35 @@ __device__ __forceinline__ bool granule_wait(u64 g, const u64* p, unsigned tag, 
     return true;
 }
 
-// blockIdx -> (team, member): members of a team 8 blocks apart (same XCD under the usual round-robin
-// placement - a speed hint only)
-__device__ __forceinline__ void team_of_block(int n_teams, int& team, int& member) {
-    const int b = blockIdx.x;
-    if ((n_teams & 7) == 0) {
-        const int x = b & 7, j = b >> 3;
-        team = (j >> 2) * 8 + x;
-        member = j & 3;
-    } else {
-        team = b >> 2;
-        member = b & 3;
+// Which (team, member) a workgroup plays is decided when it STARTS RUNNING, by a ticket, not by its block index: the
+// first four workgroups to start form team 0, the next four team 1, ...  A workgroup that has started stays resident
+// until it exits, so every team whose four tickets are taken is fully resident and makes progress - whatever else
+// occupies the chip (an RCCL kernel, a second engine's launch on another stream, a CU mask): workgroups that have not
+// been dispatched yet hold no role anyone waits for, at most one team per ticket counter is incomplete at any moment,
+// and it completes as soon as any running workgroup on the chip exits.  No co-residency of the whole grid is assumed.
+// Speed only: with a multiple of 8 teams there is one ticket counter per XCD (the workgroup reads its XCC id), so a
+// team's members share an L2 under any placement; a workgroup whose XCD has no role left takes one of another XCD.
+enum { TEAM_HDR = 16 };   // u64 words in front of the handshake granules: ticket counters (u32 each)
+__device__ __forceinline__ void team_claim_role(unsigned* claim, int n_teams, int& team, int& member) {
+    __shared__ int role_sh[2];
+    if (threadIdx.x == 0) {
+        int t = -1, m = 0;
+        if ((n_teams & 7) == 0) {
+            const int quota = (n_teams >> 3) * TEAM_M;   // roles per XCD slice: teams x, x + 8, x + 16, ...
+            const int x = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7);   // HW_REG_XCC_ID
+            for (int k = 0; k < 8 && t < 0; ++k) {
+                const int y = (x + k) & 7;
+                const unsigned o = atomicAdd(&claim[y], 1u);
+                if ((int)o < quota) { t = (int)(o >> 2) * 8 + y; m = (int)(o & 3); }
+            }
+        } else {
+            const unsigned o = atomicAdd(&claim[0], 1u);
+            if ((int)o < n_teams * TEAM_M) { t = (int)(o >> 2); m = (int)(o & 3); }
+        }
+        role_sh[0] = t; role_sh[1] = m;
     }
+    __syncthreads();
+    team = role_sh[0]; member = role_sh[1];
 }
 
 // Once per launch: do the four members of this team share an XCD (hence an L2)?  Each publishes its XCC id as a granule
@@ -138,9 +156,10 @@ __global__ __launch_bounds__(512) void rnn_team_fwd_kernel(RnnStepArgs p, u64* _
     const int kg = tid & 15, row = tid >> 4;
     const int q = tid & 3, dup = (tid >> 3) & 1;
     int team, member;
-    team_of_block(n_teams, team, member);
-    u64* const xbuf = xbuf_all + TEAM_MAX * TEAM_M;                 // [handshake granules | rings]
-    const int plain = team_same_xcd(xbuf_all + team * TEAM_M, member, allow_plain);
+    team_claim_role(reinterpret_cast<unsigned*>(xbuf_all), n_teams, team, member);
+    if (team < 0) return;                                          // more workgroups than roles: cannot happen (grid = 4 x teams)
+    u64* const xbuf = xbuf_all + TEAM_HDR + TEAM_MAX * TEAM_M;      // [tickets | handshake granules | rings]
+    const int plain = team_same_xcd(xbuf_all + TEAM_HDR + team * TEAM_M, member, allow_plain);
     const int U0 = member * TEAM_US;
     const int u = U0 + 2 * row + ((tid >> 2) & 1);
 
@@ -391,9 +410,10 @@ __global__ __launch_bounds__(512) void rnn_team_bwd_kernel(RnnStepArgs p, u64* _
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 3, dup = (lane >> 2) & 1, b3 = (lane >> 3) & 1;
     int team, member;
-    team_of_block(n_teams, team, member);
-    u64* const xbuf = xbuf_all + TEAM_MAX * TEAM_M;                 // [handshake granules | rings]
-    const int plain = team_same_xcd(xbuf_all + team * TEAM_M, member, allow_plain);
+    team_claim_role(reinterpret_cast<unsigned*>(xbuf_all), n_teams, team, member);
+    if (team < 0) return;                                          // more workgroups than roles: cannot happen (grid = 4 x teams)
+    u64* const xbuf = xbuf_all + TEAM_HDR + TEAM_MAX * TEAM_M;      // [tickets | handshake granules | rings]
+    const int plain = team_same_xcd(xbuf_all + TEAM_HDR + team * TEAM_M, member, allow_plain);
     const int U0 = member * TEAM_US;
     const int u = U0 + 8 * wave + (lane >> 3);
 
@@ -599,14 +619,10 @@ __global__ __launch_bounds__(512) void rnn_team_bwd_kernel(RnnStepArgs p, u64* _
 // ---------------------------------------------------------------------------------------------------
 namespace {
 
-// exchange ring of the largest case (backward: 4H granules per slot), allocated once per process: team launches are
-// expected on ONE stream at a time (the optimizer is single-threaded, one process per GPU - optimizer.py:726-733); two
-// launches overlapping on different streams would share it
-u64* team_xbuf() {
-    static u64* buf = nullptr;
-    if (!buf && hipMalloc(&buf, ((size_t)TEAM_MAX * TEAM_M + (size_t)TEAM_MAX * TEAM_NS_MAX * TEAM_SLOTS * 4 * TEAM_H) * sizeof(u64)) != hipSuccess) buf = nullptr;
-    return buf;
-}
+// exchange buffer = [ticket counters | handshake granules | ring of the largest case (backward: 4H granules per slot)];
+// it is part of the CALLER's workspace (DC_WS_TEAM_XBUF, RnnStepArgs::xbuf): nothing is allocated here, and two engines
+// on two streams never share one
+constexpr size_t TEAM_XBUF_WORDS = (size_t)TEAM_HDR + (size_t)TEAM_MAX * TEAM_M + (size_t)TEAM_MAX * TEAM_NS_MAX * TEAM_SLOTS * 4 * TEAM_H;
 
 // teams that can be resident together: one 512-thread workgroup per CU, four per team
 int team_capacity() {
@@ -628,14 +644,14 @@ int team_count(int n_seq) {
     return t;
 }
 
-// DC_TEAM_PLAIN=0: device-scope (write-through) granule stores even for teams that sit on one XCD (A/B measurements)
-int team_plain() { const char* e = getenv("DC_TEAM_PLAIN"); return !(e && e[0] == '0'); }
+// DC_DIMS_TEAM_DEVICE_SCOPE: device-scope (write-through) granule stores even for teams that sit on one XCD (A/B measurements)
+int team_plain(int flags) { return !(flags & DC_DIMS_TEAM_DEVICE_SCOPE); }
 
 // sequences a team keeps in flight: as many as it has to walk through anyway, up to four (a step is ~1/3 work,
-// ~2/3 waiting for the peers).  DC_RNN_TEAM_NS = 1 | 2 | 4 forces a count (A/B measurements, tests).
-int team_streams(int n_seq, int nt) {
-    const char* e = getenv("DC_RNN_TEAM_NS");
-    if (e && (e[0] == '1' || e[0] == '2' || e[0] == '4') && e[1] == 0) return e[0] - '0';
+// ~2/3 waiting for the peers).  DC_DIMS_TEAM_NS(1 | 2 | 4) forces a count (A/B measurements, tests).
+int team_streams(int n_seq, int nt, int flags) {
+    const int forced = (flags >> DC_DIMS_TEAM_NS_SHIFT) & 7;
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
     const int per = (n_seq + nt - 1) / nt;
     return per >= 3 ? 4 : (per == 2 ? 2 : 1);
 }
@@ -643,44 +659,46 @@ int team_streams(int n_seq, int nt) {
 template <int CELL>
 void launch_team_fwd(int ns, int nt, const RnnStepArgs& a, u64* xb, hipStream_t s) {
     const dim3 grid(nt * TEAM_M), block(512);
-    if (ns == 4) hipLaunchKernelGGL((rnn_team_fwd_kernel<CELL, 4>), grid, block, 0, s, a, xb, nt, team_plain());
-    else if (ns == 2) hipLaunchKernelGGL((rnn_team_fwd_kernel<CELL, 2>), grid, block, 0, s, a, xb, nt, team_plain());
-    else hipLaunchKernelGGL((rnn_team_fwd_kernel<CELL, 1>), grid, block, 0, s, a, xb, nt, team_plain());
+    if (ns == 4) hipLaunchKernelGGL((rnn_team_fwd_kernel<CELL, 4>), grid, block, 0, s, a, xb, nt, team_plain(a.flags));
+    else if (ns == 2) hipLaunchKernelGGL((rnn_team_fwd_kernel<CELL, 2>), grid, block, 0, s, a, xb, nt, team_plain(a.flags));
+    else hipLaunchKernelGGL((rnn_team_fwd_kernel<CELL, 1>), grid, block, 0, s, a, xb, nt, team_plain(a.flags));
 }
 template <int CELL>
 void launch_team_bwd(int ns, int nt, const RnnStepArgs& a, u64* xb, hipStream_t s) {
     const dim3 grid(nt * TEAM_M), block(512);
-    if (ns == 4) hipLaunchKernelGGL((rnn_team_bwd_kernel<CELL, 4>), grid, block, 0, s, a, xb, nt, team_plain());
-    else if (ns == 2) hipLaunchKernelGGL((rnn_team_bwd_kernel<CELL, 2>), grid, block, 0, s, a, xb, nt, team_plain());
-    else hipLaunchKernelGGL((rnn_team_bwd_kernel<CELL, 1>), grid, block, 0, s, a, xb, nt, team_plain());
+    if (ns == 4) hipLaunchKernelGGL((rnn_team_bwd_kernel<CELL, 4>), grid, block, 0, s, a, xb, nt, team_plain(a.flags));
+    else if (ns == 2) hipLaunchKernelGGL((rnn_team_bwd_kernel<CELL, 2>), grid, block, 0, s, a, xb, nt, team_plain(a.flags));
+    else hipLaunchKernelGGL((rnn_team_bwd_kernel<CELL, 1>), grid, block, 0, s, a, xb, nt, team_plain(a.flags));
 }
 
 }  // namespace
 
-// DC_RNN_TEAM=0 forces the launch-per-step kernels (A/B measurements, parity tests of both)
-bool rnn_team_supported(int cell, int H, int n_seq) {
-    const char* e = getenv("DC_RNN_TEAM");
-    const bool on = !(e && e[0] == '0');
+long long rnn_team_xbuf_bytes() { return (long long)(TEAM_XBUF_WORDS * sizeof(u64)); }
+
+// (DC_DIMS_RNN_PER_STEP, checked by the caller, forces the launch-per-step kernels)
+bool rnn_team_supported(int cell, int H, int n_seq, int flags) {
+    (void)flags;
+    const bool on = true;
     // measured at LSTM-256, 256 steps: 64 sequences 0.39 vs 2.2 ms per pass, 256: 0.86 vs 2.4 ms, 1024: 3.4 vs 3.8 ms - beyond
     // that the batched per-step launches (MFMA, all sequences at once) win again
     return on && H == TEAM_H && (cell == CELL_GRU || cell == CELL_LSTM) && n_seq <= 12 * TEAM_MAX && team_capacity() >= 1;
 }
 
 int rnn_team_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
-    u64* xb = team_xbuf();
-    if (!xb) { set_error("rnn_team_forward: exchange buffer allocation failed", 1012); return 1012; }
-    const int nt = team_count(a.n_seq), ns = team_streams(a.n_seq, nt);
+    u64* xb = static_cast<u64*>(a.xbuf);
+    if (!xb) { set_error("rnn_team_forward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }
+    const int nt = team_count(a.n_seq), ns = team_streams(a.n_seq, nt, a.flags);
     const double G = cell == CELL_GRU ? 3 : 4;
     ProfScope prof(cell == CELL_GRU ? "gru_fwd_team" : "lstm_fwd_team", 2.0 * a.n_seq * G * a.H * a.H * max_len,
                    4.0 * a.n_seq * max_len * a.H * (2.0 * G + 4.0), s);
-    if (hipMemsetAsync(xb, 0, ((size_t)TEAM_MAX * TEAM_M + (size_t)nt * ns * TEAM_SLOTS * TEAM_H) * sizeof(u64), s) != hipSuccess) return launch_check("rnn_team_forward memset");
-    static const bool timing = [] { const char* e = getenv("DC_TEAM_TIMING"); return e && e[0] == '1'; }();
+    if (hipMemsetAsync(xb, 0, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * TEAM_M + (size_t)nt * ns * TEAM_SLOTS * TEAM_H) * sizeof(u64), s) != hipSuccess) return launch_check("rnn_team_forward memset");
+    constexpr bool timing = DC_DEV_TIMING != 0;
     if (timing && cell == CELL_LSTM && (ns == 1 || ns == 4)) {   // debugging aid: phase cycles of one wave, printed per launch
         static long long* dbg = nullptr;
         if (!dbg) (void)hipMalloc(&dbg, 64);
         a.dbg = dbg;
-        if (ns == 1) hipLaunchKernelGGL((rnn_team_fwd_kernel<CELL_LSTM, 1, true>), dim3(nt * TEAM_M), dim3(512), 0, s, a, xb, nt, team_plain());
-        else hipLaunchKernelGGL((rnn_team_fwd_kernel<CELL_LSTM, 4, true>), dim3(nt * TEAM_M), dim3(512), 0, s, a, xb, nt, team_plain());
+        if (ns == 1) hipLaunchKernelGGL((rnn_team_fwd_kernel<CELL_LSTM, 1, true>), dim3(nt * TEAM_M), dim3(512), 0, s, a, xb, nt, team_plain(a.flags));
+        else hipLaunchKernelGGL((rnn_team_fwd_kernel<CELL_LSTM, 4, true>), dim3(nt * TEAM_M), dim3(512), 0, s, a, xb, nt, team_plain(a.flags));
         long long h[6];
         (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
         const double calls = (double)((a.n_seq + nt - 1) / nt) * max_len;   // step calls of one team (uniform lengths)
@@ -695,13 +713,13 @@ int rnn_team_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
 }
 
 int rnn_team_backward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
-    u64* xb = team_xbuf();
-    if (!xb) { set_error("rnn_team_backward: exchange buffer allocation failed", 1012); return 1012; }
-    const int nt = team_count(a.n_seq), ns = team_streams(a.n_seq, nt);
+    u64* xb = static_cast<u64*>(a.xbuf);
+    if (!xb) { set_error("rnn_team_backward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }
+    const int nt = team_count(a.n_seq), ns = team_streams(a.n_seq, nt, a.flags);
     const double G = cell == CELL_GRU ? 3 : 4;
     ProfScope prof(cell == CELL_GRU ? "gru_bwd_team" : "lstm_bwd_team", 2.0 * a.n_seq * G * a.H * a.H * max_len,
                    4.0 * a.n_seq * max_len * a.H * (3.0 * G + 6.0), s);
-    if (hipMemsetAsync(xb, 0, ((size_t)TEAM_MAX * TEAM_M + (size_t)nt * ns * TEAM_SLOTS * 4 * TEAM_H) * sizeof(u64), s) != hipSuccess) return launch_check("rnn_team_backward memset");
+    if (hipMemsetAsync(xb, 0, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * TEAM_M + (size_t)nt * ns * TEAM_SLOTS * 4 * TEAM_H) * sizeof(u64), s) != hipSuccess) return launch_check("rnn_team_backward memset");
     if (cell == CELL_GRU) launch_team_bwd<CELL_GRU>(ns, nt, a, xb, s);
     else launch_team_bwd<CELL_LSTM>(ns, nt, a, xb, s);
     return launch_check("rnn_team_backward");

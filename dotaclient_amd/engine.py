@@ -31,9 +31,16 @@ class DcDims(ctypes.Structure):
 DC_DIMS_LAZY_TU = 1     # include/dotaclient_hip.h
 DC_DIMS_BWD_UPPER = 2   # dc_policy_backward: heads .. pre-rnn projection only (zeroes the gradient buffer first)
 DC_DIMS_BWD_EMBED = 4   # dc_policy_backward: the embedding parameters only (after UPPER)
+# kernel-selection overrides (A/B measurements, tests that pit one kernel family against another): Engine.kernel_flags
+DC_DIMS_DENSE_POOL_BWD = 8
+DC_DIMS_RNN_PER_STEP = 16
+DC_DIMS_LSTM_MFMA = 32
+DC_DIMS_LSTM_VALU = 64
+DC_DIMS_TEAM_DEVICE_SCOPE = 128
+DC_DIMS_TEAM_NS = lambda n: n << 8
 
 WS_FIXED = ['BASIC', 'EMB', 'DEMB', 'XCAT', 'AMAX', 'PRE', 'HEADOUT', 'TU', 'DHEADOUT', 'DTU', 'DPRE', 'DXCAT',
-            'STATS', 'WHHT', 'SCRATCH', 'HEADW_PAD']
+            'STATS', 'WHHT', 'SCRATCH', 'HEADW_PAD', 'TEAM_XBUF']
 WS_LAYER = ['GATES', 'HN', 'HSEQ', 'HPREV', 'CSEQ', 'CPREV', 'DGX', 'DGH', 'DC', 'DH']
 
 
@@ -50,6 +57,7 @@ class PackedBatch:
         self.old_logp = self.values = self.adv = self.ret = self.argmax = None
         self.h0 = self.c0 = None
         self._chunk_meta = {}
+        self._bufs = {}            # output buffers of the passes over THIS batch, allocated once (Engine._buf)
         self.is_first = self.prev_row = None
 
     def as_chunks(self, seq_len):
@@ -62,8 +70,11 @@ class PackedBatch:
         meta = self._chunk_meta.get(seq_len)
         if meta is None:
             starts = torch.arange(b, device=dev, dtype=torch.int64) * seq_len
+            is_first = torch.isin(starts, self.seq_off)
+            # row that holds the state a chunk starts from: the last row of the previous chunk of the same rollout, -1
+            # (= zeros) for a rollout's first chunk
             meta = {'starts': starts, 'lens': torch.full((b,), seq_len, device=dev, dtype=torch.int32),
-                    'is_first': torch.isin(starts, self.seq_off), 'prev_row': (starts - 1).clamp(min=0)}
+                    'is_first': is_first, 'prev_row': torch.where(is_first, torch.full_like(starts, -1), starts - 1)}
             self._chunk_meta[seq_len] = meta
         out = PackedBatch(self.obs, self.act, self.mask, self.rew, meta['starts'], meta['lens'], seq_len)
         out.is_first, out.prev_row = meta['is_first'], meta['prev_row']
@@ -236,6 +247,9 @@ class Engine:
         self._ws = None
         self._ws_off = None
         self._ws_dims_key = None
+        self.kernel_flags = 0          # DC_DIMS_* overrides OR-ed into every call's dims (0 = the library picks by shape)
+        self.use_graphs = os.environ.get('DC_EPOCH_GRAPH', '0') == '1'   # default of train_epoch(graph=None)
+        self._graphs = {}
 
     # ---- parameters ------------------------------------------------------------------------------
     def param_view(self, name, buf=None):
@@ -293,7 +307,7 @@ class Engine:
         """lazy_tu: DC_DIMS_LAZY_TU - the target-unit logits are produced by select_logp / loss for the unmasked
         units only (the optimizer's passes); False gives DC_WS_TU for every unit (Policy.forward)."""
         return DcDims(CELL_ID[self.cell], self.hidden, self.layers, batch.n_seq, batch.max_len,
-                      DC_DIMS_LAZY_TU if lazy_tu else 0, batch.rows)
+                      (DC_DIMS_LAZY_TU if lazy_tu else 0) | self.kernel_flags, batch.rows)
 
     def _workspace(self, d):
         n = len(WS_FIXED) + len(WS_LAYER) * self.layers
@@ -330,11 +344,20 @@ class Engine:
                    'dc_policy_forward')
         return d, hT, cT
 
+    @staticmethod
+    def _buf(batch, name, shape, dtype, device):
+        """Output buffer `name` of a pass over `batch`: allocated on first use, reused by every later pass over the same
+        batch (the epochs of an iteration, the steps of the bench) - no allocation inside the steady-state step."""
+        t = batch._bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = batch._bufs[name] = torch.empty(shape, dtype=dtype, device=device)
+        return t
+
     def select_logp(self, d, batch, want_argmax=True):
         dev = self.device
-        logp = torch.empty(batch.rows, 5, device=dev)
-        values = torch.empty(batch.rows, device=dev)
-        argmax = torch.empty(batch.rows, 5, dtype=torch.int32, device=dev) if want_argmax else None
+        logp = self._buf(batch, 'old_logp', (batch.rows, 5), torch.float32, dev)
+        values = self._buf(batch, 'values', (batch.rows,), torch.float32, dev)
+        argmax = self._buf(batch, 'argmax', (batch.rows, 5), torch.int32, dev) if want_argmax else None
         _lib.check(self.lib.dc_select_logp(ctypes.byref(d), _lib.ptr(self._ws), _lib.ptr(batch.act), _lib.ptr(batch.mask),
                                            _lib.ptr(logp), _lib.ptr(values), _lib.ptr(argmax), _lib.stream_ptr()),
                    'dc_select_logp')
@@ -373,32 +396,34 @@ class Engine:
         from . import ops
         d, _, _ = self.forward(batch, lazy_tu=True)
         batch.old_logp, batch.values, batch.argmax = self.select_logp(d, batch)
-        batch.adv, batch.ret = ops.gae_scan(batch.rew, batch.values, batch.seq_off, batch.seq_len, batch.max_len,
-                                            gamma, lam)
+        dev = self.device
+        batch.adv, batch.ret = ops.gae_scan(batch.rew, batch.values, batch.seq_off, batch.seq_len, batch.max_len, gamma, lam,
+                                            adv=self._buf(batch, 'adv', (batch.rows,), torch.float32, dev),
+                                            ret=self._buf(batch, 'ret', (batch.rows,), torch.float32, dev))
         chunks = batch.as_chunks(seq_len)
         # initial state of every chunk = state after the previous chunk of the same rollout (detached,
-        # optimizer.py:384,408), zeros for a rollout's first chunk (policy.py:77-78)
-        is_first, prev_row = chunks.is_first, chunks.prev_row
-        H = self.hidden
-        h0 = []
-        c0 = []
-        for l in range(self.layers):
-            hs = self.ws_view(d, 'HSEQ', l)[:batch.rows * H].view(batch.rows, H)
-            h = hs.index_select(0, prev_row)
-            h[is_first] = 0
-            h0.append(h)
-            if self.cell == 'lstm':
-                cs = self.ws_view(d, 'CSEQ', l)[:batch.rows * H].view(batch.rows, H)
-                c = cs.index_select(0, prev_row)
-                c[is_first] = 0
-                c0.append(c)
-        chunks.h0 = torch.stack(h0)
-        chunks.c0 = torch.stack(c0) if c0 else None
+        # optimizer.py:384,408), zeros for a rollout's first chunk (policy.py:77-78): one gather launch per layer and state
+        B, H = chunks.n_seq, self.hidden
+        chunks.h0 = self._buf(batch, 'h0_%d' % seq_len, (self.layers, B, H), torch.float32, dev)
+        chunks.c0 = self._buf(batch, 'c0_%d' % seq_len, (self.layers, B, H), torch.float32, dev) if self.cell == 'lstm' else None
+        _lib.check(self.lib.dc_chunk_initial_state(ctypes.byref(d), _lib.ptr(self._ws), _lib.ptr(chunks.prev_row), B,
+                                                   _lib.ptr(chunks.h0), _lib.ptr(chunks.c0), _lib.stream_ptr()),
+                   'dc_chunk_initial_state')
         return chunks
 
-    def train_epoch(self, chunks, lr, entropy_coef, vf_coef, e_clip=0.1, grad_hook=None):
+    def train_epoch(self, chunks, lr, entropy_coef, vf_coef, e_clip=0.1, grad_hook=None, graph=None):
         """optimizer.py:581-689: one full-batch epoch.  Returns the device tensor `out`
-        (0 loss, 1 policy, 2 entropy, 3 value, 4..8 entropies, 9 unclipped, 10 clipped) and status."""
+        (0 loss, 1 policy, 2 entropy, 3 value, 4..8 entropies, 9 unclipped, 10 clipped) and status.
+
+        graph (default Engine.use_graphs): replay the epoch as ONE hipGraph launch instead of its ~45 kernel launches, memsets
+        and copies.  The first epoch over a given chunk batch and hyper-parameters runs eagerly, the second is captured,
+        later ones are replays; a data-parallel epoch (grad_hook: a collective in the middle) always runs eagerly."""
+        use_graph = self.use_graphs if graph is None else graph
+        if use_graph and grad_hook is None:
+            return self._train_epoch_graphed(chunks, lr, entropy_coef, vf_coef, e_clip)
+        return self._train_epoch_eager(chunks, lr, entropy_coef, vf_coef, e_clip, grad_hook)
+
+    def _train_epoch_eager(self, chunks, lr, entropy_coef, vf_coef, e_clip, grad_hook):
         d, _, _ = self.forward(chunks, chunks.h0, chunks.c0, lazy_tu=True)
         self.loss(d, chunks, e_clip, entropy_coef, vf_coef)
         if grad_hook is not None and getattr(grad_hook, 'overlap', False):
@@ -413,4 +438,32 @@ class Engine:
             if grad_hook is not None:
                 grad_hook(self)
         self.adam(lr, vf_coef)
+        return self.out, self.status
+
+    def _train_epoch_graphed(self, chunks, lr, entropy_coef, vf_coef, e_clip):
+        """Everything an epoch enqueues reads and writes fixed device buffers (the batch, the workspace, the flat
+        parameter / gradient / Adam buffers, `out`), and its host-side arguments are part of the key, so the recorded
+        launch sequence is valid for every later epoch with the same key."""
+        ptr = lambda t: 0 if t is None else t.data_ptr()
+        key = (ptr(chunks.obs), ptr(chunks.act), ptr(chunks.mask), ptr(chunks.old_logp), ptr(chunks.adv), ptr(chunks.ret),
+               ptr(chunks.h0), ptr(chunks.c0), ptr(chunks.seq_off), ptr(chunks.seq_len), chunks.n_seq, chunks.rows,
+               chunks.max_len, float(lr), float(entropy_coef), float(vf_coef), float(e_clip), self.kernel_flags,
+               ptr(self._ws), ptr(self.grads))
+        ent = self._graphs.get(key)
+        if ent is None:
+            # first sight of this key: run eagerly (also takes care of every one-time hipFuncSetAttribute and of the
+            # workspace allocation, neither of which belongs inside a capture)
+            if len(self._graphs) >= 4:
+                self._graphs.pop(next(iter(self._graphs)))
+            self._graphs[key] = {'graph': None, 'keep': (chunks,)}
+            out = self._train_epoch_eager(chunks, lr, entropy_coef, vf_coef, e_clip, None)
+            if ptr(self._ws) != key[-2]:          # the workspace was (re)allocated by this very call: start over next time
+                self._graphs.pop(key, None)
+            return out
+        if ent['graph'] is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._train_epoch_eager(chunks, lr, entropy_coef, vf_coef, e_clip, None)
+            ent['graph'] = g
+        ent['graph'].replay()
         return self.out, self.status

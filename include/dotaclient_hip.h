@@ -9,7 +9,9 @@
  *   - plain C: device pointers + sizes, no torch types; all pointers are DEVICE pointers unless
  *     the parameter name ends in _host;
  *   - every function enqueues work on the caller's HIP stream (dc_stream_t = hipStream_t) and returns
- *     immediately; nothing is allocated, freed or synchronised inside;
+ *     immediately; nothing is allocated, freed or synchronised inside, no state is kept between calls (all scratch comes
+ *     from the caller: the workspace of dc_workspace_layout, the scratch argument of dc_gemm_f32) and no environment
+ *     variable is read: two callers with their own buffers may drive two streams from two threads concurrently;
  *   - return value 0 = ok, anything else = HIP error code or a dc_* code >= 1000;
  *     dc_last_error() gives the message (the Python shim raises RuntimeError / ValueError from it);
  *   - inputs are never modified; outputs are fully overwritten unless documented as accumulating;
@@ -53,15 +55,12 @@ int dc_advantage_returns(const float* rewards, const float* values, int L, doubl
 /* fp32 MFMA GEMM building block (every nn.Linear of policy.py:54-75 and its autograd products).
  *   C[M,N] (op)= A[M,K] * B[K,N] (+ bias[N]) ; a_kmajor: A stored [K][lda] else [M][lda];
  *   b_kmajor: B stored [K][ldb] else [N][ldb]; relu: max(0,.); aux/ldaux: zero where aux<=0;
- *   accumulate: C += ; splits: 0 = auto split-K. */
+ *   accumulate: C += ; splits: 0 = auto split-K.
+ *   scratch / scratch_floats: device scratch of THIS call for the split-K partial slabs (reduced by a second kernel);
+ *   NULL / 0 = fp32 atomics instead.  The library keeps no scratch pointer between calls. */
 int dc_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                 int a_kmajor, int b_kmajor, const float* bias, int relu, const float* aux, int ldaux,
-                int accumulate, int splits, dc_stream_t stream);
-
-/* Optional scratch for dc_gemm_f32's split-K (partial slabs reduced by a second kernel instead of fp32
- * atomics).  floats = capacity; NULL/0 restores the atomic path.  Process-wide, not thread-safe;
- * dc_policy_backward installs its own workspace slab for the duration of the call. */
-void dc_gemm_set_scratch(float* scratch, int64_t floats);
+                int accumulate, int splits, float* scratch, int64_t scratch_floats, dc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Network + optimizer step.  Shapes: dc_dims; parameters: one flat fp32 buffer whose tensors are
@@ -95,6 +94,21 @@ typedef struct dc_dims {
  * Neither bit set: both parts, one call. */
 #define DC_DIMS_BWD_UPPER 2
 #define DC_DIMS_BWD_EMBED 4
+/* Kernel-selection overrides (A/B measurements and the parity tests that pit one kernel family against another; the
+ * default - none set - picks by shape).  They are part of the call, not of the process: nothing here reads the environment.
+ *   DC_DIMS_DENSE_POOL_BWD : dense MFMA kernels for the max-pool backward of every unit type (default: the sparse
+ *                            one-non-zero-per-channel form for the two 16-unit types when rows % 128 == 0);
+ *   DC_DIMS_RNN_PER_STEP   : one launch per time step instead of the persistent (register-resident / team) recurrent kernels;
+ *   DC_DIMS_LSTM_MFMA/_VALU: H <= 128 LSTM: force the 4-sequences-per-workgroup MFMA / 1-sequence-per-workgroup VALU variant;
+ *   DC_DIMS_TEAM_DEVICE_SCOPE : H = 256 team kernels: write-through granule stores even when a team shares an XCD;
+ *   DC_DIMS_TEAM_NS(n)     : H = 256 team kernels: n = 1, 2 or 4 sequences in flight per team (0 = by batch size). */
+#define DC_DIMS_DENSE_POOL_BWD 8
+#define DC_DIMS_RNN_PER_STEP 16
+#define DC_DIMS_LSTM_MFMA 32
+#define DC_DIMS_LSTM_VALU 64
+#define DC_DIMS_TEAM_DEVICE_SCOPE 128
+#define DC_DIMS_TEAM_NS_SHIFT 8
+#define DC_DIMS_TEAM_NS(n) ((n) << DC_DIMS_TEAM_NS_SHIFT)   /* bits 8..10 */
 
 /* index into poff[]; policy.py:54-75 names in comments */
 enum dc_param_index {
@@ -117,6 +131,7 @@ enum dc_param_index {
 enum dc_ws_index {
     DC_WS_BASIC = 0, DC_WS_EMB, DC_WS_DEMB, DC_WS_XCAT, DC_WS_AMAX, DC_WS_PRE, DC_WS_HEADOUT, DC_WS_TU,
     DC_WS_DHEADOUT, DC_WS_DTU, DC_WS_DPRE, DC_WS_DXCAT, DC_WS_STATS, DC_WS_WHHT, DC_WS_SCRATCH, DC_WS_HEADW_PAD,
+    DC_WS_TEAM_XBUF,
     DC_WS_FIXED,            /* per-layer blocks follow */
     DC_WSL_GATES = 0, DC_WSL_HN, DC_WSL_HSEQ, DC_WSL_HPREV, DC_WSL_CSEQ, DC_WSL_CPREV, DC_WSL_DGX, DC_WSL_DGH,
     DC_WSL_DC, DC_WSL_DH,
@@ -135,6 +150,14 @@ int64_t dc_workspace_layout(const dc_dims* dims, int64_t* offsets);
 int dc_policy_forward(const dc_dims* dims, const float* params, const int64_t* poff_host, const float* obs,
                       const float* h0, const float* c0, const int64_t* seq_off, const int32_t* seq_len, void* ws,
                       float* hT, float* cT, dc_stream_t stream);
+
+/* Hidden-state carry of the rollout pass, optimizer.py:384,408 (`hidden = hidden.detach()` handed from chunk to chunk) and
+ * policy.py:77-78 (zeros for a rollout's first chunk): after dc_policy_forward over whole rollouts (`dims`, `ws` = that
+ * call's), the initial state of chunk b of the seq_len view is the recurrent state at row prev_row[b] (= the chunk's first
+ * row - 1), or zeros when prev_row[b] < 0.
+ *   prev_row i64[n_chunks] (device); h0 / c0 [layers, n_chunks, H] f32 out (c0: LSTM only, may be NULL for the GRU). */
+int dc_chunk_initial_state(const dc_dims* dims, const void* ws, const int64_t* prev_row, int n_chunks, float* h0, float* c0,
+                           dc_stream_t stream);
 
 /* Rollout-pass epilogue, optimizer.py:387-390 + policy.py:169-178: log-prob of the selected action
  * per head (0 where the head took no action), value, masked argmax per head (-1 on empty mask).

@@ -12,10 +12,11 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4          # BASELINE.json north_star: losses/advantages within 1e-4 relative
 
 
-def run_hip(g, rollouts, cell='gru', hidden=256, layers=1, epochs=None):
+def run_hip(g, rollouts, cell='gru', hidden=256, layers=1, epochs=None, kernel_flags=0):
     from dotaclient_amd.engine import Engine, pack_rollouts
     dev = torch.device('cuda:0')
     eng = Engine(cell, hidden, layers, dev)
+    eng.kernel_flags = kernel_flags
     eng.load_state_dict(synth.init_state_dict(7, cell, hidden, layers))
     S = int(g['seq_len'])
     batch = pack_rollouts(rollouts, S, dev)
@@ -135,29 +136,31 @@ def test_hip_matches_oracle_at_baseline_configs(cell, hidden, B):
 
 @pytest.mark.parametrize('variant', ['mfma', 'valu'])
 @pytest.mark.parametrize('hidden,layers', [(128, 1), (64, 2)])
-def test_lstm_persist_variants_match_oracle(monkeypatch, variant, hidden, layers):
+def test_lstm_persist_variants_match_oracle(variant, hidden, layers):
     # both register-resident LSTM kernels (4 sequences/workgroup on the MFMA, 1 sequence/workgroup on the
     # packed-f32 VALU) against the oracle, on ragged rollouts (T = 50, 64, 33; chunks of 16): the size rule
     # in lstm_persist_use_valu would otherwise leave one of them untested
-    monkeypatch.setenv('DC_LSTM_PERSIST', variant)
+    from dotaclient_amd import engine as E
     g, rollouts = util.load_case('ragged_s16')
     ref, _, _ = util.oracle_run(g, rollouts, 'lstm', hidden, layers, epochs=2)
-    out, _ = run_hip(g, rollouts, 'lstm', hidden, layers, epochs=2)
+    out, _ = run_hip(g, rollouts, 'lstm', hidden, layers, epochs=2,
+                     kernel_flags=E.DC_DIMS_LSTM_MFMA if variant == 'mfma' else E.DC_DIMS_LSTM_VALU)
     ref.pop('hidden', None); out.pop('hidden', None)
     compare(out, ref, 2, ref['param_names'])
 
 
 @pytest.mark.parametrize('S,lens', [(256, [256] * 6), (7, [21, 7, 13, 30, 1, 44]), (5, [5, 9, 2])])
-def test_lstm_persist_variants_agree(monkeypatch, S, lens):
+def test_lstm_persist_variants_agree(S, lens):
     # 256-step trajectories (the bench shape: whole groups of 4 steps) and chunk lengths 7 / 5 with padded
     # rollouts of 7..49 steps (every remainder of the 4-step groups): the two variants differ only in
     # summation order
+    from dotaclient_amd import engine as E
     from dotaclient_amd.engine import Engine, pack_rollouts
     dev = torch.device('cuda:0')
     outs = {}
     for variant in ('mfma', 'valu'):
-        monkeypatch.setenv('DC_LSTM_PERSIST', variant)
         eng = Engine('lstm', 128, 1, dev)
+        eng.kernel_flags = E.DC_DIMS_LSTM_MFMA if variant == 'mfma' else E.DC_DIMS_LSTM_VALU
         eng.load_state_dict(synth.init_state_dict(7, 'lstm', 128, 1))
         rollouts = synth.make_rollouts(77, lens)
         batch = pack_rollouts(rollouts, S, dev)
@@ -172,21 +175,20 @@ def test_lstm_persist_variants_agree(monkeypatch, S, lens):
 
 @pytest.mark.parametrize('cell', ['gru', 'lstm'])
 @pytest.mark.parametrize('S,lens', [(256, [256] * 6), (7, [21, 7, 13, 30, 1, 44]), (5, [350]), (16, [50, 64, 33]), (3, [1200, 2])])
-def test_rnn_team_kernels_agree_with_per_step(monkeypatch, cell, S, lens):
+def test_rnn_team_kernels_agree_with_per_step(cell, S, lens):
     # H = 256 (the reference's GRU, the LSTM-256 configs): the four-workgroups-per-sequence persistent kernels
     # (rnn_team.hip) against the launch-per-step kernels on the same batch.  6 / 17 / 70 / 11 / 401 chunk sequences:
     # fewer teams than 8 (plain block -> team map), 16 teams with one sequence left over, more sequences than the 64
     # teams (two streams per team, then four with several sequences per stream: tag / ring continuity across sequence
     # boundaries, streams that retire early), every remainder of the step groups.  Each case also with the stream
     # count forced to 1, 2 and 4.  All differ only in summation order.
+    from dotaclient_amd import engine as E
     from dotaclient_amd.engine import Engine, pack_rollouts
     dev = torch.device('cuda:0')
     outs = {}
     for mode, ns in (('0', None), ('1', None), ('1', '1'), ('1', '2'), ('1', '4')):
-        monkeypatch.setenv('DC_RNN_TEAM', mode)
-        if ns is None: monkeypatch.delenv('DC_RNN_TEAM_NS', raising=False)
-        else: monkeypatch.setenv('DC_RNN_TEAM_NS', ns)
         eng = Engine(cell, 256, 1, dev)
+        eng.kernel_flags = E.DC_DIMS_RNN_PER_STEP if mode == '0' else (E.DC_DIMS_TEAM_NS(int(ns)) if ns else 0)
         eng.load_state_dict(synth.init_state_dict(7, cell, 256, 1))
         rollouts = synth.make_rollouts(78, lens)
         batch = pack_rollouts(rollouts, S, dev)
@@ -201,15 +203,16 @@ def test_rnn_team_kernels_agree_with_per_step(monkeypatch, cell, S, lens):
 
 
 @pytest.mark.parametrize('lens', [[128] * 4, [256] * 6, [384, 128, 256]])
-def test_sparse_pool_backward_matches_dense(monkeypatch, lens):
+def test_sparse_pool_backward_matches_dense(lens):
     # fused embedding path (rows % 128 == 0): the sparse max-pool backward of the two 16-unit types
     # (embed_sparse.hip) against the dense MFMA kernels on the same batch - gradients and post-step parameters
+    from dotaclient_amd import engine as E
     from dotaclient_amd.engine import Engine, pack_rollouts
     dev = torch.device('cuda:0')
     outs = {}
     for mode in ('0', '1'):
-        monkeypatch.setenv('DC_EMBED_SPARSE', mode)
         eng = Engine('lstm', 128, 1, dev)
+        eng.kernel_flags = E.DC_DIMS_DENSE_POOL_BWD if mode == '0' else 0
         eng.load_state_dict(synth.init_state_dict(7, 'lstm', 128, 1))
         rollouts = synth.make_rollouts(91, lens)
         batch = pack_rollouts(rollouts, 128, dev)
@@ -286,3 +289,69 @@ def test_backward_in_two_calls_equals_one_call(cell, hidden):
     (k0, up, emb0), (k1, emb1) = Hook.calls[-2:]
     assert k0 == 'upper' and up > 0 and emb0 == 0.0          # after the first call: upper gradients final, embedding ones still zero
     assert k1 == 'finish' and emb1 > 0
+
+
+@pytest.mark.parametrize('cell,hidden', [('lstm', 128), ('gru', 256)])
+def test_epoch_graph_replay_equals_eager(cell, hidden):
+    # Engine.train_epoch(graph=True): first epoch eager, second captured into a hipGraph and replayed, third a pure replay -
+    # against three eager epochs from the same start (same kernels, same order: differences only from the f64 atomics of
+    # the norm reduction)
+    from dotaclient_amd.engine import Engine, pack_rollouts
+    dev = torch.device('cuda:0')
+    rollouts = synth.make_rollouts(55, [128, 256, 128, 64])
+    outs = []
+    for graph in (False, True):
+        eng = Engine(cell, hidden, 1, dev)
+        eng.load_state_dict(synth.init_state_dict(7, cell, hidden, 1))
+        batch = pack_rollouts(rollouts, 64, dev)
+        chunks = eng.rollout_pass(batch, 64)
+        per = []
+        for ep in range(3):
+            res, status = eng.train_epoch(chunks, 5e-5, 5e-4, 0.5, graph=graph)
+            assert int(status.item()) == 0
+            per.append(res.cpu().numpy()[:11].copy())
+        if graph:
+            assert len(eng._graphs) == 1 and next(iter(eng._graphs.values()))['graph'] is not None
+        outs.append((np.stack(per), eng.params.cpu().numpy().copy(), eng.seg_step.cpu().numpy().copy()))
+    (r0, p0, s0), (r1, p1, s1) = outs
+    assert util.scaled_err(r1, r0) < 1e-6 and util.scaled_err(p1, p0) < 1e-7 and np.array_equal(s0, s1)
+
+
+def test_two_engines_on_two_streams_from_two_threads():
+    # include/dotaclient_hip.h: no state between calls, all scratch from the caller - so two engines with their own
+    # buffers can be driven from two host threads on two streams at once.  GRU-256 on 40 sequences each: two team-kernel
+    # grids of 160 workgroups compete for the 256 CUs, so neither is fully resident while the other runs - the ticketed
+    # roles of rnn_team.hip must still complete (no spin time-out, no NaN) and give each engine its sequential result.
+    import threading
+    from dotaclient_amd.engine import Engine, pack_rollouts
+    dev = torch.device('cuda:0')
+    S = 64
+    data = [synth.make_rollouts(61 + i, [S] * 40) for i in range(2)]
+
+    def run(i, stream, out):
+        with torch.cuda.stream(stream):
+            eng = Engine('gru', 256, 1, dev)
+            eng.load_state_dict(synth.init_state_dict(7 + i, 'gru', 256, 1))
+            batch = pack_rollouts(data[i], S, dev)
+            res = []
+            for it in range(3):
+                chunks = eng.rollout_pass(batch, S)
+                for ep in range(2):
+                    r, status = eng.train_epoch(chunks, 5e-5, 5e-4, 0.5)
+                    res.append(r.clone())
+            stream.synchronize()
+            assert int(eng.status.item()) == 0
+            out[i] = (torch.stack(res).cpu().numpy()[:, :11], eng.params.cpu().numpy().copy())
+
+    seq, par = {}, {}
+    for i in range(2):                                     # one after the other on the default stream
+        run(i, torch.cuda.current_stream(), seq)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    threads = [threading.Thread(target=run, args=(i, streams[i], par)) for i in range(2)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert set(par) == {0, 1}
+    for i in range(2):
+        assert np.all(np.isfinite(par[i][0]))
+        assert util.scaled_err(par[i][0], seq[i][0]) < 1e-6, i
+        assert util.scaled_err(par[i][1], seq[i][1]) < 1e-7, i

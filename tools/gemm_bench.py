@@ -38,7 +38,7 @@ def case(name, M, N, K, a_km, b_km, relu=False, aux=False, bias=False, count=1, 
     ax = torch.randn(M, N, device=dev) if aux else None
     lda = (lda or M) if a_km else K
     ldb = N if b_km else K
-    f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, a_km, b_km, bias=bz, relu=relu, aux=ax, ldaux=N)
+    f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, a_km, b_km, bias=bz, relu=relu, aux=ax, ldaux=N, scratch=SCRATCH)
     ms = t_ms(f)
     Am = A[:, :M].t() if a_km else A
     Bm = B if b_km else B.t()
@@ -60,7 +60,6 @@ def case(name, M, N, K, a_km, b_km, relu=False, aux=False, bias=False, count=1, 
 
 
 SCRATCH = torch.empty(8 << 20, device=dev)
-ops._lib.load().dc_gemm_set_scratch(ops._lib.ptr(SCRATCH), SCRATCH.numel())
 tot = 0.0
 print('--- forward')
 for U in (1, 5, 16):

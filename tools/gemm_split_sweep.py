@@ -12,7 +12,6 @@ NR = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 dev = torch.device('cuda:0')
 SCRATCH = torch.empty(16 << 20, device=dev)
-ops._lib.load().dc_gemm_set_scratch(ops._lib.ptr(SCRATCH), SCRATCH.numel())
 
 
 def t_us(fn, iters=30):
@@ -36,6 +35,6 @@ for name, M, N, lda in (('dW_heads', 154, H, 160), ('dW_ih', 4 * H, 256, None), 
     for sp in (0, 4, 8, 16, 32, 64):
         if sp and sp * M * N > SCRATCH.numel():
             continue
-        us = t_us(lambda: ops.gemm(A, B, C, M, N, NR, lda or M, N, N, True, True, splits=sp))
+        us = t_us(lambda: ops.gemm(A, B, C, M, N, NR, lda or M, N, N, True, True, splits=sp, scratch=SCRATCH))
         row.append('%s:%6.1f' % ('auto' if sp == 0 else sp, us))
     print('%-9s M=%4d N=%4d K=%6d  %s   (%.1f TF at the best)' % (name, M, N, NR, '  '.join(row), 2.0 * M * N * NR / min(float(r.split(':')[1]) for r in row) / 1e6))

@@ -14,8 +14,10 @@ try:
     print(j['value'], 'env-steps/s', j['ms_per_step'], 'ms/step')
     tot = 0
     for k in j['roofline']['kernels']:
-        print('%-28s n=%3d avg=%8.1f us  %6.3f ms  %6.1f TF' % (k['kernel'], k['launches_per_step'], k['avg_us'], k['ms_per_step'], k['achieved_tflops'])); tot += k['ms_per_step']
+        print('%-28s n=%3d avg=%8.1f us  %6.3f ms  %6.1f TF' % (k['kernel'], k['launches_per_step'], k['avg_us'], k['ms_per_step'], k.get('achieved_tflops') or 0.0)); tot += k['ms_per_step']
     print('profiled regions: %.3f ms' % tot)
+    print('secondary', json.dumps(j.get('secondary')))
+    print('epoch_graph', json.dumps(j.get('epoch_graph')))
 except Exception as e:
     print('bench failed', e); print(open('$OUT/bench.err').read()[-2000:])
 PY
