@@ -57,11 +57,81 @@ struct FastTile {
 };
 
 
-// one K step (BK = 32) of a wave's (TM x 32) x (TN x 32) output tile: 4 fragment groups, each read
-// feeds four v_mfma_f32_32x32x2_f32 per (row tile, column tile)
+// ---------------------------------------------------------------------------------------------------
+// fp32-grade products on the bf16 matrix cores (DC_GEMM_X3, the default).
+//
+// gfx950 has no reduced-precision fast path for f32 inputs (no xf32 / TF32) and its f32-input MFMA runs at the f32
+// VECTOR rate, 1/16 of the bf16 MFMA.  But an f32 splits EXACTLY into three bf16 pieces,
+//     x = h + m + l,   h = bf16(x),  m = bf16(x - h),  l = bf16(x - h - m)      (8 + 8 + 8 = 24 mantissa bits,
+// round-to-nearest pieces: every residual is exact in f32), every piece product is exact in f32, and
+//     a * b = hh + (hm + mh) + (hl + lh + mm) + O(2^-32 |ab|)
+// so six v_mfma_f32_32x32x16_bf16 (f32 accumulate) per K = 16 reproduce the f32 product to f32 round-off (measured on
+// the network's shapes, tools/ubench/gemm_x3.hip: max error 1.4e-7 .. 5.5e-7 of max |C| against an f64 reference, the
+// k-ordered f32 fma chain of the f32 MFMA: 2.1e-7 .. 3.7e-7) for 6 x 32 = 192 matrix-pipe cycles instead of the
+// 8 x 64 = 512 of eight v_mfma_f32_32x32x2_f32: a 2.67x higher ceiling (419 TF).  The split is VALU work done on the
+// fragments right after their LDS reads (v_cvt_pk_bf16_f32 + subtract, ~5.5 instructions per element), issued
+// between the MFMAs.  Build with -DDC_GEMM_X3=0 for the exact-f32 MFMA products (the A/B reference).
+// ---------------------------------------------------------------------------------------------------
+#ifndef DC_GEMM_X3
+#define DC_GEMM_X3 1
+#endif
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {   // {bf16(hi), bf16(lo)}, round to nearest even
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+struct Split3 { bf16x8 h, m, l; };
+// eight f32 (two fragment reads) -> three bf16x8 MFMA operands
+__device__ __forceinline__ Split3 split3(const float4& x0, const float4& x1) {
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        h[i] = cvt_pk_bf16(a, b);
+        const float ra = a - __uint_as_float(h[i] << 16), rb = b - __uint_as_float(h[i] & 0xffff0000u);
+        m[i] = cvt_pk_bf16(ra, rb);
+        const float sa = ra - __uint_as_float(m[i] << 16), sb = rb - __uint_as_float(m[i] & 0xffff0000u);
+        l[i] = cvt_pk_bf16(sa, sb);
+    }
+    Split3 s;
+    s.h = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]});
+    s.m = __builtin_bit_cast(bf16x8, u32x4{m[0], m[1], m[2], m[3]});
+    s.l = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
+    return s;
+}
+
+// one K step (BK = 32) of a wave's (TM x 32) x (TN x 32) output tile.
+// DC_GEMM_X3: two K = 16 sub-steps; lane (i = lane & 31, q = lane >> 5) contracts k = 16s + 4q + e and 16s + 8 + 4q + e
+// (e = 0..3) - two ds_read_b128 per operand block, the same k permutation on both operands - split into bf16 pieces, six
+// MFMAs per (row tile, column tile), smallest terms first.
+// else: 4 fragment groups, each read feeds four v_mfma_f32_32x32x2_f32 per (row tile, column tile)
 template <class LA, class LB, int TM, int TN>
 __device__ __forceinline__ void mma_kstep(const float* __restrict__ a_s, const float* __restrict__ b_s, int a_row0, int b_row0,
                                           int fr, int fq, f32x16 (&acc)[TM][TN]) {
+#if DC_GEMM_X3
+#pragma unroll
+    for (int s = 0; s < GEMM_BK / 16; ++s) {
+        Split3 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            a[i] = split3(LA::frag(a_s, a_row0 + i * 32 + fr, 2 * s, fq), LA::frag(a_s, a_row0 + i * 32 + fr, 2 * s + 1, fq));
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+            b[i] = split3(LB::frag(b_s, b_row0 + i * 32 + fr, 2 * s, fq), LB::frag(b_s, b_row0 + i * 32 + fr, 2 * s + 1, fq));
+        // piece-major order: the TM x TN accumulators take turns, so consecutive MFMAs never chain on one accumulator
+#define DC_MMA_P(X, Y)                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                          \
+            _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                                   \
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].X, b[jn].Y, acc[i][jn], 0, 0, 0);
+        DC_MMA_P(l, h) DC_MMA_P(h, l) DC_MMA_P(m, m) DC_MMA_P(m, h) DC_MMA_P(h, m) DC_MMA_P(h, h)
+#undef DC_MMA_P
+    }
+#else
 #pragma unroll
     for (int j = 0; j < GEMM_BK / 8; ++j) {
         float4 af[TM], bf[TN];
@@ -75,16 +145,10 @@ __device__ __forceinline__ void mma_kstep(const float* __restrict__ a_s, const f
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                          \
             _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                                   \
                 acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].E, bf[jn].E, acc[i][jn], 0, 0, 0);
-#ifdef DC_MMA_SETPRIO
-        __builtin_amdgcn_s_setprio(1);      // experiment (A/B build): the wave inside its MFMA burst wins issue arbitration -
-                                            // measured 2-7 % SLOWER on every MFMA kernel of the step
-#endif
         DC_MMA_E(x) DC_MMA_E(y) DC_MMA_E(z) DC_MMA_E(w)
-#ifdef DC_MMA_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
 #undef DC_MMA_E
     }
+#endif
 }
 
 }  // namespace dc
