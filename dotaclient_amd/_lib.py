@@ -25,6 +25,8 @@ SIGNATURES = {
     'dc_advantage_returns': (c_int, [c_ptr, c_ptr, c_int, c_dbl, c_dbl, c_ptr, c_ptr, c_ptr]),
     'dc_gemm_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                             c_ptr, c_int, c_ptr, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
+    'dc_gemm_x3': (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                           c_ptr, c_int, c_ptr, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
     'dc_dp_average_grads': (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_flt, c_ptr]),
     'dc_pack_rows': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int]),
     'dc_profile_enable': (c_int, [c_int]),

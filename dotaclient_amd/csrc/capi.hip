@@ -66,6 +66,31 @@ int dc_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, i
                         splits, (hipStream_t)stream, dc::GemmScratch{scratch, (long long)scratch_floats});
 }
 
+int dc_gemm_x3(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+               int a_kmajor, int b_kmajor, const float* bias, int relu, const float* aux, int ldaux,
+               int accumulate, int prec, float* scratch, int64_t scratch_floats, dc_stream_t stream) {
+    DC_ENTER();
+    using namespace dc;
+    hipStream_t s = (hipStream_t)stream;
+    X3Gemm g;
+    g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.nbias = N; g.relu = relu; g.aux = aux; g.ldaux = ldaux;
+    g.accumulate = accumulate; g.prec = prec == 1 ? 1 : 6;
+    if (a_kmajor && b_kmajor) {
+        g.A = A; g.a_mode = X3_KMAJ; g.lda = lda; g.B = B; g.b_mode = X3_KMAJ; g.ldb = ldb;
+        g.scratch = GemmScratch{scratch, (long long)scratch_floats};
+        return gemm_x3(g, s);
+    }
+    if (a_kmajor) { set_error("dc_gemm_x3: a_kmajor needs b_kmajor", 1007); return 1007; }
+    const long long plane_floats = ((long long)3 * N * K + 1) / 2;
+    if (scratch == nullptr || scratch_floats < plane_floats) { set_error("dc_gemm_x3: scratch too small for the weight planes", 1008); return 1008; }
+    // B: [N][ldb] (x W^T) or [K][ldb] (dy W): planes [3][N][K] either way
+    X3SplitJob job{B, reinterpret_cast<uint16_t*>(scratch), b_kmajor ? K : N, b_kmajor ? N : K, ldb, b_kmajor ? 1 : 0, b_kmajor ? K : N};
+    if (int e = split_weight_planes(&job, 1, g.prec, s)) return e;
+    g.A = A; g.a_mode = X3_ROW; g.lda = lda;
+    g.B = scratch; g.b_mode = X3_PLANES; g.ldb = K; g.b_plane = (long long)N * K; g.transposed_w = b_kmajor;
+    return gemm_x3(g, s);
+}
+
 int64_t dc_workspace_layout(const dc_dims* dims, int64_t* offsets) { return dc::workspace_layout(dims, offsets); }
 
 int dc_policy_forward(const dc_dims* dims, const float* params, const int64_t* poff_host, const float* obs,

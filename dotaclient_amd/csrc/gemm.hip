@@ -422,6 +422,14 @@ int splitk_reduce(const float* slab, float* C, int M, int N, int ldc, int splits
     return launch_check("splitk_reduce");
 }
 
+int splitk_reduce_pair(const float* slab, float* C, int M, int N, int ldc, int splits, int accumulate, float* C2, int ldc2,
+                       int n_split, hipStream_t s) {
+    const long long mn = (long long)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, s, slab, C, M, N, ldc, splits,
+                       (const float*)nullptr, accumulate, C2, ldc2, n_split);
+    return launch_check("splitk_reduce_pair");
+}
+
 template <int BM, int BN, bool A_KM, bool B_KM>
 static int launch_gemm(const GemmArgs& a, int splits, hipStream_t stream) {
     using LA = TileLoader<BM, A_KM>;

@@ -1,0 +1,409 @@
+// GEMM for the network's dense products on the bf16 matrix cores, f32-grade by exact 3-way splitting (PREC = 6), or
+// plain bf16 operands with f32 accumulate (PREC = 1, the bf16 path of BASELINE.json configs[4]).
+//
+// Replaces the arithmetic torch's nn.Linear forward/backward does for /root/reference/policy.py:54-75,138-155
+// (affine_pre_rnn, the recurrent cell's input projection, the head projections) and their autograd products.
+//
+// Why.  gfx950 has no reduced-precision fast path for f32 inputs, and its f32-input MFMA runs at 1/16 of the bf16 rate.
+// An f32 value splits exactly into three bf16 pieces (x = h + m + l, gemm_tiles.h), so
+//     a b = hh + (hm + mh) + (hl + lh + mm) + O(2^-32 |ab|):
+// six v_mfma_f32_32x32x16_bf16 per K = 16 give the f32 product to f32 round-off at 6 x 32 matrix-pipe cycles instead of
+// the 8 x 64 of the f32 MFMA.  The first version of this idea (mma_kstep in gemm_tiles.h, still used by the fused
+// embedding kernels) split the fragments AFTER their LDS reads, i.e. every element twice per workgroup and inside the
+// MFMA loop: the fwd / dX products went 118 -> 150 TF and stopped there, VALU-bound.  Here:
+//   * SPLIT ON LOAD: an operand tile goes global -> registers -> split once -> LDS as three bf16 planes; the MFMA loop
+//     only reads ready fragments (one ds_read_b128 per plane and 32 x 16 block);
+//   * WEIGHTS ARRIVE PRE-SPLIT: a small pre-pass per epoch writes every weight matrix as bf16 planes, in the orientation
+//     its consumer contracts over (W for the forward, W^T for dX), so the weight operand needs no VALU work at all;
+//   * k-major operands (both sides of the weight-gradient products, contraction over the env-steps) are packed in
+//     pairs along k while they are split and stored kpair-major, so the stores are 16-byte and the fragment reads
+//     conflict-free ds_read_b32;
+//   * the epilogue goes through LDS and stores 16 bytes per lane (a K = 256 product spends as long in a 4-byte-per-lane
+//     epilogue as in its main loop).
+// Tile 128 x 128 x 16, 256 threads (2 x 2 waves of 64 x 64), two stages of 36 KB: two workgroups per CU.
+#include "kernels.h"
+#include "gemm_tiles.h"
+
+namespace dc {
+namespace {
+
+enum { XB = 128, XK = 16 };
+enum { RM_ROW_BYTES = 48, RM_PLANE = XB * RM_ROW_BYTES /* 6144 */, KM_PLANE = 8 * XB * 4 /* 4096 */ };
+enum { OPER_BYTES = 3 * RM_PLANE, STAGE_BYTES = 2 * OPER_BYTES, X3_LDS = 2 * STAGE_BYTES /* 73728 */ };
+enum { EP_LD = 68 };   // floats per row of a wave's 64 x 64 epilogue image (4 x 64 x 68 x 4 = 69632 <= X3_LDS)
+
+struct X3Args {
+    const void* A; const void* B; const void* B2;
+    float* C; float* C2; const float* bias; const float* aux; float* slab;
+    long long a_plane, b_plane, b2_plane;   // plane strides (elements) of pre-split operands
+    int M, N, K, lda, ldb, ldb2, ldc, ldc2, ldaux, n_split, k_per_split, relu, accumulate, nbias;
+};
+
+// ---- operand loaders: global -> registers (issued one K step ahead) -> split -> LDS planes ---------------------------
+// MODE X3_ROW   : f32 [rows][ld], k contiguous           -> planes [row][16 k] bf16, 48-byte rows
+// MODE X3_KMAJ  : f32 [k][ld], rows contiguous           -> planes [8 kpairs][128 rows] u32
+// MODE X3_PLANES: bf16 [NP][rows][ld] pre-split weights  -> planes [row][16 k] bf16 (no arithmetic)
+template <int MODE, int NP>
+struct X3Loader {
+    struct Regs { float4 v[2]; u32x4 w[NP]; };   // one staged K step of this thread (only the members its MODE uses are live)
+    const char* src[2];
+    long long step;        // bytes per K step
+    long long plane;       // bytes between planes (X3_PLANES)
+
+    __device__ __forceinline__ void init(const void* P, int ld, long long plane_elems, int r_base, int R, int k0, int tid) {
+        if constexpr (MODE == X3_ROW) {
+            const int kc = (tid & 3) * 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = min(r_base + (tid >> 2) + 64 * i, R - 1);
+                src[i] = reinterpret_cast<const char*>(static_cast<const float*>(P) + (size_t)row * ld + k0 + kc);
+            }
+            step = XK * 4;
+        } else if constexpr (MODE == X3_KMAJ) {
+            const int kp = tid >> 5;
+            const int c = min(r_base + (tid & 31) * 4, ld - 4);   // stay inside the physical row (columns past R are never stored)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                src[i] = reinterpret_cast<const char*>(static_cast<const float*>(P) + (size_t)(k0 + 2 * kp + i) * ld + c);
+            step = (long long)XK * ld * 4;
+        } else {
+            const int row = min(r_base + (tid >> 1), R - 1);
+            src[0] = reinterpret_cast<const char*>(static_cast<const uint16_t*>(P) + (size_t)row * ld + k0 + (tid & 1) * 8);
+            src[1] = nullptr;
+            step = XK * 2;
+            plane = plane_elems * 2;
+        }
+    }
+    __device__ __forceinline__ void load(Regs& r) {
+        if constexpr (MODE == X3_PLANES) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) r.w[p] = *reinterpret_cast<const u32x4*>(src[0] + p * plane);
+            src[0] += step;
+        } else {
+            r.v[0] = *reinterpret_cast<const float4*>(src[0]);
+            r.v[1] = *reinterpret_cast<const float4*>(src[1]);
+            src[0] += step; src[1] += step;
+        }
+    }
+    // split2: two f32 -> packed bf16 pairs of the three pieces (low half = first argument)
+    static __device__ __forceinline__ void split2(float a, float b, unsigned (&o)[3]) {
+        o[0] = cvt_pk_bf16(a, b);
+        if constexpr (NP > 1) {
+            const float ra = a - __uint_as_float(o[0] << 16), rb = b - __uint_as_float(o[0] & 0xffff0000u);
+            o[1] = cvt_pk_bf16(ra, rb);
+            const float sa = ra - __uint_as_float(o[1] << 16), sb = rb - __uint_as_float(o[1] & 0xffff0000u);
+            o[2] = cvt_pk_bf16(sa, sb);
+        }
+    }
+    static __device__ __forceinline__ void store(const Regs& r, char* __restrict__ S, int tid) {
+        const float4 (&v)[2] = r.v;
+        const u32x4 (&w)[NP] = r.w;
+        if constexpr (MODE == X3_ROW) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                unsigned lo[3], hi[3];
+                split2(v[i].x, v[i].y, lo);
+                split2(v[i].z, v[i].w, hi);
+                char* d = S + ((tid >> 2) + 64 * i) * RM_ROW_BYTES + (tid & 3) * 8;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(d + p * RM_PLANE) = make_uint2(lo[p], hi[p]);
+            }
+        } else if constexpr (MODE == X3_KMAJ) {
+            // v[0] = k even, v[1] = k odd, four consecutive rows each: pack the pair along k
+            unsigned q[4][3];
+            split2(v[0].x, v[1].x, q[0]); split2(v[0].y, v[1].y, q[1]); split2(v[0].z, v[1].z, q[2]); split2(v[0].w, v[1].w, q[3]);
+            char* d = S + ((tid >> 5) * XB + (tid & 31) * 4) * 4;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d + p * KM_PLANE) = u32x4{q[0][p], q[1][p], q[2][p], q[3][p]};
+        } else {
+            char* d = S + (tid >> 1) * RM_ROW_BYTES + (tid & 1) * 16;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d + p * RM_PLANE) = w[p];
+        }
+    }
+    // the 8 k values (8g .. 8g+7) of tile row r, plane p, as an MFMA operand
+    static __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, int r, int g, int p) {
+        if constexpr (MODE == X3_KMAJ) {
+            const unsigned* s = reinterpret_cast<const unsigned*>(S + p * KM_PLANE) + (4 * g) * XB + r;
+            return __builtin_bit_cast(bf16x8, u32x4{s[0], s[XB], s[2 * XB], s[3 * XB]});
+        } else {
+            return *reinterpret_cast<const bf16x8*>(S + p * RM_PLANE + r * RM_ROW_BYTES + g * 16);
+        }
+    }
+};
+
+static __device__ __forceinline__ int p_splits(const X3Args& p) { return (p.K + p.k_per_split - 1) / p.k_per_split; }
+
+// epilogue of one work item
+template <int PREC>
+static __device__ __forceinline__ void store_tile(const X3Args& p, f32x16 (&acc)[2][2], char* smem, int m_blk, int n_blk, int z, int wave,
+                                                  int wm, int wn, int lane) {
+    const int fr = lane & 31, fg = lane >> 5;
+    // ---- epilogue: accumulators -> this wave's 64 x 64 LDS image -> 16-byte rows ----------------------------------------
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float* img = reinterpret_cast<float*>(smem) + wave * (64 * EP_LD);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                img[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * EP_LD + j * 32 + fr] = acc[i][j][r];
+    // (each wave reads back only what it wrote: no workgroup barrier needed, the LDS is in order per wave)
+    const int c4 = (lane & 15) * 4;
+    const int col = n_blk + wn * 64 + c4;
+    const bool col_ok = col < p.N;            // N is a multiple of 4 wherever this kernel is used (host check)
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias != nullptr && p.slab == nullptr) {
+        if (col + 0 < p.nbias) bv.x = p.bias[col + 0];
+        if (col + 1 < p.nbias) bv.y = p.bias[col + 1];
+        if (col + 2 < p.nbias) bv.z = p.bias[col + 2];
+        if (col + 3 < p.nbias) bv.w = p.bias[col + 3];
+    }
+    const bool to_c2 = p.n_split > 0 && col >= p.n_split;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int rl = it * 4 + (lane >> 4);
+        const int row = m_blk + wm * 64 + rl;
+        float4 v = *reinterpret_cast<const float4*>(img + rl * EP_LD + c4);
+        if (row >= p.M || !col_ok) continue;
+        if (p.slab != nullptr) {
+            *reinterpret_cast<float4*>(p.slab + ((size_t)z * p.M + row) * p.N + col) = v;
+            continue;
+        }
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (p.aux != nullptr) {
+            const float4 m = *reinterpret_cast<const float4*>(p.aux + (size_t)row * p.ldaux + col);
+            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        }
+        float* c = to_c2 ? p.C2 + (size_t)row * p.ldc2 + (col - p.n_split) : p.C + (size_t)row * p.ldc + col;
+        if (p.accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(c);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        *reinterpret_cast<float4*>(c) = v;
+    }
+}
+
+// Persistent: a workgroup walks the (row tile, column tile, K split) work items w = first, first + stride, ...; the loads
+// of the NEXT item's first two K steps are issued before the epilogue of the current one.  Inside an item the loads run
+// two K steps ahead of the MFMAs (two register staging sets), the split + LDS store one step ahead (two LDS stages).
+template <int PREC, int A_MODE, int B_MODE>
+__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args p, int n_items, int mt, int nt) {
+    constexpr int NP = PREC == 1 ? 1 : 3;
+    using LA = X3Loader<A_MODE, NP>;
+    using LB = X3Loader<B_MODE, NP>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 31, fg = lane >> 5;
+
+    // work item -> (m tile, n tile, split).  With a multiple of 8 row tiles, the workgroups of one XCD (blockIdx & 7 under the
+    // usual round-robin placement - a speed hint only) take the column tiles of the same row tile one after the other, so
+    // the A rows they share stay in that XCD's L2.
+    const bool xcd_map = (mt & 7) == 0 && (gridDim.x & 7) == 0;
+    auto decode = [&](int it, int& m_blk, int& n_blk, int& z) -> bool {
+        int w;
+        if (xcd_map) {
+            const int per = n_items >> 3;                                   // items per XCD slice
+            const int wi = it * (gridDim.x >> 3) + (blockIdx.x >> 3);
+            if (wi >= per) return false;
+            const int x = blockIdx.x & 7;
+            const int per_m = nt * p_splits(p);
+            const int ml = wi / per_m, rest = wi - ml * per_m;
+            m_blk = (ml * 8 + x) * XB; n_blk = (rest % nt) * XB; z = rest / nt;
+            (void)w;
+            return true;
+        }
+        w = it * gridDim.x + blockIdx.x;
+        if (w >= n_items) return false;
+        const int tiles = mt * nt;
+        z = w / tiles;
+        const int t = w - z * tiles;
+        m_blk = (t / nt) * XB; n_blk = (t % nt) * XB;
+        return true;
+    };
+
+    LA la;
+    LB lb;
+    typename LA::Regs ra0, ra1;
+    typename LB::Regs rb0, rb1;
+    int nk = 0;
+    auto open_item = [&](int m_blk, int n_blk, int z) {       // address state + the loads of K steps 0 and 1
+        const int k_begin = z * p.k_per_split;
+        nk = (min(p.K, k_begin + p.k_per_split) - k_begin) / XK;
+        // B of this column tile: the second operand of a pair behind n_split (workgroup-uniform)
+        const bool second = p.n_split > 0 && n_blk >= p.n_split;
+        la.init(p.A, p.lda, p.a_plane, m_blk, p.M, k_begin, tid);
+        lb.init(second ? p.B2 : p.B, second ? p.ldb2 : p.ldb, second ? p.b2_plane : p.b_plane, second ? n_blk - p.n_split : n_blk,
+                p.n_split > 0 ? (second ? p.N - p.n_split : p.n_split) : p.N, k_begin, tid);
+        la.load(ra0); lb.load(rb0);
+        if (nk > 1) { la.load(ra1); lb.load(rb1); }
+    };
+
+    int m_blk, n_blk, z;
+    if (!decode(0, m_blk, n_blk, z)) return;
+    open_item(m_blk, n_blk, z);
+    for (int it = 0;; ++it) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        LA::store(ra0, smem, tid); LB::store(rb0, smem + OPER_BYTES, tid);
+        __syncthreads();
+        // one K step: loads of step kt + 2 -> the staging set that step kt just vacated; MFMAs of step kt; split + store of kt + 1
+        auto kstep = [&](int kt, typename LA::Regs& ra_cur, typename LB::Regs& rb_cur, const typename LA::Regs& ra_nxt,
+                         const typename LB::Regs& rb_nxt) {
+            if (kt + 2 < nk) { la.load(ra_cur); lb.load(rb_cur); }
+            const char* a_s = smem + (kt & 1) * STAGE_BYTES;
+            const char* b_s = a_s + OPER_BYTES;
+            bf16x8 a[2][NP], b[2][NP];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    a[i][q] = LA::frag(a_s, wm * 64 + i * 32 + fr, fg, q);
+                    b[i][q] = LB::frag(b_s, wn * 64 + i * 32 + fr, fg, q);
+                }
+            // piece-major order, smallest terms first: the four accumulators take turns, consecutive MFMAs never chain
+#define DC_X3_P(X, Y)                                                                                             \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][X], b[j][Y], acc[i][j], 0, 0, 0);
+            if constexpr (PREC == 6) { DC_X3_P(2, 0) DC_X3_P(0, 2) DC_X3_P(1, 1) DC_X3_P(1, 0) DC_X3_P(0, 1) }
+            DC_X3_P(0, 0)
+#undef DC_X3_P
+            if (kt + 1 < nk) {
+                char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+                LA::store(ra_nxt, nxt, tid); LB::store(rb_nxt, nxt + OPER_BYTES, tid);
+            }
+            __syncthreads();
+        };
+        for (int kt = 0; kt < nk; kt += 2) {
+            kstep(kt, ra0, rb0, ra1, rb1);
+            if (kt + 1 < nk) kstep(kt + 1, ra1, rb1, ra0, rb0);
+        }
+
+        // the next item's first loads fly during this item's epilogue
+        const int cm = m_blk, cn = n_blk, cz = z;
+        const bool have_next = decode(it + 1, m_blk, n_blk, z);
+        if (have_next) open_item(m_blk, n_blk, z);
+        store_tile<PREC>(p, acc, smem, cm, cn, cz, wave, wm, wn, lane);
+        if (!have_next) break;
+        __syncthreads();          // the epilogue images live in the stage buffers the next item is about to fill
+    }
+}
+
+// weights -> bf16 planes, in the orientation the consumer contracts over
+struct SplitJob { const float* src; uint16_t* dst; int rows, cols, ld, transpose, rows_pad; };
+struct SplitJobs { SplitJob j[8]; int n; };
+template <int NP>
+__global__ __launch_bounds__(256) void split_planes_kernel(SplitJobs jobs) {
+    const SplitJob jb = jobs.j[blockIdx.y];
+    const int n_out_rows = jb.transpose ? jb.cols : jb.rows_pad, n_out_cols = jb.transpose ? jb.rows_pad : jb.cols;
+    const long long total = (long long)n_out_rows * n_out_cols;
+    for (long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 2; e < total; e += (long long)gridDim.x * 512) {
+        const int orow = (int)(e / n_out_cols), ocol = (int)(e - (long long)orow * n_out_cols);   // n_out_cols is even
+        float x[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = jb.transpose ? ocol + i : orow, c = jb.transpose ? orow : ocol + i;
+            x[i] = r < jb.rows ? jb.src[(size_t)r * jb.ld + c] : 0.f;   // rows_pad > rows: zero rows (K padding of dH)
+        }
+        unsigned o[3];
+        X3Loader<X3_ROW, NP>::split2(x[0], x[1], o);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<unsigned*>(jb.dst + p * total + e) = o[p];
+    }
+}
+
+}  // namespace
+
+bool gemm_x3_shape_ok(int M, int N, int K, int lda, int ldb, int a_mode, int b_mode) {
+    if (K % XK || (N & 3) || M <= 0 || N <= 0) return false;
+    if (a_mode == X3_ROW && (lda & 3)) return false;
+    if (a_mode == X3_KMAJ && ((lda & 3) || lda < 4)) return false;
+    if (b_mode == X3_KMAJ && ((ldb & 3) || ldb < 4)) return false;
+    if (b_mode == X3_PLANES && (ldb & 7)) return false;
+    return true;
+}
+
+template <int PREC, int AM, int BM_>
+static int launch_x3(const X3Args& a, int splits, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_x3_kernel<PREC, AM, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+        if (e != hipSuccess) { set_error("gemm_x3: hipFuncSetAttribute", (int)e); return (int)e; }
+        attr_done = true;
+    }
+    const int mt = (a.M + XB - 1) / XB, nt = (a.N + XB - 1) / XB;
+    const int n_items = mt * nt * splits;
+    static const int slots = [] {      // two workgroups per CU (LDS-limited)
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        return 2 * cus;
+    }();
+    const int grid = n_items < slots ? n_items : slots;
+    hipLaunchKernelGGL((gemm_x3_kernel<PREC, AM, BM_>), dim3(grid), dim3(256), X3_LDS, s, a, n_items, mt, nt);
+    return launch_check("gemm_x3");
+}
+
+// C[M,N] (op)= A * B^T-ish: A per a_mode (X3_ROW [M][lda] or X3_KMAJ [K][lda]), B per b_mode (X3_PLANES [NP][N][ldb] bf16,
+// X3_KMAJ [K][ldb] f32); optional second B behind column n_split (the dW_ih | dW_hh pair); split-K through the slab.
+int gemm_x3(const X3Gemm& g, hipStream_t stream) {
+    if (g.M <= 0 || g.N <= 0) return 0;
+    if (!gemm_x3_shape_ok(g.M, g.N, g.K, g.lda, g.ldb, g.a_mode, g.b_mode)) { set_error("gemm_x3: unsupported shape", 1004); return 1004; }
+    X3Args a{};
+    a.A = g.A; a.B = g.B; a.B2 = g.B2; a.C = g.C; a.C2 = g.C2; a.bias = g.bias; a.aux = g.aux; a.slab = nullptr;
+    a.a_plane = 0; a.b_plane = g.b_plane; a.b2_plane = g.b2_plane;
+    a.M = g.M; a.N = g.N; a.K = g.K; a.lda = g.lda; a.ldb = g.ldb; a.ldb2 = g.ldb2; a.ldc = g.ldc; a.ldc2 = g.ldc2; a.ldaux = g.ldaux;
+    a.n_split = g.n_split; a.relu = g.relu; a.accumulate = g.accumulate; a.nbias = g.bias ? g.nbias : 0;
+    int splits = 1;
+    const long tiles = (long)((g.M + XB - 1) / XB) * ((g.N + XB - 1) / XB);
+    if (tiles < 256 && g.K >= 4096 && !g.relu && g.aux == nullptr && g.scratch.p != nullptr) {
+        long want = 512 / tiles;                  // two workgroups per CU
+        if (want < 1) want = 1;
+        const long maxs = g.K / 512;
+        splits = (int)(want < maxs ? want : maxs);
+        if (splits < 1) splits = 1;
+        while (splits > 1 && (long long)splits * g.M * g.N > g.scratch.floats) --splits;
+    }
+    int kper = (g.K + splits - 1) / splits;
+    kper = (kper + XK - 1) / XK * XK;
+    splits = (g.K + kper - 1) / kper;
+    a.k_per_split = kper;
+    if (splits > 1) a.slab = g.scratch.p;
+    const char* name = g.a_mode == X3_KMAJ ? "gemm_f32_dW(TN,split-K)" : (g.transposed_w ? "gemm_f32_dX(NN)" : "gemm_f32_fwd(NT)");
+    ProfScope prof(name, 2.0 * g.M * (double)g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N), stream);
+    int rc;
+    if (g.a_mode == X3_ROW && g.b_mode == X3_PLANES) rc = g.prec == 1 ? launch_x3<1, X3_ROW, X3_PLANES>(a, splits, stream) : launch_x3<6, X3_ROW, X3_PLANES>(a, splits, stream);
+    else if (g.a_mode == X3_KMAJ && g.b_mode == X3_KMAJ) rc = g.prec == 1 ? launch_x3<1, X3_KMAJ, X3_KMAJ>(a, splits, stream) : launch_x3<6, X3_KMAJ, X3_KMAJ>(a, splits, stream);
+    else { set_error("gemm_x3: operand layout combination not built", 1005); return 1005; }
+    if (rc == 0 && splits > 1) {
+        // C = (C +) sum_z slab[z]; the pair form scatters columns >= n_split into C2
+        rc = splitk_reduce_pair(a.slab, g.C, g.M, g.N, g.ldc, splits, g.accumulate, g.C2, g.ldc2, g.n_split, stream);
+    }
+    return rc;
+}
+
+int split_weight_planes(const X3SplitJob* jobs, int n, int prec, hipStream_t s) {
+    if (n <= 0) return 0;
+    if (n > 8) { set_error("split_weight_planes: too many jobs", 1006); return 1006; }
+    SplitJobs sj{};
+    sj.n = n;
+    for (int i = 0; i < n; ++i) {
+        sj.j[i] = SplitJob{jobs[i].src, jobs[i].dst, jobs[i].rows, jobs[i].cols, jobs[i].ld, jobs[i].transpose,
+                           jobs[i].rows_pad > jobs[i].rows ? jobs[i].rows_pad : jobs[i].rows};
+    }
+    if (prec == 1) hipLaunchKernelGGL(split_planes_kernel<1>, dim3(64, n), dim3(256), 0, s, sj);
+    else hipLaunchKernelGGL(split_planes_kernel<3>, dim3(64, n), dim3(256), 0, s, sj);
+    return launch_check("split_weight_planes");
+}
+
+}  // namespace dc

@@ -57,6 +57,28 @@ int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int 
 int gemm_f32_tn_pair(const float* A, int lda, const float* B1, int ldb1, int N1, const float* B2, int ldb2, int N2, float* C1,
                      int ldc1, float* C2, int ldc2, int M, int K, hipStream_t stream, GemmScratch sc);   // [C1 | C2] = A^T [B1 | B2], one launch
 int splitk_reduce(const float* slab, float* C, int M, int N, int ldc, int splits, hipStream_t s);   // C = sum_z slab[z]
+// C (+)= sum_z slab[z]; columns >= n_split (> 0) go to C2 (the dW_ih | dW_hh pair)
+int splitk_reduce_pair(const float* slab, float* C, int M, int N, int ldc, int splits, int accumulate, float* C2, int ldc2,
+                       int n_split, hipStream_t s);
+// gemm_x3.hip: the dense products on the bf16 matrix cores (prec 6: f32-grade by exact 3-way splitting; prec 1: plain bf16)
+enum { X3_ROW = 0, X3_KMAJ = 1, X3_PLANES = 2 };
+struct X3Gemm {
+    const void* A = nullptr; int a_mode = X3_ROW, lda = 0;             // X3_ROW: f32 [M][lda]; X3_KMAJ: f32 [K][lda]
+    const void* B = nullptr; int b_mode = X3_PLANES, ldb = 0;          // X3_PLANES: bf16 [planes][N][ldb]; X3_KMAJ: f32 [K][ldb]
+    long long b_plane = 0;                                            // elements between planes
+    const void* B2 = nullptr; int ldb2 = 0; long long b2_plane = 0;   // second B behind output column n_split
+    float* C = nullptr; int ldc = 0; float* C2 = nullptr; int ldc2 = 0; int n_split = 0;
+    int M = 0, N = 0, K = 0;
+    const float* bias = nullptr; int nbias = 0;                       // bias[col] for col < nbias
+    int relu = 0; const float* aux = nullptr; int ldaux = 0;          // zero where aux <= 0
+    int accumulate = 0, prec = 6, transposed_w = 0;
+    GemmScratch scratch;
+};
+bool gemm_x3_shape_ok(int M, int N, int K, int lda, int ldb, int a_mode, int b_mode);
+int gemm_x3(const X3Gemm& g, hipStream_t stream);
+// weight matrices -> bf16 planes [prec == 1 ? 1 : 3][rows_pad (zero rows past `rows`)][cols], or of the transpose
+struct X3SplitJob { const float* src; uint16_t* dst; int rows, cols, ld, transpose, rows_pad; };
+int split_weight_planes(const X3SplitJob* jobs, int n, int prec, hipStream_t s);
 // n_groups (<= 8) independent reductions in one launch: C[g] (dense M x N) = sum of slabs [begin[g], begin[g+1])
 int splitk_reduce_grouped(const float* slab, float* C, int M, int N, int n_groups, const int* begin, hipStream_t s);
 // embed.hip

@@ -30,6 +30,32 @@ struct Grads {
 
 static inline int64_t align_up(int64_t x) { return (x + 255) / 256 * 256; }
 
+// Weight matrices the dense products read as pre-split bf16 planes (gemm_x3.hip), in this order: affine_pre_rnn [256][896],
+// the recurrent input projections [G*H][in_l], the head block zero-padded to [160][H].  Elements of one orientation.
+static inline int64_t wplane_elems(const dc_dims* d) {
+    const int64_t H = d->hidden, G = d->cell == 0 ? 3 : 4;
+    int64_t e = (int64_t)PREW * XCATW + (int64_t)HO_LD * H;
+    for (int l = 0; l < d->layers; ++l) e += G * H * (l == 0 ? PREW : H);
+    return e;
+}
+struct WPlanes {              // where each matrix's planes start inside DC_WS_WPLANES (element offsets per plane set)
+    uint16_t* base;           // forward orientation at base, transposed orientation at base + 3 * total
+    int64_t total, pre, heads, ih[DC_MAX_LAYERS];
+    uint16_t* fwd(int64_t off) const { return base + 3 * off; }                  // planes of one matrix are contiguous: [3][rows][cols]
+    uint16_t* bwd(int64_t off) const { return base + 3 * total + 3 * off; }
+};
+static WPlanes wplanes_of(const dc_dims* d, char* ws_base, const int64_t* off) {
+    WPlanes w;
+    w.base = reinterpret_cast<uint16_t*>(ws_base + off[DC_WS_WPLANES]);
+    w.total = wplane_elems(d);
+    const int64_t H = d->hidden, G = d->cell == 0 ? 3 : 4;
+    int64_t o = 0;
+    w.pre = o; o += (int64_t)PREW * XCATW;
+    w.heads = o; o += (int64_t)HO_LD * H;
+    for (int l = 0; l < d->layers; ++l) { w.ih[l] = o; o += G * H * (l == 0 ? PREW : H); }
+    return w;
+}
+
 // offsets (bytes) of every workspace buffer; returns total bytes.  out must hold
 // DC_WS_FIXED + DC_WS_PER_LAYER * layers entries.
 int64_t workspace_layout(const dc_dims* d, int64_t* out) {
@@ -54,6 +80,7 @@ int64_t workspace_layout(const dc_dims* d, int64_t* out) {
     put(DC_WS_SCRATCH, (int64_t)DC_SCRATCH_FLOATS * 4);   // two-stage reductions / split-K slabs
     put(DC_WS_HEADW_PAD, (int64_t)HO_LD * H * 4);          // head weights zero-padded to 160 rows (K of dH)
     put(DC_WS_TEAM_XBUF, H == 256 ? rnn_team_xbuf_bytes() : 0);   // exchange ring of the H = 256 team kernels (rnn_team.hip)
+    put(DC_WS_WPLANES, 2 * 3 * 2 * wplane_elems(d));              // weights as bf16 planes: forward + transposed orientation
     for (int l = 0; l < d->layers; ++l) {
         const int b = DC_WS_FIXED + l * DC_WS_PER_LAYER;
         put(b + DC_WSL_GATES, NR * G * H * 4);
@@ -121,16 +148,42 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
     // env embedding + max-pools -> xcat (policy.py:97,102-136)
     // (fused: only the env embedding and the 5-unit type are left to do - the GEMM epilogue pooled the rest)
     DC_TRY(pool_env_fwd(obs, w.f(DC_WS_EMB), P.p(DC_P_ENV_W), P.p(DC_P_ENV_B), w.f(DC_WS_XCAT), amax, NR, fused ? 1 : 0, s));
+    // the dense products read their weights as bf16 planes (gemm_x3.hip): one pre-pass per forward over the three / four matrices
+    // (measured, tools/gemm_bench.py at 256 x 256: x W^T / dy W run at 145-150 TF on either kernel - the round-1 tile kernel with
+    // its fragments split after the LDS reads needs no pre-pass and is the default there; the split-on-load kernel is 1.5x
+    // faster on the weight-gradient products, 94 -> 146-152 TF, and is the only one with the bf16 mode)
+    const bool x3 = ((d->flags & DC_DIMS_BF16) || (d->flags & DC_DIMS_GEMM_X3_ALL)) && !(d->flags & DC_DIMS_GEMM_FASTTILE);
+    const int prec = (d->flags & DC_DIMS_BF16) ? 1 : 6;
+    const WPlanes wp = wplanes_of(d, w.base, w.off);
+    if (x3) {
+        X3SplitJob jobs[2 + DC_MAX_LAYERS];
+        int nj = 0;
+        jobs[nj++] = X3SplitJob{P.p(DC_P_PRE_W), wp.fwd(wp.pre), PREW, XCATW, XCATW, 0, PREW};
+        jobs[nj++] = X3SplitJob{P.p(DC_P_HEADS_W), wp.fwd(wp.heads), HO_N, H, H, 0, HO_LD};
+        for (int l = 0; l < d->layers; ++l) {
+            const int in = l == 0 ? PREW : H;
+            jobs[nj++] = X3SplitJob{P.p(DC_P_RNN0 + 4 * l), wp.fwd(wp.ih[l]), G * H, in, in, 0, G * H};
+        }
+        DC_TRY(split_weight_planes(jobs, nj, prec, s));
+    }
+    // y[rows][N] = x[rows][K] W[N][K]^T + b, through the split-on-load kernel (or the round-1 kernel)
+    auto linear = [&](const float* x, int K, const float* W, const uint16_t* Wp, int N, int Npad, const float* bias, int relu, float* y,
+                      int ldy) -> int {
+        if (!x3) return gemm_f32(x, W, y, (int)NR, N, K, K, K, ldy, 0, 0, bias, relu, nullptr, 0, 0, 1, s);
+        X3Gemm g;
+        g.A = x; g.a_mode = X3_ROW; g.lda = K;
+        g.B = Wp; g.b_mode = X3_PLANES; g.ldb = K; g.b_plane = (long long)Npad * K;
+        g.C = y; g.ldc = ldy; g.M = (int)NR; g.N = Npad; g.K = K; g.bias = bias; g.nbias = N; g.relu = relu; g.prec = prec;
+        return gemm_x3(g, s);
+    };
     // pre-rnn projection (policy.py:138)
-    DC_TRY(gemm_f32(w.f(DC_WS_XCAT), P.p(DC_P_PRE_W), w.f(DC_WS_PRE), (int)NR, PREW, XCATW, XCATW, XCATW, PREW, 0, 0,
-                    P.p(DC_P_PRE_B), 1, nullptr, 0, 0, 1, s));
+    DC_TRY(linear(w.f(DC_WS_XCAT), XCATW, P.p(DC_P_PRE_W), wp.fwd(wp.pre), PREW, PREW, P.p(DC_P_PRE_B), 1, w.f(DC_WS_PRE), PREW));
     // recurrent core (policy.py:141)
     const float* x = w.f(DC_WS_PRE);
     int in = PREW;
     for (int l = 0; l < d->layers; ++l) {
         const int pb = DC_P_RNN0 + 4 * l;
-        DC_TRY(gemm_f32(x, P.p(pb + 0), w.fl(l, DC_WSL_GATES), (int)NR, G * H, in, in, in, G * H, 0, 0, P.p(pb + 2), 0, nullptr,
-                        0, 0, 1, s));
+        DC_TRY(linear(x, in, P.p(pb + 0), wp.fwd(wp.ih[l]), G * H, G * H, P.p(pb + 2), 0, w.fl(l, DC_WSL_GATES), G * H));
         RnnStepArgs a{};
         a.h0 = h0 ? h0 + (size_t)l * B * H : nullptr;
         a.c0 = (c0 && d->cell == 1) ? c0 + (size_t)l * B * H : nullptr;
@@ -147,8 +200,8 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
         in = H;
     }
     // all head projections as one GEMM (policy.py:144-155), then the attention logits (policy.py:152)
-    DC_TRY(gemm_f32(x, P.p(DC_P_HEADS_W), w.f(DC_WS_HEADOUT), (int)NR, HO_N, H, H, H, HO_LD, 0, 0, P.p(DC_P_HEADS_B), 0,
-                    nullptr, 0, 0, 1, s));
+    // (x3: the weight planes are zero-padded to 160 rows, so the pad columns 154..159 of headout are written as zeros)
+    DC_TRY(linear(x, H, P.p(DC_P_HEADS_W), wp.fwd(wp.heads), HO_N, HO_LD, P.p(DC_P_HEADS_B), 0, w.f(DC_WS_HEADOUT), HO_LD));
     // (DC_DIMS_LAZY_TU: left to dc_select_logp / dc_ppo_loss_fwd_bwd, which know which units are unmasked)
     if (!(d->flags & DC_DIMS_LAZY_TU)) DC_TRY(attn_logits(w.f(DC_WS_HEADOUT), w.f(DC_WS_EMB), w.f(DC_WS_TU), NR, s));
     return 0;
@@ -182,18 +235,56 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     const int H = d->hidden, G = d->cell == 0 ? 3 : 4, B = d->n_seq, L = d->layers;
     const int TOP = L - 1;
 
+    // dense products: split-on-load bf16-plane kernel (gemm_x3.hip) or the round-1 kernel
+    const bool x3_tn = !(d->flags & DC_DIMS_GEMM_FASTTILE);                                              // weight gradients
+    const bool x3 = ((d->flags & DC_DIMS_BF16) || (d->flags & DC_DIMS_GEMM_X3_ALL)) && x3_tn;              // input gradients (see policy_forward)
+    const int prec = (d->flags & DC_DIMS_BF16) ? 1 : 6;
+    const WPlanes wp = wplanes_of(d, w.base, w.off);
+    // dx[rows][N] = dy[rows][K] W[K][N] (optionally masked by aux > 0): reads W^T as bf16 planes [N][K]
+    auto dgrad = [&](const float* dy, int K, const float* W, const uint16_t* WTp, int N, const float* aux, float* dx) -> int {
+        if (!x3) return gemm_f32(dy, W, dx, (int)NR, N, K, K, N, N, 0, 1, nullptr, 0, aux, N, 0, 1, s);
+        X3Gemm g;
+        g.A = dy; g.a_mode = X3_ROW; g.lda = K;
+        g.B = WTp; g.b_mode = X3_PLANES; g.ldb = K; g.b_plane = (long long)N * K;
+        g.C = dx; g.ldc = N; g.M = (int)NR; g.N = N; g.K = K; g.aux = aux; g.ldaux = N; g.prec = prec; g.transposed_w = 1;
+        return gemm_x3(g, s);
+    };
+    // dW[M][N] += dy[rows][lda: M]^T x[rows][ldb: N] (contraction over the env-steps, split-K); optional second x behind N
+    auto wgrad = [&](const float* dy, int lda, int M, const float* x1, int N1, float* dW1, const float* x2, int N2, float* dW2) -> int {
+        const bool pair = x2 != nullptr;
+        if (x3_tn && gemm_x3_shape_ok(M, N1 + N2, (int)NR, lda, N1, X3_KMAJ, X3_KMAJ) && (!pair || (N1 % 128 == 0 && !(N2 & 3)))) {
+            X3Gemm g;
+            g.A = dy; g.a_mode = X3_KMAJ; g.lda = lda;
+            g.B = x1; g.b_mode = X3_KMAJ; g.ldb = N1; g.B2 = x2; g.ldb2 = N2; g.n_split = pair ? N1 : 0;
+            g.C = dW1; g.ldc = N1; g.C2 = dW2; g.ldc2 = N2; g.M = M; g.N = N1 + N2; g.K = (int)NR; g.accumulate = 1; g.prec = prec;
+            g.scratch = sc;
+            return gemm_x3(g, s);
+        }
+        if (pair) return gemm_f32_tn_pair(dy, lda, x1, N1, N1, x2, N2, N2, dW1, N1, dW2, N2, M, (int)NR, s, sc);
+        return gemm_f32(dy, x1, dW1, M, N1, (int)NR, lda, N1, N1, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s, sc);
+    };
     if (do_upper) {
+    if (x3) {   // W^T of the matrices the input gradients contract with, as bf16 planes: one pre-pass per backward
+        X3SplitJob jobs[2 + DC_MAX_LAYERS];
+        int nj = 0;
+        jobs[nj++] = X3SplitJob{P.p(DC_P_PRE_W), wp.bwd(wp.pre), PREW, XCATW, XCATW, 1, PREW};          // -> [896][256]
+        jobs[nj++] = X3SplitJob{P.p(DC_P_HEADS_W), wp.bwd(wp.heads), HO_N, H, H, 1, HO_LD};             // -> [H][160], zero k-padding
+        for (int l = 0; l < L; ++l) {
+            const int in = l == 0 ? PREW : H;
+            jobs[nj++] = X3SplitJob{P.p(DC_P_RNN0 + 4 * l), wp.bwd(wp.ih[l]), G * H, in, in, 1, G * H};  // -> [in][G*H]
+        }
+        DC_TRY(split_weight_planes(jobs, nj, prec, s));
+    }
     // heads (policy.py:144-155)
     DC_TRY(attn_bwd_q(w.f(DC_WS_DTU), w.f(DC_WS_EMB), w.f(DC_WS_DHEADOUT), NR, s));
-    // dH = dheadout[:, 0:160] * [W_heads; 0]: K padded to a multiple of 32 (dheadout's pad columns are
-    // zeroed by the loss kernel), so the product runs on the fast GEMM path
-    hipLaunchKernelGGL(copy_zero_pad_kernel, dim3((HO_LD * H / 4 + 255) / 256), dim3(256), 0, s, P.p(DC_P_HEADS_W), w.f(DC_WS_HEADW_PAD),
-                       HO_N * H / 4, HO_LD * H / 4);   // one launch instead of a copy and a memset
-    DC_TRY(launch_check("policy_backward: head weight pad"));
-    DC_TRY(gemm_f32(w.f(DC_WS_DHEADOUT), w.f(DC_WS_HEADW_PAD), w.fl(TOP, DC_WSL_DH), (int)NR, H, HO_LD, HO_LD, H, H, 0, 1, nullptr,
-                    0, nullptr, 0, 0, 1, s));
-    DC_TRY(gemm_f32(w.f(DC_WS_DHEADOUT), w.fl(TOP, DC_WSL_HSEQ), Gd.p(DC_P_HEADS_W), HO_N, H, (int)NR, HO_LD, H, H, 1, 1,
-                    nullptr, 0, nullptr, 0, 1, 0, s, sc));
+    // dH = dheadout[:, 0:160] * [W_heads; 0]: K padded to 160 (dheadout's pad columns are zeroed by the loss kernel)
+    if (!x3) {
+        hipLaunchKernelGGL(copy_zero_pad_kernel, dim3((HO_LD * H / 4 + 255) / 256), dim3(256), 0, s, P.p(DC_P_HEADS_W), w.f(DC_WS_HEADW_PAD),
+                           HO_N * H / 4, HO_LD * H / 4);   // one launch instead of a copy and a memset
+        DC_TRY(launch_check("policy_backward: head weight pad"));
+    }
+    DC_TRY(dgrad(w.f(DC_WS_DHEADOUT), HO_LD, w.f(DC_WS_HEADW_PAD), wp.bwd(wp.heads), H, nullptr, w.fl(TOP, DC_WSL_DH)));
+    DC_TRY(wgrad(w.f(DC_WS_DHEADOUT), HO_LD, HO_N, w.fl(TOP, DC_WSL_HSEQ), H, Gd.p(DC_P_HEADS_W), nullptr, 0, nullptr));
     DC_TRY(colsum(w.f(DC_WS_DHEADOUT), HO_LD, NR, HO_N, Gd.p(DC_P_HEADS_B), s));
 
     // recurrent core, top layer first
@@ -213,10 +304,10 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         const int in = l == 0 ? PREW : H;
         // dW_ih = dgx^T x ; dW_hh = dgh^T h_prev ; biases = column sums
         if (a.dgh == a.dgx) {   // LSTM: both products contract the same gate gradients - one launch
-            DC_TRY(gemm_f32_tn_pair(a.dgx, G * H, xin, in, in, a.hprev, H, H, Gd.p(pb + 0), in, Gd.p(pb + 1), H, G * H, (int)NR, s, sc));
+            DC_TRY(wgrad(a.dgx, G * H, G * H, xin, in, Gd.p(pb + 0), a.hprev, H, Gd.p(pb + 1)));
         } else {
-            DC_TRY(gemm_f32(a.dgx, xin, Gd.p(pb + 0), G * H, in, (int)NR, G * H, in, in, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s, sc));
-            DC_TRY(gemm_f32(a.dgh, a.hprev, Gd.p(pb + 1), G * H, H, (int)NR, G * H, H, H, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s, sc));
+            DC_TRY(wgrad(a.dgx, G * H, G * H, xin, in, Gd.p(pb + 0), nullptr, 0, nullptr));
+            DC_TRY(wgrad(a.dgh, G * H, G * H, a.hprev, H, Gd.p(pb + 1), nullptr, 0, nullptr));
         }
         DC_TRY(colsum(a.dgx, G * H, NR, G * H, Gd.p(pb + 2), s));
         if (d->cell == 1) {   // LSTM: dgh is dgx, so d(b_hh) = d(b_ih) - copy 2 KB instead of a second 33 MB column sum
@@ -226,19 +317,15 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
             DC_TRY(colsum(a.dgh, G * H, NR, G * H, Gd.p(pb + 3), s));
         }
         if (l > 0) {
-            DC_TRY(gemm_f32(a.dgx, P.p(pb + 0), w.fl(l - 1, DC_WSL_DH), (int)NR, H, G * H, G * H, H, H, 0, 1, nullptr, 0, nullptr,
-                            0, 0, 1, s));
+            DC_TRY(dgrad(a.dgx, G * H, P.p(pb + 0), wp.bwd(wp.ih[l]), H, nullptr, w.fl(l - 1, DC_WSL_DH)));
         } else {
             // through relu(affine_pre_rnn) (policy.py:138): mask with the stored activation
-            DC_TRY(gemm_f32(a.dgx, P.p(pb + 0), w.f(DC_WS_DPRE), (int)NR, PREW, G * H, G * H, PREW, PREW, 0, 1, nullptr, 0,
-                            w.f(DC_WS_PRE), PREW, 0, 1, s));
+            DC_TRY(dgrad(a.dgx, G * H, P.p(pb + 0), wp.bwd(wp.ih[0]), PREW, w.f(DC_WS_PRE), w.f(DC_WS_DPRE)));
         }
     }
-    DC_TRY(gemm_f32(w.f(DC_WS_DPRE), w.f(DC_WS_XCAT), Gd.p(DC_P_PRE_W), PREW, XCATW, (int)NR, PREW, XCATW, XCATW, 1, 1, nullptr,
-                    0, nullptr, 0, 1, 0, s, sc));
+    DC_TRY(wgrad(w.f(DC_WS_DPRE), PREW, PREW, w.f(DC_WS_XCAT), XCATW, Gd.p(DC_P_PRE_W), nullptr, 0, nullptr));
     DC_TRY(colsum(w.f(DC_WS_DPRE), PREW, NR, PREW, Gd.p(DC_P_PRE_B), s));
-    DC_TRY(gemm_f32(w.f(DC_WS_DPRE), P.p(DC_P_PRE_W), w.f(DC_WS_DXCAT), (int)NR, XCATW, PREW, PREW, XCATW, XCATW, 0, 1, nullptr,
-                    0, nullptr, 0, 0, 1, s));
+    DC_TRY(dgrad(w.f(DC_WS_DPRE), PREW, P.p(DC_P_PRE_W), wp.bwd(wp.pre), XCATW, nullptr, w.f(DC_WS_DXCAT)));
     }   // do_upper
     if (!do_embed) return 0;
 

@@ -38,9 +38,12 @@ DC_DIMS_LSTM_MFMA = 32
 DC_DIMS_LSTM_VALU = 64
 DC_DIMS_TEAM_DEVICE_SCOPE = 128
 DC_DIMS_TEAM_NS = lambda n: n << 8
+DC_DIMS_GEMM_FASTTILE = 2048
+DC_DIMS_BF16 = 4096
+DC_DIMS_GEMM_X3_ALL = 8192
 
 WS_FIXED = ['BASIC', 'EMB', 'DEMB', 'XCAT', 'AMAX', 'PRE', 'HEADOUT', 'TU', 'DHEADOUT', 'DTU', 'DPRE', 'DXCAT',
-            'STATS', 'WHHT', 'SCRATCH', 'HEADW_PAD', 'TEAM_XBUF']
+            'STATS', 'WHHT', 'SCRATCH', 'HEADW_PAD', 'TEAM_XBUF', 'WPLANES']
 WS_LAYER = ['GATES', 'HN', 'HSEQ', 'HPREV', 'CSEQ', 'CPREV', 'DGX', 'DGH', 'DC', 'DH']
 
 

@@ -60,10 +60,16 @@ def advantage_returns(rewards, values, gamma, lam):
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, bias=None, relu=False, aux=None,
-         ldaux=0, accumulate=False, splits=0, scratch=None):
+         ldaux=0, accumulate=False, splits=0, scratch=None, x3=0):
+    """x3 = 6 / 1: the split-on-load bf16-matrix-core kernel (dc_gemm_x3: f32-grade / plain bf16); 0: dc_gemm_f32."""
     lib = _lib.load()
     for t, n in ((A, 'A'), (B, 'B'), (C, 'C')):
         _chk(t, torch.float32, n)
+    if x3:
+        _lib.check(lib.dc_gemm_x3(_lib.ptr(A), _lib.ptr(B), _lib.ptr(C), M, N, K, lda, ldb, ldc, int(a_kmajor), int(b_kmajor),
+                                  _lib.ptr(bias), int(relu), _lib.ptr(aux), ldaux, int(accumulate), int(x3), _lib.ptr(scratch),
+                                  0 if scratch is None else scratch.numel(), _lib.stream_ptr()), 'dc_gemm_x3')
+        return C
     _lib.check(lib.dc_gemm_f32(_lib.ptr(A), _lib.ptr(B), _lib.ptr(C), M, N, K, lda, ldb, ldc, int(a_kmajor),
                                int(b_kmajor), _lib.ptr(bias), int(relu), _lib.ptr(aux), ldaux, int(accumulate),
                                splits, _lib.ptr(scratch), 0 if scratch is None else scratch.numel(), _lib.stream_ptr()),

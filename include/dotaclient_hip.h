@@ -62,6 +62,15 @@ int dc_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, i
                 int a_kmajor, int b_kmajor, const float* bias, int relu, const float* aux, int ldaux,
                 int accumulate, int splits, float* scratch, int64_t scratch_floats, dc_stream_t stream);
 
+/* The same product through the split-on-load kernel the network's dense layers use (gemm_x3.hip): operands as exact 3-way bf16
+ * splits on the bf16 matrix cores (prec 6: f32-grade results) or rounded to bf16 (prec 1), f32 accumulate.  Layouts:
+ * a_kmajor = b_kmajor = 0 (x W^T), a_kmajor = 0 / b_kmajor = 1 (dy W), a_kmajor = b_kmajor = 1 (dy^T x, split-K).  B is a weight
+ * matrix in the first two forms and is split into bf16 planes inside the call (into `scratch`, which must hold
+ * 3 * N * K / 2 floats for it, plus splits * M * N for split-K).  K % 16 == 0, N % 4 == 0.  No relu/aux with split-K. */
+int dc_gemm_x3(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+               int a_kmajor, int b_kmajor, const float* bias, int relu, const float* aux, int ldaux,
+               int accumulate, int prec, float* scratch, int64_t scratch_floats, dc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Network + optimizer step.  Shapes: dc_dims; parameters: one flat fp32 buffer whose tensors are
  * addressed by an offset table `poff` (floats, host array, index = dc_param_index); scratch: one
@@ -109,6 +118,17 @@ typedef struct dc_dims {
 #define DC_DIMS_TEAM_DEVICE_SCOPE 128
 #define DC_DIMS_TEAM_NS_SHIFT 8
 #define DC_DIMS_TEAM_NS(n) ((n) << DC_DIMS_TEAM_NS_SHIFT)   /* bits 8..10 */
+/*   DC_DIMS_GEMM_FASTTILE  : every dense product through the round-1 tile kernel (f32 tiles by LDS-DMA, fragments split after
+ *                            their LDS reads); DC_DIMS_GEMM_X3_ALL: every one through the split-on-load kernel of gemm_x3.hip
+ *                            (default: that kernel for the weight gradients, the tile kernel for x W^T and dy W);
+ * Precision.  Default: every product is f32-grade (f32 operands split exactly into three bf16 pieces, six bf16 MFMAs,
+ * f32 accumulate - results within f32 round-off of an f32 fma chain).
+ *   DC_DIMS_BF16           : BASELINE.json configs[4] "bf16 MFMA path": the operands of the dense products (pre-rnn, recurrent
+ *                            input projection, heads and their gradients) are rounded to bf16 (one MFMA instead of six),
+ *                            f32 accumulate; everything else stays f32.  Tolerance vs the f32 oracle: tests/test_gpu_bf16.py. */
+#define DC_DIMS_GEMM_FASTTILE 2048
+#define DC_DIMS_BF16 4096
+#define DC_DIMS_GEMM_X3_ALL 8192
 
 /* index into poff[]; policy.py:54-75 names in comments */
 enum dc_param_index {
@@ -131,7 +151,7 @@ enum dc_param_index {
 enum dc_ws_index {
     DC_WS_BASIC = 0, DC_WS_EMB, DC_WS_DEMB, DC_WS_XCAT, DC_WS_AMAX, DC_WS_PRE, DC_WS_HEADOUT, DC_WS_TU,
     DC_WS_DHEADOUT, DC_WS_DTU, DC_WS_DPRE, DC_WS_DXCAT, DC_WS_STATS, DC_WS_WHHT, DC_WS_SCRATCH, DC_WS_HEADW_PAD,
-    DC_WS_TEAM_XBUF,
+    DC_WS_TEAM_XBUF, DC_WS_WPLANES,
     DC_WS_FIXED,            /* per-layer blocks follow */
     DC_WSL_GATES = 0, DC_WSL_HN, DC_WSL_HSEQ, DC_WSL_HPREV, DC_WSL_CSEQ, DC_WSL_CPREV, DC_WSL_DGX, DC_WSL_DGH,
     DC_WSL_DC, DC_WSL_DH,

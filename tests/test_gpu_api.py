@@ -129,7 +129,7 @@ def test_optimizer_surface_matches_golden(case, tmp_path):
         losses, entropies, norms = opt.train(experiences=experiences)
         assert set(losses) == {'loss', 'policy_loss', 'entropy_loss', 'value_loss'} and losses['loss'].dim() == 0
         got = np.array([float(losses[k]) for k in ('loss', 'policy_loss', 'entropy_loss', 'value_loss')])
-        assert util.rel_err(got, g['ep%d_losses' % ep]) < 1e-4
+        assert util.loss_rel_err(got, g['ep%d_losses' % ep]) < 1e-4
         assert util.rel_err([float(entropies[k]) for k in L.OUTPUT_KEYS], g['ep%d_entropies' % ep]) < 1e-4
         assert util.rel_err([float(norms['unclipped']), float(norms['clipped'])], g['ep%d_grad_norms' % ep]) < 1e-4
     # .grad views expose the (clipped) gradients like the reference's parameters do

@@ -102,6 +102,52 @@ def test_gemm_layouts(akm, bkm, M, N, K):
     assert err < 2e-6, err
 
 
+@pytest.mark.parametrize('prec,tol', [(6, 2e-6), (1, 2e-2)])
+@pytest.mark.parametrize('akm,bkm', [(False, False), (False, True), (True, True)])
+@pytest.mark.parametrize('M,N,K', [(64, 64, 32), (200, 160, 256), (1000, 256, 896), (130, 72, 160), (768, 256, 5008),
+                                   (33, 12, 16), (2048, 768, 256), (154, 256, 8192)])
+def test_gemm_x3_layouts(prec, tol, akm, bkm, M, N, K):
+    # the split-on-load kernel of gemm_x3.hip (dc_gemm_x3): f32-grade at prec 6 (the same bar as the f32 kernel), operands
+    # rounded to bf16 at prec 1 (error ~ 2^-9 sqrt(K)-ish of the operand scale: 2e-2 of max |C| is loose but catches layout bugs);
+    # ragged M / N (row clamp + masked 16-byte stores), padded leading dimensions, split-K on the long-K k-major shapes
+    from dotaclient_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + prec)
+    if prec == 6 and K > 4096:
+        tol = 5e-6                               # f32 accumulation over K > 4096 terms (the f32 fma chain is at 3.5e-6 there as well)
+    lda = ((M + 3) // 4 * 4 if akm else K) + 4   # k-major rows are read 16 bytes at a time: leading dimension % 4 == 0
+    ldb = (N if bkm else K) + 8
+    A = torch.randn((K if akm else M), lda, generator=g)
+    B = torch.randn((K if bkm else N), ldb, generator=g)
+    bias = torch.randn(N, generator=g)
+    Am = (A[:, :M].t() if akm else A[:, :K]).double()
+    Bm = (B[:, :N] if bkm else B[:, :K].t()).double()
+    tn = akm and bkm
+    ref = Am @ Bm + (0 if tn else bias.double())
+    ldc = N + 4
+    C = torch.full((M, ldc), 7.0, device=dev)
+    scratch = torch.empty(max(2 * N * K, 16 * M * N) + 1024, device=dev)
+    ops.gemm(A.to(dev), B.to(dev), C, M, N, K, lda, ldb, ldc, akm, bkm, bias=None if tn else bias.to(dev), scratch=scratch, x3=prec)
+    out = C.cpu()
+    assert torch.all(out[:, N:] == 7.0), 'wrote outside the N columns'
+    err = (out[:, :N].double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < tol, err
+    if prec == 6 and not tn:                      # epilogues: relu, mask, accumulate
+        aux = torch.randn(M, N, generator=g)
+        C2 = torch.empty(M, N, device=dev)
+        ops.gemm(A.to(dev), B.to(dev), C2, M, N, K, lda, ldb, N, akm, bkm, bias=bias.to(dev), relu=True, scratch=scratch, x3=6)
+        assert (C2.cpu().double() - ref.clamp(min=0)).abs().max() / ref.abs().max() < tol
+        ops.gemm(A.to(dev), B.to(dev), C2, M, N, K, lda, ldb, N, akm, bkm, bias=bias.to(dev), aux=aux.to(dev), ldaux=N, scratch=scratch, x3=6)
+        assert (C2.cpu().double() - ref * (aux > 0)).abs().max() / ref.abs().max() < tol
+        C2.fill_(1.0)
+        ops.gemm(A.to(dev), B.to(dev), C2, M, N, K, lda, ldb, N, akm, bkm, bias=bias.to(dev), accumulate=True, scratch=scratch, x3=6)
+        assert (C2.cpu().double() - (ref + 1)).abs().max() / ref.abs().max() < tol
+    if tn:                                        # accumulate into live data through the split-K reduce
+        C3 = torch.full((M, N), 2.0, device=dev)
+        ops.gemm(A.to(dev), B.to(dev), C3, M, N, K, lda, ldb, N, True, True, accumulate=True, scratch=scratch, x3=prec)
+        assert (C3.cpu().double() - (ref + 2)).abs().max() / ref.abs().max() < tol
+
+
 def test_gemm_epilogues():
     from dotaclient_amd import ops
     dev = _dev()

@@ -33,6 +33,19 @@ def scaled_err(a, b):
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30)) if a.size else 0.0
 
 
+def loss_rel_err(a, b):
+    """Relative error of the four loss numbers [loss, policy, entropy, value] (north_star: 1e-4).  `loss` is the SUM of
+    the three parts and cancels (clip_s16, third epoch at lr 3e-3: -0.0028 = -0.0836 - 0.0040 + 0.0848, condition number
+    62): an error of 1e-4 in each part is an error of 1e-4 * (|policy| + |entropy| + |value|) in the sum, so that is what
+    the sum is measured against.  `policy_loss` is itself a mean of signed terms; each part is measured against
+    max(|itself|, 1 % of the largest part)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    den = np.maximum(np.abs(b), 0.01 * np.max(np.abs(b[1:4])))
+    den[0] = np.sum(np.abs(b[1:4]))
+    return float(np.max(np.abs(a - b) / (den + 1e-30)))
+
+
 def tensor_summary(t):
     f = t.detach().double().flatten().cpu()
     return np.array([f.sum().item(), f.abs().sum().item(), f.norm().item()]), \

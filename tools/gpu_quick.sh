@@ -4,7 +4,7 @@
 TAG=${1:-q}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1
+timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1
 echo "pytest exit $?"; tail -6 $OUT/pytest_gpu.log
 timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/bench.err
 python - <<PY
