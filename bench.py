@@ -40,7 +40,11 @@ sys.path.insert(0, REPO)
 from dotaclient_amd import synth                      # noqa: E402
 from dotaclient_amd.engine import Engine, pack_rollouts  # noqa: E402
 
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense fp32
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense fp32 (= the f32 VALU peak)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
+# f32-grade products by exact 3-way bf16 splitting execute SIX bf16 MFMAs per f32 product (gemm_tiles.h): the matrix pipes'
+# ceiling for ALGORITHMIC f32 flops on that path
+PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0
 
 
@@ -194,6 +198,20 @@ def parity_report(got, ref, tol=1e-4):
 
 
 # what bounds each timed region (the rates in `kernels` are priced against that resource's peak)
+# peak (TFLOP/s of algorithmic f32 flops) of the MFMA-bound regions.  The embedding kernels regenerate their first layer
+# (K = 12 of the 12 + 128, resp. 24 of 24 + 128 flops per output) with f32 MFMAs and run the 128 x 128 layer as x3 products:
+# time-weighted harmonic peak.
+def _mixed_peak(f32_share):
+    return 1.0 / (f32_share / PEAK_F32_MFMA_TFLOPS + (1.0 - f32_share) / PEAK_X3_TFLOPS)
+
+
+def mfma_peak(region, prec_bf16):
+    if prec_bf16 and region.startswith('gemm_'):
+        return PEAK_BF16_MFMA_TFLOPS
+    return {'embed_fwd_fused': _mixed_peak(12.0 / 140.0), 'embed_bwd_dw2': _mixed_peak(12.0 / 140.0),
+            'embed_bwd_dw1': _mixed_peak(24.0 / 152.0)}.get(region, PEAK_X3_TFLOPS)
+
+
 REGION_BOUND = {
     'embed_fwd_fused': 'mfma', 'embed_bwd_dw2': 'mfma', 'embed_bwd_dw1': 'mfma', 'gemm_f32_fwd(NT)': 'mfma', 'gemm_f32_dX(NN)': 'mfma',
     'gemm_f32_dW(TN,split-K)': 'mfma',
@@ -204,7 +222,11 @@ REGION_BOUND = {
     'gae_scan': 'hbm', 'select_logp': 'hbm', 'attn_logits': 'hbm', 'attn_bwd_q': 'hbm', 'colsum': 'hbm',
 }
 BOUND_NOTES = {
-    'mfma': 'f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32): priced against the dense f32 matrix peak',
+    'mfma': 'f32-grade products on the bf16 matrix cores: every f32 operand is split exactly into three bf16 pieces and a product is six '
+            'v_mfma_f32_32x32x16_bf16 (gemm_tiles.h / gemm_x3.hip); `achieved` = ALGORITHMIC f32 flops / time, `peak` = the dense bf16 '
+            'MFMA peak / 6 = 416.7 TF (less for the embedding kernels, whose K = 12 first layer is regenerated with f32 MFMAs), so '
+            '`frac` is the share of the matrix pipes\' capacity on this path; `frac_of_f32_mfma_peak` prices the same rate against the '
+            '157.3 TF of the f32-input MFMA the products would otherwise run on',
     'valu': 'packed-f32 VALU kernel (per-channel-scaled gathers of 512-byte W2 / basic rows; 1/16 of the dense MACs): priced against '
             'the f32 VALU peak, which equals the f32 MFMA peak (157.3 TF at 2.4 GHz); what limits it is VALU issue and LDS '
             'bandwidth at 2 waves/SIMD, not the matrix pipes',
@@ -433,7 +455,13 @@ def main():
             else:
                 tf = r['flops'] / (r['total_ms'] * 1e-3) / 1e12
                 k['achieved_tflops'] = round(tf, 3)
-                k['frac_of_f32_peak'] = round(tf / PEAK_F32_MFMA_TFLOPS, 4)
+                if bound == 'mfma':
+                    k['peak_tflops'] = round(mfma_peak(r['kernel'], bool(KERNEL_FLAGS & 4096)), 1)
+                    k['frac'] = round(tf / k['peak_tflops'], 4)
+                    k['frac_of_f32_mfma_peak'] = round(tf / PEAK_F32_MFMA_TFLOPS, 4)
+                else:                      # VALU / latency-bound f32 kernels: against the f32 vector peak
+                    k['peak_tflops'] = PEAK_F32_MFMA_TFLOPS
+                    k['frac'] = round(tf / PEAK_F32_MFMA_TFLOPS, 4)
             k['traffic'] = pmc_traffic(args.traffic_json, r['kernel'].split('(')[0], workload_key)
             kernels.append(k)
         # the HBM-bound side (GAE / loss / Adam / pooling stream their operands once): largest by time
@@ -449,9 +477,10 @@ def main():
         dom = regions[0]
         dom_bound = REGION_BOUND.get(dom['kernel'], 'mfma')
         achieved = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
+        dom_peak = mfma_peak(dom['kernel'], bool(KERNEL_FLAGS & 4096)) if dom_bound == 'mfma' else PEAK_F32_MFMA_TFLOPS
         roofline = {'bound': dom_bound, 'bound_note': BOUND_NOTES[dom_bound], 'kernel': dom['kernel'],
-                    'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    'achieved': round(achieved, 3), 'peak': round(dom_peak, 1),
+                    'unit': 'TFLOP/s', 'frac': round(achieved / dom_peak, 4),
                     'traffic': pmc_traffic(args.traffic_json, dom['kernel'], workload_key),
                     'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, %s)' % os.path.relpath(args.traffic_json, REPO),
                     'algorithmic_bytes_per_launch': dom['bytes'] / dom['launches'],
@@ -474,7 +503,14 @@ def main():
             'metric': 'env-steps/sec through PPO optimizer', 'value': round(value, 1), 'unit': 'env-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None,
+            'dtype': 'bf16' if KERNEL_FLAGS & 4096 else 'f32',
+            'dtype_note': 'DC_DIMS_BF16: bf16 operands / f32 accumulate in the dense products, f32 elsewhere' if KERNEL_FLAGS & 4096 else
+                          'f32 end to end: inputs, weights, activations, gradients and optimizer state are f32 and every product is f32-grade '
+                          '(matrix products: exact 3-way bf16 splits of both f32 operands, six bf16 MFMAs, f32 accumulate - error vs f64 '
+                          '1.4e-7..5.5e-7 of max |C| on the network\'s shapes, the f32 fma chain 2.1e-7..3.7e-7; tools/ubench/gemm_x3.hip); '
+                          '`parity` checks the whole step against the fp32 oracle at 1e-4',
+            'data': 'synthetic',
             'config': {'workload': '%s: synthetic trajectories, %s hidden=%d x%d layer, '
                                    'batch=%d trajectories x %d steps per GPU, %d epochs + rollout pass per step'
                                    % (which, args.cell.upper(), args.hidden, args.layers, B, S, E),
