@@ -15,8 +15,12 @@
 //
 // Two passes: embed_pool16_prepare_kernel sorts every step's channels by arg-max unit (wave ballots; ascending
 // channel inside a unit: deterministic sums); embed_bwd_pool16_kernel (one workgroup = one type x a contiguous range of
-// env-steps, wave w = units w, w + 8 and the dW2 rows of channels w + 8i, lane l = k 2l, 2l + 1) keeps its
-// accumulators in registers for the whole range.  Steps with a live target-unit head additionally need R[k] = sum_c q[c] W2[c][k] and
+// env-steps) keeps its accumulators in registers for the whole range.  Two lane <-> data maps, each where it saves
+// instructions: the dW2 update runs CHANNEL-per-lane (lane l owns channels l and l + 64, wave w the k range
+// [16w, 16w + 16): the scale d[c] and the source row a(c) are lane-local - no broadcast, one 8-byte read for both - and a
+// lane gathers its 64 bytes of basic[a(c)] with four ds_read_b128, rows 528 bytes apart so that sixteen different rows
+// at one column never share a bank); d(basic) runs K-per-lane (wave w owns units w, w + 8, lane l the k pair 2l, 2l + 1:
+// the rows of W2 a unit sums over are wave-uniform and read as 512 contiguous bytes).  Steps with a live target-unit head additionally need R[k] = sum_c q[c] W2[c][k] and
 // s[k] = sum_u dtu[u] basic[u][k] (two workgroup reductions through LDS) for the rank-one terms.
 // Outputs are per-workgroup partials in the formats the dense path already reduces:
 //   slab[wg][128][128] (splitk_reduce_grouped), part1[wg][13][128] (unit_basic_reduce), part2[wg][128] (colsum).
@@ -29,7 +33,8 @@ namespace dc {
 namespace {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-enum { SP_THREADS = 512, SP_LD = 128, SP_PREP = 320 };   // SP_PREP: floats per (step, type) of the prepared channel lists   // padded LDS rows: consecutive rows start 4 banks apart, so 16 lanes reading
+enum { SP_THREADS = 512, SP_LD = 128, SP_BLD = 132, SP_PREP = 320 };   // SP_BLD: floats per LDS row of `basic` (4 banks apart)
+enum { SP_OLD_ = 0 };   // SP_PREP: floats per (step, type) of the prepared channel lists   // padded LDS rows: consecutive rows start 4 banks apart, so 16 lanes reading
                                          // 16 bytes at one column offset of 16 different rows never share a bank
 constexpr int SP_OBS = 483, SP_XCAT = 896;
 
@@ -48,11 +53,11 @@ struct SparseArgs {
 enum {
     NS = 2,
     L_W2 = 0,                               // [128][128] W2_t rows
-    L_BAS = L_W2 + 128 * SP_LD,             // 2 x NS x [16][128] basic of a step (written one iteration ahead)
-    L_RED = L_BAS + 2 * NS * 16 * SP_LD,    // NS x [2][8][128] per-wave partials of R and s
+    L_BAS = L_W2 + 128 * SP_LD,             // 2 x NS x [16][SP_BLD] basic of a step (written one iteration ahead)
+    L_RED = L_BAS + 2 * NS * 16 * SP_BLD,   // NS x [2][8][128] per-wave partials of R and s
     L_STG = L_RED + NS * 2 * 8 * 128,       // 3 x NS staging blocks: the inputs of a step
     STG_Q = 0,                         //   q[128]
-    STG_PB = 128,                      //   per channel {d, byte offset of basic row a(c)}          [128] x 8 B
+    STG_PB = 128,                      //   per channel {d, byte offset of basic row a(c) (SP_BLD rows)}  [128] x 8 B
     STG_LIST = 384,                    //   channels sorted by arg-max unit: {d, byte offset of W2 row c}, [128 + 16] x 8 B
     STG_SC = 672,                      //   per unit {first list entry, number of channels}          [16] x 8 B
     STG_DT = 704,                      //   dtu[16], [16] = their sum
@@ -161,11 +166,11 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
     }
     for (int e = tid; e < 128 * 12; e += SP_THREADS) smem[L_W1 + e] = p.W1[e];
     const f32x2 b1r = mk2(p.b1[k0], p.b1[k0 + 1]);
-    f32x2 D[16];
+    f32x2 D[2][8];                 // dW2[c][16w + 2j, 16w + 2j + 1] of channels c = lane (D[0]) and lane + 64 (D[1])
     float dW1a[2][12], db1a[2];
     float db2a = 0.f;              // threads 0..127: second-layer bias gradient of channel tid
 #pragma unroll
-    for (int i = 0; i < 16; ++i) D[i] = mk2(0.f, 0.f);
+    for (int i = 0; i < 8; ++i) { D[0][i] = mk2(0.f, 0.f); D[1][i] = mk2(0.f, 0.f); }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         db1a[e] = 0.f;
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
             float* stg = stg_of(i, s2);
             if (tid < 128) {
                 stg[STG_Q + tid] = st_1[s2];
-                *reinterpret_cast<float2*>(stg + STG_PB + 2 * tid) = make_float2(st_0[s2], __int_as_float(st_a[s2] * SP_LD * 4));
+                *reinterpret_cast<float2*>(stg + STG_PB + 2 * tid) = make_float2(st_0[s2], __int_as_float(st_a[s2] * SP_BLD * 4));
             } else if (tid < 144) {        // lanes 0..15 of wave 2
                 stg[STG_DT + (tid - 128)] = st_0[s2];
                 float sum = st_0[s2];          // the sixteen lanes are one DPP row: rotate-and-add, no LDS round trips
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
         val = e.x;
         off = __float_as_int(e.y);
     };
-    auto bas_of = [&](long long i, int s2) { return smem + L_BAS + ((int)(i & 1) * NS + s2) * 16 * SP_LD; };
+    auto bas_of = [&](long long i, int s2) { return smem + L_BAS + ((int)(i & 1) * NS + s2) * 16 * SP_BLD; };
     auto phase_a = [&](long long i) {             // basic[u][k0..k0+1] of iteration i's steps, u = w and w + 8
         // W1 rows k0, k0 + 1 (24 floats); the k-ordered fmaf chain of the MFMA-generated first layer (embed_fused.hip),
         // bias last: bitwise the forward's value, hence its relu mask
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
                 float a0 = x[0] * w1[0], a1 = x[0] * w1[12];
 #pragma unroll
                 for (int f = 1; f < 12; ++f) { a0 = fmaf(x[f], w1[f], a0); a1 = fmaf(x[f], w1[12 + f], a1); }
-                *reinterpret_cast<float2*>(bas + u * SP_LD + k0) = make_float2(fmaxf(a0 + b1r.x, 0.f), fmaxf(a1 + b1r.y, 0.f));
+                *reinterpret_cast<float2*>(bas + u * SP_BLD + k0) = make_float2(fmaxf(a0 + b1r.x, 0.f), fmaxf(a1 + b1r.y, 0.f));
             }
         }
     };
@@ -293,18 +298,24 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
         for (int s2 = 0; s2 < NS; ++s2) {
             if (!on[s2]) continue;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) basic[s2][h] = *reinterpret_cast<const f32x2*>(basb[s2] + (w + 8 * h) * SP_LD * 4);
-            {
-                float dvec; int ovec;
-                gather16(stg[s2] + STG_PB, w, 8, dvec, ovec);
-                const char* bb = basb[s2];
-                for_consts([&](auto CC) {
-                    constexpr int C = decltype(CC)::value;
-                    const f32x2 r = *reinterpret_cast<const f32x2*>(bb + bcast16_i<C>(ovec));
-                    const float d = bcast16_f<C>(dvec);
-                    D[C].x = fmaf(d, r.x, D[C].x);
-                    D[C].y = fmaf(d, r.y, D[C].y);
-                }, std::make_integer_sequence<int, 16>{});
+            for (int h = 0; h < 2; ++h) basic[s2][h] = *reinterpret_cast<const f32x2*>(basb[s2] + (w + 8 * h) * SP_BLD * 4);
+            {   // phase B, channel per lane: D[h][j] += d[c] * basic[a(c)][16w + 2j .. +1], c = lane + 64 h
+                const char* brow = reinterpret_cast<const char*>(bas_of(i, s2)) + w * 64;       // k range of this wave
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float2 e = *reinterpret_cast<const float2*>(stg[s2] + STG_PB + 2 * (lane + 64 * h));   // {d, row byte offset}
+                    const float4* rp = reinterpret_cast<const float4*>(brow + __float_as_int(e.y));
+                    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+                    const f32x2 dd = mk2(e.x, e.x);
+                    D[h][0] = __builtin_elementwise_fma(dd, mk2(r0.x, r0.y), D[h][0]);
+                    D[h][1] = __builtin_elementwise_fma(dd, mk2(r0.z, r0.w), D[h][1]);
+                    D[h][2] = __builtin_elementwise_fma(dd, mk2(r1.x, r1.y), D[h][2]);
+                    D[h][3] = __builtin_elementwise_fma(dd, mk2(r1.z, r1.w), D[h][3]);
+                    D[h][4] = __builtin_elementwise_fma(dd, mk2(r2.x, r2.y), D[h][4]);
+                    D[h][5] = __builtin_elementwise_fma(dd, mk2(r2.z, r2.w), D[h][5]);
+                    D[h][6] = __builtin_elementwise_fma(dd, mk2(r3.x, r3.y), D[h][6]);
+                    D[h][7] = __builtin_elementwise_fma(dd, mk2(r3.z, r3.w), D[h][7]);
+                }
             }
             float scv; int scc;
             gather16(stg[s2] + STG_SC, 0, 1, scv, scc);          // lane u: {first entry, count} of unit u
@@ -379,16 +390,24 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
             for (int s2 = 0; s2 < NS; ++s2) {
                 if (!live[s2]) continue;
                 const f32x2 R = *reinterpret_cast<const f32x2*>(smem + L_RS + s2 * 256 + k0);
-                const f32x2 S = *reinterpret_cast<const f32x2*>(smem + L_RS + s2 * 256 + 128 + k0);
                 db[s2][0] = __builtin_elementwise_fma(mk2(dt0[s2], dt0[s2]), R, db[s2][0]);
                 db[s2][1] = __builtin_elementwise_fma(mk2(dt1[s2], dt1[s2]), R, db[s2][1]);
-                const float qv16 = qvec[s2];
-                for_consts([&](auto CC) {
-                    constexpr int C = decltype(CC)::value;
-                    const float qc = bcast16_f<C>(qv16);
-                    D[C].x = fmaf(qc, S.x, D[C].x);
-                    D[C].y = fmaf(qc, S.y, D[C].y);
-                }, std::make_integer_sequence<int, 16>{});
+                // dW2[c][k] += q[c] * s[k] in the channel-per-lane layout: q lane-local, s[16w .. 16w + 15] wave-uniform
+                const float4* sp = reinterpret_cast<const float4*>(smem + L_RS + s2 * 256 + 128 + 16 * w);
+                const float4 s0 = sp[0], s1 = sp[1], s2v = sp[2], s3 = sp[3];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float qc = stg[s2][STG_Q + lane + 64 * h];
+                    const f32x2 qq = mk2(qc, qc);
+                    D[h][0] = __builtin_elementwise_fma(qq, mk2(s0.x, s0.y), D[h][0]);
+                    D[h][1] = __builtin_elementwise_fma(qq, mk2(s0.z, s0.w), D[h][1]);
+                    D[h][2] = __builtin_elementwise_fma(qq, mk2(s1.x, s1.y), D[h][2]);
+                    D[h][3] = __builtin_elementwise_fma(qq, mk2(s1.z, s1.w), D[h][3]);
+                    D[h][4] = __builtin_elementwise_fma(qq, mk2(s2v.x, s2v.y), D[h][4]);
+                    D[h][5] = __builtin_elementwise_fma(qq, mk2(s2v.z, s2v.w), D[h][5]);
+                    D[h][6] = __builtin_elementwise_fma(qq, mk2(s3.x, s3.y), D[h][6]);
+                    D[h][7] = __builtin_elementwise_fma(qq, mk2(s3.z, s3.w), D[h][7]);
+                }
             }
         }
         stamp(4);
@@ -421,7 +440,11 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
     {
         float* out = p.slab + (size_t)blockIdx.x * 128 * 128;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x2*>(out + (size_t)(w + 8 * i) * 128 + k0) = D[i];
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float4*>(out + (size_t)(lane + 64 * h) * 128 + 16 * w + 4 * j) =
+                    make_float4(D[h][2 * j].x, D[h][2 * j].y, D[h][2 * j + 1].x, D[h][2 * j + 1].y);
         if (tid < 128) p.part2[(size_t)blockIdx.x * 128 + tid] = db2a;
     }
     // dW1 / db1: sum the 8 waves in fixed order through LDS -> part1[wg][f][k] (f = 12: db1)
