@@ -1,0 +1,214 @@
+// MFMA building blocks of the register-resident recurrent kernels (rnn_persist.hip, rnn_team_mfma.hip): the
+// v_mfma_f32_4x4x1_16b_f32 product phase with block-broadcast A operands and AGPR-resident weights, hand-issued with
+// memory "hooks" between the MFMA pairs; the gate non-linearities on the hardware transcendentals; slot mapping.
+#pragma once
+#include <utility>
+#include "kernels.h"
+
+namespace dc {
+
+template <int H>
+struct PersistCfg {
+    static constexpr int WAVES = H / 32;
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int HLD = H + 4;          // h rows in LDS: +4 floats -> the 4 rows of a b128 read hit disjoint banks
+    static constexpr int GLD = 4 * H + 8;      // gate-gradient rows in LDS
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
+// Gate non-linearities on the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each): the
+// cell epilogue sits on the per-step critical path, and libm's range-reduced expf + IEEE division +
+// branchy tanhf cost several hundred dependent cycles there.  Absolute error ~1e-7, far inside the
+// 1e-4 parity bar (tests/test_gpu_parity.py).
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    // 2*sigmoid(2x) - 1; exp2 overflow to +inf gives rcp(inf) = 0 -> -1, underflow -> +1
+    return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.0f;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Hand-issued product phase.
+//
+// A operand by BROADCAST: all 16 blocks of the 4x4x1 MFMA need the same four rows (sequences), so the
+// instruction's block broadcast (cbsz:4 abid:b = "every block takes its A from block b", verified on
+// gfx950 by tools/ubench/mfma_bcast.hip) lets ONE register carry 16 different k: lane 4b+i of register
+// j holds state[i][16j+b], and the 16 MFMAs abid = 0..15 walk k = 16j .. 16j+15.  The whole A operand
+// of a step is then H/16 (forward) or 2H/16 (backward) registers = 2 resp. 4 ds_read_b128 per lane
+// (state kept in LDS in that permuted order) instead of one read per 4 k.
+// B operand straight from AGPRs ("a" constraint: MFMA A/B operands may be AGPRs on gfx950) - hipcc
+// itself copies AGPR-resident weights back to VGPRs with v_accvgpr_read + hazard nops per MFMA.
+//
+// Issue budget (tools/ubench/mfma4x4.hip): the MFMA issues every 8.55 cycles whatever the register
+// files and chain count, and with one wave per SIMD every OTHER instruction placed between two MFMAs
+// costs ~5 cycles of its own - nothing hides behind a 2-pass MFMA.  The product phase therefore carries
+// the bare minimum: the 2-4 LDS reads, and one memory instruction per hook for next step's operands and
+// the previous step's results (32-bit byte offsets from uniform bases, no branches).
+// Every statement is asm volatile: issue order = program order, and the compiler emits no LDS/SMEM
+// operation of its own between the reads and their waits.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_read16(float4& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N));
+}
+// c0 (+)= bcast_b(a) * w0 ; c1 (+)= bcast_b(a) * w1.  ZERO: start from the inline constant 0.
+template <bool ZERO, int ABID>
+__device__ __forceinline__ void mfma_pair_same(f32x4& c0, f32x4& c1, float a, float w0, float w1) {
+    if constexpr (ZERO) {
+        asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %2, %3, 0 cbsz:4 abid:%5\n\tv_mfma_f32_4x4x1_16b_f32 %1, %2, %4, 0 cbsz:4 abid:%5"
+                     : "=&v"(c0), "=&v"(c1)
+                     : "v"(a), "a"(w0), "a"(w1), "i"(ABID));
+    } else {
+        asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %2, %3, %0 cbsz:4 abid:%5\n\tv_mfma_f32_4x4x1_16b_f32 %1, %2, %4, %1 cbsz:4 abid:%5"
+                     : "+v"(c0), "+v"(c1)
+                     : "v"(a), "a"(w0), "a"(w1), "i"(ABID));
+    }
+}
+// c0 (+)= bcast_b0(a) * w0 ; c1 (+)= bcast_b1(a) * w1   (two consecutive k of one column)
+// cbsz:3 = broadcast inside each group of 8 blocks (= each wave half): the halves keep different A
+template <bool ZERO, int ABID0, int ABID1>
+__device__ __forceinline__ void mfma_pair_seq(f32x4& c0, f32x4& c1, float a, float w0, float w1) {
+    if constexpr (ZERO) {
+        asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %2, %3, 0 cbsz:3 abid:%5\n\tv_mfma_f32_4x4x1_16b_f32 %1, %2, %4, 0 cbsz:3 abid:%6"
+                     : "=&v"(c0), "=&v"(c1)
+                     : "v"(a), "a"(w0), "a"(w1), "i"(ABID0), "i"(ABID1));
+    } else {
+        asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %2, %3, %0 cbsz:3 abid:%5\n\tv_mfma_f32_4x4x1_16b_f32 %1, %2, %4, %1 cbsz:3 abid:%6"
+                     : "+v"(c0), "+v"(c1)
+                     : "v"(a), "a"(w0), "a"(w1), "i"(ABID0), "i"(ABID1));
+    }
+}
+// MFMA -> VALU read hazard, padded by hand (nothing after an asm is padded by the compiler)
+__device__ __forceinline__ void mfma_tail_pad(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
+// lanes 32..63 of `lo` <-> lanes 0..31 of `hi_` (v_permlane32_swap): afterwards
+//   lo  = [lo.low  | hi_.low ]      hi_ = [lo.high | hi_.high]
+__device__ __forceinline__ void half_swap(float& lo, float& hi_) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi_), false, false);
+    lo = __uint_as_float(r[0]);
+    hi_ = __uint_as_float(r[1]);
+}
+
+// register j of the A operand = component (j & 3) of LDS read (j >> 2).  Components are named at the use
+// site (a sub-register reference, no instruction): copying them earlier would read the destination of a
+// ds_read the compiler does not know is still in flight.
+template <int J, int N>
+__device__ __forceinline__ const float& a_reg(const float4 (&r)[N]) {
+    if constexpr ((J & 3) == 0) return r[J >> 2].x;
+    else if constexpr ((J & 3) == 1) return r[J >> 2].y;
+    else if constexpr ((J & 3) == 2) return r[J >> 2].z;
+    else return r[J >> 2].w;
+}
+
+// position of state[seq][k] inside a broadcast-ordered LDS row set: lane 4b+i reads the NJ floats
+// [i][b][0..NJ) contiguously; k = 16j + b.  ROW = floats per sequence row (>= 16*NJ, padded).
+template <int NJ, int ROW>
+__device__ __forceinline__ int bcast_pos(int seq, int k) { return seq * ROW + (k & 15) * NJ + (k >> 4); }
+
+template <int H>
+struct FwdProduct {
+    static constexpr int NJ = H / 16;        // A registers per step
+    static constexpr int HOOKS = H / 2;      // one hook per MFMA quad (2 k x 2 columns)
+    template <int K2, class Hook>            // k = 2*K2, 2*K2+1
+    static __device__ __forceinline__ void quad(const float4 (&r)[NJ / 4], f32x4 (&acc)[4], const float (&w0)[H],
+                                                const float (&w1)[H], Hook& hook) {
+        constexpr int k = 2 * K2;
+        if constexpr (k == 0) wait_lgkm<NJ / 4 - 1>();
+        if constexpr (NJ == 8 && k == 64) wait_lgkm<0>();
+        mfma_pair_same<k == 0, k & 15>(acc[0], acc[1], a_reg<(k >> 4)>(r), w0[k], w1[k]);
+        mfma_pair_same<k == 0, (k + 1) & 15>(acc[2], acc[3], a_reg<((k + 1) >> 4)>(r), w0[k + 1], w1[k + 1]);
+        hook(std::integral_constant<int, K2>{});
+    }
+    template <class Hook, int... Ks>
+    static __device__ __forceinline__ void quads(const float4 (&r)[NJ / 4], f32x4 (&acc)[4], const float (&w0)[H],
+                                                 const float (&w1)[H], Hook& hook, std::integer_sequence<int, Ks...>) {
+        (quad<Ks>(r, acc, w0, w1, hook), ...);
+    }
+    // acc: chains [0] col0 even k, [1] col1 even k, [2] col0 odd k, [3] col1 odd k
+    template <class Hook>
+    static __device__ __forceinline__ void run(f32x4 (&acc)[4], const float (&w0)[H], const float (&w1)[H], uint32_t addr,
+                                               Hook& hook) {
+        float4 r[NJ / 4];
+        lds_read16<0>(r[0], addr);
+        if constexpr (NJ == 8) lds_read16<16>(r[1], addr);
+        quads(r, acc, w0, w1, hook, std::make_integer_sequence<int, H / 2>{});
+        mfma_tail_pad(acc[0], acc[1], acc[2], acc[3]);
+    }
+};
+
+template <int KH>
+struct BwdProduct {
+    // the two wave halves contract different k ranges, so the broadcast stays inside a half (cbsz:3):
+    // lane 4b'+i (b' = 0..7 within the half) of register j holds dgates[i][half*KH + 8j + b']
+    static constexpr int NJ = KH / 8;        // A registers per step
+    static constexpr int NR = NJ / 4;        // ds_read_b128 per step
+    static constexpr int HOOKS = KH / 4;     // one hook per MFMA quad (4 consecutive k)
+    template <int K4, class Hook>
+    static __device__ __forceinline__ void quad(const float4 (&r)[NR], f32x4 (&acc)[4], const float (&w)[KH], Hook& hook) {
+        constexpr int k = 4 * K4;
+        if constexpr (k % 32 == 0) wait_lgkm<NR - 1 - k / 32>();
+        mfma_pair_seq<k == 0, k & 7, (k + 1) & 7>(acc[0], acc[1], a_reg<(k >> 3)>(r), w[k], w[k + 1]);
+        mfma_pair_seq<k == 0, (k + 2) & 7, (k + 3) & 7>(acc[2], acc[3], a_reg<(k >> 3)>(r), w[k + 2], w[k + 3]);
+        hook(std::integral_constant<int, K4>{});
+    }
+    template <class Hook, int... Ks>
+    static __device__ __forceinline__ void quads(const float4 (&r)[NR], f32x4 (&acc)[4], const float (&w)[KH], Hook& hook,
+                                                 std::integer_sequence<int, Ks...>) {
+        (quad<Ks>(r, acc, w, hook), ...);
+    }
+    template <int... Rs>
+    static __device__ __forceinline__ void reads(float4 (&r)[NR], uint32_t addr, std::integer_sequence<int, Rs...>) {
+        (lds_read16<16 * Rs>(r[Rs], addr), ...);
+    }
+    template <class Hook>
+    static __device__ __forceinline__ void run(f32x4 (&acc)[4], const float (&w)[KH], uint32_t addr, Hook& hook) {
+        float4 r[NR];
+        reads(r, addr, std::make_integer_sequence<int, NR>{});
+        quads(r, acc, w, hook, std::make_integer_sequence<int, KH / 4>{});
+        mfma_tail_pad(acc[0], acc[1], acc[2], acc[3]);
+    }
+    // position of gate column `col` (0..2*KH) inside a sequence row of the LDS image
+    static __device__ __forceinline__ int pos(int col) {
+        const int half = col / KH, kk = col - half * KH;
+        return half * KH + (kk & 7) * NJ + (kk >> 3);
+    }
+};
+
+// The four sequence slots of a workgroup.  A slot whose sequence does not exist (ragged last
+// workgroup) or is empty duplicates the workgroup's first real sequence: it then computes and stores
+// bit-identical values to the same addresses, and no part of the step needs an "is this cell real"
+// branch.  Returns false if the workgroup has nothing to do.
+__device__ __forceinline__ bool map_slots(const RnnStepArgs& p, int b0, int (&bmap)[4], int& tmax) {
+    int first = -1;
+    tmax = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int b = b0 + q;
+        const int l = b < p.n_seq ? p.seq_len[b] : 0;
+        if (l > 0 && first < 0) first = b;
+        tmax = max(tmax, l);
+        bmap[q] = l > 0 ? b : -1;
+    }
+    if (first < 0) return false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (bmap[q] < 0) bmap[q] = first;
+    return true;
+}
+
+}  // namespace dc

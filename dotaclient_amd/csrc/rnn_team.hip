@@ -45,90 +45,9 @@
 #include <string.h>
 #include "kernels.h"
 #include "valu_util.h"
+#include "team_util.h"
 
 namespace dc {
-namespace {
-
-enum { TEAM_H = 256, TEAM_US = 64, TEAM_M = 4, TEAM_SLOTS = 4, TEAM_MAX = 64, TEAM_NS_MAX = 4 };
-enum { CELL_GRU = 0, CELL_LSTM = 1 };
-constexpr int SPIN_LIMIT = 1 << 21;   // polls (~0.5-1 us each) before a member gives up
-
-typedef unsigned long long u64;
-
-__device__ __forceinline__ u64 granule_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void granule_store(u64* p, float v, unsigned tag, int plain = 0) {
-    const u64 g = ((u64)tag << 32) | (u64)__float_as_uint(v);
-    // plain: a store that stops in the XCD's L2 instead of writing through to memory - valid (and ~0.15 us per hand-off
-    // faster) when all four members of the team run on the same XCD, which they check at start (team_same_xcd)
-    if (plain) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// spins until the granule carries `tag`; false on timeout.  g = a first read of the granule (possibly issued long ago)
-__device__ __forceinline__ bool granule_wait(u64 g, const u64* p, unsigned tag, float& v) {
-    int n = 0;
-    while ((unsigned)(g >> 32) != tag) {
-        if (++n > SPIN_LIMIT) return false;
-        __builtin_amdgcn_s_sleep(1);
-        g = granule_load(p);
-    }
-    v = __uint_as_float((unsigned)g);
-    return true;
-}
-
-// Which (team, member) a workgroup plays is decided when it STARTS RUNNING, by a ticket, not by its block index: the
-// first four workgroups to start form team 0, the next four team 1, ...  A workgroup that has started stays resident
-// until it exits, so every team whose four tickets are taken is fully resident and makes progress - whatever else
-// occupies the chip (an RCCL kernel, a second engine's launch on another stream, a CU mask): workgroups that have not
-// been dispatched yet hold no role anyone waits for, at most one team per ticket counter is incomplete at any moment,
-// and it completes as soon as any running workgroup on the chip exits.  No co-residency of the whole grid is assumed.
-// Speed only: with a multiple of 8 teams there is one ticket counter per XCD (the workgroup reads its XCC id), so a
-// team's members share an L2 under any placement; a workgroup whose XCD has no role left takes one of another XCD.
-enum { TEAM_HDR = 16 };   // u64 words in front of the handshake granules: ticket counters (u32 each)
-__device__ __forceinline__ void team_claim_role(unsigned* claim, int n_teams, int& team, int& member) {
-    __shared__ int role_sh[2];
-    if (threadIdx.x == 0) {
-        int t = -1, m = 0;
-        if ((n_teams & 7) == 0) {
-            const int quota = (n_teams >> 3) * TEAM_M;   // roles per XCD slice: teams x, x + 8, x + 16, ...
-            const int x = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7);   // HW_REG_XCC_ID
-            for (int k = 0; k < 8 && t < 0; ++k) {
-                const int y = (x + k) & 7;
-                const unsigned o = atomicAdd(&claim[y], 1u);
-                if ((int)o < quota) { t = (int)(o >> 2) * 8 + y; m = (int)(o & 3); }
-            }
-        } else {
-            const unsigned o = atomicAdd(&claim[0], 1u);
-            if ((int)o < n_teams * TEAM_M) { t = (int)(o >> 2); m = (int)(o & 3); }
-        }
-        role_sh[0] = t; role_sh[1] = m;
-    }
-    __syncthreads();
-    team = role_sh[0]; member = role_sh[1];
-}
-
-// Once per launch: do the four members of this team share an XCD (hence an L2)?  Each publishes its XCC id as a granule
-// (device scope, like the ring) and reads the three others'.  All members see the same four ids, so they agree on the answer;
-// a member that cannot read a peer answers "no" (the ring will then time out and poison the outputs anyway).
-enum { TEAM_HS_TAG = 0xFFFFFFFFu };
-__device__ __forceinline__ int team_same_xcd(u64* hs, int member, int allow) {
-    __shared__ int same_sh;
-    if (threadIdx.x == 0) {
-        const unsigned my = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID[3:0]
-        granule_store(hs + member, __uint_as_float(my), TEAM_HS_TAG);
-        bool same = allow != 0;
-        for (int m = 0; m < TEAM_M; ++m) {
-            if (m == member) continue;
-            float v = 0.f;
-            const bool ok = granule_wait(granule_load(hs + m), hs + m, TEAM_HS_TAG, v);
-            same = same && ok && __float_as_uint(v) == my;
-        }
-        same_sh = same ? 1 : 0;
-    }
-    __syncthreads();
-    return same_sh;
-}
-
-}  // namespace
 
 // ---------------------------------------------------------------------------------------------------
 // forward.  Same contract as the per-step kernels of rnn.hip: gates[row][G*H] = W_ih x + b_ih on entry,
@@ -685,6 +604,7 @@ bool rnn_team_supported(int cell, int H, int n_seq, int flags) {
 }
 
 int rnn_team_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
+    if (lstm_team_mfma_supported(cell, a.H, a.n_seq, a.flags)) return lstm_team_mfma_forward(a, max_len, team_capacity(), s);
     u64* xb = static_cast<u64*>(a.xbuf);
     if (!xb) { set_error("rnn_team_forward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }
     const int nt = team_count(a.n_seq), ns = team_streams(a.n_seq, nt, a.flags);

@@ -1,0 +1,212 @@
+// LSTM with H = 256 (BASELINE.json configs[2] / [3]) for batches of more than ~128 sequences: the team scheme of
+// rnn_team.hip - a sequence's W_hh spread over the registers of FOUR workgroups that exchange the state every step -
+// with the arithmetic of rnn_persist.hip: a team advances FOUR sequences together, one v_mfma_f32_4x4x1_16b_f32 product
+// phase per time step, instead of giving each of its sequences a turn on the packed-f32 VALU.
+//
+// Replaces the S sequential cell steps of nn.LSTM (the BASELINE.json extension of /root/reference/policy.py:66,141).
+//
+// Why.  rnn_team.hip at 256 sequences (64 teams, four sequences each, one "step call" per sequence in turn): 2 100
+// cycles per call - 1 080 of packed-FMA arithmetic with its DPP reduction trees, the rest poll, barrier and loop control -
+// i.e. 8 400 cycles per time step of the four sequences.  The 4x4x1 MFMA takes the four sequences as the four ROWS of
+// every block, so the same 4 x 65 536 MACs of a member are 1 024 MFMAs = 2 048 matrix-pipe cycles per SIMD, with one
+// poll, two barriers and one loop iteration per time step.  What is left exposed is one hand-off per step (publish ->
+// visible -> read, ~0.7 us): four sequences per team leave nothing to hide it behind, and eight would halve the number
+// of teams.
+//
+// Roles (256 threads, one workgroup per CU, member m of a team = hidden units [64m, 64m + 64), all four gates):
+//   wave w: k half kh = w >> 1 (k in [128 kh, 128 kh + 128)), unit block ub = w & 1;  lane l: gate pair hi = l >> 5
+//   (0: i, f; 1: g, o), unit u = 64 m + 32 ub + (l & 31).  A lane keeps the two gate columns of its unit over its k half
+//   in 256 AGPRs - rnn_persist.hip's register budget and its FwdProduct<128> product phase, unchanged.
+//   After the product: the two k halves swap the partial sums of the sequences the OTHER half owns (one 16-byte LDS
+//   round trip), the gate pairs swap within the wave (v_permlane32_swap), and every lane holds the four gates of ONE cell:
+//   unit u of sequence slot 2 kh + hi.  256 lanes = 64 units x 4 sequences.
+// Exchange: the protocol of rnn_team.hip (team_util.h) - one 8-byte {h, tag} granule per cell per step, ring of four
+// slots, roles by ticket, L2-scope stores when the four members share an XCD, bounded spins.  A lane publishes its cell's h
+// and collects the same unit index of the three other members for the same sequence.
+#include <stdio.h>
+#include <stdlib.h>
+#include "kernels.h"
+#include "persist_util.h"
+#include "team_util.h"
+
+namespace dc {
+namespace {
+
+enum { TM_H = TEAM_H, TM_KH = 128, TM_HLD = TM_KH + 4, TM_THREADS = 256 };
+
+// float index of h[seq][k] inside one buffer of the broadcast-ordered LDS image: [k half][seq][TM_HLD]
+__device__ __forceinline__ int tm_hpos(int seq, int k) { return ((k >> 7) * 4 + seq) * TM_HLD + bcast_pos<TM_KH / 16, TM_HLD>(0, k & 127); }
+
+template <bool TIMING>
+__global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_fwd_kernel(RnnStepArgs p, u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
+    constexpr int H = TM_H, GH = 4 * H;
+    __shared__ __attribute__((aligned(16))) float h_lds[2][2 * 4 * TM_HLD];
+    __shared__ __attribute__((aligned(16))) float4 xch[2][2][64];          // [k half][unit block][lane]: partial sums for the partner
+    __shared__ int dead;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave >> 1, ub = wave & 1, hi = lane >> 5;
+    int team, member;
+    team_claim_role(reinterpret_cast<unsigned*>(xbuf_all), n_teams, team, member);
+    if (team < 0) return;
+    u64* const xbuf = xbuf_all + TEAM_HDR + TEAM_MAX * TEAM_M;
+    const int plain = team_same_xcd(xbuf_all + TEAM_HDR + team * TEAM_M, member, allow_plain);
+    const int ul = 32 * ub + (lane & 31);              // unit inside the member's 64
+    const int u = TEAM_US * member + ul;
+    const int slot = 2 * kh + hi;                      // this lane's cell: (sequence slot, unit u)
+    if (tid == 0) dead = 0;
+
+    // ---- weights: rows (2 hi + m) H + u of W_hh, k in [128 kh, 128 kh + 128) ----------------------------------------
+    float w0[TM_KH], w1[TM_KH];
+    {
+        const float4* r0 = reinterpret_cast<const float4*>(p.Whh + (size_t)((2 * hi + 0) * H + u) * H + TM_KH * kh);
+        const float4* r1 = reinterpret_cast<const float4*>(p.Whh + (size_t)((2 * hi + 1) * H + u) * H + TM_KH * kh);
+#pragma unroll
+        for (int k = 0; k < TM_KH / 4; ++k) {
+            const float4 x = r0[k], y = r1[k];
+            w0[4 * k] = x.x; w0[4 * k + 1] = x.y; w0[4 * k + 2] = x.z; w0[4 * k + 3] = x.w;
+            w1[4 * k] = y.x; w1[4 * k + 1] = y.y; w1[4 * k + 2] = y.z; w1[4 * k + 3] = y.w;
+        }
+    }
+    float bh[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bh[g] = p.bhh[g * H + u];
+
+    unsigned tag = 0;                                  // the team's running step counter (continues across sequence groups)
+    bool failed = false;
+    const int n_groups = (p.n_seq + 3) >> 2;
+    for (int grp = team; grp < n_groups && !failed; grp += n_teams) {
+        int bmap[4], tmax;
+        if (!map_slots(p, 4 * grp, bmap, tmax)) continue;      // (all four slots empty: nothing to publish either, for any member)
+        const int b = slot == 0 ? bmap[0] : (slot == 1 ? bmap[1] : (slot == 2 ? bmap[2] : bmap[3]));
+        // is this slot a duplicate of an earlier one (ragged last group / empty sequence)?  Duplicates compute and store
+        // bit-identical values to the same addresses; they exchange through their own ring stream like any other slot.
+        const int len = p.seq_len[b];
+        const unsigned row0 = (unsigned)p.seq_off[b];
+        unsigned goff = row0 * GH + u, soff = row0 * H + u;
+        unsigned st_g = goff, st_s = soff, st_p = soff;
+        float c = p.c0 ? p.c0[(size_t)b * H + u] : 0.f;
+        const float h0v = p.h0 ? p.h0[(size_t)b * H + u] : 0.f;
+        float sv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float svp0 = c, svp1 = h0v;                    // row 0 of cprev / hprev keeps c0 / h0
+        // h0 of all 256 units of the four slots -> LDS buffer 0 (the previous group's last reads ended at its final barrier)
+        for (int e = tid; e < 4 * H; e += TM_THREADS) {
+            const int q = e >> 8, j = e & (H - 1);
+            const int bq = q == 0 ? bmap[0] : (q == 1 ? bmap[1] : (q == 2 ? bmap[2] : bmap[3]));
+            h_lds[0][tm_hpos(q, j)] = p.h0 ? p.h0[(size_t)bq * H + j] : 0.f;
+        }
+        float xc[4], xn[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xc[g] = p.gates[goff + g * H];
+        u64* const xb = xbuf + (size_t)(team * 4 + slot) * (TEAM_SLOTS * H);      // ring of this lane's sequence slot
+        __syncthreads();
+
+        auto step = [&](const int t, float (&xcur)[4], float (&xnext)[4], auto CUR) {
+            constexpr int cur = decltype(CUR)::value;
+            const bool on = t < len, on1 = t + 1 < len;
+            const unsigned gnx = goff + (on1 ? GH : 0);
+            const float* const lp = p.gates + gnx;
+            float* const gs = p.gates + st_g;
+            float* const cs = p.cseq + st_s;
+            float* const hs = p.hseq + st_s;
+            float* const cp = p.cprev + st_p;
+            float* const hp = p.hprev + st_p;
+            // between the MFMA pairs: the loads of the next step's gate pre-activations, the stores of the previous step's results
+            auto hook = [&](auto K) {
+                constexpr int k = decltype(K)::value;          // 0 .. 63
+                if constexpr (k >= 1 && k <= 4) xnext[k - 1] = lp[(k - 1) * H];
+                else if constexpr (k >= 8 && k <= 11) gs[(k - 8) * H] = sv[k - 8];
+                else if constexpr (k == 12) *cs = sv[4];
+                else if constexpr (k == 13) *hs = sv[5];
+                else if constexpr (k == 14) *cp = svp0;
+                else if constexpr (k == 15) *hp = svp1;
+            };
+            f32x4 pa[4];
+            FwdProduct<TM_KH>::run(pa, w0, w1, lds_addr(&h_lds[cur][(kh * 4 + (lane & 3)) * TM_HLD + (lane >> 2) * (TM_KH / 16)]), hook);
+            f32x4 acc0 = pa[0] + pa[2], acc1 = pa[1] + pa[3];   // gate columns 2 hi, 2 hi + 1 of the four sequences, this k half
+            // ---- k halves: hand the partner the partial sums of ITS two sequences, add its partials of mine -----------
+            const int other = 2 * (kh ^ 1);
+            xch[kh][ub][lane] = kh ? make_float4(acc0[0], acc0[1], acc1[0], acc1[1]) : make_float4(acc0[2], acc0[3], acc1[2], acc1[3]);
+            (void)other;
+            __syncthreads();
+            const float4 pr = xch[kh ^ 1][ub][lane];
+            float y0 = (kh ? acc0[2] : acc0[0]) + pr.x, x0 = (kh ? acc0[3] : acc0[1]) + pr.y;      // gate 2 hi     of sequences 2 kh, 2 kh + 1
+            float y1 = (kh ? acc1[2] : acc1[0]) + pr.z, x1 = (kh ? acc1[3] : acc1[1]) + pr.w;      // gate 2 hi + 1
+            // ---- gate pairs: afterwards y0 = i, x0 = g, y1 = f, x1 = o of this lane's own cell (sequence 2 kh + hi) --------
+            half_swap(y0, x0);
+            half_swap(y1, x1);
+            const float ig = fast_sigmoid(xcur[0] + (y0 + bh[0]));
+            const float fg = fast_sigmoid(xcur[1] + (y1 + bh[1]));
+            const float gg = fast_tanh(xcur[2] + (x0 + bh[2]));
+            const float og = fast_sigmoid(xcur[3] + (x1 + bh[3]));
+            const float cn = fg * c + ig * gg;
+            const float hn = og * fast_tanh(cn);
+            const float hpub = on ? hn : 0.f;
+            ++tag;
+            granule_store(xb + (tag & 3) * H + u, hpub, tag, plain);      // publish first: the peers are waiting for it
+            h_lds[cur ^ 1][tm_hpos(slot, u)] = hpub;
+            c = on ? cn : c;
+            sv[0] = on ? ig : sv[0]; sv[1] = on ? fg : sv[1]; sv[2] = on ? gg : sv[2];
+            sv[3] = on ? og : sv[3]; sv[4] = on ? cn : sv[4]; sv[5] = on ? hn : sv[5];
+            st_g = on ? goff : st_g;
+            st_s = on ? soff : st_s;
+            svp0 = on1 ? cn : svp0;
+            svp1 = on1 ? hn : svp1;
+            st_p = on1 ? soff + H : st_p;
+            goff = gnx;
+            soff += on1 ? H : 0;
+            // ---- the same unit index of the three other members, same sequence -> LDS ------------------------------------
+            if (t + 1 < tmax) {
+#pragma unroll
+                for (int j = 1; j < TEAM_M; ++j) {
+                    const int uu = TEAM_US * ((member + j) & 3) + ul;
+                    const u64* gptr = xb + (tag & 3) * H + uu;
+                    float v = 0.f;
+                    if (!granule_wait(granule_load(gptr), gptr, tag, v)) dead = 1;
+                    h_lds[cur ^ 1][tm_hpos(slot, uu)] = v;
+                }
+            }
+            __syncthreads();
+            return dead == 0;
+        };
+        for (int t = 0; t < tmax; t += 2) {
+            if (!step(t, xc, xn, std::integral_constant<int, 0>{})) { failed = true; break; }
+            if (t + 1 < tmax && !step(t + 1, xn, xc, std::integral_constant<int, 1>{})) { failed = true; break; }
+        }
+        // drain: the deferred stores of the group's last step
+#pragma unroll
+        for (int g = 0; g < 4; ++g) p.gates[st_g + g * H] = sv[g];
+        p.cseq[st_s] = sv[4];
+        p.hseq[st_s] = failed ? __builtin_nanf("") : sv[5];      // a peer never answered: make the failure visible downstream
+        p.cprev[st_p] = svp0;
+        p.hprev[st_p] = svp1;
+        if ((tmax & 1) && !failed) {                   // an odd number of steps ended in buffer 1: the next group starts from buffer 0
+            // (nothing to copy: the next group overwrites buffer 0 with its own h0 before its first step)
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+bool lstm_team_mfma_supported(int cell, int H, int n_seq, int flags) {
+    // measured at 256 steps: 128 sequences run as fast on the VALU team kernels with two sequences in flight per team; below
+    // that the VALU kernels use more CUs (one team per sequence) than sixteen or fewer MFMA teams would
+    return cell == 1 && H == TM_H && n_seq > 128 && !(flags & DC_DIMS_TEAM_VALU);
+}
+
+int lstm_team_mfma_forward(RnnStepArgs a, int max_len, int n_teams, hipStream_t s) {
+    u64* xb = static_cast<u64*>(a.xbuf);
+    if (!xb) { set_error("lstm_team_mfma_forward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }
+    const int groups = (a.n_seq + 3) / 4;
+    int nt = groups < n_teams ? groups : n_teams;
+    if (nt >= 8) nt &= ~7;
+    ProfScope prof("lstm_fwd_team", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * (2.0 * 4 + 4.0), s);
+    if (hipMemsetAsync(xb, 0, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * TEAM_M + (size_t)nt * 4 * TEAM_SLOTS * TEAM_H) * sizeof(u64), s) != hipSuccess)
+        return launch_check("lstm_team_mfma_forward memset");
+    hipLaunchKernelGGL(lstm_team_mfma_fwd_kernel<false>, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt,
+                       !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+    return launch_check("lstm_team_mfma_forward");
+}
+
+}  // namespace dc

@@ -129,6 +129,9 @@ typedef struct dc_dims {
 #define DC_DIMS_GEMM_FASTTILE 2048
 #define DC_DIMS_BF16 4096
 #define DC_DIMS_GEMM_X3_ALL 8192
+/*   DC_DIMS_TEAM_VALU      : H = 256 LSTM: the packed-f32 VALU team kernels (one sequence per turn) also for batches of more than
+ *                            128 sequences, where the default is the MFMA team kernel that advances four sequences together. */
+#define DC_DIMS_TEAM_VALU 16384
 
 /* index into poff[]; policy.py:54-75 names in comments */
 enum dc_param_index {

@@ -188,7 +188,8 @@ def test_lstm_persist_variants_agree(S, lens):
 
 
 @pytest.mark.parametrize('cell', ['gru', 'lstm'])
-@pytest.mark.parametrize('S,lens', [(256, [256] * 6), (7, [21, 7, 13, 30, 1, 44]), (5, [350]), (16, [50, 64, 33]), (3, [1200, 2])])
+@pytest.mark.parametrize('S,lens', [(256, [256] * 6), (7, [21, 7, 13, 30, 1, 44]), (5, [350]), (16, [50, 64, 33]), (3, [1200, 2]), (8, [8] * 131 + [24, 16]),
+                                    (2, [1100])])
 def test_rnn_team_kernels_agree_with_per_step(cell, S, lens):
     # H = 256 (the reference's GRU, the LSTM-256 configs): the four-workgroups-per-sequence persistent kernels
     # (rnn_team.hip) against the launch-per-step kernels on the same batch.  6 / 17 / 70 / 11 / 401 chunk sequences:
@@ -200,9 +201,12 @@ def test_rnn_team_kernels_agree_with_per_step(cell, S, lens):
     from dotaclient_amd.engine import Engine, pack_rollouts
     dev = torch.device('cuda:0')
     outs = {}
-    for mode, ns in (('0', None), ('1', None), ('1', '1'), ('1', '2'), ('1', '4')):
+    # mode '1' / None = the default selection (LSTM with more than 128 sequences: the MFMA team kernel, four sequences per
+    # team step); 'v' = the VALU team kernels whatever the batch
+    for mode, ns in (('0', None), ('1', None), ('v', None), ('v', '1'), ('v', '2'), ('v', '4')):
         eng = Engine(cell, 256, 1, dev)
-        eng.kernel_flags = E.DC_DIMS_RNN_PER_STEP if mode == '0' else (E.DC_DIMS_TEAM_NS(int(ns)) if ns else 0)
+        eng.kernel_flags = E.DC_DIMS_RNN_PER_STEP if mode == '0' else \
+            ((E.DC_DIMS_TEAM_VALU if mode == 'v' else 0) | (E.DC_DIMS_TEAM_NS(int(ns)) if ns else 0))
         eng.load_state_dict(synth.init_state_dict(7, cell, 256, 1))
         rollouts = synth.make_rollouts(78, lens)
         batch = pack_rollouts(rollouts, S, dev)
