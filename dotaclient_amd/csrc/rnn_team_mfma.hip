@@ -157,12 +157,14 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_fwd_kernel(RnnSt
             soff += on1 ? H : 0;
             // ---- the same unit index of the three other members, same sequence -> LDS ------------------------------------
             if (t + 1 < tmax) {
+                u64 gr[3];
+#pragma unroll
+                for (int j = 1; j < TEAM_M; ++j) gr[j - 1] = granule_load(xb + (tag & 3) * H + TEAM_US * ((member + j) & 3) + ul);
 #pragma unroll
                 for (int j = 1; j < TEAM_M; ++j) {
                     const int uu = TEAM_US * ((member + j) & 3) + ul;
-                    const u64* gptr = xb + (tag & 3) * H + uu;
                     float v = 0.f;
-                    if (!granule_wait(granule_load(gptr), gptr, tag, v)) dead = 1;
+                    if (!granule_wait(gr[j - 1], xb + (tag & 3) * H + uu, tag, v)) dead = 1;
                     h_lds[cur ^ 1][tm_hpos(slot, uu)] = v;
                 }
             }
@@ -187,6 +189,147 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_fwd_kernel(RnnSt
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// backward through time, same team / lane scheme.  Member m accumulates dh_rec[seq][u] = sum over ALL 1024 gate columns
+// of dgates_{t+1}[seq][col] W_hh[col][u] for its 64 units u: wave w = (quarter pair kp = w >> 1, unit block ub = w & 1),
+// lane (hi, l & 31) contracts quarter 2 kp + hi of the gate columns - with H = 256 a quarter IS a gate - over all 256 units
+// (256 AGPRs, rnn_persist.hip's BwdProduct<256> unchanged).  The four quarters are summed like the forward's k halves
+// (16-byte LDS hand-over between the wave pairs, v_permlane32_swap inside the wave); every lane then finishes ONE cell
+// (unit u, sequence slot 2 kp + hi), publishes its FOUR gate gradients and collects the twelve of the same unit index and
+// sequence from the three other members.  In: dh (from the layer above), the forward's gates / cseq / cprev; out: dgx.
+// ---------------------------------------------------------------------------------------------------
+enum { TB_KH = 256, TB_GLD = 2 * TB_KH + 8 };
+
+// float index of gate gradient (gate g, unit k) of sequence `seq` inside one buffer: [quarter pair][seq][TB_GLD], broadcast order
+__device__ __forceinline__ int tb_gpos(int seq, int g, int k) { return ((g >> 1) * 4 + seq) * TB_GLD + BwdProduct<TB_KH>::pos((g & 1) * TB_KH + k); }
+
+__global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_bwd_kernel(RnnStepArgs p, u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
+    constexpr int H = TM_H, GH = 4 * H, KH = TB_KH;
+    __shared__ __attribute__((aligned(16))) float g_lds[2][2 * 4 * TB_GLD];
+    __shared__ float2 xch[2][2][64];
+    __shared__ int dead;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kp = wave >> 1, ub = wave & 1, hi = lane >> 5;
+    int team, member;
+    team_claim_role(reinterpret_cast<unsigned*>(xbuf_all), n_teams, team, member);
+    if (team < 0) return;
+    u64* const xbuf = xbuf_all + TEAM_HDR + TEAM_MAX * TEAM_M;
+    const int plain = team_same_xcd(xbuf_all + TEAM_HDR + team * TEAM_M, member, allow_plain);
+    const int ul = 32 * ub + (lane & 31);
+    const int u = TEAM_US * member + ul;
+    const int slot = 2 * kp + hi;
+    const int quarter = 2 * kp + hi;                   // gate whose columns this lane contracts
+    if (tid == 0) dead = 0;
+
+    // ---- weights: W_hh[quarter H + kk][u], kk = 0 .. 255 -------------------------------------------------------------
+    float w[KH];
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk) w[kk] = p.Whh[(size_t)(quarter * H + kk) * H + u];
+
+    unsigned tag = 0;
+    bool failed = false;
+    const int n_groups = (p.n_seq + 3) >> 2;
+    for (int grp = team; grp < n_groups && !failed; grp += n_teams) {
+        int bmap[4], tmax;
+        if (!map_slots(p, 4 * grp, bmap, tmax)) continue;
+        const int b = slot == 0 ? bmap[0] : (slot == 1 ? bmap[1] : (slot == 2 ? bmap[2] : bmap[3]));
+        const int len = p.seq_len[b];
+        const unsigned row = (unsigned)p.seq_off[b] + (unsigned)min(tmax - 1, len - 1);
+        unsigned goff = row * GH + u, soff = row * H + u, st_g = goff;
+        float dc_next = 0.f, f_next = 0.f;
+        float cur_v[7], nxt_v[7];                      // i, f, g, o, c, c_prev, dh
+        float sv[4] = {0.f, 0.f, 0.f, 0.f};            // gate gradients of the last finished step, stored one step late
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cur_v[g] = p.gates[goff + g * H];
+        cur_v[4] = p.cseq[soff];
+        cur_v[5] = p.cprev[soff];
+        cur_v[6] = p.dh[soff];
+        for (int e = tid; e < 2 * 4 * TB_GLD; e += TM_THREADS) g_lds[0][e] = 0.f;      // "step tmax" has no gradient
+        u64* const xb = xbuf + (size_t)(team * 4 + slot) * (TEAM_SLOTS * GH);
+        __syncthreads();
+
+        auto step = [&](const int t, float (&cv)[7], float (&nv)[7], auto CUR) {
+            constexpr int cur = decltype(CUR)::value;
+            const bool on = t < len, has_next = t + 1 < len, dec = t < len && t > 0;      // dec: the row below is next
+            const unsigned gnx = goff - (dec ? GH : 0), snx = soff - (dec ? H : 0);
+            const float* const lg = p.gates + gnx;
+            const float* const lc = p.cseq + snx;
+            const float* const lcp = p.cprev + snx;
+            const float* const ldh = p.dh + snx;
+            float* const gs = p.dgx + st_g;
+            auto hook = [&](auto K) {
+                constexpr int k = decltype(K)::value;          // 0 .. 63
+                if constexpr (k >= 1 && k <= 4) nv[k - 1] = lg[(k - 1) * H];
+                else if constexpr (k == 5) nv[4] = *lc;
+                else if constexpr (k == 6) nv[5] = *lcp;
+                else if constexpr (k == 7) nv[6] = *ldh;
+                else if constexpr (k >= 10 && k <= 13) gs[(k - 10) * H] = sv[k - 10];
+            };
+            f32x4 pa[4];
+            BwdProduct<KH>::run(pa, w, lds_addr(&g_lds[cur][(kp * 4 + (lane & 3)) * TB_GLD + KH * hi + ((lane >> 2) & 7) * BwdProduct<KH>::NJ]), hook);
+            const f32x4 acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);      // this quarter's share of dh_rec[seq 0..3][u]
+            // ---- quarter pairs: hand the partner the partial sums of ITS two sequences, add its partials of mine ----------
+            xch[kp][ub][lane] = kp ? make_float2(acc[0], acc[1]) : make_float2(acc[2], acc[3]);
+            __syncthreads();
+            const float2 pr = xch[kp ^ 1][ub][lane];
+            float y = (kp ? acc[2] : acc[0]) + pr.x, x = (kp ? acc[3] : acc[1]) + pr.y;      // sequences 2 kp, 2 kp + 1; two of the four quarters
+            half_swap(y, x);                                      // + the other two quarters (lane ^ 32): low lanes sequence 2 kp, high lanes 2 kp + 1
+            const float rec = y + x;
+
+            float dh = cv[6];
+            dh += has_next ? rec : 0.f;
+            const float ig = cv[0], fg = cv[1], gg = cv[2], og = cv[3];
+            const float tc = fast_tanh(cv[4]);
+            float dcv = dh * og * (1.f - tc * tc);
+            dcv += has_next ? dc_next * f_next : 0.f;
+            const float dgr[4] = {on ? dcv * gg * ig * (1.f - ig) : 0.f, on ? dcv * cv[5] * fg * (1.f - fg) : 0.f,
+                                  on ? dcv * ig * (1.f - gg * gg) : 0.f, on ? dh * tc * og * (1.f - og) : 0.f};
+            ++tag;
+            u64* const ring = xb + (tag & 3) * GH;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) granule_store(ring + g * H + u, dgr[g], tag, plain);      // publish first
+#pragma unroll
+            for (int g = 0; g < 4; ++g) g_lds[cur ^ 1][tb_gpos(slot, g, u)] = dgr[g];
+            sv[0] = on ? dgr[0] : sv[0]; sv[1] = on ? dgr[1] : sv[1]; sv[2] = on ? dgr[2] : sv[2]; sv[3] = on ? dgr[3] : sv[3];
+            st_g = on ? goff : st_g;
+            dc_next = on ? dcv : dc_next;
+            f_next = on ? fg : f_next;
+            goff = gnx;
+            soff = snx;
+            // ---- the four gate gradients of the same unit index of the three other members, same sequence -> LDS ---------
+            if (t > 0) {
+                u64 gr[3][4];
+#pragma unroll
+                for (int j = 1; j < TEAM_M; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) gr[j - 1][g] = granule_load(ring + g * H + TEAM_US * ((member + j) & 3) + ul);
+#pragma unroll
+                for (int j = 1; j < TEAM_M; ++j) {
+                    const int uu = TEAM_US * ((member + j) & 3) + ul;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v = 0.f;
+                        if (!granule_wait(gr[j - 1][g], ring + g * H + uu, tag, v)) dead = 1;
+                        g_lds[cur ^ 1][tb_gpos(slot, g, uu)] = v;
+                    }
+                }
+            }
+            __syncthreads();
+            return dead == 0;
+        };
+        for (int t = tmax - 1; t >= 0; t -= 2) {
+            if (!step(t, cur_v, nxt_v, std::integral_constant<int, 0>{})) { failed = true; break; }
+            if (t - 1 >= 0 && !step(t - 1, nxt_v, cur_v, std::integral_constant<int, 1>{})) { failed = true; break; }
+        }
+        // drain the deferred stores of step 0
+#pragma unroll
+        for (int g = 0; g < 4; ++g) p.dgx[st_g + g * H] = failed ? __builtin_nanf("") : sv[g];
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 bool lstm_team_mfma_supported(int cell, int H, int n_seq, int flags) {
@@ -207,6 +350,19 @@ int lstm_team_mfma_forward(RnnStepArgs a, int max_len, int n_teams, hipStream_t 
     hipLaunchKernelGGL(lstm_team_mfma_fwd_kernel<false>, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt,
                        !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
     return launch_check("lstm_team_mfma_forward");
+}
+
+int lstm_team_mfma_backward(RnnStepArgs a, int max_len, int n_teams, hipStream_t s) {
+    u64* xb = static_cast<u64*>(a.xbuf);
+    if (!xb) { set_error("lstm_team_mfma_backward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }
+    const int groups = (a.n_seq + 3) / 4;
+    int nt = groups < n_teams ? groups : n_teams;
+    if (nt >= 8) nt &= ~7;
+    ProfScope prof("lstm_bwd_team", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * (3.0 * 4 + 6.0), s);
+    if (hipMemsetAsync(xb, 0, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * TEAM_M + (size_t)nt * 4 * TEAM_SLOTS * 4 * TEAM_H) * sizeof(u64), s) != hipSuccess)
+        return launch_check("lstm_team_mfma_backward memset");
+    hipLaunchKernelGGL(lstm_team_mfma_bwd_kernel, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+    return launch_check("lstm_team_mfma_backward");
 }
 
 }  // namespace dc
