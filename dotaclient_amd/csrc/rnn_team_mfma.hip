@@ -191,43 +191,46 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_fwd_kernel(RnnSt
 
 
 // ---------------------------------------------------------------------------------------------------
-// backward through time, same team / lane scheme.  Member m accumulates dh_rec[seq][u] = sum over ALL 1024 gate columns
-// of dgates_{t+1}[seq][col] W_hh[col][u] for its 64 units u: wave w = (quarter pair kp = w >> 1, unit block ub = w & 1),
-// lane (hi, l & 31) contracts quarter 2 kp + hi of the gate columns - with H = 256 a quarter IS a gate - over all 256 units
-// (256 AGPRs, rnn_persist.hip's BwdProduct<256> unchanged).  The four quarters are summed like the forward's k halves
-// (16-byte LDS hand-over between the wave pairs, v_permlane32_swap inside the wave); every lane then finishes ONE cell
-// (unit u, sequence slot 2 kp + hi), publishes its FOUR gate gradients and collects the twelve of the same unit index and
-// sequence from the three other members.  In: dh (from the layer above), the forward's gates / cseq / cprev; out: dgx.
+// backward through time.  The forward is COLUMN-parallel (a member owns the gate columns of its 64 units and needs all of
+// h_{t-1}: an all-gather of 192 foreign values per sequence).  Done the same way, the backward would need all 1 024 gate
+// gradients of every sequence in every member - 3 072 eight-byte reads per member and step, and that exchange, not the
+// arithmetic, is what a step then costs (measured: 3.8 us per step, the VALU team kernel's time).  So the backward is
+// ROW-parallel: a member contracts ITS OWN 256 gate gradients (4 gates x its 64 units - no input from anyone) with the rows
+// W_hh[own column][u'] for ALL 256 output units u' - the very weights of its forward slice - and the partial sums
+// dh_rec[seq][u'] are reduce-scattered: a lane whose u' belongs to another member publishes its four sums to the owner
+// (768 granules out, 768 in per member and step: a quarter of the reads), the owner adds the three it receives to its own.
+//   lane (wave w, l): output unit u' = 64 w + l, K = 256 own columns kk = 64 g + j (gate g, own unit j): 256 AGPRs,
+//   rnn_persist.hip's BwdProduct<256> with both wave halves on the same k range - no cross-lane reduction at all.
+//   cell (unit 64 m + (tid & 63), sequence slot tid >> 6): own partial through LDS + three granules -> gate gradients ->
+//   the LDS image of the next product (all local) and dgx.
+// In: dh (from the layer above), the forward's gates / cseq / cprev; out: dgx.
 // ---------------------------------------------------------------------------------------------------
-enum { TB_KH = 256, TB_GLD = 2 * TB_KH + 8 };
-
-// float index of gate gradient (gate g, unit k) of sequence `seq` inside one buffer: [quarter pair][seq][TB_GLD], broadcast order
-__device__ __forceinline__ int tb_gpos(int seq, int g, int k) { return ((g >> 1) * 4 + seq) * TB_GLD + BwdProduct<TB_KH>::pos((g & 1) * TB_KH + k); }
+enum { TB_KH = 256, TB_GLD = TB_KH + 8 };
 
 __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_bwd_kernel(RnnStepArgs p, u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
     constexpr int H = TM_H, GH = 4 * H, KH = TB_KH;
-    __shared__ __attribute__((aligned(16))) float g_lds[2][2 * 4 * TB_GLD];
-    __shared__ float2 xch[2][2][64];
+    __shared__ __attribute__((aligned(16))) float g_lds[2][4 * TB_GLD];      // own gate gradients [seq][pos(kk)], kk = 64 gate + own unit
+    __shared__ float own[4][TEAM_US];                                         // own partial sums dh_rec[seq][own unit]
     __shared__ int dead;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kp = wave >> 1, ub = wave & 1, hi = lane >> 5;
     int team, member;
     team_claim_role(reinterpret_cast<unsigned*>(xbuf_all), n_teams, team, member);
     if (team < 0) return;
     u64* const xbuf = xbuf_all + TEAM_HDR + TEAM_MAX * TEAM_M;
     const int plain = team_same_xcd(xbuf_all + TEAM_HDR + team * TEAM_M, member, allow_plain);
-    const int ul = 32 * ub + (lane & 31);
+    const int up = tid;                                // product role: output unit u' = tid, owner member = wave
+    const int slot = wave, ul = lane;                  // cell role: sequence slot, own unit
     const int u = TEAM_US * member + ul;
-    const int slot = 2 * kp + hi;
-    const int quarter = 2 * kp + hi;                   // gate whose columns this lane contracts
     if (tid == 0) dead = 0;
 
-    // ---- weights: W_hh[quarter H + kk][u], kk = 0 .. 255 -------------------------------------------------------------
+    // ---- weights: W_hh[(kk >> 6) H + 64 m + (kk & 63)][u'], kk = 0 .. 255 ---------------------------------------------
     float w[KH];
 #pragma unroll
-    for (int kk = 0; kk < KH; ++kk) w[kk] = p.Whh[(size_t)(quarter * H + kk) * H + u];
+    for (int kk = 0; kk < KH; ++kk) w[kk] = p.Whh[(size_t)((kk >> 6) * H + TEAM_US * member + (kk & 63)) * H + up];
 
+    // ring of a team: [tag & 3][owner member][source member][sequence slot][64 units] granules
+    u64* const ring0 = xbuf + (size_t)team * (TEAM_SLOTS * 4 * 4 * 4 * TEAM_US);
     unsigned tag = 0;
     bool failed = false;
     const int n_groups = (p.n_seq + 3) >> 2;
@@ -246,13 +249,13 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_bwd_kernel(RnnSt
         cur_v[4] = p.cseq[soff];
         cur_v[5] = p.cprev[soff];
         cur_v[6] = p.dh[soff];
-        for (int e = tid; e < 2 * 4 * TB_GLD; e += TM_THREADS) g_lds[0][e] = 0.f;      // "step tmax" has no gradient
-        u64* const xb = xbuf + (size_t)(team * 4 + slot) * (TEAM_SLOTS * GH);
+        for (int e = tid; e < 4 * TB_GLD; e += TM_THREADS) g_lds[0][e] = 0.f;      // "step tmax" has no gradient
         __syncthreads();
 
         auto step = [&](const int t, float (&cv)[7], float (&nv)[7], auto CUR) {
             constexpr int cur = decltype(CUR)::value;
             const bool on = t < len, has_next = t + 1 < len, dec = t < len && t > 0;      // dec: the row below is next
+            const bool xchg = t + 1 < tmax;                                               // workgroup- and team-uniform
             const unsigned gnx = goff - (dec ? GH : 0), snx = soff - (dec ? H : 0);
             const float* const lg = p.gates + gnx;
             const float* const lc = p.cseq + snx;
@@ -267,17 +270,36 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_bwd_kernel(RnnSt
                 else if constexpr (k == 7) nv[6] = *ldh;
                 else if constexpr (k >= 10 && k <= 13) gs[(k - 10) * H] = sv[k - 10];
             };
+            // ---- partial dh_rec[seq 0..3][u'] over this member's 256 gate columns ------------------------------------------
             f32x4 pa[4];
-            BwdProduct<KH>::run(pa, w, lds_addr(&g_lds[cur][(kp * 4 + (lane & 3)) * TB_GLD + KH * hi + ((lane >> 2) & 7) * BwdProduct<KH>::NJ]), hook);
-            const f32x4 acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);      // this quarter's share of dh_rec[seq 0..3][u]
-            // ---- quarter pairs: hand the partner the partial sums of ITS two sequences, add its partials of mine ----------
-            xch[kp][ub][lane] = kp ? make_float2(acc[0], acc[1]) : make_float2(acc[2], acc[3]);
+            BwdProduct<KH>::run(pa, w, lds_addr(&g_lds[cur][(lane & 3) * TB_GLD + ((lane >> 2) & 7) * BwdProduct<KH>::NJ]), hook);
+            const f32x4 acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+            ++tag;
+            u64* const ring = ring0 + (size_t)(tag & 3) * (4 * 4 * 4 * TEAM_US);
+            if (xchg) {
+                if (wave == member) {                                  // my own units: through LDS
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) own[q][lane] = acc[q];
+                } else {                                               // the owner's: [owner = wave][source = member][seq][unit]
+                    u64* dst = ring + ((size_t)(wave * 4 + member) * 4) * TEAM_US + lane;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) granule_store(dst + q * TEAM_US, acc[q], tag, plain);
+                }
+            }
             __syncthreads();
-            const float2 pr = xch[kp ^ 1][ub][lane];
-            float y = (kp ? acc[2] : acc[0]) + pr.x, x = (kp ? acc[3] : acc[1]) + pr.y;      // sequences 2 kp, 2 kp + 1; two of the four quarters
-            half_swap(y, x);                                      // + the other two quarters (lane ^ 32): low lanes sequence 2 kp, high lanes 2 kp + 1
-            const float rec = y + x;
-
+            float rec = 0.f;
+            if (xchg) {
+                u64 gr[3];
+#pragma unroll
+                for (int j = 1; j < TEAM_M; ++j) gr[j - 1] = granule_load(ring + ((size_t)(member * 4 + ((member + j) & 3)) * 4 + slot) * TEAM_US + ul);
+                rec = own[slot][ul];
+#pragma unroll
+                for (int j = 1; j < TEAM_M; ++j) {
+                    float v = 0.f;
+                    if (!granule_wait(gr[j - 1], ring + ((size_t)(member * 4 + ((member + j) & 3)) * 4 + slot) * TEAM_US + ul, tag, v)) dead = 1;
+                    rec += v;
+                }
+            }
             float dh = cv[6];
             dh += has_next ? rec : 0.f;
             const float ig = cv[0], fg = cv[1], gg = cv[2], og = cv[3];
@@ -286,36 +308,14 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_bwd_kernel(RnnSt
             dcv += has_next ? dc_next * f_next : 0.f;
             const float dgr[4] = {on ? dcv * gg * ig * (1.f - ig) : 0.f, on ? dcv * cv[5] * fg * (1.f - fg) : 0.f,
                                   on ? dcv * ig * (1.f - gg * gg) : 0.f, on ? dh * tc * og * (1.f - og) : 0.f};
-            ++tag;
-            u64* const ring = xb + (tag & 3) * GH;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) granule_store(ring + g * H + u, dgr[g], tag, plain);      // publish first
-#pragma unroll
-            for (int g = 0; g < 4; ++g) g_lds[cur ^ 1][tb_gpos(slot, g, u)] = dgr[g];
+            for (int g = 0; g < 4; ++g) g_lds[cur ^ 1][slot * TB_GLD + BwdProduct<KH>::pos(TEAM_US * g + ul)] = dgr[g];
             sv[0] = on ? dgr[0] : sv[0]; sv[1] = on ? dgr[1] : sv[1]; sv[2] = on ? dgr[2] : sv[2]; sv[3] = on ? dgr[3] : sv[3];
             st_g = on ? goff : st_g;
             dc_next = on ? dcv : dc_next;
             f_next = on ? fg : f_next;
             goff = gnx;
             soff = snx;
-            // ---- the four gate gradients of the same unit index of the three other members, same sequence -> LDS ---------
-            if (t > 0) {
-                u64 gr[3][4];
-#pragma unroll
-                for (int j = 1; j < TEAM_M; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) gr[j - 1][g] = granule_load(ring + g * H + TEAM_US * ((member + j) & 3) + ul);
-#pragma unroll
-                for (int j = 1; j < TEAM_M; ++j) {
-                    const int uu = TEAM_US * ((member + j) & 3) + ul;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float v = 0.f;
-                        if (!granule_wait(gr[j - 1][g], ring + g * H + uu, tag, v)) dead = 1;
-                        g_lds[cur ^ 1][tb_gpos(slot, g, uu)] = v;
-                    }
-                }
-            }
             __syncthreads();
             return dead == 0;
         };
