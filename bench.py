@@ -85,10 +85,16 @@ def pmc_traffic(path, kernel, workload_key):
         return None
     if j.get('meta', {}).get('workload') not in (None, workload_key):
         return None
-    region_kernels = {'gru_fwd_team': 'rnn_team_fwd', 'lstm_fwd_team': 'rnn_team_fwd', 'gru_bwd_team': 'rnn_team_bwd',
-                      'lstm_bwd_team': 'rnn_team_bwd', 'lstm_fwd_persist': 'lstm_fwd_valu', 'lstm_bwd_persist': 'lstm_bwd_valu'}
-    k = j.get('kernels', {}).get(region_kernels.get(kernel, kernel) + '_kernel')
-    return int(k['bytes']) if k else None
+    # profiling region -> kernel(s) that run inside it (the first one present in the summary wins)
+    region_kernels = {'gru_fwd_team': ['rnn_team_fwd'], 'gru_bwd_team': ['rnn_team_bwd'],
+                      'lstm_fwd_team': ['lstm_team_mfma_fwd', 'rnn_team_fwd'], 'lstm_bwd_team': ['lstm_team_mfma_bwd', 'rnn_team_bwd'],
+                      'lstm_fwd_persist': ['lstm_fwd_valu'], 'lstm_bwd_persist': ['lstm_bwd_valu'],
+                      'gemm_f32_dW': ['gemm_x3'], 'gemm_f32_fwd': ['gemm_fast'], 'gemm_f32_dX': ['gemm_fast']}
+    for cand in region_kernels.get(kernel, [kernel]):
+        k = j.get('kernels', {}).get(cand + '_kernel')
+        if k:
+            return int(k['bytes'])
+    return None
 
 
 def _tensor_samples(t, stride=251):

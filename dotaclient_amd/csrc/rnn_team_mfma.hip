@@ -34,8 +34,14 @@ namespace {
 
 enum { TM_H = TEAM_H, TM_KH = 128, TM_HLD = TM_KH + 4, TM_THREADS = 256 };
 
-// float index of h[seq][k] inside one buffer of the broadcast-ordered LDS image: [k half][seq][TM_HLD]
-__device__ __forceinline__ int tm_hpos(int seq, int k) { return ((k >> 7) * 4 + seq) * TM_HLD + bcast_pos<TM_KH / 16, TM_HLD>(0, k & 127); }
+// float index of h[seq][k] inside one buffer of the LDS image: [k half][seq][TM_HLD], k in PLAIN order inside a row.  The
+// product phase (FwdProduct<128>) hands MFMA number kk' (block broadcast abid = kk' & 15 of A register kk' >> 4) the eight
+// consecutive floats lane 4b+i read at [i][8b ..]: it contracts k = 8 (kk' & 15) + (kk' >> 4) - so the WEIGHTS are loaded
+// into the registers in that order (tm_korder), once, and the per-step LDS stores of h (consecutive lanes = consecutive
+// units) are consecutive words instead of the 8-word stride of rnn_persist.hip's broadcast order (measured there: 48 % of
+// the LDS cycles were bank conflicts).
+__device__ __forceinline__ int tm_hpos(int seq, int k) { return ((k >> 7) * 4 + seq) * TM_HLD + (k & 127); }
+__device__ __forceinline__ constexpr int tm_korder(int kk) { return 8 * (kk & 15) + (kk >> 4); }
 
 template <bool TIMING>
 __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_fwd_kernel(RnnStepArgs p, u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
@@ -59,14 +65,10 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_fwd_kernel(RnnSt
     // ---- weights: rows (2 hi + m) H + u of W_hh, k in [128 kh, 128 kh + 128) ----------------------------------------
     float w0[TM_KH], w1[TM_KH];
     {
-        const float4* r0 = reinterpret_cast<const float4*>(p.Whh + (size_t)((2 * hi + 0) * H + u) * H + TM_KH * kh);
-        const float4* r1 = reinterpret_cast<const float4*>(p.Whh + (size_t)((2 * hi + 1) * H + u) * H + TM_KH * kh);
+        const float* r0 = p.Whh + (size_t)((2 * hi + 0) * H + u) * H + TM_KH * kh;
+        const float* r1 = p.Whh + (size_t)((2 * hi + 1) * H + u) * H + TM_KH * kh;
 #pragma unroll
-        for (int k = 0; k < TM_KH / 4; ++k) {
-            const float4 x = r0[k], y = r1[k];
-            w0[4 * k] = x.x; w0[4 * k + 1] = x.y; w0[4 * k + 2] = x.z; w0[4 * k + 3] = x.w;
-            w1[4 * k] = y.x; w1[4 * k + 1] = y.y; w1[4 * k + 2] = y.z; w1[4 * k + 3] = y.w;
-        }
+        for (int kk = 0; kk < TM_KH; ++kk) { w0[kk] = r0[tm_korder(kk)]; w1[kk] = r1[tm_korder(kk)]; }
     }
     float bh[4];
 #pragma unroll
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_fwd_kernel(RnnSt
                 else if constexpr (k == 15) *hp = svp1;
             };
             f32x4 pa[4];
-            FwdProduct<TM_KH>::run(pa, w0, w1, lds_addr(&h_lds[cur][(kh * 4 + (lane & 3)) * TM_HLD + (lane >> 2) * (TM_KH / 16)]), hook);
+            FwdProduct<TM_KH>::run(pa, w0, w1, lds_addr(&h_lds[cur][(kh * 4 + (lane & 3)) * TM_HLD + (lane >> 2) * 8]), hook);
             f32x4 acc0 = pa[0] + pa[2], acc1 = pa[1] + pa[3];   // gate columns 2 hi, 2 hi + 1 of the four sequences, this k half
             // ---- k halves: hand the partner the partial sums of ITS two sequences, add its partials of mine -----------
             const int other = 2 * (kh ^ 1);
@@ -206,6 +208,9 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_fwd_kernel(RnnSt
 // In: dh (from the layer above), the forward's gates / cseq / cprev; out: dgx.
 // ---------------------------------------------------------------------------------------------------
 enum { TB_KH = 256, TB_GLD = TB_KH + 8 };
+// BwdProduct<256> hands MFMA number kk' (abid = kk' & 7 of A register kk' >> 3) the 32 consecutive floats lane 4b'+i read at
+// [i][32 b' ..]: with the image in PLAIN order it contracts kk = 32 (kk' & 7) + (kk' >> 3); the weights are loaded in that order
+__device__ __forceinline__ constexpr int tb_korder(int kk) { return 32 * (kk & 7) + (kk >> 3); }
 
 __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_bwd_kernel(RnnStepArgs p, u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
     constexpr int H = TM_H, GH = 4 * H, KH = TB_KH;
@@ -227,7 +232,10 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_bwd_kernel(RnnSt
     // ---- weights: W_hh[(kk >> 6) H + 64 m + (kk & 63)][u'], kk = 0 .. 255 ---------------------------------------------
     float w[KH];
 #pragma unroll
-    for (int kk = 0; kk < KH; ++kk) w[kk] = p.Whh[(size_t)((kk >> 6) * H + TEAM_US * member + (kk & 63)) * H + up];
+    for (int kk = 0; kk < KH; ++kk) {
+        const int k = tb_korder(kk);                   // own gate column 64 gate + own unit
+        w[kk] = p.Whh[(size_t)((k >> 6) * H + TEAM_US * member + (k & 63)) * H + up];
+    }
 
     // ring of a team: [tag & 3][owner member][source member][sequence slot][64 units] granules
     u64* const ring0 = xbuf + (size_t)team * (TEAM_SLOTS * 4 * 4 * 4 * TEAM_US);
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_bwd_kernel(RnnSt
             const float dgr[4] = {on ? dcv * gg * ig * (1.f - ig) : 0.f, on ? dcv * cv[5] * fg * (1.f - fg) : 0.f,
                                   on ? dcv * ig * (1.f - gg * gg) : 0.f, on ? dh * tc * og * (1.f - og) : 0.f};
 #pragma unroll
-            for (int g = 0; g < 4; ++g) g_lds[cur ^ 1][slot * TB_GLD + BwdProduct<KH>::pos(TEAM_US * g + ul)] = dgr[g];
+            for (int g = 0; g < 4; ++g) g_lds[cur ^ 1][slot * TB_GLD + TEAM_US * g + ul] = dgr[g];
             sv[0] = on ? dgr[0] : sv[0]; sv[1] = on ? dgr[1] : sv[1]; sv[2] = on ? dgr[2] : sv[2]; sv[3] = on ? dgr[3] : sv[3];
             st_g = on ? goff : st_g;
             dc_next = on ? dcv : dc_next;

@@ -5,7 +5,7 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r'dc::(\w+)', name)
+    m = re.search(r'dc::(?:\(anonymous namespace\)::)?(\w+)', name)
     return m.group(1) if m else name.split('(')[0][:50]
 
 
