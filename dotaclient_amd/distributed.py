@@ -21,17 +21,17 @@ def is_distributed():
 
 
 class FlatGradAllReducer:
-    """overlap (default: environment DC_DP_OVERLAP == '1'; off unless asked for - it has only been exercised with two
-    gloo ranks so far, tools/gpu_two_ranks.sh): the bucket is reduced in two collectives.  The gradients of every
-    parameter from affine_pre_rnn on (82 % of the bucket, final once the first half of the backward is enqueued) plus
-    the head flags go first, asynchronously, while the embedding backward runs; the embedding gradients follow.  Same
-    sums, same averaging."""
+    """overlap (default on; DC_DP_OVERLAP=0 or overlap=False for the single collective): the bucket is reduced in two
+    collectives.  The gradients of every parameter from affine_pre_rnn on (82 % of the bucket, final once the first half of the
+    backward is enqueued) plus the head flags go first, asynchronously, while the embedding backward runs; the embedding
+    gradients follow.  Same sums, same averaging: both forms are checked against the reference wrapper's two-rank fixture
+    with real engines (tests/test_gpu_dp.py)."""
 
     def __init__(self, engine, group=None, overlap=None):
         import os
         self.engine = engine
         self.group = group
-        self.overlap = (os.environ.get('DC_DP_OVERLAP') == '1') if overlap is None else bool(overlap)
+        self.overlap = (os.environ.get('DC_DP_OVERLAP', '1') != '0') if overlap is None else bool(overlap)
         self._work = None
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         dev = engine.device
