@@ -81,9 +81,12 @@ __device__ __forceinline__ const float* ef_record(const float* __restrict__ obs,
 //   * the epilogue transposes the accumulators through the other (free) stage buffer and writes emb
 //     with 16-byte stores, 256 contiguous bytes per 16 lanes.
 // ---------------------------------------------------------------------------------------------------
-template <bool TIMING>   // TIMING (DC_EF_TIMING=1): s_memtime phase sums of wave 0 of every workgroup -> dbg[wg][4]
+// BPL: W2 arrives as pre-split bf16 planes W2p [3][6 x 128][128] (split_weight_planes, once per pass) and goes to LDS as such:
+// its fragments need no split in the K loop (half of the loop's VALU work)
+template <bool TIMING, bool BPL>   // TIMING (DC_DEV_TIMING build): s_memtime phase sums of wave 0 of every workgroup -> dbg[wg][4]
 __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __restrict__ obs, const float* __restrict__ W1,
                                                                  const float* __restrict__ b1, const float* __restrict__ W2,
+                                                                 const uint16_t* __restrict__ W2p,
                                                                  const float* __restrict__ b2, float* __restrict__ emb,
                                                                  float* __restrict__ xcat, uint8_t* __restrict__ amax,
                                                                  EmbTypes ty, int n_tiles, long long* __restrict__ dbg) {
@@ -91,8 +94,9 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
     if constexpr (TIMING) tm_start = __builtin_amdgcn_s_memtime();
     using LT = FastTile<128, false>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* stage = smem;               // 2 x (A [128][32] | B [128][32])
-    constexpr int STAGE_FL = 2 * 4096;
+    using PT = PlaneTile<128>;
+    float* stage = smem;               // 2 x (A [128][32] f32 | B [128][32] f32, or three bf16 planes of it)
+    constexpr int STAGE_FL = 4096 + (BPL ? PT::LDS_FLOATS : 4096);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,6 +125,12 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
     }
     size_t offb[LT::NI];
     LT::src_offsets<false>(offb, EF_EMB, 0, 128, wave, lane);
+    size_t offp[PT::NI];
+    PT::src_offsets(offp, EF_EMB, (long long)6 * EF_EMB * EF_EMB, 0, wave, lane);
+    auto issue_b = [&](int t, int kt, float* dst) {      // W2_t, k in [32 kt, 32 kt + 32) -> the B half of a stage
+        if constexpr (BPL) PT::issue(W2p + (size_t)t * EF_EMB * EF_EMB + kt * GEMM_BK, offp, dst, wave);
+        else LT::issue(W2 + (size_t)t * EF_EMB * EF_EMB + kt * GEMM_BK, offb, dst, wave);
+    };
 
     auto load_x = [&](int tile, float (&x)[6]) {
         const int tl = min(tile, n_tiles - 1);                      // past the end: a valid tile, never used
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
     load_x(tile, xa);
     {   // step-0 operands of the first tile
         const int t0 = ef_type_of_tile(ty, tile);
-        LT::issue(W2 + (size_t)t0 * EF_EMB * EF_EMB, offb, stage + 4096, wave);
+        issue_b(t0, 0, stage + 4096);
         gen_a(std::integral_constant<int, 0>{}, xa, stage);
     }
     __syncthreads();
@@ -154,7 +164,6 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
     for (; tile < n_tiles; tile += gridDim.x) {
         const int t = ef_type_of_tile(ty, tile);
         const long long row0 = (long long)tile * EF_TILE;
-        const float* gb = W2 + (size_t)t * EF_EMB * EF_EMB;
         const int ntile = tile + gridDim.x;
         const bool more = ntile < n_tiles;
         load_x(ntile, xn);              // lands behind the K loop
@@ -175,16 +184,17 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
             float* cur = stage + (kt & 1) * STAGE_FL;
             float* nxt = stage + ((kt + 1) & 1) * STAGE_FL;
             if (kt < 3) {
-                LT::issue(gb + (kt + 1) * GEMM_BK, offb, nxt + 4096, wave);
+                issue_b(t, kt + 1, nxt + 4096);
                 if (kt == 0) gen_a(std::integral_constant<int, 1>{}, xa, nxt);
                 else if (kt == 1) gen_a(std::integral_constant<int, 2>{}, xa, nxt);
                 else gen_a(std::integral_constant<int, 3>{}, xa, nxt);
             } else if (more) {          // the next tile's step 0, into the buffer step 3 does not read
                 const int t1 = ef_type_of_tile(ty, ntile);
-                LT::issue(W2 + (size_t)t1 * EF_EMB * EF_EMB, offb, nxt + 4096, wave);
+                issue_b(t1, 0, nxt + 4096);
                 gen_a(std::integral_constant<int, 0>{}, xn, nxt);
             }
-            mma_kstep<LT, LT, 2, 2>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc);
+            if constexpr (BPL) mma_kstep_bplanes<LT, 128, 2, 2>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc);
+            else mma_kstep<LT, LT, 2, 2>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc);
             __syncthreads();
         }
 
@@ -535,23 +545,26 @@ static int set_lds(K kernel, size_t bytes, bool* done) {
     return 0;
 }
 
-int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const float* W2, const float* b2, float* emb,
+int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const float* W2, const uint16_t* W2p, const float* b2, float* emb,
                     float* xcat, uint8_t* amax, long long nr, hipStream_t s) {
     int nwg;
     const EmbTypes ty = make_types(nr, &nwg);
-    const size_t lds = (size_t)(4 * 4096) * sizeof(float);
-    static bool attr = false;
-    if (int e = set_lds(embed_fwd_fused_kernel<false>, lds, &attr)) return e;
+    const bool bpl = W2p != nullptr;
+    const size_t lds = (size_t)(2 * (4096 + (bpl ? PlaneTile<128>::LDS_FLOATS : 4096))) * sizeof(float);
+    static bool attr = false, attr_p = false;
+    if (bpl) { if (int e = set_lds(embed_fwd_fused_kernel<false, true>, lds, &attr_p)) return e; }
+    else if (int e = set_lds(embed_fwd_fused_kernel<false, false>, lds, &attr)) return e;
     const int tiles = (int)(nr * 40 / EF_TILE);
     const int grid = tiles < 512 ? tiles : 512;      // two resident workgroups per CU
     ProfScope prof("embed_fwd_fused", 2.0 * nr * 40 * 128 * (128 + 12), 4.0 * nr * 40 * (12 + 128), s);
     constexpr bool timing = DC_DEV_TIMING != 0;
     if (timing) {   // debugging aid: mean per-tile phase cycles (wave 0 of each workgroup), printed per launch
         static bool attr2 = false;
-        if (int e = set_lds(embed_fwd_fused_kernel<true>, lds, &attr2)) return e;
+        if (int e = set_lds(embed_fwd_fused_kernel<true, false>, (size_t)(4 * 4096) * sizeof(float), &attr2)) return e;
         static long long* dbg = nullptr;
         if (!dbg) (void)hipMalloc(&dbg, 512 * 4 * sizeof(long long));
-        hipLaunchKernelGGL(embed_fwd_fused_kernel<true>, dim3(grid), dim3(256), lds, s, obs, W1, b1, W2, b2, emb, xcat, amax, ty, tiles, dbg);
+        hipLaunchKernelGGL((embed_fwd_fused_kernel<true, false>), dim3(grid), dim3(256), (size_t)(4 * 4096) * sizeof(float), s, obs, W1, b1, W2,
+                           (const uint16_t*)nullptr, b2, emb, xcat, amax, ty, tiles, dbg);
         long long h[512 * 4];
         (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
         double ph[4] = {0, 0, 0, 0};
@@ -561,8 +574,10 @@ int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const fl
                 grid, ph[0] / tiles, ph[1] / tiles, ph[2] / tiles, ph[3] / grid, tiles / grid);
         return launch_check("embed_fwd_fused");
     }
-    hipLaunchKernelGGL(embed_fwd_fused_kernel<false>, dim3(grid), dim3(256), lds, s, obs, W1, b1, W2, b2, emb, xcat, amax, ty, tiles,
-                       (long long*)nullptr);
+    if (bpl) hipLaunchKernelGGL((embed_fwd_fused_kernel<false, true>), dim3(grid), dim3(256), lds, s, obs, W1, b1, W2, W2p, b2, emb, xcat, amax, ty,
+                                tiles, (long long*)nullptr);
+    else hipLaunchKernelGGL((embed_fwd_fused_kernel<false, false>), dim3(grid), dim3(256), lds, s, obs, W1, b1, W2, W2p, b2, emb, xcat, amax, ty,
+                            tiles, (long long*)nullptr);
     return launch_check("embed_fwd_fused");
 }
 

@@ -151,4 +151,69 @@ __device__ __forceinline__ void mma_kstep(const float* __restrict__ a_s, const f
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// A k-contiguous operand that arrives PRE-SPLIT (the weights: split once per pass by split_weight_planes, gemm_x3.hip):
+// three bf16 planes [plane][rows][ld], moved global -> LDS by DMA like FastTile.  Image of one K step (32 k) per plane:
+// [BR rows][64 bytes], lane-linear (a DMA piece = 16 rows x 64 B), the four 16-byte k chunks of a row XOR-swizzled on the
+// SOURCE side with (row >> 2) & 3: the 16 rows of every ds_read_b128 lane group then hit 16 different 16-byte bank groups.
+// Its fragments need no VALU work at all.
+// ---------------------------------------------------------------------------------------------------
+template <int BR>
+struct PlaneTile {
+    static constexpr int PLANE_FLOATS = BR * 16;            // BR x 32 bf16
+    static constexpr int LDS_FLOATS = 3 * PLANE_FLOATS;
+    static constexpr int NI = 3 * BR / 16 / 4;              // DMA pieces per wave per K step (4 waves): 6 at BR = 128
+    // per-lane source offsets (bf16 elements, relative to plane 0 at k = k_base) of this wave's pieces
+    static __device__ __forceinline__ void src_offsets(size_t (&off)[NI], int ld, long long plane_elems, int r_base, int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int n = wave * NI + i;                   // piece index over the three planes
+            const int pl = n / (BR / 16), pr = n % (BR / 16);
+            const int row = pr * 16 + (lane >> 2), slot = lane & 3;
+            off[i] = (size_t)pl * plane_elems + (size_t)(r_base + row) * ld + 8 * (slot ^ ((row >> 2) & 3));
+        }
+    }
+    static __device__ __forceinline__ void issue(const uint16_t* __restrict__ origin, const size_t (&off)[NI], float* __restrict__ S, int wave) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(origin + off[i]), (lptr_t)(S + (wave * NI + i) * 256), 16, 0, 0);
+    }
+    // k = 16 s + 8 g .. + 7 of row r, plane p
+    static __device__ __forceinline__ bf16x8 frag(const float* __restrict__ S, int r, int s, int g, int p) {
+        const int chunk = (2 * s + g) ^ ((r >> 2) & 3);
+        return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(S + p * PLANE_FLOATS) + r * 64 + chunk * 16);
+    }
+};
+
+// K step with an f32 A image (FastTile: split after the fragment reads) and a pre-split B image (PlaneTile).  A's k
+// permutation inside a K = 16 sub-step (lane group q contracts k = 16s + 4q + e and 16s + 8 + 4q + e) differs from the
+// natural order of the planes (group g: k = 16s + 8g + e'), so A fragments are read in the planes' order instead: group q
+// takes the two float4 at k chunks 4s + 2q and 4s + 2q + 1 (k = 16s + 8q .. + 7).
+template <class LA, int BRB, int TM, int TN>
+__device__ __forceinline__ void mma_kstep_bplanes(const float* __restrict__ a_s, const float* __restrict__ b_s, int a_row0, int b_row0,
+                                                  int fr, int fq, f32x16 (&acc)[TM][TN]) {
+    using LB = PlaneTile<BRB>;
+#pragma unroll
+    for (int s = 0; s < GEMM_BK / 16; ++s) {
+        Split3 a[TM];
+        bf16x8 bh[TN], bm[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            a[i] = split3(LA::frag(a_s, a_row0 + i * 32 + fr, 2 * s + fq, 0), LA::frag(a_s, a_row0 + i * 32 + fr, 2 * s + fq, 1));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bh[j] = LB::frag(b_s, b_row0 + j * 32 + fr, s, fq, 0);
+            bm[j] = LB::frag(b_s, b_row0 + j * 32 + fr, s, fq, 1);
+            bl[j] = LB::frag(b_s, b_row0 + j * 32 + fr, s, fq, 2);
+        }
+#define DC_MMA_Q(X, Y)                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                          \
+            _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                                   \
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].X, Y[jn], acc[i][jn], 0, 0, 0);
+        DC_MMA_Q(l, bh) DC_MMA_Q(h, bl) DC_MMA_Q(m, bm) DC_MMA_Q(m, bh) DC_MMA_Q(h, bm) DC_MMA_Q(h, bh)
+#undef DC_MMA_Q
+    }
+}
+
 }  // namespace dc

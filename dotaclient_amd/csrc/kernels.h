@@ -99,7 +99,8 @@ int unit_basic_reduce(const float* partials, int nblk, float* dW1, float* db1, h
 bool embed_fused_supported(long long nr);
 // xcat/amax != nullptr: the max-pools of the one-unit and 16-unit types are produced by the epilogue (then call
 // pool_env_fwd with residual = 1 for the env embedding and the 5-unit type only)
-int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const float* W2, const float* b2, float* emb,
+// W2p != nullptr: W2 also as pre-split bf16 planes [3][6 x 128][128] (split_weight_planes): no fragment split for that operand
+int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const float* W2, const uint16_t* W2p, const float* b2, float* emb,
                     float* xcat, uint8_t* amax, long long nr, hipStream_t s);
 // inputs of the sparse max-pool backward of the two 16-unit types (embed_sparse.hip); db2 [6][128] is accumulated into
 // (prep: 2 * nr * 320 floats of scratch - the d(emb) rows of the two types, which the sparse path never writes)

@@ -34,13 +34,13 @@ static inline int64_t align_up(int64_t x) { return (x + 255) / 256 * 256; }
 // the recurrent input projections [G*H][in_l], the head block zero-padded to [160][H].  Elements of one orientation.
 static inline int64_t wplane_elems(const dc_dims* d) {
     const int64_t H = d->hidden, G = d->cell == 0 ? 3 : 4;
-    int64_t e = (int64_t)PREW * XCATW + (int64_t)HO_LD * H;
+    int64_t e = (int64_t)PREW * XCATW + (int64_t)HO_LD * H + (int64_t)6 * EMBW * EMBW;   // + the six unit-type matrices
     for (int l = 0; l < d->layers; ++l) e += G * H * (l == 0 ? PREW : H);
     return e;
 }
 struct WPlanes {              // where each matrix's planes start inside DC_WS_WPLANES (element offsets per plane set)
     uint16_t* base;           // forward orientation at base, transposed orientation at base + 3 * total
-    int64_t total, pre, heads, ih[DC_MAX_LAYERS];
+    int64_t total, pre, heads, unit, ih[DC_MAX_LAYERS];
     uint16_t* fwd(int64_t off) const { return base + 3 * off; }                  // planes of one matrix are contiguous: [3][rows][cols]
     uint16_t* bwd(int64_t off) const { return base + 3 * total + 3 * off; }
 };
@@ -52,6 +52,7 @@ static WPlanes wplanes_of(const dc_dims* d, char* ws_base, const int64_t* off) {
     int64_t o = 0;
     w.pre = o; o += (int64_t)PREW * XCATW;
     w.heads = o; o += (int64_t)HO_LD * H;
+    w.unit = o; o += (int64_t)6 * EMBW * EMBW;
     for (int l = 0; l < d->layers; ++l) { w.ih[l] = o; o += G * H * (l == 0 ? PREW : H); }
     return w;
 }
@@ -134,8 +135,15 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
     uint8_t* amax = reinterpret_cast<uint8_t*>(w.base + w.off[DC_WS_AMAX]);
     const bool fused = embed_fused_supported(NR);
     if (fused) {
-        DC_TRY(embed_fwd_fused(obs, P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), P.p(DC_P_UNIT_W), P.p(DC_P_UNIT_B), w.f(DC_WS_EMB),
-                               w.f(DC_WS_XCAT), amax, NR, s));
+        // W2 of the six unit types as bf16 planes (one tiny pre-pass): the fused kernel's weight operand then needs no split
+        const WPlanes wpe = wplanes_of(d, w.base, w.off);
+        const bool bpl = !(d->flags & DC_DIMS_GEMM_FASTTILE);
+        if (bpl) {
+            X3SplitJob job{P.p(DC_P_UNIT_W), wpe.fwd(wpe.unit), 6 * EMBW, EMBW, EMBW, 0, 6 * EMBW};
+            DC_TRY(split_weight_planes(&job, 1, 6, s));
+        }
+        DC_TRY(embed_fwd_fused(obs, P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), P.p(DC_P_UNIT_W), bpl ? wpe.fwd(wpe.unit) : nullptr, P.p(DC_P_UNIT_B),
+                               w.f(DC_WS_EMB), w.f(DC_WS_XCAT), amax, NR, s));
     } else {
         DC_TRY(unit_basic_fwd(obs, P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), w.f(DC_WS_BASIC), NR, s));
         for (int t = 0; t < 6; ++t) {
