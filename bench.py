@@ -246,7 +246,7 @@ MASK_DEPENDENT_BYTES = ('attn_logits', 'attn_bwd_q')   # mask-aware: bytes moved
 
 
 def run_workload(cell, hidden, layers, B, S, E, steps, warmup, dev, rank, world, hook_factory=None, want_parity=False,
-                 want_profile=False):
+                 want_profile=False, lengths=None):
     """Builds an engine + a resident batch, runs warmup + `steps` timed iterations; returns a dict of raw results."""
     lr, ent, vf = 5e-5, 5e-4, 0.5
     eng = Engine(cell, hidden, layers, dev)
@@ -257,7 +257,7 @@ def run_workload(cell, hidden, layers, B, S, E, steps, warmup, dev, rank, world,
     if hook is not None:
         hook.sync_parameters()
     # every rank gets its own shard of trajectories (the reference's ranks pull from a shared queue)
-    rollouts = synth.make_rollouts(1000 + rank, [S] * B)
+    rollouts = synth.make_rollouts(1000 + rank, [S] * B if lengths is None else lengths)
     batch = pack_rollouts(rollouts, S, dev)
     res = {'eng': eng, 'rollouts': rollouts, 'batch': batch, 'hook': hook, 'lr': lr, 'ent': ent, 'vf': vf}
     if want_parity:
@@ -436,6 +436,22 @@ def main():
                               'ms_per_step': round(r['elapsed'] / args.steps * 1e3, 3), 'nan_status': r['status']}
             del r
             torch.cuda.empty_cache()
+        # the reference's production shape (optimizer.py:776-794 defaults: seq_len 16, whole rollouts until >= 1024 chunks, its own
+        # GRU-256): ragged rollouts, a row count that is a multiple of 16 only - the fused embedding kernels run on padded blocks
+        rng = np.random.Generator(np.random.PCG64(99))
+        lens, chunks = [], 0
+        while chunks < 1024:
+            t = int(rng.integers(100, 900))
+            lens.append(t)
+            chunks += (t + 15) // 16
+        r = run_workload('gru', 256, 1, len(lens), 16, E, args.steps, args.warmup, dev, rank, world, lengths=lens)
+        secondary['reference_defaults_gru256_s16_ragged'] = {
+            'workload': "the reference's own defaults: GRU-256, seq_len 16, %d ragged rollouts (100..899 steps) = %d chunks of 16 = %d env-steps "
+                        '(a multiple of 16, not of 128)' % (len(lens), chunks, chunks * 16),
+            'value': round(chunks * 16 * args.steps / r['elapsed'], 1), 'unit': 'env-steps/s',
+            'ms_per_step': round(r['elapsed'] / args.steps * 1e3, 3), 'nan_status': r['status']}
+        del r
+        torch.cuda.empty_cache()
 
     if rank == 0:
         n_steps = world * B * S * args.steps

@@ -23,6 +23,7 @@ int launch_check(const char* what) {
 }
 
 int64_t workspace_layout(const dc_dims* d, int64_t* out);
+long long emb_rows_of(const dc_dims* d);   // rows per unit of the type-major emb blocks (policy.hip)
 int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, const float* obs, const float* h0,
                    const float* c0, const int64_t* seq_off, const int32_t* seq_len, void* ws_base, float* hT, float* cT,
                    hipStream_t s);
@@ -129,7 +130,7 @@ int dc_select_logp(const dc_dims* dims, const void* ws, const uint8_t* act, cons
     if (dims->rows <= 0) return 0;
     if (dims->flags & DC_DIMS_LAZY_TU)
         if (int e = dc::attn_logits_masked(ws_f(dims, ws, DC_WS_HEADOUT), ws_f(dims, ws, DC_WS_EMB), mask, ws_f(dims, ws, DC_WS_TU),
-                                           dims->rows, (hipStream_t)stream))
+                                           dims->rows, dc::emb_rows_of(dims), (hipStream_t)stream))
             return e;
     return dc::select_logp(ws_f(dims, ws, DC_WS_HEADOUT), ws_f(dims, ws, DC_WS_TU), act, mask, logp_sel, values, argmax,
                            dims->rows, (hipStream_t)stream);
@@ -142,7 +143,7 @@ int dc_ppo_loss_fwd_bwd(const dc_dims* dims, void* ws, const uint8_t* act, const
     if (dims->rows <= 0) { dc::set_error("ppo_loss: empty batch", 1030); return 1030; }
     if (dims->flags & DC_DIMS_LAZY_TU)
         if (int e = dc::attn_logits_masked(ws_f(dims, ws, DC_WS_HEADOUT), ws_f(dims, ws, DC_WS_EMB), mask, ws_f(dims, ws, DC_WS_TU),
-                                           dims->rows, (hipStream_t)stream))
+                                           dims->rows, dc::emb_rows_of(dims), (hipStream_t)stream))
             return e;
     return dc::ppo_loss_fwd_bwd(ws_f(dims, ws, DC_WS_HEADOUT), ws_f(dims, ws, DC_WS_TU), act, mask, old_logp, adv, ret,
                                 reinterpret_cast<double*>(ws_f(dims, ws, DC_WS_STATS)), ws_f(dims, ws, DC_WS_DHEADOUT),

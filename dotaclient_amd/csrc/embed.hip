@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void unit_basic_fwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void pool_env_fwd_kernel(const float* __restrict__ obs, const float* __restrict__ emb,
                                                            const float* __restrict__ Wenv, const float* __restrict__ benv,
                                                            float* __restrict__ xcat, uint8_t* __restrict__ amax,
-                                                           long long nr, int residual) {
+                                                           long long nr, long long nrp, int residual) {
+    // nrp: rows per unit of the type-major emb blocks (nr padded to a multiple of 128 on the fused path)
     // residual != 0: embed_fwd_fused's epilogue already pooled every type except eh (t = 1)
     const int c = threadIdx.x & 127;
     const int sub = threadIdx.x >> 7;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void pool_env_fwd_kernel(const float* __restri
         float* xo = xcat + n * XCAT;
         xo[c] = fmaxf(fmaf(e[2], w2, fmaf(e[1], w1, fmaf(e[0], w0, be))), 0.f);  // policy.py:97
         if (residual) {
-            const float* p = emb + (nr * c_type_cum[1] + n * 5) * EMB + c;
+            const float* p = emb + (nrp * c_type_cum[1] + n * 5) * EMB + c;
             float m = p[0];
             int am = 0;
 #pragma unroll
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void pool_env_fwd_kernel(const float* __restri
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
             const int U = c_type_units[t];
-            const float* p = emb + (nr * c_type_cum[t] + n * U) * EMB + c;
+            const float* p = emb + (nrp * c_type_cum[t] + n * U) * EMB + c;
             float m = p[0];
             int am = 0;
             for (int u = 1; u < U; ++u) {
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void pool_env_fwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(
     const float* __restrict__ obs, const float* __restrict__ xcat, const float* __restrict__ dxcat,
     const float* __restrict__ dtu, const float* __restrict__ q, int ldq, const uint8_t* __restrict__ amax,
-    float* __restrict__ demb, float* __restrict__ partials, long long nr, int steps_per_block, int skip16) {
+    float* __restrict__ demb, float* __restrict__ partials, long long nr, long long nrp, int steps_per_block, int skip16) {
     constexpr int kU[6] = {1, 5, 16, 16, 1, 1};
     constexpr int kCum[7] = {0, 1, 6, 22, 38, 39, 40};
     const int c = threadIdx.x & 127;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
             if (skip16 && (t == 2 || t == 3)) continue;     // handled by embed_bwd_pool16 without materialising d(emb)
-            float* p = demb + (nr * kCum[t] + n * kU[t]) * EMB + c;
+            float* p = demb + (nrp * kCum[t] + n * kU[t]) * EMB + c;
             float sum_dt = 0.f;
 #pragma unroll
             for (int u = 0; u < kU[t]; ++u) {
@@ -310,16 +311,16 @@ int unit_basic_fwd(const float* obs, const float* W1, const float* b1, float* ba
 }
 
 int pool_env_fwd(const float* obs, const float* emb, const float* Wenv, const float* benv, float* xcat, uint8_t* amax,
-                 long long nr, int residual, hipStream_t s) {
+                 long long nr, long long nrp, int residual, hipStream_t s) {
     ProfScope prof("pool_env_fwd", 0.0, 4.0 * nr * ((residual ? 5 : 40) * 128 + 896), s);
     hipLaunchKernelGGL(pool_env_fwd_kernel, dim3(grid_for(nr, 2, 256 * 16)), dim3(256), 0, s, obs, emb, Wenv, benv, xcat,
-                       amax, nr, residual);
+                       amax, nr, nrp, residual);
     return launch_check("pool_env_fwd");
 }
 
 int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, const float* dtu, const float* q, int ldq,
                       const uint8_t* amax, float* demb, float* dWenv, float* dbenv, float* db2, float* scratch,
-                      long long nr, int skip16, hipStream_t s) {
+                      long long nr, long long nrp, int skip16, hipStream_t s) {
     int spb = (int)((nr + 2047) / 2048);
     if (spb < 4) spb = 4;
     const int nblk = (int)((nr + spb - 1) / spb);        // <= 2048 -> <= 10.5 MB of scratch
@@ -328,7 +329,7 @@ int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, c
     const double units = skip16 ? 8.0 : 40.0;
     ProfScope prof("embed_scatter_bwd(+reduce)", 2.0 * nr * units * 128, 4.0 * nr * (units * 128 + 896 * 2 + 128 + 40), s);
     hipLaunchKernelGGL(embed_scatter_bwd_kernel, dim3(nblk), dim3(256), 0, s, obs, xcat, dxcat, dtu, q, ldq, amax, demb,
-                       scratch, nr, spb, skip16);
+                       scratch, nr, nrp, spb, skip16);
     hipLaunchKernelGGL(embed_scatter_reduce_kernel, dim3(5, 32), dim3(256), 0, s, scratch, nblk, dWenv, dbenv, db2);
     return launch_check("embed_scatter_bwd");
 }

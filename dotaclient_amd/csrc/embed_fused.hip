@@ -36,6 +36,8 @@ struct EmbTypes {
     int tile_begin[7];        // row_begin / 128
     int wg_begin[7];          // embed_bwd_dw2: first workgroup of type t
     int steps_per_wg;         // embed_bwd_dw2: K steps (32 rows) per workgroup
+    long long nr_valid;       // env-steps that exist; steps in [nr_valid, nr) are padding up to a multiple of 128: their records re-read
+                              // the last valid step (forward results land in pad rows nobody reads, backward sees zero gradients)
     int sparse16;             // backward: the two 16-unit types are handled by embed_bwd_pool16 (embed_sparse.hip);
                               // their dW2 slab ranges [wg_begin[2], wg_begin[4]) are written by that kernel
 };
@@ -52,12 +54,13 @@ __device__ __forceinline__ int ef_cum(int t) { return t == 0 ? 0 : (t == 1 ? 1 :
 
 // 12-feature record of type-major row `local` (relative to its type block; < 2^31: policy.hip check_dims).
 // The unit counts are 1, 5 and 16: shift / multiply-high instead of a 64-bit division per record.
-__device__ __forceinline__ const float* ef_record(const float* __restrict__ obs, int t, long long local_) {
+__device__ __forceinline__ const float* ef_record(const float* __restrict__ obs, int t, long long local_, long long nr_valid) {
     const unsigned local = (unsigned)local_;
     unsigned n, u;
     if (t == 2 || t == 3) { n = local >> 4; u = local & 15u; }
     else if (t == 1) { n = __umulhi(local, 0xCCCCCCCDu) >> 2; u = local - 5u * n; }
     else { n = local; u = 0u; }
+    n = min(n, (unsigned)(nr_valid - 1));        // padding steps
     return obs + (size_t)n * EF_OBS + 3 + (ef_cum(t) + (int)u) * 12;
 }
 
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
     auto load_x = [&](int tile, float (&x)[6]) {
         const int tl = min(tile, n_tiles - 1);                      // past the end: a valid tile, never used
         const int tt = ef_type_of_tile(ty, tl);
-        const float* xp = ef_record(obs, tt, (long long)tl * EF_TILE + 32 * wave + fr - ty.row_begin[tt]) + fq;
+        const float* xp = ef_record(obs, tt, (long long)tl * EF_TILE + 32 * wave + fr - ty.row_begin[tt], ty.nr_valid) + fq;
 #pragma unroll
         for (int kk = 0; kk < 6; ++kk) x[kk] = xp[2 * kk];
     };
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restr
     const float* ga = demb + (size_t)(ty.row_begin[t] + s0 * GEMM_BK) * EF_EMB;
 
     auto load_x = [&](int s, float (&x)[6]) {
-        const float* xp = ef_record(obs, t, (s0 + min(s, ns - 1)) * GEMM_BK + fr) + fq;   // clamped: always a valid step
+        const float* xp = ef_record(obs, t, (s0 + min(s, ns - 1)) * GEMM_BK + fr, ty.nr_valid) + fq;   // clamped: always a valid step
 #pragma unroll
         for (int kk = 0; kk < 6; ++kk) x[kk] = xp[2 * kk];
     };
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void embed_bwd_dw1_kernel(const float* __re
         __syncthreads();   // previous tile's epilogue is done with xs / the stage buffers
         for (int e = tid; e < 1536; e += 256) {
             const int r = e / 12, f = e - r * 12;
-            xs[e] = ef_record(obs, t, row0 + r - ty.row_begin[t])[f];
+            xs[e] = ef_record(obs, t, row0 + r - ty.row_begin[t], ty.nr_valid)[f];
         }
         LA::issue(ga, offa, stage, wave);
         LB::issue(gb, offb, stage + 4096, wave);
@@ -508,13 +511,14 @@ __global__ __launch_bounds__(256, 2) void embed_bwd_dw1_kernel(const float* __re
 static const int H_UNITS[6] = {1, 5, 16, 16, 1, 1};
 static const int H_CUM[7] = {0, 1, 6, 22, 38, 39, 40};
 
-bool embed_fused_supported(long long nr) { return nr > 0 && nr % 128 == 0; }
+bool embed_fused_supported(long long nr) { return nr > 0 && nr % 128 == 0; }   // nr: the PADDED step count
 
 enum { SPARSE_WG_PER_TYPE = 128 };   // embed_bwd_pool16: one workgroup per CU over the two 16-unit types
 
-static EmbTypes make_types(long long nr, int* total_wg, bool sparse16 = false) {
+static EmbTypes make_types(long long nr, long long nr_valid, int* total_wg, bool sparse16 = false) {
     EmbTypes ty;
     ty.sparse16 = sparse16 ? 1 : 0;
+    ty.nr_valid = nr_valid;
     for (int t = 0; t <= 6; ++t) {
         ty.row_begin[t] = nr * H_CUM[t];
         ty.tile_begin[t] = (int)(ty.row_begin[t] / EF_TILE);
@@ -546,9 +550,9 @@ static int set_lds(K kernel, size_t bytes, bool* done) {
 }
 
 int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const float* W2, const uint16_t* W2p, const float* b2, float* emb,
-                    float* xcat, uint8_t* amax, long long nr, hipStream_t s) {
+                    float* xcat, uint8_t* amax, long long nr_valid, long long nr, hipStream_t s) {
     int nwg;
-    const EmbTypes ty = make_types(nr, &nwg);
+    const EmbTypes ty = make_types(nr, nr_valid, &nwg);
     const bool bpl = W2p != nullptr;
     const size_t lds = (size_t)(2 * (4096 + (bpl ? PlaneTile<128>::LDS_FLOATS : 4096))) * sizeof(float);
     static bool attr = false, attr_p = false;
@@ -588,11 +592,11 @@ int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const fl
 // their second-layer bias gradients are ACCUMULATED into sp->db2 [6][128]); the four small types stay dense.
 // scratch: >= (dense + sparse workgroups) * 16384 + sparse partials floats
 int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const float* b1, const float* W2, float* dW2,
-                    float* dW1, float* db1, float* scratch, long long scratch_floats, long long nr, const EmbSparseIn* sp,
-                    hipStream_t s) {
+                    float* dW1, float* db1, float* scratch, long long scratch_floats, long long nr_valid, long long nr,
+                    const EmbSparseIn* sp, hipStream_t s) {
     int nwg;
     const bool sparse16 = sp != nullptr;
-    const EmbTypes ty = make_types(nr, &nwg, sparse16);
+    const EmbTypes ty = make_types(nr, nr_valid, &nwg, sparse16);
     const long long sp_floats = sparse16 ? 2LL * SPARSE_WG_PER_TYPE * (1664 + 128) : 0;
     if ((long long)nwg * EF_EMB * EF_EMB + sp_floats > scratch_floats || 512LL * 1664 + sp_floats > scratch_floats) {
         set_error("embed_bwd_fused: scratch too small", 1040);
@@ -602,7 +606,7 @@ int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const 
     float* part2 = part1 + 2LL * SPARSE_WG_PER_TYPE * 1664;
     if (sparse16) {
         if (int e = embed_bwd_pool16(obs, sp->dxcat, sp->amax, sp->dtu, sp->q, sp->ldq, W1, b1, W2,
-                                     scratch + (size_t)ty.wg_begin[2] * EF_EMB * EF_EMB, part1, part2, sp->prep, nr, SPARSE_WG_PER_TYPE, s))
+                                     scratch + (size_t)ty.wg_begin[2] * EF_EMB * EF_EMB, part1, part2, sp->prep, nr_valid, SPARSE_WG_PER_TYPE, s))
             return e;
     }
     {

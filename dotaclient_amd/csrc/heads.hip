@@ -25,7 +25,7 @@ enum { ST_ADV_SUM = 0, ST_ADV_SQ = 1, ST_NSEL = 2 /*5*/, ST_POL = 7 /*5*/, ST_EN
 // target-unit logits: tu[n][u] = sum_c q[n][c] * emb[n][u][c];  16 lanes per unit, 4 units per wave pass
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restrict__ headout, const float* __restrict__ emb,
-                                                          float* __restrict__ tu, long long nr) {
+                                                          float* __restrict__ tu, long long nr, long long nrp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane >> 4, l16 = lane & 15;
     for (long long n = (long long)blockIdx.x * 4 + wave; n < nr; n += (long long)gridDim.x * 4) {
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restric
 #pragma unroll
             for (int i = 1; i < 6; ++i) if (u >= c_t_cum[i]) t = i;
             const float4* ep = reinterpret_cast<const float4*>(
-                emb + (nr * c_t_cum[t] + n * c_t_units[t] + (u - c_t_cum[t])) * EMBW);
+                emb + (nrp * c_t_cum[t] + n * c_t_units[t] + (u - c_t_cum[t])) * EMBW);
             const float4 e0 = ep[l16], e1 = ep[16 + l16];
             float s = q0.x * e0.x + q0.y * e0.y + q0.z * e0.z + q0.w * e0.w + q1.x * e1.x + q1.y * e1.y + q1.z * e1.z +
                       q1.w * e1.w;
@@ -62,7 +62,7 @@ __device__ __forceinline__ long long unit_row(long long nr, long long n, int u) 
 // wave takes every fourth set bit.
 __global__ __launch_bounds__(256) void attn_logits_masked_kernel(const float* __restrict__ headout, const float* __restrict__ emb,
                                                                  const uint8_t* __restrict__ mask, float* __restrict__ tu,
-                                                                 long long nr) {
+                                                                 long long nr, long long nrp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane >> 4, l16 = lane & 15;
     for (long long n = (long long)blockIdx.x * 4 + wave; n < nr; n += (long long)gridDim.x * 4) {
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void attn_logits_masked_kernel(const float* __
             const bool have = b != 0ull;
             const int u = have ? __builtin_ctzll(b) : 0;
             if (have) {
-                const float4* ep = reinterpret_cast<const float4*>(emb + unit_row(nr, n, u) * EMBW);
+                const float4* ep = reinterpret_cast<const float4*>(emb + unit_row(nrp, n, u) * EMBW);
                 const float4 e0 = ep[l16], e1 = ep[16 + l16];
                 float s = q0.x * e0.x + q0.y * e0.y + q0.z * e0.z + q0.w * e0.w + q1.x * e1.x + q1.y * e1.y + q1.z * e1.z +
                           q1.w * e1.w;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void attn_logits_masked_kernel(const float* __
 // Only units with a non-zero gradient are read: dtu is zero outside the masked-in units of the steps whose
 // target_unit head is live (most steps have none and cost 160 bytes instead of 20 KB).
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ dtu, const float* __restrict__ emb,
-                                                         float* __restrict__ dheadout, long long nr) {
+                                                         float* __restrict__ dheadout, long long nr, long long nrp) {
     const int c = threadIdx.x & 127, sub = threadIdx.x >> 7, lane = threadIdx.x & 63;
     for (long long n = (long long)blockIdx.x * 2 + sub; n < nr; n += (long long)gridDim.x * 2) {
         const float* dt = dtu + n * NUNITS;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
         while (bits) {
             const int u = __builtin_ctzll(bits);
             bits &= bits - 1;
-            acc = fmaf(dt[u], emb[unit_row(nr, n, u) * EMBW + c], acc);
+            acc = fmaf(dt[u], emb[unit_row(nrp, n, u) * EMBW + c], acc);
         }
         dheadout[n * HO_LD + c] = acc;
     }
@@ -422,21 +422,21 @@ static inline int grid1d(long long items, int per_block, int cap) {
     return (int)g;
 }
 
-int attn_logits(const float* headout, const float* emb, float* tu, long long nr, hipStream_t s) {
+int attn_logits(const float* headout, const float* emb, float* tu, long long nr, long long nrp, hipStream_t s) {
     ProfScope prof("attn_logits", 2.0 * nr * 40 * 128, 4.0 * nr * (40 * 128 + 128 + 40), s);
-    hipLaunchKernelGGL(attn_logits_kernel, dim3(grid1d(nr, 4, 256 * 16)), dim3(256), 0, s, headout, emb, tu, nr);
+    hipLaunchKernelGGL(attn_logits_kernel, dim3(grid1d(nr, 4, 256 * 16)), dim3(256), 0, s, headout, emb, tu, nr, nrp);
     return launch_check("attn_logits");
 }
 
-int attn_logits_masked(const float* headout, const float* emb, const uint8_t* mask, float* tu, long long nr, hipStream_t s) {
+int attn_logits_masked(const float* headout, const float* emb, const uint8_t* mask, float* tu, long long nr, long long nrp, hipStream_t s) {
     ProfScope prof("attn_logits", 2.0 * nr * 40 * 128, 4.0 * nr * (40 * 128 + 128 + 40), s);
-    hipLaunchKernelGGL(attn_logits_masked_kernel, dim3(grid1d(nr, 4, 256 * 16)), dim3(256), 0, s, headout, emb, mask, tu, nr);
+    hipLaunchKernelGGL(attn_logits_masked_kernel, dim3(grid1d(nr, 4, 256 * 16)), dim3(256), 0, s, headout, emb, mask, tu, nr, nrp);
     return launch_check("attn_logits_masked");
 }
 
-int attn_bwd_q(const float* dtu, const float* emb, float* dheadout, long long nr, hipStream_t s) {
+int attn_bwd_q(const float* dtu, const float* emb, float* dheadout, long long nr, long long nrp, hipStream_t s) {
     ProfScope prof("attn_bwd_q", 2.0 * nr * 40 * 128, 4.0 * nr * (40 * 128 + 128 + 40), s);
-    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(grid1d(nr, 2, 256 * 16)), dim3(256), 0, s, dtu, emb, dheadout, nr);
+    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(grid1d(nr, 2, 256 * 16)), dim3(256), 0, s, dtu, emb, dheadout, nr, nrp);
     return launch_check("attn_bwd_q");
 }
 

@@ -83,12 +83,13 @@ int split_weight_planes(const X3SplitJob* jobs, int n, int prec, hipStream_t s);
 int splitk_reduce_grouped(const float* slab, float* C, int M, int N, int n_groups, const int* begin, hipStream_t s);
 // embed.hip
 int unit_basic_fwd(const float* obs, const float* W1, const float* b1, float* basic, long long nr, hipStream_t s);
+// nrp (here and below): env-steps per unit of the type-major emb / d(emb) blocks = nr padded to a multiple of 128 on the fused path
 int pool_env_fwd(const float* obs, const float* emb, const float* Wenv, const float* benv, float* xcat, uint8_t* amax,
-                 long long nr, int residual, hipStream_t s);
+                 long long nr, long long nrp, int residual, hipStream_t s);
 // skip16: the two 16-unit types are left out (no d(emb) rows written, no db2 contribution): embed_bwd_pool16 has them
 int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, const float* dtu, const float* q, int ldq,
                       const uint8_t* amax, float* demb, float* dWenv, float* dbenv, float* db2, float* scratch,
-                      long long nr, int skip16, hipStream_t s);
+                      long long nr, long long nrp, int skip16, hipStream_t s);
 int unit_basic_bwd(const float* obs, const float* dbasic, float* dW1, float* db1, float* scratch, long long nr,
                    hipStream_t s);
 int embed_tail_reduce(const float* pa, int na, const float* pb, int nb, float* dW1, float* db1, const float* p2, int n2,
@@ -96,27 +97,27 @@ int embed_tail_reduce(const float* pa, int na, const float* pb, int nb, float* d
 int colsum(const float* X, int ld, long long rows, int cols, float* out, hipStream_t s);
 int unit_basic_reduce(const float* partials, int nblk, float* dW1, float* db1, hipStream_t s);   // partials [nblk][13][128]
 // embed_fused.hip (rows % 128 == 0: first embedding layer recomputed on chip, `basic` never stored)
-bool embed_fused_supported(long long nr);
+bool embed_fused_supported(long long nr_padded);
 // xcat/amax != nullptr: the max-pools of the one-unit and 16-unit types are produced by the epilogue (then call
 // pool_env_fwd with residual = 1 for the env embedding and the 5-unit type only)
 // W2p != nullptr: W2 also as pre-split bf16 planes [3][6 x 128][128] (split_weight_planes): no fragment split for that operand
 int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const float* W2, const uint16_t* W2p, const float* b2, float* emb,
-                    float* xcat, uint8_t* amax, long long nr, hipStream_t s);
+                    float* xcat, uint8_t* amax, long long nr_valid, long long nr_padded, hipStream_t s);
 // inputs of the sparse max-pool backward of the two 16-unit types (embed_sparse.hip); db2 [6][128] is accumulated into
 // (prep: 2 * nr * 320 floats of scratch - the d(emb) rows of the two types, which the sparse path never writes)
 struct EmbSparseIn { const float* dxcat; const uint8_t* amax; const float* dtu; const float* q; int ldq; float* db2; float* prep; };
 int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const float* b1, const float* W2, float* dW2,
-                    float* dW1, float* db1, float* scratch, long long scratch_floats, long long nr, const EmbSparseIn* sp,
-                    hipStream_t s);
+                    float* dW1, float* db1, float* scratch, long long scratch_floats, long long nr_valid, long long nr_padded,
+                    const EmbSparseIn* sp, hipStream_t s);
 // embed_sparse.hip
 int embed_bwd_pool16(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq,
                      const float* W1, const float* b1, const float* W2, float* slab, float* part1, float* part2, float* prep,
                      long long nr, int wg_per_type, hipStream_t s);
 // heads.hip
-int attn_logits(const float* headout, const float* emb, float* tu, long long nr, hipStream_t s);
+int attn_logits(const float* headout, const float* emb, float* tu, long long nr, long long nrp, hipStream_t s);
 // target-unit logits of the units whose mask byte (mask[n][22 + u]) is set; 0 elsewhere
-int attn_logits_masked(const float* headout, const float* emb, const uint8_t* mask, float* tu, long long nr, hipStream_t s);
-int attn_bwd_q(const float* dtu, const float* emb, float* dheadout, long long nr, hipStream_t s);
+int attn_logits_masked(const float* headout, const float* emb, const uint8_t* mask, float* tu, long long nr, long long nrp, hipStream_t s);
+int attn_bwd_q(const float* dtu, const float* emb, float* dheadout, long long nr, long long nrp, hipStream_t s);
 int select_logp(const float* headout, const float* tu, const uint8_t* act, const uint8_t* mask, float* logp_sel,
                 float* values, int32_t* argmax, long long nr, hipStream_t s);
 int ppo_loss_fwd_bwd(const float* headout, const float* tu, const uint8_t* act, const uint8_t* mask, const float* old_logp,

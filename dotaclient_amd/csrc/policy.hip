@@ -30,6 +30,12 @@ struct Grads {
 
 static inline int64_t align_up(int64_t x) { return (x + 255) / 256 * 256; }
 
+// The fused embedding kernels work on 128-row tiles of the type-major emb / d(emb) blocks: the blocks are laid out for the row
+// count padded to a multiple of 128 (padding steps re-read the last real step; nobody reads their results, their gradients are
+// zero).  DC_DIMS_EMBED_UNFUSED: the layer-by-layer path, exact row count.
+static inline bool embed_fused_on(const dc_dims* d) { return !(d->flags & DC_DIMS_EMBED_UNFUSED) && d->rows > 0; }
+static inline int64_t emb_rows(const dc_dims* d) { return embed_fused_on(d) ? (d->rows + 127) / 128 * 128 : d->rows; }
+
 // Weight matrices the dense products read as pre-split bf16 planes (gemm_x3.hip), in this order: affine_pre_rnn [256][896],
 // the recurrent input projections [G*H][in_l], the head block zero-padded to [160][H].  Elements of one orientation.
 static inline int64_t wplane_elems(const dc_dims* d) {
@@ -60,7 +66,7 @@ static WPlanes wplanes_of(const dc_dims* d, char* ws_base, const int64_t* off) {
 // offsets (bytes) of every workspace buffer; returns total bytes.  out must hold
 // DC_WS_FIXED + DC_WS_PER_LAYER * layers entries.
 int64_t workspace_layout(const dc_dims* d, int64_t* out) {
-    const int64_t NR = d->rows, H = d->hidden, G = d->cell == 0 ? 3 : 4, B = d->n_seq;
+    const int64_t NR = emb_rows(d), H = d->hidden, G = d->cell == 0 ? 3 : 4, B = d->n_seq;   // (every buffer sized for the padded row count)
     (void)B;
     int64_t off = 0;
     auto put = [&](int idx, int64_t bytes) { out[idx] = off; off = align_up(off + bytes); };
@@ -98,6 +104,8 @@ int64_t workspace_layout(const dc_dims* d, int64_t* out) {
     return off;
 }
 
+long long emb_rows_of(const dc_dims* d) { return emb_rows(d); }
+
 struct Ws {
     char* base;
     int64_t off[DC_WS_FIXED + DC_WS_PER_LAYER * DC_MAX_LAYERS];
@@ -133,7 +141,8 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
     // per-unit embedding MLP (policy.py:100-126).  Fused (rows % 128 == 0): layer 1 recomputed on chip inside
     // the layer-2 product; otherwise layer 1 on VALU into `basic`, layer 2 as six dense GEMMs
     uint8_t* amax = reinterpret_cast<uint8_t*>(w.base + w.off[DC_WS_AMAX]);
-    const bool fused = embed_fused_supported(NR);
+    const bool fused = embed_fused_on(d);
+    const long long NRp = emb_rows(d);               // rows per unit of the type-major blocks
     if (fused) {
         // W2 of the six unit types as bf16 planes (one tiny pre-pass): the fused kernel's weight operand then needs no split
         const WPlanes wpe = wplanes_of(d, w.base, w.off);
@@ -143,7 +152,7 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
             DC_TRY(split_weight_planes(&job, 1, 6, s));
         }
         DC_TRY(embed_fwd_fused(obs, P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), P.p(DC_P_UNIT_W), bpl ? wpe.fwd(wpe.unit) : nullptr, P.p(DC_P_UNIT_B),
-                               w.f(DC_WS_EMB), w.f(DC_WS_XCAT), amax, NR, s));
+                               w.f(DC_WS_EMB), w.f(DC_WS_XCAT), amax, NR, NRp, s));
     } else {
         DC_TRY(unit_basic_fwd(obs, P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), w.f(DC_WS_BASIC), NR, s));
         for (int t = 0; t < 6; ++t) {
@@ -155,7 +164,7 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
     }
     // env embedding + max-pools -> xcat (policy.py:97,102-136)
     // (fused: only the env embedding and the 5-unit type are left to do - the GEMM epilogue pooled the rest)
-    DC_TRY(pool_env_fwd(obs, w.f(DC_WS_EMB), P.p(DC_P_ENV_W), P.p(DC_P_ENV_B), w.f(DC_WS_XCAT), amax, NR, fused ? 1 : 0, s));
+    DC_TRY(pool_env_fwd(obs, w.f(DC_WS_EMB), P.p(DC_P_ENV_W), P.p(DC_P_ENV_B), w.f(DC_WS_XCAT), amax, NR, NRp, fused ? 1 : 0, s));
     // the dense products read their weights as bf16 planes (gemm_x3.hip): one pre-pass per forward over the three / four matrices
     // (measured, tools/gemm_bench.py at 256 x 256: x W^T / dy W run at 145-150 TF on either kernel - the round-1 tile kernel with
     // its fragments split after the LDS reads needs no pre-pass and is the default there; the split-on-load kernel is 1.5x
@@ -211,7 +220,7 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
     // (x3: the weight planes are zero-padded to 160 rows, so the pad columns 154..159 of headout are written as zeros)
     DC_TRY(linear(x, H, P.p(DC_P_HEADS_W), wp.fwd(wp.heads), HO_N, HO_LD, P.p(DC_P_HEADS_B), 0, w.f(DC_WS_HEADOUT), HO_LD));
     // (DC_DIMS_LAZY_TU: left to dc_select_logp / dc_ppo_loss_fwd_bwd, which know which units are unmasked)
-    if (!(d->flags & DC_DIMS_LAZY_TU)) DC_TRY(attn_logits(w.f(DC_WS_HEADOUT), w.f(DC_WS_EMB), w.f(DC_WS_TU), NR, s));
+    if (!(d->flags & DC_DIMS_LAZY_TU)) DC_TRY(attn_logits(w.f(DC_WS_HEADOUT), w.f(DC_WS_EMB), w.f(DC_WS_TU), NR, NRp, s));
     return 0;
 }
 
@@ -284,7 +293,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         DC_TRY(split_weight_planes(jobs, nj, prec, s));
     }
     // heads (policy.py:144-155)
-    DC_TRY(attn_bwd_q(w.f(DC_WS_DTU), w.f(DC_WS_EMB), w.f(DC_WS_DHEADOUT), NR, s));
+    DC_TRY(attn_bwd_q(w.f(DC_WS_DTU), w.f(DC_WS_EMB), w.f(DC_WS_DHEADOUT), NR, emb_rows(d), s));
     // dH = dheadout[:, 0:160] * [W_heads; 0]: K padded to 160 (dheadout's pad columns are zeroed by the loss kernel)
     if (!x3) {
         hipLaunchKernelGGL(copy_zero_pad_kernel, dim3((HO_LD * H / 4 + 255) / 256), dim3(256), 0, s, P.p(DC_P_HEADS_W), w.f(DC_WS_HEADW_PAD),
@@ -340,21 +349,31 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     // max-pool routing + attention keys -> per-unit embedding gradients; env embedding weights
     // Fused path: the two 16-unit types (32 of the 40 units) take the sparse max-pool backward (embed_sparse.hip);
     // DC_DIMS_DENSE_POOL_BWD: the dense kernels for all types.
-    const bool fusedb = embed_fused_supported(NR);
+    const bool fusedb = embed_fused_on(d);
+    const long long NRp = emb_rows(d);
     const bool sparse16 = fusedb && embed_sparse_enabled(d);
     const uint8_t* amaxp = reinterpret_cast<const uint8_t*>(w.base + w.off[DC_WS_AMAX]);
     DC_TRY(embed_scatter_bwd(obs, w.f(DC_WS_XCAT), w.f(DC_WS_DXCAT), w.f(DC_WS_DTU), w.f(DC_WS_HEADOUT), HO_LD, amaxp,
                              w.f(DC_WS_DEMB), Gd.p(DC_P_ENV_W), Gd.p(DC_P_ENV_B), Gd.p(DC_P_UNIT_B), w.f(DC_WS_SCRATCH), NR,
-                             sparse16 ? 1 : 0, s));
+                             NRp, sparse16 ? 1 : 0, s));
+    if (fusedb && NRp > NR) {
+        // padding steps of the type-major d(emb) blocks the dense kernels read: zero gradients
+        for (int t = 0; t < 6; ++t) {
+            if (sparse16 && (t == 2 || t == 3)) continue;
+            hipError_t e = hipMemsetAsync(w.f(DC_WS_DEMB) + ((size_t)NRp * T_CUM[t] + (size_t)NR * T_UNITS[t]) * EMBW, 0,
+                                          (size_t)(NRp - NR) * T_UNITS[t] * EMBW * sizeof(float), s);
+            if (e != hipSuccess) { set_error("policy_backward: d(emb) padding memset", (int)e); return (int)e; }
+        }
+    }
     if (fusedb) {
         // dW2 (split-K with the first layer regenerated as B operand) and dW1/db1 (d(basic) kept in the
         // accumulators) - neither `basic` nor d(basic) exists in HBM on this path
         // the channel lists of the sparse path live in the d(emb) rows of the two 16-unit types (2 * 16 * 128 floats per
         // step, never written on that path; the lists take 2 * 320)
         const EmbSparseIn sp{w.f(DC_WS_DXCAT), amaxp, w.f(DC_WS_DTU), w.f(DC_WS_HEADOUT), HO_LD, Gd.p(DC_P_UNIT_B),
-                             w.f(DC_WS_DEMB) + (size_t)NR * T_CUM[2] * EMBW};
+                             w.f(DC_WS_DEMB) + (size_t)NRp * T_CUM[2] * EMBW};
         DC_TRY(embed_bwd_fused(obs, w.f(DC_WS_DEMB), P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), P.p(DC_P_UNIT_W), Gd.p(DC_P_UNIT_W),
-                               Gd.p(DC_P_BASIC_W), Gd.p(DC_P_BASIC_B), w.f(DC_WS_SCRATCH), DC_SCRATCH_FLOATS, NR,
+                               Gd.p(DC_P_BASIC_W), Gd.p(DC_P_BASIC_B), w.f(DC_WS_SCRATCH), DC_SCRATCH_FLOATS, NR, NRp,
                                sparse16 ? &sp : nullptr, s));
     } else {
         for (int t = 0; t < 6; ++t) {

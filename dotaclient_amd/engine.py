@@ -42,6 +42,7 @@ DC_DIMS_GEMM_FASTTILE = 2048
 DC_DIMS_BF16 = 4096
 DC_DIMS_GEMM_X3_ALL = 8192
 DC_DIMS_TEAM_VALU = 16384
+DC_DIMS_EMBED_UNFUSED = 32768
 
 WS_FIXED = ['BASIC', 'EMB', 'DEMB', 'XCAT', 'AMAX', 'PRE', 'HEADOUT', 'TU', 'DHEADOUT', 'DTU', 'DPRE', 'DXCAT',
             'STATS', 'WHHT', 'SCRATCH', 'HEADW_PAD', 'TEAM_XBUF', 'WPLANES']

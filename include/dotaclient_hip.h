@@ -132,6 +132,9 @@ typedef struct dc_dims {
 /*   DC_DIMS_TEAM_VALU      : H = 256 LSTM: the packed-f32 VALU team kernels (one sequence per turn) also for batches of more than
  *                            128 sequences, where the default is the MFMA team kernel that advances four sequences together. */
 #define DC_DIMS_TEAM_VALU 16384
+/*   DC_DIMS_EMBED_UNFUSED  : the unit-embedding MLP layer by layer (first layer materialised, six dense products) instead of the
+ *                            fused kernels, which handle any row count by padding the type-major blocks to a multiple of 128 rows. */
+#define DC_DIMS_EMBED_UNFUSED 32768
 
 /* index into poff[]; policy.py:54-75 names in comments */
 enum dc_param_index {

@@ -130,6 +130,18 @@ def test_hip_matches_oracle_at_baseline_configs(cell, hidden, B):
     compare(out, ref, 1, ref['param_names'])
 
 
+@pytest.mark.parametrize('case', ['ragged_s16', 'clip_s16', 'emptyhead_s16'])
+def test_unfused_embedding_path_matches_reference_golden(case):
+    # default: the fused embedding kernels on type-major blocks padded to a multiple of 128 rows (176 / 176 / 80 rows here) with
+    # the sparse max-pool backward; DC_DIMS_EMBED_UNFUSED: layer by layer with the dense products - the same golden vectors
+    from dotaclient_amd import engine as E
+    g, rollouts = util.load_case(case)
+    out, _ = run_hip(g, rollouts, kernel_flags=E.DC_DIMS_EMBED_UNFUSED)
+    compare(out, g, int(g['epochs']), g['param_names'])
+    out, _ = run_hip(g, rollouts, kernel_flags=E.DC_DIMS_DENSE_POOL_BWD)      # fused + padded, dense max-pool backward
+    compare(out, g, int(g['epochs']), g['param_names'])
+
+
 @pytest.mark.parametrize('which', ['x3_all', 'fasttile'])
 @pytest.mark.parametrize('case,cell,hidden,layers', [('ragged_s16', 'gru', 256, 1), ('cfg1_4x128', 'gru', 256, 1), ('ragged_s16', 'lstm', 128, 2)])
 def test_dense_product_kernels_both_match(which, case, cell, hidden, layers):
