@@ -207,7 +207,11 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_fwd_kernel(RnnSt
 //   the LDS image of the next product (all local) and dgx.
 // In: dh (from the layer above), the forward's gates / cseq / cprev; out: dgx.
 // ---------------------------------------------------------------------------------------------------
-enum { TB_KH = 256, TB_GLD = TB_KH + 8 };
+// LDS image of the A operand: per sequence eight blocks of 32 floats (one per broadcast group b'), 36 floats apart, rows 336
+// floats apart: the sixteen lanes of every ds_read_b128 lane group (four sequences x four blocks) then start 16 bytes x an odd
+// pattern apart - no bank conflicts (32-float blocks in rows of 264 gave two-way conflicts on every read)
+enum { TB_KH = 256, TB_BLK = 36, TB_GLD = 336 };
+__device__ __forceinline__ int tb_pos(int kk) { return TB_BLK * (kk >> 5) + (kk & 31); }
 // BwdProduct<256> hands MFMA number kk' (abid = kk' & 7 of A register kk' >> 3) the 32 consecutive floats lane 4b'+i read at
 // [i][32 b' ..]: with the image in PLAIN order it contracts kk = 32 (kk' & 7) + (kk' >> 3); the weights are loaded in that order
 __device__ __forceinline__ constexpr int tb_korder(int kk) { return 32 * (kk & 7) + (kk >> 3); }
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_bwd_kernel(RnnSt
             };
             // ---- partial dh_rec[seq 0..3][u'] over this member's 256 gate columns ------------------------------------------
             f32x4 pa[4];
-            BwdProduct<KH>::run(pa, w, lds_addr(&g_lds[cur][(lane & 3) * TB_GLD + ((lane >> 2) & 7) * BwdProduct<KH>::NJ]), hook);
+            BwdProduct<KH>::run(pa, w, lds_addr(&g_lds[cur][(lane & 3) * TB_GLD + ((lane >> 2) & 7) * TB_BLK]), hook);
             const f32x4 acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
             ++tag;
             u64* const ring = ring0 + (size_t)(tag & 3) * (4 * 4 * 4 * TEAM_US);
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_bwd_kernel(RnnSt
             const float dgr[4] = {on ? dcv * gg * ig * (1.f - ig) : 0.f, on ? dcv * cv[5] * fg * (1.f - fg) : 0.f,
                                   on ? dcv * ig * (1.f - gg * gg) : 0.f, on ? dh * tc * og * (1.f - og) : 0.f};
 #pragma unroll
-            for (int g = 0; g < 4; ++g) g_lds[cur ^ 1][slot * TB_GLD + TEAM_US * g + ul] = dgr[g];
+            for (int g = 0; g < 4; ++g) g_lds[cur ^ 1][slot * TB_GLD + tb_pos(TEAM_US * g + ul)] = dgr[g];
             sv[0] = on ? dgr[0] : sv[0]; sv[1] = on ? dgr[1] : sv[1]; sv[2] = on ? dgr[2] : sv[2]; sv[3] = on ? dgr[3] : sv[3];
             st_g = on ? goff : st_g;
             dc_next = on ? dcv : dc_next;
