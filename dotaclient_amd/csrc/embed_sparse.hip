@@ -21,7 +21,8 @@
 // lane gathers its 64 bytes of basic[a(c)] with four ds_read_b128, rows 528 bytes apart so that sixteen different rows
 // at one column never share a bank); d(basic) runs K-per-lane (wave w owns units w, w + 8, lane l the k pair 2l, 2l + 1:
 // the rows of W2 a unit sums over are wave-uniform and read as 512 contiguous bytes).  Steps with a live target-unit head additionally need R[k] = sum_c q[c] W2[c][k] and
-// s[k] = sum_u dtu[u] basic[u][k] (two workgroup reductions through LDS) for the rank-one terms.
+// s[k] = sum_u dtu[u] basic[u][k] for the rank-one terms: R is a dense product over all steps (q W2_t, 2 x 2 GFLOP on the
+// matrix cores, written straight into the staging image), s a sixteen-lane DPP sum per wave - no workgroup reduction.
 // Outputs are per-workgroup partials in the formats the dense path already reduces:
 //   slab[wg][128][128] (splitk_reduce_grouped), part1[wg][13][128] (unit_basic_reduce), part2[wg][128] (colsum).
 #include <stdio.h>
@@ -33,9 +34,10 @@ namespace dc {
 namespace {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-enum { SP_THREADS = 512, SP_LD = 128, SP_BLD = 132, SP_PREP = 320 };   // SP_BLD: floats per LDS row of `basic` (4 banks apart)
-enum { SP_OLD_ = 0 };   // SP_PREP: floats per (step, type) of the prepared channel lists   // padded LDS rows: consecutive rows start 4 banks apart, so 16 lanes reading
-                                         // 16 bytes at one column offset of 16 different rows never share a bank
+enum { SP_THREADS = 512, SP_LD = 128, SP_BLD = 132 };   // SP_BLD: floats per LDS row of `basic`: consecutive rows start 4 banks apart, so
+                                                        // 16 lanes reading 16 bytes at one column offset of 16 different rows never share a bank
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr int SP_OBS = 483, SP_XCAT = 896;
 
 struct SparseArgs {
@@ -44,7 +46,7 @@ struct SparseArgs {
     float* slab; float* part1; float* part2;
     long long nr; int wg_per_type; int steps_per_wg;
     long long* dbg;
-    float* prep;      // [2][nr][SP_PREP]: per step and type {d, W2-row byte offset} sorted by arg-max unit [144] | {first, count} [16]
+    float* prep;      // [2][nr][STG_SIZE]: pass 1's image of pass 2's staging block per (type, step)
 };
 
 // LDS carve-up (floats).  A workgroup runs NS = 2 independent step streams in lock step (one barrier per iteration):
@@ -54,8 +56,8 @@ enum {
     NS = 2,
     L_W2 = 0,                               // [128][128] W2_t rows
     L_BAS = L_W2 + 128 * SP_LD,             // 2 x NS x [16][SP_BLD] basic of a step (written one iteration ahead)
-    L_RED = L_BAS + 2 * NS * 16 * SP_BLD,   // NS x [2][8][128] per-wave partials of R and s
-    L_STG = L_RED + NS * 2 * 8 * 128,       // 3 x NS staging blocks: the inputs of a step
+    L_RED = L_BAS + 2 * NS * 16 * SP_BLD,   // [13][128]: the final sum of the half-waves' dW1 / db1
+    L_STG = L_RED + 13 * 128,               // 3 x NS staging blocks: the inputs of a step
     STG_Q = 0,                         //   q[128]
     STG_PB = 128,                      //   per channel {d, byte offset of basic row a(c) (SP_BLD rows)}  [128] x 8 B
     STG_LIST = 384,                    //   channels sorted by arg-max unit: {d, byte offset of W2 row c}, [128 + 16] x 8 B
@@ -63,9 +65,9 @@ enum {
     STG_DT = 704,                      //   dtu[16], [16] = their sum
     STG_FLAG = 736,                    //   1 if any dtu != 0
     STG_X = 752,                       //   unit records [16][12]
-    STG_SIZE = 944,
-    L_RS = L_STG + 3 * NS * STG_SIZE,       // NS x (R[128] | s[128])
-    L_W1 = L_RS + NS * 256,                 // [128][12] W1
+    STG_R = 944,                       //   R[k] = sum_c q[c] W2[c][k]  (written by a dense product, see embed_bwd_pool16)
+    STG_SIZE = 1072,
+    L_W1 = L_STG + 3 * NS * STG_SIZE,       // W1 as [12 f][128 k]: feature f of rows k4 .. k4 + 3 is one 16-byte read
     L_TOTAL = L_W1 + 128 * 12
 };
 enum { SP_SLOTS = 12 };   // channels of a unit handled in straight-line code (a unit holds 8 on average); the rest in a loop
@@ -91,16 +93,21 @@ __device__ __forceinline__ void pk_fma_s(f32x2& acc, f32x2 row, float d_uniform)
 
 }  // namespace
 
-// Pass 1: the channel list of every (env-step, type), sorted by arg-max unit.  One wave per (step, type); lane l owns
-// channels l and l + 64.  Per unit: two ballots, popcounts (count, running first position), v_mbcnt ranks - ascending
-// channel inside a unit, so the sums of pass 2 are deterministic.
+// Pass 1: everything pass 2 needs of an (env-step, type), laid out exactly as pass 2's LDS staging block (STG_*), so that
+// pass 2 fetches it with LDS-DMA (global_load_lds, 16 bytes per lane, no registers, no per-thread loader roles): q, the
+// per-channel {d, basic-row offset} pairs, the channel list sorted by arg-max unit, the units' {first, count}, dtu with its
+// sum and the "head is live" flag, the sixteen unit records.  One wave per (step, type); lane l owns channels l and l + 64.
+// The sort - per unit: two ballots, popcounts (count, running first position), v_mbcnt ranks - keeps ascending channel
+// order inside a unit, so the sums of pass 2 are deterministic.
 __global__ __launch_bounds__(256) void embed_pool16_prepare_kernel(SparseArgs p) {
     const int lane = threadIdx.x & 63;
     const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= 2 * p.nr) return;
     const int t = item < p.nr ? 2 : 3;
     const long long n = item < p.nr ? item : item - p.nr;
+    const int cum = t == 2 ? 6 : 22;                        // first unit of the type inside the 40
     const float* dx = p.dxcat + n * SP_XCAT;
+    float* out = p.prep + (size_t)item * STG_SIZE;
     float d[2];
     int a[2];
 #pragma unroll
@@ -108,6 +115,8 @@ __global__ __launch_bounds__(256) void embed_pool16_prepare_kernel(SparseArgs p)
         const int c = lane + 64 * h;
         d[h] = t == 2 ? dx[3 * 128 + c] : dx[4 * 128 + c] + dx[6 * 128 + c];   // policy.py:127: enh feeds two slots
         a[h] = p.amax[(n * 3 + (t - 1)) * 128 + c];
+        out[STG_Q + c] = p.q[n * p.ldq + c];
+        *reinterpret_cast<float2*>(out + STG_PB + 2 * c) = make_float2(d[h], __int_as_float(a[h] * SP_BLD * 4));
     }
     int pos[2] = {0, 0};
     int start = 0, my_start = 0, my_cnt = 0;
@@ -123,26 +132,40 @@ __global__ __launch_bounds__(256) void embed_pool16_prepare_kernel(SparseArgs p)
         my_cnt = lane == u ? c0 + c1 : my_cnt;
         start += c0 + c1;
     }
-    float* out = p.prep + (size_t)item * SP_PREP;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
-        *reinterpret_cast<float2*>(out + 2 * pos[h]) = make_float2(d[h], __int_as_float((lane + 64 * h) * SP_LD * 4));
-    if (lane < 16) {
-        // pass 2 reads SP_SLOTS entries from a unit's first one whatever its count: 16 zero-valued entries of row 0 behind
-        *reinterpret_cast<float2*>(out + 2 * (128 + lane)) = make_float2(0.f, __int_as_float(0));
-        *reinterpret_cast<int2*>(out + 288 + 2 * lane) = make_int2(my_start, my_cnt);
+        *reinterpret_cast<float2*>(out + STG_LIST + 2 * pos[h]) = make_float2(d[h], __int_as_float((lane + 64 * h) * SP_LD * 4));
+    {   // dtu of the sixteen units (lanes 0..15 = one DPP row: rotate-and-add leaves the sum in every lane), live flag
+        const float v = lane < 16 ? p.dtu[n * 40 + cum + lane] : 0.f;
+        float sum = v;
+        sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x128, 0xf, 0xf, true));
+        sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x124, 0xf, 0xf, true));
+        sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x122, 0xf, 0xf, true));
+        sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x121, 0xf, 0xf, true));
+        const unsigned long long nz = __ballot(v != 0.f);
+        if (lane < 16) {
+            out[STG_DT + lane] = v;
+            // pass 2 reads SP_SLOTS entries from a unit's first one whatever its count: 16 zero-valued entries of row 0 behind
+            *reinterpret_cast<float2*>(out + STG_LIST + 2 * (128 + lane)) = make_float2(0.f, __int_as_float(0));
+            *reinterpret_cast<int2*>(out + STG_SC + 2 * lane) = make_int2(my_start, my_cnt);
+        }
+        if (lane == 0) { out[STG_DT + 16] = sum; reinterpret_cast<int*>(out)[STG_FLAG] = nz != 0ull; }
     }
+    const float* rec = p.obs + n * SP_OBS + 3 + cum * 12;        // the type's sixteen records [16][12]
+#pragma unroll
+    for (int j = 0; j < 3; ++j) out[STG_X + lane + 64 * j] = rec[lane + 64 * j];
 }
 
 // Pass 2.  Workgroup = one type x a contiguous range of env-steps, split into two streams that advance one step per
 // iteration each (one barrier per iteration).
-// Wave w owns units w and w + 8 and the dW2 rows of channels w + 8i (i < 16); lane l owns k = 2l, 2l + 1 - so every
-// row of W2 / basic a wave touches is read by its 64 lanes as 512 contiguous bytes, and WHICH row is wave-uniform: the
-// {value, row offset} entries are fetched sixteen at a time (one 8-byte LDS read by sixteen lanes) and broadcast with
-// v_readlane into scalar registers.  One LDS round trip per row instead of two dependent ones, no divergent loops.
+// Lane maps (header): dW2 update - lane l owns channels l, l + 64, wave w the k range [16w, 16w + 16).  Everything else -
+// half hh = lane >> 5 of wave w owns unit u = w + 8 hh, lane l = lane & 31 of the half owns k4 = 4l .. 4l + 3.  The
+// {value, W2-row offset} entries of a unit's channels are fetched sixteen at a time (one 8-byte LDS read per lane, every
+// 16-lane DPP row of a half holding the same sixteen entries) and broadcast with row_newbcast: the two units of a wave
+// advance in the same instructions, one LDS round trip per W2 row, no divergent loops.
 //   iteration i: every thread hands its prefetched values of iteration i+1 to staging[(i+1) % 3] and issues the loads of
 //   iteration i+2  -- barrier --  phase A of iteration i+1 (basic -> bas[(i+1) & 1]), phases B, C, (live), D of iteration i.
-template <bool TIMING>   // TIMING (DC_SP_TIMING=1): s_memtime phase sums of every wave of workgroup 0 -> p.dbg[8][6]
+template <bool TIMING>   // TIMING (DC_DEV_TIMING build): s_memtime phase sums of every wave of workgroup 0 -> p.dbg[8][6]
 __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs p) {
     long long tm[6] = {0, 0, 0, 0, 0, 0}, tm0 = 0;
     auto stamp = [&](int i) {
@@ -151,262 +174,208 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int k0 = 2 * lane;
+    const int hh = lane >> 5, l32 = lane & 31;
+    const int k4 = 4 * l32;
+    const int u_own = w + 8 * hh;                           // this half-wave's unit
     const int t = 2 + blockIdx.x / p.wg_per_type;          // 2 = allied non-heroes, 3 = enemy non-heroes
     const int wgi = blockIdx.x % p.wg_per_type;
     const long long n0 = (long long)wgi * p.steps_per_wg;
     const long long n1 = min(p.nr, n0 + p.steps_per_wg);
-    const int cum = t == 2 ? 6 : 22;                        // first unit of the type inside the 40
-    const float* prep_t = p.prep + (size_t)(t - 2) * p.nr * SP_PREP;
+    const float* prep_t = p.prep + (size_t)(t - 2) * p.nr * STG_SIZE;
 
     // ---- stationary operands ---------------------------------------------------------------------------
     {
         const float4* src = reinterpret_cast<const float4*>(p.W2 + (size_t)t * 128 * 128);
         for (int e = tid; e < 128 * 32; e += SP_THREADS) *reinterpret_cast<float4*>(smem + L_W2 + 4 * e) = src[e];
     }
-    for (int e = tid; e < 128 * 12; e += SP_THREADS) smem[L_W1 + e] = p.W1[e];
-    const f32x2 b1r = mk2(p.b1[k0], p.b1[k0 + 1]);
+    for (int e = tid; e < 128 * 12; e += SP_THREADS) {       // W1[k][f] -> [f][k >> 2][k & 3]
+        const int k = e / 12, f = e - 12 * k;
+        smem[L_W1 + f * 128 + k] = p.W1[e];
+    }
+    const float4 b1r = *reinterpret_cast<const float4*>(p.b1 + k4);
     f32x2 D[2][8];                 // dW2[c][16w + 2j, 16w + 2j + 1] of channels c = lane (D[0]) and lane + 64 (D[1])
-    float dW1a[2][12], db1a[2];
+    f32x2 dW1a[12][2];             // dW1[k4 + 2e, k4 + 2e + 1][f] contributions of this half-wave's unit: [f][e]
+    f32x2 db1a[2];
     float db2a = 0.f;              // threads 0..127: second-layer bias gradient of channel tid
 #pragma unroll
     for (int i = 0; i < 8; ++i) { D[0][i] = mk2(0.f, 0.f); D[1][i] = mk2(0.f, 0.f); }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        db1a[e] = 0.f;
+        db1a[e] = mk2(0.f, 0.f);
 #pragma unroll
-        for (int f = 0; f < 12; ++f) dW1a[e][f] = 0.f;
+        for (int f = 0; f < 12; ++f) dW1a[f][e] = mk2(0.f, 0.f);
     }
 
     // ---- two step streams: stream s covers steps [nb[s], ne[s]); iteration i works on step nb[s] + i of both ----------
     const long long half = (n1 - n0 + 1) / 2;
     const long long nb[NS] = {n0, n0 + half}, ne[NS] = {min(n1, n0 + half), n1};
     const long long iters = half;
-
-    // ---- loader roles: tid < 128 channel tid (d, q, arg-max) | 128..143 dtu | 144..335 record floats | 336..495 prepared list
-    float st_0[NS] = {0.f, 0.f}, st_1[NS] = {0.f, 0.f};
-    int st_a[NS] = {0, 0};
-    auto stage_load = [&](long long i) {
-#pragma unroll
-        for (int s2 = 0; s2 < NS; ++s2) {
-            const long long n = nb[s2] + i;
-            if (n >= ne[s2]) continue;
-            if (tid < 128) {
-                const float* dx = p.dxcat + n * SP_XCAT;
-                st_0[s2] = t == 2 ? dx[3 * 128 + tid] : dx[4 * 128 + tid] + dx[6 * 128 + tid];   // policy.py:127: enh feeds two slots
-                st_1[s2] = p.q[n * p.ldq + tid];
-                st_a[s2] = p.amax[(n * 3 + (t - 1)) * 128 + tid];
-            } else if (tid < 144) {
-                st_0[s2] = p.dtu[n * 40 + cum + (tid - 128)];
-            } else if (tid < 336) {
-                st_0[s2] = p.obs[n * SP_OBS + 3 + cum * 12 + (tid - 144)];
-            } else if (tid < 496) {
-                const float2 v = *reinterpret_cast<const float2*>(prep_t + (size_t)n * SP_PREP + 2 * (tid - 336));
-                st_0[s2] = v.x; st_1[s2] = v.y;
-            }
-        }
-    };
+    // ---- staging: the block of (stream, iteration) goes global -> LDS by DMA, 1 KB per wave (+ the 192-byte tail):
+    // waves 0..3 stream 0, waves 4..7 stream 1.  Issued behind the barrier of iteration i for iteration i + 2, awaited
+    // (s_waitcnt vmcnt(0): the kernel's only vector-memory traffic) before the barrier of iteration i + 1.
     auto stg_of = [&](long long i, int s2) { return smem + L_STG + ((int)(i % 3) * NS + s2) * STG_SIZE; };
-    auto hand_over = [&](long long i) {           // registers -> staging[i % 3][stream]
-#pragma unroll
-        for (int s2 = 0; s2 < NS; ++s2) {
-            if (nb[s2] + i >= ne[s2]) continue;
-            float* stg = stg_of(i, s2);
-            if (tid < 128) {
-                stg[STG_Q + tid] = st_1[s2];
-                *reinterpret_cast<float2*>(stg + STG_PB + 2 * tid) = make_float2(st_0[s2], __int_as_float(st_a[s2] * SP_BLD * 4));
-            } else if (tid < 144) {        // lanes 0..15 of wave 2
-                stg[STG_DT + (tid - 128)] = st_0[s2];
-                float sum = st_0[s2];          // the sixteen lanes are one DPP row: rotate-and-add, no LDS round trips
-                sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x128, 0xf, 0xf, true));
-                sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x124, 0xf, 0xf, true));
-                sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x122, 0xf, 0xf, true));
-                sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x121, 0xf, 0xf, true));
-                const unsigned long long nz = __ballot(st_0[s2] != 0.f) & 0xffffull;
-                if (tid == 128) { stg[STG_DT + 16] = sum; reinterpret_cast<int*>(stg)[STG_FLAG] = nz != 0ull; }
-            } else if (tid < 336) {
-                stg[STG_X + (tid - 144)] = st_0[s2];
-            } else if (tid < 496) {        // LIST [288] and SC [32] are contiguous in the prepared block and in staging
-                *reinterpret_cast<float2*>(stg + STG_LIST + 2 * (tid - 336)) = make_float2(st_0[s2], st_1[s2]);
-            }
-        }
-    };
-    // sixteen {value, offset} entries starting at `first`, stride `stride` entries -> lanes 0..15 of (val, off)
-    auto gather16 = [&](const float* base, int first, int stride, float& val, int& off) {
-        const float2 e = *reinterpret_cast<const float2*>(base + 2 * (first + stride * (lane & 15)));
-        val = e.x;
-        off = __float_as_int(e.y);
+    auto dma_issue = [&](long long i) {
+        const int s2 = w >> 2, part = w & 3;
+        const long long n = nb[s2] + i;
+        if (n >= ne[s2]) return;                               // wave-uniform
+        const float* src = prep_t + (size_t)n * STG_SIZE;
+        float* dst = stg_of(i, s2);
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + part * 256 + lane * 4), (lptr_t)(dst + part * 256), 16, 0, 0);
+        if (part == 0 && 4096 + lane * 16 < STG_SIZE * 4)        // the tail behind the four full kilobytes
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + 1024 + lane * 4), (lptr_t)(dst + 1024), 16, 0, 0);
     };
     auto bas_of = [&](long long i, int s2) { return smem + L_BAS + ((int)(i & 1) * NS + s2) * 16 * SP_BLD; };
-    auto phase_a = [&](long long i) {             // basic[u][k0..k0+1] of iteration i's steps, u = w and w + 8
-        // W1 rows k0, k0 + 1 (24 floats); the k-ordered fmaf chain of the MFMA-generated first layer (embed_fused.hip),
-        // bias last: bitwise the forward's value, hence its relu mask
-        const float4* wp = reinterpret_cast<const float4*>(smem + L_W1 + k0 * 12);
-        float w1[24];
+    // the twelve record floats of this half-wave's unit (two distinct addresses per wave: broadcast reads)
+    auto load_x = [&](const float* stg, float (&x)[12]) {
+        const float4* xp = reinterpret_cast<const float4*>(stg + STG_X + u_own * 12);
+        const float4 xa = xp[0], xb = xp[1], xc = xp[2];
+        x[0] = xa.x; x[1] = xa.y; x[2] = xa.z; x[3] = xa.w; x[4] = xb.x; x[5] = xb.y; x[6] = xb.z; x[7] = xb.w;
+        x[8] = xc.x; x[9] = xc.y; x[10] = xc.z; x[11] = xc.w;
+    };
+    // BOTH (here and in the loop body): both streams have a step in this iteration, known at compile time - no branch splits
+    // the two streams' instruction chains into separate blocks, so the scheduler interleaves them (the point of having two)
+    auto phase_a = [&](long long i, auto both_c) {             // basic[u_own][k4 .. k4 + 3] of iteration i's steps
+        constexpr bool BOTH = decltype(both_c)::value;
+        // the k-ordered fmaf chain of the MFMA-generated first layer (embed_fused.hip), bias last: bitwise the forward's
+        // value, hence its relu mask
+        f32x2 wl[12], wh[12];
 #pragma unroll
-        for (int v = 0; v < 6; ++v) { const float4 q4 = wp[v]; w1[4 * v] = q4.x; w1[4 * v + 1] = q4.y; w1[4 * v + 2] = q4.z; w1[4 * v + 3] = q4.w; }
+        for (int f = 0; f < 12; ++f) {
+            const float4 q4 = *reinterpret_cast<const float4*>(smem + L_W1 + f * 128 + k4);
+            wl[f] = mk2(q4.x, q4.y); wh[f] = mk2(q4.z, q4.w);
+        }
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) {
-            if (nb[s2] + i >= ne[s2]) continue;
-            const float* stg = stg_of(i, s2);
-            float* bas = bas_of(i, s2);
+            if (!BOTH && nb[s2] + i >= ne[s2]) continue;
+            float x[12];
+            load_x(stg_of(i, s2), x);
+            f32x2 al = mk2(x[0], x[0]) * wl[0], ah = mk2(x[0], x[0]) * wh[0];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int u = w + 8 * h;
-                const float4* xp = reinterpret_cast<const float4*>(stg + STG_X + u * 12);     // wave-uniform address
-                const float4 xa = xp[0], xb = xp[1], xc = xp[2];
-                const float x[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
-                float a0 = x[0] * w1[0], a1 = x[0] * w1[12];
-#pragma unroll
-                for (int f = 1; f < 12; ++f) { a0 = fmaf(x[f], w1[f], a0); a1 = fmaf(x[f], w1[12 + f], a1); }
-                *reinterpret_cast<float2*>(bas + u * SP_BLD + k0) = make_float2(fmaxf(a0 + b1r.x, 0.f), fmaxf(a1 + b1r.y, 0.f));
+            for (int f = 1; f < 12; ++f) {
+                al = __builtin_elementwise_fma(mk2(x[f], x[f]), wl[f], al);
+                ah = __builtin_elementwise_fma(mk2(x[f], x[f]), wh[f], ah);
             }
+            *reinterpret_cast<float4*>(bas_of(i, s2) + u_own * SP_BLD + k4) =
+                make_float4(fmaxf(al.x + b1r.x, 0.f), fmaxf(al.y + b1r.y, 0.f), fmaxf(ah.x + b1r.z, 0.f), fmaxf(ah.y + b1r.w, 0.f));
         }
     };
 
-    stage_load(0);
-    hand_over(0);
-    stage_load(1);
-    __syncthreads();          // W2 / W1 / staging[0]
-    phase_a(0);
+    dma_issue(0);
+    dma_issue(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();          // W2 / W1 / staging[0], staging[1]
+    phase_a(0, std::false_type{});
 
-    const char* w2b = reinterpret_cast<const char*>(smem + L_W2 + k0);     // + W2-row byte offset
-    for (long long i = 0; i < iters; ++i) {
+    const char* w2b = reinterpret_cast<const char*>(smem + L_W2 + k4);     // + W2-row byte offset
+    auto iteration = [&](long long i, auto both_c) {     // BOTH: both streams on in iterations i and i + 1
+        constexpr bool BOTH = decltype(both_c)::value;
         if constexpr (TIMING) tm0 = __builtin_amdgcn_s_memtime();
-        hand_over(i + 1);
-        stage_load(i + 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // staging[i + 1] of this wave's quarter has landed
         stamp(0);
         __syncthreads();
         stamp(1);
-        phase_a(i + 1);
+        dma_issue(i + 2);
+        phase_a(i + 1, both_c);
         const float* stg[NS];
-        const char* basb[NS];
         bool on[NS], live[NS];
-        f32x2 basic[NS][2], db[NS][2];
+        float4 basic[NS];
+        f32x2 dbl[NS], dbh[NS];       // d(basic)[u_own][k4, k4 + 1] and [k4 + 2, k4 + 3]
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) {
-            on[s2] = nb[s2] + i < ne[s2];                                         // workgroup-uniform
+            on[s2] = BOTH || nb[s2] + i < ne[s2];                                 // workgroup-uniform
             stg[s2] = stg_of(i, s2);
-            basb[s2] = reinterpret_cast<const char*>(bas_of(i, s2) + k0);
             live[s2] = on[s2] && reinterpret_cast<const int*>(stg[s2])[STG_FLAG] != 0;
-            db[s2][0] = mk2(0.f, 0.f); db[s2][1] = mk2(0.f, 0.f);
-            basic[s2][0] = mk2(0.f, 0.f); basic[s2][1] = mk2(0.f, 0.f);
+            dbl[s2] = mk2(0.f, 0.f); dbh[s2] = mk2(0.f, 0.f);
+            basic[s2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        // ---- phase B: dW2[c][k] += d[c] * basic[a(c)][k], c = w + 8 i;  phase C: dbasic[u][k] = sum over the unit's
-        // channels of d[c] * W2[c][k], u = w, w + 8 - for both streams
+        // ---- phase B: dW2[c][k] += d[c] * basic[a(c)][k], c = lane, lane + 64;  phase C: dbasic[u][k] = sum over the
+        // unit's channels of d[c] * W2[c][k], u = u_own - for both streams
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) {
             if (!on[s2]) continue;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) basic[s2][h] = *reinterpret_cast<const f32x2*>(basb[s2] + (w + 8 * h) * SP_BLD * 4);
+            basic[s2] = *reinterpret_cast<const float4*>(bas_of(i, s2) + u_own * SP_BLD + k4);
             {   // phase B, channel per lane: D[h][j] += d[c] * basic[a(c)][16w + 2j .. +1], c = lane + 64 h
                 const char* brow = reinterpret_cast<const char*>(bas_of(i, s2)) + w * 64;       // k range of this wave
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const float2 e = *reinterpret_cast<const float2*>(stg[s2] + STG_PB + 2 * (lane + 64 * h));   // {d, row byte offset}
                     const float4* rp = reinterpret_cast<const float4*>(brow + __float_as_int(e.y));
-                    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
                     const f32x2 dd = mk2(e.x, e.x);
-                    D[h][0] = __builtin_elementwise_fma(dd, mk2(r0.x, r0.y), D[h][0]);
-                    D[h][1] = __builtin_elementwise_fma(dd, mk2(r0.z, r0.w), D[h][1]);
-                    D[h][2] = __builtin_elementwise_fma(dd, mk2(r1.x, r1.y), D[h][2]);
-                    D[h][3] = __builtin_elementwise_fma(dd, mk2(r1.z, r1.w), D[h][3]);
-                    D[h][4] = __builtin_elementwise_fma(dd, mk2(r2.x, r2.y), D[h][4]);
-                    D[h][5] = __builtin_elementwise_fma(dd, mk2(r2.z, r2.w), D[h][5]);
-                    D[h][6] = __builtin_elementwise_fma(dd, mk2(r3.x, r3.y), D[h][6]);
-                    D[h][7] = __builtin_elementwise_fma(dd, mk2(r3.z, r3.w), D[h][7]);
-                }
-            }
-            float scv; int scc;
-            gather16(stg[s2] + STG_SC, 0, 1, scv, scc);          // lane u: {first entry, count} of unit u
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int first = __builtin_amdgcn_readlane(__float_as_int(scv), w + 8 * h);
-                const int cnt = __builtin_amdgcn_readlane(scc, w + 8 * h);
-                float dvec; int ovec;
-                gather16(stg[s2] + STG_LIST, first, 1, dvec, ovec);
-                dvec = (lane & 15) < cnt ? dvec : 0.f;        // past the unit's segment: the next unit's entries, weight 0
-                f32x2& dbh = db[s2][h];
-                f32x2 dbo = mk2(0.f, 0.f);       // odd slots: a second chain (a unit's 8-12 dependent packed FMAs are the
-                                                 // longest serial chain of the step; order of the sum stays fixed)
-                auto slot = [&](auto JC) {
-                    constexpr int J = decltype(JC)::value;
-                    const f32x2 wv = *reinterpret_cast<const f32x2*>(w2b + bcast16_i<J>(ovec));
-                    const float d = bcast16_f<J>(dvec);
-                    f32x2& acc = (J & 1) ? dbo : dbh;
-                    acc.x = fmaf(d, wv.x, acc.x);
-                    acc.y = fmaf(d, wv.y, acc.y);
-                };
-                for_consts(slot, std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>{});         // a unit holds 8 channels on average
-                if (cnt > 8) for_consts(slot, std::integer_sequence<int, 8, 9, 10, 11>{});      // wave-uniform
-                for (int j = SP_SLOTS; j < cnt; ++j) {        // wave-uniform trip count
-                    const float2 e = *reinterpret_cast<const float2*>(stg[s2] + STG_LIST + 2 * (first + j));
-                    const f32x2 wv = *reinterpret_cast<const f32x2*>(w2b + __float_as_int(e.y));
-                    db[s2][h] = __builtin_elementwise_fma(mk2(e.x, e.x), wv, db[s2][h]);
+                    for (int v = 0; v < 4; ++v) {
+                        const float4 r4 = rp[v];
+                        D[h][2 * v] = __builtin_elementwise_fma(dd, mk2(r4.x, r4.y), D[h][2 * v]);
+                        D[h][2 * v + 1] = __builtin_elementwise_fma(dd, mk2(r4.z, r4.w), D[h][2 * v + 1]);
+                    }
                 }
-                db[s2][h] += dbo;
             }
+            // phase C: {first entry, count} of the own unit, then its entries first .. first + 15 in every 16-lane row
+            const int2 sc = *reinterpret_cast<const int2*>(stg[s2] + STG_SC + 2 * u_own);
+            const int first = sc.x, cnt = sc.y;
+            const float2 ent = *reinterpret_cast<const float2*>(stg[s2] + STG_LIST + 2 * (first + (lane & 15)));
+            const float dvec = (lane & 15) < cnt ? ent.x : 0.f;       // past the unit's segment: the next unit's entries, weight 0
+            const int ovec = __float_as_int(ent.y);
+            f32x2 ol = mk2(0.f, 0.f), oh = mk2(0.f, 0.f);    // odd slots: a second chain (a unit's 8-12 dependent packed FMAs are the
+                                                             // longest serial chain of the step; order of the sum stays fixed)
+            auto slot = [&](auto JC) {
+                constexpr int J = decltype(JC)::value;
+                const float4 wv = *reinterpret_cast<const float4*>(w2b + bcast16_i<J>(ovec));
+                const float d = bcast16_f<J>(dvec);
+                const f32x2 dd = mk2(d, d);
+                if constexpr (J & 1) {
+                    ol = __builtin_elementwise_fma(dd, mk2(wv.x, wv.y), ol); oh = __builtin_elementwise_fma(dd, mk2(wv.z, wv.w), oh);
+                } else {
+                    dbl[s2] = __builtin_elementwise_fma(dd, mk2(wv.x, wv.y), dbl[s2]); dbh[s2] = __builtin_elementwise_fma(dd, mk2(wv.z, wv.w), dbh[s2]);
+                }
+            };
+            for_consts(slot, std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>{});         // a unit holds 8 channels on average
+            const int cmax = max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 32));
+            if (cmax > 8) for_consts(slot, std::integer_sequence<int, 8, 9, 10, 11>{});     // wave-uniform
+            for (int j = SP_SLOTS; j < cmax; ++j) {       // wave-uniform trip count; a half past its own count adds zeros
+                const float2 e = *reinterpret_cast<const float2*>(stg[s2] + STG_LIST + 2 * (first + min(j, cnt - 1 < 0 ? 0 : cnt - 1)));
+                const float4 wv = *reinterpret_cast<const float4*>(w2b + __float_as_int(e.y));
+                const float d = j < cnt ? e.x : 0.f;
+                dbl[s2] = __builtin_elementwise_fma(mk2(d, d), mk2(wv.x, wv.y), dbl[s2]);
+                dbh[s2] = __builtin_elementwise_fma(mk2(d, d), mk2(wv.z, wv.w), dbh[s2]);
+            }
+            dbl[s2] += ol; dbh[s2] += oh;
         }
         stamp(2);
         stamp(3);
         if (live[0] || live[1]) {
             // rank-one attention terms: d(emb)[u][c] += dtu[u] q[c]
-            //   dbasic[u][k] += dtu[u] * R[k],  R[k] = sum_c q[c] W2[c][k]
+            //   dbasic[u][k] += dtu[u] * R[k],  R[k] = sum_c q[c] W2[c][k]       (R: staging, a dense product over all steps)
             //   dW2[c][k]    += q[c] * s[k],    s[k] = sum_u dtu[u] basic[u][k]
-            float dt0[NS] = {0.f, 0.f}, dt1[NS] = {0.f, 0.f}, qvec[NS] = {0.f, 0.f};
+            // Both streams whenever either is live (dtu = 0 adds zeros): one block, the streams' chains interleave.
 #pragma unroll
             for (int s2 = 0; s2 < NS; ++s2) {
-                if (!live[s2]) continue;
-                dt0[s2] = stg[s2][STG_DT + w]; dt1[s2] = stg[s2][STG_DT + w + 8];
-                qvec[s2] = stg[s2][STG_Q + w + 8 * (lane & 15)];       // lane c: q of channel w + 8 c
-                float* red = smem + L_RED + s2 * 2048;
-                f32x2 r = mk2(0.f, 0.f);
-                const float qv16 = qvec[s2];
-                for_consts([&](auto CC) {
-                    constexpr int C = decltype(CC)::value;
-                    const float qc = bcast16_f<C>(qv16);
-                    const f32x2 wv = *reinterpret_cast<const f32x2*>(w2b + (w + 8 * C) * SP_LD * 4);
-                    r.x = fmaf(qc, wv.x, r.x);
-                    r.y = fmaf(qc, wv.y, r.y);
-                }, std::make_integer_sequence<int, 16>{});
-                *reinterpret_cast<f32x2*>(red + w * 128 + k0) = r;
-                *reinterpret_cast<f32x2*>(red + 1024 + w * 128 + k0) =
-                    mk2(dt0[s2], dt0[s2]) * basic[s2][0] + mk2(dt1[s2], dt1[s2]) * basic[s2][1];
-            }
-            __syncthreads();
+                if (!on[s2]) continue;
+                const float dt = stg[s2][STG_DT + u_own];
+                const float4 R = *reinterpret_cast<const float4*>(stg[s2] + STG_R + k4);
+                dbl[s2] = __builtin_elementwise_fma(mk2(dt, dt), mk2(R.x, R.y), dbl[s2]);
+                dbh[s2] = __builtin_elementwise_fma(mk2(dt, dt), mk2(R.z, R.w), dbh[s2]);
+                // s[16w .. 16w + 15] (this wave's k range of the dW2 update): lane (u = lane & 15, g = lane >> 4) takes
+                // dtu[u] * basic[u][16w + 4g .. + 3]; rotate-and-add over the sixteen lanes of each DPP row
+                const float du = stg[s2][STG_DT + (lane & 15)];
+                const float4 bv = *reinterpret_cast<const float4*>(bas_of(i, s2) + (lane & 15) * SP_BLD + 16 * w + 4 * (lane >> 4));
+                float sv[4] = {du * bv.x, du * bv.y, du * bv.z, du * bv.w};
 #pragma unroll
-            for (int s2 = 0; s2 < NS; ++s2) {
-                if (!live[s2]) continue;
-                if (tid < 256) {     // R[k] (tid < 128) and s[k] (128 <= tid < 256): sums over the 8 waves, fixed order
-                    const float* src = smem + L_RED + s2 * 2048 + (tid >> 7) * 1024 + (tid & 127);
-                    float acc = 0.f;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) acc += src[u * 128];
-                    smem[L_RS + s2 * 256 + tid] = acc;
+                for (int e = 0; e < 4; ++e) {
+                    sv[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv[e]), 0x128, 0xf, 0xf, true));
+                    sv[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv[e]), 0x124, 0xf, 0xf, true));
+                    sv[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv[e]), 0x122, 0xf, 0xf, true));
+                    sv[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv[e]), 0x121, 0xf, 0xf, true));
                 }
-            }
-            __syncthreads();
+                // dW2[c][k] += q[c] * s[k] in the channel-per-lane layout: q lane-local, s wave-uniform (row g of the wave -> SGPRs)
+                const float q0 = stg[s2][STG_Q + lane], q1 = stg[s2][STG_Q + lane + 64];
 #pragma unroll
-            for (int s2 = 0; s2 < NS; ++s2) {
-                if (!live[s2]) continue;
-                const f32x2 R = *reinterpret_cast<const f32x2*>(smem + L_RS + s2 * 256 + k0);
-                db[s2][0] = __builtin_elementwise_fma(mk2(dt0[s2], dt0[s2]), R, db[s2][0]);
-                db[s2][1] = __builtin_elementwise_fma(mk2(dt1[s2], dt1[s2]), R, db[s2][1]);
-                // dW2[c][k] += q[c] * s[k] in the channel-per-lane layout: q lane-local, s[16w .. 16w + 15] wave-uniform
-                const float4* sp = reinterpret_cast<const float4*>(smem + L_RS + s2 * 256 + 128 + 16 * w);
-                const float4 s0 = sp[0], s1 = sp[1], s2v = sp[2], s3 = sp[3];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float qc = stg[s2][STG_Q + lane + 64 * h];
-                    const f32x2 qq = mk2(qc, qc);
-                    D[h][0] = __builtin_elementwise_fma(qq, mk2(s0.x, s0.y), D[h][0]);
-                    D[h][1] = __builtin_elementwise_fma(qq, mk2(s0.z, s0.w), D[h][1]);
-                    D[h][2] = __builtin_elementwise_fma(qq, mk2(s1.x, s1.y), D[h][2]);
-                    D[h][3] = __builtin_elementwise_fma(qq, mk2(s1.z, s1.w), D[h][3]);
-                    D[h][4] = __builtin_elementwise_fma(qq, mk2(s2v.x, s2v.y), D[h][4]);
-                    D[h][5] = __builtin_elementwise_fma(qq, mk2(s2v.z, s2v.w), D[h][5]);
-                    D[h][6] = __builtin_elementwise_fma(qq, mk2(s3.x, s3.y), D[h][6]);
-                    D[h][7] = __builtin_elementwise_fma(qq, mk2(s3.z, s3.w), D[h][7]);
+                for (int g = 0; g < 4; ++g) {
+                    auto rl = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16 * g)); };
+                    const float sa = rl(sv[0]), sb = rl(sv[1]), sc2 = rl(sv[2]), sd = rl(sv[3]);
+                    D[0][2 * g] = __builtin_elementwise_fma(mk2(q0, q0), mk2(sa, sb), D[0][2 * g]);
+                    D[0][2 * g + 1] = __builtin_elementwise_fma(mk2(q0, q0), mk2(sc2, sd), D[0][2 * g + 1]);
+                    D[1][2 * g] = __builtin_elementwise_fma(mk2(q1, q1), mk2(sa, sb), D[1][2 * g]);
+                    D[1][2 * g + 1] = __builtin_elementwise_fma(mk2(q1, q1), mk2(sc2, sd), D[1][2 * g + 1]);
                 }
             }
         }
@@ -415,22 +384,25 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) {
             if (!on[s2]) continue;
+            float x[12];
+            load_x(stg[s2], x);
+            const f32x2 ml = mk2(basic[s2].x > 0.f ? dbl[s2].x : 0.f, basic[s2].y > 0.f ? dbl[s2].y : 0.f);
+            const f32x2 mh = mk2(basic[s2].z > 0.f ? dbh[s2].x : 0.f, basic[s2].w > 0.f ? dbh[s2].y : 0.f);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float4* xp = reinterpret_cast<const float4*>(stg[s2] + STG_X + (w + 8 * h) * 12);
-                const float4 xa = xp[0], xb = xp[1], xc = xp[2];
-                const float x[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
-                const float dbm[2] = {basic[s2][h].x > 0.f ? db[s2][h].x : 0.f, basic[s2][h].y > 0.f ? db[s2][h].y : 0.f};
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-#pragma unroll
-                    for (int f = 0; f < 12; ++f) dW1a[e][f] = fmaf(dbm[e], x[f], dW1a[e][f]);
-                    db1a[e] += dbm[e];
-                }
+            for (int f = 0; f < 12; ++f) {
+                dW1a[f][0] = __builtin_elementwise_fma(ml, mk2(x[f], x[f]), dW1a[f][0]);
+                dW1a[f][1] = __builtin_elementwise_fma(mh, mk2(x[f], x[f]), dW1a[f][1]);
             }
+            db1a[0] += ml; db1a[1] += mh;
             if (tid < 128) db2a += stg[s2][STG_PB + 2 * tid] + (live[s2] ? stg[s2][STG_Q + tid] * stg[s2][STG_DT + 16] : 0.f);   // column sum of d(emb)
         }
         stamp(5);
+    };
+    {
+        const long long full = ne[1] - nb[1];       // stream 1 has as many steps as stream 0 or one fewer
+        long long i = 0;
+        for (; i + 1 < full; ++i) iteration(i, std::true_type{});
+        for (; i < iters; ++i) iteration(i, std::false_type{});
     }
 
     if constexpr (TIMING) {
@@ -447,7 +419,7 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
                     make_float4(D[h][2 * j].x, D[h][2 * j].y, D[h][2 * j + 1].x, D[h][2 * j + 1].y);
         if (tid < 128) p.part2[(size_t)blockIdx.x * 128 + tid] = db2a;
     }
-    // dW1 / db1: sum the 8 waves in fixed order through LDS -> part1[wg][f][k] (f = 12: db1)
+    // dW1 / db1: sum the 16 half-waves (= units) in fixed order through LDS -> part1[wg][f][k] (f = 12: db1)
     __syncthreads();
     float* acc = smem + L_RED;      // [13][128]
     for (int e = tid; e < 13 * 128; e += SP_THREADS) acc[e] = 0.f;
@@ -455,10 +427,20 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
     for (int ww = 0; ww < 8; ++ww) {
         if (w == ww) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
+            for (int part = 0; part < 2; ++part) {       // lanes 0..31, then lanes 32..63 (same addresses; in-order per wave)
+                if (hh == part) {
 #pragma unroll
-                for (int f = 0; f < 12; ++f) acc[f * 128 + k0 + e] += dW1a[e][f];
-                acc[12 * 128 + k0 + e] += db1a[e];
+                    for (int f = 0; f < 12; ++f) {
+                        float4* a4 = reinterpret_cast<float4*>(acc + f * 128 + k4);
+                        float4 v = *a4;
+                        v.x += dW1a[f][0].x; v.y += dW1a[f][0].y; v.z += dW1a[f][1].x; v.w += dW1a[f][1].y;
+                        *a4 = v;
+                    }
+                    float4* a4 = reinterpret_cast<float4*>(acc + 12 * 128 + k4);
+                    float4 v = *a4;
+                    v.x += db1a[0].x; v.y += db1a[0].y; v.z += db1a[1].x; v.w += db1a[1].y;
+                    *a4 = v;
+                }
             }
         }
         __syncthreads();
@@ -468,7 +450,7 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
 }
 
 // slab: 2 * wg_per_type x [128][128]; part1: 2 * wg_per_type x [13][128]; part2: 2 * wg_per_type x [128];
-// prep: 2 * nr * 320 floats of scratch for the prepared channel lists
+// prep: 2 * nr * 1072 floats of scratch for the prepared staging blocks
 int embed_bwd_pool16(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq,
                      const float* W1, const float* b1, const float* W2, float* slab, float* part1, float* part2, float* prep,
                      long long nr, int wg_per_type, hipStream_t s) {
@@ -484,6 +466,11 @@ int embed_bwd_pool16(const float* obs, const float* dxcat, const uint8_t* amax, 
     }
     hipLaunchKernelGGL(embed_pool16_prepare_kernel, dim3((unsigned)((2 * nr + 3) / 4)), dim3(256), 0, s, a);
     if (int e = launch_check("embed_pool16_prepare")) return e;
+    // R[n][k] = sum_c q[n][c] W2_t[c][k] of every step, straight into the R section of the staging images (row stride STG_SIZE)
+    for (int t = 2; t < 4; ++t)
+        if (int e = gemm_f32(q, W2 + (size_t)t * 128 * 128, prep + (size_t)(t - 2) * nr * STG_SIZE + STG_R, (int)nr, 128, 128, ldq, 128,
+                             STG_SIZE, 0, 1, nullptr, 0, nullptr, 0, 0, 1, s))
+            return e;
     // algorithmic work: basic + dW1 fold 2 x 16 x 128 x 12 MACs, the two gathers 2 x 128 x 128 MACs per step and type
     ProfScope prof("embed_bwd_pool16", 2.0 * 2.0 * nr * (2.0 * 16 * 128 * 12 + 2.0 * 128 * 128),
                    4.0 * 2.0 * nr * (16 * 12 + 3 * 128 + 16 + 32), s);
