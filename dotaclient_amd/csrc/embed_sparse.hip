@@ -46,7 +46,8 @@ struct SparseArgs {
     float* slab; float* part1; float* part2;
     long long nr; int wg_per_type; int steps_per_wg;
     long long* dbg;
-    float* prep;      // [2][nr][STG_SIZE]: pass 1's image of pass 2's staging block per (type, step)
+    float* prep;      // [2][nr][IMG_SIZE]: pass 1's image of the head of pass 2's staging block per (type, step)
+    const float* rbuf; // [2][nr][128]: R of every (type, step)
 };
 
 // LDS carve-up (floats).  A workgroup runs NS = 2 independent step streams in lock step (one barrier per iteration):
@@ -58,15 +59,18 @@ enum {
     L_BAS = L_W2 + 128 * SP_LD,             // 2 x NS x [16][SP_BLD] basic of a step (written one iteration ahead)
     L_RED = L_BAS + 2 * NS * 16 * SP_BLD,   // [13][128]: the final sum of the half-waves' dW1 / db1
     L_STG = L_RED + 13 * 128,               // 3 x NS staging blocks: the inputs of a step
-    STG_Q = 0,                         //   q[128]
-    STG_PB = 128,                      //   per channel {d, byte offset of basic row a(c) (SP_BLD rows)}  [128] x 8 B
-    STG_LIST = 384,                    //   channels sorted by arg-max unit: {d, byte offset of W2 row c}, [128 + 16] x 8 B
-    STG_SC = 672,                      //   per unit {first list entry, number of channels}          [16] x 8 B
-    STG_DT = 704,                      //   dtu[16], [16] = their sum
-    STG_FLAG = 736,                    //   1 if any dtu != 0
-    STG_X = 752,                       //   unit records [16][12]
-    STG_R = 944,                       //   R[k] = sum_c q[c] W2[c][k]  (written by a dense product, see embed_bwd_pool16)
-    STG_SIZE = 1072,
+    // pass 1's image of a step (IMG_SIZE floats, contiguous in HBM and in LDS) ...
+    STG_PB = 0,                        //   per channel {d, byte offset of basic row a(c) (SP_BLD rows)}  [128] x 8 B
+    STG_LIST = 256,                    //   channels sorted by arg-max unit: {d, byte offset of W2 row c}, [128 + 16] x 8 B
+    STG_SC = 544,                      //   per unit {first list entry, number of channels}          [16] x 8 B
+    STG_DT = 576,                      //   dtu[16], [16] = their sum
+    STG_FLAG = 600,                    //   1 if any dtu != 0
+    IMG_SIZE = 608,
+    // ... and what pass 2 fetches from where it already lies
+    STG_Q = 608,                       //   q[128]                                  <- headout row
+    STG_R = 736,                       //   R[k] = sum_c q[c] W2[c][k]              <- a dense product over all steps (embed_bwd_pool16)
+    STG_X = 864,                       //   unit records [16][12]                   <- obs row
+    STG_SIZE = 1056,
     L_W1 = L_STG + 3 * NS * STG_SIZE,       // W1 as [12 f][128 k]: feature f of rows k4 .. k4 + 3 is one 16-byte read
     L_TOTAL = L_W1 + 128 * 12
 };
@@ -93,10 +97,10 @@ __device__ __forceinline__ void pk_fma_s(f32x2& acc, f32x2 row, float d_uniform)
 
 }  // namespace
 
-// Pass 1: everything pass 2 needs of an (env-step, type), laid out exactly as pass 2's LDS staging block (STG_*), so that
-// pass 2 fetches it with LDS-DMA (global_load_lds, 16 bytes per lane, no registers, no per-thread loader roles): q, the
-// per-channel {d, basic-row offset} pairs, the channel list sorted by arg-max unit, the units' {first, count}, dtu with its
-// sum and the "head is live" flag, the sixteen unit records.  One wave per (step, type); lane l owns channels l and l + 64.
+// Pass 1: what pass 2 needs of an (env-step, type) beyond plain copies, laid out exactly as the head of pass 2's LDS staging
+// block (STG_*), so that pass 2 fetches it with LDS-DMA (global_load_lds, 16 bytes per lane, no registers, no per-thread loader
+// roles): the per-channel {d, basic-row offset} pairs, the channel list sorted by arg-max unit, the units' {first, count},
+// dtu with its sum and the "head is live" flag.  One wave per (step, type); lane l owns channels l and l + 64.
 // The sort - per unit: two ballots, popcounts (count, running first position), v_mbcnt ranks - keeps ascending channel
 // order inside a unit, so the sums of pass 2 are deterministic.
 __global__ __launch_bounds__(256) void embed_pool16_prepare_kernel(SparseArgs p) {
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256) void embed_pool16_prepare_kernel(SparseArgs p)
     const long long n = item < p.nr ? item : item - p.nr;
     const int cum = t == 2 ? 6 : 22;                        // first unit of the type inside the 40
     const float* dx = p.dxcat + n * SP_XCAT;
-    float* out = p.prep + (size_t)item * STG_SIZE;
+    float* out = p.prep + (size_t)item * IMG_SIZE;
     float d[2];
     int a[2];
 #pragma unroll
@@ -115,7 +119,6 @@ __global__ __launch_bounds__(256) void embed_pool16_prepare_kernel(SparseArgs p)
         const int c = lane + 64 * h;
         d[h] = t == 2 ? dx[3 * 128 + c] : dx[4 * 128 + c] + dx[6 * 128 + c];   // policy.py:127: enh feeds two slots
         a[h] = p.amax[(n * 3 + (t - 1)) * 128 + c];
-        out[STG_Q + c] = p.q[n * p.ldq + c];
         *reinterpret_cast<float2*>(out + STG_PB + 2 * c) = make_float2(d[h], __int_as_float(a[h] * SP_BLD * 4));
     }
     int pos[2] = {0, 0};
@@ -151,9 +154,6 @@ __global__ __launch_bounds__(256) void embed_pool16_prepare_kernel(SparseArgs p)
         }
         if (lane == 0) { out[STG_DT + 16] = sum; reinterpret_cast<int*>(out)[STG_FLAG] = nz != 0ull; }
     }
-    const float* rec = p.obs + n * SP_OBS + 3 + cum * 12;        // the type's sixteen records [16][12]
-#pragma unroll
-    for (int j = 0; j < 3; ++j) out[STG_X + lane + 64 * j] = rec[lane + 64 * j];
 }
 
 // Pass 2.  Workgroup = one type x a contiguous range of env-steps, split into two streams that advance one step per
@@ -181,7 +181,9 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
     const int wgi = blockIdx.x % p.wg_per_type;
     const long long n0 = (long long)wgi * p.steps_per_wg;
     const long long n1 = min(p.nr, n0 + p.steps_per_wg);
-    const float* prep_t = p.prep + (size_t)(t - 2) * p.nr * STG_SIZE;
+    const int cum = t == 2 ? 6 : 22;                        // first unit of the type inside the 40
+    const float* prep_t = p.prep + (size_t)(t - 2) * p.nr * IMG_SIZE;
+    const float* rbuf_t = p.rbuf + (size_t)(t - 2) * p.nr * 128;
 
     // ---- stationary operands ---------------------------------------------------------------------------
     {
@@ -210,19 +212,29 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
     const long long half = (n1 - n0 + 1) / 2;
     const long long nb[NS] = {n0, n0 + half}, ne[NS] = {min(n1, n0 + half), n1};
     const long long iters = half;
-    // ---- staging: the block of (stream, iteration) goes global -> LDS by DMA, 1 KB per wave (+ the 192-byte tail):
-    // waves 0..3 stream 0, waves 4..7 stream 1.  Issued behind the barrier of iteration i for iteration i + 2, awaited
-    // (s_waitcnt vmcnt(0): the kernel's only vector-memory traffic) before the barrier of iteration i + 1.
+    // ---- staging: the block of (stream, iteration) goes global -> LDS by DMA, eight pieces per stream, wave w issues piece w of
+    // both streams: 0..2 pass 1's image (2432 bytes), 3 q, 4 R (512 bytes each), 5..7 the unit records (768 bytes at a 4-byte
+    // aligned address: dword pieces).  Issued behind the barrier of iteration i for iteration i + 2, awaited (s_waitcnt
+    // vmcnt(0): the kernel's only vector-memory traffic) before the barrier of iteration i + 1.
     auto stg_of = [&](long long i, int s2) { return smem + L_STG + ((int)(i % 3) * NS + s2) * STG_SIZE; };
     auto dma_issue = [&](long long i) {
-        const int s2 = w >> 2, part = w & 3;
-        const long long n = nb[s2] + i;
-        if (n >= ne[s2]) return;                               // wave-uniform
-        const float* src = prep_t + (size_t)n * STG_SIZE;
-        float* dst = stg_of(i, s2);
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + part * 256 + lane * 4), (lptr_t)(dst + part * 256), 16, 0, 0);
-        if (part == 0 && 4096 + lane * 16 < STG_SIZE * 4)        // the tail behind the four full kilobytes
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + 1024 + lane * 4), (lptr_t)(dst + 1024), 16, 0, 0);
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) {
+            const long long n = nb[s2] + i;
+            if (n >= ne[s2]) continue;                             // workgroup-uniform
+            float* dst = stg_of(i, s2);
+            if (w < 3) {
+                if (w * 1024 + lane * 16 < IMG_SIZE * 4)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(prep_t + (size_t)n * IMG_SIZE + w * 256 + lane * 4), (lptr_t)(dst + w * 256), 16, 0, 0);
+            } else if (w == 3) {
+                if (lane < 32) __builtin_amdgcn_global_load_lds((gptr_t)(p.q + (size_t)n * p.ldq + lane * 4), (lptr_t)(dst + STG_Q), 16, 0, 0);
+            } else if (w == 4) {
+                if (lane < 32) __builtin_amdgcn_global_load_lds((gptr_t)(rbuf_t + (size_t)n * 128 + lane * 4), (lptr_t)(dst + STG_R), 16, 0, 0);
+            } else {
+                __builtin_amdgcn_global_load_lds((gptr_t)(p.obs + (size_t)n * SP_OBS + 3 + cum * 12 + (w - 5) * 64 + lane),
+                                                 (lptr_t)(dst + STG_X + (w - 5) * 64), 4, 0, 0);
+            }
+        }
     };
     auto bas_of = [&](long long i, int s2) { return smem + L_BAS + ((int)(i & 1) * NS + s2) * 16 * SP_BLD; };
     // the twelve record floats of this half-wave's unit (two distinct addresses per wave: broadcast reads)
@@ -450,12 +462,13 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
 }
 
 // slab: 2 * wg_per_type x [128][128]; part1: 2 * wg_per_type x [13][128]; part2: 2 * wg_per_type x [128];
-// prep: 2 * nr * 1072 floats of scratch for the prepared staging blocks
+// prep: 2 * nr * 736 floats of scratch for the prepared staging blocks
 int embed_bwd_pool16(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq,
                      const float* W1, const float* b1, const float* W2, float* slab, float* part1, float* part2, float* prep,
                      long long nr, int wg_per_type, hipStream_t s) {
+    float* rbuf = prep + (size_t)2 * nr * IMG_SIZE;
     SparseArgs a{obs, dxcat, amax, dtu, q, ldq, W1, b1, W2, slab, part1, part2, nr, wg_per_type,
-                 (int)((nr + wg_per_type - 1) / wg_per_type), nullptr, prep};
+                 (int)((nr + wg_per_type - 1) / wg_per_type), nullptr, prep, rbuf};
     const size_t lds = (size_t)L_TOTAL * sizeof(float);
     static bool attr = false;
     if (!attr) {
@@ -466,10 +479,11 @@ int embed_bwd_pool16(const float* obs, const float* dxcat, const uint8_t* amax, 
     }
     hipLaunchKernelGGL(embed_pool16_prepare_kernel, dim3((unsigned)((2 * nr + 3) / 4)), dim3(256), 0, s, a);
     if (int e = launch_check("embed_pool16_prepare")) return e;
-    // R[n][k] = sum_c q[n][c] W2_t[c][k] of every step, straight into the R section of the staging images (row stride STG_SIZE)
+    // R[n][k] = sum_c q[n][c] W2_t[c][k] of every step and type: 2 x 2 GFLOP on the matrix cores instead of 128 x 128 MACs
+    // per live step on the vector unit
     for (int t = 2; t < 4; ++t)
-        if (int e = gemm_f32(q, W2 + (size_t)t * 128 * 128, prep + (size_t)(t - 2) * nr * STG_SIZE + STG_R, (int)nr, 128, 128, ldq, 128,
-                             STG_SIZE, 0, 1, nullptr, 0, nullptr, 0, 0, 1, s))
+        if (int e = gemm_f32(q, W2 + (size_t)t * 128 * 128, rbuf + (size_t)(t - 2) * nr * 128, (int)nr, 128, 128, ldq, 128, 128, 0, 1,
+                             nullptr, 0, nullptr, 0, 0, 1, s))
             return e;
     // algorithmic work: basic + dW1 fold 2 x 16 x 128 x 12 MACs, the two gathers 2 x 128 x 128 MACs per step and type
     ProfScope prof("embed_bwd_pool16", 2.0 * 2.0 * nr * (2.0 * 16 * 128 * 12 + 2.0 * 128 * 128),

@@ -104,7 +104,7 @@ bool embed_fused_supported(long long nr_padded);
 int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const float* W2, const uint16_t* W2p, const float* b2, float* emb,
                     float* xcat, uint8_t* amax, long long nr_valid, long long nr_padded, hipStream_t s);
 // inputs of the sparse max-pool backward of the two 16-unit types (embed_sparse.hip); db2 [6][128] is accumulated into
-// (prep: 2 * nr * 1072 floats of scratch - it lives in the d(emb) rows of the two types, which the sparse path never writes)
+// (prep: 2 * nr * 736 floats of scratch - it lives in the d(emb) rows of the two types, which the sparse path never writes)
 struct EmbSparseIn { const float* dxcat; const uint8_t* amax; const float* dtu; const float* q; int ldq; float* db2; float* prep; };
 int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const float* b1, const float* W2, float* dW2,
                     float* dW1, float* db1, float* scratch, long long scratch_floats, long long nr_valid, long long nr_padded,

@@ -369,7 +369,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         // dW2 (split-K with the first layer regenerated as B operand) and dW1/db1 (d(basic) kept in the
         // accumulators) - neither `basic` nor d(basic) exists in HBM on this path
         // the prepared staging blocks of the sparse path live in the d(emb) rows of the two 16-unit types (2 * 16 * 128 floats per
-        // step, never written on that path; the prepared blocks take 2 * 1072)
+        // step, never written on that path; the prepared blocks take 2 * 736)
         const EmbSparseIn sp{w.f(DC_WS_DXCAT), amaxp, w.f(DC_WS_DTU), w.f(DC_WS_HEADOUT), HO_LD, Gd.p(DC_P_UNIT_B),
                              w.f(DC_WS_DEMB) + (size_t)NRp * T_CUM[2] * EMBW};
         DC_TRY(embed_bwd_fused(obs, w.f(DC_WS_DEMB), P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), P.p(DC_P_UNIT_W), Gd.p(DC_P_UNIT_W),
