@@ -13,6 +13,9 @@ struct RnnStepArgs {
     void* xbuf;            // DC_WS_TEAM_XBUF: exchange ring of the H = 256 team kernels (caller workspace)
     // forward
     const float* Whh;      // [G*H][H]
+    const uint16_t* Whh_bf;   // bf16 mode: W_hh as bf16 [G*H][H] (nullptr: not provided)
+    const uint16_t* WhhT_bf;  // bf16 mode: W_hh^T as bf16 [H][G*H]
+    uint16_t* stepbf;         // bf16 mode: [2][n_seq][G*H] bf16, step-major copies of h_t (forward) / the gate gradients (backward)
     const float* bhh;      // [G*H]
     float* gates;          // [rows][G*H] in: W_ih x + b_ih, out: activated gates
     float* hn;             // [rows][H]   GRU: W_hn h + b_hn
@@ -145,6 +148,10 @@ int lstm_backward_valu(RnnStepArgs a, hipStream_t s);
 // rnn_team.hip (GRU / LSTM with H = 256: all time steps in one launch, a sequence's W_hh spread over the registers
 // of four workgroups that exchange the state every step)
 bool rnn_team_supported(int cell, int H, int n_seq, int flags);
+// rnn_step_bf16.hip: LSTM recurrence steps on the bf16 MFMA (DC_DIMS_BF16, H = 512 / 1024)
+bool lstm_step_bf16_supported(int cell, int H, int flags, const void* Wb);
+int lstm_forward_steps_bf16(RnnStepArgs a, int max_len, hipStream_t s);
+int lstm_backward_steps_bf16(RnnStepArgs a, int max_len, hipStream_t s);
 long long rnn_team_xbuf_bytes();   // size of DC_WS_TEAM_XBUF
 // rnn_team_mfma.hip (LSTM-256, more than 128 sequences: a team advances four sequences together on the 4x4x1 MFMA)
 bool lstm_team_mfma_supported(int cell, int H, int n_seq, int flags);

@@ -41,12 +41,12 @@ static inline int64_t emb_rows(const dc_dims* d) { return embed_fused_on(d) ? (d
 static inline int64_t wplane_elems(const dc_dims* d) {
     const int64_t H = d->hidden, G = d->cell == 0 ? 3 : 4;
     int64_t e = (int64_t)PREW * XCATW + (int64_t)HO_LD * H + (int64_t)6 * EMBW * EMBW;   // + the six unit-type matrices
-    for (int l = 0; l < d->layers; ++l) e += G * H * (l == 0 ? PREW : H);
+    for (int l = 0; l < d->layers; ++l) e += G * H * (l == 0 ? PREW : H) + G * H * H;   // W_ih and W_hh (bf16 recurrence steps)
     return e;
 }
 struct WPlanes {              // where each matrix's planes start inside DC_WS_WPLANES (element offsets per plane set)
     uint16_t* base;           // forward orientation at base, transposed orientation at base + 3 * total
-    int64_t total, pre, heads, unit, ih[DC_MAX_LAYERS];
+    int64_t total, pre, heads, unit, ih[DC_MAX_LAYERS], hh[DC_MAX_LAYERS];
     uint16_t* fwd(int64_t off) const { return base + 3 * off; }                  // planes of one matrix are contiguous: [3][rows][cols]
     uint16_t* bwd(int64_t off) const { return base + 3 * total + 3 * off; }
 };
@@ -60,6 +60,7 @@ static WPlanes wplanes_of(const dc_dims* d, char* ws_base, const int64_t* off) {
     w.heads = o; o += (int64_t)HO_LD * H;
     w.unit = o; o += (int64_t)6 * EMBW * EMBW;
     for (int l = 0; l < d->layers; ++l) { w.ih[l] = o; o += G * H * (l == 0 ? PREW : H); }
+    for (int l = 0; l < d->layers; ++l) { w.hh[l] = o; o += G * H * H; }
     return w;
 }
 
@@ -183,6 +184,14 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
         }
         DC_TRY(split_weight_planes(jobs, nj, prec, s));
     }
+    // W_hh as bf16 for the recurrence steps; their step-major bf16 state copies (2 x n_seq x 4H) live in the layer's `hn` buffer
+    // (rows x H floats, GRU only)
+    const bool hh_bf = lstm_step_bf16_supported(d->cell, H, d->flags, wp.base) && 4 * (long long)B <= NR;
+    if (hh_bf) {
+        X3SplitJob jobs[DC_MAX_LAYERS];
+        for (int l = 0; l < d->layers; ++l) jobs[l] = X3SplitJob{P.p(DC_P_RNN0 + 4 * l + 1), wp.fwd(wp.hh[l]), G * H, H, H, 0, G * H};
+        DC_TRY(split_weight_planes(jobs, d->layers, 1, s));
+    }
     // y[rows][N] = x[rows][K] W[N][K]^T + b, through the split-on-load kernel (or the round-1 kernel)
     auto linear = [&](const float* x, int K, const float* W, const uint16_t* Wp, int N, int Npad, const float* bias, int relu, float* y,
                       int ldy) -> int {
@@ -207,6 +216,8 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
         a.seq_off = seq_off; a.seq_len = seq_len; a.n_seq = B; a.H = H;
         a.flags = d->flags; a.xbuf = w.base + w.off[DC_WS_TEAM_XBUF];
         a.Whh = P.p(pb + 1); a.bhh = P.p(pb + 3);
+        a.Whh_bf = hh_bf ? wp.fwd(wp.hh[l]) : nullptr;
+        a.stepbf = reinterpret_cast<uint16_t*>(w.fl(l, DC_WSL_HN));
         a.gates = w.fl(l, DC_WSL_GATES); a.hn = w.fl(l, DC_WSL_HN); a.hseq = w.fl(l, DC_WSL_HSEQ);
         a.hprev = w.fl(l, DC_WSL_HPREV); a.cseq = w.fl(l, DC_WSL_CSEQ); a.cprev = w.fl(l, DC_WSL_CPREV);
         DC_TRY(rnn_forward_layer(d->cell, a, d->max_len, s));
@@ -292,6 +303,12 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         }
         DC_TRY(split_weight_planes(jobs, nj, prec, s));
     }
+    const bool hh_bf = lstm_step_bf16_supported(d->cell, H, d->flags, wp.base) && 4 * (long long)B <= NR;     // W_hh^T as bf16 for the recurrence steps
+    if (hh_bf) {
+        X3SplitJob jobs[DC_MAX_LAYERS];
+        for (int l = 0; l < L; ++l) jobs[l] = X3SplitJob{P.p(DC_P_RNN0 + 4 * l + 1), wp.bwd(wp.hh[l]), G * H, H, H, 1, G * H};   // -> [H][G*H]
+        DC_TRY(split_weight_planes(jobs, L, 1, s));
+    }
     // heads (policy.py:144-155)
     DC_TRY(attn_bwd_q(w.f(DC_WS_DTU), w.f(DC_WS_EMB), w.f(DC_WS_DHEADOUT), NR, emb_rows(d), s));
     // dH = dheadout[:, 0:160] * [W_heads; 0]: K padded to 160 (dheadout's pad columns are zeroed by the loss kernel)
@@ -307,12 +324,14 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     // recurrent core, top layer first
     for (int l = TOP; l >= 0; --l) {
         const int pb = DC_P_RNN0 + 4 * l;
-        if (!rnn_uses_persistent(d->cell, H, d->flags)) DC_TRY(transpose(P.p(pb + 1), w.f(DC_WS_WHHT), G * H, H, s));
+        if (!rnn_uses_persistent(d->cell, H, d->flags) && !hh_bf) DC_TRY(transpose(P.p(pb + 1), w.f(DC_WS_WHHT), G * H, H, s));
         RnnStepArgs a{};
         a.seq_off = seq_off; a.seq_len = seq_len; a.n_seq = B; a.H = H;
         a.flags = d->flags; a.xbuf = w.base + w.off[DC_WS_TEAM_XBUF];
         a.gates = w.fl(l, DC_WSL_GATES); a.hn = w.fl(l, DC_WSL_HN); a.hseq = w.fl(l, DC_WSL_HSEQ);
         a.hprev = w.fl(l, DC_WSL_HPREV); a.cseq = w.fl(l, DC_WSL_CSEQ); a.cprev = w.fl(l, DC_WSL_CPREV);
+        a.WhhT_bf = hh_bf ? wp.bwd(wp.hh[l]) : nullptr;
+        a.stepbf = reinterpret_cast<uint16_t*>(w.fl(l, DC_WSL_HN));
         a.Whh = P.p(pb + 1); a.WhhT = w.f(DC_WS_WHHT); a.dh = w.fl(l, DC_WSL_DH); a.dc = w.fl(l, DC_WSL_DC);
         a.dgx = w.fl(l, DC_WSL_DGX);
         a.dgh = d->cell == 0 ? w.fl(l, DC_WSL_DGH) : w.fl(l, DC_WSL_DGX);

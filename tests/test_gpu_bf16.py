@@ -2,8 +2,9 @@
 
 DC_DIMS_BF16 rounds the operands of the dense products - affine_pre_rnn, the recurrent cell's input projections, the head
 projections and all their gradient products (policy.py:138-155 and autograd's products for them) - to bf16 (8 mantissa bits),
-one v_mfma_f32_32x32x16_bf16 per K = 16 with f32 accumulation; the unit embeddings, the recurrence itself, the loss, the
-norms and Adam stay f32.  There is no bf16 reference ("compared to this fp32 oracle with a looser,
+one v_mfma_f32_32x32x16_bf16 per K = 16 with f32 accumulation; at H = 512 (no register-resident recurrent kernel) the
+recurrent products W_hh h and their BPTT counterparts too (csrc/rnn_step_bf16.hip: bf16 operands, f32 accumulate, f32 state
+and gate maths); the unit embeddings, the H <= 256 recurrences, the loss, the norms and Adam stay f32.  There is no bf16 reference ("compared to this fp32 oracle with a looser,
 separately-stated tolerance"), so the tolerances below ARE the statement:
 
   quantity (one epoch from the same weights, oracle fp32)          tolerance      why
