@@ -242,6 +242,7 @@ BOUND_NOTES = {
 }
 KERNEL_FLAGS = 0      # --kernel-flags: DC_DIMS_* kernel-selection overrides for A/B runs (include/dotaclient_hip.h)
 USE_GRAPHS = False    # --epoch-graph: replay every epoch as one hipGraph launch (Engine.train_epoch(graph=True))
+REUSE_FORWARD = False  # side measurement only: Engine.reuse_rollout_forward
 MASK_DEPENDENT_BYTES = ('attn_logits', 'attn_bwd_q')   # mask-aware: bytes moved depend on the masks; the host-side figure is the dense form
 
 
@@ -252,6 +253,7 @@ def run_workload(cell, hidden, layers, B, S, E, steps, warmup, dev, rank, world,
     eng = Engine(cell, hidden, layers, dev)
     eng.kernel_flags = KERNEL_FLAGS
     eng.use_graphs = USE_GRAPHS
+    eng.reuse_rollout_forward = REUSE_FORWARD
     eng.load_state_dict(synth.init_state_dict(7, cell, hidden, layers))
     hook = hook_factory(eng) if hook_factory is not None else None
     if hook is not None:
@@ -334,7 +336,7 @@ def main():
                     help='per-kernel HBM bytes from the rocprofv3 PMC passes (tools/gpu_round.sh + tools/pmc_traffic.py); '
                          'PMC counters cannot be read from inside the process, so `traffic` is taken from this file')
     args = ap.parse_args()
-    global KERNEL_FLAGS, USE_GRAPHS
+    global KERNEL_FLAGS, USE_GRAPHS, REUSE_FORWARD
     KERNEL_FLAGS = args.kernel_flags
     USE_GRAPHS = args.epoch_graph == 1
 
@@ -419,6 +421,17 @@ def main():
                        'timed_line_uses': 'eager',
                        'note': 'Engine.train_epoch(graph=True): the ~45 launches / memsets / copies of an epoch captured once and replayed as '
                                'ONE hipGraph launch (the rollout pass stays eager); same kernels, same order'}
+        del r
+        torch.cuda.empty_cache()
+        # ... and with the first epoch's forward taken from the rollout pass (same weights, same inputs: Engine.reuse_rollout_forward).
+        # NOT the timed line: `value` counts the reference's five forward passes per step.
+        REUSE_FORWARD = True
+        r = run_workload(args.cell, args.hidden, args.layers, B, S, E, args.steps, args.warmup, dev, rank, world)
+        REUSE_FORWARD = False
+        epoch_graph['first_epoch_reuses_rollout_forward_ms_per_step'] = round(r['elapsed'] / args.steps * 1e3, 3)
+        epoch_graph['first_epoch_reuse_note'] = ('opt-in Engine.reuse_rollout_forward: epoch 0 runs on the weights the rollout pass has just used '
+                                                 '(optimizer.py:328-430 then :581-689), so its forward is skipped and the rollout pass\'s activations '
+                                                 'are back-propagated; four forward passes per step instead of five, results equal (tests/test_gpu_parity.py)')
         del r
         torch.cuda.empty_cache()
 

@@ -386,3 +386,27 @@ def test_two_engines_on_two_streams_from_two_threads():
         assert np.all(np.isfinite(par[i][0]))
         assert util.scaled_err(par[i][0], seq[i][0]) < 1e-5, i
         assert util.scaled_err(par[i][1], seq[i][1]) < 1e-3, i        # Adam turns last-bit gradient differences (f64 atomics in the norm) into steps of order lr
+
+
+@pytest.mark.parametrize('cell,hidden,lens,S', [('lstm', 256, [64] * 8, 64), ('lstm', 128, [50, 64, 33, 16], 16), ('gru', 256, [40, 33], 16)])
+def test_first_epoch_can_reuse_the_rollout_pass_forward(cell, hidden, lens, S):
+    # Engine.reuse_rollout_forward: epoch 0 runs on the weights the rollout pass has just used, so its forward is the same
+    # function of the same inputs (optimizer.py:328-430 then :581-689); skipping it must not change any result beyond the
+    # kernels' summation orders (rollout-shaped vs chunk-shaped launches).  Later epochs (new weights) must recompute.
+    from dotaclient_amd.engine import Engine, pack_rollouts
+    dev = torch.device('cuda:0')
+    outs = {}
+    for reuse in (False, True):
+        eng = Engine(cell, hidden, 1, dev)
+        eng.reuse_rollout_forward = reuse
+        eng.load_state_dict(synth.init_state_dict(7, cell, hidden, 1))
+        batch = pack_rollouts(synth.make_rollouts(321, lens), S, dev)
+        chunks = eng.rollout_pass(batch, S)
+        res = []
+        for _ in range(3):
+            out, status = eng.train_epoch(chunks, 3e-4, 5e-4, 0.5)
+            assert int(status.item()) == 0
+            res.append(out.cpu().numpy().copy())
+        outs[reuse] = (np.stack(res), eng.params.cpu().numpy().copy(), eng.grads.cpu().numpy().copy())
+    for a, b in zip(outs[True], outs[False]):
+        assert util.scaled_err(a, b) < 2e-5, util.scaled_err(a, b)
