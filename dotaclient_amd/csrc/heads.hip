@@ -102,10 +102,18 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
         const float mine = lane < NUNITS ? dt[lane] : 0.f;
         unsigned long long bits = __ballot(mine != 0.f);        // the same in both waves of the step
         float acc = 0.f;
-        while (bits) {
-            const int u = __builtin_ctzll(bits);
-            bits &= bits - 1;
-            acc = fmaf(dt[u], emb[unit_row(nrp, n, u) * EMBW + c], acc);
+        while (bits) {      // four units per trip: their rows are in flight together (the loop is a chain of memory round trips)
+            int u[4];
+            float w[4], e[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u[i] = bits ? __builtin_ctzll(bits) : -1;         // wave-uniform
+                bits &= bits - 1;
+                w[i] = u[i] >= 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), u[i] < 0 ? 0 : u[i])) : 0.f;
+                e[i] = u[i] >= 0 ? emb[unit_row(nrp, n, u[i]) * EMBW + c] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = fmaf(w[i], e[i], acc);   // ascending unit order, as before
         }
         dheadout[n * HO_LD + c] = acc;
     }

@@ -143,6 +143,11 @@ class DotaOptimizer:
         self.learning_rate, self.checkpoint = learning_rate, checkpoint
         self.mq_prefetch_count, self.log_dir = mq_prefetch_count, log_dir
         self.entropy_coef, self.vf_coef, self.run_local = entropy_coef, vf_coef, run_local
+        if not run_local:
+            # optimizer.py:231-266,697-723 with run_local=False resumes from / uploads to a GCS bucket: storage plumbing outside the
+            # hot path, not re-implemented - fail loudly instead of silently starting from scratch
+            raise ValueError('run_local=False (GCS checkpoint resume / upload) is outside this package: keep the reference\'s own '
+                             'checkpoint code around DotaOptimizer, or pass run_local=True')
         self.iteration_start = 1
         self.iterations = 100000
         self.model_upload_freq = 10
