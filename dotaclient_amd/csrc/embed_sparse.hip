@@ -13,16 +13,19 @@
 // they run on the packed-f32 VALU with W2_t stationary in LDS; d(emb) of these types is never written to or
 // read from HBM (2 x 268 MB per pass at the bench batch), and d(basic) exists only in registers.
 //
-// Two passes: embed_pool16_prepare_kernel sorts every step's channels by arg-max unit (wave ballots; ascending
-// channel inside a unit: deterministic sums); embed_bwd_pool16_kernel (one workgroup = one type x a contiguous range of
-// env-steps) keeps its accumulators in registers for the whole range.  Two lane <-> data maps, each where it saves
-// instructions: the dW2 update runs CHANNEL-per-lane (lane l owns channels l and l + 64, wave w the k range
+// Two passes: embed_pool16_prepare_kernel sorts every step's channels by arg-max unit (wave ballots; ascending channel inside
+// a unit: deterministic sums) and leaves the result as an image of the head of pass 2's LDS staging block;
+// embed_bwd_pool16_kernel (one workgroup = one type x a contiguous range of env-steps, two steps in flight) keeps its
+// accumulators in registers for the whole range and fetches everything per step by LDS-DMA.  Two lane <-> data maps, each
+// where it saves instructions: the dW2 update runs CHANNEL-per-lane (lane l owns channels l and l + 64, wave w the k range
 // [16w, 16w + 16): the scale d[c] and the source row a(c) are lane-local - no broadcast, one 8-byte read for both - and a
-// lane gathers its 64 bytes of basic[a(c)] with four ds_read_b128, rows 528 bytes apart so that sixteen different rows
-// at one column never share a bank); d(basic) runs K-per-lane (wave w owns units w, w + 8, lane l the k pair 2l, 2l + 1:
-// the rows of W2 a unit sums over are wave-uniform and read as 512 contiguous bytes).  Steps with a live target-unit head additionally need R[k] = sum_c q[c] W2[c][k] and
-// s[k] = sum_u dtu[u] basic[u][k] for the rank-one terms: R is a dense product over all steps (q W2_t, 2 x 2 GFLOP on the
-// matrix cores, written straight into the staging image), s a sixteen-lane DPP sum per wave - no workgroup reduction.
+// lane gathers its 64 bytes of basic[a(c)] with four ds_read_b128, rows 528 bytes apart so that sixteen different rows at
+// one column never share a bank); the first layer, d(basic) and the dW1 fold run UNIT-per-half-wave (wave w, lanes 0..31:
+// unit w, lanes 32..63: unit w + 8; lane l of a half owns k = 4l .. 4l + 3: a row of W2 is read by a half as 512 contiguous
+// bytes with one ds_read_b128 per lane, the two units of a wave advance in the same instructions, every FMA is packed).
+// Steps with a live target-unit head additionally need R[k] = sum_c q[c] W2[c][k] and s[k] = sum_u dtu[u] basic[u][k] for
+// the rank-one terms: R is a dense product over all steps (q W2_t, 2 x 2 GFLOP on the matrix cores, fetched like q), s a
+// sixteen-lane DPP sum per wave - no workgroup reduction.
 // Outputs are per-workgroup partials in the formats the dense path already reduces:
 //   slab[wg][128][128] (splitk_reduce_grouped), part1[wg][13][128] (unit_basic_reduce), part2[wg][128] (colsum).
 #include <stdio.h>
