@@ -410,3 +410,34 @@ def test_first_epoch_can_reuse_the_rollout_pass_forward(cell, hidden, lens, S):
         outs[reuse] = (np.stack(res), eng.params.cpu().numpy().copy(), eng.grads.cpu().numpy().copy())
     for a, b in zip(outs[True], outs[False]):
         assert util.scaled_err(a, b) < 2e-5, util.scaled_err(a, b)
+
+
+def test_sparse_pool_backward_with_one_unit_taking_every_channel():
+    # Degenerate arg-max patterns for embed_sparse.hip: steps whose sixteen non-hero units are IDENTICAL (ties: the first unit
+    # wins all 128 channels, torch.max's rule - the kernel's per-unit channel list is 128 long, far beyond its twelve
+    # straight-line slots), steps where two units share them, and ordinary steps, mixed in one batch; against the dense kernels.
+    from dotaclient_amd import engine as E
+    from dotaclient_amd.engine import Engine, pack_rollouts
+    from dotaclient_amd import layout as L
+    dev = torch.device('cuda:0')
+    rollouts = synth.make_rollouts(55, [128, 128, 128])
+    for ri, data in enumerate(rollouts):
+        for key in ('allied_nonheroes', 'enemy_nonheroes'):
+            if key not in data['observations']:
+                continue
+            x = np.asarray(data['observations'][key]).copy()          # [T, 16, 12]
+            x[ri::4] = x[ri::4, :1]                                    # every fourth step: sixteen copies of unit 0
+            x[(ri + 2) % 4::8, 1::2] = x[(ri + 2) % 4::8, 1:2]        # and some steps with eight copies of unit 1 among the others
+            data['observations'][key] = x
+    outs = {}
+    for mode in ('dense', 'sparse'):
+        eng = Engine('lstm', 128, 1, dev)
+        eng.kernel_flags = E.DC_DIMS_DENSE_POOL_BWD if mode == 'dense' else 0
+        eng.load_state_dict(synth.init_state_dict(7, 'lstm', 128, 1))
+        batch = pack_rollouts(rollouts, 128, dev)
+        chunks = eng.rollout_pass(batch, 128)
+        res, status = eng.train_epoch(chunks, 5e-5, 5e-4, 0.5)
+        assert int(status.item()) == 0
+        outs[mode] = (eng.grads.cpu().numpy().copy(), res.cpu().numpy().copy())
+    assert util.scaled_err(outs['sparse'][0], outs['dense'][0]) < 2e-5
+    assert util.scaled_err(outs['sparse'][1][:11], outs['dense'][1][:11]) < 2e-5
