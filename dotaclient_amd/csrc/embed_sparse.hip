@@ -50,7 +50,6 @@ struct SparseArgs {
     long long nr; int wg_per_type; int steps_per_wg;
     long long* dbg;
     float* prep;      // [2][nr][IMG_SIZE]: pass 1's image of the head of pass 2's staging block per (type, step)
-    const float* rbuf; // [2][nr][128]: R of every (type, step)
 };
 
 // LDS carve-up (floats).  A workgroup runs NS = 2 independent step streams in lock step (one barrier per iteration):
@@ -68,14 +67,15 @@ enum {
     STG_SC = 544,                      //   per unit {first list entry, number of channels}          [16] x 8 B
     STG_DT = 576,                      //   dtu[16], [16] = their sum
     STG_FLAG = 600,                    //   1 if any dtu != 0
-    IMG_SIZE = 608,
+    STG_R = 608,                       //   R[k] = sum_c q[c] W2[c][k]: written into the image by a dense product over all steps (embed_bwd_pool16)
+    IMG_SIZE = 736,
     // ... and what pass 2 fetches from where it already lies
-    STG_Q = 608,                       //   q[128]                                  <- headout row
-    STG_R = 736,                       //   R[k] = sum_c q[c] W2[c][k]              <- a dense product over all steps (embed_bwd_pool16)
-    STG_X = 864,                       //   unit records [16][12]                   <- obs row
-    STG_SIZE = 1056,
-    L_W1 = L_STG + 3 * NS * STG_SIZE,       // W1 as [12 f][128 k]: feature f of rows k4 .. k4 + 3 is one 16-byte read
-    L_TOTAL = L_W1 + 128 * 12
+    STG_Q = 736,                       //   q[128]                                  <- headout row
+    STG_X = 864,                       //   unit records [16][12], behind 0..3 floats of slack <- obs row, fetched from its 16-byte aligned floor
+    STG_SIZE = 1060,
+    L_T = L_STG + 3 * NS * STG_SIZE,        // per wave [4 (stream, unit) rows][T_LD]: relu-masked d(basic), re-read as an MFMA operand
+    T_LD = 144,                             //   (rows 16 banks apart: the two rows a 32-lane group reads never share a bank)
+    L_TOTAL = L_T + 8 * 4 * T_LD
 };
 enum { SP_SLOTS = 12 };   // channels of a unit handled in straight-line code (a unit holds 8 on average); the rest in a loop
 
@@ -186,92 +186,81 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
     const long long n1 = min(p.nr, n0 + p.steps_per_wg);
     const int cum = t == 2 ? 6 : 22;                        // first unit of the type inside the 40
     const float* prep_t = p.prep + (size_t)(t - 2) * p.nr * IMG_SIZE;
-    const float* rbuf_t = p.rbuf + (size_t)(t - 2) * p.nr * 128;
 
     // ---- stationary operands ---------------------------------------------------------------------------
     {
         const float4* src = reinterpret_cast<const float4*>(p.W2 + (size_t)t * 128 * 128);
         for (int e = tid; e < 128 * 32; e += SP_THREADS) *reinterpret_cast<float4*>(smem + L_W2 + 4 * e) = src[e];
     }
-    for (int e = tid; e < 128 * 12; e += SP_THREADS) {       // W1[k][f] -> [f][k >> 2][k & 3]
-        const int k = e / 12, f = e - 12 * k;
-        smem[L_W1 + f * 128 + k] = p.W1[e];
-    }
-    const float4 b1r = *reinterpret_cast<const float4*>(p.b1 + k4);
+    // The first layer (12 -> 128, phase A) and the dW1 / db1 fold (phase D) run as 16 x 16 x 4 f32 MFMA products on the otherwise idle
+    // matrix pipe (v_mfma_f32_16x16x4_f32: A[i][q], B[q][n] in lane (i or n = lane & 15, q = lane >> 4); D[4 (lane >> 4) + r][lane & 15]):
+    //   first layer  basic[u][16w + n] = sum_f x[u][f] W1[16w + n][f]: wave w owns the k block 16w .. 16w + 15 of all sixteen units;
+    //                B = W1 (three K = 4 steps) stays in registers for the whole kernel
+    //   dW1 fold     out[f][k] += sum over the wave's four (stream, unit) rows of x[row][f] dbm[row][k], f = 12: ones (db1)
+    // - a fifth of the kernel's instructions and its two longest FMA chains less than the packed-f32 form (measured: 838 -> 795 us).
+    const int mi = lane & 15, mq = lane >> 4;
+    float w1b[3];
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) w1b[kk] = p.W1[(16 * w + mi) * 12 + 4 * kk + mq];
+    const float b1c = p.b1[16 * w + mi];
+    f32x4 accD[8];                 // out[4 mq + r][16 kb + mi]
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) accD[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x2 D[2][8];                 // dW2[c][16w + 2j, 16w + 2j + 1] of channels c = lane (D[0]) and lane + 64 (D[1])
-    f32x2 dW1a[12][2];             // dW1[k4 + 2e, k4 + 2e + 1][f] contributions of this half-wave's unit: [f][e]
-    f32x2 db1a[2];
     float db2a = 0.f;              // threads 0..127: second-layer bias gradient of channel tid
 #pragma unroll
     for (int i = 0; i < 8; ++i) { D[0][i] = mk2(0.f, 0.f); D[1][i] = mk2(0.f, 0.f); }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        db1a[e] = mk2(0.f, 0.f);
-#pragma unroll
-        for (int f = 0; f < 12; ++f) dW1a[f][e] = mk2(0.f, 0.f);
-    }
 
     // ---- two step streams: stream s covers steps [nb[s], ne[s]); iteration i works on step nb[s] + i of both ----------
     const long long half = (n1 - n0 + 1) / 2;
     const long long nb[NS] = {n0, n0 + half}, ne[NS] = {min(n1, n0 + half), n1};
     const long long iters = half;
-    // ---- staging: the block of (stream, iteration) goes global -> LDS by DMA, eight pieces per stream, wave w issues piece w of
-    // both streams: 0..2 pass 1's image (2432 bytes), 3 q, 4 R (512 bytes each), 5..7 the unit records (768 bytes at a 4-byte
-    // aligned address: dword pieces).  Issued behind the barrier of iteration i for iteration i + 2, awaited (s_waitcnt
-    // vmcnt(0): the kernel's only vector-memory traffic) before the barrier of iteration i + 1.
+    // ---- staging: the block of (stream, iteration) goes global -> LDS by DMA, five wave-instructions per stream (the address
+    // path takes 100+ cycles per instruction and all of them are issued at once behind the barrier: with sixteen per iteration the
+    // last wave in line sat 600 cycles per step in the queue - s_memtime per wave, roles swapped to tell): the image incl. R in three
+    // 1 KB pieces, q (512 bytes), the unit records (768 bytes at a 4-byte aligned address) as 49 16-byte lanes from the aligned floor
+    // of their address - consumers add the 0..3 floats of slack.  Issued behind
+    // the barrier of iteration i for iteration i + 2, awaited (s_waitcnt vmcnt(0): the kernel's only vector-memory traffic) before
+    // the barrier of iteration i + 1.
     auto stg_of = [&](long long i, int s2) { return smem + L_STG + ((int)(i % 3) * NS + s2) * STG_SIZE; };
+    auto rec_off = [&](long long n) { return (size_t)n * SP_OBS + 3 + cum * 12; };      // first float of the type's records in obs
     auto dma_issue = [&](long long i) {
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) {
             const long long n = nb[s2] + i;
             if (n >= ne[s2]) continue;                             // workgroup-uniform
             float* dst = stg_of(i, s2);
-            if (w < 3) {
-                if (w * 1024 + lane * 16 < IMG_SIZE * 4)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(prep_t + (size_t)n * IMG_SIZE + w * 256 + lane * 4), (lptr_t)(dst + w * 256), 16, 0, 0);
-            } else if (w == 3) {
+            // this wave's piece of the stream (5..7: none).  q and the records come from buffers last touched a pass ago and take long to
+            // issue; they go to the older waves 0..3 (which win their SIMD's arbitration and have slack at the barrier), the image pieces
+            // (written by pass 1 a moment ago) to waves 4..7
+            const int j = w < 4 ? ((w >> 1) == s2 ? 3 + (w & 1) : 7) : (w < 6 ? w - 4 : (w - 6 == s2 ? 2 : 7));
+            if (j < 3) {
+                if (j * 1024 + lane * 16 < IMG_SIZE * 4)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(prep_t + (size_t)n * IMG_SIZE + j * 256 + lane * 4), (lptr_t)(dst + j * 256), 16, 0, 0);
+            } else if (j == 3) {
                 if (lane < 32) __builtin_amdgcn_global_load_lds((gptr_t)(p.q + (size_t)n * p.ldq + lane * 4), (lptr_t)(dst + STG_Q), 16, 0, 0);
-            } else if (w == 4) {
-                if (lane < 32) __builtin_amdgcn_global_load_lds((gptr_t)(rbuf_t + (size_t)n * 128 + lane * 4), (lptr_t)(dst + STG_R), 16, 0, 0);
-            } else {
-                __builtin_amdgcn_global_load_lds((gptr_t)(p.obs + (size_t)n * SP_OBS + 3 + cum * 12 + (w - 5) * 64 + lane),
-                                                 (lptr_t)(dst + STG_X + (w - 5) * 64), 4, 0, 0);
+            } else if (j == 4) {
+                if (lane < 49) __builtin_amdgcn_global_load_lds((gptr_t)(p.obs + (rec_off(n) & ~(size_t)3) + lane * 4), (lptr_t)(dst + STG_X), 16, 0, 0);
             }
         }
     };
     auto bas_of = [&](long long i, int s2) { return smem + L_BAS + ((int)(i & 1) * NS + s2) * 16 * SP_BLD; };
-    // the twelve record floats of this half-wave's unit (two distinct addresses per wave: broadcast reads)
-    auto load_x = [&](const float* stg, float (&x)[12]) {
-        const float4* xp = reinterpret_cast<const float4*>(stg + STG_X + u_own * 12);
-        const float4 xa = xp[0], xb = xp[1], xc = xp[2];
-        x[0] = xa.x; x[1] = xa.y; x[2] = xa.z; x[3] = xa.w; x[4] = xb.x; x[5] = xb.y; x[6] = xb.z; x[7] = xb.w;
-        x[8] = xc.x; x[9] = xc.y; x[10] = xc.z; x[11] = xc.w;
-    };
     // BOTH (here and in the loop body): both streams have a step in this iteration, known at compile time - no branch splits
     // the two streams' instruction chains into separate blocks, so the scheduler interleaves them (the point of having two)
-    auto phase_a = [&](long long i, auto both_c) {             // basic[u_own][k4 .. k4 + 3] of iteration i's steps
+    auto phase_a = [&](long long i, auto both_c) {             // basic[all units][16w .. 16w + 15] of iteration i's steps
         constexpr bool BOTH = decltype(both_c)::value;
-        // the k-ordered fmaf chain of the MFMA-generated first layer (embed_fused.hip), bias last: bitwise the forward's
-        // value, hence its relu mask
-        f32x2 wl[12], wh[12];
-#pragma unroll
-        for (int f = 0; f < 12; ++f) {
-            const float4 q4 = *reinterpret_cast<const float4*>(smem + L_W1 + f * 128 + k4);
-            wl[f] = mk2(q4.x, q4.y); wh[f] = mk2(q4.z, q4.w);
-        }
+        // (the forward's first layer is an f32 MFMA as well, 32 x 32 x 2: the two may differ in the last bit, i.e. in the relu
+        // mask of pre-activations within an ulp of zero)
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) {
             if (!BOTH && nb[s2] + i >= ne[s2]) continue;
-            float x[12];
-            load_x(stg_of(i, s2), x);
-            f32x2 al = mk2(x[0], x[0]) * wl[0], ah = mk2(x[0], x[0]) * wh[0];
+            const float* xs = stg_of(i, s2) + STG_X + (int)(rec_off(nb[s2] + i) & 3) + mi * 12 + mq;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int f = 1; f < 12; ++f) {
-                al = __builtin_elementwise_fma(mk2(x[f], x[f]), wl[f], al);
-                ah = __builtin_elementwise_fma(mk2(x[f], x[f]), wh[f], ah);
-            }
-            *reinterpret_cast<float4*>(bas_of(i, s2) + u_own * SP_BLD + k4) =
-                make_float4(fmaxf(al.x + b1r.x, 0.f), fmaxf(al.y + b1r.y, 0.f), fmaxf(ah.x + b1r.z, 0.f), fmaxf(ah.y + b1r.w, 0.f));
+            for (int kk = 0; kk < 3; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[4 * kk], w1b[kk], acc, 0, 0, 0);
+            float* bo = bas_of(i, s2) + 4 * mq * SP_BLD + 16 * w + mi;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bo[r * SP_BLD] = fmaxf(acc[r] + b1c, 0.f);
         }
     };
 
@@ -395,20 +384,24 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
             }
         }
         stamp(4);
-        // ---- phase D: through the relu into dW1 / db1; second-layer bias gradient -----------------------
+        // ---- phase D: through the relu into dW1 / db1 (MFMA, above); second-layer bias gradient
+        {
+            float* T = smem + L_T + w * (4 * T_LD);
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2)        // a stream without a step this iteration: db = basic = 0, a row of zeros
+                *reinterpret_cast<float4*>(T + (2 * s2 + hh) * T_LD + k4) =
+                    make_float4(basic[s2].x > 0.f ? dbl[s2].x : 0.f, basic[s2].y > 0.f ? dbl[s2].y : 0.f,
+                                basic[s2].z > 0.f ? dbh[s2].x : 0.f, basic[s2].w > 0.f ? dbh[s2].y : 0.f);
+            // A[f][row mq]: the record of row mq = (stream mq >> 1, unit w + 8 (mq & 1)); f = 12: ones (db1); f > 12: zeros
+            const int sq = mq >> 1;
+            const float* sx = (sq ? stg[1] : stg[0]) + STG_X + (int)(rec_off(nb[sq] + i) & 3);
+            const float xa = mi < 12 ? sx[(w + 8 * (mq & 1)) * 12 + mi] : (mi == 12 ? 1.f : 0.f);
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) accD[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, T[mq * T_LD + 16 * kb + mi], accD[kb], 0, 0, 0);
+        }
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) {
             if (!on[s2]) continue;
-            float x[12];
-            load_x(stg[s2], x);
-            const f32x2 ml = mk2(basic[s2].x > 0.f ? dbl[s2].x : 0.f, basic[s2].y > 0.f ? dbl[s2].y : 0.f);
-            const f32x2 mh = mk2(basic[s2].z > 0.f ? dbh[s2].x : 0.f, basic[s2].w > 0.f ? dbh[s2].y : 0.f);
-#pragma unroll
-            for (int f = 0; f < 12; ++f) {
-                dW1a[f][0] = __builtin_elementwise_fma(ml, mk2(x[f], x[f]), dW1a[f][0]);
-                dW1a[f][1] = __builtin_elementwise_fma(mh, mk2(x[f], x[f]), dW1a[f][1]);
-            }
-            db1a[0] += ml; db1a[1] += mh;
             if (tid < 128) db2a += stg[s2][STG_PB + 2 * tid] + (live[s2] ? stg[s2][STG_Q + tid] * stg[s2][STG_DT + 16] : 0.f);   // column sum of d(emb)
         }
         stamp(5);
@@ -434,7 +427,7 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
                     make_float4(D[h][2 * j].x, D[h][2 * j].y, D[h][2 * j + 1].x, D[h][2 * j + 1].y);
         if (tid < 128) p.part2[(size_t)blockIdx.x * 128 + tid] = db2a;
     }
-    // dW1 / db1: sum the 16 half-waves (= units) in fixed order through LDS -> part1[wg][f][k] (f = 12: db1)
+    // dW1 / db1: sum the 8 waves in fixed order through LDS -> part1[wg][f][k] (f = 12: db1)
     __syncthreads();
     float* acc = smem + L_RED;      // [13][128]
     for (int e = tid; e < 13 * 128; e += SP_THREADS) acc[e] = 0.f;
@@ -442,21 +435,10 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
     for (int ww = 0; ww < 8; ++ww) {
         if (w == ww) {
 #pragma unroll
-            for (int part = 0; part < 2; ++part) {       // lanes 0..31, then lanes 32..63 (same addresses; in-order per wave)
-                if (hh == part) {
+            for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
-                    for (int f = 0; f < 12; ++f) {
-                        float4* a4 = reinterpret_cast<float4*>(acc + f * 128 + k4);
-                        float4 v = *a4;
-                        v.x += dW1a[f][0].x; v.y += dW1a[f][0].y; v.z += dW1a[f][1].x; v.w += dW1a[f][1].y;
-                        *a4 = v;
-                    }
-                    float4* a4 = reinterpret_cast<float4*>(acc + 12 * 128 + k4);
-                    float4 v = *a4;
-                    v.x += db1a[0].x; v.y += db1a[0].y; v.z += db1a[1].x; v.w += db1a[1].y;
-                    *a4 = v;
-                }
-            }
+                for (int r = 0; r < 4; ++r)
+                    if (4 * mq + r < 13) acc[(4 * mq + r) * 128 + 16 * kb + mi] += accD[kb][r];
         }
         __syncthreads();
     }
@@ -469,9 +451,8 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
 int embed_bwd_pool16(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq,
                      const float* W1, const float* b1, const float* W2, float* slab, float* part1, float* part2, float* prep,
                      long long nr, int wg_per_type, hipStream_t s) {
-    float* rbuf = prep + (size_t)2 * nr * IMG_SIZE;
     SparseArgs a{obs, dxcat, amax, dtu, q, ldq, W1, b1, W2, slab, part1, part2, nr, wg_per_type,
-                 (int)((nr + wg_per_type - 1) / wg_per_type), nullptr, prep, rbuf};
+                 (int)((nr + wg_per_type - 1) / wg_per_type), nullptr, prep};
     const size_t lds = (size_t)L_TOTAL * sizeof(float);
     static bool attr = false;
     if (!attr) {
@@ -482,11 +463,11 @@ int embed_bwd_pool16(const float* obs, const float* dxcat, const uint8_t* amax, 
     }
     hipLaunchKernelGGL(embed_pool16_prepare_kernel, dim3((unsigned)((2 * nr + 3) / 4)), dim3(256), 0, s, a);
     if (int e = launch_check("embed_pool16_prepare")) return e;
-    // R[n][k] = sum_c q[n][c] W2_t[c][k] of every step and type: 2 x 2 GFLOP on the matrix cores instead of 128 x 128 MACs
-    // per live step on the vector unit
+    // R[n][k] = sum_c q[n][c] W2_t[c][k] of every step and type, straight into the R section of the images (row stride IMG_SIZE):
+    // 2 x 2 GFLOP on the matrix cores instead of 128 x 128 MACs per live step on the vector unit
     for (int t = 2; t < 4; ++t)
-        if (int e = gemm_f32(q, W2 + (size_t)t * 128 * 128, rbuf + (size_t)(t - 2) * nr * 128, (int)nr, 128, 128, ldq, 128, 128, 0, 1,
-                             nullptr, 0, nullptr, 0, 0, 1, s))
+        if (int e = gemm_f32(q, W2 + (size_t)t * 128 * 128, prep + (size_t)(t - 2) * nr * IMG_SIZE + STG_R, (int)nr, 128, 128, ldq, 128,
+                             IMG_SIZE, 0, 1, nullptr, 0, nullptr, 0, 0, 1, s))
             return e;
     // algorithmic work: basic + dW1 fold 2 x 16 x 128 x 12 MACs, the two gathers 2 x 128 x 128 MACs per step and type
     ProfScope prof("embed_bwd_pool16", 2.0 * 2.0 * nr * (2.0 * 16 * 128 * 12 + 2.0 * 128 * 128),
