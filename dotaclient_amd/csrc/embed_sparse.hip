@@ -271,6 +271,16 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
     phase_a(0, std::false_type{});
 
     const char* w2b = reinterpret_cast<const char*>(smem + L_W2 + k4);     // + W2-row byte offset
+    // dW1 fold, deferred by one iteration: an iteration ends by leaving its four relu-masked d(basic) rows in the wave's T block and
+    // the matching record operand in xa_prev; the eight MFMAs that fold them run at the top of the NEXT iteration, under its phase A / B
+    // instructions, instead of at the end of a chain (LDS round trip + 8 x 32 pipe cycles) with nothing beside them
+    float* T = smem + L_T + w * (4 * T_LD);
+    for (int e = lane; e < 4 * T_LD; e += 64) T[e] = 0.f;
+    float xa_prev = 0.f;
+    auto fold_prev = [&]() {
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) accD[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa_prev, T[mq * T_LD + 16 * kb + mi], accD[kb], 0, 0, 0);
+    };
     auto iteration = [&](long long i, auto both_c) {     // BOTH: both streams on in iterations i and i + 1
         constexpr bool BOTH = decltype(both_c)::value;
         if constexpr (TIMING) tm0 = __builtin_amdgcn_s_memtime();
@@ -279,6 +289,7 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
         __syncthreads();
         stamp(1);
         dma_issue(i + 2);
+        fold_prev();
         phase_a(i + 1, both_c);
         const float* stg[NS];
         bool on[NS], live[NS];
@@ -386,18 +397,16 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
         stamp(4);
         // ---- phase D: through the relu into dW1 / db1 (MFMA, above); second-layer bias gradient
         {
-            float* T = smem + L_T + w * (4 * T_LD);
 #pragma unroll
             for (int s2 = 0; s2 < NS; ++s2)        // a stream without a step this iteration: db = basic = 0, a row of zeros
                 *reinterpret_cast<float4*>(T + (2 * s2 + hh) * T_LD + k4) =
                     make_float4(basic[s2].x > 0.f ? dbl[s2].x : 0.f, basic[s2].y > 0.f ? dbl[s2].y : 0.f,
                                 basic[s2].z > 0.f ? dbh[s2].x : 0.f, basic[s2].w > 0.f ? dbh[s2].y : 0.f);
-            // A[f][row mq]: the record of row mq = (stream mq >> 1, unit w + 8 (mq & 1)); f = 12: ones (db1); f > 12: zeros
+            // A[f][row mq]: the record of row mq = (stream mq >> 1, unit w + 8 (mq & 1)); f = 12: ones (db1); f > 12: zeros.  Read now:
+            // the next iteration's DMA reuses this staging slot
             const int sq = mq >> 1;
             const float* sx = (sq ? stg[1] : stg[0]) + STG_X + (int)(rec_off(nb[sq] + i) & 3);
-            const float xa = mi < 12 ? sx[(w + 8 * (mq & 1)) * 12 + mi] : (mi == 12 ? 1.f : 0.f);
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) accD[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, T[mq * T_LD + 16 * kb + mi], accD[kb], 0, 0, 0);
+            xa_prev = mi < 12 ? sx[(w + 8 * (mq & 1)) * 12 + mi] : (mi == 12 ? 1.f : 0.f);
         }
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) {
@@ -411,6 +420,7 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
         long long i = 0;
         for (; i + 1 < full; ++i) iteration(i, std::true_type{});
         for (; i < iters; ++i) iteration(i, std::false_type{});
+        fold_prev();
     }
 
     if constexpr (TIMING) {
