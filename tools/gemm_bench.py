@@ -33,6 +33,8 @@ def case(name, M, N, K, a_km, b_km, relu=False, aux=False, bias=False, count=1, 
     # storage shapes (lda > M: k-major A with padded rows, as the [rows][160] head-gradient buffer)
     A = torch.randn((K, lda or M) if a_km else (M, K), device=dev)
     B = torch.randn((K, N) if b_km else (N, K), device=dev)
+    if os.environ.get('GEMM_ZERO'):   # zero-filled operands: the same instruction stream at a lower power draw (DVFS check)
+        A.zero_(); B.zero_()
     C = torch.empty(M, N, device=dev)
     bz = torch.randn(N, device=dev) if bias else None
     ax = torch.randn(M, N, device=dev) if aux else None
