@@ -34,7 +34,7 @@ enum { EP_LD = 68 };   // floats per row of a wave's 64 x 64 epilogue image (4 x
 
 struct X3Args {
     const void* A; const void* B; const void* B2;
-    float* C; float* C2; const float* bias; const float* aux; float* slab;
+    float* C; float* C2; const float* bias; const float* aux; float* slab; float* a_colsum;
     long long a_plane, b_plane, b2_plane;   // plane strides (elements) of pre-split operands
     int M, N, K, lda, ldb, ldb2, ldc, ldc2, ldaux, n_split, k_per_split, relu, accumulate, nbias;
 };
@@ -255,6 +255,15 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args p, int n_items, 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+        // column sums of A (k-major A only): the work items of column tile 0 add up what passes through their loader
+        const bool do_cs = A_MODE == X3_KMAJ && p.a_colsum != nullptr && n_blk == 0;
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto cs_add = [&](const typename LA::Regs& r) {
+            if constexpr (A_MODE == X3_KMAJ) {
+                cs.x += r.v[0].x + r.v[1].x; cs.y += r.v[0].y + r.v[1].y; cs.z += r.v[0].z + r.v[1].z; cs.w += r.v[0].w + r.v[1].w;
+            }
+        };
+        if (do_cs) cs_add(ra0);
         LA::store(ra0, smem, tid); LB::store(rb0, smem + OPER_BYTES, tid);
         __syncthreads();
         // one K step: loads of step kt + 2 -> the staging set that step kt just vacated; MFMAs of step kt; split + store of kt + 1
@@ -281,6 +290,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args p, int n_items, 
 #undef DC_X3_P
             if (kt + 1 < nk) {
                 char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+                if (do_cs) cs_add(ra_nxt);
                 LA::store(ra_nxt, nxt, tid); LB::store(rb_nxt, nxt + OPER_BYTES, tid);
             }
             __syncthreads();
@@ -290,6 +300,18 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args p, int n_items, 
             if (kt + 1 < nk) kstep(kt + 1, ra1, rb1, ra0, rb0);
         }
 
+        if (do_cs) {     // thread (kp = tid >> 5, c4 = tid & 31) holds the sums of rows m_blk + 4 c4 .. + 3 over its k of every pair: fold the
+                         // eight k lanes through the 4 KB of LDS behind the epilogue images, one atomic per row (like colsum_kernel's)
+            float* red = reinterpret_cast<float*>(smem + 4 * 64 * EP_LD * 4);
+            *reinterpret_cast<float4*>(red + (tid >> 5) * XB + (tid & 31) * 4) = cs;
+            __syncthreads();
+            if (tid < XB && m_blk + tid < p.M) {
+                float acc = 0.f;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) acc += red[g * XB + tid];
+                atomicAdd(p.a_colsum + m_blk + tid, acc);
+            }
+        }
         // the next item's first loads fly during this item's epilogue
         const int cm = m_blk, cn = n_blk, cz = z;
         const bool have_next = decode(it + 1, m_blk, n_blk, z);
@@ -364,6 +386,7 @@ int gemm_x3(const X3Gemm& g, hipStream_t stream) {
     a.a_plane = 0; a.b_plane = g.b_plane; a.b2_plane = g.b2_plane;
     a.M = g.M; a.N = g.N; a.K = g.K; a.lda = g.lda; a.ldb = g.ldb; a.ldb2 = g.ldb2; a.ldc = g.ldc; a.ldc2 = g.ldc2; a.ldaux = g.ldaux;
     a.n_split = g.n_split; a.relu = g.relu; a.accumulate = g.accumulate; a.nbias = g.bias ? g.nbias : 0;
+    a.a_colsum = g.a_mode == X3_KMAJ ? g.a_colsum : nullptr;
     int splits = 1;
     const long tiles = (long)((g.M + XB - 1) / XB) * ((g.N + XB - 1) / XB);
     if (tiles < 256 && g.K >= 4096 && !g.relu && g.aux == nullptr && g.scratch.p != nullptr) {

@@ -76,6 +76,8 @@ struct X3Gemm {
     int relu = 0; const float* aux = nullptr; int ldaux = 0;          // zero where aux <= 0
     int accumulate = 0, prec = 6, transposed_w = 0;
     GemmScratch scratch;
+    float* a_colsum = nullptr;    // X3_KMAJ A only: a_colsum[m] += sum_k A[k][m] (the bias gradient that goes with a weight gradient),
+                                  // summed while the tiles pass through the loader - no second pass over A
 };
 bool gemm_x3_shape_ok(int M, int N, int K, int lda, int ldb, int a_mode, int b_mode);
 int gemm_x3(const X3Gemm& g, hipStream_t stream);

@@ -278,16 +278,21 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         return gemm_x3(g, s);
     };
     // dW[M][N] += dy[rows][lda: M]^T x[rows][ldb: N] (contraction over the env-steps, split-K); optional second x behind N
-    auto wgrad = [&](const float* dy, int lda, int M, const float* x1, int N1, float* dW1, const float* x2, int N2, float* dW2) -> int {
+    // db (optional): the bias gradient that goes with dW, db[m] += sum over the env-steps of dy[.][m] - summed by the same kernel as dy
+    // passes through its loader (a separate column-sum pass re-reads dy: 12 launches, 0.44 ms per configs[2] step)
+    auto wgrad = [&](const float* dy, int lda, int M, const float* x1, int N1, float* dW1, const float* x2, int N2, float* dW2,
+                     float* db = nullptr) -> int {
         const bool pair = x2 != nullptr;
         if (x3_tn && gemm_x3_shape_ok(M, N1 + N2, (int)NR, lda, N1, X3_KMAJ, X3_KMAJ) && (!pair || (N1 % 128 == 0 && !(N2 & 3)))) {
             X3Gemm g;
+            g.a_colsum = db;
             g.A = dy; g.a_mode = X3_KMAJ; g.lda = lda;
             g.B = x1; g.b_mode = X3_KMAJ; g.ldb = N1; g.B2 = x2; g.ldb2 = N2; g.n_split = pair ? N1 : 0;
             g.C = dW1; g.ldc = N1; g.C2 = dW2; g.ldc2 = N2; g.M = M; g.N = N1 + N2; g.K = (int)NR; g.accumulate = 1; g.prec = prec;
             g.scratch = sc;
             return gemm_x3(g, s);
         }
+        if (db != nullptr) DC_TRY(colsum(dy, lda, NR, M, db, s));
         if (pair) return gemm_f32_tn_pair(dy, lda, x1, N1, N1, x2, N2, N2, dW1, N1, dW2, N2, M, (int)NR, s, sc);
         return gemm_f32(dy, x1, dW1, M, N1, (int)NR, lda, N1, N1, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s, sc);
     };
@@ -318,8 +323,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         DC_TRY(launch_check("policy_backward: head weight pad"));
     }
     DC_TRY(dgrad(w.f(DC_WS_DHEADOUT), HO_LD, w.f(DC_WS_HEADW_PAD), wp.bwd(wp.heads), H, nullptr, w.fl(TOP, DC_WSL_DH)));
-    DC_TRY(wgrad(w.f(DC_WS_DHEADOUT), HO_LD, HO_N, w.fl(TOP, DC_WSL_HSEQ), H, Gd.p(DC_P_HEADS_W), nullptr, 0, nullptr));
-    DC_TRY(colsum(w.f(DC_WS_DHEADOUT), HO_LD, NR, HO_N, Gd.p(DC_P_HEADS_B), s));
+    DC_TRY(wgrad(w.f(DC_WS_DHEADOUT), HO_LD, HO_N, w.fl(TOP, DC_WSL_HSEQ), H, Gd.p(DC_P_HEADS_W), nullptr, 0, nullptr, Gd.p(DC_P_HEADS_B)));
 
     // recurrent core, top layer first
     for (int l = TOP; l >= 0; --l) {
@@ -340,17 +344,13 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         const int in = l == 0 ? PREW : H;
         // dW_ih = dgx^T x ; dW_hh = dgh^T h_prev ; biases = column sums
         if (a.dgh == a.dgx) {   // LSTM: both products contract the same gate gradients - one launch
-            DC_TRY(wgrad(a.dgx, G * H, G * H, xin, in, Gd.p(pb + 0), a.hprev, H, Gd.p(pb + 1)));
-        } else {
-            DC_TRY(wgrad(a.dgx, G * H, G * H, xin, in, Gd.p(pb + 0), nullptr, 0, nullptr));
-            DC_TRY(wgrad(a.dgh, G * H, G * H, a.hprev, H, Gd.p(pb + 1), nullptr, 0, nullptr));
-        }
-        DC_TRY(colsum(a.dgx, G * H, NR, G * H, Gd.p(pb + 2), s));
-        if (d->cell == 1) {   // LSTM: dgh is dgx, so d(b_hh) = d(b_ih) - copy 2 KB instead of a second 33 MB column sum
+            DC_TRY(wgrad(a.dgx, G * H, G * H, xin, in, Gd.p(pb + 0), a.hprev, H, Gd.p(pb + 1), Gd.p(pb + 2)));
+            // dgh is dgx, so d(b_hh) = d(b_ih): copy 2 KB
             hipError_t ec = hipMemcpyAsync(Gd.p(pb + 3), Gd.p(pb + 2), (size_t)G * H * sizeof(float), hipMemcpyDeviceToDevice, s);
             if (ec != hipSuccess) { set_error("policy_backward: bias gradient copy", (int)ec); return (int)ec; }
         } else {
-            DC_TRY(colsum(a.dgh, G * H, NR, G * H, Gd.p(pb + 3), s));
+            DC_TRY(wgrad(a.dgx, G * H, G * H, xin, in, Gd.p(pb + 0), nullptr, 0, nullptr, Gd.p(pb + 2)));
+            DC_TRY(wgrad(a.dgh, G * H, G * H, a.hprev, H, Gd.p(pb + 1), nullptr, 0, nullptr, Gd.p(pb + 3)));
         }
         if (l > 0) {
             DC_TRY(dgrad(a.dgx, G * H, P.p(pb + 0), wp.bwd(wp.ih[l]), H, nullptr, w.fl(l - 1, DC_WSL_DH)));
@@ -359,8 +359,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
             DC_TRY(dgrad(a.dgx, G * H, P.p(pb + 0), wp.bwd(wp.ih[0]), PREW, w.f(DC_WS_PRE), w.f(DC_WS_DPRE)));
         }
     }
-    DC_TRY(wgrad(w.f(DC_WS_DPRE), PREW, PREW, w.f(DC_WS_XCAT), XCATW, Gd.p(DC_P_PRE_W), nullptr, 0, nullptr));
-    DC_TRY(colsum(w.f(DC_WS_DPRE), PREW, NR, PREW, Gd.p(DC_P_PRE_B), s));
+    DC_TRY(wgrad(w.f(DC_WS_DPRE), PREW, PREW, w.f(DC_WS_XCAT), XCATW, Gd.p(DC_P_PRE_W), nullptr, 0, nullptr, Gd.p(DC_P_PRE_B)));
     DC_TRY(dgrad(w.f(DC_WS_DPRE), PREW, P.p(DC_P_PRE_W), wp.bwd(wp.pre), XCATW, nullptr, w.f(DC_WS_DXCAT)));
     }   // do_upper
     if (!do_embed) return 0;
