@@ -604,7 +604,7 @@ bool rnn_team_supported(int cell, int H, int n_seq, int flags) {
 }
 
 int rnn_team_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
-    if (lstm_team_mfma_supported(cell, a.H, a.n_seq, a.flags)) return lstm_team_mfma_forward(a, max_len, team_capacity(), s);
+    if (lstm_team_mfma_supported(cell, a.H, a.n_seq, a.flags, false)) return lstm_team_mfma_forward(a, max_len, team_capacity(), s);
     u64* xb = static_cast<u64*>(a.xbuf);
     if (!xb) { set_error("rnn_team_forward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }
     const int nt = team_count(a.n_seq), ns = team_streams(a.n_seq, nt, a.flags);
@@ -633,7 +633,7 @@ int rnn_team_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
 }
 
 int rnn_team_backward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
-    if (lstm_team_mfma_supported(cell, a.H, a.n_seq, a.flags)) return lstm_team_mfma_backward(a, max_len, team_capacity(), s);
+    if (lstm_team_mfma_supported(cell, a.H, a.n_seq, a.flags, true)) return lstm_team_mfma_backward(a, max_len, team_capacity(), s);
     u64* xb = static_cast<u64*>(a.xbuf);
     if (!xb) { set_error("rnn_team_backward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }
     const int nt = team_count(a.n_seq), ns = team_streams(a.n_seq, nt, a.flags);

@@ -344,10 +344,11 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_bwd_kernel(RnnSt
 
 }  // namespace
 
-bool lstm_team_mfma_supported(int cell, int H, int n_seq, int flags) {
-    // measured at 256 steps: 128 sequences run as fast on the VALU team kernels with two sequences in flight per team; below
-    // that the VALU kernels use more CUs (one team per sequence) than sixteen or fewer MFMA teams would
-    return cell == 1 && H == TM_H && n_seq > 128 && !(flags & DC_DIMS_TEAM_VALU);
+bool lstm_team_mfma_supported(int cell, int H, int n_seq, int flags, bool backward) {
+    // measured at 256 steps (end of round 2): at 128 sequences the forward is faster on the VALU team kernels with two sequences
+    // in flight per team (486 vs 543 us), the backward on these (491 vs 539 us: its row-parallel exchange moves a quarter of the
+    // granules); at 64 the VALU kernels (one team per sequence: all CUs) win both ways by 2x over sixteen MFMA teams
+    return cell == 1 && H == TM_H && n_seq >= (backward ? 128 : 129) && !(flags & DC_DIMS_TEAM_VALU);
 }
 
 int lstm_team_mfma_forward(RnnStepArgs a, int max_len, int n_teams, hipStream_t s) {
