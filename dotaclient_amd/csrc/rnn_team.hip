@@ -596,11 +596,15 @@ long long rnn_team_xbuf_bytes() { return (long long)(TEAM_XBUF_WORDS * sizeof(u6
 
 // (DC_DIMS_RNN_PER_STEP, checked by the caller, forces the launch-per-step kernels)
 bool rnn_team_supported(int cell, int H, int n_seq, int flags) {
-    (void)flags;
-    const bool on = true;
-    // measured at LSTM-256, 256 steps: 64 sequences 0.39 vs 2.2 ms per pass, 256: 0.86 vs 2.4 ms, 1024: 3.4 vs 3.8 ms - beyond
-    // that the batched per-step launches (MFMA, all sequences at once) win again
-    return on && H == TEAM_H && (cell == CELL_GRU || cell == CELL_LSTM) && n_seq <= 12 * TEAM_MAX && team_capacity() >= 1;
+    if (H != TEAM_H || (cell != CELL_GRU && cell != CELL_LSTM) || team_capacity() < 1) return false;
+    // The MFMA team kernels (LSTM) cost the same per sequence-step whatever the number of sequences (a team works through its
+    // groups of four one after the other): 1 065 chunks of 16 steps - the reference's default shape - 215 / 205 us per forward /
+    // backward pass against 16 launches of 21.6 / 27.0 us.  No upper limit.
+    if (lstm_team_mfma_supported(cell, H, n_seq, flags, false)) return true;
+    // VALU team kernels, measured at LSTM-256, 256 steps: 64 sequences 0.39 vs 2.2 ms per pass, 256: 0.86 vs 2.4 ms, 1024: 3.4 vs
+    // 3.8 ms (GRU, 1 065 x 16 steps: 315 / 368 us against 16 x 17.5 / 22.4 us) - beyond that the batched per-step launches (f32
+    // MFMA, all sequences at once) win again
+    return n_seq <= 12 * TEAM_MAX;
 }
 
 int rnn_team_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {

@@ -201,13 +201,14 @@ def test_lstm_persist_variants_agree(S, lens):
 
 @pytest.mark.parametrize('cell', ['gru', 'lstm'])
 @pytest.mark.parametrize('S,lens', [(256, [256] * 6), (7, [21, 7, 13, 30, 1, 44]), (5, [350]), (16, [50, 64, 33]), (3, [1200, 2]), (8, [8] * 131 + [24, 16]),
-                                    (2, [1100])])
+                                    (2, [1100]), (4, [3600, 30])])
 def test_rnn_team_kernels_agree_with_per_step(cell, S, lens):
     # H = 256 (the reference's GRU, the LSTM-256 configs): the four-workgroups-per-sequence persistent kernels
     # (rnn_team.hip) against the launch-per-step kernels on the same batch.  6 / 17 / 70 / 11 / 401 chunk sequences:
     # fewer teams than 8 (plain block -> team map), 16 teams with one sequence left over, more sequences than the 64
     # teams (two streams per team, then four with several sequences per stream: tag / ring continuity across sequence
-    # boundaries, streams that retire early), every remainder of the step groups.  Each case also with the stream
+    # boundaries, streams that retire early), every remainder of the step groups; 908 chunks: beyond the VALU team kernels' limit of
+    # 768 sequences (the LSTM's MFMA team kernels have none, the others fall back to the per-step kernels).  Each case also with the stream
     # count forced to 1, 2 and 4.  All differ only in summation order.
     from dotaclient_amd import engine as E
     from dotaclient_amd.engine import Engine, pack_rollouts
