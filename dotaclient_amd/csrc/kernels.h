@@ -157,8 +157,8 @@ int lstm_backward_steps_bf16(RnnStepArgs a, int max_len, hipStream_t s);
 long long rnn_team_xbuf_bytes();   // size of DC_WS_TEAM_XBUF
 // rnn_team_mfma.hip (LSTM-256, more than 128 sequences: a team advances four sequences together on the 4x4x1 MFMA)
 bool lstm_team_mfma_supported(int cell, int H, int n_seq, int flags, bool backward);
-int lstm_team_mfma_forward(RnnStepArgs a, int max_len, int n_teams, hipStream_t s);
-int lstm_team_mfma_backward(RnnStepArgs a, int max_len, int n_teams, hipStream_t s);
+int lstm_team_mfma_forward(int cell, RnnStepArgs a, int max_len, int n_teams, hipStream_t s);
+int lstm_team_mfma_backward(int cell, RnnStepArgs a, int max_len, int n_teams, hipStream_t s);
 int rnn_team_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s);
 int rnn_team_backward(int cell, RnnStepArgs a, int max_len, hipStream_t s);
 // adam.hip

@@ -597,18 +597,17 @@ long long rnn_team_xbuf_bytes() { return (long long)(TEAM_XBUF_WORDS * sizeof(u6
 // (DC_DIMS_RNN_PER_STEP, checked by the caller, forces the launch-per-step kernels)
 bool rnn_team_supported(int cell, int H, int n_seq, int flags) {
     if (H != TEAM_H || (cell != CELL_GRU && cell != CELL_LSTM) || team_capacity() < 1) return false;
-    // The MFMA team kernels (LSTM) cost the same per sequence-step whatever the number of sequences (a team works through its
-    // groups of four one after the other): 1 065 chunks of 16 steps - the reference's default shape - 215 / 205 us per forward /
-    // backward pass against 16 launches of 21.6 / 27.0 us.  No upper limit.
+    // The MFMA team kernels (rnn_team_mfma.hip, both cells) where their rounds of 64 x 4 sequences are cheaper than the alternative
+    // (cost model there): no upper limit on the number of sequences - 1 065 chunks of 16 steps, the reference's default shape,
+    // take 215 / 205 us per forward / backward pass against 16 launches of 17-27 us.
     if (lstm_team_mfma_supported(cell, H, n_seq, flags, false)) return true;
     // VALU team kernels, measured at LSTM-256, 256 steps: 64 sequences 0.39 vs 2.2 ms per pass, 256: 0.86 vs 2.4 ms, 1024: 3.4 vs
-    // 3.8 ms (GRU, 1 065 x 16 steps: 315 / 368 us against 16 x 17.5 / 22.4 us) - beyond that the batched per-step launches (f32
-    // MFMA, all sequences at once) win again
+    // 3.8 ms - beyond that the batched per-step launches (f32 MFMA, all sequences at once) win again
     return n_seq <= 12 * TEAM_MAX;
 }
 
 int rnn_team_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
-    if (lstm_team_mfma_supported(cell, a.H, a.n_seq, a.flags, false)) return lstm_team_mfma_forward(a, max_len, team_capacity(), s);
+    if (lstm_team_mfma_supported(cell, a.H, a.n_seq, a.flags, false)) return lstm_team_mfma_forward(cell, a, max_len, team_capacity(), s);
     u64* xb = static_cast<u64*>(a.xbuf);
     if (!xb) { set_error("rnn_team_forward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }
     const int nt = team_count(a.n_seq), ns = team_streams(a.n_seq, nt, a.flags);
@@ -637,7 +636,7 @@ int rnn_team_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
 }
 
 int rnn_team_backward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
-    if (lstm_team_mfma_supported(cell, a.H, a.n_seq, a.flags, true)) return lstm_team_mfma_backward(a, max_len, team_capacity(), s);
+    if (lstm_team_mfma_supported(cell, a.H, a.n_seq, a.flags, true)) return lstm_team_mfma_backward(cell, a, max_len, team_capacity(), s);
     u64* xb = static_cast<u64*>(a.xbuf);
     if (!xb) { set_error("rnn_team_backward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }
     const int nt = team_count(a.n_seq), ns = team_streams(a.n_seq, nt, a.flags);

@@ -3,7 +3,9 @@
 // with the arithmetic of rnn_persist.hip: a team advances FOUR sequences together, one v_mfma_f32_4x4x1_16b_f32 product
 // phase per time step, instead of giving each of its sequences a turn on the packed-f32 VALU.
 //
-// Replaces the S sequential cell steps of nn.LSTM (the BASELINE.json extension of /root/reference/policy.py:66,141).
+// Replaces the S sequential cell steps of nn.LSTM (the BASELINE.json extension of /root/reference/policy.py:66,141) and of the
+// reference's own nn.GRU (CELL = 0: three gates r, z, n in the same four-slot layout, zero weights in slot 3 - a step is bound by the
+// hand-off, not by the product; n = tanh(W_in x + b_in + r (W_hn h + b_hn)), h' = (1 - z) n + z h, torch 1.0 cell maths as in rnn.hip).
 //
 // Why.  rnn_team.hip at 256 sequences (64 teams, four sequences each, one "step call" per sequence in turn): 2 100
 // cycles per call - 1 080 of packed-FMA arithmetic with its DPP reduction trees, the rest poll, barrier and loop control -
@@ -43,9 +45,10 @@ enum { TM_H = TEAM_H, TM_KH = 128, TM_HLD = TM_KH + 4, TM_THREADS = 256 };
 __device__ __forceinline__ int tm_hpos(int seq, int k) { return ((k >> 7) * 4 + seq) * TM_HLD + (k & 127); }
 __device__ __forceinline__ constexpr int tm_korder(int kk) { return 8 * (kk & 15) + (kk >> 4); }
 
-template <bool TIMING>
-__global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_fwd_kernel(RnnStepArgs p, u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
-    constexpr int H = TM_H, GH = 4 * H;
+template <int CELL>     // 1: LSTM, 0: GRU
+__global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_kernel(RnnStepArgs p, u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
+    constexpr bool LSTM = CELL == 1;
+    constexpr int H = TM_H, G = LSTM ? 4 : 3, GH = G * H;
     __shared__ __attribute__((aligned(16))) float h_lds[2][2 * 4 * TM_HLD];
     __shared__ __attribute__((aligned(16))) float4 xch[2][2][64];          // [k half][unit block][lane]: partial sums for the partner
     __shared__ int dead;
@@ -65,14 +68,15 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_fwd_kernel(RnnSt
     // ---- weights: rows (2 hi + m) H + u of W_hh, k in [128 kh, 128 kh + 128) ----------------------------------------
     float w0[TM_KH], w1[TM_KH];
     {
+        const bool has1 = 2 * hi + 1 < G;              // the GRU has no gate 3: zero weights in that slot
         const float* r0 = p.Whh + (size_t)((2 * hi + 0) * H + u) * H + TM_KH * kh;
-        const float* r1 = p.Whh + (size_t)((2 * hi + 1) * H + u) * H + TM_KH * kh;
+        const float* r1 = p.Whh + (size_t)((has1 ? 2 * hi + 1 : 0) * H + u) * H + TM_KH * kh;
 #pragma unroll
-        for (int kk = 0; kk < TM_KH; ++kk) { w0[kk] = r0[tm_korder(kk)]; w1[kk] = r1[tm_korder(kk)]; }
+        for (int kk = 0; kk < TM_KH; ++kk) { w0[kk] = r0[tm_korder(kk)]; w1[kk] = has1 ? r1[tm_korder(kk)] : 0.f; }
     }
     float bh[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bh[g] = p.bhh[g * H + u];
+    for (int g = 0; g < 4; ++g) bh[g] = g < G ? p.bhh[g * H + u] : 0.f;
 
     unsigned tag = 0;                                  // the team's running step counter (continues across sequence groups)
     bool failed = false;
@@ -87,9 +91,9 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_fwd_kernel(RnnSt
         const unsigned row0 = (unsigned)p.seq_off[b];
         unsigned goff = row0 * GH + u, soff = row0 * H + u;
         unsigned st_g = goff, st_s = soff, st_p = soff;
-        float c = p.c0 ? p.c0[(size_t)b * H + u] : 0.f;
         const float h0v = p.h0 ? p.h0[(size_t)b * H + u] : 0.f;
-        float sv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float c = LSTM ? (p.c0 ? p.c0[(size_t)b * H + u] : 0.f) : h0v;     // the cell's carried state: c (LSTM) / h (GRU)
+        float sv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // results of the last finished step: gates 0..3 (GRU: [3] = W_hn h + b_hn), c, h
         float svp0 = c, svp1 = h0v;                    // row 0 of cprev / hprev keeps c0 / h0
         // h0 of all 256 units of the four slots -> LDS buffer 0 (the previous group's last reads ended at its final barrier)
         for (int e = tid; e < 4 * H; e += TM_THREADS) {
@@ -97,9 +101,9 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_fwd_kernel(RnnSt
             const int bq = q == 0 ? bmap[0] : (q == 1 ? bmap[1] : (q == 2 ? bmap[2] : bmap[3]));
             h_lds[0][tm_hpos(q, j)] = p.h0 ? p.h0[(size_t)bq * H + j] : 0.f;
         }
-        float xc[4], xn[4];
+        float xc[4] = {0.f, 0.f, 0.f, 0.f}, xn[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) xc[g] = p.gates[goff + g * H];
+        for (int g = 0; g < G; ++g) xc[g] = p.gates[goff + g * H];
         u64* const xb = xbuf + (size_t)(team * 4 + slot) * (TEAM_SLOTS * H);      // ring of this lane's sequence slot
         __syncthreads();
 
@@ -109,18 +113,18 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_fwd_kernel(RnnSt
             const unsigned gnx = goff + (on1 ? GH : 0);
             const float* const lp = p.gates + gnx;
             float* const gs = p.gates + st_g;
-            float* const cs = p.cseq + st_s;
+            float* const cs = (LSTM ? p.cseq : p.hn) + st_s;     // GRU: W_hn h + b_hn of the step (the backward's r-gate term)
             float* const hs = p.hseq + st_s;
-            float* const cp = p.cprev + st_p;
+            float* const cp = LSTM ? p.cprev + st_p : nullptr;
             float* const hp = p.hprev + st_p;
             // between the MFMA pairs: the loads of the next step's gate pre-activations, the stores of the previous step's results
             auto hook = [&](auto K) {
                 constexpr int k = decltype(K)::value;          // 0 .. 63
-                if constexpr (k >= 1 && k <= 4) xnext[k - 1] = lp[(k - 1) * H];
-                else if constexpr (k >= 8 && k <= 11) gs[(k - 8) * H] = sv[k - 8];
-                else if constexpr (k == 12) *cs = sv[4];
+                if constexpr (k >= 1 && k <= G) xnext[k - 1] = lp[(k - 1) * H];
+                else if constexpr (k >= 8 && k < 8 + G) gs[(k - 8) * H] = sv[k - 8];
+                else if constexpr (k == 12) *cs = sv[LSTM ? 4 : 3];
                 else if constexpr (k == 13) *hs = sv[5];
-                else if constexpr (k == 14) *cp = svp0;
+                else if constexpr (k == 14 && LSTM) *cp = svp0;
                 else if constexpr (k == 15) *hp = svp1;
             };
             f32x4 pa[4];
@@ -137,12 +141,13 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_fwd_kernel(RnnSt
             // ---- gate pairs: afterwards y0 = i, x0 = g, y1 = f, x1 = o of this lane's own cell (sequence 2 kh + hi) --------
             half_swap(y0, x0);
             half_swap(y1, x1);
+            // LSTM: i, f, g, o -> c' = f c + i g, h' = o tanh(c');   GRU: r, z, n (og = W_hn h + b_hn) -> h' = (1 - z) n + z h
             const float ig = fast_sigmoid(xcur[0] + (y0 + bh[0]));
             const float fg = fast_sigmoid(xcur[1] + (y1 + bh[1]));
-            const float gg = fast_tanh(xcur[2] + (x0 + bh[2]));
-            const float og = fast_sigmoid(xcur[3] + (x1 + bh[3]));
-            const float cn = fg * c + ig * gg;
-            const float hn = og * fast_tanh(cn);
+            const float og = LSTM ? fast_sigmoid(xcur[3] + (x1 + bh[3])) : x0 + bh[2];
+            const float gg = LSTM ? fast_tanh(xcur[2] + (x0 + bh[2])) : fast_tanh(xcur[2] + ig * og);
+            const float cn = LSTM ? fg * c + ig * gg : (1.f - fg) * gg + fg * c;
+            const float hn = LSTM ? og * fast_tanh(cn) : cn;
             const float hpub = on ? hn : 0.f;
             ++tag;
             granule_store(xb + (tag & 3) * H + u, hpub, tag, plain);      // publish first: the peers are waiting for it
@@ -179,10 +184,10 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_fwd_kernel(RnnSt
         }
         // drain: the deferred stores of the group's last step
 #pragma unroll
-        for (int g = 0; g < 4; ++g) p.gates[st_g + g * H] = sv[g];
-        p.cseq[st_s] = sv[4];
+        for (int g = 0; g < G; ++g) p.gates[st_g + g * H] = sv[g];
+        if constexpr (LSTM) { p.cseq[st_s] = sv[4]; p.cprev[st_p] = svp0; }
+        else p.hn[st_s] = sv[3];
         p.hseq[st_s] = failed ? __builtin_nanf("") : sv[5];      // a peer never answered: make the failure visible downstream
-        p.cprev[st_p] = svp0;
         p.hprev[st_p] = svp1;
         if ((tmax & 1) && !failed) {                   // an odd number of steps ended in buffer 1: the next group starts from buffer 0
             // (nothing to copy: the next group overwrites buffer 0 with its own h0 before its first step)
@@ -216,8 +221,10 @@ __device__ __forceinline__ int tb_pos(int kk) { return TB_BLK * (kk >> 5) + (kk 
 // [i][32 b' ..]: with the image in PLAIN order it contracts kk = 32 (kk' & 7) + (kk' >> 3); the weights are loaded in that order
 __device__ __forceinline__ constexpr int tb_korder(int kk) { return 32 * (kk & 7) + (kk >> 3); }
 
-__global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_bwd_kernel(RnnStepArgs p, u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
-    constexpr int H = TM_H, GH = 4 * H, KH = TB_KH;
+template <int CELL>     // 1: LSTM, 0: GRU (contracts dgh = d(W_hh h + b_hh) of step t + 1; writes dgx and dgh)
+__global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_bwd_kernel(RnnStepArgs p, u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
+    constexpr bool LSTM = CELL == 1;
+    constexpr int H = TM_H, G = LSTM ? 4 : 3, GH = G * H, KH = TB_KH;
     __shared__ __attribute__((aligned(16))) float g_lds[2][4 * TB_GLD];      // own gate gradients [seq][pos(kk)], kk = 64 gate + own unit
     __shared__ float own[4][TEAM_US];                                         // own partial sums dh_rec[seq][own unit]
     __shared__ int dead;
@@ -237,8 +244,8 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_bwd_kernel(RnnSt
     float w[KH];
 #pragma unroll
     for (int kk = 0; kk < KH; ++kk) {
-        const int k = tb_korder(kk);                   // own gate column 64 gate + own unit
-        w[kk] = p.Whh[(size_t)((k >> 6) * H + TEAM_US * member + (k & 63)) * H + up];
+        const int k = tb_korder(kk);                   // own gate column 64 gate + own unit (GRU: slot 3 is empty)
+        w[kk] = (k >> 6) < G ? p.Whh[(size_t)((k >> 6) * H + TEAM_US * member + (k & 63)) * H + up] : 0.f;
     }
 
     // ring of a team: [tag & 3][owner member][source member][sequence slot][64 units] granules
@@ -253,13 +260,15 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_bwd_kernel(RnnSt
         const int len = p.seq_len[b];
         const unsigned row = (unsigned)p.seq_off[b] + (unsigned)min(tmax - 1, len - 1);
         unsigned goff = row * GH + u, soff = row * H + u, st_g = goff;
-        float dc_next = 0.f, f_next = 0.f;
-        float cur_v[7], nxt_v[7];                      // i, f, g, o, c, c_prev, dh
+        float dc_next = 0.f, f_next = 0.f;             // LSTM: dc, f of step t + 1;  GRU: total dh, z of step t + 1 (the direct path z h)
+        float cur_v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, nxt_v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // LSTM: i, f, g, o, c, c_prev, dh;  GRU: r, z, n, W_hn h + b_hn, -, h_prev, dh
         float sv[4] = {0.f, 0.f, 0.f, 0.f};            // gate gradients of the last finished step, stored one step late
+        float svh2 = 0.f;                              // GRU: the n column of dgh (= sv[2] * r; the r, z columns equal dgx's)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) cur_v[g] = p.gates[goff + g * H];
-        cur_v[4] = p.cseq[soff];
-        cur_v[5] = p.cprev[soff];
+        for (int g = 0; g < G; ++g) cur_v[g] = p.gates[goff + g * H];
+        if constexpr (LSTM) { cur_v[4] = p.cseq[soff]; cur_v[5] = p.cprev[soff]; }
+        else { cur_v[3] = p.hn[soff]; cur_v[5] = p.hprev[soff]; }
         cur_v[6] = p.dh[soff];
         for (int e = tid; e < 4 * TB_GLD; e += TM_THREADS) g_lds[0][e] = 0.f;      // "step tmax" has no gradient
         __syncthreads();
@@ -270,17 +279,20 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_bwd_kernel(RnnSt
             const bool xchg = t + 1 < tmax;                                               // workgroup- and team-uniform
             const unsigned gnx = goff - (dec ? GH : 0), snx = soff - (dec ? H : 0);
             const float* const lg = p.gates + gnx;
-            const float* const lc = p.cseq + snx;
-            const float* const lcp = p.cprev + snx;
+            const float* const lc = (LSTM ? p.cseq : p.hn) + snx;
+            const float* const lcp = (LSTM ? p.cprev : p.hprev) + snx;
             const float* const ldh = p.dh + snx;
             float* const gs = p.dgx + st_g;
+            float* const ghs = LSTM ? nullptr : p.dgh + st_g;
             auto hook = [&](auto K) {
                 constexpr int k = decltype(K)::value;          // 0 .. 63
-                if constexpr (k >= 1 && k <= 4) nv[k - 1] = lg[(k - 1) * H];
-                else if constexpr (k == 5) nv[4] = *lc;
+                if constexpr (k >= 1 && k <= G) nv[k - 1] = lg[(k - 1) * H];
+                else if constexpr (k == 5) nv[LSTM ? 4 : 3] = *lc;
                 else if constexpr (k == 6) nv[5] = *lcp;
                 else if constexpr (k == 7) nv[6] = *ldh;
-                else if constexpr (k >= 10 && k <= 13) gs[(k - 10) * H] = sv[k - 10];
+                else if constexpr (k >= 10 && k < 10 + G) gs[(k - 10) * H] = sv[k - 10];
+                else if constexpr (!LSTM && (k == 14 || k == 15)) ghs[(k - 14) * H] = sv[k - 14];
+                else if constexpr (!LSTM && k == 16) ghs[2 * H] = svh2;
             };
             // ---- partial dh_rec[seq 0..3][u'] over this member's 256 gate columns ------------------------------------------
             f32x4 pa[4];
@@ -315,16 +327,28 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_bwd_kernel(RnnSt
             float dh = cv[6];
             dh += has_next ? rec : 0.f;
             const float ig = cv[0], fg = cv[1], gg = cv[2], og = cv[3];
-            const float tc = fast_tanh(cv[4]);
-            float dcv = dh * og * (1.f - tc * tc);
-            dcv += has_next ? dc_next * f_next : 0.f;
-            const float dgr[4] = {on ? dcv * gg * ig * (1.f - ig) : 0.f, on ? dcv * cv[5] * fg * (1.f - fg) : 0.f,
-                                  on ? dcv * ig * (1.f - gg * gg) : 0.f, on ? dh * tc * og * (1.f - og) : 0.f};
+            float dgr[4];                                  // what the next product contracts: d(W_hh h + b_hh) of this step
+            if constexpr (LSTM) {
+                const float tc = fast_tanh(cv[4]);
+                float dcv = dh * og * (1.f - tc * tc);
+                dcv += has_next ? dc_next * f_next : 0.f;
+                dgr[0] = on ? dcv * gg * ig * (1.f - ig) : 0.f; dgr[1] = on ? dcv * cv[5] * fg * (1.f - fg) : 0.f;
+                dgr[2] = on ? dcv * ig * (1.f - gg * gg) : 0.f; dgr[3] = on ? dh * tc * og * (1.f - og) : 0.f;
+                sv[0] = on ? dgr[0] : sv[0]; sv[1] = on ? dgr[1] : sv[1]; sv[2] = on ? dgr[2] : sv[2]; sv[3] = on ? dgr[3] : sv[3];
+                dc_next = on ? dcv : dc_next;
+            } else {                                       // r = ig, z = fg, n = gg, og = W_hn h + b_hn, cv[5] = h_{t-1}  (rnn.hip)
+                dh += has_next ? dc_next * f_next : 0.f;   // direct path h_{t+1} = ... + z_{t+1} h_t
+                const float dn_pre = dh * (1.f - fg) * (1.f - gg * gg);
+                const float dz_pre = dh * (cv[5] - gg) * fg * (1.f - fg);
+                const float dr_pre = dn_pre * og * ig * (1.f - ig);
+                dgr[0] = on ? dr_pre : 0.f; dgr[1] = on ? dz_pre : 0.f; dgr[2] = on ? dn_pre * ig : 0.f; dgr[3] = 0.f;
+                sv[0] = on ? dr_pre : sv[0]; sv[1] = on ? dz_pre : sv[1]; sv[2] = on ? dn_pre : sv[2];
+                svh2 = on ? dn_pre * ig : svh2;
+                dc_next = on ? dh : dc_next;
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) g_lds[cur ^ 1][slot * TB_GLD + tb_pos(TEAM_US * g + ul)] = dgr[g];
-            sv[0] = on ? dgr[0] : sv[0]; sv[1] = on ? dgr[1] : sv[1]; sv[2] = on ? dgr[2] : sv[2]; sv[3] = on ? dgr[3] : sv[3];
             st_g = on ? goff : st_g;
-            dc_next = on ? dcv : dc_next;
             f_next = on ? fg : f_next;
             goff = gnx;
             soff = snx;
@@ -337,44 +361,69 @@ __global__ __launch_bounds__(TM_THREADS, 1) void lstm_team_mfma_bwd_kernel(RnnSt
         }
         // drain the deferred stores of step 0
 #pragma unroll
-        for (int g = 0; g < 4; ++g) p.dgx[st_g + g * H] = failed ? __builtin_nanf("") : sv[g];
+        for (int g = 0; g < G; ++g) p.dgx[st_g + g * H] = failed ? __builtin_nanf("") : sv[g];
+        if constexpr (!LSTM) { p.dgh[st_g] = sv[0]; p.dgh[st_g + H] = sv[1]; p.dgh[st_g + 2 * H] = svh2; }
         __syncthreads();
     }
 }
 
 }  // namespace
 
-bool lstm_team_mfma_supported(int cell, int H, int n_seq, int flags, bool backward) {
-    // measured at 256 steps (end of round 2): at 128 sequences the forward is faster on the VALU team kernels with two sequences
-    // in flight per team (486 vs 543 us), the backward on these (491 vs 539 us: its row-parallel exchange moves a quarter of the
-    // granules); at 64 the VALU kernels (one team per sequence: all CUs) win both ways by 2x over sixteen MFMA teams
-    return cell == 1 && H == TM_H && n_seq >= (backward ? 128 : 129) && !(flags & DC_DIMS_TEAM_VALU);
+// Teams to launch for n_seq sequences and the number of rounds (groups of four sequences per team, one after the other) that
+// follow.  A multiple of 8 teams lets the four members of every team share an XCD (team_claim_role: L2-scope hand-off); another
+// count keeps the teams busy in fewer rounds at the price of device-scope hand-offs (about a quarter slower per step, measured).
+static int team_mfma_plan(int n_seq, int n_teams, double& cost_rounds) {
+    const int groups = (n_seq + 3) / 4;
+    const int nt_f = groups < n_teams ? groups : n_teams;
+    const int nt_q = nt_f >= 8 ? (nt_f & ~7) : nt_f;
+    const int rounds_f = (groups + nt_f - 1) / nt_f, rounds_q = (groups + nt_q - 1) / nt_q;
+    if (nt_q != nt_f && rounds_f * 1.25 < rounds_q) { cost_rounds = rounds_f * 1.25; return nt_f; }
+    cost_rounds = rounds_q;
+    return nt_q;
 }
 
-int lstm_team_mfma_forward(RnnStepArgs a, int max_len, int n_teams, hipStream_t s) {
+// MFMA team kernels or VALU team kernels (rnn_team.hip)?  Cost per 256 time steps in us, measured at the end of round 2 (GRU- and
+// LSTM-256 alike within 10 %).  Both are quantised: the MFMA kernels take a round of 620 (forward) / 550 (backward) per 64 x 4
+// sequences; the VALU kernels keep s = ceil(n / 64) sequences in flight per team - s = 1: 390 / 450, 2: 486 / 540, 3: 790 / 940,
+// 4: 883 / 1 050, and more than four one after the other (260 sequences: 1 650 / 1 890) - and stop at 768 sequences (per-step
+// launches instead: ~19 us per step).  E.g. 128 sequences: forward VALU (486 < 620), backward MFMA (550 > 540 is a tie: measured
+// 491 vs 539); 256: MFMA; 260: MFMA in two rounds; 1 065 chunks (the reference's default shape): MFMA in five.
+bool lstm_team_mfma_supported(int cell, int H, int n_seq, int flags, bool backward) {
+    if ((cell != 1 && cell != 0) || H != TM_H || n_seq < 65 || (flags & DC_DIMS_TEAM_VALU)) return false;
+    double rounds;
+    (void)team_mfma_plan(n_seq, 64, rounds);
+    const double mfma = rounds * (backward ? 540.0 : 620.0);
+    static const double kValu[2][4] = {{390.0, 486.0, 790.0, 883.0}, {450.0, 540.0, 940.0, 1050.0}};
+    const int s = (n_seq + 63) / 64;
+    const double valu = n_seq > 768 ? 256.0 * 19.0 : (s <= 4 ? kValu[backward][s - 1] : ((s + 3) / 4) * kValu[backward][3]);
+    return mfma <= valu;
+}
+
+int lstm_team_mfma_forward(int cell, RnnStepArgs a, int max_len, int n_teams, hipStream_t s) {
     u64* xb = static_cast<u64*>(a.xbuf);
     if (!xb) { set_error("lstm_team_mfma_forward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }
-    const int groups = (a.n_seq + 3) / 4;
-    int nt = groups < n_teams ? groups : n_teams;
-    if (nt >= 8) nt &= ~7;
-    ProfScope prof("lstm_fwd_team", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * (2.0 * 4 + 4.0), s);
+    double rounds;
+    const int nt = team_mfma_plan(a.n_seq, n_teams, rounds);
+    const double G = cell == 1 ? 4.0 : 3.0;
+    ProfScope prof(cell == 1 ? "lstm_fwd_team" : "gru_fwd_team", 2.0 * a.n_seq * G * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * (2.0 * G + 4.0), s);
     if (hipMemsetAsync(xb, 0, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * TEAM_M + (size_t)nt * 4 * TEAM_SLOTS * TEAM_H) * sizeof(u64), s) != hipSuccess)
         return launch_check("lstm_team_mfma_forward memset");
-    hipLaunchKernelGGL(lstm_team_mfma_fwd_kernel<false>, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt,
-                       !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+    if (cell == 1) hipLaunchKernelGGL(team_mfma_fwd_kernel<1>, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+    else hipLaunchKernelGGL(team_mfma_fwd_kernel<0>, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
     return launch_check("lstm_team_mfma_forward");
 }
 
-int lstm_team_mfma_backward(RnnStepArgs a, int max_len, int n_teams, hipStream_t s) {
+int lstm_team_mfma_backward(int cell, RnnStepArgs a, int max_len, int n_teams, hipStream_t s) {
     u64* xb = static_cast<u64*>(a.xbuf);
     if (!xb) { set_error("lstm_team_mfma_backward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }
-    const int groups = (a.n_seq + 3) / 4;
-    int nt = groups < n_teams ? groups : n_teams;
-    if (nt >= 8) nt &= ~7;
-    ProfScope prof("lstm_bwd_team", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * (3.0 * 4 + 6.0), s);
+    double rounds;
+    const int nt = team_mfma_plan(a.n_seq, n_teams, rounds);
+    const double G = cell == 1 ? 4.0 : 3.0;
+    ProfScope prof(cell == 1 ? "lstm_bwd_team" : "gru_bwd_team", 2.0 * a.n_seq * G * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * (3.0 * G + 6.0), s);
     if (hipMemsetAsync(xb, 0, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * TEAM_M + (size_t)nt * 4 * TEAM_SLOTS * 4 * TEAM_H) * sizeof(u64), s) != hipSuccess)
         return launch_check("lstm_team_mfma_backward memset");
-    hipLaunchKernelGGL(lstm_team_mfma_bwd_kernel, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+    if (cell == 1) hipLaunchKernelGGL(team_mfma_bwd_kernel<1>, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+    else hipLaunchKernelGGL(team_mfma_bwd_kernel<0>, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
     return launch_check("lstm_team_mfma_backward");
 }
 
