@@ -598,7 +598,8 @@ def main():
                        'ms_per_step_with_next_batch_packed_concurrently': None if ingest_overlap_ms is None else round(ingest_overlap_ms, 3),
                        'env_steps_per_s_with_ingest_overlapped': None if ingest_overlap_ms is None else round(B * S / (ingest_overlap_ms * 1e-3), 1),
                        'note': 'wire-format dicts -> page-locked staging (dc_pack_rows, DC_PACK_THREADS host threads) -> HBM (engine.pack_rollouts); '
-                               'not part of `value`'},
+                               'serialised = one after the other; overlapped = a host thread packs the next batch on its own stream while the GPU '
+                               'works on the current one (the timed steps repeated that way); not part of `value`'},
             'publish': {'ms_per_publish': publish_ms,
                         'note': 'model publish once per iteration (optimizer.py:697-716): D2H + torch.save of the 34-tensor state_dict; '
                                 'flat_snapshot = one asynchronous copy of the flat buffer into page-locked memory (Engine.start_param_snapshot), '
