@@ -137,7 +137,7 @@ class DotaOptimizer:
 
     def __init__(self, rmq_host, rmq_port, epochs, min_seq_per_epoch, seq_len, learning_rate, checkpoint,
                  pretrained_model, mq_prefetch_count, log_dir, entropy_coef, vf_coef, run_local,
-                 mq=None, metrics_sink=None, cell='gru', hidden=256, layers=1, device='cuda:0'):
+                 mq=None, metrics_sink=None, cell='gru', hidden=256, layers=1, device='cuda:0', reuse_rollout_forward=True):
         self.rmq_host, self.rmq_port = rmq_host, rmq_port
         self.epochs, self.min_seq_per_epoch, self.seq_len = epochs, min_seq_per_epoch, seq_len
         self.learning_rate, self.checkpoint = learning_rate, checkpoint
@@ -159,6 +159,10 @@ class DotaOptimizer:
         self.policy = self.policy_base
         self.engine = self.policy_base.engine
         self.device = self.engine.device
+        # run()'s first epoch evaluates the policy on the weights experiences_from_rollout has just used (optimizer.py:328-430, then
+        # :581-689): the engine back-propagates those activations instead of recomputing the same forward (Engine.reuse_rollout_forward;
+        # results equal, one forward pass in five saved).  False restores the reference's pass count.
+        self.engine.reuse_rollout_forward = bool(reuse_rollout_forward)
 
         if pretrained_model is not None:                                    # optimizer.py:264-267 (a local file)
             self.policy_base.load_state_dict(torch.load(pretrained_model, map_location='cpu'), strict=False)
