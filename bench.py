@@ -17,7 +17,12 @@ shard as `weak_scaling_unit` so that a scaling efficiency can be formed from lik
 (LSTM-128, 64 x 256) and the reference's own GRU-256 on the same batch are measured as `secondary` lines at N = 1.
 Padded steps would count as steps as in the reference (optimizer.py:486); the throughput runs have none.
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the launch stream in one
+Prints ONE JSON line (rank 0) and flushes it BEFORE anything optional runs: timed loop -> status check -> profile iteration
+-> cpu_baseline / parity -> print.  Side measurements (ingest, publish, hipGraph replay, reuse-forward, the other
+single-GPU configurations) only run with `--extras`, in a SUBPROCESS, after the line is out; their JSON goes to
+`--extras-out` (default gpurun_out/bench_extras.json) and to stderr - a failure there cannot cost the headline (round 2's
+BENCH_r02 died in such a side workload with the headline still unprinted; profiles/r03/crash_bisect.md).
+`roofline` is measured live with HIP events on the launch stream in one
 extra, untimed iteration right after the timed region; `cpu_baseline` times the CPU oracle
 (oracle/, restatement of the reference - kind "port") on the host cores, rank 0, N = 1 only, on one full step of the
 same workload - and the same oracle run is the checker of `parity`: advantages, returns, old log-probs, the losses /
@@ -86,8 +91,8 @@ def pmc_traffic(path, kernel, workload_key):
     if j.get('meta', {}).get('workload') not in (None, workload_key):
         return None
     # profiling region -> kernel(s) that run inside it (the first one present in the summary wins)
-    region_kernels = {'gru_fwd_team': ['rnn_team_fwd'], 'gru_bwd_team': ['rnn_team_bwd'],
-                      'lstm_fwd_team': ['lstm_team_mfma_fwd', 'rnn_team_fwd'], 'lstm_bwd_team': ['lstm_team_mfma_bwd', 'rnn_team_bwd'],
+    region_kernels = {'gru_fwd_team': ['team_mfma_fwd', 'rnn_team_fwd'], 'gru_bwd_team': ['team_mfma_bwd', 'rnn_team_bwd'],
+                      'lstm_fwd_team': ['team_mfma_fwd', 'rnn_team_fwd'], 'lstm_bwd_team': ['team_mfma_bwd', 'rnn_team_bwd'],
                       'lstm_fwd_persist': ['lstm_fwd_valu'], 'lstm_bwd_persist': ['lstm_bwd_valu'],
                       'gemm_f32_dW': ['gemm_x3'], 'gemm_f32_fwd': ['gemm_fast'], 'gemm_f32_dX': ['gemm_fast']}
     for cand in region_kernels.get(kernel, [kernel]):
@@ -95,6 +100,25 @@ def pmc_traffic(path, kernel, workload_key):
         if k:
             return int(k['bytes'])
     return None
+
+
+def pmc_whole_step(path, workload_key, passes_per_step):
+    """Sum over the library's kernels of (HBM bytes per launch x launches) / iterations in the PMC summary: the HBM traffic of one
+    bench step.  The number of iterations the profiled run made is recovered from the fused embedding forward, which runs once per pass."""
+    try:
+        with open(path) as f:
+            j = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if j.get('meta', {}).get('workload') not in (None, workload_key):
+        return None
+    ks = j.get('kernels', {})
+    ref = ks.get('embed_fwd_fused_kernel')
+    if not ref or not ref.get('launches'):
+        return None
+    iters = ref['launches'] / float(passes_per_step)
+    total = sum(v['bytes'] * v['launches'] for k, v in ks.items() if k.endswith('_kernel') and not k.startswith(('void', 'at::', '__amd')))
+    return total / iters
 
 
 def _tensor_samples(t, stride=251):
@@ -123,10 +147,11 @@ def hip_parity_iteration(eng, batch, S, E, lr, ent, vf, hook=None):
 
 
 def cpu_baseline(cell, hidden, layers, rollouts, seq_len, epochs, lr, ent, vf):
-    """Times the CPU oracle (kind "port") on the same synthetic workload: one rollout pass + `epochs`
-    epochs = one bench step, and returns what that run computed (the checker side of `parity`).  Thread count: the best
-    of a short sweep (torch CPU ops of this size get slower, not faster, when spread over all 256 host threads of the
-    GPU box)."""
+    """Times the CPU oracle (kind "port") on the same synthetic workload.  First ONE full bench step (rollout pass + `epochs`
+    epochs over all trajectories): that run is the checker side of `parity` and the warm-up; then a BOUNDED sample - the first 64
+    trajectories of the same batch, one full step, three times - whose best is `value` (best of 3 after a
+    warm-up).  Thread count: the best of a short sweep (torch CPU ops of this size get slower, not faster, when spread over all
+    host threads of the GPU box)."""
     from oracle import ref_optimizer as RO
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     sd = synth.init_state_dict(7, cell, hidden, layers)
@@ -160,20 +185,27 @@ def cpu_baseline(cell, hidden, layers, rollouts, seq_len, epochs, lr, ent, vf):
 
     cands = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 8)})
     best, best_t = cands[0], None
-    for t in cands:                                   # short sweep on 4 trajectories, 1 epoch
+    for t in cands:                                   # short sweep: 8 trajectories, 1 epoch, after a warm-up of the same size
         torch.set_num_threads(t)
-        one_iteration(rollouts[:2], 1)                # warm-up
-        a, b, _, _ = one_iteration(rollouts[:4], 1)
+        one_iteration(rollouts[:8], 1)
+        a, b, _, _ = one_iteration(rollouts[:8], 1)
         if best_t is None or a + b < best_t:
             best, best_t = t, a + b
     torch.set_num_threads(best)
-    t_roll, t_train, n_chunks, ref = one_iteration(rollouts, epochs, keep=True)
-    n_steps = n_chunks * seq_len
+    t_roll, t_train, n_chunks, ref = one_iteration(rollouts, epochs, keep=True)      # the checker run = full-batch warm-up
+    full_rate = n_chunks * seq_len / (t_roll + t_train)
+    sample = rollouts[:min(64, len(rollouts))]
+    rates = []
+    for _ in range(3):
+        a, b, n, _ = one_iteration(sample, epochs)
+        rates.append(n * seq_len / (a + b))
     return {
-        'value': round(n_steps / (t_roll + t_train), 1), 'unit': 'env-steps/s', 'cores': best, 'kind': 'port',
-        'sample': '1 full bench step (rollout pass %.2fs + %d epochs %.2fs) of the same %dx%d workload, run once (a repeat '
-                  'moves it by about +-10 %%); oracle/ref_optimizer.py, torch CPU fp32, %d of %d host threads (best of sweep %s)'
-                  % (t_roll, epochs, t_train, len(rollouts), seq_len, best, ncpu, cands),
+        'value': round(max(rates), 1), 'unit': 'env-steps/s', 'cores': best, 'kind': 'port',
+        'sample': 'best of 3 full steps (rollout pass + %d epochs) on the first %d of the %d trajectories x %d steps of the same workload '
+                  '(rates %s), after one full-batch step as warm-up (%.1f env-steps/s: rollout pass %.2fs + epochs %.2fs - that run is '
+                  '`parity`\'s checker); oracle/ref_optimizer.py, torch CPU fp32, %d of %d host threads (best of sweep %s)'
+                  % (epochs, len(sample), len(rollouts), seq_len, [round(r, 1) for r in rates], full_rate, t_roll, t_train, best, ncpu, cands),
+        'full_batch_once': round(full_rate, 1),
     }, ref
 
 
@@ -312,11 +344,11 @@ def run_workload(cell, hidden, layers, B, S, E, steps, warmup, dev, rank, world,
     return res
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--cell', default='lstm')
     ap.add_argument('--hidden', type=int, default=256)
     ap.add_argument('--layers', type=int, default=1)
@@ -325,17 +357,35 @@ def main():
     ap.add_argument('--seq-len', type=int, default=256)
     ap.add_argument('--epochs', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true', help='also skips `parity` (the oracle run is its checker)')
-    ap.add_argument('--no-secondary', action='store_true', help='skip the configs[1] / GRU-256 / weak-scaling-unit side measurements')
-    ap.add_argument('--no-host-extras', action='store_true',
-                    help='skip the ingest / publish timings (hundreds of small copies that would pollute a kernel trace)')
+    ap.add_argument('--extras', action='store_true',
+                    help='after the JSON line is printed and flushed: run the side measurements (ingest, publish, hipGraph replay, '
+                         'reuse-forward, the other single-GPU configurations) in a subprocess; result to --extras-out and stderr')
+    ap.add_argument('--extras-only', action='store_true', help='(what --extras runs in the subprocess) print only the side measurements')
+    ap.add_argument('--extras-out', default=os.path.join(REPO, 'gpurun_out', 'bench_extras.json'))
     ap.add_argument('--kernel-flags', type=int, default=0, help='DC_DIMS_* kernel-selection overrides (A/B measurements)')
-    ap.add_argument('--epoch-graph', type=int, default=-1,
-                    help='1: replay each epoch as ONE hipGraph launch, 0: eager launches; default: eager for the timed line, and the '
-                         'other mode is timed beside it (`epoch_graph` in the JSON)')
+    ap.add_argument('--epoch-graph', type=int, default=0, help='1: replay each epoch as ONE hipGraph launch (single GPU), 0: eager launches')
     ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'pmc_traffic_latest.json'),
                     help='per-kernel HBM bytes from the rocprofv3 PMC passes (tools/gpu_round.sh + tools/pmc_traffic.py); '
                          'PMC counters cannot be read from inside the process, so `traffic` is taken from this file')
-    args = ap.parse_args()
+    # accepted and ignored (round-2 command lines): the side measurements are opt-in now
+    ap.add_argument('--no-secondary', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--no-host-extras', action='store_true', help=argparse.SUPPRESS)
+    return ap.parse_args()
+
+
+def check_status(res, what):
+    """Stops the bench the moment a workload reports a non-zero status word (1 NaN loss, 2 NaN gradient norm, >= 16 a team kernel
+    that timed out: include/dotaclient_hip.h) instead of timing garbage."""
+    st = res['status']
+    if st != 0:
+        from dotaclient_amd.engine import describe_status
+        sys.stderr.write('bench.py: %s ended with status %s\n' % (what, describe_status(res['eng'])))
+        sys.stderr.flush()
+        sys.exit(4)
+
+
+def main():
+    args = parse_args()
     global KERNEL_FLAGS, USE_GRAPHS, REUSE_FORWARD
     KERNEL_FLAGS = args.kernel_flags
     USE_GRAPHS = args.epoch_graph == 1
@@ -359,144 +409,26 @@ def main():
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node = --gpus'
     dev = torch.device('cuda', dev_index)
     S, E = args.seq_len, args.epochs
-    default_family = (args.cell, args.hidden, args.layers, S) == ('lstm', 256, 1, 256) and args.batch == 0
     B = args.batch if args.batch > 0 else (256 if world == 1 else 128)
+
+    if args.extras_only:
+        extras = side_measurements(args, dev, B, S, E)
+        print(json.dumps(extras))
+        sys.stdout.flush()
+        return
 
     hook_factory = None
     if world > 1:
         from dotaclient_amd.distributed import FlatGradAllReducer
         hook_factory = FlatGradAllReducer
+    want_cpu = world == 1 and rank == 0 and not args.no_cpu_baseline
     main_run = run_workload(args.cell, args.hidden, args.layers, B, S, E, args.steps, args.warmup, dev, rank, world, hook_factory,
-                            want_parity=(world == 1 and rank == 0 and not args.no_cpu_baseline), want_profile=True)
-    eng, rollouts, batch = main_run['eng'], main_run['rollouts'], main_run['batch']
+                            want_parity=want_cpu, want_profile=True)
+    check_status(main_run, 'the timed workload')
+    eng, rollouts = main_run['eng'], main_run['rollouts']
     elapsed, status, losses, regions = main_run['elapsed'], main_run['status'], main_run['losses'], main_run['regions']
     rollout_ms, epochs_ms = main_run['rollout_ms'], main_run['epochs_ms']
     lr, ent, vf = main_run['lr'], main_run['ent'], main_run['vf']
-
-    # host -> device ingest of one batch (pack_rollouts: page-locked staging + 4 H2D copies), steady state; reported
-    # beside the headline, never inside it (inputs are resident in HBM when the timed region starts)
-    ingest_ms = ingest_overlap_ms = None
-    if rank == 0 and not args.no_host_extras:
-        for _ in range(2):
-            pack_rollouts(rollouts, S, dev)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            pack_rollouts(rollouts, S, dev)
-        torch.cuda.synchronize()
-        ingest_ms = (time.perf_counter() - t0) / 3 * 1e3
-        # ... and the way a consumer loop runs it: a host thread packs the NEXT batch (own stream for its H2D copies) while the GPU
-        # works on the current one - the timed steps again, with that thread packing one batch per step
-        if world == 1:
-            import threading
-            side = torch.cuda.Stream(device=dev)
-            go, done, stop = threading.Semaphore(0), threading.Semaphore(0), []
-
-            def feeder():
-                torch.cuda.set_device(dev)
-                while True:
-                    go.acquire()
-                    if stop:
-                        return
-                    with torch.cuda.stream(side):
-                        pack_rollouts(rollouts, S, dev)
-                    side.synchronize()
-                    done.release()
-
-            th = threading.Thread(target=feeder, daemon=True)
-            th.start()
-            step_fn = main_run['step']
-            for _ in range(2):
-                go.release(); step_fn(); done.acquire()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                go.release()
-                step_fn()
-                done.acquire()          # the next batch must be there before the next step could start
-            torch.cuda.synchronize()
-            ingest_overlap_ms = (time.perf_counter() - t0) / args.steps * 1e3
-            stop.append(1); go.release(); th.join()
-
-    # model publish (optimizer.py:697-716, once per iteration): flat snapshot D2H + host views vs per-tensor .cpu() copies;
-    # reported beside the headline, not inside it
-    publish_ms = None
-    if rank == 0 and not args.no_host_extras:
-        import io
-
-        def pub_flat():
-            i = eng.start_param_snapshot()
-            buf = io.BytesIO()
-            torch.save(eng.snapshot_state_dict(i), buf)
-
-        def pub_per_tensor():
-            buf = io.BytesIO()
-            torch.save({k: v.cpu() for k, v in eng.state_dict().items()}, buf)
-
-        samples = {'flat_snapshot': [], 'per_tensor_copies': []}
-        for it in range(17):                      # interleaved, median: single samples of host-side work scatter by 10x
-            for name, fn in (('flat_snapshot', pub_flat), ('per_tensor_copies', pub_per_tensor)):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                fn()
-                if it >= 2:
-                    samples[name].append((time.perf_counter() - t0) * 1e3)
-        publish_ms = {k: round(float(np.median(v)), 3) for k, v in samples.items()}
-
-    # ---- the same workload with each epoch replayed as one hipGraph launch (or eagerly, if the timed line used graphs) -----
-    epoch_graph = None
-    if world == 1 and args.epoch_graph == -1 and not args.no_secondary:
-        USE_GRAPHS = True
-        r = run_workload(args.cell, args.hidden, args.layers, B, S, E, args.steps, args.warmup, dev, rank, world)
-        USE_GRAPHS = False
-        epoch_graph = {'eager_ms_per_step': round(elapsed / args.steps * 1e3, 3), 'graph_replay_ms_per_step': round(r['elapsed'] / args.steps * 1e3, 3),
-                       'timed_line_uses': 'eager',
-                       'note': 'Engine.train_epoch(graph=True): the ~45 launches / memsets / copies of an epoch captured once and replayed as '
-                               'ONE hipGraph launch (the rollout pass stays eager); same kernels, same order'}
-        del r
-        torch.cuda.empty_cache()
-        # ... and with the first epoch's forward taken from the rollout pass (same weights, same inputs: Engine.reuse_rollout_forward).
-        # NOT the timed line: `value` counts the reference's five forward passes per step.
-        REUSE_FORWARD = True
-        r = run_workload(args.cell, args.hidden, args.layers, B, S, E, args.steps, args.warmup, dev, rank, world)
-        REUSE_FORWARD = False
-        epoch_graph['first_epoch_reuses_rollout_forward_ms_per_step'] = round(r['elapsed'] / args.steps * 1e3, 3)
-        epoch_graph['first_epoch_reuse_note'] = ('opt-in Engine.reuse_rollout_forward: epoch 0 runs on the weights the rollout pass has just used '
-                                                 '(optimizer.py:328-430 then :581-689), so its forward is skipped and the rollout pass\'s activations '
-                                                 'are back-propagated; four forward passes per step instead of five, results equal (tests/test_gpu_parity.py)')
-        del r
-        torch.cuda.empty_cache()
-
-    # ---- side measurements at N = 1: the other BASELINE.json single-GPU configurations and the weak-scaling unit --------
-    secondary = None
-    if world == 1 and default_family and not args.no_secondary:
-        secondary = {}
-        for key, (c, h, b, what) in {
-                'weak_scaling_unit': ('lstm', 256, 128, "configs[3]'s per-GPU shard (128 trajectories x 256 steps, LSTM-256) on ONE GPU, "
-                                                        'no all-reduce: the N = 1 reference point for the N > 1 lines of this script'),
-                'configs[1]': ('lstm', 128, 64, 'BASELINE.json configs[1]: 1v1-mid, LSTM-128, 64 trajectories x 256 steps'),
-                'reference_gru256_64x256': ('gru', 256, 64, "configs[1]'s batch on the reference's own cell (GRU-256, policy.py:66)")}.items():
-            r = run_workload(c, h, 1, b, S, E, args.steps, args.warmup, dev, rank, world)
-            secondary[key] = {'workload': what, 'value': round(b * S * args.steps / r['elapsed'], 1), 'unit': 'env-steps/s',
-                              'ms_per_step': round(r['elapsed'] / args.steps * 1e3, 3), 'nan_status': r['status']}
-            del r
-            torch.cuda.empty_cache()
-        # the reference's production shape (optimizer.py:776-794 defaults: seq_len 16, whole rollouts until >= 1024 chunks, its own
-        # GRU-256): ragged rollouts, a row count that is a multiple of 16 only - the fused embedding kernels run on padded blocks
-        rng = np.random.Generator(np.random.PCG64(99))
-        lens, chunks = [], 0
-        while chunks < 1024:
-            t = int(rng.integers(100, 900))
-            lens.append(t)
-            chunks += (t + 15) // 16
-        r = run_workload('gru', 256, 1, len(lens), 16, E, args.steps, args.warmup, dev, rank, world, lengths=lens)
-        secondary['reference_defaults_gru256_s16_ragged'] = {
-            'workload': "the reference's own defaults: GRU-256, seq_len 16, %d ragged rollouts (100..899 steps) = %d chunks of 16 = %d env-steps "
-                        '(a multiple of 16, not of 128)' % (len(lens), chunks, chunks * 16),
-            'value': round(chunks * 16 * args.steps / r['elapsed'], 1), 'unit': 'env-steps/s',
-            'ms_per_step': round(r['elapsed'] / args.steps * 1e3, 3), 'nan_status': r['status']}
-        del r
-        torch.cuda.empty_cache()
 
     if rank == 0:
         n_steps = world * B * S * args.steps
@@ -545,6 +477,9 @@ def main():
         dom_bound = REGION_BOUND.get(dom['kernel'], 'mfma')
         achieved = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
         dom_peak = mfma_peak(dom['kernel'], bool(KERNEL_FLAGS & 4096)) if dom_bound == 'mfma' else PEAK_F32_MFMA_TFLOPS
+        P = eng.total
+        alg_step_bytes = 2100.0 * (1 + E) * B * S + 28.0 * P * E            # 2.1 KB per env-step and pass + 28 B per parameter and optimizer step
+        step_traffic = pmc_whole_step(args.traffic_json, workload_key, 1 + E)
         roofline = {'bound': dom_bound, 'bound_note': BOUND_NOTES[dom_bound], 'kernel': dom['kernel'],
                     'achieved': round(achieved, 3), 'peak': round(dom_peak, 1),
                     'unit': 'TFLOP/s', 'frac': round(achieved / dom_peak, 4),
@@ -555,15 +490,21 @@ def main():
                     'flops_per_launch': dom['flops'] / dom['launches'],
                     'whole_step': {'flops_per_env_step_dense': ffwd * (1 + 3 * E),
                                    'effective_tflops_dense_count': round(value / world * ffwd * (1 + 3 * E) / 1e12, 3),
+                                   'hbm_traffic_bytes': None if step_traffic is None else round(step_traffic),
+                                   'algorithmic_bytes': round(alg_step_bytes),
+                                   'traffic_over_algorithmic': None if step_traffic is None else round(step_traffic / alg_step_bytes, 1),
                                    'note': 'steps/s x the reference\'s DENSE flop count (SURVEY.md 8(d)); the sparse max-pool backward '
                                            'executes 1/16 of the dense MACs of the 16-unit types, so this is an effective rate, not pipe '
-                                           'utilisation - per-kernel utilisation is in `kernels`'},
+                                           'utilisation - per-kernel utilisation is in `kernels`; hbm_traffic_bytes = sum over kernels of '
+                                           'PMC bytes x launches per step, algorithmic_bytes = SURVEY.md 8(d)\'s per-unit figures x this batch'},
                     'kernels': kernels}
         key = (args.cell, args.hidden, args.layers, B, S, world > 1)
         which = {('lstm', 256, 1, 256, 256, False): 'BASELINE.json configs[2] (5v5 synthetic, LSTM hidden=256, batch=256x256 steps, 1xMI355X)',
                  ('lstm', 256, 1, 128, 256, True): "BASELINE.json configs[3] geometry (5v5 synthetic, LSTM hidden=256, 128 trajectories x 256 "
                                                    'steps per GPU = 1024x256 at DP=8, RCCL gradient all-reduce every epoch)',
+                 ('lstm', 256, 1, 128, 256, False): "BASELINE.json configs[3]'s per-GPU shard on one GPU (128 trajectories x 256 steps, no all-reduce)",
                  ('lstm', 128, 1, 64, 256, False): 'BASELINE.json configs[1] (1v1-mid, LSTM hidden=128, batch=64x256 steps)',
+                 ('lstm', 512, 2, 256, 512, False): "BASELINE.json configs[4]'s per-GPU shard on one GPU (2-layer LSTM-512, 256 trajectories x 512 steps)",
                  ('gru', 256, 1, 64, 256, False): "configs[1]'s batch with the reference's own cell (GRU-256, policy.py:66)"}.get(
                      key, 'other configuration (not a BASELINE.json bench line)')
         line = {
@@ -572,7 +513,7 @@ def main():
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None,
             'dtype': 'bf16' if KERNEL_FLAGS & 4096 else 'f32',
-            'dtype_note': 'DC_DIMS_BF16: bf16 operands / f32 accumulate in the dense products, f32 elsewhere' if KERNEL_FLAGS & 4096 else
+            'dtype_note': 'DC_DIMS_BF16: bf16 operands / f32 accumulate in the dense products and the recurrent products, f32 elsewhere' if KERNEL_FLAGS & 4096 else
                           'f32 end to end: inputs, weights, activations, gradients and optimizer state are f32 and every product is f32-grade '
                           '(matrix products: exact 3-way bf16 splits of both f32 operands, six bf16 MFMAs, f32 accumulate - error vs f64 '
                           '1.4e-7..5.5e-7 of max |C| on the network\'s shapes, the f32 fma chain 2.1e-7..3.7e-7; tools/ubench/gemm_x3.hip); '
@@ -582,7 +523,7 @@ def main():
                                    'batch=%d trajectories x %d steps per GPU, %d epochs + rollout pass per step'
                                    % (which, args.cell.upper(), args.hidden, args.layers, B, S, E),
                        'cell': args.cell, 'hidden': args.hidden, 'layers': args.layers, 'batch_per_gpu': B,
-                       'seq_len': S, 'epochs': E, 'parallelism': 'dp%d' % world},
+                       'seq_len': S, 'epochs': E, 'parallelism': 'dp%d' % world, 'epoch_launch': 'hipGraph replay' if USE_GRAPHS else 'eager'},
             'phases': {'rollout_pass_ms': round(rollout_ms, 3), 'epoch_ms': round(epochs_ms / E, 3),
                        'train_only_env_steps_per_s_per_gpu': round(B * S / (epochs_ms / E * 1e-3), 1),
                        'note': 'one untimed iteration on rank 0: no-grad forward + old log-probs + GAE, then the mean of the %d '
@@ -590,33 +531,142 @@ def main():
             'roofline': roofline,
             'roofline_hbm': roofline_hbm,
             'nan_status': status, 'final_loss': float(losses[0]),
-            'secondary': secondary,
-            'epoch_graph': epoch_graph,
-            'ingest': None if ingest_ms is None else {
-                       'pack_h2d_ms_per_batch': round(ingest_ms, 3),
-                       'env_steps_per_s_with_ingest_serialised': round(B * S / (elapsed / args.steps + ingest_ms * 1e-3), 1),
-                       'ms_per_step_with_next_batch_packed_concurrently': None if ingest_overlap_ms is None else round(ingest_overlap_ms, 3),
-                       'env_steps_per_s_with_ingest_overlapped': None if ingest_overlap_ms is None else round(B * S / (ingest_overlap_ms * 1e-3), 1),
-                       'note': 'wire-format dicts -> page-locked staging (dc_pack_rows, DC_PACK_THREADS host threads) -> HBM (engine.pack_rollouts); '
-                               'serialised = one after the other; overlapped = a host thread packs the next batch on its own stream while the GPU '
-                               'works on the current one (the timed steps repeated that way); not part of `value`'},
-            'publish': {'ms_per_publish': publish_ms,
-                        'note': 'model publish once per iteration (optimizer.py:697-716): D2H + torch.save of the 34-tensor state_dict; '
-                                'flat_snapshot = one asynchronous copy of the flat buffer into page-locked memory (Engine.start_param_snapshot), '
-                                'per_tensor_copies = the reference\'s form; not part of `value`'},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if want_cpu:
             line['cpu_baseline'], ref = cpu_baseline(args.cell, args.hidden, args.layers, rollouts, S, E, lr, ent, vf)
             line['parity'] = parity_report(main_run['first_iteration'], ref)
         else:
             line['cpu_baseline'] = None
             line['parity'] = None
         print(json.dumps(line))
+        sys.stdout.flush()                      # the headline is out before anything optional runs
         if line['parity'] is not None and not line['parity']['ok']:
             sys.stderr.write('bench.py: PARITY FAILED against the oracle: %s\n' % json.dumps(line['parity']))
             sys.exit(3)
     if world > 1:
         torch.distributed.destroy_process_group()
+    elif args.extras and rank == 0:
+        run_extras_subprocess(args)
+
+
+def run_extras_subprocess(args):
+    """The side measurements in a process of their own: whatever happens there, this process has already printed its line and exits 0."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--extras-only', '--steps', str(args.steps), '--warmup', str(args.warmup),
+           '--cell', args.cell, '--hidden', str(args.hidden), '--layers', str(args.layers), '--batch', str(args.batch),
+           '--seq-len', str(args.seq_len), '--epochs', str(args.epochs), '--kernel-flags', str(args.kernel_flags)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        out = (r.stdout.strip().splitlines() or [''])[-1]
+        if r.returncode == 0 and out.startswith('{'):
+            os.makedirs(os.path.dirname(args.extras_out), exist_ok=True)
+            with open(args.extras_out, 'w') as f:
+                f.write(out + '\n')
+            sys.stderr.write('bench.py extras: %s\n' % out)
+        else:
+            sys.stderr.write('bench.py extras: subprocess failed (rc %d): %s\n' % (r.returncode, r.stderr[-600:]))
+    except Exception as e:                                  # noqa: BLE001 - nothing here may cost the exit code
+        sys.stderr.write('bench.py extras: %r\n' % (e,))
+
+
+def side_measurements(args, dev, B, S, E):
+    """Beside the headline, never inside it (single GPU): host -> device ingest serial and through the consumer loop's own
+    prefetcher, model publish, the epochs replayed as hipGraphs, the first epoch on the rollout pass's activations, and the other
+    BASELINE.json single-GPU configurations.  Every workload's status word is checked."""
+    global USE_GRAPHS, REUSE_FORWARD
+    import io
+    out = {'steps': args.steps, 'warmup': args.warmup}
+    default_family = (args.cell, args.hidden, args.layers, S) == ('lstm', 256, 1, 256) and args.batch == 0
+
+    def timed(cell, hidden, layers, b, lengths=None, seq_len=S):
+        r = run_workload(cell, hidden, layers, b, seq_len, E, args.steps, args.warmup, dev, 0, 1, lengths=lengths)
+        check_status(r, 'side workload %s-%d x%d B=%d S=%d graphs=%s reuse=%s' % (cell, hidden, layers, b, seq_len, USE_GRAPHS, REUSE_FORWARD))
+        ms = r['elapsed'] / args.steps * 1e3
+        eng, rollouts = r['eng'], r['rollouts']
+        return ms, eng, rollouts
+
+    base_ms, eng, rollouts = timed(args.cell, args.hidden, args.layers, B)
+    out['eager_ms_per_step'] = round(base_ms, 3)
+
+    # ---- ingest: wire-format dicts -> pinned staging -> HBM -------------------------------------------------------------------------
+    for _ in range(2):
+        pack_rollouts(rollouts, S, dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        pack_rollouts(rollouts, S, dev)
+    torch.cuda.synchronize()
+    ingest_ms = (time.perf_counter() - t0) / 3 * 1e3
+    out['ingest'] = {'pack_h2d_ms_per_batch': round(ingest_ms, 3),
+                     'env_steps_per_s_with_ingest_serialised': round(B * S / ((base_ms + ingest_ms) * 1e-3), 1),
+                     'note': 'wire-format dicts -> page-locked staging (dc_pack_rows, DC_PACK_THREADS host threads) -> HBM (engine.pack_rollouts); '
+                             'the consumer loop overlaps it with the previous iteration\'s epochs (DotaOptimizer prefetch: '
+                             'tests/test_gpu_api.py); not part of `value`'}
+
+    # ---- model publish (optimizer.py:697-716, once per iteration) ---------------------------------------------------------------
+    def pub_flat():
+        i = eng.start_param_snapshot()
+        buf = io.BytesIO()
+        torch.save(eng.snapshot_state_dict(i), buf)
+
+    def pub_per_tensor():
+        buf = io.BytesIO()
+        torch.save({k: v.cpu() for k, v in eng.state_dict().items()}, buf)
+
+    samples = {'flat_snapshot': [], 'per_tensor_copies': []}
+    for it in range(17):                      # interleaved, median: single samples of host-side work scatter by 10x
+        for name, fn in (('flat_snapshot', pub_flat), ('per_tensor_copies', pub_per_tensor)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            if it >= 2:
+                samples[name].append((time.perf_counter() - t0) * 1e3)
+    out['publish'] = {'ms_per_publish': {k: round(float(np.median(v)), 3) for k, v in samples.items()},
+                      'note': 'D2H + torch.save of the 34-tensor state_dict; flat_snapshot = one asynchronous copy of the flat buffer into '
+                              'page-locked memory (Engine.start_param_snapshot), per_tensor_copies = the reference\'s form'}
+    del eng
+    torch.cuda.empty_cache()
+
+    # ---- epochs as hipGraph replays; first epoch on the rollout pass's activations ---------------------------------------------------
+    USE_GRAPHS = True
+    g_ms, _, _ = timed(args.cell, args.hidden, args.layers, B)
+    USE_GRAPHS = False
+    torch.cuda.empty_cache()
+    REUSE_FORWARD = True
+    r_ms, _, _ = timed(args.cell, args.hidden, args.layers, B)
+    REUSE_FORWARD = False
+    torch.cuda.empty_cache()
+    out['epoch_graph'] = {'eager_ms_per_step': round(base_ms, 3), 'graph_replay_ms_per_step': round(g_ms, 3),
+                          'first_epoch_reuses_rollout_forward_ms_per_step': round(r_ms, 3),
+                          'note': 'Engine.train_epoch(graph=True): an epoch captured once and replayed as ONE hipGraph launch (kernel nodes only: '
+                                  'csrc/fill.hip); Engine.reuse_rollout_forward: epoch 0 back-propagates the rollout pass\'s activations (four '
+                                  'forward passes per step instead of five) - opt-in, `value` counts the reference\'s five'}
+
+    # ---- the other BASELINE.json single-GPU configurations ---------------------------------------------------------------------------
+    if default_family:
+        sec = {}
+        for key, (c, h, b, what) in {
+                'weak_scaling_unit': ('lstm', 256, 128, "configs[3]'s per-GPU shard (128 trajectories x 256 steps, LSTM-256) on ONE GPU, "
+                                                        'no all-reduce: the N = 1 reference point for the N > 1 lines of this script'),
+                'configs[1]': ('lstm', 128, 64, 'BASELINE.json configs[1]: 1v1-mid, LSTM-128, 64 trajectories x 256 steps'),
+                'reference_gru256_64x256': ('gru', 256, 64, "configs[1]'s batch on the reference's own cell (GRU-256, policy.py:66)")}.items():
+            ms, _, _ = timed(c, h, 1, b)
+            sec[key] = {'workload': what, 'value': round(b * S / (ms * 1e-3), 1), 'unit': 'env-steps/s', 'ms_per_step': round(ms, 3)}
+            torch.cuda.empty_cache()
+        # the reference's production shape (optimizer.py:776-794 defaults: seq_len 16, whole rollouts until >= 1024 chunks, its own GRU-256)
+        rng = np.random.Generator(np.random.PCG64(99))
+        lens, chunks = [], 0
+        while chunks < 1024:
+            t = int(rng.integers(100, 900))
+            lens.append(t)
+            chunks += (t + 15) // 16
+        ms, _, _ = timed('gru', 256, 1, len(lens), lengths=lens, seq_len=16)
+        sec['reference_defaults_gru256_s16_ragged'] = {
+            'workload': "the reference's own defaults: GRU-256, seq_len 16, %d ragged rollouts (100..899 steps) = %d chunks of 16 = %d env-steps"
+                        % (len(lens), chunks, chunks * 16),
+            'value': round(chunks * 16 / (ms * 1e-3), 1), 'unit': 'env-steps/s', 'ms_per_step': round(ms, 3)}
+        out['secondary'] = sec
+    return out
 
 
 if __name__ == '__main__':

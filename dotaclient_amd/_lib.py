@@ -41,6 +41,8 @@ SIGNATURES = {
                               [c_flt, c_flt, c_dbl, c_dbl, c_dbl, c_flt, c_ptr]),
 }
 
+ABI_VERSION = 3      # include/dotaclient_hip.h DC_ABI_VERSION: a library built from other sources would mis-call silently
+
 _lib = None
 
 
@@ -65,6 +67,10 @@ def load():
         fn = getattr(lib, name)        # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    got = lib.dc_abi_version()
+    if got != ABI_VERSION:
+        raise DotaHipError('%s reports ABI version %d, this binding speaks %d - rebuild it (python -m dotaclient_amd.build)'
+                           % (LIB_PATH, got, ABI_VERSION))
     _lib = lib
     return lib
 

@@ -163,8 +163,7 @@ int gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const int
                        float max_norm, float vf_coef, double lr, double beta1, double beta2, float eps, hipStream_t s) {
     AdamSegs sg{seg_off, seg_len, seg_gate, n_seg};
     ProfScope prof("gradnorm_clip_adam", 0.0, 32.0 * n_seg * max_seg_len / 8, s);
-    hipError_t e = hipMemsetAsync(segsq, 0, sizeof(double) * n_seg, s);
-    if (e != hipSuccess) { set_error("adam: memset", (int)e); return (int)e; }
+    if (int rc0 = zero_async(segsq, sizeof(double) * n_seg, s)) return rc0;
     dim3 grid((max_seg_len + ADAM_CHUNK - 1) / ADAM_CHUNK, n_seg);
     hipLaunchKernelGGL(grad_sqnorm_kernel, grid, dim3(256), 0, s, sg, grad, segsq);
     hipLaunchKernelGGL(clip_finalize_kernel, dim3(1), dim3(64), 0, s, sg, segsq, head_on, losses, norms_out, ctl, seg_step,

@@ -39,7 +39,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
 
 extern "C" {
 
-int dc_abi_version(void) { return 1; }
+int dc_abi_version(void) { return DC_ABI_VERSION; }
 const char* dc_last_error(void) { return dc::g_err; }
 
 int dc_gae_scan(const float* rewards, const float* values, const int64_t* seq_off, const int32_t* seq_len,

@@ -10,6 +10,11 @@
 #ifndef DC_DEV_TIMING
 #define DC_DEV_TIMING 0
 #endif
+// 1: clear buffers with hipMemsetAsync / hipMemset2DAsync / hipMemcpyAsync instead of this library's own kernels (fill.hip) -
+// the round-2 behaviour, kept as an A/B build for the hipGraph replay fault (profiles/r03/crash_bisect.md)
+#ifndef DC_HIP_MEMSET
+#define DC_HIP_MEMSET 0
+#endif
 #ifndef DC_DEV_HOOKMODE
 #define DC_DEV_HOOKMODE 0
 #endif

@@ -558,8 +558,7 @@ int gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int 
         } else {
             if (!accumulate) {
                 // split-K accumulates with atomics: start from zero
-                hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, stream);
-                if (e != hipSuccess) { set_error("gemm_f32: memset", (int)e); return (int)e; }
+                if (int rc0 = zero2d_f32_async(C, ldc, N, M, stream)) return rc0;
             }
             a.atomic = 1;
             a.accumulate = 0;

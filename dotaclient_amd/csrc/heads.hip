@@ -460,8 +460,7 @@ int ppo_loss_fwd_bwd(const float* headout, const float* tu, const uint8_t* act, 
                      const float* adv, const float* ret, double* stats, float* dheadout, float* dtu, float* losses_out,
                      int32_t* head_on, long long nr, float e_clip, float entropy_coef, float vf_coef, hipStream_t s) {
     ProfScope prof("ppo_loss(stats+loss+finalize)", 0.0, (double)nr * (4.0 * (26 + 40 + 5 + 2) + 2.0 * 65 + 4.0 * (32 + 40)), s);
-    hipError_t e = hipMemsetAsync(stats, 0, ST_COUNT * sizeof(double), s);
-    if (e != hipSuccess) { set_error("ppo_loss: memset", (int)e); return (int)e; }
+    if (int rc0 = zero_async(stats, ST_COUNT * sizeof(double), s)) return rc0;
     hipLaunchKernelGGL(batch_stats_kernel, dim3(grid1d(nr, 256, 1024)), dim3(256), 0, s, adv, act, stats, nr);
     LossArgs a;
     a.headout = headout; a.tu = tu; a.act = act; a.mask = mask; a.old_logp = old_logp; a.adv = adv; a.ret = ret;

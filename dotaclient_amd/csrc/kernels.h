@@ -11,6 +11,8 @@ struct RnnStepArgs {
     int n_seq, H, t;
     int flags;             // dc_dims.flags (DC_DIMS_* kernel-selection overrides)
     void* xbuf;            // DC_WS_TEAM_XBUF: exchange ring of the H = 256 team kernels (caller workspace)
+    int* fault;            // DC_WS_FAULT: sticky fault record (nullptr: none)
+    int layer;             // which recurrent layer this call works on (reported in the fault record)
     // forward
     const float* Whh;      // [G*H][H]
     const uint16_t* Whh_bf;   // bf16 mode: W_hh as bf16 [G*H][H] (nullptr: not provided)
@@ -33,6 +35,11 @@ struct RnnStepArgs {
     float* dgh;            // [rows][G*H] grad wrt (W_hh h + b_hh)   (GRU; LSTM: == dgx)
     long long* dbg;        // DC_LSTM_TIMING=1: phase cycle sums of workgroup 0 (else nullptr)
 };
+
+// fill.hip: zero-fill / small copies as kernels of this library (a captured epoch holds kernel nodes only)
+int zero_async(void* p, size_t bytes, hipStream_t s);
+int zero2d_f32_async(float* p, long long ld, int width, long long rows, hipStream_t s);
+int copy_f32_async(float* dst, const float* src, long long n, hipStream_t s);
 
 // prof.hip (inert unless dc_profile_enable(1))
 bool prof_enabled();

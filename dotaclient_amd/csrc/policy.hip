@@ -71,6 +71,7 @@ int64_t workspace_layout(const dc_dims* d, int64_t* out) {
     (void)B;
     int64_t off = 0;
     auto put = [&](int idx, int64_t bytes) { out[idx] = off; off = align_up(off + bytes); };
+    put(DC_WS_FAULT, 8 * 4);                      // always at offset 0: the sticky fault record (header)
     put(DC_WS_BASIC, NR * 40 * EMBW * 4);
     put(DC_WS_EMB, NR * 40 * EMBW * 4);
     put(DC_WS_DEMB, NR * 40 * EMBW * 4);
@@ -215,6 +216,7 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
         a.c0 = (c0 && d->cell == 1) ? c0 + (size_t)l * B * H : nullptr;
         a.seq_off = seq_off; a.seq_len = seq_len; a.n_seq = B; a.H = H;
         a.flags = d->flags; a.xbuf = w.base + w.off[DC_WS_TEAM_XBUF];
+        a.fault = reinterpret_cast<int*>(w.base + w.off[DC_WS_FAULT]); a.layer = l;
         a.Whh = P.p(pb + 1); a.bhh = P.p(pb + 3);
         a.Whh_bf = hh_bf ? wp.fwd(wp.hh[l]) : nullptr;
         a.stepbf = reinterpret_cast<uint16_t*>(w.fl(l, DC_WSL_HN));
@@ -251,8 +253,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     const bool do_upper = !(d->flags & DC_DIMS_BWD_EMBED) || (d->flags & DC_DIMS_BWD_UPPER);
     const bool do_embed = !(d->flags & DC_DIMS_BWD_UPPER) || (d->flags & DC_DIMS_BWD_EMBED);
     if (do_upper) {
-        hipError_t e = hipMemsetAsync(grads, 0, (size_t)total_floats * sizeof(float), s);
-        if (e != hipSuccess) { set_error("policy_backward: memset", (int)e); return (int)e; }
+        DC_TRY(zero_async(grads, (size_t)total_floats * sizeof(float), s));
     }
     if (d->rows <= 0 || d->n_seq <= 0) return 0;
     Ws w; w.base = (char*)ws_base; workspace_layout(d, w.off);
@@ -332,6 +333,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         RnnStepArgs a{};
         a.seq_off = seq_off; a.seq_len = seq_len; a.n_seq = B; a.H = H;
         a.flags = d->flags; a.xbuf = w.base + w.off[DC_WS_TEAM_XBUF];
+        a.fault = reinterpret_cast<int*>(w.base + w.off[DC_WS_FAULT]); a.layer = l;
         a.gates = w.fl(l, DC_WSL_GATES); a.hn = w.fl(l, DC_WSL_HN); a.hseq = w.fl(l, DC_WSL_HSEQ);
         a.hprev = w.fl(l, DC_WSL_HPREV); a.cseq = w.fl(l, DC_WSL_CSEQ); a.cprev = w.fl(l, DC_WSL_CPREV);
         a.WhhT_bf = hh_bf ? wp.bwd(wp.hh[l]) : nullptr;
@@ -346,8 +348,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         if (a.dgh == a.dgx) {   // LSTM: both products contract the same gate gradients - one launch
             DC_TRY(wgrad(a.dgx, G * H, G * H, xin, in, Gd.p(pb + 0), a.hprev, H, Gd.p(pb + 1), Gd.p(pb + 2)));
             // dgh is dgx, so d(b_hh) = d(b_ih): copy 2 KB
-            hipError_t ec = hipMemcpyAsync(Gd.p(pb + 3), Gd.p(pb + 2), (size_t)G * H * sizeof(float), hipMemcpyDeviceToDevice, s);
-            if (ec != hipSuccess) { set_error("policy_backward: bias gradient copy", (int)ec); return (int)ec; }
+            DC_TRY(copy_f32_async(Gd.p(pb + 3), Gd.p(pb + 2), (long long)G * H, s));
         } else {
             DC_TRY(wgrad(a.dgx, G * H, G * H, xin, in, Gd.p(pb + 0), nullptr, 0, nullptr, Gd.p(pb + 2)));
             DC_TRY(wgrad(a.dgh, G * H, G * H, a.hprev, H, Gd.p(pb + 1), nullptr, 0, nullptr, Gd.p(pb + 3)));
@@ -378,9 +379,8 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         // padding steps of the type-major d(emb) blocks the dense kernels read: zero gradients
         for (int t = 0; t < 6; ++t) {
             if (sparse16 && (t == 2 || t == 3)) continue;
-            hipError_t e = hipMemsetAsync(w.f(DC_WS_DEMB) + ((size_t)NRp * T_CUM[t] + (size_t)NR * T_UNITS[t]) * EMBW, 0,
-                                          (size_t)(NRp - NR) * T_UNITS[t] * EMBW * sizeof(float), s);
-            if (e != hipSuccess) { set_error("policy_backward: d(emb) padding memset", (int)e); return (int)e; }
+            DC_TRY(zero_async(w.f(DC_WS_DEMB) + ((size_t)NRp * T_CUM[t] + (size_t)NR * T_UNITS[t]) * EMBW,
+                              (size_t)(NRp - NR) * T_UNITS[t] * EMBW * sizeof(float), s));
         }
     }
     if (fusedb) {

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(512) void rnn_team_fwd_kernel(RnnStepArgs p, u64* _
                 stamp(1);                                          // first read back
                 if ((unsigned)(g >> 32) != tag[s]) tm[5] += 1;     // ... and it was stale
             }
-            if (!granule_wait(g, gptr, tag[s], v)) dead = 1;
+            if (!granule_wait(g, gptr, tag[s], v)) { dead = 1; team_report_timeout(p.fault, TEAM_K_VALU_FWD, p.layer, team, member, t, sq[s], tag[s]); }
             h_lds[s][par][pidx] = v;
         }
         stamp(2);      // spinning
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(512) void rnn_team_bwd_kernel(RnnStepArgs p, u64* _
                 ok = granule_wait(g1, base + i1, tag[s], v1) && ok;
                 g_lds[s][cur][i1] = v1;
             }
-            if (!ok) dead = 1;
+            if (!ok) { dead = 1; team_report_timeout(p.fault, TEAM_K_VALU_BWD, p.layer, team, member, t, sq[s], tag[s]); }
         }
         pre_owner = -1;
         __syncthreads();
@@ -614,7 +614,7 @@ int rnn_team_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     const double G = cell == CELL_GRU ? 3 : 4;
     ProfScope prof(cell == CELL_GRU ? "gru_fwd_team" : "lstm_fwd_team", 2.0 * a.n_seq * G * a.H * a.H * max_len,
                    4.0 * a.n_seq * max_len * a.H * (2.0 * G + 4.0), s);
-    if (hipMemsetAsync(xb, 0, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * TEAM_M + (size_t)nt * ns * TEAM_SLOTS * TEAM_H) * sizeof(u64), s) != hipSuccess) return launch_check("rnn_team_forward memset");
+    if (int rc = zero_async(xb, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * TEAM_M + (size_t)nt * ns * TEAM_SLOTS * TEAM_H) * sizeof(u64), s)) return rc;
     constexpr bool timing = DC_DEV_TIMING != 0;
     if (timing && cell == CELL_LSTM && (ns == 1 || ns == 4)) {   // debugging aid: phase cycles of one wave, printed per launch
         static long long* dbg = nullptr;
@@ -643,7 +643,7 @@ int rnn_team_backward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     const double G = cell == CELL_GRU ? 3 : 4;
     ProfScope prof(cell == CELL_GRU ? "gru_bwd_team" : "lstm_bwd_team", 2.0 * a.n_seq * G * a.H * a.H * max_len,
                    4.0 * a.n_seq * max_len * a.H * (3.0 * G + 6.0), s);
-    if (hipMemsetAsync(xb, 0, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * TEAM_M + (size_t)nt * ns * TEAM_SLOTS * 4 * TEAM_H) * sizeof(u64), s) != hipSuccess) return launch_check("rnn_team_backward memset");
+    if (int rc = zero_async(xb, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * TEAM_M + (size_t)nt * ns * TEAM_SLOTS * 4 * TEAM_H) * sizeof(u64), s)) return rc;
     if (cell == CELL_GRU) launch_team_bwd<CELL_GRU>(ns, nt, a, xb, s);
     else launch_team_bwd<CELL_LSTM>(ns, nt, a, xb, s);
     return launch_check("rnn_team_backward");

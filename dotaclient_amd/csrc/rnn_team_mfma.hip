@@ -171,7 +171,7 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_kernel(RnnStepArg
                 for (int j = 1; j < TEAM_M; ++j) {
                     const int uu = TEAM_US * ((member + j) & 3) + ul;
                     float v = 0.f;
-                    if (!granule_wait(gr[j - 1], xb + (tag & 3) * H + uu, tag, v)) dead = 1;
+                    if (!granule_wait(gr[j - 1], xb + (tag & 3) * H + uu, tag, v)) { dead = 1; team_report_timeout(p.fault, TEAM_K_MFMA_FWD, p.layer, team, member, t, b, tag); }
                     h_lds[cur ^ 1][tm_hpos(slot, uu)] = v;
                 }
             }
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_bwd_kernel(RnnStepArg
 #pragma unroll
                 for (int j = 1; j < TEAM_M; ++j) {
                     float v = 0.f;
-                    if (!granule_wait(gr[j - 1], ring + ((size_t)(member * 4 + ((member + j) & 3)) * 4 + slot) * TEAM_US + ul, tag, v)) dead = 1;
+                    if (!granule_wait(gr[j - 1], ring + ((size_t)(member * 4 + ((member + j) & 3)) * 4 + slot) * TEAM_US + ul, tag, v)) { dead = 1; team_report_timeout(p.fault, TEAM_K_MFMA_BWD, p.layer, team, member, t, b, tag); }
                     rec += v;
                 }
             }
@@ -406,8 +406,7 @@ int lstm_team_mfma_forward(int cell, RnnStepArgs a, int max_len, int n_teams, hi
     const int nt = team_mfma_plan(a.n_seq, n_teams, rounds);
     const double G = cell == 1 ? 4.0 : 3.0;
     ProfScope prof(cell == 1 ? "lstm_fwd_team" : "gru_fwd_team", 2.0 * a.n_seq * G * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * (2.0 * G + 4.0), s);
-    if (hipMemsetAsync(xb, 0, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * TEAM_M + (size_t)nt * 4 * TEAM_SLOTS * TEAM_H) * sizeof(u64), s) != hipSuccess)
-        return launch_check("lstm_team_mfma_forward memset");
+    if (int rc = zero_async(xb, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * TEAM_M + (size_t)nt * 4 * TEAM_SLOTS * TEAM_H) * sizeof(u64), s)) return rc;
     if (cell == 1) hipLaunchKernelGGL(team_mfma_fwd_kernel<1>, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
     else hipLaunchKernelGGL(team_mfma_fwd_kernel<0>, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
     return launch_check("lstm_team_mfma_forward");
@@ -420,8 +419,7 @@ int lstm_team_mfma_backward(int cell, RnnStepArgs a, int max_len, int n_teams, h
     const int nt = team_mfma_plan(a.n_seq, n_teams, rounds);
     const double G = cell == 1 ? 4.0 : 3.0;
     ProfScope prof(cell == 1 ? "lstm_bwd_team" : "gru_bwd_team", 2.0 * a.n_seq * G * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * (3.0 * G + 6.0), s);
-    if (hipMemsetAsync(xb, 0, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * TEAM_M + (size_t)nt * 4 * TEAM_SLOTS * 4 * TEAM_H) * sizeof(u64), s) != hipSuccess)
-        return launch_check("lstm_team_mfma_backward memset");
+    if (int rc = zero_async(xb, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * TEAM_M + (size_t)nt * 4 * TEAM_SLOTS * 4 * TEAM_H) * sizeof(u64), s)) return rc;
     if (cell == 1) hipLaunchKernelGGL(team_mfma_bwd_kernel<1>, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
     else hipLaunchKernelGGL(team_mfma_bwd_kernel<0>, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
     return launch_check("lstm_team_mfma_backward");

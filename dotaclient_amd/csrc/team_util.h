@@ -32,6 +32,16 @@ __device__ __forceinline__ bool granule_wait(u64 g, const u64* p, unsigned tag, 
     return true;
 }
 
+// A wait timed out: first writer wins, the record stays until the workspace's owner clears it (include/dotaclient_hip.h, DC_WS_FAULT).
+enum { TEAM_K_VALU_FWD = 1, TEAM_K_VALU_BWD = 2, TEAM_K_MFMA_FWD = 3, TEAM_K_MFMA_BWD = 4 };
+__device__ __noinline__ void team_report_timeout(int* fault, int kernel_id, int layer, int team, int member, int step, int seq, unsigned tag) {
+    if (fault == nullptr) return;
+    if (atomicCAS(&fault[0], 0, DC_FAULT_TEAM_TIMEOUT + kernel_id) == 0) {
+        fault[1] = layer; fault[2] = team; fault[3] = member; fault[4] = step; fault[5] = seq; fault[6] = (int)tag;
+        __threadfence();
+    }
+}
+
 // Which (team, member) a workgroup plays is decided when it STARTS RUNNING, by a ticket, not by its block index: the
 // first four workgroups to start form team 0, the next four team 1, ...  A workgroup that has started stays resident
 // until it exits, so every team whose four tickets are taken is fully resident and makes progress - whatever else

@@ -44,6 +44,7 @@ class FlatGradAllReducer:
         """distributed.py:71-74: every rank starts from rank 0's weights (one broadcast of the flat buffer)."""
         if self.world > 1:
             dist.broadcast(self.engine.params, src=0, group=self.group)
+            self.engine.params_changed()
 
     def _set_tail(self, engine):
         self.tail[:5] = engine.head_on[:5].to(torch.float32)

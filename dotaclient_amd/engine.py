@@ -9,6 +9,7 @@ Mirrors what the reference does implicitly through torch objects:
 """
 import ctypes
 import os
+import threading
 
 import numpy as np
 import torch
@@ -44,9 +45,50 @@ DC_DIMS_GEMM_X3_ALL = 8192
 DC_DIMS_TEAM_VALU = 16384
 DC_DIMS_EMBED_UNFUSED = 32768
 
-WS_FIXED = ['BASIC', 'EMB', 'DEMB', 'XCAT', 'AMAX', 'PRE', 'HEADOUT', 'TU', 'DHEADOUT', 'DTU', 'DPRE', 'DXCAT',
+WS_FIXED = ['FAULT', 'BASIC', 'EMB', 'DEMB', 'XCAT', 'AMAX', 'PRE', 'HEADOUT', 'TU', 'DHEADOUT', 'DTU', 'DPRE', 'DXCAT',
             'STATS', 'WHHT', 'SCRATCH', 'HEADW_PAD', 'TEAM_XBUF', 'WPLANES']
 WS_LAYER = ['GATES', 'HN', 'HSEQ', 'HPREV', 'CSEQ', 'CPREV', 'DGX', 'DGH', 'DC', 'DH']
+
+
+# Every device buffer the C ABI gets to see is allocated here.  DEVICE_ALLOC_HOOK (tests only: tools/guard_soak.py) replaces the
+# allocation by one that places the buffer at the edge of its own mapping with unmapped memory beyond, so that a kernel overrun
+# faults; torch's own temporaries keep torch's allocator.
+DEVICE_ALLOC_HOOK = None
+
+
+def device_empty(shape, dtype, device):
+    if DEVICE_ALLOC_HOOK is not None:
+        return DEVICE_ALLOC_HOOK(tuple(shape) if not isinstance(shape, int) else (shape,), dtype, torch.device(device))
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
+def device_zeros(shape, dtype, device):
+    return device_empty(shape, dtype, device).zero_() if DEVICE_ALLOC_HOOK is not None else torch.zeros(shape, dtype=dtype, device=device)
+
+
+def device_copy(t, device, non_blocking=False):
+    """`t` (host or device tensor) as a device buffer of its own."""
+    if DEVICE_ALLOC_HOOK is None:
+        return t.to(device, non_blocking=non_blocking) if t.device != torch.device(device) else t
+    out = device_empty(t.shape, t.dtype, device)
+    out.copy_(t, non_blocking=non_blocking)
+    return out
+
+
+FAULT_KERNELS = {1: 'rnn_team_fwd', 2: 'rnn_team_bwd', 3: 'team_mfma_fwd', 4: 'team_mfma_bwd'}
+DC_FAULT_TEAM_TIMEOUT = 16
+
+
+def describe_status(engine):
+    """The engine's status word (0 ok, 1 NaN loss, 2 NaN gradient norm: dc_gradnorm_clip_adam) and, if a team kernel recorded a
+    timeout in the workspace's DC_WS_FAULT block, which launch it was - as one line of text."""
+    st = int(engine.status.item())
+    text = {0: '0 (ok)', 1: '1 (NaN loss)', 2: '2 (NaN gradient norm)'}.get(st, str(st))
+    f = engine.fault()
+    if f is not None:
+        text += '; team kernel timeout: %s, layer %d, team %d, member %d, time step %d, sequence %d, waited for tag %d' % (
+            FAULT_KERNELS.get(f[0] - DC_FAULT_TEAM_TIMEOUT, 'kernel %d' % f[0]), f[1], f[2], f[3], f[4], f[5], f[6])
+    return text
 
 
 class PackedBatch:
@@ -78,8 +120,8 @@ class PackedBatch:
             is_first = torch.isin(starts, self.seq_off)
             # row that holds the state a chunk starts from: the last row of the previous chunk of the same rollout, -1
             # (= zeros) for a rollout's first chunk
-            meta = {'starts': starts, 'lens': torch.full((b,), seq_len, device=dev, dtype=torch.int32),
-                    'is_first': is_first, 'prev_row': torch.where(is_first, torch.full_like(starts, -1), starts - 1)}
+            meta = {'starts': device_copy(starts, dev), 'lens': device_copy(torch.full((b,), seq_len, device=dev, dtype=torch.int32), dev),
+                    'is_first': is_first, 'prev_row': device_copy(torch.where(is_first, torch.full_like(starts, -1), starts - 1), dev)}
             self._chunk_meta[seq_len] = meta
         out = PackedBatch(self.obs, self.act, self.mask, self.rew, meta['starts'], meta['lens'], seq_len)
         out.is_first, out.prev_row = meta['is_first'], meta['prev_row']
@@ -92,16 +134,7 @@ def _as_np(x):
     return x.numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
 
 
-class _Staging:
-    """Page-locked host buffers for one batch, reused across iterations (a fresh 32 MB allocation costs more in page
-    faults than filling it).  ONE double-buffered pair per process, sized to the largest batch seen so far and grown
-    geometrically (the consumer loop adds whole rollouts until min_seq_per_epoch is reached, so the row count changes
-    almost every iteration: a pair per exact size would pin host memory without bound); a batch uses the leading
-    `rows` of each buffer.  A set is handed out again only after the H2D copies that read it have completed (event
-    recorded behind them); the old set is released when a larger one replaces it."""
-    _sets = {}        # pin -> [set, set]
-    _next = {}
-
+class _StagingSet:
     def __init__(self, capacity, pin):
         mk = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=pin)
         self.capacity = capacity
@@ -111,27 +144,56 @@ class _Staging:
         self.rew = mk((capacity, 10), torch.float32)
         self.event = None
 
-    @classmethod
-    def get(cls, rows, pin):
-        sets = cls._sets.setdefault(pin, [None, None])
-        i = cls._next.get(pin, 0)
-        cls._next[pin] = i ^ 1
-        st = sets[i]
+
+class StagingPair:
+    """Page-locked host buffers for one batch, reused across iterations (a fresh 32 MB allocation costs more in page
+    faults than filling it).  ONE double-buffered pair, sized to the largest batch seen so far and grown geometrically
+    (the consumer loop adds whole rollouts until min_seq_per_epoch is reached, so the row count changes almost every
+    iteration: a pair per exact size would pin host memory without bound); a batch uses the leading `rows` of each
+    buffer.  A set is handed out again only after the H2D copies that read it have completed (event recorded behind
+    them); the old set is released when a larger one replaces it.
+
+    A pair belongs to whoever packs with it: `pack_rollouts` holds the pair's lock from taking a set to recording the
+    event behind its copies, so two threads that share a pair (the process-wide default) are serialised instead of
+    filling the same buffers; a caller that wants to pack concurrently brings its own pair (DotaOptimizer's prefetcher)."""
+
+    def __init__(self, pin):
+        self.pin = pin
+        self.sets = [None, None]
+        self.next = 0
+        self.lock = threading.Lock()
+
+    def take(self, rows):
+        """Call with self.lock held."""
+        i = self.next
+        self.next = i ^ 1
+        st = self.sets[i]
         if st is not None and st.event is not None:
             st.event.synchronize()
             st.event = None
         if st is None or st.capacity < rows:
             cap = rows if st is None else max(rows, st.capacity + st.capacity // 2)
-            sets[i] = st = None               # release the old pinned buffers before allocating the larger ones
-            sets[i] = st = cls(cap, pin)
+            self.sets[i] = st = None               # release the old pinned buffers before allocating the larger ones
+            self.sets[i] = st = _StagingSet(cap, self.pin)
         return st
+
+
+_DEFAULT_STAGING = {}
+_DEFAULT_STAGING_LOCK = threading.Lock()
+
+
+def default_staging(pin):
+    with _DEFAULT_STAGING_LOCK:
+        if pin not in _DEFAULT_STAGING:
+            _DEFAULT_STAGING[pin] = StagingPair(pin)
+        return _DEFAULT_STAGING[pin]
 
 
 PACK_THREADS = int(os.environ.get('DC_PACK_THREADS', '8'))
 _TORCH_OF = {np.float32: torch.float32, np.uint8: torch.uint8}
 
 
-def pack_rollouts(rollouts, seq_len, device):
+def pack_rollouts(rollouts, seq_len, device, staging=None):
     """Wire-format rollout dicts (optimizer.py:314-326) -> PackedBatch with one sequence per rollout, each
     zero-padded to a multiple of seq_len (optimizer.py:343-382).
 
@@ -140,14 +202,19 @@ def pack_rollouts(rollouts, seq_len, device):
     ([rows,483] f32 observations, [rows,65] u8 actions and masks, [rows,10] f32 sub-rewards; reused across
     iterations) - no per-rollout temporaries, no concatenation; the ~17 copies per rollout are one native call for the
     whole batch (`dc_pack_rows`, a few host threads) - followed by one asynchronous H2D copy per field (four per batch
-    instead of the reference's 17 per chunk)."""
+    instead of the reference's 17 per chunk).  `staging`: the StagingPair to pack through (default: the process-wide one)."""
     if len(rollouts) == 0:
         raise ValueError('pack_rollouts: no rollouts')
     lens = [(int(d['rewards'].shape[0]) + seq_len - 1) // seq_len * seq_len for d in rollouts]
     rows = int(sum(lens))
     dev = torch.device(device)
     pin = dev.type == 'cuda'
-    st = _Staging.get(rows, pin)
+    pair = staging if staging is not None else default_staging(pin)
+    with pair.lock:
+        return _pack_locked(rollouts, seq_len, dev, pin, pair.take(rows), lens, rows)
+
+
+def _pack_locked(rollouts, seq_len, dev, pin, st, lens, rows):
     lens_n = np.asarray(lens, dtype=np.int64)
     off = np.concatenate([[0], np.cumsum(lens_n)[:-1]]).astype(np.int64)
 
@@ -195,9 +262,9 @@ def pack_rollouts(rollouts, seq_len, device):
     tab = np.ascontiguousarray(np.array(items, dtype=np.int64).reshape(-1, 5).T)          # [5, n_items] (items: flat list)
     col = lambda k: ctypes.c_void_p(tab[k].ctypes.data)
     _lib.check(_lib.load().dc_pack_rows(col(0), col(1), col(2), col(3), col(4), tab.shape[1], PACK_THREADS), 'dc_pack_rows')
-    to = lambda x: x[:rows].to(dev, non_blocking=True) if pin else x[:rows].clone()
-    batch = PackedBatch(to(st.obs), to(st.act), to(st.msk), to(st.rew), torch.from_numpy(off).to(dev),
-                        torch.from_numpy(lens_n.astype(np.int32)).to(dev), int(lens_n.max()))
+    to = lambda x: device_copy(x[:rows], dev, non_blocking=True) if pin else x[:rows].clone()
+    batch = PackedBatch(to(st.obs), to(st.act), to(st.msk), to(st.rew), device_copy(torch.from_numpy(off), dev),
+                        device_copy(torch.from_numpy(lens_n.astype(np.int32)), dev), int(lens_n.max()))
     if pin:
         st.event = torch.cuda.Event()
         st.event.record()
@@ -212,7 +279,7 @@ class Engine:
         if self.device.type != 'cuda':
             raise _lib.DotaHipError('the PPO hot path only runs on the GPU (no CPU fallback)')
         self.layout, self.total = L.flat_layout(cell, hidden, layers)
-        z = lambda: torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        z = lambda: device_zeros(self.total, torch.float32, self.device)
         self.params, self.grads, self.adam_m, self.adam_v = z(), z(), z(), z()
         # offsets in dc_param_index order
         names = ['affine_env.weight', 'affine_env.bias', 'affine_unit_basic_stats.weight',
@@ -237,16 +304,16 @@ class Engine:
         self.seg_names = seg_names
         self.seg_gate_host = gate
         dev = self.device
-        self.seg_off = torch.tensor([self.layout[n][0] for n in seg_names], dtype=torch.int64, device=dev)
-        self.seg_len = torch.tensor([self.layout[n][1] for n in seg_names], dtype=torch.int32, device=dev)
-        self.seg_gate = torch.tensor(gate, dtype=torch.int32, device=dev)
+        self.seg_off = device_copy(torch.tensor([self.layout[n][0] for n in seg_names], dtype=torch.int64), dev)
+        self.seg_len = device_copy(torch.tensor([self.layout[n][1] for n in seg_names], dtype=torch.int32), dev)
+        self.seg_gate = device_copy(torch.tensor(gate, dtype=torch.int32), dev)
         self.max_seg_len = max(self.layout[n][1] for n in seg_names)
-        self.seg_step = torch.zeros(len(seg_names), dtype=torch.int32, device=dev)
-        self.segsq = torch.zeros(len(seg_names), dtype=torch.float64, device=dev)
-        self.out = torch.zeros(16, dtype=torch.float32, device=dev)     # 0..8 losses/entropies, 9..10 norms
-        self.ctl = torch.zeros(2, dtype=torch.float32, device=dev)
-        self.head_on = torch.zeros(8, dtype=torch.int32, device=dev)
-        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.seg_step = device_zeros(len(seg_names), torch.int32, dev)
+        self.segsq = device_zeros(len(seg_names), torch.float64, dev)
+        self.out = device_zeros(16, torch.float32, dev)     # 0..8 losses/entropies, 9..10 norms
+        self.ctl = device_zeros(2, torch.float32, dev)
+        self.head_on = device_zeros(8, torch.int32, dev)
+        self.status = device_zeros(1, torch.int32, dev)
         # flat offset of the first parameter that is not part of the unit / env embeddings (they come first in the layout)
         self.embed_floats = self.layout['affine_pre_rnn.weight'][0]
         self._ws = None
@@ -271,7 +338,13 @@ class Engine:
     def load_state_dict(self, sd):
         for n in self.layout:
             self.param_view(n).copy_(sd[n].to(self.device, torch.float32))
+        self.params_changed()
+
+    def params_changed(self):
+        """To be called by whoever writes the flat parameter buffer behind the engine's back (Policy.load_state_dict through the
+        parameter views, the data-parallel broadcast): activations held in the workspace no longer belong to the weights."""
         self._param_version += 1
+        self._ws_holds = None
 
     def state_dict(self):
         return {n: self.param_view(n).detach().clone() for n in L.param_shapes(self.cell, self.hidden, self.layers)}
@@ -329,10 +402,24 @@ class Engine:
         key = (d.rows, d.n_seq)
         if self._ws is None or self._ws.numel() < total:
             self._ws = None
-            self._ws = torch.empty(int(total), dtype=torch.uint8, device=self.device)
+            self._ws = device_empty(int(total), torch.uint8, self.device)
+            self._ws[:256].zero_()          # DC_WS_FAULT (offset 0 for every dims): the owner clears it once, the library only sets it
+            self._ws_holds = None
         self._ws_off = list(offs)
         self._ws_dims_key = key
         return self._ws
+
+    def fault(self):
+        """The sticky fault record of the H = 256 team kernels (include/dotaclient_hip.h, DC_WS_FAULT) as a list of 8 ints, or
+        None when nothing was recorded (synchronises)."""
+        if self._ws is None:
+            return None
+        f = self._ws[:32].view(torch.int32).cpu().tolist()
+        return f if f[0] != 0 else None
+
+    def clear_fault(self):
+        if self._ws is not None:
+            self._ws[:256].zero_()
 
     def ws_view(self, d, name, layer=None, dtype=torch.float32):
         """Tensor view of a workspace buffer (tests / plumbing)."""
@@ -347,11 +434,12 @@ class Engine:
     def forward(self, batch, h0=None, c0=None, want_final=False, lazy_tu=False):
         d = self.dims(batch, lazy_tu)
         ws = self._workspace(d)
-        self._ws_holds = (batch.rows, batch.obs.data_ptr(), self._param_version, bool(lazy_tu))
+        # what the workspace's activations are a function of (Engine.reuse_rollout_forward compares it)
+        self._ws_holds = (batch.rows, batch.obs.data_ptr(), self._param_version, bool(lazy_tu), self.kernel_flags)
         hT = cT = None
         if want_final:
-            hT = torch.empty(self.layers, batch.n_seq, self.hidden, device=self.device)
-            cT = torch.empty_like(hT) if self.cell == 'lstm' else None
+            hT = device_empty((self.layers, batch.n_seq, self.hidden), torch.float32, self.device)
+            cT = device_empty((self.layers, batch.n_seq, self.hidden), torch.float32, self.device) if self.cell == 'lstm' else None
         _lib.check(self.lib.dc_policy_forward(ctypes.byref(d), _lib.ptr(self.params), self.poff, _lib.ptr(batch.obs),
                                               _lib.ptr(h0), _lib.ptr(c0), _lib.ptr(batch.seq_off), _lib.ptr(batch.seq_len),
                                               _lib.ptr(ws), _lib.ptr(hT), _lib.ptr(cT), _lib.stream_ptr()),
@@ -364,7 +452,7 @@ class Engine:
         batch (the epochs of an iteration, the steps of the bench) - no allocation inside the steady-state step."""
         t = batch._bufs.get(name)
         if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
-            t = batch._bufs[name] = torch.empty(shape, dtype=dtype, device=device)
+            t = batch._bufs[name] = device_empty(shape, dtype, device)
         return t
 
     def select_logp(self, d, batch, want_argmax=True):
@@ -440,7 +528,7 @@ class Engine:
 
     def _train_epoch_eager(self, chunks, lr, entropy_coef, vf_coef, e_clip, grad_hook):
         if (self.reuse_rollout_forward and self._ws is not None
-                and self._ws_holds == (chunks.rows, chunks.obs.data_ptr(), self._param_version, True)):
+                and self._ws_holds == (chunks.rows, chunks.obs.data_ptr(), self._param_version, True, self.kernel_flags)):
             # same rows, same weights: the rollout pass's activations are what this forward would write (a chunk's initial state is
             # the state the rollout pass carried into its first row)
             d = self.dims(chunks, True)
@@ -450,6 +538,7 @@ class Engine:
                 d, _, _ = self.forward(chunks, chunks.h0, chunks.c0, lazy_tu=True)
         else:
             d, _, _ = self.forward(chunks, chunks.h0, chunks.c0, lazy_tu=True)
+        self._ws_holds = None          # the loss / backward overwrite parts of the saved forward; Adam changes the weights
         self.loss(d, chunks, e_clip, entropy_coef, vf_coef)
         if grad_hook is not None and getattr(grad_hook, 'overlap', False):
             # data-parallel with overlap: the all-reduce of everything but the embedding gradients (82 % of the bucket)
@@ -478,7 +567,7 @@ class Engine:
         if ent is None:
             # first sight of this key: run eagerly (also takes care of every one-time hipFuncSetAttribute and of the
             # workspace allocation, neither of which belongs inside a capture)
-            if len(self._graphs) >= 4:
+            if len(self._graphs) >= 2:          # a batch is replayed for the epochs of ONE iteration: keep the current and the previous one
                 self._graphs.pop(next(iter(self._graphs)))
             self._graphs[key] = {'graph': None, 'keep': (chunks,)}
             out = self._train_epoch_eager(chunks, lr, entropy_coef, vf_coef, e_clip, None)
@@ -491,4 +580,6 @@ class Engine:
                 self._train_epoch_eager(chunks, lr, entropy_coef, vf_coef, e_clip, None)
             ent['graph'] = g
         ent['graph'].replay()
+        self._param_version += 1       # the replay ran Adam
+        self._ws_holds = None
         return self.out, self.status

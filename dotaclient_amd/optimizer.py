@@ -137,7 +137,8 @@ class DotaOptimizer:
 
     def __init__(self, rmq_host, rmq_port, epochs, min_seq_per_epoch, seq_len, learning_rate, checkpoint,
                  pretrained_model, mq_prefetch_count, log_dir, entropy_coef, vf_coef, run_local,
-                 mq=None, metrics_sink=None, cell='gru', hidden=256, layers=1, device='cuda:0', reuse_rollout_forward=True):
+                 mq=None, metrics_sink=None, cell='gru', hidden=256, layers=1, device='cuda:0', reuse_rollout_forward=False,
+                 prefetch=True):
         self.rmq_host, self.rmq_port = rmq_host, rmq_port
         self.epochs, self.min_seq_per_epoch, self.seq_len = epochs, min_seq_per_epoch, seq_len
         self.learning_rate, self.checkpoint = learning_rate, checkpoint
@@ -148,6 +149,8 @@ class DotaOptimizer:
             # hot path, not re-implemented - fail loudly instead of silently starting from scratch
             raise ValueError('run_local=False (GCS checkpoint resume / upload) is outside this package: keep the reference\'s own '
                              'checkpoint code around DotaOptimizer, or pass run_local=True')
+        if self.checkpoint:
+            os.makedirs(self.log_dir, exist_ok=True)                        # optimizer.py:231-233 (events + models live there)
         self.iteration_start = 1
         self.iterations = 100000
         self.model_upload_freq = 10
@@ -164,7 +167,18 @@ class DotaOptimizer:
         # results equal, one forward pass in five saved).  False restores the reference's pass count.
         self.engine.reuse_rollout_forward = bool(reuse_rollout_forward)
 
-        if pretrained_model is not None:                                    # optimizer.py:264-267 (a local file)
+        # optimizer.py:241-267, the run_local branch: the newest model_%09d.pt of log_dir overrides an explicit pretrained model,
+        # and the iteration counter resumes behind the file's number so that published versions never go backwards
+        if self.checkpoint:
+            latest_model = self.get_latest_model(prefix=self.log_dir)
+            if latest_model is not None:
+                logger.info('Found a latest model in pretrained dir: %s', latest_model)
+                if pretrained_model is not None:
+                    logger.warning('Overriding pretrained model by latest model.')
+                pretrained_model = latest_model
+            if pretrained_model is not None:
+                self.iteration_start = self.iteration_from_model_filename(filename=pretrained_model) + 1
+        if pretrained_model is not None:
             self.policy_base.load_state_dict(torch.load(pretrained_model, map_location='cpu'), strict=False)
 
         # data parallel: flat-bucket RCCL all-reduce instead of the reference's per-parameter gloo wrapper
@@ -185,6 +199,21 @@ class DotaOptimizer:
         self.metrics_sink = metrics_sink
         self.mq.connect()
         self.upload_model(version=self.iteration_start)
+
+    @staticmethod
+    def iteration_from_model_filename(filename):
+        """optimizer.py:298-308: 'model_000000123.pt' -> 123 (1 if the name carries no number)."""
+        import re
+        x = re.search(r'(\d+)(?=\.pt)', os.path.basename(filename))
+        return int(x.group(0)) if x else 1
+
+    def get_latest_model(self, prefix):
+        """optimizer.py:287-296, local directory instead of the GCS bucket: newest model file under `prefix`, or None."""
+        try:
+            names = sorted(f for f in os.listdir(prefix) if f.startswith('model_') and f.endswith('.pt'))
+        except OSError:
+            return None
+        return os.path.join(prefix, names[-1]) if names else None
 
     # ---- experience ingest ---------------------------------------------------------------------------
     def get_rollout(self):

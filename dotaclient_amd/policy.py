@@ -88,6 +88,7 @@ class Policy(nn.Module):
                 if tuple(state_dict[k].shape) != tuple(own[k]):
                     raise RuntimeError('size mismatch for %s' % k)
                 self.engine.param_view(k).copy_(state_dict[k].to(self.engine.device, torch.float32))
+        self.engine.params_changed()
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     def attach_grads(self):

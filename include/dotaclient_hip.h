@@ -29,6 +29,9 @@ extern "C" {
 
 typedef void* dc_stream_t; /* hipStream_t */
 
+/* 3 (round 3): DC_WS_FAULT inserted at workspace index 0; round 2's unannounced changes (dc_gemm_f32's scratch arguments,
+ * DC_WS_TEAM_XBUF / DC_WS_WPLANES) were version 2 in effect.  The Python binding refuses any other value. */
+#define DC_ABI_VERSION 3
 int dc_abi_version(void);
 const char* dc_last_error(void);
 
@@ -155,7 +158,8 @@ enum dc_param_index {
 
 /* workspace buffer ids (for dc_workspace_layout's offsets[]; bytes) */
 enum dc_ws_index {
-    DC_WS_BASIC = 0, DC_WS_EMB, DC_WS_DEMB, DC_WS_XCAT, DC_WS_AMAX, DC_WS_PRE, DC_WS_HEADOUT, DC_WS_TU,
+    DC_WS_FAULT = 0,        /* i32[8] at workspace offset 0 (whatever the dims): fault record, see below */
+    DC_WS_BASIC, DC_WS_EMB, DC_WS_DEMB, DC_WS_XCAT, DC_WS_AMAX, DC_WS_PRE, DC_WS_HEADOUT, DC_WS_TU,
     DC_WS_DHEADOUT, DC_WS_DTU, DC_WS_DPRE, DC_WS_DXCAT, DC_WS_STATS, DC_WS_WHHT, DC_WS_SCRATCH, DC_WS_HEADW_PAD,
     DC_WS_TEAM_XBUF, DC_WS_WPLANES,
     DC_WS_FIXED,            /* per-layer blocks follow */
@@ -163,6 +167,15 @@ enum dc_ws_index {
     DC_WSL_DC, DC_WSL_DH,
     DC_WS_PER_LAYER
 };
+
+/* DC_WS_FAULT - where a failure of the H = 256 team kernels is reported.  Those kernels hand state between four workgroups
+ * through tagged granules; a member that polls one for ~1 s without seeing its tag gives up, NaN-poisons its outputs (the loss
+ * turns NaN: status 1 of dc_gradnorm_clip_adam, the reference's own guard, optimizer.py:667-669) and - first writer wins - records
+ *   [0] DC_FAULT_TEAM_TIMEOUT + kernel (1 rnn_team_fwd, 2 rnn_team_bwd, 3 team_mfma_fwd, 4 team_mfma_bwd), [1] layer, [2] team,
+ *   [3] member, [4] time step, [5] sequence, [6] the tag it waited for, [7] reserved.
+ * The record is STICKY: the library never clears it.  The owner of the workspace zeroes these 32 bytes once after allocating it
+ * (and again after reading a fault, if it wants to carry on). */
+#define DC_FAULT_TEAM_TIMEOUT 16
 
 /* Byte offsets of every workspace buffer into offsets[DC_WS_FIXED + DC_WS_PER_LAYER*layers]; returns
  * the total workspace size in bytes (host-only helper, no GPU work). */

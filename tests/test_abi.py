@@ -21,7 +21,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
         assert s in _lib.SIGNATURES, 'ctypes signature missing for ' + s
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.dc_abi_version() >= 1
+    hdr = open(os.path.join(REPO, "include", "dotaclient_hip.h")).read()
+    assert lib.dc_abi_version() == int(re.search(r"#define DC_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION
 
 
 def test_every_declaration_cites_the_reference():

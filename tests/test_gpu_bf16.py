@@ -24,7 +24,9 @@ from tests.test_gpu_parity import run_hip
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('cell,hidden,layers,lens,S', [('lstm', 512, 2, [64] * 6, 64), ('lstm', 256, 1, [50, 64, 33], 16), ('gru', 256, 1, [128] * 4, 128)])
+@pytest.mark.parametrize('cell,hidden,layers,lens,S', [('lstm', 512, 2, [64] * 6, 64), ('lstm', 256, 1, [50, 64, 33], 16), ('gru', 256, 1, [128] * 4, 128),
+                                                       # a sub-batch of BASELINE.json configs[4]'s shard: 64 of its 256 trajectories x 512 steps
+                                                       ('lstm', 512, 2, [512] * 64, 512)])
 def test_bf16_path_within_stated_tolerance_of_fp32_oracle(cell, hidden, layers, lens, S):
     from dotaclient_amd import engine as E
     g = {'seq_len': S, 'lr': 5e-5, 'entropy_coef': 5e-4, 'vf_coef': 0.5, 'epochs': 1}

@@ -1,0 +1,112 @@
+"""Soak of every workload bench.py times: 25 back-to-back iterations without a synchronisation in between -
+the way the bench's timed loop and the consumer loop drive the engine - eager, as hipGraph replays, with the first epoch on the
+rollout pass's activations, and with a host thread packing the next batch concurrently.  After them: status word 0, no team-kernel
+fault record, finite parameters, and the 25th iteration's losses equal to those of ONE iteration started from a snapshot of the
+state after the 24th (a long run must not differ from a restart: nothing may leak from one iteration into the next).
+
+Round 2's bench died in exactly this regime (graph replays, no per-step sync): profiles/r03/crash_bisect.md."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from dotaclient_amd import synth
+from dotaclient_amd.engine import Engine, StagingPair, pack_rollouts
+
+pytestmark = pytest.mark.gpu
+LR, ENT, VF, E = 5e-5, 5e-4, 0.5, 4
+
+
+def ragged_reference_defaults():
+    rng = np.random.Generator(np.random.PCG64(99))          # bench.py's reference-defaults shape: >= 1024 chunks of 16
+    lens, chunks = [], 0
+    while chunks < 1024:
+        t = int(rng.integers(100, 900))
+        lens.append(t)
+        chunks += (t + 15) // 16
+    return lens
+
+
+WORKLOADS = {
+    'cfg2_lstm256_256x256': ('lstm', 256, [256] * 256, 256),
+    'cfg3shard_lstm256_128x256': ('lstm', 256, [256] * 128, 256),
+    'cfg1_lstm128_64x256': ('lstm', 128, [256] * 64, 256),
+    'gru256_64x256': ('gru', 256, [256] * 64, 256),
+    'gru256_s16_ragged_1065chunks': ('gru', 256, ragged_reference_defaults(), 16),
+}
+
+
+def iteration(eng, batch, S, graph):
+    chunks = eng.rollout_pass(batch, S)
+    for _ in range(E):
+        eng.train_epoch(chunks, LR, ENT, VF, graph=graph)
+    return chunks
+
+
+def clone_state(eng):
+    return {k: getattr(eng, k).clone() for k in ('params', 'adam_m', 'adam_v', 'seg_step')}
+
+
+@pytest.mark.parametrize('mode', ['eager', 'graph', 'reuse', 'feeder'])
+@pytest.mark.parametrize('name', list(WORKLOADS))
+def test_soak_25_iterations_then_restart_equality(name, mode):
+    cell, hidden, lens, S = WORKLOADS[name]
+    if mode == 'feeder' and name != 'cfg2_lstm256_256x256':
+        pytest.skip('the concurrent-ingest soak runs on the headline workload')
+    dev = torch.device('cuda:0')
+    eng = Engine(cell, hidden, 1, dev)
+    eng.reuse_rollout_forward = mode == 'reuse'
+    eng.load_state_dict(synth.init_state_dict(7, cell, hidden, 1))
+    rollouts = synth.make_rollouts(1000, lens)
+    batch = pack_rollouts(rollouts, S, dev)
+    graph = mode == 'graph'
+
+    stop, packed = [], []
+    th = None
+    if mode == 'feeder':                       # a consumer loop's prefetcher: own staging pair, own stream, packs while the GPU works
+        pair, side = StagingPair(True), torch.cuda.Stream(device=dev)
+
+        def feeder():
+            torch.cuda.set_device(dev)
+            while not stop:
+                with torch.cuda.stream(side):
+                    b = pack_rollouts(rollouts, S, dev, staging=pair)
+                side.synchronize()
+                packed.append(b.rows)
+        th = threading.Thread(target=feeder, daemon=True)
+        th.start()
+
+    for _ in range(24):
+        iteration(eng, batch, S, graph)
+    snap = clone_state(eng)                    # enqueued behind the 24th iteration on the same stream
+    iteration(eng, batch, S, graph)
+    torch.cuda.synchronize()
+    if th is not None:
+        stop.append(1)
+        th.join()
+        assert len(packed) >= 2 and all(r == batch.rows for r in packed)
+    assert int(eng.status.item()) == 0
+    assert eng.fault() is None
+    assert bool(torch.isfinite(eng.params).all())
+    long_run = eng.out[:11].cpu().numpy().astype(np.float64)
+    assert np.all(np.isfinite(long_run))
+
+    fresh = Engine(cell, hidden, 1, dev)
+    for k, v in snap.items():
+        getattr(fresh, k).copy_(v)
+    fresh.params_changed()
+    iteration(fresh, batch, S, False)
+    torch.cuda.synchronize()
+    restart = fresh.out[:11].cpu().numpy().astype(np.float64)
+    # Same weights, same batch.  Losses and entropies are continuous in the weights: equal up to the summation order of the atomic
+    # accumulations.  The GRADIENT is not: the clipped ratio (optimizer.py:637-640) switches a sample's gradient on or off at
+    # ratio = 1 +- e_clip and the max-pools route theirs to whichever unit wins, so a 1e-9 difference in the weights (epoch 0 of the
+    # restart runs the forward that `reuse` skips; atomics order) moves a few of 65 536 samples across a boundary: the norms agree to
+    # about 1e-3 only (tools/determinism_probe.py: at FIXED weights every gradient repeats to < 2e-5), and one Adam step of such a
+    # gradient moves a weight by at most lr.
+    den = np.maximum(np.abs(restart), 1e-3 * np.abs(restart[1:4]).sum())
+    err = np.abs(long_run - restart) / den
+    assert err[:9].max() < 2e-4, (long_run, restart)
+    assert err[9:11].max() < 2e-2, (long_run, restart)
+    assert float((eng.params - fresh.params).abs().max()) <= 4 * LR * 1.01

@@ -79,7 +79,7 @@ def test_staging_is_one_growing_pair_not_one_per_batch_size():
     # buffers per distinct size - one double-buffered pair, grown geometrically, a batch uses its leading rows
     from dotaclient_amd import engine as E
     dev = torch.device('cpu')
-    E._Staging._sets.pop(False, None)
+    E._DEFAULT_STAGING.pop(False, None)
     caps = []
     for seed, lens in enumerate([[16], [48, 16], [32], [200, 40], [64], [16, 16, 16], [500], [16]]):
         rollouts = synth.make_rollouts(40 + seed, lens)
@@ -87,10 +87,10 @@ def test_staging_is_one_growing_pair_not_one_per_batch_size():
         assert b.rows == sum((t + 15) // 16 * 16 for t in lens) and b.obs.shape[0] == b.rows
         o, a, m, r = synth.flatten_rollout(rollouts[0])
         assert np.array_equal(b.obs[:lens[0]].numpy(), o) and np.array_equal(b.mask[:lens[0]].numpy(), m)
-        sets = E._Staging._sets[False]
+        sets = E._DEFAULT_STAGING[False].sets
         assert len(sets) == 2
         caps.append(sorted(st.capacity for st in sets if st is not None))
-    assert max(caps[-1]) >= 512 and len(E._Staging._sets) == 1          # still exactly one pair
+    assert max(caps[-1]) >= 512 and len(E._DEFAULT_STAGING) == 1        # still exactly one pair
     assert all(c >= p for p, c in zip(caps[1:-1:2], caps[3::2]))          # capacities only ever grow
 
 
@@ -208,6 +208,9 @@ class _FakeLib:
 
 
 class _FakeEngine:
+    def params_changed(self):
+        self.params_changed_calls = getattr(self, 'params_changed_calls', 0) + 1
+
     def __init__(self, head_on):
         lay, total = L.flat_layout()
         names = list(L.param_shapes().keys())

@@ -3,7 +3,7 @@
 TAG=${1:-b}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/bench.err
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/bench.err
 python - <<PY
 import json
 try:

@@ -5,7 +5,7 @@ TAG=${1:-cfg4}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 for MODE in 4096 0; do
-  timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-host-extras --cell lstm --hidden 512 --layers 2 --batch 256 --seq-len 512 --kernel-flags $MODE > $OUT/bench_flags$MODE.json 2> $OUT/bench_flags$MODE.err
+  timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --cell lstm --hidden 512 --layers 2 --batch 256 --seq-len 512 --kernel-flags $MODE > $OUT/bench_flags$MODE.json 2> $OUT/bench_flags$MODE.err
   python - <<PY
 import json
 try:

@@ -6,7 +6,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1
 echo "pytest exit $?"; tail -6 $OUT/pytest_gpu.log
-timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/bench.err
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/bench.err
 python - <<PY
 import json
 try:

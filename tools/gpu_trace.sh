@@ -7,7 +7,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$(pwd)
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/$OUT/prof -o trace -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --no-host-extras "$@" > $REPO/$OUT/prof_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/$OUT/prof -o trace -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $REPO/$OUT/prof_bench.log 2>&1
 cd $REPO
 DB=$(find $OUT/prof -name '*.db' | head -1)
 [ -n "$DB" ] && python tools/rocpd_stats.py $DB $OUT/kernel_stats.csv

@@ -6,7 +6,7 @@ export DC_BENCH_ONE_DEVICE=1
 for ov in 0 1; do
 export DC_DP_OVERLAP=$ov
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 2951$ov \
-    bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline --no-host-extras > gpurun_out/two/bench_$ov.json 2> gpurun_out/two/bench_$ov.err
+    bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/two/bench_$ov.json 2> gpurun_out/two/bench_$ov.err
 echo "DC_DP_OVERLAP=$ov exit $?"
 python - <<PY
 import json

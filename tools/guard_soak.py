@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""Runs bench workloads on the GUARD allocator (tools/guard/guard_alloc.cpp): every torch device allocation sits at the end
+(DC_GUARD_MODE=end) or start (=start) of its own mapping with unmapped memory beyond, so an out-of-bounds access of any
+kernel faults deterministically.  Each workload runs in its own subprocess (a fault kills the process).
+
+  python tools/guard_soak.py                 all workloads, one line each; exit code 1 if any failed
+  python tools/guard_soak.py <workload>      one workload in this process  (DC_GUARD_TRACE=1: name every C-ABI call, sync after it)
+  python tools/guard_soak.py selftest        must die of a memory access fault (reads one element past a buffer)
+"""
+import os
+import subprocess
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+GUARD_SO = os.path.join(REPO, 'tools', 'guard', 'libdc_guard.so')
+
+WORKLOADS = {
+    # name: (cell, hidden, layers, n_rollouts or lengths, seq_len, kernel_flags, reuse_forward)
+    'cfg2_lstm256_256x256': ('lstm', 256, 1, 256, 256, 0, False),
+    'cfg3shard_lstm256_128x256': ('lstm', 256, 1, 128, 256, 0, False),
+    'cfg1_lstm128_64x256': ('lstm', 128, 1, 64, 256, 0, False),
+    'gru256_64x256': ('gru', 256, 1, 64, 256, 0, False),
+    'gru256_s16_ragged': ('gru', 256, 1, 'ragged', 16, 0, False),
+    'cfg2_reuse_forward': ('lstm', 256, 1, 256, 256, 0, True),
+    'lstm256_ragged_s16': ('lstm', 256, 1, 'ragged_small', 16, 0, False),
+    'gru256_tiny_ragged': ('gru', 256, 1, [40, 32, 21], 16, 0, False),
+    'cfg4_bf16_2xlstm512_16x512': ('lstm', 512, 2, 16, 512, 4096, False),
+    # epochs replayed as a hipGraph captured with raw HIP calls (torch.cuda.graph needs torch's own allocator)
+    'graph:cfg2_lstm256_256x256': ('lstm', 256, 1, 256, 256, 0, False),
+    'graph:cfg1_lstm128_64x256': ('lstm', 128, 1, 64, 256, 0, False),
+    'graph:gru256_s16_ragged': ('gru', 256, 1, 'ragged', 16, 0, False),
+}
+
+
+class RawHipGraph:
+    """hipStreamBeginCapture .. hipGraphLaunch through ctypes on the HIP runtime torch has loaded."""
+
+    def __init__(self, torch):
+        import ctypes
+        self.ct = ctypes
+        self.hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))
+        self.exec_ = ctypes.c_void_p()
+
+    def _chk(self, e, what):
+        if e != 0:
+            raise RuntimeError('%s -> hipError %d' % (what, e))
+
+    def capture(self, stream, fn):
+        ct = self.ct
+        s = ct.c_void_p(stream.cuda_stream)
+        self._chk(self.hip.hipStreamBeginCapture(s, 2), 'hipStreamBeginCapture')      # 2 = relaxed
+        fn()
+        g = ct.c_void_p()
+        self._chk(self.hip.hipStreamEndCapture(s, ct.byref(g)), 'hipStreamEndCapture')
+        self._chk(self.hip.hipGraphInstantiate(ct.byref(self.exec_), g, None, None, ct.c_size_t(0)), 'hipGraphInstantiate')
+        n = ct.c_size_t(0)
+        self.hip.hipGraphGetNodes(g, None, ct.byref(n))
+        self.n_nodes = n.value
+        if os.environ.get('DC_GUARD_DUMP_NODES') == '1':
+            class MemsetParams(ct.Structure):
+                _fields_ = [('dst', ct.c_void_p), ('elementSize', ct.c_uint), ('height', ct.c_size_t), ('pitch', ct.c_size_t),
+                            ('value', ct.c_uint), ('width', ct.c_size_t)]
+            nodes = (ct.c_void_p * n.value)()
+            self.hip.hipGraphGetNodes(g, nodes, ct.byref(n))
+            kinds = {}
+            for nd in nodes:
+                t = ct.c_int(-1)
+                self.hip.hipGraphNodeGetType(ct.c_void_p(nd), ct.byref(t))
+                kinds[t.value] = kinds.get(t.value, 0) + 1
+                if t.value == 2:
+                    mp = MemsetParams()
+                    e = self.hip.hipGraphMemsetNodeGetParams(ct.c_void_p(nd), ct.byref(mp))
+                    sys.stderr.write('memset node: rc=%d dst=%#x elementSize=%d width=%d height=%d pitch=%d value=%d\n'
+                                     % (e, mp.dst or 0, mp.elementSize, mp.width, mp.height, mp.pitch, mp.value))
+            sys.stderr.write('node types (0 kernel, 1 memcpy, 2 memset): %s\n' % kinds)
+
+    def launch(self, stream):
+        self._chk(self.hip.hipGraphLaunch(self.exec_, self.ct.c_void_p(stream.cuda_stream)), 'hipGraphLaunch')
+
+
+
+class GuardedStorage:
+    """One guarded allocation (tools/guard/guard_alloc.cpp) exposed through __cuda_array_interface__; freed (after a device
+    synchronisation) when the last tensor viewing it is gone."""
+    lib = None
+
+    def __init__(self, nbytes, device_index):
+        import ctypes
+        if GuardedStorage.lib is None:
+            if not os.path.exists(GUARD_SO):
+                subprocess.check_call(['/opt/rocm/bin/hipcc', '-O1', '-fPIC', '-shared', '-o', GUARD_SO,
+                                       os.path.join(os.path.dirname(GUARD_SO), 'guard_alloc.cpp')])
+            lib = ctypes.CDLL(GUARD_SO)
+            lib.dc_guard_malloc.restype = ctypes.c_void_p
+            lib.dc_guard_malloc.argtypes = [ctypes.c_ssize_t, ctypes.c_int, ctypes.c_void_p]
+            lib.dc_guard_free.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_void_p]
+            GuardedStorage.lib = lib
+        self.nbytes, self.device_index = max(int(nbytes), 1), device_index
+        self.ptr = GuardedStorage.lib.dc_guard_malloc(self.nbytes, device_index, None)
+        self.__cuda_array_interface__ = {'shape': (self.nbytes,), 'typestr': '|u1', 'data': (self.ptr, False), 'version': 2}
+
+    def __del__(self):
+        if getattr(self, 'ptr', None):
+            GuardedStorage.lib.dc_guard_free(self.ptr, self.nbytes, self.device_index, None)
+            self.ptr = None
+
+
+def install_guard():
+    """Every device buffer the engine hands to the C ABI (dotaclient_amd.engine.DEVICE_ALLOC_HOOK) becomes a guarded allocation;
+    torch's own temporaries stay on torch's allocator (its kernels misbehave on a foreign one: torch.isin returned wrong counts)."""
+    import torch
+    from dotaclient_amd import engine as E
+    torch.zeros(1, device='cuda:0')                      # HIP context first
+
+    def alloc(shape, dtype, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        itemsize = torch.empty(0, dtype=dtype).element_size()
+        st = GuardedStorage(n * itemsize, device.index or 0)
+        t = torch.as_tensor(st, device=device)
+        return t[:n * itemsize].view(dtype).view(shape)
+    E.DEVICE_ALLOC_HOOK = alloc
+    return torch
+
+
+def trace_calls(lib):
+    """DC_GUARD_TRACE=1: print every C-ABI call before it is made and synchronise after it - the last name printed is the
+    call whose kernels faulted."""
+    import torch
+    from dotaclient_amd import _lib
+    for name in _lib.SIGNATURES:
+        if not name.startswith('dc_') or name in ('dc_last_error', 'dc_abi_version', 'dc_workspace_layout', 'dc_pack_rows',
+                                                  'dc_profile_enable', 'dc_profile_report'):
+            continue
+        fn = getattr(lib, name)
+
+        def wrapped(*a, _fn=fn, _name=name):
+            sys.stderr.write('[call] %s\n' % _name); sys.stderr.flush()
+            r = _fn(*a)
+            torch.cuda.synchronize()
+            return r
+        setattr(lib, name, wrapped)
+
+
+def lengths_of(spec, S):
+    import numpy as np
+    if spec == 'ragged':           # bench.py's reference-defaults shape: >= 1024 chunks of 16
+        rng = np.random.Generator(np.random.PCG64(99))
+        lens, chunks = [], 0
+        while chunks < 1024:
+            t = int(rng.integers(100, 900))
+            lens.append(t)
+            chunks += (t + 15) // 16
+        return lens
+    if spec == 'ragged_small':
+        rng = np.random.Generator(np.random.PCG64(5))
+        return [int(rng.integers(1, 200)) for _ in range(37)]
+    if isinstance(spec, int):
+        return [S] * spec
+    return list(spec)
+
+
+def one(name, iters):
+    torch = install_guard()
+    from dotaclient_amd import synth, _lib
+    from dotaclient_amd.engine import Engine, pack_rollouts
+    cell, hidden, layers, spec, S, flags, reuse = WORKLOADS[name]
+    use_graph = name.startswith('graph:')
+    if os.environ.get('DC_GUARD_TRACE') == '1':
+        trace_calls(_lib.load())
+    dev = torch.device('cuda:0')
+    eng = Engine(cell, hidden, layers, dev)
+    eng.kernel_flags = flags
+    eng.reuse_rollout_forward = reuse
+    eng.load_state_dict(synth.init_state_dict(7, cell, hidden, layers))
+    batch = pack_rollouts(synth.make_rollouts(1000, lengths_of(spec, S)), S, dev)
+    t0 = time.time()
+    graph = None
+    stream = torch.cuda.Stream(device=dev) if use_graph else torch.cuda.current_stream()
+    for i in range(iters):
+        with torch.cuda.stream(stream):
+            chunks = eng.rollout_pass(batch, S)
+            for ep in range(4):
+                if not use_graph or (i == 0 and ep == 0):
+                    eng.train_epoch(chunks, 5e-5, 5e-4, 0.5, graph=False)
+                elif graph is None:
+                    torch.cuda.synchronize()
+                    graph = RawHipGraph(torch)
+                    graph.capture(stream, lambda: eng.train_epoch(chunks, 5e-5, 5e-4, 0.5, graph=False))
+                    sys.stderr.write('captured %d nodes\n' % graph.n_nodes)
+                    graph.launch(stream)
+                else:
+                    graph.launch(stream)
+            if os.environ.get('DC_GUARD_NOSYNC') == '1' and i + 1 < iters:
+                continue
+        torch.cuda.synchronize()
+        st = int(eng.status.item())
+        if st != 0:
+            print('FAIL %s: status %d at iteration %d' % (name, st, i)); sys.exit(2)
+    fin = bool(torch.isfinite(eng.params).all()) and bool(torch.isfinite(eng.out[:11]).all())
+    print('%s %s rows=%d iters=%d loss=%.6f finite=%s %.1fs' % ('OK' if fin else 'FAIL', name, batch.rows, iters, float(eng.out[0]), fin,
+                                                              time.time() - t0))
+    sys.exit(0 if fin else 2)
+
+
+def selftest():
+    torch = install_guard()
+    from dotaclient_amd import _lib
+    from dotaclient_amd import engine as E
+    x = E.device_empty(1024, torch.float32, "cuda:0").fill_(1.0)          # exactly 4096 bytes, ends at the edge of its mapping
+    y = E.device_empty(2048, torch.float32, "cuda:0")
+    lib = _lib.load()
+    _lib.check(lib.dc_discount(_lib.ptr(x), 1024, 0.5, _lib.ptr(y), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    sys.stderr.write('in-bounds call fine; now one element past the end\n'); sys.stderr.flush()
+    _lib.check(lib.dc_discount(_lib.ptr(x), 1025, 0.5, _lib.ptr(y), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    print('selftest: NO FAULT - the guard does not work')
+
+
+if __name__ == '__main__':
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    iters = int(os.environ.get('DC_GUARD_ITERS', '3'))
+    if args and args[0] == 'selftest':
+        selftest()
+    elif args and args[0] in WORKLOADS and len(args) == 1:
+        one(args[0], iters)
+    else:
+        names = args or list(WORKLOADS)
+        bad = 0
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), 'selftest'], capture_output=True, text=True, timeout=300)
+        ok = r.returncode != 0 and 'fault' in r.stderr
+        print('%-32s %s (rc=%d)' % ('selftest(overrun must fault)', 'OK' if ok else 'GUARD INEFFECTIVE', r.returncode), flush=True)
+        bad += 0 if ok else 1
+        START_MODE = ('cfg2_lstm256_256x256', 'gru256_s16_ragged', 'gru256_tiny_ragged', 'graph:cfg2_lstm256_256x256')
+        for mode in os.environ.get('DC_GUARD_MODES', 'end,start').split(','):
+            for n in names:
+                if mode == 'start' and not args and n not in START_MODE:
+                    continue
+                env = dict(os.environ, DC_GUARD_MODE=mode)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), n], capture_output=True, text=True, timeout=900, env=env)
+                tail = (r.stdout.strip().splitlines() or [''])[-1]
+                err = [l for l in r.stderr.splitlines() if 'fault' in l or 'rror' in l or 'ERROR' in l or 'failed' in l]
+                if r.returncode != 0 and not err:
+                    err = r.stderr.strip().splitlines()[-3:]
+                print('%-5s %-32s rc=%d %s %s' % (mode, n, r.returncode, tail, ' | '.join(err[:3])), flush=True)
+                bad += 1 if r.returncode != 0 else 0
+        sys.exit(1 if bad else 0)
