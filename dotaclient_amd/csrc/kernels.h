@@ -161,7 +161,12 @@ bool rnn_team_supported(int cell, int H, int n_seq, int flags);
 bool lstm_step_bf16_supported(int cell, int H, int flags, const void* Wb);
 int lstm_forward_steps_bf16(RnnStepArgs a, int max_len, hipStream_t s);
 int lstm_backward_steps_bf16(RnnStepArgs a, int max_len, hipStream_t s);
-long long rnn_team_xbuf_bytes();   // size of DC_WS_TEAM_XBUF
+long long rnn_team_xbuf_bytes();   // size of DC_WS_TEAM_XBUF (H = 256)
+// rnn_team512.hip: persistent bf16 LSTM-512 (teams of sixteen workgroups, 32-sequence MFMA tiles)
+bool lstm_team512_supported(int cell, int H, int flags, const void* Wb);
+int lstm_team512_forward(RnnStepArgs a, int max_len, hipStream_t s);
+int lstm_team512_backward(RnnStepArgs a, int max_len, hipStream_t s);
+long long lstm_team512_xbuf_bytes();   // size of DC_WS_TEAM_XBUF (H = 512)
 // rnn_team_mfma.hip (LSTM-256, more than 128 sequences: a team advances four sequences together on the 4x4x1 MFMA)
 bool lstm_team_mfma_supported(int cell, int H, int n_seq, int flags, bool backward);
 int lstm_team_mfma_forward(int cell, RnnStepArgs a, int max_len, int n_teams, hipStream_t s);

@@ -88,7 +88,8 @@ int64_t workspace_layout(const dc_dims* d, int64_t* out) {
     put(DC_WS_WHHT, H * G * H * 4);
     put(DC_WS_SCRATCH, (int64_t)DC_SCRATCH_FLOATS * 4);   // two-stage reductions / split-K slabs
     put(DC_WS_HEADW_PAD, (int64_t)HO_LD * H * 4);          // head weights zero-padded to 160 rows (K of dH)
-    put(DC_WS_TEAM_XBUF, H == 256 ? rnn_team_xbuf_bytes() : 0);   // exchange ring of the H = 256 team kernels (rnn_team.hip)
+    // exchange ring of the team kernels: H = 256 (rnn_team.hip, rnn_team_mfma.hip), H = 512 (rnn_team512.hip: 64 MB for sixteen teams)
+    put(DC_WS_TEAM_XBUF, H == 256 ? rnn_team_xbuf_bytes() : (H == 512 ? lstm_team512_xbuf_bytes() : 0));
     put(DC_WS_WPLANES, 2 * 3 * 2 * wplane_elems(d));              // weights as bf16 planes: forward + transposed orientation
     for (int l = 0; l < d->layers; ++l) {
         const int b = DC_WS_FIXED + l * DC_WS_PER_LAYER;

@@ -336,6 +336,7 @@ int rnn_forward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     }
     if (lstm_persist) return lstm_forward_persist(a, max_len, s);
     if (team) return rnn_team_forward(cell, a, max_len, s);
+    if (lstm_team512_supported(cell, a.H, a.flags, a.Whh_bf)) return lstm_team512_forward(a, max_len, s);
     if (lstm_step_bf16_supported(cell, a.H, a.flags, a.Whh_bf)) return lstm_forward_steps_bf16(a, max_len, s);
     dim3 grid(a.H / 16, (a.n_seq + 15) / 16);
     for (int t = 0; t < max_len; ++t) {
@@ -353,6 +354,7 @@ int rnn_backward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     if (int e = check_h(a.H)) return e;
     if (cell == CELL_LSTM && lstm_persist_supported(a.H) && persist_enabled(a.flags)) return lstm_backward_persist(a, max_len, s);
     if (persist_enabled(a.flags) && rnn_team_supported(cell, a.H, a.n_seq, a.flags)) return rnn_team_backward(cell, a, max_len, s);
+    if (lstm_team512_supported(cell, a.H, a.flags, a.WhhT_bf)) return lstm_team512_backward(a, max_len, s);
     if (lstm_step_bf16_supported(cell, a.H, a.flags, a.WhhT_bf)) return lstm_backward_steps_bf16(a, max_len, s);
     dim3 grid(a.H / 16, (a.n_seq + 15) / 16);
     for (int t = max_len - 1; t >= 0; --t) {

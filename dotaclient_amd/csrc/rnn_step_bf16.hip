@@ -266,7 +266,7 @@ static int set_lds(K kern, int bytes) {
 
 // LSTM layers in bf16 mode whose W_hh arrived as bf16 (both orientations); H = 256 keeps its team kernels (f32 recurrence)
 bool lstm_step_bf16_supported(int cell, int H, int flags, const void* Wb) {
-    return cell == 1 && (flags & DC_DIMS_BF16) && !(flags & DC_DIMS_RNN_PER_STEP) && Wb != nullptr && (H == 512 || H == 1024);
+    return cell == 1 && (flags & DC_DIMS_BF16) && !(flags & DC_DIMS_RNN_PER_STEP) && Wb != nullptr && (H == 512 || H == 1024);   // (H = 512: behind rnn_team512.hip)
 }
 // (the callers also need 4 * n_seq <= rows: the step-major bf16 copies live in the layer's GRU-only `hn` buffer, policy.hip)
 

@@ -44,6 +44,7 @@ DC_DIMS_BF16 = 4096
 DC_DIMS_GEMM_X3_ALL = 8192
 DC_DIMS_TEAM_VALU = 16384
 DC_DIMS_EMBED_UNFUSED = 32768
+DC_DIMS_RNN_STEP_BF16 = 65536
 
 WS_FIXED = ['FAULT', 'BASIC', 'EMB', 'DEMB', 'XCAT', 'AMAX', 'PRE', 'HEADOUT', 'TU', 'DHEADOUT', 'DTU', 'DPRE', 'DXCAT',
             'STATS', 'WHHT', 'SCRATCH', 'HEADW_PAD', 'TEAM_XBUF', 'WPLANES']
@@ -75,7 +76,7 @@ def device_copy(t, device, non_blocking=False):
     return out
 
 
-FAULT_KERNELS = {1: 'rnn_team_fwd', 2: 'rnn_team_bwd', 3: 'team_mfma_fwd', 4: 'team_mfma_bwd'}
+FAULT_KERNELS = {1: 'rnn_team_fwd', 2: 'rnn_team_bwd', 3: 'team_mfma_fwd', 4: 'team_mfma_bwd', 5: 'lstm512_team_fwd', 6: 'lstm512_team_bwd'}
 DC_FAULT_TEAM_TIMEOUT = 16
 
 
@@ -106,6 +107,7 @@ class PackedBatch:
         self._chunk_meta = {}
         self._bufs = {}            # output buffers of the passes over THIS batch, allocated once (Engine._buf)
         self.is_first = self.prev_row = None
+        self.ready = None          # IncrementalPacker: event behind the H2D copies of this batch (the first pass waits on it)
 
     def as_chunks(self, seq_len):
         """Same rows viewed as B = rows/seq_len sequences of seq_len steps (rollouts are stored padded to a
@@ -214,12 +216,22 @@ def pack_rollouts(rollouts, seq_len, device, staging=None):
         return _pack_locked(rollouts, seq_len, dev, pin, pair.take(rows), lens, rows)
 
 
-def _pack_locked(rollouts, seq_len, dev, pin, st, lens, rows):
-    lens_n = np.asarray(lens, dtype=np.int64)
-    off = np.concatenate([[0], np.cumsum(lens_n)[:-1]]).astype(np.int64)
+_OBS_B, _ACT_B, _REW_B = 4 * L.OBS_DIM, L.ACT_DIM, 40
 
-    # five numbers (src, dst, rows, row_bytes, dst_stride) per key per rollout, executed by dc_pack_rows in one call
-    keep, items = [], []
+
+def _obs_columns():
+    cols = [('env', 0, L.ENV_FEATS)]
+    c = L.ENV_FEATS
+    for key, cnt in L.UNIT_COUNTS.items():
+        cols.append((key, c, cnt * L.UNIT_FEATS))
+        c += cnt * L.UNIT_FEATS
+    return cols
+
+
+def _rollout_items(d, r0, lp, st, keep, items):
+    """Appends the copy descriptors (src, dst, rows, row_bytes, dst_stride) of ONE rollout whose rows start at r0 of staging set `st`
+    and which is stored padded to lp rows."""
+    T = int(d['rewards'].shape[0])
 
     def ptr_of(x, dtype, width):
         if type(x) is torch.Tensor and x.dtype is _TORCH_OF[dtype] and x.numel() == T * width and x.is_contiguous():
@@ -237,31 +249,36 @@ def _pack_locked(rollouts, seq_len, dev, pin, st, lens, rows):
         return a.__array_interface__['data'][0]
 
     obs_p, act_p, msk_p, rew_p = st.obs.data_ptr(), st.act.data_ptr(), st.msk.data_ptr(), st.rew.data_ptr()
-    OBS_B, ACT_B, REW_B = 4 * L.OBS_DIM, L.ACT_DIM, 40
-    obs_cols = [('env', 0, L.ENV_FEATS)]
-    c = L.ENV_FEATS
-    for key, cnt in L.UNIT_COUNTS.items():
-        obs_cols.append((key, c, cnt * L.UNIT_FEATS))
-        c += cnt * L.UNIT_FEATS
-    for i, d in enumerate(rollouts):
-        T, lp, r0 = int(d['rewards'].shape[0]), lens[i], int(off[i])
-        o, acts, msks = d['observations'], d['actions'], d['masks']
-        for key, c0, w in obs_cols:
-            items += (ptr_of(o[key], np.float32, w), obs_p + r0 * OBS_B + 4 * c0, T, 4 * w, OBS_B)
-        for key in L.OUTPUT_KEYS:
-            h0, hc = L.HEAD_OFFSETS[key], L.HEAD_COUNTS[key]
-            items += (ptr_of(acts[key], np.uint8, hc), act_p + r0 * ACT_B + h0, T, hc, ACT_B)
-            items += (ptr_of(msks[key], np.uint8, hc), msk_p + r0 * ACT_B + h0, T, hc, ACT_B)
-        items += (ptr_of(d['rewards'], np.float32, 10), rew_p + r0 * REW_B, T, REW_B, REW_B)
-        if lp > T:      # the zero pad of optimizer.py:367-382 (the buffers are reused: clear just these rows)
-            n = lp - T
-            items += (0, obs_p + (r0 + T) * OBS_B, n, OBS_B, OBS_B)
-            items += (0, act_p + (r0 + T) * ACT_B, n, ACT_B, ACT_B)
-            items += (0, msk_p + (r0 + T) * ACT_B, n, ACT_B, ACT_B)
-            items += (0, rew_p + (r0 + T) * REW_B, n, REW_B, REW_B)
+    o, acts, msks = d['observations'], d['actions'], d['masks']
+    for key, c0, w in _obs_columns():
+        items += (ptr_of(o[key], np.float32, w), obs_p + r0 * _OBS_B + 4 * c0, T, 4 * w, _OBS_B)
+    for key in L.OUTPUT_KEYS:
+        h0, hc = L.HEAD_OFFSETS[key], L.HEAD_COUNTS[key]
+        items += (ptr_of(acts[key], np.uint8, hc), act_p + r0 * _ACT_B + h0, T, hc, _ACT_B)
+        items += (ptr_of(msks[key], np.uint8, hc), msk_p + r0 * _ACT_B + h0, T, hc, _ACT_B)
+    items += (ptr_of(d['rewards'], np.float32, 10), rew_p + r0 * _REW_B, T, _REW_B, _REW_B)
+    if lp > T:      # the zero pad of optimizer.py:367-382 (the buffers are reused: clear just these rows)
+        n = lp - T
+        items += (0, obs_p + (r0 + T) * _OBS_B, n, _OBS_B, _OBS_B)
+        items += (0, act_p + (r0 + T) * _ACT_B, n, _ACT_B, _ACT_B)
+        items += (0, msk_p + (r0 + T) * _ACT_B, n, _ACT_B, _ACT_B)
+        items += (0, rew_p + (r0 + T) * _REW_B, n, _REW_B, _REW_B)
+
+
+def _run_items(items, threads=None):
     tab = np.ascontiguousarray(np.array(items, dtype=np.int64).reshape(-1, 5).T)          # [5, n_items] (items: flat list)
     col = lambda k: ctypes.c_void_p(tab[k].ctypes.data)
-    _lib.check(_lib.load().dc_pack_rows(col(0), col(1), col(2), col(3), col(4), tab.shape[1], PACK_THREADS), 'dc_pack_rows')
+    _lib.check(_lib.load().dc_pack_rows(col(0), col(1), col(2), col(3), col(4), tab.shape[1], PACK_THREADS if threads is None else threads),
+               'dc_pack_rows')
+
+
+def _pack_locked(rollouts, seq_len, dev, pin, st, lens, rows):
+    lens_n = np.asarray(lens, dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(lens_n)[:-1]]).astype(np.int64)
+    keep, items = [], []      # five numbers per key per rollout, executed by dc_pack_rows in one call
+    for i, d in enumerate(rollouts):
+        _rollout_items(d, int(off[i]), lens[i], st, keep, items)
+    _run_items(items)
     to = lambda x: device_copy(x[:rows], dev, non_blocking=True) if pin else x[:rows].clone()
     batch = PackedBatch(to(st.obs), to(st.act), to(st.msk), to(st.rew), device_copy(torch.from_numpy(off), dev),
                         device_copy(torch.from_numpy(lens_n.astype(np.int32)), dev), int(lens_n.max()))
@@ -269,6 +286,87 @@ def _pack_locked(rollouts, seq_len, dev, pin, st, lens, rows):
         st.event = torch.cuda.Event()
         st.event.record()
     return batch
+
+
+class IncrementalPacker:
+    """pack_rollouts one rollout at a time - the consumer loop's form (optimizer.py:448-462 receives the rollouts of a batch one by
+    one from the experience queue): `add` copies a rollout into the page-locked staging set THE MOMENT IT ARRIVES (host work that
+    hides behind the wait for the next message - and, when the loop prefetches, behind the previous iteration's epochs on the GPU);
+    `finish` enqueues the four H2D copies on a side stream and returns the PackedBatch, whose `ready` event the rollout pass waits on.
+    The batch is byte-for-byte what pack_rollouts makes of the same rollouts in the same order (tests/test_host_logic.py).
+
+    Owns its StagingPair (two sets: the one being filled and the one whose H2D copies may still be in flight)."""
+
+    def __init__(self, seq_len, device, expected_rows=0):
+        self.seq_len, self.dev = int(seq_len), torch.device(device)
+        self.pin = self.dev.type == 'cuda'
+        self.pair = StagingPair(self.pin)
+        self.expected_rows = int(expected_rows)
+        self.stream = torch.cuda.Stream(device=self.dev) if self.pin else None
+        self._begin()
+
+    def _begin(self):
+        self.st = None
+        self.rows, self.lens, self.n = 0, [], 0
+
+    def __len__(self):
+        return self.n
+
+    @property
+    def n_seq(self):
+        return self.rows // self.seq_len
+
+    def add(self, d):
+        lp = (int(d['rewards'].shape[0]) + self.seq_len - 1) // self.seq_len * self.seq_len
+        need = self.rows + lp
+        if self.st is None:
+            with self.pair.lock:
+                self.st = self.pair.take(max(need, self.expected_rows))
+        elif self.st.capacity < need:                 # rare (a batch larger than any before): move what is packed into a larger set
+            old = self.st
+            new = _StagingSet(max(need, old.capacity + old.capacity // 2), self.pin)
+            for name in ('obs', 'act', 'msk', 'rew'):
+                getattr(new, name)[:self.rows].copy_(getattr(old, name)[:self.rows])
+            with self.pair.lock:
+                self.pair.sets[self.pair.sets.index(old)] = new
+            self.st = new
+        keep, items = [], []
+        _rollout_items(d, self.rows, lp, self.st, keep, items)
+        _run_items(items, threads=min(PACK_THREADS, 4))
+        self.rows = need
+        self.lens.append(lp)
+        self.n += 1
+        self.expected_rows = max(self.expected_rows, need)
+
+    def finish(self):
+        if self.n == 0:
+            raise ValueError('IncrementalPacker.finish: no rollouts')
+        lens_n = np.asarray(self.lens, dtype=np.int64)
+        off = np.concatenate([[0], np.cumsum(lens_n)[:-1]]).astype(np.int64)
+        st, rows, dev = self.st, self.rows, self.dev
+        if not self.pin:
+            batch = PackedBatch(st.obs[:rows].clone(), st.act[:rows].clone(), st.msk[:rows].clone(), st.rew[:rows].clone(),
+                                torch.from_numpy(off), torch.from_numpy(lens_n.astype(np.int32)), int(lens_n.max()))
+            self._begin()
+            return batch
+        cur = torch.cuda.current_stream(dev)
+        # destination buffers belong to the CURRENT stream (where the passes will use and eventually free them); the copies run on the
+        # side stream, which the copy engine serves while the current stream's kernels keep computing
+        dst = [device_empty(x[:rows].shape, x.dtype, dev) for x in (st.obs, st.act, st.msk, st.rew)]
+        seq_off = device_copy(torch.from_numpy(off), dev)
+        seq_len = device_copy(torch.from_numpy(lens_n.astype(np.int32)), dev)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            for t, x in zip(dst, (st.obs, st.act, st.msk, st.rew)):
+                t.copy_(x[:rows], non_blocking=True)
+                t.record_stream(self.stream)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        st.event = ready
+        batch = PackedBatch(dst[0], dst[1], dst[2], dst[3], seq_off, seq_len, int(lens_n.max()))
+        batch.ready = ready
+        self._begin()
+        return batch
 
 
 class Engine:
@@ -497,6 +595,9 @@ class Engine:
         """optimizer.py:328-430 for all rollouts of `batch` at once: no-grad forward with the hidden state
         carried across a rollout's chunks, old log-probs, values, GAE.  Returns the chunk view."""
         from . import ops
+        if batch.ready is not None:                   # the batch's H2D copies ran on a side stream
+            torch.cuda.current_stream(self.device).wait_event(batch.ready)
+            batch.ready = None
         d, _, _ = self.forward(batch, lazy_tu=True)
         batch.old_logp, batch.values, batch.argmax = self.select_logp(d, batch)
         dev = self.device

@@ -27,7 +27,7 @@ import torch
 
 from . import layout as L
 from . import ops
-from .engine import PackedBatch, pack_rollouts
+from .engine import IncrementalPacker, PackedBatch, pack_rollouts
 from .policy import Policy
 
 logger = logging.getLogger(__name__)
@@ -166,6 +166,12 @@ class DotaOptimizer:
         # :581-689): the engine back-propagates those activations instead of recomputing the same forward (Engine.reuse_rollout_forward;
         # results equal, one forward pass in five saved).  False restores the reference's pass count.
         self.engine.reuse_rollout_forward = bool(reuse_rollout_forward)
+        # Ingest: every rollout is copied into page-locked staging the moment it arrives (IncrementalPacker),
+        # and with prefetch=True run_iteration drains what ALREADY WAITS in the experience queue into the next batch's staging while
+        # the GPU works through this iteration's epochs (never blocking on an empty queue: the model publish is not delayed).
+        self.prefetch = bool(prefetch)
+        self._packer = IncrementalPacker(seq_len, self.device, expected_rows=(min_seq_per_epoch + 64) * seq_len)
+        self._prefetched = None
 
         # optimizer.py:241-267, the run_local branch: the newest model_%09d.pt of log_dir overrides an explicit pretrained model,
         # and the iteration counter resumes behind the file's number so that published versions never go backwards
@@ -226,7 +232,9 @@ class DotaOptimizer:
     def experiences_from_rollouts(self, rollouts):
         """Batched form of optimizer.py:328-430: all rollouts go through ONE rollout pass (the hidden
         state only couples chunks within a rollout).  Returns (list[Sequence], chunk PackedBatch)."""
-        batch = pack_rollouts(rollouts, self.seq_len, self.device)
+        return self._experiences_from_batch(rollouts, pack_rollouts(rollouts, self.seq_len, self.device))
+
+    def _experiences_from_batch(self, rollouts, batch):
         chunks = self.engine.rollout_pass(batch, self.seq_len, gamma=0.98, lam=0.97)
         seqs = []
         lens = batch.seq_len.cpu().tolist()
@@ -297,32 +305,79 @@ class DotaOptimizer:
     def list_of_dicts_to_dict_of_lists(x):
         return {k: torch.stack([d[k] for d in x]) for k in x[0]}
 
-    def run_iteration(self, it):
-        """Body of the reference's run() loop (optimizer.py:437-531); returns the metrics dict."""
-        experiences, rollouts, subrewards, rollout_lens, weight_ages = [], [], [], [], []
-        start_xp = time.time()
-        xp_waits = 0.0
-        n_seq = 0
-        while n_seq < self.min_seq_per_epoch:                               # optimizer.py:448-462
-            t0 = time.time()
-            rollout, rollout_subrewards, rollout_len, weight_version, canvas = self.get_rollout()
-            xp_waits += time.time() - t0
-            rollouts.append(rollout)
-            n_seq += (rollout_len + self.seq_len - 1) // self.seq_len
-            subrewards.append(rollout_subrewards)
-            rollout_lens.append(rollout_len)
-            weight_ages.append(it - weight_version)
-        experiences, _ = self.experiences_from_rollouts(rollouts)
-        time_xp = time.time() - start_xp
+    @staticmethod
+    def _new_gather():
+        return {'rollouts': [], 'subrewards': [], 'rollout_lens': [], 'weight_versions': [], 'xp_waits': 0.0, 'hidden_s': 0.0,
+                'n_prefetched': 0}
 
-        losses, entropies, grad_norms = [], [], []
+    def _consume_one(self, acc):
+        """One message off the experience queue (optimizer.py:452-455), packed into the staging set at once."""
+        t0 = time.time()
+        rollout, rollout_subrewards, rollout_len, weight_version, canvas = self.get_rollout()
+        acc['xp_waits'] += time.time() - t0
+        self._packer.add(rollout)
+        acc['rollouts'].append(rollout)
+        acc['subrewards'].append(rollout_subrewards)
+        acc['rollout_lens'].append(rollout_len)
+        acc['weight_versions'].append(weight_version)
+
+    def _queue_has_messages(self):
+        """The reference MessageQueue's own `xp_queue_size` (optimizer.py:126-132: a passive queue_declare, None on failure); an
+        injected queue object without it simply never prefetches."""
+        try:
+            return bool(getattr(self.mq, 'xp_queue_size', None))
+        except Exception:                                                   # noqa: BLE001 - the reference swallows everything here too
+            return False
+
+    def run_iteration(self, it):
+        """Body of the reference's run() loop (optimizer.py:437-531); returns the metrics dict.
+
+        Same work in the same order as the reference on the device; what differs is when the HOST waits: the E epochs are enqueued
+        back to back (their losses / status land in a device-side history, read with ONE synchronisation at the end - the reference
+        synchronises after every epoch through .item()), and while the GPU works the host already drains the experience queue into
+        the next batch's staging (`prefetch`).  NaN guards (optimizer.py:667-669,678-679): the optimizer step of a NaN epoch is skipped
+        on the device, so raising after the last epoch leaves the same parameters behind as raising in the middle."""
+        acc = self._prefetched if self._prefetched is not None else self._new_gather()
+        self._prefetched = None
+        start_xp = time.time()
+        while self._packer.n_seq < self.min_seq_per_epoch:                  # optimizer.py:448-462
+            self._consume_one(acc)
+        batch = self._packer.finish()                                       # H2D on the packer's stream; the rollout pass waits on its event
+        experiences, chunks = self._experiences_from_batch(acc['rollouts'], batch)
+        time_xp = time.time() - start_xp
+        subrewards, rollout_lens = acc['subrewards'], acc['rollout_lens']
+        weight_ages = [it - v for v in acc['weight_versions']]
+        xp_waits = acc['xp_waits']
+
         start_opt = time.time()
+        hist = torch.empty(self.epochs, 12, dtype=torch.float32, device=self.device)
         for ep in range(self.epochs):                                       # optimizer.py:469-475
             self.mq.process_data_events()
-            l, e, g = self.train(experiences=experiences)
-            losses.append(l); entropies.append(e); grad_norms.append(g)
+            out, status = self.engine.train_epoch(chunks, self.learning_rate, self.entropy_coef, self.vf_coef,
+                                                  e_clip=self.e_clip, grad_hook=self.grad_hook)
+            hist[ep, :11].copy_(out[:11])
+            hist[ep, 11:].copy_(status)
         if self.checkpoint:
-            self._snapshot = self.engine.start_param_snapshot()            # D2H for the publish, beside the metric reads below
+            self._snapshot = self.engine.start_param_snapshot()            # D2H for the publish, behind the last epoch
+        if self.prefetch:
+            t0 = time.time()
+            nxt = self._new_gather()
+            while self._packer.n_seq < self.min_seq_per_epoch and self._queue_has_messages():
+                self._consume_one(nxt)
+            nxt['hidden_s'], nxt['n_prefetched'] = time.time() - t0, len(nxt['rollouts'])
+            self._prefetched = nxt
+        host = hist.cpu()                                                   # the one synchronisation of the iteration
+        losses, entropies, grad_norms = [], [], []
+        for ep in range(self.epochs):
+            row = host[ep]
+            st = int(row[11].item())
+            if st == 1:                                                     # optimizer.py:667-669
+                raise ValueError('loss={}, policy_loss={}, entropy_loss={}, value_loss={}'.format(*row[:4].tolist()))
+            if st == 2:                                                     # optimizer.py:678-679
+                raise ValueError('grad_norm={}'.format(row[9].item()))
+            losses.append({'loss': row[0], 'policy_loss': row[1], 'entropy_loss': row[2], 'value_loss': row[3]})
+            entropies.append({k: row[4 + i] for i, k in enumerate(L.OUTPUT_KEYS)})
+            grad_norms.append({'unclipped': row[9], 'clipped': row[10]})
         time_opt = time.time() - start_opt
         losses = self.list_of_dicts_to_dict_of_lists(losses)
         entropies = self.list_of_dicts_to_dict_of_lists(entropies)
@@ -340,6 +395,9 @@ class DotaOptimizer:
             'avg_rollout_len': float(np.mean(rollout_lens)), 'avg_weight_age': float(np.mean(weight_ages)),
             'timing/it': time_it, 'timing/xp_total': time_xp, 'timing/xp_mq_wait': xp_waits,
             'timing/optimizer': time_opt,
+            # not in the reference: the part of gathering + packing this batch that ran during the previous iteration's epochs, and how
+            # many of its rollouts came in that way (timing/xp_total is the foreground part only)
+            'timing/xp_hidden': acc['hidden_s'], 'xp_rollouts_prefetched': float(acc['n_prefetched']),
         }
         for k, v in entropies.items():
             metrics['entropy/' + k] = v.mean()

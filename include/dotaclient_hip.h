@@ -138,6 +138,9 @@ typedef struct dc_dims {
 /*   DC_DIMS_EMBED_UNFUSED  : the unit-embedding MLP layer by layer (first layer materialised, six dense products) instead of the
  *                            fused kernels, which handle any row count by padding the type-major blocks to a multiple of 128 rows. */
 #define DC_DIMS_EMBED_UNFUSED 32768
+/*   DC_DIMS_RNN_STEP_BF16  : DC_DIMS_BF16 with H = 512: the launch-per-step bf16 recurrent kernels (rnn_step_bf16.hip) instead of the
+ *                            persistent team kernel (rnn_team512.hip: sixteen workgroups hold W_hh as bf16 in their registers). */
+#define DC_DIMS_RNN_STEP_BF16 65536
 
 /* index into poff[]; policy.py:54-75 names in comments */
 enum dc_param_index {
@@ -171,7 +174,8 @@ enum dc_ws_index {
 /* DC_WS_FAULT - where a failure of the H = 256 team kernels is reported.  Those kernels hand state between four workgroups
  * through tagged granules; a member that polls one for ~1 s without seeing its tag gives up, NaN-poisons its outputs (the loss
  * turns NaN: status 1 of dc_gradnorm_clip_adam, the reference's own guard, optimizer.py:667-669) and - first writer wins - records
- *   [0] DC_FAULT_TEAM_TIMEOUT + kernel (1 rnn_team_fwd, 2 rnn_team_bwd, 3 team_mfma_fwd, 4 team_mfma_bwd), [1] layer, [2] team,
+ *   [0] DC_FAULT_TEAM_TIMEOUT + kernel (1 rnn_team_fwd, 2 rnn_team_bwd, 3 team_mfma_fwd, 4 team_mfma_bwd, 5 lstm512_team_fwd,
+ *   6 lstm512_team_bwd), [1] layer, [2] team,
  *   [3] member, [4] time step, [5] sequence, [6] the tag it waited for, [7] reserved.
  * The record is STICKY: the library never clears it.  The owner of the workspace zeroes these 32 bytes once after allocating it
  * (and again after reading a fault, if it wants to carry on). */

@@ -25,6 +25,10 @@ class FakeMQ:
     def consume_xp(self): return None, None, self.bodies.pop(0)
     def publish_model(self, msg, hdr): self.published.append((hdr, len(msg)))
 
+    @property
+    def xp_queue_size(self):                       # optimizer.py:126-132
+        return len(self.bodies)
+
 
 def make_opt(rollouts, g, tmp_path, **kw):
     from dotaclient_amd.optimizer import DotaOptimizer
@@ -150,6 +154,70 @@ def test_run_iteration_and_nan_guard(tmp_path):
     with pytest.raises(ValueError):
         opt.train(experiences=seqs)
     assert torch.equal(before, opt.engine.params)
+
+
+def test_run_iteration_raises_on_nan_like_the_reference(tmp_path):
+    # a NaN observation inside run_iteration itself: the epochs are enqueued back to back and checked once at the end - ValueError
+    # (optimizer.py:667-669) and untouched parameters all the same
+    g, rollouts = util.load_case('ragged_s16')
+    bad = synth.make_rollouts(77, [32, 48])
+    bad[1]['observations']['env'][3, 0] = float('nan')
+    opt = make_opt(bad, g, tmp_path)
+    opt.min_seq_per_epoch = 4
+    before = opt.engine.params.clone()
+    with pytest.raises(ValueError):
+        opt.run_iteration(1)
+    assert torch.equal(before, opt.engine.params)
+
+
+def test_prefetching_consumer_loop_equals_the_serial_one(tmp_path):
+    # run_iteration packs every rollout as it arrives and, while the GPU works through the epochs, already drains
+    # the experience queue into the NEXT batch's staging.  Same rollout stream through a prefetching and a serial optimizer: the
+    # batches of every iteration are bit-identical, the metrics equal, and the prefetched part is not counted in timing/xp_total.
+    g, _ = util.load_case('ragged_s16')
+    stream = synth.make_rollouts(31, [40, 64, 21, 33, 50, 16, 64, 48, 17, 80, 30, 64, 25, 70, 44, 16, 90, 35])
+    opts = {pf: make_opt([dict(r) for r in stream], g, tmp_path, prefetch=pf) for pf in (True, False)}
+    seen = {True: [], False: []}
+    for pf, opt in opts.items():
+        opt.min_seq_per_epoch = 9
+        orig = opt._experiences_from_batch
+
+        def spy(rollouts, batch, _orig=orig, _pf=pf):
+            seen[_pf].append({k: getattr(batch, k).clone() for k in ('obs', 'act', 'mask', 'rew', 'seq_off', 'seq_len')})
+            return _orig(rollouts, batch)
+        opt._experiences_from_batch = spy
+    metrics = {pf: [opt.run_iteration(it) for it in (1, 2, 3)] for pf, opt in opts.items()}
+    for it in range(3):
+        a, b = seen[True][it], seen[False][it]
+        for k in a:
+            assert torch.equal(a[k], b[k]), (it, k)
+        ma, mb = metrics[True][it], metrics[False][it]
+        for k in ('loss/sum', 'loss/policy', 'loss/value', 'entropy', 'grad_norm/unclipped', 'avg_rollout_len', 'avg_weight_age', 'reward_per_sec/sum'):
+            assert abs(float(ma[k]) - float(mb[k])) <= 2e-5 * max(1.0, abs(float(mb[k]))), (it, k, float(ma[k]), float(mb[k]))
+    assert metrics[False][1]['xp_rollouts_prefetched'] == 0 and metrics[False][1]['timing/xp_hidden'] == 0
+    # iterations 2 and 3 found their rollouts already packed
+    assert metrics[True][1]['xp_rollouts_prefetched'] >= 1 and metrics[True][2]['xp_rollouts_prefetched'] >= 1
+    assert metrics[True][1]['timing/xp_hidden'] > 0
+    assert torch.allclose(opts[True].engine.params, opts[False].engine.params, rtol=0, atol=2e-6)
+
+
+def test_checkpoint_resume_restores_the_iteration_counter(tmp_path):
+    # optimizer.py:231-267 (run_local): log_dir is created, the newest model_%09d.pt there is loaded and the published versions carry
+    # on behind it (a restart republished from version 1)
+    g, rollouts = util.load_case('ragged_s16')
+    log_dir = tmp_path / 'fresh' / 'logs'
+    from dotaclient_amd.optimizer import DotaOptimizer
+    kw = dict(rmq_host='x', rmq_port=0, epochs=1, min_seq_per_epoch=1, seq_len=16, learning_rate=1e-4, pretrained_model=None,
+              mq_prefetch_count=1, log_dir=str(log_dir), entropy_coef=5e-4, vf_coef=0.5, run_local=True)
+    a = DotaOptimizer(checkpoint=True, mq=FakeMQ(rollouts), **kw)
+    assert a.iteration_start == 1 and (log_dir / 'model_000000001.pt').exists()
+    a.policy_base.load_state_dict(synth.init_state_dict(11), strict=True)
+    a.upload_model(version=7)
+    b = DotaOptimizer(checkpoint=True, mq=FakeMQ(rollouts), **kw)
+    assert b.iteration_start == 8
+    assert (log_dir / 'model_000000008.pt').exists() and b.mq.published[-1][0] == {'version': 8}
+    assert torch.equal(a.engine.params, b.engine.params)
+    assert DotaOptimizer.iteration_from_model_filename('x/model_000000123.pt') == 123
 
 
 def test_model_publish_is_the_reference_wire_format(tmp_path):

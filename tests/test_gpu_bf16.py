@@ -46,3 +46,30 @@ def test_bf16_path_within_stated_tolerance_of_fp32_oracle(cell, hidden, layers, 
     assert util.scaled_err(out['ep0_param_samples'], ref['ep0_param_samples']) < 1e-3
     # and it is really a different arithmetic: the bf16 run must NOT meet the fp32 bar
     assert util.scaled_err(out['values'], ref['values']) > 1e-5
+
+
+@pytest.mark.parametrize('lens,S', [([64] * 6, 64), ([50, 64, 33, 7, 100, 64, 1, 16] * 5, 16), ([256] * 40, 256)])
+def test_persistent_lstm512_matches_the_step_kernels(lens, S):
+    # rnn_team512.hip (the whole time loop of an LSTM-512 layer in one launch: sixteen workgroups hold W_hh as bf16 in registers and hand
+    # h_t / the partial dh sums around as tagged granules) against rnn_step_bf16.hip (one launch per time step) - the same bf16-operand /
+    # f32-accumulate arithmetic in another summation order.  Not bit-comparable: h_t is ROUNDED to bf16 before it becomes the next
+    # step's operand, so a 1-ulp f32 difference next to a rounding boundary becomes a 2^-9 difference in that element (the first
+    # steps agree to 8 digits, then single elements flip); and the persistent backward rounds its sixteen PARTIAL recurrent sums to
+    # bf16 before adding them.  Both are bf16-path approximations of the same f32 function (bar against the oracle: 3e-2, above);
+    # against each other they stay an order of magnitude closer than that.
+    # Shapes: one partial tile; ragged rollouts -> 4 tiles of chunks incl. a partial one and sequences of 1 step; two tiles x 256 steps.
+    from dotaclient_amd import engine as E
+    g = {'seq_len': S, 'lr': 5e-5, 'entropy_coef': 5e-4, 'vf_coef': 0.5, 'epochs': 1}
+    rollouts = synth.make_rollouts(77, lens)
+    team, eng = run_hip(g, rollouts, 'lstm', 512, 2, epochs=1, kernel_flags=E.DC_DIMS_BF16)
+    step, _ = run_hip(g, rollouts, 'lstm', 512, 2, epochs=1, kernel_flags=E.DC_DIMS_BF16 | E.DC_DIMS_RNN_STEP_BF16)
+    assert eng.fault() is None
+    errs = {key: util.scaled_err(team[key], step[key]) for key in ['advantages', 'values', 'hidden'] + ['old_logp_' + k for k in ('enum', 'x', 'y', 'target_unit', 'ability')]}
+    errs['argmax_mismatch'] = float((team['argmax'] != step['argmax']).mean())
+    errs['losses'] = util.loss_rel_err(team['ep0_losses'], step['ep0_losses'])
+    errs['grad_norms'] = util.rel_err(team['ep0_grad_norms'], step['ep0_grad_norms'])
+    errs['grad_samples'] = util.scaled_err(team['ep0_grad_samples'], step['ep0_grad_samples'])
+    errs['grad_tensor_norms'] = util.scaled_err(team['ep0_grad_summary'][:, 2], step['ep0_grad_summary'][:, 2])
+    print('team512 vs step kernels:', {k: float('%.3g' % v) for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < (5e-3 if k != 'argmax_mismatch' else 5e-3), (k, errs)

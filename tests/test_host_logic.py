@@ -74,6 +74,25 @@ def test_pack_rollouts_matches_flatten_and_reuses_staging():
         assert b.rows == r0
 
 
+def test_incremental_packer_equals_pack_rollouts():
+    # the consumer loop's form (one rollout at a time, as they come off the queue) must build byte-for-byte the batch pack_rollouts
+    # builds from the same rollouts - also when the staging set has to grow mid-batch and when it is reused for the next batch
+    from dotaclient_amd.engine import IncrementalPacker, pack_rollouts
+    pk = IncrementalPacker(16, torch.device('cpu'), expected_rows=32)
+    for seed, lens in [(5, [40, 64, 7, 300, 16]), (6, [16]), (7, [500, 3, 3, 90])]:
+        rollouts = synth.make_rollouts(seed, lens)
+        want = pack_rollouts(rollouts, 16, torch.device('cpu'))
+        for i, d in enumerate(rollouts):
+            pk.add(d)
+            assert len(pk) == i + 1 and pk.n_seq == sum((t + 15) // 16 for t in lens[:i + 1])
+        got = pk.finish()
+        assert len(pk) == 0 and got.max_len == want.max_len and got.rows == want.rows
+        for k in ('obs', 'act', 'mask', 'rew', 'seq_off', 'seq_len'):
+            assert torch.equal(getattr(got, k), getattr(want, k)), k
+    with pytest.raises(ValueError):
+        pk.finish()
+
+
 def test_staging_is_one_growing_pair_not_one_per_batch_size():
     # the consumer loop's row count changes almost every iteration: the page-locked staging must not accumulate a pair of
     # buffers per distinct size - one double-buffered pair, grown geometrically, a batch uses its leading rows
