@@ -22,9 +22,12 @@
 //
 // Roles by ticket, XCD-local teams when the team count is a multiple of 8, L2-scope granule stores when a team shares an XCD,
 // timeouts reported in DC_WS_FAULT: as in rnn_team.hip / team_util.h.
+#include <cstdio>
+#include <type_traits>
 #include "kernels.h"
 #include "gemm_tiles.h"
 #include "team_util.h"
+#include "persist_util.h"
 
 namespace dc {
 namespace {
@@ -40,7 +43,7 @@ enum {
     T5_FWD_RING = T5_SLOTS * T5_M * T5_PAIRS,            // words per team
     T5_BWD_RING = T5_SLOTS * T5_M * T5_M * T5_PAIRS,     // words per team: [slot][owner][source][512]
     T5_FWD_LDS = 2 * T5_NS * T5_HROW + 4 * T5_NS * T5_RED_LD * 4,
-    T5_BWD_LDS = 2 * T5_NS * T5_GROW + T5_NS * T5_RED_LD * 4,
+    T5_BWD_LDS = 2 * T5_NS * T5_GROW + 2 * T5_NS * T5_RED_LD * 4,
     T5_K_FWD = 5, T5_K_BWD = 6,              // kernel ids in the fault record (include/dotaclient_hip.h)
 };
 
@@ -96,8 +99,9 @@ __device__ __forceinline__ int t5_same_xcd(u64* hs, int member, int allow) {
 // every stale first read pay its own round trip: 30 granules per thread, 5.6 us per step.)  false on timeout.
 enum { T5_SPIN = 1 << 20 };
 template <int N, class Addr>
-__device__ __forceinline__ bool t5_poll_all(Addr addr, unsigned tag, u64 (&g)[N]) {
+__device__ __forceinline__ bool t5_poll_all(Addr addr, unsigned tag, u64 (&g)[N], long long* retries = nullptr) {
     for (int spins = 0;; ++spins) {
+        if (DC_DEV_TIMING && retries) *retries += 1;
 #pragma unroll
         for (int n = 0; n < N; ++n) g[n] = granule_load(addr(n));
         bool ok = true;
@@ -127,6 +131,9 @@ __device__ __forceinline__ int t5_tile_tmax(const RnnStepArgs& p, int b0) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 // forward.  In: gates = W_ih x + b_ih (overwritten by the activated gates), hprev / cprev rows 0 of every sequence = h0 / c0 (seeded
 // by rnn_forward_layer); out: gates, cseq, hseq, hprev / cprev (the rows the backward and the weight gradients read).
+// With one wave per SIMD nothing hides an instruction's latency and a wave64 VALU instruction occupies its SIMD for four cycles:
+// the step is as long as its instruction stream.  Hence: a thread's cells are FOUR CONSECUTIVE UNITS OF ONE SEQUENCE (one row
+// address, 16-byte loads and stores), row pointers advance by a stride, transcendental gates on v_exp / v_rcp.
 // ---------------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStepArgs p, const uint16_t* __restrict__ Wb,
                                                                           u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
@@ -153,29 +160,31 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
 #pragma unroll
         for (int ks = 0; ks < 32; ++ks) wreg[ks] = *reinterpret_cast<const bf16x8*>(wrow + ks * 16);
     }
-    // ---- this thread's cells: sequences (tid >> 4) and 16 + (tid >> 4) of the tile, units 2 (tid & 15), + 1 ----------------------------
-    const int up = tid & 15, j0 = U0 + 2 * up;
-    float bh[4][2];
+    // ---- this thread's cells: sequence tid >> 3 of the tile, units 4 (tid & 7) .. + 3 of the member's 32 --------------------------------
+    const int cs_ = tid >> 3, ub = 4 * (tid & 7), j0 = U0 + ub;
+    float4 bh[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) { bh[g][0] = p.bhh[g * H + j0]; bh[g][1] = p.bhh[g * H + j0 + 1]; }
+    for (int g = 0; g < 4; ++g) bh[g] = *reinterpret_cast<const float4*>(p.bhh + g * H + j0);
 
+    // developer builds (DC_DEV_TIMING): phase clocks of (team 0, member 0, thread 0), summed over the steps
+    long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    const bool timing = DC_DEV_TIMING && p.dbg != nullptr && team == 0 && member == 0 && tid == 0;
+    auto stamp = [&](int k) {
+        if (DC_DEV_TIMING && timing) { const long long now = (long long)__builtin_amdgcn_s_memtime(); tm[k] += now - tlast; tlast = now; }
+    };
     unsigned tag = 0;
     bool failed = false;
     const int n_tiles = (p.n_seq + T5_NS - 1) / T5_NS;
     for (int tile = team; tile < n_tiles && !failed; tile += n_teams) {
         const int b0 = tile * T5_NS;
         const int tmax = t5_tile_tmax(p, b0);
-        int len[2];
-        size_t row0[2];
-        float c[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int b = b0 + (tid >> 4) + 16 * i;
-            len[i] = b < p.n_seq ? p.seq_len[b] : 0;
-            row0[i] = len[i] > 0 ? (size_t)p.seq_off[b] : 0;
-            c[i][0] = len[i] > 0 ? p.cprev[row0[i] * H + j0] : 0.f;
-            c[i][1] = len[i] > 0 ? p.cprev[row0[i] * H + j0 + 1] : 0.f;
-        }
+        const int bq = b0 + cs_;
+        const int len = bq < p.n_seq ? p.seq_len[bq] : 0;
+        const size_t row0 = len > 0 ? (size_t)p.seq_off[bq] : 0;
+        float* const gbase = p.gates + row0 * GH + j0;                 // row t: + t * GH
+        float* const sbase = p.cseq + row0 * H + j0;                   // cseq; hseq / cprev / hprev at the same offset of their buffers
+        const ptrdiff_t d_h = p.hseq - p.cseq, d_cp = p.cprev - p.cseq, d_hp = p.hprev - p.cseq;
+        float4 c = len > 0 ? *reinterpret_cast<const float4*>(sbase + d_cp) : make_float4(0.f, 0.f, 0.f, 0.f);
         // h0 of all 512 units of the tile's sequences -> tile buffer 0
         for (int e = tid; e < T5_NS * 64; e += T5_THREADS) {
             const int s = e >> 6, k8 = (e & 63) * 8;
@@ -187,15 +196,30 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
             }
             *reinterpret_cast<u32x4*>(ht0 + s * T5_HROW + k8 * 2) = v;
         }
-        // the input projections W_ih x + b_ih of a step are fetched ONE STEP AHEAD: vector memory operations complete in order, so a
-        // load from HBM (2 us) issued right before the granule loads would sit in front of every one of them
-        float2 gxn[2][4];
+        // A step's results are STORED one step late, behind the next step's granule loads: vector memory operations complete in
+        // order, so the scattered stores of a step would otherwise sit in front of the loads the next step waits for ...
+        float4 pact[4], pc, ph;
+        bool pend = false, pnext = false;
+        int pt = 0;
+        auto flush = [&]() {
+            if (!pend) return;
+            float* gt = gbase + (size_t)pt * GH;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float* gt = p.gates + row0[i] * GH + j0;
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(gt + g * H) = pact[g];
+            float* st = sbase + (size_t)pt * H;
+            *reinterpret_cast<float4*>(st) = pc;
+            *reinterpret_cast<float4*>(st + d_h) = ph;
+            if (pnext) {
+                *reinterpret_cast<float4*>(st + H + d_cp) = pc;
+                *reinterpret_cast<float4*>(st + H + d_hp) = ph;
+            }
+            pend = false;
+        };
+        // ... and the input projections W_ih x + b_ih of a step are fetched ONE STEP AHEAD, for the same reason (a load from HBM
+        // issued right before the granule loads would sit in front of every one of them)
+        float4 gxn[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) gxn[i][g] = len[i] > 0 ? *reinterpret_cast<const float2*>(gt + g * H) : make_float2(0.f, 0.f);
-        }
+        for (int g = 0; g < 4; ++g) gxn[g] = len > 0 ? *reinterpret_cast<const float4*>(gbase + g * H) : make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
 
 #pragma unroll 1
@@ -203,15 +227,11 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
             char* const hcur = ht0 + (t & 1) * (T5_NS * T5_HROW);          // holds h_{t-1}
             char* const hnxt = ht0 + ((t + 1) & 1) * (T5_NS * T5_HROW);    // receives h_t
             ++tag;
-            // (a) this step's input projections (fetched during the previous step)
-            bool on[2];
-            float2 gx[2][4];
+            if (DC_DEV_TIMING && timing && t == 0) tlast = (long long)__builtin_amdgcn_s_memtime();
+            const bool on = t < len;
+            float4 gx[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                on[i] = t < len[i];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) gx[i][g] = gxn[i][g];
-            }
+            for (int g = 0; g < 4; ++g) gx[g] = gxn[g];
             // (b) the fifteen peers' h_{t-1}: 30 granules per thread (granule nn: peer nn >> 1, pair 256 (nn & 1) + tid)
             if (t > 0) {
                 const unsigned rt = tag - 1;
@@ -220,7 +240,7 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
                 const bool ok = t5_poll_all<30>([&](int nn) {
                     const int pi = nn >> 1, mp = pi + (pi >= member ? 1 : 0);
                     return slot + (size_t)mp * T5_PAIRS + (nn & 1) * 256 + tid;
-                }, rt, g);
+                }, rt, g, timing ? &tm[6] : nullptr);
                 if (!ok) {
                     dead = 1;
                     team_report_timeout(p.fault, T5_K_FWD, p.layer, team, member, t, b0 + (tid >> 4), rt);
@@ -228,76 +248,82 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
 #pragma unroll
                 for (int nn = 0; nn < 30; ++nn) {
                     const int pi = nn >> 1, mp = pi + (pi >= member ? 1 : 0);
-                    const int pair = (nn & 1) * 256 + tid;
+                    const int pair = (nn & 1) * 256 + tid;             // pair = sequence * 16 + unit pair of the peer's 32 units
                     *reinterpret_cast<unsigned*>(hcur + (pair >> 4) * T5_HROW + (T5_US * mp + 2 * (pair & 15)) * 2) = (unsigned)g[nn];
                 }
             }
-            // the next step's input projections: behind the granule loads in the queue, a whole step ahead of their use
+            stamp(0);      // poll + LDS writes
+            flush();       // the previous step's results
+            {              // the next step's input projections
+                const bool onn = t + 1 < len;
+                const float* gt = gbase + (size_t)(t + 1) * GH;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const bool onn = t + 1 < len[i];
-                const float* gt = p.gates + (row0[i] + (size_t)(t + 1)) * GH + j0;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) gxn[i][g] = onn ? *reinterpret_cast<const float2*>(gt + g * H) : make_float2(0.f, 0.f);
+                for (int g = 0; g < 4; ++g) gxn[g] = onn ? *reinterpret_cast<const float4*>(gt + g * H) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             __syncthreads();
+            stamp(1);      // stores + prefetch issue + barrier
             if (dead) { failed = true; break; }
             // (c) [32 seq] x [32 gate columns] += h_{t-1} W_hh^T over K = 512: two accumulator chains
             f32x16 acc0, acc1;
 #pragma unroll
             for (int q = 0; q < 16; ++q) { acc0[q] = 0.f; acc1[q] = 0.f; }
             const char* arow = hcur + fr * T5_HROW + fq * 16;
+            bf16x8 af[32];              // every fragment read is issued before the first MFMA (one wave per SIMD: nothing else hides LDS latency)
+#pragma unroll
+            for (int ks = 0; ks < 32; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(arow + ks * 32);
 #pragma unroll
             for (int ks = 0; ks < 32; ks += 2) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(arow + ks * 32), wreg[ks], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(arow + ks * 32 + 32), wreg[ks + 1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], wreg[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks + 1], wreg[ks + 1], acc1, 0, 0, 0);
             }
             // (d) C layout: column (= unit) lane & 31, row (= sequence) (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 red[(wave * T5_NS + (r & 3) + 8 * (r >> 2) + 4 * fq) * T5_RED_LD + fr] = acc0[r] + acc1[r];
+            stamp(2);      // product + spill
             __syncthreads();
+            stamp(3);      // barrier
             // (e) the cells
-            const bool publish = t + 1 < tmax;
-            u64* const out_slot = ring + (size_t)(tag & (T5_SLOTS - 1)) * (T5_M * T5_PAIRS) + (size_t)member * T5_PAIRS;
+            unsigned packed0 = 0, packed1 = 0;
+            if (on) {
+                float pre[4][4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int s = (tid >> 4) + 16 * i;
-                unsigned packed = 0;
-                if (on[i]) {
-                    float act[4][2], hv[2], cn[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        float pre[4];
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            pre[g] = (e == 0 ? gx[i][g].x : gx[i][g].y) + red[(g * T5_NS + s) * T5_RED_LD + 2 * up + e] + bh[g][e];
-                        const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
-                        cn[e] = fg * c[i][e] + ig * gg;
-                        hv[e] = og * tanhf(cn[e]);
-                        c[i][e] = cn[e];
-                        act[0][e] = ig; act[1][e] = fg; act[2][e] = gg; act[3][e] = og;
-                    }
-                    const size_t r = row0[i] + (size_t)t;
-                    float* gt = p.gates + r * GH + j0;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) *reinterpret_cast<float2*>(gt + g * H) = make_float2(act[g][0], act[g][1]);
-                    *reinterpret_cast<float2*>(p.cseq + r * H + j0) = make_float2(cn[0], cn[1]);
-                    *reinterpret_cast<float2*>(p.hseq + r * H + j0) = make_float2(hv[0], hv[1]);
-                    if (t + 1 < len[i]) {
-                        *reinterpret_cast<float2*>(p.cprev + (r + 1) * H + j0) = make_float2(cn[0], cn[1]);
-                        *reinterpret_cast<float2*>(p.hprev + (r + 1) * H + j0) = make_float2(hv[0], hv[1]);
-                    }
-                    packed = cvt_pk_bf16(hv[0], hv[1]);
+                for (int g = 0; g < 4; ++g) {
+                    const float* rr = red + (g * T5_NS + cs_) * T5_RED_LD + ub;
+                    pre[g][0] = gx[g].x + rr[0] + bh[g].x; pre[g][1] = gx[g].y + rr[1] + bh[g].y;
+                    pre[g][2] = gx[g].z + rr[2] + bh[g].z; pre[g][3] = gx[g].w + rr[3] + bh[g].w;
                 }
-                // own units of h_t for the next product, and the same two values to the peers (finished sequences publish zeros:
-                // every peer waits for all 512 granules of every member)
-                *reinterpret_cast<unsigned*>(hnxt + s * T5_HROW + j0 * 2) = packed;
-                if (publish) granule_store(out_slot + i * 256 + tid, __uint_as_float(packed), tag, plain);
+                float cv[4] = {c.x, c.y, c.z, c.w}, hv[4], act[4][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ig = fast_sigmoid(pre[0][e]), fg = fast_sigmoid(pre[1][e]), gg = fast_tanh(pre[2][e]), og = fast_sigmoid(pre[3][e]);
+                    cv[e] = fg * cv[e] + ig * gg;
+                    hv[e] = og * fast_tanh(cv[e]);
+                    act[0][e] = ig; act[1][e] = fg; act[2][e] = gg; act[3][e] = og;
+                }
+                c = make_float4(cv[0], cv[1], cv[2], cv[3]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pact[g] = make_float4(act[g][0], act[g][1], act[g][2], act[g][3]);
+                pc = c;
+                ph = make_float4(hv[0], hv[1], hv[2], hv[3]);
+                pt = t; pnext = t + 1 < len; pend = true;
+                packed0 = cvt_pk_bf16(hv[0], hv[1]);
+                packed1 = cvt_pk_bf16(hv[2], hv[3]);
             }
+            // own units of h_t for the next product, and the same values to the peers as pairs 2 tid, 2 tid + 1 (finished sequences
+            // publish zeros: every peer waits for all 512 granules of every member)
+            *reinterpret_cast<uint2*>(hnxt + cs_ * T5_HROW + j0 * 2) = make_uint2(packed0, packed1);
+            if (t + 1 < tmax) {
+                u64* const out = ring + (size_t)(tag & (T5_SLOTS - 1)) * (T5_M * T5_PAIRS) + (size_t)member * T5_PAIRS + 2 * tid;
+                granule_store(out, __uint_as_float(packed0), tag, plain);
+                granule_store(out + 1, __uint_as_float(packed1), tag, plain);
+            }
+            stamp(4);      // cells + publish
         }
+        flush();
         __syncthreads();
     }
+    if (DC_DEV_TIMING && timing) { tm[7] = plain; for (int k = 0; k < 8; ++k) p.dbg[k] = tm[k]; }
     if (failed && tid < T5_US) {        // a peer never answered: make the failure visible downstream (NaN loss -> status 1)
         const int b = min(team * T5_NS, p.n_seq - 1);
         p.hseq[(size_t)p.seq_off[b] * H + U0 + tid] = __builtin_nanf("");
@@ -462,7 +488,7 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
                     if (has_next[q]) dh += rec[q];
                     p.dh[r[q] * H + j] = dh;
                     const float ig = gv[q][0], fg = gv[q][1], gg = gv[q][2], og = gv[q][3];
-                    const float tc = tanhf(cs[q]);
+                    const float tc = fast_tanh(cs[q]);
                     float dcv = dh * og * (1.f - tc * tc);
                     if (has_next[q]) dcv += ndc[q] * nf[q];              // dc_{t+1} * f_{t+1}
                     p.dc[r[q] * H + j] = dcv;
@@ -534,8 +560,23 @@ int lstm_team512_forward(RnnStepArgs a, int max_len, hipStream_t s) {
     const int nt = t5_teams(a.n_seq);
     ProfScope prof("lstm_fwd_team", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * 12.0, s);
     if (int rc = zero_async(xb, ((size_t)T5_HDR + T5_HS + (size_t)nt * T5_FWD_RING) * sizeof(u64), s)) return rc;
+#if DC_DEV_TIMING
+    static long long* dbg = nullptr;
+    if (!dbg) (void)hipMalloc(&dbg, 64);
+    (void)hipMemsetAsync(dbg, 0, 64, s);
+    a.dbg = dbg;
+#endif
     hipLaunchKernelGGL(lstm512_team_fwd_kernel, dim3(nt * T5_M), dim3(T5_THREADS), T5_FWD_LDS, s, a, a.Whh_bf, xb, nt,
                        !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+#if DC_DEV_TIMING
+    {
+        long long h[8];
+        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        const double n = (double)max_len * (((a.n_seq + T5_NS - 1) / T5_NS + nt - 1) / nt);
+        fprintf(stderr, "lstm512_team_fwd timing (clocks per step, %.0f steps): poll %.0f  prefetch+barrier %.0f  product+spill %.0f  barrier %.0f  "
+                        "cells+publish %.0f  | poll rounds per step %.2f  plain %lld\n", n, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[6] / n, h[7]);
+    }
+#endif
     return launch_check("lstm_team512_forward");
 }
 
@@ -547,6 +588,12 @@ int lstm_team512_backward(RnnStepArgs a, int max_len, hipStream_t s) {
     const int nt = t5_teams(a.n_seq);
     ProfScope prof("lstm_bwd_team", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * 18.0, s);
     if (int rc = zero_async(xb, ((size_t)T5_HDR + T5_HS + (size_t)nt * T5_BWD_RING) * sizeof(u64), s)) return rc;
+#if DC_DEV_TIMING
+    static long long* dbg = nullptr;
+    if (!dbg) (void)hipMalloc(&dbg, 64);
+    (void)hipMemsetAsync(dbg, 0, 64, s);
+    a.dbg = dbg;
+#endif
     hipLaunchKernelGGL(lstm512_team_bwd_kernel, dim3(nt * T5_M), dim3(T5_THREADS), T5_BWD_LDS, s, a, a.WhhT_bf, xb, nt,
                        !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
     return launch_check("lstm_team512_backward");
