@@ -597,11 +597,42 @@ def side_measurements(args, dev, B, S, E):
         pack_rollouts(rollouts, S, dev)
     torch.cuda.synchronize()
     ingest_ms = (time.perf_counter() - t0) / 3 * 1e3
+    # ... and the way the consumer loop (DotaOptimizer.run_iteration, prefetch=True) runs it: while the GPU works on the current batch the
+    # host packs the NEXT one rollout by rollout (engine.IncrementalPacker: pinned staging, H2D on its own stream) - the timed steps
+    # again with that going on beside them
+    from dotaclient_amd.engine import IncrementalPacker
+    packer = IncrementalPacker(S, dev, expected_rows=B * S)
+    step_fn, lr_, ent_, vf_ = None, 5e-5, 5e-4, 0.5
+    batch0 = pack_rollouts(rollouts, S, dev)
+
+    def one_step(batch):
+        chunks = eng.rollout_pass(batch, S)
+        for _ in range(E):
+            eng.train_epoch(chunks, lr_, ent_, vf_)
+
+    def prefetch_next():
+        for d in rollouts:
+            packer.add(d)
+        return packer.finish()
+    cur = batch0
+    for _ in range(2):
+        one_step(cur); cur = prefetch_next()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(cur)                    # enqueued; the GPU is busy for ~a step
+        cur = prefetch_next()            # host packs + H2D of the next batch meanwhile
+    torch.cuda.synchronize()
+    overlap_ms = (time.perf_counter() - t0) / args.steps * 1e3
     out['ingest'] = {'pack_h2d_ms_per_batch': round(ingest_ms, 3),
                      'env_steps_per_s_with_ingest_serialised': round(B * S / ((base_ms + ingest_ms) * 1e-3), 1),
-                     'note': 'wire-format dicts -> page-locked staging (dc_pack_rows, DC_PACK_THREADS host threads) -> HBM (engine.pack_rollouts); '
-                             'the consumer loop overlaps it with the previous iteration\'s epochs (DotaOptimizer prefetch: '
-                             'tests/test_gpu_api.py); not part of `value`'}
+                     'ms_per_step_with_next_batch_prefetched': round(overlap_ms, 3),
+                     'env_steps_per_s_with_ingest_prefetched': round(B * S / (overlap_ms * 1e-3), 1),
+                     'note': 'wire-format dicts -> page-locked staging (dc_pack_rows) -> HBM; serialised = engine.pack_rollouts then the step; '
+                             'prefetched = the consumer loop\'s form (DotaOptimizer.run_iteration with prefetch: engine.IncrementalPacker packs the '
+                             'next batch rollout by rollout on its own stream while the GPU works on the current one; a fresh batch every step); '
+                             'not part of `value`'}
+    del batch0, cur
 
     # ---- model publish (optimizer.py:697-716, once per iteration) ---------------------------------------------------------------
     def pub_flat():

@@ -108,6 +108,7 @@ class PackedBatch:
         self._bufs = {}            # output buffers of the passes over THIS batch, allocated once (Engine._buf)
         self.is_first = self.prev_row = None
         self.ready = None          # IncrementalPacker: event behind the H2D copies of this batch (the first pass waits on it)
+        self.host_lens = None      # padded rollout lengths as the packer knew them on the host (saves a device read-back)
 
     def as_chunks(self, seq_len):
         """Same rows viewed as B = rows/seq_len sequences of seq_len steps (rollouts are stored padded to a
@@ -144,6 +145,8 @@ class _StagingSet:
         self.act = mk((capacity, L.ACT_DIM), torch.uint8)
         self.msk = mk((capacity, L.ACT_DIM), torch.uint8)
         self.rew = mk((capacity, 10), torch.float32)
+        self.off = mk((4096,), torch.int64)          # sequence offsets / lengths of the batch (IncrementalPacker: no pageable copy,
+        self.len = mk((4096,), torch.int32)          # which would block the host until the current stream has drained)
         self.event = None
 
 
@@ -282,6 +285,7 @@ def _pack_locked(rollouts, seq_len, dev, pin, st, lens, rows):
     to = lambda x: device_copy(x[:rows], dev, non_blocking=True) if pin else x[:rows].clone()
     batch = PackedBatch(to(st.obs), to(st.act), to(st.msk), to(st.rew), device_copy(torch.from_numpy(off), dev),
                         device_copy(torch.from_numpy(lens_n.astype(np.int32)), dev), int(lens_n.max()))
+    batch.host_lens = [int(x) for x in lens]
     if pin:
         st.event = torch.cuda.Event()
         st.event.record()
@@ -347,24 +351,37 @@ class IncrementalPacker:
         if not self.pin:
             batch = PackedBatch(st.obs[:rows].clone(), st.act[:rows].clone(), st.msk[:rows].clone(), st.rew[:rows].clone(),
                                 torch.from_numpy(off), torch.from_numpy(lens_n.astype(np.int32)), int(lens_n.max()))
+            batch.host_lens = [int(x) for x in self.lens]
             self._begin()
             return batch
         cur = torch.cuda.current_stream(dev)
-        # destination buffers belong to the CURRENT stream (where the passes will use and eventually free them); the copies run on the
-        # side stream, which the copy engine serves while the current stream's kernels keep computing
-        dst = [device_empty(x[:rows].shape, x.dtype, dev) for x in (st.obs, st.act, st.msk, st.rew)]
-        seq_off = device_copy(torch.from_numpy(off), dev)
-        seq_len = device_copy(torch.from_numpy(lens_n.astype(np.int32)), dev)
-        self.stream.wait_stream(cur)
+        # The copies run on the packer's stream, which the copy engine serves while the current stream's kernels keep computing -
+        # so nothing here may wait for the current stream.  The destination buffers are therefore allocated UNDER the packer's stream
+        # (the caching allocator only hands that stream blocks whose earlier uses it has seen complete) and marked as also used
+        # by the current stream, where the passes read them (record_stream: not recycled before that work is done).
         with torch.cuda.stream(self.stream):
+            dst = [device_empty(x[:rows].shape, x.dtype, dev) for x in (st.obs, st.act, st.msk, st.rew)]
             for t, x in zip(dst, (st.obs, st.act, st.msk, st.rew)):
                 t.copy_(x[:rows], non_blocking=True)
-                t.record_stream(self.stream)
+            n = len(self.lens)
+            if n > st.off.numel():
+                st.off = torch.empty(2 * n, dtype=torch.int64, pin_memory=True)
+                st.len = torch.empty(2 * n, dtype=torch.int32, pin_memory=True)
+            st.off[:n] = torch.from_numpy(off)
+            st.len[:n] = torch.from_numpy(lens_n.astype(np.int32))
+            seq_off = device_empty((n,), torch.int64, dev)
+            seq_len = device_empty((n,), torch.int32, dev)
+            seq_off.copy_(st.off[:n], non_blocking=True)
+            seq_len.copy_(st.len[:n], non_blocking=True)
+            dst += [seq_off, seq_len]
             ready = torch.cuda.Event()
             ready.record(self.stream)
+        for t in dst:
+            t.record_stream(cur)
         st.event = ready
         batch = PackedBatch(dst[0], dst[1], dst[2], dst[3], seq_off, seq_len, int(lens_n.max()))
         batch.ready = ready
+        batch.host_lens = [int(x) for x in self.lens]
         self._begin()
         return batch
 

@@ -237,7 +237,7 @@ class DotaOptimizer:
     def _experiences_from_batch(self, rollouts, batch):
         chunks = self.engine.rollout_pass(batch, self.seq_len, gamma=0.98, lam=0.97)
         seqs = []
-        lens = batch.seq_len.cpu().tolist()
+        lens = batch.host_lens if batch.host_lens is not None else batch.seq_len.cpu().tolist()
         i = 0
         for data, Lr in zip(rollouts, lens):
             for _ in range(Lr // self.seq_len):

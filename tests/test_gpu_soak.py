@@ -28,12 +28,14 @@ def ragged_reference_defaults():
     return lens
 
 
-WORKLOADS = {
+WORKLOADS = {      # name: (cell, hidden, rollout lengths, seq_len[, layers, kernel flags])
     'cfg2_lstm256_256x256': ('lstm', 256, [256] * 256, 256),
     'cfg3shard_lstm256_128x256': ('lstm', 256, [256] * 128, 256),
     'cfg1_lstm128_64x256': ('lstm', 128, [256] * 64, 256),
     'gru256_64x256': ('gru', 256, [256] * 64, 256),
     'gru256_s16_ragged_1065chunks': ('gru', 256, ragged_reference_defaults(), 16),
+    # a quarter of configs[4]'s shard on the bf16 path: the persistent sixteen-member team kernels (rnn_team512.hip), two tiles + a partial one
+    'cfg4sub_bf16_2xlstm512_72x256': ('lstm', 512, [256] * 72, 256, 2, 4096),
 }
 
 
@@ -51,13 +53,15 @@ def clone_state(eng):
 @pytest.mark.parametrize('mode', ['eager', 'graph', 'reuse', 'feeder'])
 @pytest.mark.parametrize('name', list(WORKLOADS))
 def test_soak_25_iterations_then_restart_equality(name, mode):
-    cell, hidden, lens, S = WORKLOADS[name]
+    cell, hidden, lens, S = WORKLOADS[name][:4]
+    layers, flags = (WORKLOADS[name] + (1, 0))[4:6]
     if mode == 'feeder' and name != 'cfg2_lstm256_256x256':
         pytest.skip('the concurrent-ingest soak runs on the headline workload')
     dev = torch.device('cuda:0')
-    eng = Engine(cell, hidden, 1, dev)
+    eng = Engine(cell, hidden, layers, dev)
+    eng.kernel_flags = flags
     eng.reuse_rollout_forward = mode == 'reuse'
-    eng.load_state_dict(synth.init_state_dict(7, cell, hidden, 1))
+    eng.load_state_dict(synth.init_state_dict(7, cell, hidden, layers))
     rollouts = synth.make_rollouts(1000, lens)
     batch = pack_rollouts(rollouts, S, dev)
     graph = mode == 'graph'
@@ -92,7 +96,8 @@ def test_soak_25_iterations_then_restart_equality(name, mode):
     long_run = eng.out[:11].cpu().numpy().astype(np.float64)
     assert np.all(np.isfinite(long_run))
 
-    fresh = Engine(cell, hidden, 1, dev)
+    fresh = Engine(cell, hidden, layers, dev)
+    fresh.kernel_flags = flags
     for k, v in snap.items():
         getattr(fresh, k).copy_(v)
     fresh.params_changed()
@@ -107,6 +112,7 @@ def test_soak_25_iterations_then_restart_equality(name, mode):
     # gradient moves a weight by at most lr.
     den = np.maximum(np.abs(restart), 1e-3 * np.abs(restart[1:4]).sum())
     err = np.abs(long_run - restart) / den
-    assert err[:9].max() < 2e-4, (long_run, restart)
+    # (bf16 path: an operand next to a bf16 rounding boundary flips on a 1-ulp difference - same discontinuity, one level earlier)
+    assert err[:9].max() < (2e-4 if not flags & 4096 else 5e-3), (long_run, restart)
     assert err[9:11].max() < 2e-2, (long_run, restart)
     assert float((eng.params - fresh.params).abs().max()) <= 4 * LR * 1.01
