@@ -33,19 +33,23 @@ namespace dc {
 namespace {
 
 enum {
-    T5_H = 512, T5_M = 16, T5_US = 32, T5_NS = 32, T5_THREADS = 256, T5_SLOTS = 4, T5_MAXTEAMS = 16,
-    T5_PAIRS = T5_NS * T5_US / 2,            // granules a member publishes per step (forward) / per owner (backward)
+    T5_H = 512, T5_M = 16, T5_US = 32, T5_NS_MAX = 32, T5_THREADS = 256, T5_SLOTS = 4, T5_MAXTEAMS = 16,
     T5_HROW = T5_H * 2 + 16,                 // bytes: LDS row of the h tile [32 seq][512 k] (16 bytes of padding: conflict-free b128 reads)
     T5_GROW = 4 * T5_US * 2 + 16,            // bytes: LDS row of the own gate-gradient tile [32 seq][128 k]
     T5_RED_LD = 33,
     T5_HDR = 16,                             // u64 words: ticket counters
     T5_HS = T5_MAXTEAMS * T5_M,              // handshake granules
-    T5_FWD_RING = T5_SLOTS * T5_M * T5_PAIRS,            // words per team
-    T5_BWD_RING = T5_SLOTS * T5_M * T5_M * T5_PAIRS,     // words per team: [slot][owner][source][512]
-    T5_FWD_LDS = 2 * T5_NS * T5_HROW + 4 * T5_NS * T5_RED_LD * 4,
-    T5_BWD_LDS = 2 * T5_NS * T5_GROW + 2 * T5_NS * T5_RED_LD * 4,
     T5_K_FWD = 5, T5_K_BWD = 6,              // kernel ids in the fault record (include/dotaclient_hip.h)
 };
+
+// A tile is NS = 32 or 16 sequences (template parameter of the kernels; the MFMA tile is 32 rows either way, the upper half unused at
+// 16).  16 when the batch then still fits one round of teams: 256 sequences = 16 teams = all 256 CUs instead of 8 teams on 128, and a
+// member's per-step exchange, LDS reads, spill and cell work halve.
+constexpr int t5_pairs(int ns) { return ns * T5_US / 2; }                           // granules a member publishes per step (forward) / per owner (backward)
+constexpr size_t t5_fwd_ring(int ns) { return (size_t)T5_SLOTS * T5_M * t5_pairs(ns); }          // u64 words per team
+constexpr size_t t5_bwd_ring(int ns) { return (size_t)T5_SLOTS * T5_M * T5_M * t5_pairs(ns); }   // [slot][owner][source][pairs]
+constexpr int t5_fwd_lds(int ns) { return 2 * ns * T5_HROW + 4 * ns * T5_RED_LD * 4; }
+constexpr int t5_bwd_lds(int ns) { return 2 * ns * T5_GROW + ns * T5_RED_LD * 4; }
 
 __device__ __forceinline__ u32x4 t5_to_bf16x8(const float4& a, const float4& b) {
     return u32x4{cvt_pk_bf16(a.x, a.y), cvt_pk_bf16(a.z, a.w), cvt_pk_bf16(b.x, b.y), cvt_pk_bf16(b.z, b.w)};
@@ -114,12 +118,12 @@ __device__ __forceinline__ bool t5_poll_all(Addr addr, unsigned tag, u64 (&g)[N]
 }
 
 // longest sequence of the tile that starts at sequence b0 (all 256 threads call; result uniform)
-__device__ __forceinline__ int t5_tile_tmax(const RnnStepArgs& p, int b0) {
+__device__ __forceinline__ int t5_tile_tmax(const RnnStepArgs& p, int b0, int ns) {
     __shared__ int tmax_sh;
     __syncthreads();
     if (threadIdx.x < 64) {
         const int b = b0 + (int)threadIdx.x;
-        int v = (threadIdx.x < T5_NS && b < p.n_seq) ? p.seq_len[b] : 0;
+        int v = ((int)threadIdx.x < ns && b < p.n_seq) ? p.seq_len[b] : 0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
         if (threadIdx.x == 0) tmax_sh = v;
@@ -135,13 +139,14 @@ __device__ __forceinline__ int t5_tile_tmax(const RnnStepArgs& p, int b0) {
 // the step is as long as its instruction stream.  Hence: a thread's cells are FOUR CONSECUTIVE UNITS OF ONE SEQUENCE (one row
 // address, 16-byte loads and stores), row pointers advance by a stride, transcendental gates on v_exp / v_rcp.
 // ---------------------------------------------------------------------------------------------------------------------------------
+template <int NS>
 __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStepArgs p, const uint16_t* __restrict__ Wb,
                                                                           u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ht0 = smem;                                            // h tiles, double-buffered by the parity of t
-    float* const red = reinterpret_cast<float*>(smem + 2 * T5_NS * T5_HROW);   // [gate][seq][unit] pre-activations W_hh h
+    float* const red = reinterpret_cast<float*>(smem + 2 * NS * T5_HROW);   // [gate][seq][unit] pre-activations W_hh h
     __shared__ int dead;
-    constexpr int H = T5_H, GH = 4 * T5_H;
+    constexpr int H = T5_H, GH = 4 * T5_H, PAIRS = t5_pairs(NS), NPOLL = 15 * PAIRS / T5_THREADS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // = the gate this wave computes
     const int fr = lane & 31, fq = lane >> 5;
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
     t5_claim_role(reinterpret_cast<unsigned*>(xbuf_all), n_teams, team, member);
     if (team < 0) return;
     const int plain = t5_same_xcd(xbuf_all + T5_HDR + team * T5_M, member, allow_plain);
-    u64* const ring = xbuf_all + T5_HDR + T5_HS + (size_t)team * T5_FWD_RING;
+    u64* const ring = xbuf_all + T5_HDR + T5_HS + (size_t)team * t5_fwd_ring(NS);
     const int U0 = T5_US * member;
     if (tid == 0) dead = 0;
 
@@ -160,8 +165,10 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
 #pragma unroll
         for (int ks = 0; ks < 32; ++ks) wreg[ks] = *reinterpret_cast<const bf16x8*>(wrow + ks * 16);
     }
-    // ---- this thread's cells: sequence tid >> 3 of the tile, units 4 (tid & 7) .. + 3 of the member's 32 --------------------------------
+    // ---- this thread's cells: sequence tid >> 3 of the tile (NS = 16: the upper half of the threads has none), units 4 (tid & 7) .. + 3
+    //      of the member's 32 ----------------------------------------------------------------------------------------------------------------
     const int cs_ = tid >> 3, ub = 4 * (tid & 7), j0 = U0 + ub;
+    const bool has_cell = cs_ < NS;
     float4 bh[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) bh[g] = *reinterpret_cast<const float4*>(p.bhh + g * H + j0);
@@ -174,19 +181,19 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
     };
     unsigned tag = 0;
     bool failed = false;
-    const int n_tiles = (p.n_seq + T5_NS - 1) / T5_NS;
+    const int n_tiles = (p.n_seq + NS - 1) / NS;
     for (int tile = team; tile < n_tiles && !failed; tile += n_teams) {
-        const int b0 = tile * T5_NS;
-        const int tmax = t5_tile_tmax(p, b0);
+        const int b0 = tile * NS;
+        const int tmax = t5_tile_tmax(p, b0, NS);
         const int bq = b0 + cs_;
-        const int len = bq < p.n_seq ? p.seq_len[bq] : 0;
+        const int len = (has_cell && bq < p.n_seq) ? p.seq_len[bq] : 0;
         const size_t row0 = len > 0 ? (size_t)p.seq_off[bq] : 0;
         float* const gbase = p.gates + row0 * GH + j0;                 // row t: + t * GH
         float* const sbase = p.cseq + row0 * H + j0;                   // cseq; hseq / cprev / hprev at the same offset of their buffers
         const ptrdiff_t d_h = p.hseq - p.cseq, d_cp = p.cprev - p.cseq, d_hp = p.hprev - p.cseq;
         float4 c = len > 0 ? *reinterpret_cast<const float4*>(sbase + d_cp) : make_float4(0.f, 0.f, 0.f, 0.f);
         // h0 of all 512 units of the tile's sequences -> tile buffer 0
-        for (int e = tid; e < T5_NS * 64; e += T5_THREADS) {
+        for (int e = tid; e < NS * 64; e += T5_THREADS) {
             const int s = e >> 6, k8 = (e & 63) * 8;
             const int b = b0 + s;
             u32x4 v = u32x4{0, 0, 0, 0};
@@ -224,31 +231,31 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
 
 #pragma unroll 1
         for (int t = 0; t < tmax; ++t) {
-            char* const hcur = ht0 + (t & 1) * (T5_NS * T5_HROW);          // holds h_{t-1}
-            char* const hnxt = ht0 + ((t + 1) & 1) * (T5_NS * T5_HROW);    // receives h_t
+            char* const hcur = ht0 + (t & 1) * (NS * T5_HROW);          // holds h_{t-1}
+            char* const hnxt = ht0 + ((t + 1) & 1) * (NS * T5_HROW);    // receives h_t
             ++tag;
             if (DC_DEV_TIMING && timing && t == 0) tlast = (long long)__builtin_amdgcn_s_memtime();
             const bool on = t < len;
             float4 gx[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) gx[g] = gxn[g];
-            // (b) the fifteen peers' h_{t-1}: 30 granules per thread (granule nn: peer nn >> 1, pair 256 (nn & 1) + tid)
+            // (b) the fifteen peers' h_{t-1}: NPOLL granules per thread (granule nn: peer 256 nn / PAIRS, pair 256 nn % PAIRS + tid)
             if (t > 0) {
                 const unsigned rt = tag - 1;
-                const u64* const slot = ring + (size_t)(rt & (T5_SLOTS - 1)) * (T5_M * T5_PAIRS);
-                u64 g[30];
-                const bool ok = t5_poll_all<30>([&](int nn) {
-                    const int pi = nn >> 1, mp = pi + (pi >= member ? 1 : 0);
-                    return slot + (size_t)mp * T5_PAIRS + (nn & 1) * 256 + tid;
+                const u64* const slot = ring + (size_t)(rt & (T5_SLOTS - 1)) * (T5_M * PAIRS);
+                u64 g[NPOLL];
+                const bool ok = t5_poll_all<NPOLL>([&](int nn) {
+                    const int pi = (nn * T5_THREADS) / PAIRS, mp = pi + (pi >= member ? 1 : 0);
+                    return slot + (size_t)mp * PAIRS + (nn * T5_THREADS) % PAIRS + tid;
                 }, rt, g, timing ? &tm[6] : nullptr);
                 if (!ok) {
                     dead = 1;
                     team_report_timeout(p.fault, T5_K_FWD, p.layer, team, member, t, b0 + (tid >> 4), rt);
                 }
 #pragma unroll
-                for (int nn = 0; nn < 30; ++nn) {
-                    const int pi = nn >> 1, mp = pi + (pi >= member ? 1 : 0);
-                    const int pair = (nn & 1) * 256 + tid;             // pair = sequence * 16 + unit pair of the peer's 32 units
+                for (int nn = 0; nn < NPOLL; ++nn) {
+                    const int pi = (nn * T5_THREADS) / PAIRS, mp = pi + (pi >= member ? 1 : 0);
+                    const int pair = (nn * T5_THREADS) % PAIRS + tid;  // pair = sequence * 16 + unit pair of the peer's 32 units
                     *reinterpret_cast<unsigned*>(hcur + (pair >> 4) * T5_HROW + (T5_US * mp + 2 * (pair & 15)) * 2) = (unsigned)g[nn];
                 }
             }
@@ -270,7 +277,8 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
             const char* arow = hcur + fr * T5_HROW + fq * 16;
             bf16x8 af[32];              // every fragment read is issued before the first MFMA (one wave per SIMD: nothing else hides LDS latency)
 #pragma unroll
-            for (int ks = 0; ks < 32; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(arow + ks * 32);
+            for (int ks = 0; ks < 32; ++ks)          // (NS = 16: rows 16..31 of the MFMA tile are not sequences)
+                af[ks] = (NS == 32 || fr < NS) ? *reinterpret_cast<const bf16x8*>(arow + ks * 32) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < 32; ks += 2) {
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], wreg[ks], acc0, 0, 0, 0);
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
             // (d) C layout: column (= unit) lane & 31, row (= sequence) (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                red[(wave * T5_NS + (r & 3) + 8 * (r >> 2) + 4 * fq) * T5_RED_LD + fr] = acc0[r] + acc1[r];
+                if ((r >> 2) < NS / 8) red[(wave * NS + (r & 3) + 8 * (r >> 2) + 4 * fq) * T5_RED_LD + fr] = acc0[r] + acc1[r];
             stamp(2);      // product + spill
             __syncthreads();
             stamp(3);      // barrier
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
                 float pre[4][4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float* rr = red + (g * T5_NS + cs_) * T5_RED_LD + ub;
+                    const float* rr = red + (g * NS + cs_) * T5_RED_LD + ub;
                     pre[g][0] = gx[g].x + rr[0] + bh[g].x; pre[g][1] = gx[g].y + rr[1] + bh[g].y;
                     pre[g][2] = gx[g].z + rr[2] + bh[g].z; pre[g][3] = gx[g].w + rr[3] + bh[g].w;
                 }
@@ -312,9 +320,9 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
             }
             // own units of h_t for the next product, and the same values to the peers as pairs 2 tid, 2 tid + 1 (finished sequences
             // publish zeros: every peer waits for all 512 granules of every member)
-            *reinterpret_cast<uint2*>(hnxt + cs_ * T5_HROW + j0 * 2) = make_uint2(packed0, packed1);
-            if (t + 1 < tmax) {
-                u64* const out = ring + (size_t)(tag & (T5_SLOTS - 1)) * (T5_M * T5_PAIRS) + (size_t)member * T5_PAIRS + 2 * tid;
+            if (has_cell) *reinterpret_cast<uint2*>(hnxt + cs_ * T5_HROW + j0 * 2) = make_uint2(packed0, packed1);
+            if (has_cell && t + 1 < tmax) {
+                u64* const out = ring + (size_t)(tag & (T5_SLOTS - 1)) * (T5_M * PAIRS) + (size_t)member * PAIRS + 2 * tid;
                 granule_store(out, __uint_as_float(packed0), tag, plain);
                 granule_store(out + 1, __uint_as_float(packed1), tag, plain);
             }
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
     }
     if (DC_DEV_TIMING && timing) { tm[7] = plain; for (int k = 0; k < 8; ++k) p.dbg[k] = tm[k]; }
     if (failed && tid < T5_US) {        // a peer never answered: make the failure visible downstream (NaN loss -> status 1)
-        const int b = min(team * T5_NS, p.n_seq - 1);
+        const int b = min(team * NS, p.n_seq - 1);
         p.hseq[(size_t)p.seq_off[b] * H + U0 + tid] = __builtin_nanf("");
     }
 }
@@ -334,13 +342,14 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
 // backward through time.  In: dh (from the layer above / the heads), the forward's gates / cseq / cprev; out: dgx (gradient w.r.t.
 // W_ih x + b_ih = w.r.t. W_hh h + b_hh), dh (total), dc.
 // ---------------------------------------------------------------------------------------------------------------------------------
+template <int NS>
 __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStepArgs p, const uint16_t* __restrict__ WTb,
                                                                           u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const dg0 = smem;                                             // own gate gradients [seq][gate * 32 + unit] bf16, double-buffered
-    float* const own = reinterpret_cast<float*>(smem + 2 * T5_NS * T5_GROW);   // own partial sums [seq][unit]
+    float* const own = reinterpret_cast<float*>(smem + 2 * NS * T5_GROW);   // own partial sums [seq][unit]
     __shared__ int dead;
-    constexpr int H = T5_H, GH = 4 * T5_H;
+    constexpr int H = T5_H, GH = 4 * T5_H, PAIRS = t5_pairs(NS), NPOLL = 15 * PAIRS / T5_THREADS, KP = NS / 16, NC = 2 * KP;   // NC cells per thread
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fq = lane >> 5;
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
     t5_claim_role(reinterpret_cast<unsigned*>(xbuf_all), n_teams, team, member);
     if (team < 0) return;
     const int plain = t5_same_xcd(xbuf_all + T5_HDR + team * T5_M, member, allow_plain);
-    u64* const ring = xbuf_all + T5_HDR + T5_HS + (size_t)team * T5_BWD_RING;
+    u64* const ring = xbuf_all + T5_HDR + T5_HS + (size_t)team * t5_bwd_ring(NS);
     const int U0 = T5_US * member;
     if (tid == 0) dead = 0;
 
@@ -363,33 +372,33 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
     // ---- this thread's cells: unit U0 + (lane & 31); sequence pairs sb[k], sb[k] + 1 where the granule (register pair rp = wave + 4 k,
     //      lane) of a source's 32 x 32 block lands: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) with r = 2 rp --------------------------------
     const int u = fr, j = U0 + u;
-    int sb[2];
+    int sb[KP];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) { const int r = 2 * (wave + 4 * k); sb[k] = (r & 3) + 8 * (r >> 2) + 4 * fq; }
+    for (int k = 0; k < KP; ++k) { const int r = 2 * (wave + 4 * k); sb[k] = (r & 3) + 8 * (r >> 2) + 4 * fq; }
 
     unsigned tag = 0;
     bool failed = false;
-    const int n_tiles = (p.n_seq + T5_NS - 1) / T5_NS;
+    const int n_tiles = (p.n_seq + NS - 1) / NS;
     for (int tile = team; tile < n_tiles && !failed; tile += n_teams) {
-        const int b0 = tile * T5_NS;
-        const int tmax = t5_tile_tmax(p, b0);
-        int len[4];
-        size_t row0[4];
-        float nf[4], ndc[4];                                  // f_{t+1} and dc_{t+1} of the cell (carried from the previous iteration)
+        const int b0 = tile * NS;
+        const int tmax = t5_tile_tmax(p, b0, NS);
+        int len[NC];
+        size_t row0[NC];
+        float nf[NC], ndc[NC];                                // f_{t+1} and dc_{t+1} of the cell (carried from the previous iteration)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NC; ++q) {
             const int b = b0 + sb[q >> 1] + (q & 1);
             len[q] = b < p.n_seq ? p.seq_len[b] : 0;
             row0[q] = len[q] > 0 ? (size_t)p.seq_off[b] : 0;
             nf[q] = 0.f; ndc[q] = 0.f;
         }
         // no gate gradients yet: the first product (skipped) would read zeros
-        for (int e = tid; e < 2 * T5_NS * T5_GROW / 4; e += T5_THREADS) reinterpret_cast<unsigned*>(dg0)[e] = 0u;
+        for (int e = tid; e < 2 * NS * T5_GROW / 4; e += T5_THREADS) reinterpret_cast<unsigned*>(dg0)[e] = 0u;
         // the cells' operands of a step are fetched ONE STEP AHEAD (see the forward)
-        float gvn[4][4], dhn[4], csn[4], cpn[4];
+        float gvn[NC][4], dhn[NC], csn[NC], cpn[NC];
         auto fetch = [&](int tt) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NC; ++q) {
                 const bool o = tt >= 0 && tt < len[q];
                 const size_t rr = row0[q] + (size_t)(tt < 0 ? 0 : tt);
                 const float* gt = p.gates + rr * GH + j;
@@ -405,15 +414,15 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
 
 #pragma unroll 1
         for (int t = tmax - 1; t >= 0; --t) {
-            char* const dcur = dg0 + (t & 1) * (T5_NS * T5_GROW);          // holds the gate gradients of step t + 1
-            char* const dnxt = dg0 + ((t + 1) & 1) * (T5_NS * T5_GROW);    // receives those of step t
+            char* const dcur = dg0 + (t & 1) * (NS * T5_GROW);          // holds the gate gradients of step t + 1
+            char* const dnxt = dg0 + ((t + 1) & 1) * (NS * T5_GROW);    // receives those of step t
             ++tag;
             // (a) the cells' operands (fetched during the previous iteration)
-            bool on[4], has_next[4];
-            float gv[4][4], dhv[4], cs[4], cp[4];
-            size_t r[4];
+            bool on[NC], has_next[NC];
+            float gv[NC][4], dhv[NC], cs[NC], cp[NC];
+            size_t r[NC];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NC; ++q) {
                 on[q] = t < len[q];
                 has_next[q] = t + 1 < len[q];
                 r[q] = row0[q] + (size_t)t;
@@ -421,7 +430,9 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
                 for (int g = 0; g < 4; ++g) gv[q][g] = gvn[q][g];
                 dhv[q] = dhn[q]; cs[q] = csn[q]; cp[q] = cpn[q];
             }
-            float rec[4] = {0.f, 0.f, 0.f, 0.f};
+            float rec[NC];
+#pragma unroll
+            for (int q = 0; q < NC; ++q) rec[q] = 0.f;
             if (t + 1 < tmax) {
                 // (b) partial dh_rec[32 seq][32 units of owner o] over the 128 own gate columns, o = 4 wave + i
                 f32x16 acc[4];
@@ -432,55 +443,57 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
                 const char* arow = dcur + fr * T5_GROW + fq * 16;
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + ks * 32);
+                    const bf16x8 a = (NS == 32 || fr < NS) ? *reinterpret_cast<const bf16x8*>(arow + ks * 32) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wreg[i][ks], acc[i], 0, 0, 0);
                 }
                 // (c) to the owners: own block through LDS, the others as granules [slot][owner][source = member][rp * 64 + lane]
-                u64* const out_slot = ring + (size_t)(tag & (T5_SLOTS - 1)) * (T5_M * T5_M * T5_PAIRS);
+                u64* const out_slot = ring + (size_t)(tag & (T5_SLOTS - 1)) * (T5_M * T5_M * PAIRS);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int o = 4 * wave + i;
                     if (o == member) {
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) own[((q & 3) + 8 * (q >> 2) + 4 * fq) * T5_RED_LD + fr] = acc[i][q];
+                        for (int q = 0; q < 16; ++q)
+                            if ((q >> 2) < NS / 8) own[((q & 3) + 8 * (q >> 2) + 4 * fq) * T5_RED_LD + fr] = acc[i][q];
                     } else {
-                        u64* dst = out_slot + ((size_t)o * T5_M + member) * T5_PAIRS + lane;
+                        u64* dst = out_slot + ((size_t)o * T5_M + member) * PAIRS + lane;
 #pragma unroll
-                        for (int rp = 0; rp < 8; ++rp)
+                        for (int rp = 0; rp < 4 * KP; ++rp)       // register pairs whose rows are sequences of the tile
                             granule_store(dst + rp * 64, __uint_as_float(cvt_pk_bf16(acc[i][2 * rp], acc[i][2 * rp + 1])), tag, plain);
                     }
                 }
                 __syncthreads();
                 // (d) own partial + the fifteen sources'
-                const u64* const in_slot = ring + (size_t)(tag & (T5_SLOTS - 1)) * (T5_M * T5_M * T5_PAIRS) + (size_t)member * T5_M * T5_PAIRS;
+                const u64* const in_slot = ring + (size_t)(tag & (T5_SLOTS - 1)) * (T5_M * T5_M * PAIRS) + (size_t)member * T5_M * PAIRS;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < KP; ++k) {
                     rec[2 * k] = own[sb[k] * T5_RED_LD + u];
                     rec[2 * k + 1] = own[(sb[k] + 1) * T5_RED_LD + u];
                 }
                 {
-                    u64 g[30];         // granule nn: source nn >> 1 (skipping this member), register-pair block k = nn & 1
-                    const bool ok = t5_poll_all<30>([&](int nn) {
-                        const int n = nn >> 1, src = n + (n >= member ? 1 : 0);
-                        return in_slot + (size_t)src * T5_PAIRS + (nn & 1) * 256 + tid;
+                    u64 g[NPOLL];      // granule nn: source 256 nn / PAIRS (skipping this member), register-pair block k = (256 nn % PAIRS) / 256
+                    const bool ok = t5_poll_all<NPOLL>([&](int nn) {
+                        const int n = (nn * T5_THREADS) / PAIRS, src = n + (n >= member ? 1 : 0);
+                        return in_slot + (size_t)src * PAIRS + (nn * T5_THREADS) % PAIRS + tid;
                     }, tag, g);
                     if (!ok) {
                         dead = 1;
                         team_report_timeout(p.fault, T5_K_BWD, p.layer, team, member, t, b0 + sb[0], tag);
                     }
 #pragma unroll
-                    for (int nn = 0; nn < 30; ++nn) {
+                    for (int nn = 0; nn < NPOLL; ++nn) {
+                        const int k = ((nn * T5_THREADS) % PAIRS) / T5_THREADS;
                         const unsigned w = (unsigned)g[nn];
-                        rec[2 * (nn & 1)] += t5_bf16_lo(w);
-                        rec[2 * (nn & 1) + 1] += t5_bf16_hi(w);
+                        rec[2 * k] += t5_bf16_lo(w);
+                        rec[2 * k + 1] += t5_bf16_hi(w);
                     }
                 }
             }
             fetch(t - 1);        // behind the granule loads in the queue, a whole iteration ahead of their use
             // (e) the cells (rnn_step_bf16.hip's epilogue)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NC; ++q) {
                 const int s = sb[q >> 1] + (q & 1);
                 float d4[4] = {0.f, 0.f, 0.f, 0.f};
                 if (on[q]) {
@@ -511,7 +524,7 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
         __syncthreads();
     }
     if (failed && tid < T5_US) {
-        const int b = min(team * T5_NS, p.n_seq - 1);
+        const int b = min(team * NS, p.n_seq - 1);
         p.dgx[(size_t)p.seq_off[b] * GH + U0 + tid] = __builtin_nanf("");
     }
 }
@@ -526,8 +539,11 @@ int t5_capacity() {
     return cap < T5_MAXTEAMS ? cap : T5_MAXTEAMS;
 }
 
-int t5_teams(int n_seq) {
-    const int tiles = (n_seq + T5_NS - 1) / T5_NS;
+// sequences per tile: 16 when the batch then still runs in one round of teams (twice the teams, half the per-step work of a member)
+int t5_tile_seqs(int n_seq) { return n_seq <= 16 * t5_capacity() ? 16 : 32; }
+
+int t5_teams(int n_seq, int ns) {
+    const int tiles = (n_seq + ns - 1) / ns;
     int nt = tiles < t5_capacity() ? tiles : t5_capacity();
     if (nt > 8) nt = nt / 8 * 8;           // whole XCD slices: a team's sixteen members then share an L2
     return nt;
@@ -544,7 +560,7 @@ int t5_attr(K kern, int bytes, bool* done) {
 
 }  // namespace
 
-long long lstm_team512_xbuf_bytes() { return (long long)((size_t)T5_HDR + T5_HS + (size_t)T5_MAXTEAMS * T5_BWD_RING) * (long long)sizeof(u64); }
+long long lstm_team512_xbuf_bytes() { return (long long)((size_t)T5_HDR + T5_HS + (size_t)T5_MAXTEAMS * t5_bwd_ring(T5_NS_MAX)) * (long long)sizeof(u64); }
 
 // DC_DIMS_BF16 LSTM-512 layers whose W_hh arrived as bf16; DC_DIMS_RNN_STEP_BF16 (or DC_DIMS_RNN_PER_STEP) keeps the launch-per-step kernels
 bool lstm_team512_supported(int cell, int H, int flags, const void* Wb) {
@@ -555,24 +571,28 @@ bool lstm_team512_supported(int cell, int H, int flags, const void* Wb) {
 int lstm_team512_forward(RnnStepArgs a, int max_len, hipStream_t s) {
     u64* xb = static_cast<u64*>(a.xbuf);
     if (!xb) { set_error("lstm_team512_forward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }
-    static bool attr = false;
-    if (int e = t5_attr(lstm512_team_fwd_kernel, T5_FWD_LDS, &attr)) return e;
-    const int nt = t5_teams(a.n_seq);
+    static bool attr16 = false, attr32 = false;
+    if (int e = t5_attr(lstm512_team_fwd_kernel<16>, t5_fwd_lds(16), &attr16)) return e;
+    if (int e = t5_attr(lstm512_team_fwd_kernel<32>, t5_fwd_lds(32), &attr32)) return e;
+    const int ns = (a.flags & DC_DIMS_TEAM_NS(2)) ? 32 : t5_tile_seqs(a.n_seq);     // DC_DIMS_TEAM_NS(2): force 32-sequence tiles (A/B)
+    const int nt = t5_teams(a.n_seq, ns);
     ProfScope prof("lstm_fwd_team", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * 12.0, s);
-    if (int rc = zero_async(xb, ((size_t)T5_HDR + T5_HS + (size_t)nt * T5_FWD_RING) * sizeof(u64), s)) return rc;
+    if (int rc = zero_async(xb, ((size_t)T5_HDR + T5_HS + (size_t)nt * (ns == 16 ? t5_fwd_ring(16) : t5_fwd_ring(32))) * sizeof(u64), s)) return rc;
 #if DC_DEV_TIMING
     static long long* dbg = nullptr;
     if (!dbg) (void)hipMalloc(&dbg, 64);
     (void)hipMemsetAsync(dbg, 0, 64, s);
     a.dbg = dbg;
 #endif
-    hipLaunchKernelGGL(lstm512_team_fwd_kernel, dim3(nt * T5_M), dim3(T5_THREADS), T5_FWD_LDS, s, a, a.Whh_bf, xb, nt,
-                       !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+    if (ns == 16) hipLaunchKernelGGL(lstm512_team_fwd_kernel<16>, dim3(nt * T5_M), dim3(T5_THREADS), t5_fwd_lds(16), s, a, a.Whh_bf, xb, nt,
+                                     !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+    else hipLaunchKernelGGL(lstm512_team_fwd_kernel<32>, dim3(nt * T5_M), dim3(T5_THREADS), t5_fwd_lds(32), s, a, a.Whh_bf, xb, nt,
+                            !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
 #if DC_DEV_TIMING
     {
         long long h[8];
         (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
-        const double n = (double)max_len * (((a.n_seq + T5_NS - 1) / T5_NS + nt - 1) / nt);
+        const double n = (double)max_len * (((a.n_seq + ns - 1) / ns + nt - 1) / nt);
         fprintf(stderr, "lstm512_team_fwd timing (clocks per step, %.0f steps): poll %.0f  prefetch+barrier %.0f  product+spill %.0f  barrier %.0f  "
                         "cells+publish %.0f  | poll rounds per step %.2f  plain %lld\n", n, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[6] / n, h[7]);
     }
@@ -583,19 +603,23 @@ int lstm_team512_forward(RnnStepArgs a, int max_len, hipStream_t s) {
 int lstm_team512_backward(RnnStepArgs a, int max_len, hipStream_t s) {
     u64* xb = static_cast<u64*>(a.xbuf);
     if (!xb) { set_error("lstm_team512_backward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }
-    static bool attr = false;
-    if (int e = t5_attr(lstm512_team_bwd_kernel, T5_BWD_LDS, &attr)) return e;
-    const int nt = t5_teams(a.n_seq);
+    static bool attr16 = false, attr32 = false;
+    if (int e = t5_attr(lstm512_team_bwd_kernel<16>, t5_bwd_lds(16), &attr16)) return e;
+    if (int e = t5_attr(lstm512_team_bwd_kernel<32>, t5_bwd_lds(32), &attr32)) return e;
+    const int ns = (a.flags & DC_DIMS_TEAM_NS(2)) ? 32 : t5_tile_seqs(a.n_seq);
+    const int nt = t5_teams(a.n_seq, ns);
     ProfScope prof("lstm_bwd_team", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * 18.0, s);
-    if (int rc = zero_async(xb, ((size_t)T5_HDR + T5_HS + (size_t)nt * T5_BWD_RING) * sizeof(u64), s)) return rc;
+    if (int rc = zero_async(xb, ((size_t)T5_HDR + T5_HS + (size_t)nt * (ns == 16 ? t5_bwd_ring(16) : t5_bwd_ring(32))) * sizeof(u64), s)) return rc;
 #if DC_DEV_TIMING
     static long long* dbg = nullptr;
     if (!dbg) (void)hipMalloc(&dbg, 64);
     (void)hipMemsetAsync(dbg, 0, 64, s);
     a.dbg = dbg;
 #endif
-    hipLaunchKernelGGL(lstm512_team_bwd_kernel, dim3(nt * T5_M), dim3(T5_THREADS), T5_BWD_LDS, s, a, a.WhhT_bf, xb, nt,
-                       !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+    if (ns == 16) hipLaunchKernelGGL(lstm512_team_bwd_kernel<16>, dim3(nt * T5_M), dim3(T5_THREADS), t5_bwd_lds(16), s, a, a.WhhT_bf, xb, nt,
+                                     !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+    else hipLaunchKernelGGL(lstm512_team_bwd_kernel<32>, dim3(nt * T5_M), dim3(T5_THREADS), t5_bwd_lds(32), s, a, a.WhhT_bf, xb, nt,
+                            !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
     return launch_check("lstm_team512_backward");
 }
 

@@ -48,8 +48,9 @@ def test_bf16_path_within_stated_tolerance_of_fp32_oracle(cell, hidden, layers, 
     assert util.scaled_err(out['values'], ref['values']) > 1e-5
 
 
+@pytest.mark.parametrize('tile32', [False, True])
 @pytest.mark.parametrize('lens,S', [([64] * 6, 64), ([50, 64, 33, 7, 100, 64, 1, 16] * 5, 16), ([256] * 40, 256)])
-def test_persistent_lstm512_matches_the_step_kernels(lens, S):
+def test_persistent_lstm512_matches_the_step_kernels(lens, S, tile32):
     # rnn_team512.hip (the whole time loop of an LSTM-512 layer in one launch: sixteen workgroups hold W_hh as bf16 in registers and hand
     # h_t / the partial dh sums around as tagged granules) against rnn_step_bf16.hip (one launch per time step) - the same bf16-operand /
     # f32-accumulate arithmetic in another summation order.  Not bit-comparable: h_t is ROUNDED to bf16 before it becomes the next
@@ -61,7 +62,8 @@ def test_persistent_lstm512_matches_the_step_kernels(lens, S):
     from dotaclient_amd import engine as E
     g = {'seq_len': S, 'lr': 5e-5, 'entropy_coef': 5e-4, 'vf_coef': 0.5, 'epochs': 1}
     rollouts = synth.make_rollouts(77, lens)
-    team, eng = run_hip(g, rollouts, 'lstm', 512, 2, epochs=1, kernel_flags=E.DC_DIMS_BF16)
+    # tile32: 32-sequence tiles forced (DC_DIMS_TEAM_NS(2)); the default takes 16-sequence tiles while the batch fits one round of teams
+    team, eng = run_hip(g, rollouts, 'lstm', 512, 2, epochs=1, kernel_flags=E.DC_DIMS_BF16 | (E.DC_DIMS_TEAM_NS(2) if tile32 else 0))
     step, _ = run_hip(g, rollouts, 'lstm', 512, 2, epochs=1, kernel_flags=E.DC_DIMS_BF16 | E.DC_DIMS_RNN_STEP_BF16)
     assert eng.fault() is None
     errs = {key: util.scaled_err(team[key], step[key]) for key in ['advantages', 'values', 'hidden'] + ['old_logp_' + k for k in ('enum', 'x', 'y', 'target_unit', 'ability')]}
