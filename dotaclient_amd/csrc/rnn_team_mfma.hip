@@ -165,15 +165,16 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_kernel(RnnStepArg
             // ---- the same unit index of the three other members, same sequence -> LDS ------------------------------------
             if (t + 1 < tmax) {
                 u64 gr[3];
-#pragma unroll
-                for (int j = 1; j < TEAM_M; ++j) gr[j - 1] = granule_load(xb + (tag & 3) * H + TEAM_US * ((member + j) & 3) + ul);
+                const u64* ga[3];
 #pragma unroll
                 for (int j = 1; j < TEAM_M; ++j) {
-                    const int uu = TEAM_US * ((member + j) & 3) + ul;
-                    float v = 0.f;
-                    if (!granule_wait(gr[j - 1], xb + (tag & 3) * H + uu, tag, v)) { dead = 1; team_report_timeout(p.fault, TEAM_K_MFMA_FWD, p.layer, team, member, t, b, tag); }
-                    h_lds[cur ^ 1][tm_hpos(slot, uu)] = v;
+                    ga[j - 1] = xb + (tag & 3) * H + TEAM_US * ((member + j) & 3) + ul;
+                    gr[j - 1] = granule_load(ga[j - 1]);
                 }
+                if (!granule_wait_all<3>(gr, ga, tag)) { dead = 1; team_report_timeout(p.fault, TEAM_K_MFMA_FWD, p.layer, team, member, t, b, tag); }
+#pragma unroll
+                for (int j = 1; j < TEAM_M; ++j)
+                    h_lds[cur ^ 1][tm_hpos(slot, TEAM_US * ((member + j) & 3) + ul)] = __uint_as_float((unsigned)gr[j - 1]);
             }
             __syncthreads();
             return dead == 0;
@@ -314,15 +315,16 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_bwd_kernel(RnnStepArg
             float rec = 0.f;
             if (xchg) {
                 u64 gr[3];
-#pragma unroll
-                for (int j = 1; j < TEAM_M; ++j) gr[j - 1] = granule_load(ring + ((size_t)(member * 4 + ((member + j) & 3)) * 4 + slot) * TEAM_US + ul);
-                rec = own[slot][ul];
+                const u64* ga[3];
 #pragma unroll
                 for (int j = 1; j < TEAM_M; ++j) {
-                    float v = 0.f;
-                    if (!granule_wait(gr[j - 1], ring + ((size_t)(member * 4 + ((member + j) & 3)) * 4 + slot) * TEAM_US + ul, tag, v)) { dead = 1; team_report_timeout(p.fault, TEAM_K_MFMA_BWD, p.layer, team, member, t, b, tag); }
-                    rec += v;
+                    ga[j - 1] = ring + ((size_t)(member * 4 + ((member + j) & 3)) * 4 + slot) * TEAM_US + ul;
+                    gr[j - 1] = granule_load(ga[j - 1]);
                 }
+                rec = own[slot][ul];
+                if (!granule_wait_all<3>(gr, ga, tag)) { dead = 1; team_report_timeout(p.fault, TEAM_K_MFMA_BWD, p.layer, team, member, t, b, tag); }
+#pragma unroll
+                for (int j = 1; j < TEAM_M; ++j) rec += __uint_as_float((unsigned)gr[j - 1]);
             }
             float dh = cv[6];
             dh += has_next ? rec : 0.f;

@@ -32,6 +32,24 @@ __device__ __forceinline__ bool granule_wait(u64 g, const u64* p, unsigned tag, 
     return true;
 }
 
+// N granules at once: every granule whose tag is still missing is re-read in the SAME round, so once the data is there the wait ends
+// one L2 round trip later - waited for one after the other, each stale first read paid a round trip of its own (rnn_team512.hip measured
+// that on 30 granules per thread).  g = first reads (possibly issued long ago); false on timeout.
+template <int N>
+__device__ __forceinline__ bool granule_wait_all(u64 (&g)[N], const u64* const (&p)[N], unsigned tag) {
+    for (int n = 0;; ++n) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) ok = ok && (unsigned)(g[i] >> 32) == tag;
+        if (ok) return true;
+        if (n > SPIN_LIMIT) return false;
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if ((unsigned)(g[i] >> 32) != tag) g[i] = granule_load(p[i]);
+    }
+}
+
 // A wait timed out: first writer wins, the record stays until the workspace's owner clears it (include/dotaclient_hip.h, DC_WS_FAULT).
 enum { TEAM_K_VALU_FWD = 1, TEAM_K_VALU_BWD = 2, TEAM_K_MFMA_FWD = 3, TEAM_K_MFMA_BWD = 4 };
 __device__ __noinline__ void team_report_timeout(int* fault, int kernel_id, int layer, int team, int member, int step, int seq, unsigned tag) {
