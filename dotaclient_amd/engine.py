@@ -80,16 +80,20 @@ FAULT_KERNELS = {1: 'rnn_team_fwd', 2: 'rnn_team_bwd', 3: 'team_mfma_fwd', 4: 't
 DC_FAULT_TEAM_TIMEOUT = 16
 
 
+def describe_fault(engine):
+    """'' or '; team kernel timeout: <kernel>, layer, team, member, time step, sequence, tag' from the workspace's DC_WS_FAULT record."""
+    f = engine.fault()
+    if f is None:
+        return ''
+    return '; team kernel timeout: %s, layer %d, team %d, member %d, time step %d, sequence %d, waited for tag %d' % (
+        FAULT_KERNELS.get(f[0] - DC_FAULT_TEAM_TIMEOUT, 'kernel %d' % f[0]), f[1], f[2], f[3], f[4], f[5], f[6])
+
+
 def describe_status(engine):
     """The engine's status word (0 ok, 1 NaN loss, 2 NaN gradient norm: dc_gradnorm_clip_adam) and, if a team kernel recorded a
     timeout in the workspace's DC_WS_FAULT block, which launch it was - as one line of text."""
     st = int(engine.status.item())
-    text = {0: '0 (ok)', 1: '1 (NaN loss)', 2: '2 (NaN gradient norm)'}.get(st, str(st))
-    f = engine.fault()
-    if f is not None:
-        text += '; team kernel timeout: %s, layer %d, team %d, member %d, time step %d, sequence %d, waited for tag %d' % (
-            FAULT_KERNELS.get(f[0] - DC_FAULT_TEAM_TIMEOUT, 'kernel %d' % f[0]), f[1], f[2], f[3], f[4], f[5], f[6])
-    return text
+    return {0: '0 (ok)', 1: '1 (NaN loss)', 2: '2 (NaN gradient norm)'}.get(st, str(st)) + describe_fault(engine)
 
 
 class PackedBatch:

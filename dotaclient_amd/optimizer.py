@@ -27,7 +27,7 @@ import torch
 
 from . import layout as L
 from . import ops
-from .engine import IncrementalPacker, PackedBatch, pack_rollouts
+from .engine import IncrementalPacker, PackedBatch, describe_fault, pack_rollouts
 from .policy import Policy
 
 logger = logging.getLogger(__name__)
@@ -290,9 +290,9 @@ class DotaOptimizer:
         host = torch.cat([out[:11], status.to(torch.float32)]).cpu()      # the one sync of the epoch
         st = int(host[11].item())
         if st == 1:                                                         # optimizer.py:667-669
-            raise ValueError('loss={}, policy_loss={}, entropy_loss={}, value_loss={}'.format(*host[:4].tolist()))
+            raise ValueError('loss={}, policy_loss={}, entropy_loss={}, value_loss={}'.format(*host[:4].tolist()) + describe_fault(self.engine))
         if st == 2:                                                         # optimizer.py:678-679
-            raise ValueError('grad_norm={}'.format(host[9].item()))
+            raise ValueError('grad_norm={}'.format(host[9].item()) + describe_fault(self.engine))
         losses = {'loss': host[0], 'policy_loss': host[1], 'entropy_loss': host[2], 'value_loss': host[3]}
         entropies = {k: host[4 + i] for i, k in enumerate(L.OUTPUT_KEYS)}
         return losses, entropies, {'unclipped': host[9], 'clipped': host[10]}
@@ -372,9 +372,9 @@ class DotaOptimizer:
             row = host[ep]
             st = int(row[11].item())
             if st == 1:                                                     # optimizer.py:667-669
-                raise ValueError('loss={}, policy_loss={}, entropy_loss={}, value_loss={}'.format(*row[:4].tolist()))
+                raise ValueError('loss={}, policy_loss={}, entropy_loss={}, value_loss={}'.format(*row[:4].tolist()) + describe_fault(self.engine))
             if st == 2:                                                     # optimizer.py:678-679
-                raise ValueError('grad_norm={}'.format(row[9].item()))
+                raise ValueError('grad_norm={}'.format(row[9].item()) + describe_fault(self.engine))
             losses.append({'loss': row[0], 'policy_loss': row[1], 'entropy_loss': row[2], 'value_loss': row[3]})
             entropies.append({k: row[4 + i] for i, k in enumerate(L.OUTPUT_KEYS)})
             grad_norms.append({'unclipped': row[9], 'clipped': row[10]})

@@ -170,6 +170,25 @@ def test_run_iteration_raises_on_nan_like_the_reference(tmp_path):
     assert torch.equal(before, opt.engine.params)
 
 
+def test_nan_error_names_the_team_kernel_that_timed_out(tmp_path):
+    # the reference's NaN guard (optimizer.py:667-669) is how a timed-out team kernel surfaces (it NaN-poisons its outputs); the
+    # workspace's DC_WS_FAULT record says which launch it was, and the ValueError carries it.  Here the record is
+    # injected by hand next to a NaN observation.
+    from dotaclient_amd.engine import describe_status
+    g, _ = util.load_case('ragged_s16')
+    bad = synth.make_rollouts(77, [32, 48])
+    bad[1]['observations']['env'][3, 0] = float('nan')
+    opt = make_opt(bad, g, tmp_path)
+    opt.min_seq_per_epoch = 4
+    seqs = opt.experiences_from_rollouts([dict(r) for r in bad])[0]
+    assert opt.engine.fault() is None and 'timeout' not in describe_status(opt.engine)
+    opt.engine._ws[:32].view(torch.int32).copy_(torch.tensor([16 + 3, 0, 5, 2, 17, 40, 18, 0], dtype=torch.int32))
+    with pytest.raises(ValueError, match='team kernel timeout: team_mfma_fwd, layer 0, team 5, member 2, time step 17, sequence 40'):
+        opt.train(experiences=seqs)
+    opt.engine.clear_fault()
+    assert opt.engine.fault() is None
+
+
 def test_prefetching_consumer_loop_equals_the_serial_one(tmp_path):
     # run_iteration packs every rollout as it arrives and, while the GPU works through the epochs, already drains
     # the experience queue into the NEXT batch's staging.  Same rollout stream through a prefetching and a serial optimizer: the
