@@ -77,7 +77,8 @@ __device__ __forceinline__ void t5_claim_role(unsigned* claim, int n_teams, int&
         role_sh[0] = t; role_sh[1] = m;
     }
     __syncthreads();
-    team = role_sh[0]; member = role_sh[1];
+    team = __builtin_amdgcn_readfirstlane(role_sh[0]);        // uniform: everything derived from them stays on the scalar unit
+    member = __builtin_amdgcn_readfirstlane(role_sh[1]);
 }
 
 __device__ __forceinline__ int t5_same_xcd(u64* hs, int member, int allow) {
@@ -95,7 +96,7 @@ __device__ __forceinline__ int t5_same_xcd(u64* hs, int member, int allow) {
         same_sh = same ? 1 : 0;
     }
     __syncthreads();
-    return same_sh;
+    return __builtin_amdgcn_readfirstlane(same_sh);
 }
 
 // All N granules of a thread in ONE batch, the whole batch re-issued until every tag matches: a retry costs one L2 round trip
@@ -129,7 +130,7 @@ __device__ __forceinline__ int t5_tile_tmax(const RnnStepArgs& p, int b0, int ns
         if (threadIdx.x == 0) tmax_sh = v;
     }
     __syncthreads();
-    return tmax_sh;
+    return __builtin_amdgcn_readfirstlane(tmax_sh);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -274,11 +275,12 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
             f32x16 acc0, acc1;
 #pragma unroll
             for (int q = 0; q < 16; ++q) { acc0[q] = 0.f; acc1[q] = 0.f; }
-            const char* arow = hcur + fr * T5_HROW + fq * 16;
+            // (NS = 16: rows 16..31 of the MFMA tile are no sequences - their lanes read rows 0..15 again and their results are never
+            //  looked at; a predicate here cost ~200 exec-mask / zero-fill instructions per step)
+            const char* arow = hcur + (fr & (NS - 1)) * T5_HROW + fq * 16;
             bf16x8 af[32];              // every fragment read is issued before the first MFMA (one wave per SIMD: nothing else hides LDS latency)
 #pragma unroll
-            for (int ks = 0; ks < 32; ++ks)          // (NS = 16: rows 16..31 of the MFMA tile are not sequences)
-                af[ks] = (NS == 32 || fr < NS) ? *reinterpret_cast<const bf16x8*>(arow + ks * 32) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            for (int ks = 0; ks < 32; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(arow + ks * 32);
 #pragma unroll
             for (int ks = 0; ks < 32; ks += 2) {
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], wreg[ks], acc0, 0, 0, 0);
@@ -394,26 +396,30 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
         }
         // no gate gradients yet: the first product (skipped) would read zeros
         for (int e = tid; e < 2 * NS * T5_GROW / 4; e += T5_THREADS) reinterpret_cast<unsigned*>(dg0)[e] = 0u;
-        // the cells' operands of a step are fetched ONE STEP AHEAD (see the forward)
-        float gvn[NC][4], dhn[NC], csn[NC], cpn[NC];
-        auto fetch = [&](int tt) {
+        // The cells' operands of a step are fetched TWO STEPS AHEAD into one of two register sets (static indices: the loop is unrolled by
+        // two).  Two, not one: the loads come from HBM (> 2 us) and are issued behind a step's granule loads; a set loaded during step
+        // t + 1 and copied out at the top of step t was waited for there (about 1 us per step).
+        float gvn[2][NC][4], dhn[2][NC], csn[2][NC], cpn[2][NC];
+        auto fetch = [&](int tt, auto PAR) {
+            constexpr int P = decltype(PAR)::value;
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
                 const bool o = tt >= 0 && tt < len[q];
                 const size_t rr = row0[q] + (size_t)(tt < 0 ? 0 : tt);
                 const float* gt = p.gates + rr * GH + j;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) gvn[q][g] = o ? gt[g * H] : 0.f;
-                dhn[q] = o ? p.dh[rr * H + j] : 0.f;
-                csn[q] = o ? p.cseq[rr * H + j] : 0.f;
-                cpn[q] = o ? p.cprev[rr * H + j] : 0.f;
+                for (int g = 0; g < 4; ++g) gvn[P][q][g] = o ? gt[g * H] : 0.f;
+                dhn[P][q] = o ? p.dh[rr * H + j] : 0.f;
+                csn[P][q] = o ? p.cseq[rr * H + j] : 0.f;
+                cpn[P][q] = o ? p.cprev[rr * H + j] : 0.f;
             }
         };
-        fetch(tmax - 1);
+        fetch(tmax - 1, std::integral_constant<int, 0>{});
+        fetch(tmax - 2, std::integral_constant<int, 1>{});
         __syncthreads();
 
-#pragma unroll 1
-        for (int t = tmax - 1; t >= 0; --t) {
+        auto step = [&](const int t, auto PAR) -> bool {
+            constexpr int P = decltype(PAR)::value;
             char* const dcur = dg0 + (t & 1) * (NS * T5_GROW);          // holds the gate gradients of step t + 1
             char* const dnxt = dg0 + ((t + 1) & 1) * (NS * T5_GROW);    // receives those of step t
             ++tag;
@@ -427,8 +433,8 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
                 has_next[q] = t + 1 < len[q];
                 r[q] = row0[q] + (size_t)t;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) gv[q][g] = gvn[q][g];
-                dhv[q] = dhn[q]; cs[q] = csn[q]; cp[q] = cpn[q];
+                for (int g = 0; g < 4; ++g) gv[q][g] = gvn[P][q][g];
+                dhv[q] = dhn[P][q]; cs[q] = csn[P][q]; cp[q] = cpn[P][q];
             }
             float rec[NC];
 #pragma unroll
@@ -440,10 +446,10 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
-                const char* arow = dcur + fr * T5_GROW + fq * 16;
+                const char* arow = dcur + (fr & (NS - 1)) * T5_GROW + fq * 16;        // (NS = 16: lanes 16..31 re-read rows 0..15, results unused)
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
-                    const bf16x8 a = (NS == 32 || fr < NS) ? *reinterpret_cast<const bf16x8*>(arow + ks * 32) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + ks * 32);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wreg[i][ks], acc[i], 0, 0, 0);
                 }
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
                     }
                 }
             }
-            fetch(t - 1);        // behind the granule loads in the queue, a whole iteration ahead of their use
+            fetch(t - 2, PAR);   // behind the granule loads in the queue, two iterations ahead of their use
             // (e) the cells (rnn_step_bf16.hip's epilogue)
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
@@ -519,7 +525,12 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
                     *reinterpret_cast<uint16_t*>(dnxt + s * T5_GROW + (g * T5_US + u) * 2) = (uint16_t)(cvt_pk_bf16(d4[g], 0.f) & 0xffffu);
             }
             __syncthreads();
-            if (dead) { failed = true; break; }
+            return dead == 0;
+        };
+#pragma unroll 1
+        for (int t = tmax - 1; t >= 0; t -= 2) {
+            if (!step(t, std::integral_constant<int, 0>{})) { failed = true; break; }
+            if (t - 1 >= 0 && !step(t - 1, std::integral_constant<int, 1>{})) { failed = true; break; }
         }
         __syncthreads();
     }
