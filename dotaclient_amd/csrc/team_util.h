@@ -88,7 +88,8 @@ __device__ __forceinline__ void team_claim_role(unsigned* claim, int n_teams, in
         role_sh[0] = t; role_sh[1] = m;
     }
     __syncthreads();
-    team = role_sh[0]; member = role_sh[1];
+    team = __builtin_amdgcn_readfirstlane(role_sh[0]);      // uniform values: what is derived from them stays on the scalar unit
+    member = __builtin_amdgcn_readfirstlane(role_sh[1]);
 }
 
 // Once per launch: do the four members of this team share an XCD (hence an L2)?  Each publishes its XCC id as a granule
@@ -110,7 +111,7 @@ __device__ __forceinline__ int team_same_xcd(u64* hs, int member, int allow) {
         same_sh = same ? 1 : 0;
     }
     __syncthreads();
-    return same_sh;
+    return __builtin_amdgcn_readfirstlane(same_sh);
 }
 
 }  // namespace
