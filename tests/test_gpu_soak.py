@@ -81,15 +81,19 @@ def test_soak_25_iterations_then_restart_equality(name, mode):
         th = threading.Thread(target=feeder, daemon=True)
         th.start()
 
-    for _ in range(24):
-        iteration(eng, batch, S, graph)
-    snap = clone_state(eng)                    # enqueued behind the 24th iteration on the same stream
+    n_done = 0
+    while n_done < 24 or (th is not None and len(packed) < 3 and n_done < 400):
+        iteration(eng, batch, S, graph)        # (feeder mode: at least until three batches were packed beside the iterations -
+        n_done += 1                            #  how often the packing thread gets the interpreter is up to the scheduler)
+        if th is not None and n_done >= 24:
+            torch.cuda.synchronize()           # lets the packing thread run while this one waits
+    snap = clone_state(eng)                    # enqueued behind the last of those iterations on the same stream
     iteration(eng, batch, S, graph)
     torch.cuda.synchronize()
     if th is not None:
         stop.append(1)
         th.join()
-        assert len(packed) >= 2 and all(r == batch.rows for r in packed)
+        assert len(packed) >= 3 and all(r == batch.rows for r in packed)
     assert int(eng.status.item()) == 0
     assert eng.fault() is None
     assert bool(torch.isfinite(eng.params).all())
