@@ -6,19 +6,27 @@
 //
 // W_hh of a 512-wide LSTM is 2 MB as bf16: no CU holds it.  A TEAM of 16 workgroups (16 CUs) does: member m owns the hidden units
 // 32 m .. 32 m + 31, i.e. 128 gate columns x 512 = 128 KB of bf16 weights, resident in the registers of its four waves (128 VGPRs
-// per lane) for the whole launch.  A team advances a TILE of 32 sequences together on v_mfma_f32_32x32x16_bf16 (the sequences are
-// the rows of every product) and works through its tiles one after the other.
+// per lane) for the whole launch.  A team advances a TILE of NS = 16 or 32 sequences together on v_mfma_f32_32x32x16_bf16 (the
+// sequences are the rows of every product) and works through its tiles one after the other.  NS = 16 while the batch then still fits
+// one round of teams: 256 sequences = 16 teams on all 256 CUs instead of 8 on 128, and a member's per-step exchange, LDS reads,
+// spill and cell work halve (measured: 4.6 / 6.3 -> 3.15 / 4.9 us per time step; the MFMA tile stays 32 rows, half of them unused -
+// the product is not what bounds a step).
 //
-//   forward  (column-parallel): wave g of member m multiplies h_{t-1}[32 seq][512] (bf16, LDS) with its gate-g rows of W_hh:
-//            32 MFMAs; the four gate blocks meet in LDS, 256 threads finish four (sequence, unit) cells each; the member's
-//            h_t[32 seq][32 units] goes to the 15 peers as 512 tagged granules {bf16, bf16, tag} (team_util.h) - an all-gather of
-//            7 680 granule reads per member and step.
+//   forward  (column-parallel): wave g of member m multiplies h_{t-1}[NS seq][512] (bf16, LDS) with its gate-g rows of W_hh:
+//            32 MFMAs; the four gate blocks meet in LDS, a thread finishes four consecutive units of one sequence (one row address,
+//            16-byte loads and stores); the member's h_t[NS seq][32 units] goes to the 15 peers as NS x 16 tagged granules
+//            {bf16, bf16, tag} (team_util.h) - an all-gather of 15 x NS x 16 granule reads per member and step.
 //   backward (row-parallel): a member contracts ITS OWN 128 gate gradients of step t + 1 (bf16, LDS - no input from anyone)
-//            with W_hh[own column][u'] for all 512 output units: 32 MFMAs per wave; the partial sums dh_rec[32 seq][32 units] for
-//            each owner go out as 512 granules of two bf16 each (a reduce-scatter: 7 680 out, 7 680 in) and the owner adds the
-//            fifteen it receives to its own.  Rounding the PARTIAL sums to bf16 is the one place this kernel is coarser than the
-//            per-step form (whose 2 048-term sums stay f32): sixteen roundings of 2^-9 each on sums of 128 terms - the same order
-//            as the bf16 rounding of the 2 048 operands themselves; tolerances in tests/test_gpu_bf16.py are unchanged.
+//            with W_hh[own column][u'] for all 512 output units: 32 MFMAs per wave; the partial sums dh_rec[NS seq][32 units] for
+//            each owner go out as granules of two bf16 each (a reduce-scatter) and the owner adds the fifteen it receives to its
+//            own.  Rounding the PARTIAL sums to bf16 is the one place this kernel is coarser than the per-step form (whose
+//            2 048-term sums stay f32): sixteen roundings of 2^-9 each on sums of 128 terms - the same order as the bf16 rounding of
+//            the 2 048 operands themselves; gradients agree with the step kernels to 1e-5 (tests/test_gpu_bf16.py).
+//
+// What shapes the step (profiles/r03/team512_phases.md): one wave per SIMD - nothing hides an instruction's latency, a step is as long
+// as its instruction stream - and vector memory operations that complete IN ORDER.  Hence: all granules of a thread are polled as
+// ONE batch and re-issued as a batch (t5_poll_all); the HBM operands of a step are fetched one (forward) / two (backward) steps
+// ahead, behind the granule loads in the queue; the forward stores a step's results one step late; gates on v_exp / v_rcp.
 //
 // Roles by ticket, XCD-local teams when the team count is a multiple of 8, L2-scope granule stores when a team shares an XCD,
 // timeouts reported in DC_WS_FAULT: as in rnn_team.hip / team_util.h.
