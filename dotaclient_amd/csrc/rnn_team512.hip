@@ -126,6 +126,27 @@ __device__ __forceinline__ bool t5_poll_all(Addr addr, unsigned tag, u64 (&g)[N]
     }
 }
 
+// The same in two halves, so that independent work can be issued between the first batch of loads and the wait for it (memory
+// operations complete in order: what is issued BEHIND the granule loads does not delay them).
+template <int N, class Addr>
+__device__ __forceinline__ void t5_poll_issue(Addr addr, u64 (&g)[N]) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) g[n] = granule_load(addr(n));
+}
+template <int N, class Addr>
+__device__ __forceinline__ bool t5_poll_wait(Addr addr, unsigned tag, u64 (&g)[N]) {
+    for (int spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int n = 0; n < N; ++n) ok = ok && (unsigned)(g[n] >> 32) == tag;
+        if (ok) return true;
+        if (spins > T5_SPIN) return false;
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int n = 0; n < N; ++n) g[n] = granule_load(addr(n));
+    }
+}
+
 // longest sequence of the tile that starts at sequence b0 (all 256 threads call; result uniform)
 __device__ __forceinline__ int t5_tile_tmax(const RnnStepArgs& p, int b0, int ns) {
     __shared__ int tmax_sh;
@@ -386,6 +407,11 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
 #pragma unroll
     for (int k = 0; k < KP; ++k) { const int r = 2 * (wave + 4 * k); sb[k] = (r & 3) + 8 * (r >> 2) + 4 * fq; }
 
+    long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    const bool timing = DC_DEV_TIMING && p.dbg != nullptr && team == 0 && member == 0 && tid == 0;
+    auto stamp = [&](int k) {
+        if (DC_DEV_TIMING && timing) { const long long now = (long long)__builtin_amdgcn_s_memtime(); tm[k] += now - tlast; tlast = now; }
+    };
     unsigned tag = 0;
     bool failed = false;
     const int n_tiles = (p.n_seq + NS - 1) / NS;
@@ -424,6 +450,24 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
         };
         fetch(tmax - 1, std::integral_constant<int, 0>{});
         fetch(tmax - 2, std::integral_constant<int, 1>{});
+        // a step's results are stored one step late, BEHIND the next step's granule loads and while those are in flight
+        float pd[NC][6];
+        size_t prow[NC];
+        bool pend[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) { pend[q] = false; prow[q] = 0; }
+        auto flush = [&]() {
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                if (!pend[q]) continue;
+                p.dh[prow[q] * H + j] = pd[q][4];
+                p.dc[prow[q] * H + j] = pd[q][5];
+                float* gx = p.dgx + prow[q] * GH + j;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gx[g * H] = pd[q][g];
+                pend[q] = false;
+            }
+        };
         __syncthreads();
 
         auto step = [&](const int t, auto PAR) -> bool {
@@ -431,6 +475,8 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
             char* const dcur = dg0 + (t & 1) * (NS * T5_GROW);          // holds the gate gradients of step t + 1
             char* const dnxt = dg0 + ((t + 1) & 1) * (NS * T5_GROW);    // receives those of step t
             ++tag;
+            if (DC_DEV_TIMING && timing && t == tmax - 1) tlast = (long long)__builtin_amdgcn_s_memtime();
+            stamp(5);      // (loop control)
             // (a) the cells' operands (fetched during the previous iteration)
             bool on[NC], has_next[NC];
             float gv[NC][4], dhv[NC], cs[NC], cp[NC];
@@ -461,6 +507,7 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wreg[i][ks], acc[i], 0, 0, 0);
                 }
+                stamp(0);      // operand copies + product
                 // (c) to the owners: own block through LDS, the others as granules [slot][owner][source = member][rp * 64 + lane]
                 u64* const out_slot = ring + (size_t)(tag & (T5_SLOTS - 1)) * (T5_M * T5_M * PAIRS);
 #pragma unroll
@@ -477,34 +524,42 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
                             granule_store(dst + rp * 64, __uint_as_float(cvt_pk_bf16(acc[i][2 * rp], acc[i][2 * rp + 1])), tag, plain);
                     }
                 }
+                stamp(1);      // publish
                 __syncthreads();
-                // (d) own partial + the fifteen sources'
+                stamp(2);      // barrier
+                // (d) the fifteen sources' granules: issued now, waited for after the work below
                 const u64* const in_slot = ring + (size_t)(tag & (T5_SLOTS - 1)) * (T5_M * T5_M * PAIRS) + (size_t)member * T5_M * PAIRS;
+                auto addr = [&](int nn) {
+                    const int n = (nn * T5_THREADS) / PAIRS, src = n + (n >= member ? 1 : 0);
+                    return in_slot + (size_t)src * PAIRS + (nn * T5_THREADS) % PAIRS + tid;
+                };
+                u64 g[NPOLL];      // granule nn: source 256 nn / PAIRS (skipping this member), register-pair block k = (256 nn % PAIRS) / 256
+                t5_poll_issue<NPOLL>(addr, g);
+                // ... meanwhile: the previous step's stores, the operand fetch for two steps ahead, and everything of the cells that does
+                // not need the received sums
+                flush();
+                fetch(t - 2, PAR);
 #pragma unroll
                 for (int k = 0; k < KP; ++k) {
                     rec[2 * k] = own[sb[k] * T5_RED_LD + u];
                     rec[2 * k + 1] = own[(sb[k] + 1) * T5_RED_LD + u];
                 }
-                {
-                    u64 g[NPOLL];      // granule nn: source 256 nn / PAIRS (skipping this member), register-pair block k = (256 nn % PAIRS) / 256
-                    const bool ok = t5_poll_all<NPOLL>([&](int nn) {
-                        const int n = (nn * T5_THREADS) / PAIRS, src = n + (n >= member ? 1 : 0);
-                        return in_slot + (size_t)src * PAIRS + (nn * T5_THREADS) % PAIRS + tid;
-                    }, tag, g);
-                    if (!ok) {
-                        dead = 1;
-                        team_report_timeout(p.fault, T5_K_BWD, p.layer, team, member, t, b0 + sb[0], tag);
-                    }
-#pragma unroll
-                    for (int nn = 0; nn < NPOLL; ++nn) {
-                        const int k = ((nn * T5_THREADS) % PAIRS) / T5_THREADS;
-                        const unsigned w = (unsigned)g[nn];
-                        rec[2 * k] += t5_bf16_lo(w);
-                        rec[2 * k + 1] += t5_bf16_hi(w);
-                    }
+                if (!t5_poll_wait<NPOLL>(addr, tag, g)) {
+                    dead = 1;
+                    team_report_timeout(p.fault, T5_K_BWD, p.layer, team, member, t, b0 + sb[0], tag);
                 }
+#pragma unroll
+                for (int nn = 0; nn < NPOLL; ++nn) {
+                    const int k = ((nn * T5_THREADS) % PAIRS) / T5_THREADS;
+                    const unsigned w = (unsigned)g[nn];
+                    rec[2 * k] += t5_bf16_lo(w);
+                    rec[2 * k + 1] += t5_bf16_hi(w);
+                }
+            } else {
+                flush();
+                fetch(t - 2, PAR);
             }
-            fetch(t - 2, PAR);   // behind the granule loads in the queue, two iterations ahead of their use
+            stamp(3);      // poll (+ stores, prefetch under it) + sum
             // (e) the cells (rnn_step_bf16.hip's epilogue)
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
@@ -513,26 +568,28 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
                 if (on[q]) {
                     float dh = dhv[q];
                     if (has_next[q]) dh += rec[q];
-                    p.dh[r[q] * H + j] = dh;
                     const float ig = gv[q][0], fg = gv[q][1], gg = gv[q][2], og = gv[q][3];
                     const float tc = fast_tanh(cs[q]);
                     float dcv = dh * og * (1.f - tc * tc);
                     if (has_next[q]) dcv += ndc[q] * nf[q];              // dc_{t+1} * f_{t+1}
-                    p.dc[r[q] * H + j] = dcv;
                     d4[0] = dcv * gg * ig * (1.f - ig);
                     d4[1] = dcv * cp[q] * fg * (1.f - fg);
                     d4[2] = dcv * ig * (1.f - gg * gg);
                     d4[3] = dh * tc * og * (1.f - og);
-                    float* gx = p.dgx + r[q] * GH + j;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) gx[g * H] = d4[g];
+                    for (int g4 = 0; g4 < 4; ++g4) pd[q][g4] = d4[g4];
+                    pd[q][4] = dh; pd[q][5] = dcv;
+                    prow[q] = r[q];
+                    pend[q] = true;
                     nf[q] = fg; ndc[q] = dcv;
                 }
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<uint16_t*>(dnxt + s * T5_GROW + (g * T5_US + u) * 2) = (uint16_t)(cvt_pk_bf16(d4[g], 0.f) & 0xffffu);
+                for (int g4 = 0; g4 < 4; ++g4)
+                    *reinterpret_cast<uint16_t*>(dnxt + s * T5_GROW + (g4 * T5_US + u) * 2) = (uint16_t)(cvt_pk_bf16(d4[g4], 0.f) & 0xffffu);
             }
+            stamp(4);      // prefetch issue + cells + stores
             __syncthreads();
+            stamp(6);      // barrier
             return dead == 0;
         };
 #pragma unroll 1
@@ -540,8 +597,10 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
             if (!step(t, std::integral_constant<int, 0>{})) { failed = true; break; }
             if (t - 1 >= 0 && !step(t - 1, std::integral_constant<int, 1>{})) { failed = true; break; }
         }
+        flush();
         __syncthreads();
     }
+    if (DC_DEV_TIMING && timing) { tm[7] = plain; for (int k = 0; k < 8; ++k) p.dbg[k] = tm[k]; }
     if (failed && tid < T5_US) {
         const int b = min(team * NS, p.n_seq - 1);
         p.dgx[(size_t)p.seq_off[b] * GH + U0 + tid] = __builtin_nanf("");
@@ -627,18 +686,27 @@ int lstm_team512_backward(RnnStepArgs a, int max_len, hipStream_t s) {
     if (int e = t5_attr(lstm512_team_bwd_kernel<32>, t5_bwd_lds(32), &attr32)) return e;
     const int ns = (a.flags & DC_DIMS_TEAM_NS(2)) ? 32 : t5_tile_seqs(a.n_seq);
     const int nt = t5_teams(a.n_seq, ns);
-    ProfScope prof("lstm_bwd_team", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * 18.0, s);
-    if (int rc = zero_async(xb, ((size_t)T5_HDR + T5_HS + (size_t)nt * (ns == 16 ? t5_bwd_ring(16) : t5_bwd_ring(32))) * sizeof(u64), s)) return rc;
 #if DC_DEV_TIMING
     static long long* dbg = nullptr;
     if (!dbg) (void)hipMalloc(&dbg, 64);
     (void)hipMemsetAsync(dbg, 0, 64, s);
     a.dbg = dbg;
 #endif
+    ProfScope prof("lstm_bwd_team", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * 18.0, s);
+    if (int rc = zero_async(xb, ((size_t)T5_HDR + T5_HS + (size_t)nt * (ns == 16 ? t5_bwd_ring(16) : t5_bwd_ring(32))) * sizeof(u64), s)) return rc;
     if (ns == 16) hipLaunchKernelGGL(lstm512_team_bwd_kernel<16>, dim3(nt * T5_M), dim3(T5_THREADS), t5_bwd_lds(16), s, a, a.WhhT_bf, xb, nt,
                                      !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
     else hipLaunchKernelGGL(lstm512_team_bwd_kernel<32>, dim3(nt * T5_M), dim3(T5_THREADS), t5_bwd_lds(32), s, a, a.WhhT_bf, xb, nt,
                             !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+#if DC_DEV_TIMING
+    {
+        long long h[8];
+        (void)hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost);
+        const double n = (double)max_len * (((a.n_seq + ns - 1) / ns + nt - 1) / nt);
+        fprintf(stderr, "lstm512_team_bwd timing (clocks per step, %.0f steps, NS %d): copies+product %.0f  publish %.0f  barrier %.0f  poll+sum %.0f  "
+                        "prefetch+cells+stores %.0f  barrier %.0f  loop %.0f\n", n, ns, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[6] / n, h[5] / n);
+    }
+#endif
     return launch_check("lstm_team512_backward");
 }
 
