@@ -147,11 +147,11 @@ def hip_parity_iteration(eng, batch, S, E, lr, ent, vf, hook=None):
 
 
 def cpu_baseline(cell, hidden, layers, rollouts, seq_len, epochs, lr, ent, vf):
-    """Times the CPU oracle (kind "port") on the same synthetic workload.  First ONE full bench step (rollout pass + `epochs`
-    epochs over all trajectories): that run is the checker side of `parity` and the warm-up; then a BOUNDED sample - the first 64
-    trajectories of the same batch, one full step, three times - whose best is `value` (best of 3 after a
-    warm-up).  Thread count: the best of a short sweep (torch CPU ops of this size get slower, not faster, when spread over all
-    host threads of the GPU box)."""
+    """Times the CPU oracle (kind "port") on the same synthetic workload: after a thread sweep and two warm-up steps on a bounded
+    sample (the first 64 trajectories), ONE full bench step (rollout pass + `epochs` epochs) over ALL trajectories of the GPU's own
+    batch - `value`, so that any GPU / CPU ratio compares the same workload, ~16 s of CPU work at configs[2] - which is
+    also the checker side of `parity`.  Thread count: the best of a short sweep (torch CPU ops of this size get slower, not
+    faster, when spread over all host threads of the GPU box)."""
     from oracle import ref_optimizer as RO
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     sd = synth.init_state_dict(7, cell, hidden, layers)
@@ -192,20 +192,21 @@ def cpu_baseline(cell, hidden, layers, rollouts, seq_len, epochs, lr, ent, vf):
         if best_t is None or a + b < best_t:
             best, best_t = t, a + b
     torch.set_num_threads(best)
-    t_roll, t_train, n_chunks, ref = one_iteration(rollouts, epochs, keep=True)      # the checker run = full-batch warm-up
-    full_rate = n_chunks * seq_len / (t_roll + t_train)
+    # warm-up of the timed run: one step on the bounded sample (the sweep above ran 8 trajectories only)
     sample = rollouts[:min(64, len(rollouts))]
     rates = []
-    for _ in range(3):
+    for _ in range(2):
         a, b, n, _ = one_iteration(sample, epochs)
         rates.append(n * seq_len / (a + b))
+    t_roll, t_train, n_chunks, ref = one_iteration(rollouts, epochs, keep=True)      # the timed run = `parity`'s checker
+    full_rate = n_chunks * seq_len / (t_roll + t_train)
     return {
-        'value': round(max(rates), 1), 'unit': 'env-steps/s', 'cores': best, 'kind': 'port',
-        'sample': 'best of 3 full steps (rollout pass + %d epochs) on the first %d of the %d trajectories x %d steps of the same workload '
-                  '(rates %s), after one full-batch step as warm-up (%.1f env-steps/s: rollout pass %.2fs + epochs %.2fs - that run is '
-                  '`parity`\'s checker); oracle/ref_optimizer.py, torch CPU fp32, %d of %d host threads (best of sweep %s)'
-                  % (epochs, len(sample), len(rollouts), seq_len, [round(r, 1) for r in rates], full_rate, t_roll, t_train, best, ncpu, cands),
-        'full_batch_once': round(full_rate, 1),
+        'value': round(full_rate, 1), 'unit': 'env-steps/s', 'cores': best, 'kind': 'port',
+        'sample': 'ONE full bench step (rollout pass %.2fs + %d epochs %.2fs) on ALL %d trajectories x %d steps of the GPU\'s own batch - the same '
+                  'run is `parity`\'s checker - after two warm-up steps on the first %d trajectories (%s env-steps/s, reported as '
+                  '`sample_rates`); oracle/ref_optimizer.py, torch CPU fp32, %d of %d host threads (best of sweep %s)'
+                  % (t_roll, epochs, t_train, len(rollouts), seq_len, len(sample), [round(r, 1) for r in rates], best, ncpu, cands),
+        'sample_rates': [round(r, 1) for r in rates], 'sample_trajectories': len(sample),
     }, ref
 
 
@@ -248,6 +249,15 @@ def mfma_peak(region, prec_bf16):
         return PEAK_BF16_MFMA_TFLOPS
     return {'embed_fwd_fused': _mixed_peak(12.0 / 140.0), 'embed_bwd_dw2': _mixed_peak(12.0 / 140.0),
             'embed_bwd_dw1': _mixed_peak(24.0 / 152.0)}.get(region, PEAK_X3_TFLOPS)
+
+
+def latency_peak(region, prec_bf16, hidden):
+    """Peak for the VALU / latency-bound regions.  f32 kernels: the f32 vector peak (= the f32-input MFMA peak).  In bf16 mode the
+    H >= 512 recurrences run on v_mfma_f32_32x32x16_bf16 (rnn_team512.hip, rnn_step_bf16.hip): priced against the dense bf16 MFMA
+    peak (against the f32 peak their `frac` came out above 1)."""
+    if prec_bf16 and hidden >= 512 and region in ('lstm_fwd_team', 'lstm_bwd_team', 'rnn_fwd_steps', 'rnn_bwd_steps'):
+        return PEAK_BF16_MFMA_TFLOPS
+    return PEAK_F32_MFMA_TFLOPS
 
 
 REGION_BOUND = {
@@ -357,6 +367,7 @@ def parse_args():
     ap.add_argument('--seq-len', type=int, default=256)
     ap.add_argument('--epochs', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true', help='also skips `parity` (the oracle run is its checker)')
+    ap.add_argument('--no-weak-unit', action='store_true', help='skip the 128-trajectory `weak_scaling_unit` run of the default N = 1 line')
     ap.add_argument('--extras', action='store_true',
                     help='after the JSON line is printed and flushed: run the side measurements (ingest, publish, hipGraph replay, '
                          'reuse-forward, the other single-GPU configurations) in a subprocess; result to --extras-out and stderr')
@@ -384,12 +395,43 @@ def check_status(res, what):
         sys.exit(4)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): re-executes this very command line
+    under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one rank per GPU, and passes
+    rank 0's JSON line through.  Refuses (exit code 2, nothing on stdout) when fewer than N devices are visible - a one-rank run
+    labelled as N GPUs, or N ranks piled on one device, would be a wrong number, not a slow one."""
+    import socket
+    import subprocess
+    one_device = os.environ.get('DC_BENCH_ONE_DEVICE') == '1'       # test aid: every rank on cuda:0 over gloo (see main)
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < (1 if one_device else args.gpus):
+        sys.stderr.write('bench.py: --gpus %d asked for, %d GPU(s) visible: refusing to run (no line printed)\n' % (args.gpus, have))
+        sys.stderr.flush()
+        return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')               # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '8')
+    sys.stderr.write('bench.py: launching %d ranks: %s\n' % (args.gpus, ' '.join(cmd)))
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
     global KERNEL_FLAGS, USE_GRAPHS, REUSE_FORWARD
     KERNEL_FLAGS = args.kernel_flags
     USE_GRAPHS = args.epoch_graph == 1
 
+    if args.gpus < 1:
+        sys.stderr.write('bench.py: --gpus must be >= 1\n')
+        sys.exit(2)
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -398,6 +440,13 @@ def main():
     # exercised on a one-GPU box; RCCL refuses two ranks on one device.
     one_device = os.environ.get('DC_BENCH_ONE_DEVICE') == '1'
     dev_index = 0 if (one_device or world == 1) else local_rank
+    if world != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but the launcher started %d rank(s): launch with --nproc-per-node = --gpus\n' % (args.gpus, world))
+        sys.exit(2)
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= dev_index:
+        sys.stderr.write('bench.py: rank %d needs cuda:%d, %d GPU(s) visible: refusing to run\n'
+                         % (rank, dev_index, torch.cuda.device_count() if torch.cuda.is_available() else 0))
+        sys.exit(2)
     torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
@@ -406,7 +455,6 @@ def main():
             dist.init_process_group(backend='gloo')
         else:
             dist.init_process_group(backend='nccl', device_id=torch.device('cuda', dev_index))
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node = --gpus'
     dev = torch.device('cuda', dev_index)
     S, E = args.seq_len, args.epochs
     B = args.batch if args.batch > 0 else (256 if world == 1 else 128)
@@ -451,6 +499,11 @@ def main():
                     gbs = r['bytes'] / (r['total_ms'] * 1e-3) / 1e9
                     k['achieved_gbs'] = round(gbs, 1)
                     k['frac_of_hbm_peak'] = round(gbs / PEAK_HBM_GBS, 4)
+                    # the counters' view of the same launch: a read served by a cache is not HBM traffic, so the HBM rate is
+                    # min(algorithmic, counter) bytes / time
+                    tr = pmc_traffic(args.traffic_json, r['kernel'].split('(')[0], workload_key)
+                    if tr is not None:
+                        k['hbm_gbs_by_counter'] = round(tr / (avg_us * 1e-6) / 1e9, 1)
             else:
                 tf = r['flops'] / (r['total_ms'] * 1e-3) / 1e12
                 k['achieved_tflops'] = round(tf, 3)
@@ -458,9 +511,9 @@ def main():
                     k['peak_tflops'] = round(mfma_peak(r['kernel'], bool(KERNEL_FLAGS & 4096)), 1)
                     k['frac'] = round(tf / k['peak_tflops'], 4)
                     k['frac_of_f32_mfma_peak'] = round(tf / PEAK_F32_MFMA_TFLOPS, 4)
-                else:                      # VALU / latency-bound f32 kernels: against the f32 vector peak
-                    k['peak_tflops'] = PEAK_F32_MFMA_TFLOPS
-                    k['frac'] = round(tf / PEAK_F32_MFMA_TFLOPS, 4)
+                else:                      # VALU / latency-bound kernels: against the peak of the pipe their arithmetic runs on
+                    k['peak_tflops'] = latency_peak(r['kernel'], bool(KERNEL_FLAGS & 4096), args.hidden)
+                    k['frac'] = round(tf / k['peak_tflops'], 4)
             k['traffic'] = pmc_traffic(args.traffic_json, r['kernel'].split('(')[0], workload_key)
             kernels.append(k)
         # the HBM-bound side (GAE / loss / Adam / pooling stream their operands once): largest by time
@@ -468,15 +521,21 @@ def main():
         roofline_hbm = None
         if hbm:
             hd = hbm[0]
-            gbs = hd['bytes'] / (hd['total_ms'] * 1e-3) / 1e9
+            alg_b = hd['bytes'] / hd['launches']
+            tr = pmc_traffic(args.traffic_json, hd['kernel'].split('(')[0], workload_key)
+            # bytes that actually crossed the HBM interface: the counters' figure when there is one and it is SMALLER than the
+            # algorithmic count (part of the operands came out of a cache: pricing those against the HBM peak would inflate frac)
+            used_b = alg_b if tr is None else min(alg_b, tr)
+            gbs = used_b / (hd['total_ms'] * 1e-3 / hd['launches']) / 1e9
             roofline_hbm = {'bound': 'hbm', 'kernel': hd['kernel'], 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                             'frac': round(gbs / PEAK_HBM_GBS, 4), 'avg_launch_us': round(hd['total_ms'] * 1e3 / hd['launches'], 3),
-                            'algorithmic_bytes_per_launch': hd['bytes'] / hd['launches'],
-                            'traffic': pmc_traffic(args.traffic_json, hd['kernel'].split('(')[0], workload_key)}
+                            'algorithmic_bytes_per_launch': alg_b, 'bytes_priced': used_b,
+                            'bytes_priced_note': 'min(algorithmic, PMC counter) bytes per launch', 'traffic': tr}
         dom = regions[0]
         dom_bound = REGION_BOUND.get(dom['kernel'], 'mfma')
         achieved = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
-        dom_peak = mfma_peak(dom['kernel'], bool(KERNEL_FLAGS & 4096)) if dom_bound == 'mfma' else PEAK_F32_MFMA_TFLOPS
+        dom_peak = mfma_peak(dom['kernel'], bool(KERNEL_FLAGS & 4096)) if dom_bound == 'mfma' else \
+            latency_peak(dom['kernel'], bool(KERNEL_FLAGS & 4096), args.hidden)
         P = eng.total
         alg_step_bytes = 2100.0 * (1 + E) * B * S + 28.0 * P * E            # 2.1 KB per env-step and pass + 28 B per parameter and optimizer step
         step_traffic = pmc_whole_step(args.traffic_json, workload_key, 1 + E)
@@ -532,6 +591,26 @@ def main():
             'roofline_hbm': roofline_hbm,
             'nan_status': status, 'final_loss': float(losses[0]),
         }
+        # The N > 1 lines of this script time 128 trajectories per GPU (configs[3]'s shard); the N = 1 line times configs[2]'s 256.  So
+        # that N = 1 and N > 1 compare like with like, the default N = 1 line also carries the one-GPU rate of that 128-trajectory
+        # shard (same kernels, no all-reduce), timed the same way (barrier + synchronize around K steps) - a short run, in a try:
+        # nothing here may cost the headline.
+        line['weak_scaling_unit'] = None
+        if world == 1 and args.batch == 0 and not args.no_weak_unit:
+            try:
+                k_unit, w_unit = min(args.steps, 10), min(args.warmup, 3)
+                u = run_workload(args.cell, args.hidden, args.layers, 128, S, E, k_unit, w_unit, dev, 0, 1)
+                if u['status'] == 0:
+                    ums = u['elapsed'] / k_unit * 1e3
+                    line['weak_scaling_unit'] = {
+                        'workload': "BASELINE.json configs[3]'s per-GPU shard on ONE GPU (128 trajectories x %d steps, %s-%d, no all-reduce): the "
+                                    'like-for-like N = 1 point for the N > 1 lines of this script (which time 128 trajectories per GPU)'
+                                    % (S, args.cell.upper(), args.hidden),
+                        'value': round(128 * S / (ums * 1e-3), 1), 'unit': 'env-steps/s', 'ms_per_step': round(ums, 3),
+                        'steps': k_unit, 'warmup': w_unit, 'batch_per_gpu': 128}
+                del u
+            except Exception as e:                                  # noqa: BLE001
+                sys.stderr.write('bench.py: weak_scaling_unit failed: %r\n' % (e,))
         if want_cpu:
             line['cpu_baseline'], ref = cpu_baseline(args.cell, args.hidden, args.layers, rollouts, S, E, lr, ent, vf)
             line['parity'] = parity_report(main_run['first_iteration'], ref)

@@ -5,6 +5,8 @@
 // clamped to <= 1) and torch.optim.Adam(lr).step() (betas 0.9/0.999, eps 1e-8, no weight decay;
 // optimizer.py:275), including the two NaN guards (optimizer.py:667-669, 678-679): when the loss or
 // the gradient norm is NaN nothing is updated and `status` is set so the host can raise ValueError.
+// `status` is STICKY: a non-zero word makes every later call skip its update as well (epochs are enqueued back to back
+// and read by the host once; the reference would have raised before the next epoch) - the caller zeroes it.
 //
 // The 34 named parameters are "segments" of the flat buffer (offset, length).  A segment whose head
 // took no action in the batch has no gradient in the reference (torch leaves .grad = None): it is
@@ -75,8 +77,10 @@ __global__ __launch_bounds__(64) void clip_finalize_kernel(AdamSegs sg, const do
     if (coef > 1.f) coef = 1.f;
     const bool loss_nan = losses[0] != losses[0];
     const bool norm_nan = unclipped != unclipped;
-    int st = 0;
-    if (loss_nan) st = 1; else if (norm_nan) st = 2;
+    int st = *status;             // sticky: once an epoch tripped a guard, later epochs skip their update too until the caller
+    if (st == 0) {                // clears the word (the reference raises at the first NaN epoch: nothing runs after it)
+        if (loss_nan) st = 1; else if (norm_nan) st = 2;
+    }
     if (lane == 0) {
         norms_out[0] = unclipped;
         norms_out[1] = unclipped * coef;   // every per-parameter norm scales by the same coefficient

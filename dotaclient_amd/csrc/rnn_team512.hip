@@ -607,13 +607,20 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
     }
 }
 
+// Teams of sixteen one-per-CU workgroups the CURRENT device can hold (queried per device id: a process may drive several different
+// devices).  Roles are taken by ticket, so a team never waits for a workgroup that is not running - but the kernels do
+// assume that nt * 16 workgroups get a CU each; a CU mask or a co-tenant that takes CUs away shows up as the DC_WS_FAULT timeout.
 int t5_capacity() {
-    static const int cap = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 0;
+    enum { MAXDEV = 64 };
+    static int cap_of[MAXDEV];             // 0 = not queried yet
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return 0;
+    int cap = __atomic_load_n(&cap_of[dev], __ATOMIC_RELAXED);
+    if (cap == 0) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        return cus / T5_M;                 // one workgroup per CU (its registers hold 128 KB of weights, its LDS 83 KB)
-    }();
+        cap = cus / T5_M;                  // one workgroup per CU (its registers hold 128 KB of weights, its LDS 83 KB)
+        __atomic_store_n(&cap_of[dev], cap, __ATOMIC_RELAXED);
+    }
     return cap < T5_MAXTEAMS ? cap : T5_MAXTEAMS;
 }
 

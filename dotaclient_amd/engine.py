@@ -490,11 +490,11 @@ class Engine:
         sn['done'][i] = done
         return i
 
-    def snapshot_state_dict(self, which=None):
+    def snapshot_state_dict(self, which=None, clone=True):
         """The last (or the given) snapshot as the reference's wire format: the 34 names / shapes / dtypes of
         `Policy.state_dict()` (optimizer.py:706, loaded with strict=True by the actors, agent.py:186,315), as host
-        tensors that own their memory (the snapshot buffer is reused two publishes later).  Blocks only on that
-        snapshot's copy."""
+        tensors that own their memory (the snapshot buffer is reused two publishes later; clone=False: views of that buffer, for a
+        caller that serialises them at once).  Blocks only on that snapshot's copy."""
         sn = getattr(self, '_snap', None)
         if sn is None or sn['done'][sn['cur'] if which is None else which] is None:
             raise _lib.DotaHipError('snapshot_state_dict: no snapshot started')
@@ -504,7 +504,8 @@ class Engine:
         out = {}
         for n in L.param_shapes(self.cell, self.hidden, self.layers):
             off, numel, shape = self.layout[n]
-            out[n] = host[off:off + numel].view(shape).clone()
+            t = host[off:off + numel].view(shape)
+            out[n] = t.clone() if clone else t
         return out
 
     # ---- workspace -------------------------------------------------------------------------------

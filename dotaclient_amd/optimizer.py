@@ -171,7 +171,14 @@ class DotaOptimizer:
         # the GPU works through this iteration's epochs (never blocking on an empty queue: the model publish is not delayed).
         self.prefetch = bool(prefetch)
         self._packer = IncrementalPacker(seq_len, self.device, expected_rows=(min_seq_per_epoch + 64) * seq_len)
-        self._prefetched = None
+        # the gather state of the batch being assembled lives next to the packer that holds its rows (a retry after an
+        # MQ / unpickling error continues the same batch, the two can not drift apart)
+        self._acc = self._new_gather()
+        # a batch whose rollout pass was ALREADY enqueued behind the previous iteration's epochs: (acc, experiences, chunks)
+        self._ready = None
+        self._hist_host = None
+        self.pipeline_rollout_pass = True
+        self.prefetch_past_gpu_done = False        # tests: keep draining the queue after the epochs have finished (deterministic batches)
 
         # optimizer.py:241-267, the run_local branch: the newest model_%09d.pt of log_dir overrides an explicit pretrained model,
         # and the iteration counter resumes behind the file's number so that published versions never go backwards
@@ -289,10 +296,13 @@ class DotaOptimizer:
                                               e_clip=self.e_clip, grad_hook=self.grad_hook)
         host = torch.cat([out[:11], status.to(torch.float32)]).cpu()      # the one sync of the epoch
         st = int(host[11].item())
+        if st != 0:
+            msg = describe_fault(self.engine)
+            self.engine.status.zero_()                                      # sticky on the device (csrc/adam.hip): the caller clears it
         if st == 1:                                                         # optimizer.py:667-669
-            raise ValueError('loss={}, policy_loss={}, entropy_loss={}, value_loss={}'.format(*host[:4].tolist()) + describe_fault(self.engine))
+            raise ValueError('loss={}, policy_loss={}, entropy_loss={}, value_loss={}'.format(*host[:4].tolist()) + msg)
         if st == 2:                                                         # optimizer.py:678-679
-            raise ValueError('grad_norm={}'.format(host[9].item()) + describe_fault(self.engine))
+            raise ValueError('grad_norm={}'.format(host[9].item()) + msg)
         losses = {'loss': host[0], 'policy_loss': host[1], 'entropy_loss': host[2], 'value_loss': host[3]}
         entropies = {k: host[4 + i] for i, k in enumerate(L.OUTPUT_KEYS)}
         return losses, entropies, {'unclipped': host[9], 'clipped': host[10]}
@@ -308,18 +318,44 @@ class DotaOptimizer:
     @staticmethod
     def _new_gather():
         return {'rollouts': [], 'subrewards': [], 'rollout_lens': [], 'weight_versions': [], 'xp_waits': 0.0, 'hidden_s': 0.0,
-                'n_prefetched': 0}
+                'n_prefetched': 0, 'pipelined': 0}
 
     def _consume_one(self, acc):
-        """One message off the experience queue (optimizer.py:452-455), packed into the staging set at once."""
+        """One message off the experience queue (optimizer.py:452-455), packed into the staging set at once.  The packer's rows and
+        `acc` change together, after everything that can raise."""
         t0 = time.time()
         rollout, rollout_subrewards, rollout_len, weight_version, canvas = self.get_rollout()
         acc['xp_waits'] += time.time() - t0
-        self._packer.add(rollout)
+        self._packer.add(rollout)                                           # raises before it commits its rows
         acc['rollouts'].append(rollout)
         acc['subrewards'].append(rollout_subrewards)
         acc['rollout_lens'].append(rollout_len)
         acc['weight_versions'].append(weight_version)
+
+    def _finish_batch(self):
+        """The gathered rollouts -> H2D (packer's stream) -> rollout pass enqueued.  Returns (acc, experiences, chunks)."""
+        acc = self._acc
+        batch = self._packer.finish()                                       # the rollout pass waits on the batch's `ready` event
+        self._acc = self._new_gather()
+        assert len(acc['rollouts']) == len(batch.host_lens), 'gather state and packed batch disagree'
+        experiences, chunks = self._experiences_from_batch(acc['rollouts'], batch)
+        return acc, experiences, chunks
+
+    def _drop_ready(self):
+        """An early rollout pass whose iteration will not run (error path): its rollouts go back to the front of the gather state so
+        that a caller who catches the error and carries on loses nothing."""
+        if self._ready is None:
+            return
+        acc, _, _ = self._ready
+        self._ready = None
+        redo, self._acc = self._acc, self._new_gather()
+        self._packer._begin()
+        for a in (acc, redo):
+            for i, r in enumerate(a['rollouts']):
+                self._packer.add(r)
+                for k in ('rollouts', 'subrewards', 'rollout_lens', 'weight_versions'):
+                    self._acc[k].append(a[k][i])
+            self._acc['xp_waits'] += a['xp_waits']
 
     def _queue_has_messages(self):
         """The reference MessageQueue's own `xp_queue_size` (optimizer.py:126-132: a passive queue_declare, None on failure); an
@@ -337,13 +373,14 @@ class DotaOptimizer:
         synchronises after every epoch through .item()), and while the GPU works the host already drains the experience queue into
         the next batch's staging (`prefetch`).  NaN guards (optimizer.py:667-669,678-679): the optimizer step of a NaN epoch is skipped
         on the device, so raising after the last epoch leaves the same parameters behind as raising in the middle."""
-        acc = self._prefetched if self._prefetched is not None else self._new_gather()
-        self._prefetched = None
         start_xp = time.time()
-        while self._packer.n_seq < self.min_seq_per_epoch:                  # optimizer.py:448-462
-            self._consume_one(acc)
-        batch = self._packer.finish()                                       # H2D on the packer's stream; the rollout pass waits on its event
-        experiences, chunks = self._experiences_from_batch(acc['rollouts'], batch)
+        if self._ready is not None:                                         # rollout pass already enqueued during the last iteration
+            acc, experiences, chunks = self._ready
+            self._ready = None
+        else:
+            while self._packer.n_seq < self.min_seq_per_epoch:              # optimizer.py:448-462
+                self._consume_one(self._acc)
+            acc, experiences, chunks = self._finish_batch()
         time_xp = time.time() - start_xp
         subrewards, rollout_lens = acc['subrewards'], acc['rollout_lens']
         weight_ages = [it - v for v in acc['weight_versions']]
@@ -357,24 +394,50 @@ class DotaOptimizer:
                                                   e_clip=self.e_clip, grad_hook=self.grad_hook)
             hist[ep, :11].copy_(out[:11])
             hist[ep, 11:].copy_(status)
+        # the history goes to page-locked memory behind the last epoch; the host waits for THAT copy only, not for what it
+        # enqueues further down (the next batch's rollout pass)
+        if self._hist_host is None or self._hist_host.shape[0] != self.epochs:
+            self._hist_host = torch.empty(self.epochs, 12, dtype=torch.float32).pin_memory()
+        host = self._hist_host
+        host.copy_(hist, non_blocking=True)
+        hist_done = torch.cuda.Event()
+        hist_done.record(torch.cuda.current_stream(self.device))
         if self.checkpoint:
             self._snapshot = self.engine.start_param_snapshot()            # D2H for the publish, behind the last epoch
         if self.prefetch:
+            # While the GPU works through the epochs: drain what already waits in the experience queue into the next batch's staging.
+            # Stops the moment the GPU has finished (event behind the last epoch): from then on gathering would delay the
+            # model publish - and with it the agents' weight age - instead of hiding behind device work.
+            done = hist_done
             t0 = time.time()
-            nxt = self._new_gather()
-            while self._packer.n_seq < self.min_seq_per_epoch and self._queue_has_messages():
-                self._consume_one(nxt)
-            nxt['hidden_s'], nxt['n_prefetched'] = time.time() - t0, len(nxt['rollouts'])
-            self._prefetched = nxt
-        host = hist.cpu()                                                   # the one synchronisation of the iteration
+            n0 = len(self._acc['rollouts'])
+            while self._packer.n_seq < self.min_seq_per_epoch and (self.prefetch_past_gpu_done or not done.query()) \
+                    and self._queue_has_messages():
+                self._consume_one(self._acc)
+            self._acc['hidden_s'] += time.time() - t0
+            self._acc['n_prefetched'] += len(self._acc['rollouts']) - n0
+            if self.pipeline_rollout_pass and self._packer.n_seq >= self.min_seq_per_epoch:
+                # the next batch is complete: its rollout pass (which needs exactly the weights the last epoch above produces) is
+                # enqueued NOW, so the GPU runs it while the host synchronises, builds the metrics and serialises / publishes the
+                # model (optimizer.py:697-716) - the publish is off the device's critical path
+                self._acc['pipelined'] = 1
+                self._ready = self._finish_batch()
+        hist_done.synchronize()                                             # the one synchronisation of the iteration
+        host = host.clone()
         losses, entropies, grad_norms = [], [], []
         for ep in range(self.epochs):
             row = host[ep]
             st = int(row[11].item())
+            if st != 0:
+                # the status word is sticky on the device (csrc/adam.hip): epochs behind the first NaN one applied nothing, like the
+                # reference, which never reaches them; cleared here, with the early rollout pass of the next batch dropped
+                msg = describe_fault(self.engine)
+                self.engine.status.zero_()
+                self._drop_ready()
             if st == 1:                                                     # optimizer.py:667-669
-                raise ValueError('loss={}, policy_loss={}, entropy_loss={}, value_loss={}'.format(*row[:4].tolist()) + describe_fault(self.engine))
+                raise ValueError('loss={}, policy_loss={}, entropy_loss={}, value_loss={}'.format(*row[:4].tolist()) + msg)
             if st == 2:                                                     # optimizer.py:678-679
-                raise ValueError('grad_norm={}'.format(row[9].item()) + describe_fault(self.engine))
+                raise ValueError('grad_norm={}'.format(row[9].item()) + msg)
             losses.append({'loss': row[0], 'policy_loss': row[1], 'entropy_loss': row[2], 'value_loss': row[3]})
             entropies.append({k: row[4 + i] for i, k in enumerate(L.OUTPUT_KEYS)})
             grad_norms.append({'unclipped': row[9], 'clipped': row[10]})
@@ -398,6 +461,7 @@ class DotaOptimizer:
             # not in the reference: the part of gathering + packing this batch that ran during the previous iteration's epochs, and how
             # many of its rollouts came in that way (timing/xp_total is the foreground part only)
             'timing/xp_hidden': acc['hidden_s'], 'xp_rollouts_prefetched': float(acc['n_prefetched']),
+            'xp_rollout_pass_pipelined': float(acc['pipelined']),          # 1: this batch's rollout pass ran behind the previous iteration's epochs
         }
         for k, v in entropies.items():
             metrics['entropy/' + k] = v.mean()
@@ -425,7 +489,8 @@ class DotaOptimizer:
         if self._snapshot is None:
             self._snapshot = self.engine.start_param_snapshot()
         buf = io.BytesIO()
-        torch.save(self.engine.snapshot_state_dict(self._snapshot), buf)
+        # serialised at once, so views of the page-locked snapshot buffer do (no 34 clones); the buffer is reused two publishes later
+        torch.save(self.engine.snapshot_state_dict(self._snapshot, clone=False), buf)
         self._snapshot = None
         blob = buf.getvalue()
         if self.checkpoint:

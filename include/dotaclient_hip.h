@@ -172,8 +172,8 @@ enum dc_ws_index {
     DC_WS_PER_LAYER
 };
 
-/* DC_WS_FAULT - where a failure of the H = 256 team kernels is reported.  Those kernels hand state between four workgroups
- * through tagged granules; a member that polls one for ~1 s without seeing its tag gives up, NaN-poisons its outputs (the loss
+/* DC_WS_FAULT - where a failure of the team kernels (H = 256: four workgroups per team; LSTM-512 in bf16 mode: sixteen) is
+ * reported.  Those kernels hand state between the workgroups of a team through tagged granules; a member that polls one for ~1 s without seeing its tag gives up, NaN-poisons its outputs (the loss
  * turns NaN: status 1 of dc_gradnorm_clip_adam, the reference's own guard, optimizer.py:667-669) and - first writer wins - records
  *   [0] DC_FAULT_TEAM_TIMEOUT + kernel (1 rnn_team_fwd, 2 rnn_team_bwd, 3 team_mfma_fwd, 4 team_mfma_bwd, 5 lstm512_team_fwd,
  *   6 lstm512_team_bwd), [1] layer, [2] team,
@@ -227,7 +227,8 @@ int dc_policy_backward(const dc_dims* dims, const float* params, const int64_t* 
  *   seg_off i64 / seg_len i32 / seg_gate i32 [n_seg] (device): the named parameters inside the flat
  *   buffer; seg_gate -1 = always has a gradient, 0..4 = only when head k acted, 5 = only if vf_coef>0;
  *   m, v: Adam moments (flat); segsq f64[n_seg], ctl f32[2], seg_step i32[n_seg] (persistent step
- *   counters), status i32[1] (0 ok, 1 NaN loss, 2 NaN grad norm: nothing updated) - all device;
+ *   counters), status i32[1] (0 ok, 1 NaN loss, 2 NaN grad norm: nothing updated; STICKY - while it is non-zero every
+ *   later call skips its update too, the caller clears it after handling the error) - all device;
  *   norms_out f32[2] = unclipped, clipped mean gradient norm. */
 int dc_gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const int32_t* seg_gate, int n_seg,
                           int max_seg_len, float* params, float* grads, float* m, float* v, double* segsq,

@@ -42,3 +42,52 @@ def test_flop_model_matches_the_survey():
     assert bench.fwd_flops_per_step('lstm', 128, 1) == 2336000
     assert bench.fwd_flops_per_step('lstm', 256, 1) == 3030784
     assert bench.fwd_flops_per_step('lstm', 512, 2) == 9401088
+
+
+def test_gpus_n_without_enough_devices_refuses_instead_of_mislabelling():
+    """a plain `python bench.py --gpus 2` (no launcher, WORLD_SIZE unset) must either start 2 ranks or fail
+    loudly - never run one rank and print n_gpus 1.  This container has no GPU: the self-launcher refuses with exit code 2 and
+    prints no JSON line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'DC_BENCH_ONE_DEVICE')}
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        return                                           # a real multi-GPU box: covered by the GPU tests
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert r.stdout.strip() == ''
+    assert 'refusing' in r.stderr
+
+
+def test_rank_count_must_match_gpus(monkeypatch):
+    """Under a launcher whose world size differs from --gpus the script stops (exit 2) before touching a device."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '4', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2 and r.stdout.strip() == ''
+    assert 'launcher started 1 rank' in r.stderr
+
+
+def test_self_launch_command_line(monkeypatch):
+    """What the self-launcher executes: torch.distributed.run, one node, --nproc-per-node = --gpus, loopback rendezvous, this file and
+    the caller's own arguments."""
+    import subprocess
+    seen = {}
+    monkeypatch.setattr(subprocess, 'call', lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setenv('DC_BENCH_ONE_DEVICE', '1')
+    import torch
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 1)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1'])
+    a = bench.parse_args()
+    assert bench.self_launch(a) == 0
+    cmd = seen['cmd']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1']
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '2' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-6:] == ['--gpus', '2', '--steps', '3', '--warmup', '1'] and cmd[-7].endswith('bench.py')
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    # without the test aid two ranks on a one-GPU box are refused
+    monkeypatch.delenv('DC_BENCH_ONE_DEVICE')
+    assert bench.self_launch(a) == 2

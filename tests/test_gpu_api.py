@@ -199,6 +199,7 @@ def test_prefetching_consumer_loop_equals_the_serial_one(tmp_path):
     seen = {True: [], False: []}
     for pf, opt in opts.items():
         opt.min_seq_per_epoch = 9
+        opt.prefetch_past_gpu_done = True          # deterministic: these tiny epochs may finish before the host has unpickled a rollout
         orig = opt._experiences_from_batch
 
         def spy(rollouts, batch, _orig=orig, _pf=pf):
@@ -268,3 +269,64 @@ def test_model_publish_is_the_reference_wire_format(tmp_path):
     opt.engine.start_param_snapshot()
     for k, v in opt.engine.snapshot_state_dict(i).items():
         assert torch.equal(v, before[k])
+
+
+def test_next_rollout_pass_is_enqueued_before_the_publish(tmp_path):
+    # the model publish (torch.save + file + MQ, optimizer.py:697-716) must not idle the GPU.  With the next batch
+    # already waiting in the queue, run_iteration(k) enqueues batch k+1's rollout pass behind its last epoch, so by the time
+    # publish_model(k) is called the device already has iteration k+1's kernels; the results equal a non-pipelined optimizer's.
+    g, _ = util.load_case('ragged_s16')
+    stream = synth.make_rollouts(31, [40, 64, 21, 33, 50, 16, 64, 48, 17, 80, 30, 64, 25, 70, 44, 16, 90, 35])
+    seen = {}
+    params = {}
+    for pipe in (True, False):
+        opt = make_opt([dict(r) for r in stream], g, tmp_path, prefetch=True)
+        opt.checkpoint, opt.min_seq_per_epoch, opt.prefetch_past_gpu_done, opt.pipeline_rollout_pass = True, 9, True, pipe
+        log = seen[pipe] = []
+        opt.mq.publish_model = lambda msg, hdr, _opt=opt, _log=log: _log.append(
+            (hdr['version'], _opt._ready is not None, None if _opt._ready is None else _opt._ready[2].values is not None))
+        metrics = []
+        for it in (1, 2, 3):
+            metrics.append(opt.run_iteration(it))
+            opt.upload_model(version=it)
+        params[pipe] = opt.engine.params.clone()
+        seen[pipe] = (log, metrics)
+    log, metrics = seen[True]
+    # iterations 1 and 2 found the next batch complete in the queue: its rollout pass (values filled in) was enqueued before the publish
+    assert log[0] == (1, True, True) and log[1] == (2, True, True)
+    assert metrics[1]['xp_rollout_pass_pipelined'] == 1.0 and metrics[2]['xp_rollout_pass_pipelined'] == 1.0
+    assert metrics[0]['xp_rollout_pass_pipelined'] == 0.0
+    assert all(not l[1] for l in seen[False][0])
+    for a, b in zip(metrics, seen[False][1]):
+        for k in ('loss/sum', 'loss/policy', 'loss/value', 'entropy', 'grad_norm/unclipped', 'avg_weight_age'):
+            assert abs(float(a[k]) - float(b[k])) <= 2e-5 * max(1.0, abs(float(b[k]))), k
+    assert torch.allclose(params[True], params[False], rtol=0, atol=2e-6)
+
+
+def test_nan_status_is_sticky_until_the_caller_clears_it(tmp_path):
+    # epochs are enqueued back to back and checked once; an epoch behind a NaN one must not apply its update (the
+    # reference raises before it would run).  Engine level: NaN batch -> status 1; a GOOD batch's epoch without clearing changes
+    # nothing and keeps the word; after clearing it steps.
+    g, rollouts = util.load_case('ragged_s16')
+    opt = make_opt(rollouts, g, tmp_path)
+    eng = opt.engine
+    from dotaclient_amd.engine import pack_rollouts
+    bad = synth.make_rollouts(77, [32])
+    bad[0]['observations']['env'][3, 0] = float('nan')
+    good = synth.make_rollouts(78, [32, 48])
+    before = eng.params.clone()
+    cb = eng.rollout_pass(pack_rollouts(bad, 16, eng.device), 16)
+    eng.train_epoch(cb, 1e-4, 5e-4, 0.5)
+    assert int(eng.status.item()) == 1
+    cg = eng.rollout_pass(pack_rollouts(good, 16, eng.device), 16)
+    steps = eng.seg_step.clone()
+    eng.train_epoch(cg, 1e-4, 5e-4, 0.5)
+    assert int(eng.status.item()) == 1 and torch.equal(before, eng.params) and torch.equal(steps, eng.seg_step)
+    eng.status.zero_()
+    eng.train_epoch(cg, 1e-4, 5e-4, 0.5)
+    assert int(eng.status.item()) == 0 and not torch.equal(before, eng.params)
+    # DotaOptimizer.train clears the word when it raises: the next call works (like the reference, whose guards keep no state)
+    seqs = opt.experiences_from_rollout(bad[0])
+    with pytest.raises(ValueError):
+        opt.train(experiences=seqs)
+    opt.train(experiences=opt.experiences_from_rollouts(good)[0])
