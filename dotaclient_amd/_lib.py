@@ -41,7 +41,7 @@ SIGNATURES = {
                               [c_flt, c_flt, c_dbl, c_dbl, c_dbl, c_flt, c_ptr]),
 }
 
-ABI_VERSION = 3      # include/dotaclient_hip.h DC_ABI_VERSION: a library built from other sources would mis-call silently
+ABI_VERSION = 4      # include/dotaclient_hip.h DC_ABI_VERSION: a library built from other sources would mis-call silently
 
 _lib = None
 

@@ -20,6 +20,7 @@ import io
 import logging
 import os
 import pickle
+import sys
 import time
 
 import numpy as np
@@ -134,6 +135,7 @@ class DotaOptimizer:
     MODEL_HISTOGRAM_FREQ = 128
     MAX_GRAD_NORM = 0.5
     SPEED_KEY = 'steps per s'
+    MessageQueue = None        # the queue class to construct when no mq= object is passed (default: __main__.MessageQueue, see __init__)
 
     def __init__(self, rmq_host, rmq_port, epochs, min_seq_per_epoch, seq_len, learning_rate, checkpoint,
                  pretrained_model, mq_prefetch_count, log_dir, entropy_coef, vf_coef, run_local,
@@ -205,9 +207,16 @@ class DotaOptimizer:
         self.time_last_it = time.time()
 
         if mq is None:
-            raise ValueError('DotaOptimizer needs the experience / model queue object: pass the reference\'s own '
-                             'MessageQueue(host, port, prefetch_count, use_model_exchange) as mq= (optimizer.py:67-174; '
-                             'the broker client is outside the hot path and is not re-implemented, INTEGRATION.md)')
+            # optimizer.py:278-280 builds its MessageQueue itself.  When this class is swapped into the reference's optimizer.py by
+            # import (INTEGRATION.md option A) that module still defines MessageQueue (optimizer.py:67-174) and runs as __main__:
+            # construct it exactly like the reference does, so that main() (optimizer.py:751-765) needs no edit.
+            mq_cls = self.MessageQueue or getattr(sys.modules.get('__main__'), 'MessageQueue', None)
+            if mq_cls is None:
+                raise ValueError('DotaOptimizer needs the experience / model queue: pass the reference\'s own MessageQueue(host, port, '
+                                 'prefetch_count, use_model_exchange) as mq=, set DotaOptimizer.MessageQueue to that class, or run from '
+                                 'the reference\'s optimizer.py, whose MessageQueue is picked up (optimizer.py:67-174; the broker client '
+                                 'is outside the hot path and is not re-implemented, INTEGRATION.md)')
+            mq = mq_cls(host=self.rmq_host, port=self.rmq_port, prefetch_count=mq_prefetch_count, use_model_exchange=self.checkpoint)
         self.mq = mq
         self.metrics_sink = metrics_sink
         self.mq.connect()

@@ -30,8 +30,11 @@ extern "C" {
 typedef void* dc_stream_t; /* hipStream_t */
 
 /* 3 (round 3): DC_WS_FAULT inserted at workspace index 0; round 2's unannounced changes (dc_gemm_f32's scratch arguments,
- * DC_WS_TEAM_XBUF / DC_WS_WPLANES) were version 2 in effect.  The Python binding refuses any other value. */
-#define DC_ABI_VERSION 3
+ * DC_WS_TEAM_XBUF / DC_WS_WPLANES) were version 2 in effect.
+ * 4 (round 4): same signatures, changed contracts - dc_gradnorm_clip_adam's status word is sticky (a non-zero word makes later calls
+ * skip their update until the caller clears it); dc_gae_scan / dc_discount / dc_advantage_returns accept any length (error 1001 is gone).
+ * The Python binding refuses any other value. */
+#define DC_ABI_VERSION 4
 int dc_abi_version(void);
 const char* dc_last_error(void);
 
@@ -45,13 +48,14 @@ int dc_gae_scan(const float* rewards, const float* values, const int64_t* seq_of
 
 /* Replaces optimizer.py:53-54 `discount(x, gamma)` for one vector: y[t] = x[t] + gamma * y[t+1] (the reversed
  * scipy lfilter([1],[1,-gamma]) of the reference: float32 in, float64 accumulate, float32 out).
- *   x, y [n] f32 (device; y may alias x); n <= 40960. */
+ *   x, y [n] f32 (device; y may alias x); any n (vectors longer than one 40 960-entry LDS block are scanned block by block
+ *   from the end, carrying the float64 state - the reference's lfilter has no length limit). */
 int dc_discount(const float* x, int n, double gamma, float* y, dc_stream_t stream);
 
 /* Replaces optimizer.py:57-64 `advantage_returns(rewards, values, gamma, lam)` for ONE rollout, with the reference's
  * own argument shapes: rewards, values [L+1] f32 (entry L is whatever the caller appended - the reference's run()
  * appends 0, optimizer.py:417-420, but the function itself accepts any terminal reward / bootstrap value);
- * adv, ret [L] f32 out.  L <= 20480. */
+ * adv, ret [L] f32 out.  Any L (blocks of 20 480 steps from the end, float64 carry). */
 int dc_advantage_returns(const float* rewards, const float* values, int L, double gamma, double lam, float* adv,
                          float* ret, dc_stream_t stream);
 

@@ -210,6 +210,25 @@ def run_dp_case(name):
           '%.1f KB' % (os.path.getsize(path) / 1024))
 
 
+def gae_long_fixture(ref_optimizer):
+    import hashlib
+    from tests.util import gae_long_inputs        # the tests regenerate the same inputs
+    r, v, x = gae_long_inputs()
+    out = {}
+    for tag, rr, vv in (('zero_terminal', np.concatenate([r[:-1], [0]]).astype(np.float32), np.concatenate([v[:-1], [0]]).astype(np.float32)),
+                        ('any_terminal', r, v)):
+        adv, ret = ref_optimizer.advantage_returns(rr, vv, 0.98, 0.97)
+        adv, ret = np.ascontiguousarray(adv, np.float32), np.ascontiguousarray(ret, np.float32)
+        out[tag + '_adv_sha256'] = np.frombuffer(hashlib.sha256(adv.tobytes()).digest(), np.uint8)
+        out[tag + '_ret_sha256'] = np.frombuffer(hashlib.sha256(ret.tobytes()).digest(), np.uint8)
+        out[tag + '_adv_samples'], out[tag + '_ret_samples'] = adv[::997], ret[::997]
+    d = np.ascontiguousarray(ref_optimizer.discount(x, 0.98 * 0.97), np.float32)
+    out['discount_sha256'] = np.frombuffer(hashlib.sha256(d.tobytes()).digest(), np.uint8)
+    out['discount_samples'] = d[::997]
+    np.savez_compressed(os.path.join(HERE, 'gae_long.npz'), n=np.int64(50000), seed=np.int64(50), **out)
+    print('gae_long', out['zero_terminal_adv_samples'][:3], '%.1f KB' % (os.path.getsize(os.path.join(HERE, 'gae_long.npz')) / 1024))
+
+
 def main():
     ref_optimizer, ref_policy = import_reference()
     torch.set_num_threads(8)
@@ -231,6 +250,10 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'gae_kat.npz'), adv=adv, ret=ret, r2=r, v2=v, adv2=adv2, ret2=ret2,
                         r3=r3, v3=v3, adv3=adv3, ret3=ret3, x4=x4, disc4=disc4, disc4b=disc4b)
     print('gae_kat', adv, ret)
+    # rollouts longer than one LDS block of the HIP scan (20 480 steps): 50 000 steps through the real
+    # reference.  Inputs are regenerated from the seed by the tests; the fixture holds a SHA-256 of the reference's full float32
+    # outputs (bit-exactness over all 50 000 entries from 64 bytes) plus every 997th value for a readable diff.
+    gae_long_fixture(ref_optimizer)
 
     common = dict(entropy_coef=5e-4, vf_coef=0.5)
     run_case(ref_optimizer, ref_policy, 'ragged_s16', [50, 64, 33], 16, 2, 5e-5, data_seed=123, **common)

@@ -330,3 +330,31 @@ def test_nan_status_is_sticky_until_the_caller_clears_it(tmp_path):
     with pytest.raises(ValueError):
         opt.train(experiences=seqs)
     opt.train(experiences=opt.experiences_from_rollouts(good)[0])
+
+
+def test_mq_is_built_like_the_reference_when_none_is_passed(tmp_path, monkeypatch):
+    # INTEGRATION.md option A: the reference's main() (optimizer.py:751-765) passes no queue object - its constructor builds
+    # MessageQueue(host, port, prefetch_count, use_model_exchange) itself (optimizer.py:278-280).  With mq=None this class does the
+    # same with the class it finds in __main__ (the reference's optimizer.py, which still defines it) or in DotaOptimizer.MessageQueue.
+    import sys
+    from dotaclient_amd.optimizer import DotaOptimizer
+    made = []
+
+    class MessageQueue(FakeMQ):
+        def __init__(self, host, port, prefetch_count, use_model_exchange):
+            super().__init__([])
+            made.append((host, port, prefetch_count, use_model_exchange))
+    kw = dict(rmq_host='h', rmq_port=5672, epochs=1, min_seq_per_epoch=1, seq_len=16, learning_rate=1e-4, checkpoint=False,
+              pretrained_model=None, mq_prefetch_count=3, log_dir=str(tmp_path), entropy_coef=5e-4, vf_coef=0.5, run_local=True)
+    monkeypatch.setattr(sys.modules['__main__'], 'MessageQueue', MessageQueue, raising=False)
+    opt = DotaOptimizer(**kw)
+    assert made == [('h', 5672, 3, False)] and isinstance(opt.mq, MessageQueue) and opt.mq.published[0][0] == {'version': 1}
+    monkeypatch.delattr(sys.modules['__main__'], 'MessageQueue')
+    monkeypatch.setattr(DotaOptimizer, 'MessageQueue', MessageQueue)
+    DotaOptimizer(**kw)
+    assert len(made) == 2
+    monkeypatch.setattr(DotaOptimizer, 'MessageQueue', None)
+    with pytest.raises(ValueError, match='MessageQueue'):
+        DotaOptimizer(**kw)
+    with pytest.raises(ValueError, match='run_local'):
+        DotaOptimizer(**dict(kw, run_local=False))

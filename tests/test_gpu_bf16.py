@@ -75,3 +75,37 @@ def test_persistent_lstm512_matches_the_step_kernels(lens, S, tile32):
     print('team512 vs step kernels:', {k: float('%.3g' % v) for k, v in errs.items()})
     for k, v in errs.items():
         assert v < (5e-3 if k != 'argmax_mismatch' else 5e-3), (k, errs)
+
+
+def test_bf16_path_on_the_full_configs4_shard_against_the_oracle_fixture():
+    # the persistent H = 512 kernels at BASELINE.json configs[4]'s FULL per-GPU shard (2-layer LSTM-512, 256
+    # trajectories x 512 steps: sixteen teams, one 16-sequence tile each, 512 time steps per launch) against the fp32 oracle's outputs on
+    # the same seeded inputs - computed offline (tests/golden/make_cfg4_fixture.py, ~30 s and tens of GB of autograd state on the host)
+    # and committed as strided samples (tests/golden/cfg4_shard_oracle.npz).  Same stated bf16 tolerances as above.
+    from dotaclient_amd import engine as E
+    f = np.load(util.GOLDEN + '/cfg4_shard_oracle.npz')
+    B, S, stride = int(f['B']), int(f['S']), int(f['stride'])
+    assert (B, S) == (256, 512)
+    g = {'seq_len': S, 'lr': 5e-5, 'entropy_coef': 5e-4, 'vf_coef': 0.5, 'epochs': 1}
+    rollouts = synth.make_rollouts(int(f['seed']), [S] * B)
+    out, eng = run_hip(g, rollouts, 'lstm', 512, 2, epochs=1, kernel_flags=E.DC_DIMS_BF16)
+    assert eng.fault() is None
+    errs = {}
+    for key in ['advantages', 'values'] + ['old_logp_' + k for k in ('enum', 'x', 'y', 'target_unit', 'ability')]:
+        got = np.asarray(out[key]).ravel()
+        assert got.size == int(f[key + '_n']), key
+        errs[key] = float(np.abs(got[::stride] - f[key]).max() / float(f[key + '_max']))
+        assert errs[key] < 3e-2, (key, errs[key])
+    # returns do not depend on the network: bit-exact against the oracle's
+    assert np.array_equal(np.asarray(out['returns']).ravel()[::stride], f['returns'])
+    same = float((out['argmax'].reshape(-1, 5)[::16] == f['argmax_rows16']).mean())
+    errs['argmax_equal'] = same
+    assert same >= 0.97, same
+    errs['losses'] = util.loss_rel_err(out['ep0_losses'], f['ep0_losses'])
+    errs['entropies'] = util.rel_err(out['ep0_entropies'], f['ep0_entropies'])
+    errs['grad_norms'] = util.rel_err(out['ep0_grad_norms'], f['ep0_grad_norms'])
+    errs['param_samples'] = util.scaled_err(out['ep0_param_samples'], f['ep0_param_samples'])
+    errs['grad_tensor_norms'] = util.scaled_err(out['ep0_grad_summary'][:, 2], f['ep0_grad_summary'][:, 2])
+    print('configs[4] full shard, bf16 path vs fp32 oracle fixture:', {k: float('%.3g' % v) for k, v in errs.items()})
+    assert errs['losses'] < 3e-2 and errs['entropies'] < 3e-2 and errs['grad_norms'] < 3e-2 and errs['param_samples'] < 1e-3
+    assert errs['grad_tensor_norms'] < 5e-2

@@ -24,7 +24,8 @@ def _gae_oracle(rew10, values, lens):
     return np.concatenate(adv), np.concatenate(ret)
 
 
-@pytest.mark.parametrize('lens', [[16], [1], [48, 64, 32], [256] * 64, [7, 300, 64, 1, 2049, 640], [20000]])
+@pytest.mark.parametrize('lens', [[16], [1], [48, 64, 32], [256] * 64, [7, 300, 64, 1, 2049, 640], [20000], [20480], [20481, 5],
+                                  [50000, 300, 41000], [61441]])
 def test_gae_scan_bit_exact(lens):
     from dotaclient_amd import ops
     dev = _dev()
@@ -55,6 +56,33 @@ def test_gae_scan_golden_vector():
     assert np.array_equal(adv.cpu().numpy(), g['adv2']) and np.array_equal(ret.cpu().numpy(), g['ret2'])
 
 
+def test_gae_rollouts_longer_than_one_lds_block_golden():
+    # the reference's lfilter has no length limit (optimizer.py:53-64); rollouts / vectors longer than one LDS
+    # block (20 480 steps, 40 960 for discount) are scanned block by block from the end with a float64 carry.  50 000 steps against
+    # the REAL reference's output, every entry bit-exact (SHA-256 of the float32 bytes, tests/golden/gae_long.npz), through all
+    # three entry points.
+    from dotaclient_amd import ops
+    from dotaclient_amd.optimizer import advantage_returns, discount
+    dev = _dev()
+    g = np.load(util.GOLDEN + '/gae_long.npz')
+    n = int(g['n'])
+    r, v, x = util.gae_long_inputs(n, int(g['seed']))
+    r0, v0 = r.copy(), v.copy()
+    r0[-1] = 0; v0[-1] = 0
+    for tag, rr, vv in (('zero_terminal', r0, v0), ('any_terminal', r, v)):
+        adv, ret = advantage_returns(rr, vv, 0.98, 0.97)
+        assert np.array_equal(adv[::997], g[tag + '_adv_samples']) and np.array_equal(ret[::997], g[tag + '_ret_samples']), tag
+        assert np.array_equal(util.sha256_of(adv), g[tag + '_adv_sha256']) and np.array_equal(util.sha256_of(ret), g[tag + '_ret_sha256']), tag
+    d = discount(x, 0.98 * 0.97)
+    assert np.array_equal(d[::997], g['discount_samples']) and np.array_equal(util.sha256_of(d), g['discount_sha256'])
+    # the batched scan of the rollout pass (sub-rewards summed on the way; terminal zeros)
+    rew = np.zeros((n, 10), np.float32); rew[:, 7] = r0[:-1]
+    adv, ret = ops.gae_scan(torch.from_numpy(rew).to(dev), torch.from_numpy(v0[:-1].copy()).to(dev),
+                            torch.zeros(1, dtype=torch.int64, device=dev), torch.tensor([n], dtype=torch.int32, device=dev), n)
+    assert np.array_equal(util.sha256_of(adv.cpu().numpy()), g['zero_terminal_adv_sha256'])
+    assert np.array_equal(util.sha256_of(ret.cpu().numpy()), g['zero_terminal_ret_sha256'])
+
+
 def test_discount_and_advantage_returns_any_terminals():
     # optimizer.py:53-64 with the reference's own signatures: non-zero terminal reward / bootstrap value, `discount` on its
     # own - bit-exact against vectors produced by the real reference (gae_kat.npz) and against the oracle on other lengths
@@ -67,7 +95,7 @@ def test_discount_and_advantage_returns_any_terminals():
     assert np.array_equal(discount(g['x4'], 0.98), g['disc4'])
     assert np.array_equal(discount(g['x4'][:65], 0.98 * 0.97), g['disc4b'])
     rng = np.random.Generator(np.random.PCG64(11))
-    for n in (2, 3, 64, 65, 129, 1000, 20001):
+    for n in (2, 3, 64, 65, 129, 1000, 20001, 20481, 20482, 40961, 45000, 90001):
         r = (0.3 * rng.standard_normal(n)).astype(np.float32)
         v = rng.standard_normal(n).astype(np.float32)
         a, t = advantage_returns(r, v, 0.98, 0.97)

@@ -67,10 +67,20 @@ def _loss_err(a, b, key):
     return float(np.max(np.abs(a - b) / (np.abs(b) + 1e-30)))
 
 
+ELEM_TOL = 2e-2     # element-wise relative error on entries above 1e-3 * max|ref| (util.elementwise_rel_err): recorded for every
+                    # compare() into gpurun_out/elementwise_parity.json (tests/conftest.py) and bounded here; the 1e-4 bar is the scaled one
+
+
 def compare(out, ref, n_ep, names_ref, tol=TOL):
+    from tests import conftest
+    rec = {}
     for key in ['advantages', 'returns', 'values'] + ['old_logp_' + k for k in L.OUTPUT_KEYS]:
         assert out[key].shape == ref[key].shape, key
         assert util.scaled_err(out[key], ref[key]) < tol, (key, util.scaled_err(out[key], ref[key]))
+        ew, frac = util.elementwise_rel_err(out[key], ref[key])
+        rec[key] = {'scaled': util.scaled_err(out[key], ref[key]), 'elementwise': ew, 'entries_above_floor': frac}
+        assert ew < ELEM_TOL, (key, ew)
+    conftest.record_elementwise(rec)
     # action argmax indices: bit-exact
     assert np.array_equal(out['argmax'], ref['argmax'].astype(out['argmax'].dtype))
     if 'hidden' in ref and 'hidden' in out:

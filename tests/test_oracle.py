@@ -86,3 +86,17 @@ def test_c_oracle_matches_numpy_oracle_and_golden():
                                     np.append(val[o:o + L], np.float32(0)), 0.98, 0.97)
         assert np.array_equal(adv[o:o + L], a) and np.array_equal(ret[o:o + L], t)
         o += L
+
+
+def test_gae_long_rollouts_golden_sha256():
+    # 50 000 steps (longer than one 20 480-step LDS block of the HIP scan): the oracle against the real reference's output, bit for
+    # bit over every entry (SHA-256 of the float32 bytes, tests/golden/gae_long.npz)
+    g = np.load(util.GOLDEN + '/gae_long.npz')
+    r, v, x = util.gae_long_inputs(int(g['n']), int(g['seed']))
+    r0, v0 = r.copy(), v.copy()
+    r0[-1] = 0; v0[-1] = 0
+    for tag, rr, vv in (('zero_terminal', r0, v0), ('any_terminal', r, v)):
+        adv, ret = RO.advantage_returns(rr, vv, 0.98, 0.97)
+        assert np.array_equal(adv[::997], g[tag + '_adv_samples']) and np.array_equal(ret[::997], g[tag + '_ret_samples'])
+        assert np.array_equal(util.sha256_of(adv), g[tag + '_adv_sha256']) and np.array_equal(util.sha256_of(ret), g[tag + '_ret_sha256'])
+    assert np.array_equal(util.sha256_of(RO.discount(x, 0.98 * 0.97)), g['discount_sha256'])

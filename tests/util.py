@@ -33,6 +33,21 @@ def scaled_err(a, b):
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30)) if a.size else 0.0
 
 
+def elementwise_rel_err(a, b, floor=1e-3):
+    """The literal reading of north_star's "within 1e-4 relative": max over the entries with |b| > floor * max|b| of
+    |a - b| / |b| (entries closer to zero than that carry no relative information in float32: a value of 1e-3 * max computed
+    from O(max) terms has an absolute error of O(1e-7 * max), i.e. 1e-4 of itself, from rounding alone).  Returned as
+    (worst, fraction of entries above the floor); reported next to scaled_err by the parity tests and bench.py."""
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    if not a.size:
+        return 0.0, 0.0
+    keep = np.abs(b) > floor * np.max(np.abs(b))
+    if not keep.any():
+        return 0.0, 0.0
+    return float(np.max(np.abs(a[keep] - b[keep]) / np.abs(b[keep]))), float(keep.mean())
+
+
 def loss_rel_err(a, b):
     """Relative error of the four loss numbers [loss, policy, entropy, value] (north_star: 1e-4).  `loss` is the SUM of
     the three parts and cancels (clip_s16, third epoch at lr 3e-3: -0.0028 = -0.0836 - 0.0040 + 0.0848, condition number
@@ -126,3 +141,18 @@ def oracle_dp_run(g, shards):
             out[pre + 'param_samples'] = np.concatenate(pv)
             out[pre + 'has_grad'] = np.array(hg)
     return out
+
+
+def gae_long_inputs(n=50000, seed=50):
+    """Inputs of tests/golden/gae_long.npz (rollouts longer than one LDS block of the HIP scan): (n+1)-vectors of rewards and
+    values for advantage_returns, a (2n+1)-vector for discount.  make_golden.py runs the real reference on exactly these."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    r = (0.3 * rng.standard_normal(n + 1)).astype(np.float32)
+    v = rng.standard_normal(n + 1).astype(np.float32)
+    x = rng.standard_normal(2 * n + 1).astype(np.float32)
+    return r, v, x
+
+
+def sha256_of(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a, np.float32).tobytes()).digest(), np.uint8)
