@@ -193,7 +193,7 @@ def cpu_baseline(cell, hidden, layers, rollouts, seq_len, epochs, lr, ent, vf):
             best, best_t = t, a + b
     torch.set_num_threads(best)
     # warm-up of the timed run: one step on the bounded sample (the sweep above ran 8 trajectories only)
-    sample = rollouts[:min(64, len(rollouts))]
+    sample = rollouts[:min(64, max(8, len(rollouts) // 4))]
     rates = []
     for _ in range(2):
         a, b, n, _ = one_iteration(sample, epochs)
@@ -210,7 +210,7 @@ def cpu_baseline(cell, hidden, layers, rollouts, seq_len, epochs, lr, ent, vf):
     }, ref
 
 
-def parity_report(got, ref, tol=1e-4):
+def parity_report(got, ref, tol=1e-4, argmax_min_equal=None, sub_batch=None):
     """HIP path vs oracle on the bench workload itself.  Vectors: max |a-b| / max |b|; per-epoch scalars: relative, a loss
     part measured against max(|itself|, 1 % of the largest part), the total against the sum of |parts| (the same yardsticks as tests/test_gpu_parity.py)."""
     def scaled(a, b):
@@ -232,12 +232,18 @@ def parity_report(got, ref, tol=1e-4):
     rep['losses'] = float(err[:, :4].max())
     rep['entropies'] = float(err[:, 4:9].max())
     rep['grad_norms'] = float(err[:, 9:11].max())
+    if argmax_min_equal is not None:
+        rep.pop('returns', None)       # do not depend on the network: bit-exact either way
     worst = max(rep.values())
     argmax_equal = bool(np.array_equal(got['argmax'], ref['argmax'].astype(got['argmax'].dtype)))
-    return {'checker': 'oracle/ref_optimizer.py on the same %d env-steps, first iteration from the same initial weights, all %d epochs'
-                       % (ref['advantages'].size, re_.shape[0]),
-            'parity_rel_err': worst, 'tolerance': tol, 'argmax_bit_exact': argmax_equal,
-            'ok': bool(worst < tol and argmax_equal), 'per_quantity': {k: float('%.3g' % v) for k, v in rep.items()},
+    argmax_frac = float((got['argmax'] == ref['argmax'].astype(got['argmax'].dtype)).mean())
+    argmax_ok = argmax_equal if argmax_min_equal is None else argmax_frac >= argmax_min_equal
+    return {'checker': 'oracle/ref_optimizer.py (fp32) on the same %d env-steps%s, first iteration from the same initial weights, all %d epochs'
+                       % (ref['advantages'].size, '' if sub_batch is None else ' (the first %d trajectories of the timed batch, run as a batch of their own)' % sub_batch,
+                          re_.shape[0]),
+            'parity_rel_err': worst, 'tolerance': tol, 'argmax_bit_exact': argmax_equal, 'argmax_equal_fraction': argmax_frac,
+            'argmax_rule': 'bit-exact' if argmax_min_equal is None else 'bf16 path: >= %.2f of the masked argmax indices equal (near-ties flip under a 2^-9 perturbation; tests/test_gpu_bf16.py)' % argmax_min_equal,
+            'ok': bool(worst < tol and argmax_ok), 'per_quantity': {k: float('%.3g' % v) for k, v in rep.items()},
             'yardstick': 'vectors: max|a-b| / max|b|; loss parts: relative (floor 1 % of the largest part), total loss against the sum of |parts|',
             'elementwise_rel_err': {k: float('%.3g' % v) for k, v in elem.items()},
             'elementwise_note': 'reported beside the scaled figures, not part of `ok`: max over entries with |ref| > 1e-3 * max|ref| of '
@@ -292,6 +298,7 @@ BOUND_NOTES = {
                'between the four CUs that share a sequence), not by arithmetic or HBM',
     'hbm': 'streams its operands once: priced against the 8 TB/s HBM peak',
 }
+PARITY_FULL_MAX = 65536   # env-steps per GPU up to which `parity` / `cpu_baseline` run the oracle on the whole timed batch
 KERNEL_FLAGS = 0      # --kernel-flags: DC_DIMS_* kernel-selection overrides for A/B runs (include/dotaclient_hip.h)
 USE_GRAPHS = False    # --epoch-graph: replay every epoch as one hipGraph launch (Engine.train_epoch(graph=True))
 REUSE_FORWARD = False  # side measurement only: Engine.reuse_rollout_forward
@@ -481,7 +488,7 @@ def main():
         hook_factory = FlatGradAllReducer
     want_cpu = world == 1 and rank == 0 and not args.no_cpu_baseline
     main_run = run_workload(args.cell, args.hidden, args.layers, B, S, E, args.steps, args.warmup, dev, rank, world, hook_factory,
-                            want_parity=want_cpu, want_profile=True)
+                            want_parity=want_cpu and B * S <= PARITY_FULL_MAX, want_profile=True)
     check_status(main_run, 'the timed workload')
     eng, rollouts = main_run['eng'], main_run['rollouts']
     elapsed, status, losses, regions = main_run['elapsed'], main_run['status'], main_run['losses'], main_run['regions']
@@ -622,8 +629,26 @@ def main():
             except Exception as e:                                  # noqa: BLE001
                 sys.stderr.write('bench.py: weak_scaling_unit failed: %r\n' % (e,))
         if want_cpu:
-            line['cpu_baseline'], ref = cpu_baseline(args.cell, args.hidden, args.layers, rollouts, S, E, lr, ent, vf)
-            line['parity'] = parity_report(main_run['first_iteration'], ref)
+            bf16 = bool(KERNEL_FLAGS & 4096)
+            tol, amin = (3e-2, 0.97) if bf16 else (1e-4, None)       # bf16 path: the stated tolerances of tests/test_gpu_bf16.py
+            if B * S > PARITY_FULL_MAX:
+                # a batch the oracle would need minutes (and tens of GB) for: checker and CPU baseline run on a bounded sample, the first
+                # 64 trajectories, which the HIP path runs again as a batch of its own (first iteration from the same initial weights)
+                nsub = min(64, B)
+                sub = rollouts[:nsub]
+                eng2 = Engine(args.cell, args.hidden, args.layers, dev)
+                eng2.kernel_flags = KERNEL_FLAGS
+                eng2.load_state_dict(synth.init_state_dict(7, args.cell, args.hidden, args.layers))
+                got = hip_parity_iteration(eng2, pack_rollouts(sub, S, dev), S, E, lr, ent, vf)
+                st2 = int(eng2.status.item())
+                del eng2
+                line['cpu_baseline'], ref = cpu_baseline(args.cell, args.hidden, args.layers, sub, S, E, lr, ent, vf)
+                line['cpu_baseline']['sample'] += '; BOUNDED SAMPLE: the first %d of the %d trajectories of the timed batch' % (nsub, B)
+                line['parity'] = parity_report(got, ref, tol, amin, sub_batch=nsub)
+                line['parity']['status_of_the_sub_batch_run'] = st2
+            else:
+                line['cpu_baseline'], ref = cpu_baseline(args.cell, args.hidden, args.layers, rollouts, S, E, lr, ent, vf)
+                line['parity'] = parity_report(main_run['first_iteration'], ref, tol, amin)
         else:
             line['cpu_baseline'] = None
             line['parity'] = None

@@ -317,11 +317,12 @@ def test_nan_status_is_sticky_until_the_caller_clears_it(tmp_path):
     before = eng.params.clone()
     cb = eng.rollout_pass(pack_rollouts(bad, 16, eng.device), 16)
     eng.train_epoch(cb, 1e-4, 5e-4, 0.5)
-    assert int(eng.status.item()) == 1
+    st = int(eng.status.item())
+    assert st in (1, 2)                          # NaN loss or NaN gradient norm, whichever guard sees it first
     cg = eng.rollout_pass(pack_rollouts(good, 16, eng.device), 16)
     steps = eng.seg_step.clone()
     eng.train_epoch(cg, 1e-4, 5e-4, 0.5)
-    assert int(eng.status.item()) == 1 and torch.equal(before, eng.params) and torch.equal(steps, eng.seg_step)
+    assert int(eng.status.item()) == st and torch.equal(before, eng.params) and torch.equal(steps, eng.seg_step)
     eng.status.zero_()
     eng.train_epoch(cg, 1e-4, 5e-4, 0.5)
     assert int(eng.status.item()) == 0 and not torch.equal(before, eng.params)
