@@ -500,6 +500,9 @@ def main():
         value = n_steps / elapsed
         ffwd = fwd_flops_per_step(args.cell, args.hidden, args.layers)
         workload_key = '%s-%d-%dx%d' % (args.cell, args.hidden, B, S)
+        for r in regions:
+            if r['kernel'] == 'gradnorm_clip_adam':          # the library does not know the parameter count (segments live on the device): 4 B
+                r['bytes'] = 32.0 * eng.total * r['launches']   # read for the norms + 28 B read / written by the update, per parameter
         regions.sort(key=lambda r: -r['total_ms'])
         kernels = []
         for r in regions:

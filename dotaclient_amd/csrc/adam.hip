@@ -32,38 +32,23 @@ __device__ __forceinline__ bool seg_active(const AdamSegs& sg, int seg, const in
     return vf_coef > 0.f;
 }
 
-__global__ __launch_bounds__(256) void grad_sqnorm_kernel(AdamSegs sg, const float* __restrict__ grad,
-                                                          double* __restrict__ segsq) {
-    const int seg = blockIdx.y;
-    const long long len = sg.seg_len[seg];
-    const long long c0 = (long long)blockIdx.x * ADAM_CHUNK;
-    if (c0 >= len) return;
-    const float* g = grad + sg.seg_off[seg];
-    const long long c1 = min(len, c0 + ADAM_CHUNK);
-    double s = 0.0;
-    for (long long i = c0 + threadIdx.x; i < c1; i += 256) {
-        const double v = g[i];
-        s += v * v;
-    }
-    __shared__ double sh[4];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&segsq[seg], (sh[0] + sh[1]) + (sh[2] + sh[3]));
-}
-
-// ctl[0] = clip coefficient, ctl[1] = ok flag (1.0 = apply the update).  One wave: lane s owns segment s
-// (34 named parameters; the loop covers more), sums in the segment order of the reference via wave_sum.
-__global__ __launch_bounds__(64) void clip_finalize_kernel(AdamSegs sg, const double* __restrict__ segsq,
-                                                           const int32_t* __restrict__ head_on,
-                                                           const float* __restrict__ losses, float* __restrict__ norms_out,
-                                                           float* __restrict__ ctl, int32_t* __restrict__ seg_step,
-                                                           int32_t* __restrict__ status, float max_norm, float vf_coef) {
-    const int lane = threadIdx.x;
+// ctl[0] = clip coefficient, ctl[1] = ok flag (1.0 = apply the update), ctl[2] (as u32) = arrival counter of grad_sqnorm_kernel's
+// blocks (zero between calls), ctl[3] unused.
+// The norms: every (segment, 4096-element chunk) block leaves its partial sum of squares in segsq[n_seg + seg * nchunk + chunk] - no
+// clear launch, no same-address atomics, a fixed summation order - and the LAST block to arrive (release / ticket / acquire) does
+// what used to be a launch of its own: per-segment norms in the reference's order, clip coefficient, the two NaN guards, step counters.
+__device__ __forceinline__ void clip_finalize(const AdamSegs& sg, double* __restrict__ segsq, int nchunk, const int32_t* __restrict__ head_on,
+                                              const float* __restrict__ losses, float* __restrict__ norms_out, float* __restrict__ ctl,
+                                              int32_t* __restrict__ seg_step, int32_t* __restrict__ status, float max_norm, float vf_coef,
+                                              int lane) {
     double sum_norm = 0.0, tot_sq = 0.0, n_act = 0.0;
     for (int s = lane; s < sg.n_seg; s += 64) {
+        const int nc = (sg.seg_len[s] + ADAM_CHUNK - 1) / ADAM_CHUNK;
+        double sq = 0.0;
+        for (int c = 0; c < nc; ++c) sq += segsq[sg.n_seg + s * nchunk + c];
+        segsq[s] = sq;                                   // the total, for inspection
         if (!seg_active(sg, s, head_on, vf_coef)) continue;
-        const float nrm = (float)sqrt(segsq[s]);
+        const float nrm = (float)sqrt(sq);
         sum_norm += (double)nrm;
         tot_sq += (double)nrm * (double)nrm;
         n_act += 1.0;
@@ -91,6 +76,46 @@ __global__ __launch_bounds__(64) void clip_finalize_kernel(AdamSegs sg, const do
     if (st == 0)
         for (int s = lane; s < sg.n_seg; s += 64)
             if (seg_active(sg, s, head_on, vf_coef)) seg_step[s] += 1;
+}
+
+__global__ __launch_bounds__(256) void grad_sqnorm_kernel(AdamSegs sg, const float* __restrict__ grad, double* __restrict__ segsq,
+                                                          const int32_t* __restrict__ head_on,
+                                                          const float* __restrict__ losses, float* __restrict__ norms_out,
+                                                          float* __restrict__ ctl, int32_t* __restrict__ seg_step,
+                                                          int32_t* __restrict__ status, float max_norm, float vf_coef) {
+    const int seg = blockIdx.y;
+    const long long len = sg.seg_len[seg];
+    const long long c0 = (long long)blockIdx.x * ADAM_CHUNK;
+    __shared__ double sh[4];
+    __shared__ int sh_last;
+    if (c0 < len) {
+        const float* g = grad + sg.seg_off[seg];
+        const long long c1 = min(len, c0 + ADAM_CHUNK);
+        double s = 0.0;
+        for (long long i = c0 + threadIdx.x; i < c1; i += 256) {
+            const double v = g[i];
+            s += v * v;
+        }
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) segsq[sg.n_seg + seg * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    }
+    // every block of the grid arrives (also the ones past their segment's end): the last one finalises
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned* cnt = reinterpret_cast<unsigned*>(ctl + 2);
+        const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = t == gridDim.x * gridDim.y - 1;
+        if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next call
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        sh_last = last;
+    }
+    __syncthreads();
+    if (sh_last && threadIdx.x < 64)
+        clip_finalize(sg, segsq, (int)gridDim.x, head_on, losses, norms_out, ctl, seg_step, status, max_norm, vf_coef, threadIdx.x);
 }
 
 __global__ __launch_bounds__(256) void adam_update_kernel(AdamSegs sg, float* __restrict__ param, float* __restrict__ grad,
@@ -166,11 +191,9 @@ int gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const int
                        const float* losses, float* norms_out, float* ctl, int32_t* seg_step, int32_t* status,
                        float max_norm, float vf_coef, double lr, double beta1, double beta2, float eps, hipStream_t s) {
     AdamSegs sg{seg_off, seg_len, seg_gate, n_seg};
-    ProfScope prof("gradnorm_clip_adam", 0.0, 32.0 * n_seg * max_seg_len / 8, s);
-    if (int rc0 = zero_async(segsq, sizeof(double) * n_seg, s)) return rc0;
+    ProfScope prof("gradnorm_clip_adam", 0.0, 32.0 * n_seg * max_seg_len / 8, s);   // (bytes: a stand-in; bench.py prices the region by 32 B x parameters)
     dim3 grid((max_seg_len + ADAM_CHUNK - 1) / ADAM_CHUNK, n_seg);
-    hipLaunchKernelGGL(grad_sqnorm_kernel, grid, dim3(256), 0, s, sg, grad, segsq);
-    hipLaunchKernelGGL(clip_finalize_kernel, dim3(1), dim3(64), 0, s, sg, segsq, head_on, losses, norms_out, ctl, seg_step,
+    hipLaunchKernelGGL(grad_sqnorm_kernel, grid, dim3(256), 0, s, sg, grad, segsq, head_on, losses, norms_out, ctl, seg_step,
                        status, max_norm, vf_coef);
     hipLaunchKernelGGL(adam_update_kernel, grid, dim3(256), 0, s, sg, param, grad, m, v, ctl, seg_step, head_on, vf_coef, lr,
                        beta1, beta2, eps);

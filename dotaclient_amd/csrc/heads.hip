@@ -20,6 +20,11 @@ __constant__ int c_t_cum[7] = {0, 1, 6, 22, 38, 39, 40};
 
 // stats block (doubles), shared by the loss kernels and the finaliser
 enum { ST_ADV_SUM = 0, ST_ADV_SQ = 1, ST_NSEL = 2 /*5*/, ST_POL = 7 /*5*/, ST_ENT = 12 /*5*/, ST_VAL = 17, ST_COUNT = 18 };
+// Layout of DC_WS_STATS (doubles; policy.hip sizes it): [0, 64) the totals above (written by the last block of ppo_loss_kernel,
+// for inspection), [ST_PART1, +ST_G1 * 8) batch_stats_kernel's per-block partial sums, [ST_PART2, +ST_G2 * 12) ppo_loss_kernel's,
+// [ST_TICKET] a 32-bit arrival counter.  Per-block partials summed in a fixed order instead of f64 atomics on eleven words:
+// 4 096 blocks x 11 same-address atomics serialised at one L2 channel (the kernel's tail), and made the sums order-dependent.
+enum { ST_G1 = 256, ST_G2 = 2048, ST_PART1 = 64, ST_PART2 = ST_PART1 + ST_G1 * 8, ST_TICKET = ST_PART2 + ST_G2 * 12, ST_DOUBLES = ST_TICKET + 8 };
 
 // ---------------------------------------------------------------------------------------------------
 // target-unit logits: tu[n][u] = sum_c q[n][c] * emb[n][u][c];  16 lanes per unit, 4 units per wave pass
@@ -203,8 +208,9 @@ __global__ __launch_bounds__(256) void batch_stats_kernel(const float* __restric
     __syncthreads();
     if (threadIdx.x < 7) {
         const double r = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
-        atomicAdd(&stats[threadIdx.x], r);   // ST_ADV_SUM, ST_ADV_SQ, ST_NSEL..
+        stats[ST_PART1 + blockIdx.x * 8 + threadIdx.x] = r;   // ST_ADV_SUM, ST_ADV_SQ, ST_NSEL..: summed by ppo_loss_kernel's blocks
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<unsigned*>(stats + ST_TICKET) = 0u;   // ppo_loss_kernel's arrival counter
 }
 
 struct LossArgs {
@@ -218,6 +224,8 @@ struct LossArgs {
     float* dtu;              // [nr][40]
     long long nr;
     float e_clip, entropy_coef, vf_coef, adv_eps;
+    int g1;                  // blocks of batch_stats_kernel (rows of its partial sums)
+    float* losses_out; int32_t* head_on;    // written by the last block to finish (loss_finalize)
 };
 
 // 16 lanes (one DPP row) per env-step: lane j owns the act/mask columns j, j+16, j+32, j+48 (and lane 0 column
@@ -246,23 +254,64 @@ __device__ __forceinline__ int row_min16_i(int x) {
 }
 __device__ __forceinline__ int head_of_col(int c) { return c < 4 ? 0 : (c < 13 ? 1 : (c < 22 ? 2 : (c < 62 ? 3 : 4))); }
 
+// losses[0..3] = loss, policy_loss, entropy_loss, value_loss ; losses[4..8] = entropies per head
+// (optimizer.py:649-665, 682-689); flags[0..4] = 1 if head k had at least one action in the batch.  One thread.
+__device__ __forceinline__ void loss_finalize(const double* stats, float* out, int32_t* head_on, long long nr, float entropy_coef,
+                                              float vf_coef) {
+    double pol_sum = 0.0, ent_sum = 0.0;
+    for (int k = 0; k < 5; ++k) {
+        const double nsel = stats[ST_NSEL + k];
+        // fp32 like the reference's 0-d tensors: mean of the per-step terms, then mean over the 5 heads
+        const float lk = nsel > 0.0 ? (float)(stats[ST_POL + k] / nsel) : 0.f;
+        const float hk = nsel > 0.0 ? (float)(stats[ST_ENT + k] / nsel) : 0.f;
+        pol_sum += (double)lk;
+        ent_sum += (double)hk;
+        out[4 + k] = hk;
+        head_on[k] = nsel > 0.0 ? 1 : 0;
+    }
+    const float policy_loss = (float)(pol_sum / 5.0);
+    const float entropy_loss = entropy_coef > 0.f ? -entropy_coef * (float)ent_sum : 0.f;
+    const float value_loss = vf_coef > 0.f ? vf_coef * (0.5f * (float)(stats[ST_VAL] / (double)nr)) : 0.f;
+    out[0] = policy_loss + entropy_loss + value_loss;
+    out[1] = policy_loss;
+    out[2] = entropy_loss;
+    out[3] = value_loss;
+}
+
 __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
     __shared__ float sh_norm[2];
+    __shared__ double sh_tot[ST_COUNT];
     __shared__ double sh[4][11];
-    if (threadIdx.x == 0) {
-        const double N = (double)p.nr;
-        const double mean = p.stats[ST_ADV_SUM] / N;
-        double var = (p.stats[ST_ADV_SQ] - N * mean * mean) / (N - 1.0);   // torch.std: unbiased (N-1); optimizer.py:588
-        if (var < 0.0) var = 0.0;
-        sh_norm[0] = (float)mean;
-        sh_norm[1] = (float)(sqrt(var) + (double)p.adv_eps);
+    __shared__ int sh_last;
+    // batch statistics: every block sums batch_stats_kernel's partial rows itself, in one fixed order (lane-strided, then the wave
+    // butterfly): bit-identical in every block and from run to run
+    if (threadIdx.x < 64) {
+        double v[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int b = threadIdx.x; b < p.g1; b += 64)
+#pragma unroll
+            for (int q = 0; q < 7; ++q) v[q] += p.stats[ST_PART1 + b * 8 + q];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const double r = wave_sum(v[q]);
+            if (threadIdx.x == 0) sh_tot[q] = r;
+        }
+        if (threadIdx.x == 0) {
+            const double N = (double)p.nr;
+            const double mean = sh_tot[ST_ADV_SUM] / N;
+            double var = (sh_tot[ST_ADV_SQ] - N * mean * mean) / (N - 1.0);   // torch.std: unbiased (N-1); optimizer.py:588
+            if (var < 0.0) var = 0.0;
+            sh_norm[0] = (float)mean;
+            sh_norm[1] = (float)(sqrt(var) + (double)p.adv_eps);
+        }
     }
     __syncthreads();
     const int j = threadIdx.x & 15;
-    const long long n = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const bool on = n < p.nr;
-    const long long nn = on ? n : p.nr - 1;     // idle rows of the last block recompute a valid step and store nothing
     double pol[5] = {0, 0, 0, 0, 0}, ent[5] = {0, 0, 0, 0, 0}, val = 0.0;
+    const long long groups = (p.nr + 15) / 16;
+    for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {      // persistent blocks: one set of partial sums per block
+    const long long n = grp * 16 + (threadIdx.x >> 4);
+    const bool on = n < p.nr;
+    const long long nn = on ? n : p.nr - 1;     // idle rows of the last group recompute a valid step and store nothing
 
     const float* ho = p.headout + nn * HO_LD;
     const float* tun = p.tu + nn * NUNITS;
@@ -302,7 +351,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
     for (int kk = 0; kk < 5; ++kk) {
         lse[kk] = logf(row_sum16(se_c[kk]));
         amin[kk] = row_min16_i(amin_c[kk]);
-        nselv[kk] = (float)p.stats[ST_NSEL + kk];
+        nselv[kk] = (float)sh_tot[ST_NSEL + kk];
     }
     // log-probs of this lane's columns, entropy terms, the selected action's surrogate
     float lp[5], pc[5];
@@ -381,7 +430,8 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
 #pragma unroll
         for (int c = HO_VALUE + 1; c < HO_LD; ++c) p.dheadout[n * HO_LD + c] = 0.f;
     }
-    // block reduction: 5 policy sums + 5 entropy sums + value sum
+    }   // groups of this block
+    // block reduction: 5 policy sums + 5 entropy sums + value sum -> this block's row of partial sums
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int kk = 0; kk < 5; ++kk) {
@@ -392,35 +442,38 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
     const double vs = wave_sum(val);
     if (lane == 0) sh[wave][10] = vs;
     __syncthreads();
-    if (threadIdx.x < 11) {
-        const double r = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
-        if (r != 0.0) atomicAdd(&p.stats[ST_POL + threadIdx.x], r);   // ST_POL(5) ST_ENT(5) ST_VAL contiguous
+    if (threadIdx.x < 11)
+        p.stats[ST_PART2 + blockIdx.x * 12 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    // the last block to arrive sums all rows (fixed order) and finalises the losses: release our row, take a ticket, acquire
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(p.stats + ST_TICKET), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        sh_last = t == gridDim.x - 1;
     }
-}
-
-// losses[0..3] = loss, policy_loss, entropy_loss, value_loss ; losses[4..8] = entropies per head
-// (optimizer.py:649-665, 682-689); flags[0..4] = 1 if head k had at least one action in the batch
-__global__ void loss_finalize_kernel(const double* __restrict__ stats, float* __restrict__ out, int32_t* __restrict__ head_on,
-                                     long long nr, float entropy_coef, float vf_coef) {
-    if (threadIdx.x != 0) return;
-    double pol_sum = 0.0, ent_sum = 0.0;
-    for (int k = 0; k < 5; ++k) {
-        const double nsel = stats[ST_NSEL + k];
-        // fp32 like the reference's 0-d tensors: mean of the per-step terms, then mean over the 5 heads
-        const float lk = nsel > 0.0 ? (float)(stats[ST_POL + k] / nsel) : 0.f;
-        const float hk = nsel > 0.0 ? (float)(stats[ST_ENT + k] / nsel) : 0.f;
-        pol_sum += (double)lk;
-        ent_sum += (double)hk;
-        out[4 + k] = hk;
-        head_on[k] = nsel > 0.0 ? 1 : 0;
+    __syncthreads();
+    if (!sh_last) return;
+    {
+        double v[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int b = threadIdx.x; b < (int)gridDim.x; b += 256)
+#pragma unroll
+            for (int q = 0; q < 11; ++q) v[q] += p.stats[ST_PART2 + b * 12 + q];
+#pragma unroll
+        for (int q = 0; q < 11; ++q) {
+            const double r = wave_sum(v[q]);
+            if (lane == 0) sh[wave][q] = r;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int q = 0; q < 7; ++q) p.stats[q] = sh_tot[q];
+#pragma unroll
+            for (int q = 0; q < 11; ++q) p.stats[ST_POL + q] = (sh[0][q] + sh[1][q]) + (sh[2][q] + sh[3][q]);
+            loss_finalize(p.stats, p.losses_out, p.head_on, p.nr, p.entropy_coef, p.vf_coef);
+        }
     }
-    const float policy_loss = (float)(pol_sum / 5.0);
-    const float entropy_loss = entropy_coef > 0.f ? -entropy_coef * (float)ent_sum : 0.f;
-    const float value_loss = vf_coef > 0.f ? vf_coef * (0.5f * (float)(stats[ST_VAL] / (double)nr)) : 0.f;
-    out[0] = policy_loss + entropy_loss + value_loss;
-    out[1] = policy_loss;
-    out[2] = entropy_loss;
-    out[3] = value_loss;
 }
 
 static inline int grid1d(long long items, int per_block, int cap) {
@@ -460,15 +513,17 @@ int ppo_loss_fwd_bwd(const float* headout, const float* tu, const uint8_t* act, 
                      const float* adv, const float* ret, double* stats, float* dheadout, float* dtu, float* losses_out,
                      int32_t* head_on, long long nr, float e_clip, float entropy_coef, float vf_coef, hipStream_t s) {
     ProfScope prof("ppo_loss(stats+loss+finalize)", 0.0, (double)nr * (4.0 * (26 + 40 + 5 + 2) + 2.0 * 65 + 4.0 * (32 + 40)), s);
-    if (int rc0 = zero_async(stats, ST_COUNT * sizeof(double), s)) return rc0;
-    hipLaunchKernelGGL(batch_stats_kernel, dim3(grid1d(nr, 256, 1024)), dim3(256), 0, s, adv, act, stats, nr);
+    // two launches: batch statistics (per-block partial sums; also clears the arrival counter), then the loss, whose last block
+    // to finish sums the blocks' partial losses and finalises them - no clear launch, no finalise launch, no same-address atomics
+    const int g1 = grid1d(nr, 256, ST_G1);
+    hipLaunchKernelGGL(batch_stats_kernel, dim3(g1), dim3(256), 0, s, adv, act, stats, nr);
     LossArgs a;
     a.headout = headout; a.tu = tu; a.act = act; a.mask = mask; a.old_logp = old_logp; a.adv = adv; a.ret = ret;
     a.stats = stats; a.dheadout = dheadout; a.dtu = dtu; a.nr = nr;
     a.e_clip = e_clip; a.entropy_coef = entropy_coef; a.vf_coef = vf_coef;
     a.adv_eps = 1.1920928955078125e-07f;   // np.finfo(np.float32).eps, optimizer.py:38
-    hipLaunchKernelGGL(ppo_loss_kernel, dim3((unsigned)((nr + 15) / 16)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, stats, losses_out, head_on, nr, entropy_coef, vf_coef);
+    a.g1 = g1; a.losses_out = losses_out; a.head_on = head_on;
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3(grid1d(nr, 16, ST_G2)), dim3(256), 0, s, a);
     return launch_check("ppo_loss_fwd_bwd");
 }
 
