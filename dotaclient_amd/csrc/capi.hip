@@ -75,7 +75,7 @@ int dc_gemm_x3(const float* A, const float* B, float* C, int M, int N, int K, in
     hipStream_t s = (hipStream_t)stream;
     X3Gemm g;
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.nbias = N; g.relu = relu; g.aux = aux; g.ldaux = ldaux;
-    g.accumulate = accumulate; g.prec = prec == 1 ? 1 : 6;
+    g.accumulate = accumulate; g.prec = prec == 1 ? 1 : (prec == 4 ? 4 : 6);      // 4: two f16 pieces, unit pre-scales (sa = sb = 1)
     if (a_kmajor && b_kmajor) {
         g.A = A; g.a_mode = X3_KMAJ; g.lda = lda; g.B = B; g.b_mode = X3_KMAJ; g.ldb = ldb;
         g.scratch = GemmScratch{scratch, (long long)scratch_floats};

@@ -21,6 +21,18 @@
 //   * the epilogue goes through LDS and stores 16 bytes per lane (a K = 256 product spends as long in a 4-byte-per-lane
 //     epilogue as in its main loop).
 // Tile 128 x 128 x 16, 256 threads (2 x 2 waves of 64 x 64), two stages of 36 KB: two workgroups per CU.
+//
+// PREC = 4 (round 4, DC_DIMS_F16X2): TWO f16 pieces instead of three bf16 ones.  x 2^s = h + m + l with h = f16(x 2^s), m = f16(x 2^s - h):
+// 11 + 11 significand bits plus the sign of m carry 23 of the 24 bits of an f32, |l| <= 2^-23 |x|, and
+//     a b = hh + hm + mh + mm + (hl + lh + ...),   dropped: <= 2^-22 |ab|
+// is FOUR v_mfma_f32_32x32x16_f16 per K = 16 instead of six bf16 ones (measured against f64 on the network's shapes,
+// tools/ubench/gemm_x3.hip: 1.2e-7 .. 4.9e-7 of max |C| - the six-bf16 form 1.4e-7 .. 5.5e-7, the f32 fma chain 2.1e-7 .. 3.7e-7), two
+// planes through the LDS instead of three, 3.5 instead of 5.5 VALU instructions per element split.  These products run at the
+// chip's power limit (profiles/r04/gemm_power_evidence.json), so fewer MFMAs and fewer LDS bytes per flop is what buys time.
+// f16 has five exponent bits: every operand is pre-scaled by a power of two (exact; `sa`, `sb`: activations 2^4, weights 2^8,
+// gradients 2^(ceil(log2 rows) + 2)) so that the m pieces stay normal, and the accumulators are scaled back in the epilogue.
+// An operand entry beyond 65504 / scale becomes inf -> NaN downstream -> the optimizer's own NaN guard (status word) stops the
+// update: the host then re-runs with the bf16 pieces (Engine: DC_DIMS_F16X2 cleared), whose exponent range is f32's.
 #include "kernels.h"
 #include "gemm_tiles.h"
 
@@ -37,20 +49,30 @@ struct X3Args {
     float* C; float* C2; const float* bias; const float* aux; float* slab; float* a_colsum;
     long long a_plane, b_plane, b2_plane;   // plane strides (elements) of pre-split operands
     int M, N, K, lda, ldb, ldb2, ldc, ldc2, ldaux, n_split, k_per_split, relu, accumulate, nbias;
+    float sa, sb, inv;      // PREC = 4: power-of-two pre-scales of the A / B operands and 1 / (sa sb)
 };
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2v;
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {      // {f16(b), f16(a)}, round to nearest even (v_cvt_pk_f16_f32)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{a, b}, f16x2));
+}
 
 // ---- operand loaders: global -> registers (issued one K step ahead) -> split -> LDS planes ---------------------------
 // MODE X3_ROW   : f32 [rows][ld], k contiguous           -> planes [row][16 k] bf16, 48-byte rows
 // MODE X3_KMAJ  : f32 [k][ld], rows contiguous           -> planes [8 kpairs][128 rows] u32
 // MODE X3_PLANES: bf16 [NP][rows][ld] pre-split weights  -> planes [row][16 k] bf16 (no arithmetic)
-template <int MODE, int NP>
+template <int MODE, int NP, bool F16 = false>
 struct X3Loader {
     struct Regs { float4 v[2]; u32x4 w[NP]; };   // one staged K step of this thread (only the members its MODE uses are live)
     const char* src[2];
     long long step;        // bytes per K step
     long long plane;       // bytes between planes (X3_PLANES)
+    float scale;           // F16: power-of-two pre-scale of this operand
 
-    __device__ __forceinline__ void init(const void* P, int ld, long long plane_elems, int r_base, int R, int k0, int tid) {
+    __device__ __forceinline__ void init(const void* P, int ld, long long plane_elems, int r_base, int R, int k0, int tid, float sc = 1.f) {
+        scale = sc;
         if constexpr (MODE == X3_ROW) {
             const int kc = (tid & 3) * 4;
 #pragma unroll
@@ -85,8 +107,15 @@ struct X3Loader {
             src[0] += step; src[1] += step;
         }
     }
-    // split2: two f32 -> packed bf16 pairs of the three pieces (low half = first argument)
-    static __device__ __forceinline__ void split2(float a, float b, unsigned (&o)[3]) {
+    // split2: two f32 -> packed bf16 pairs of the three pieces (low half = first argument); F16: scaled, two f16 pieces
+    static __device__ __forceinline__ void split2(float a, float b, unsigned (&o)[3], float sc = 1.f) {
+        if constexpr (F16) {
+            a *= sc; b *= sc;
+            o[0] = pk_f16(a, b);
+            const f16x2 hv = __builtin_bit_cast(f16x2, o[0]);
+            o[1] = pk_f16(a - (float)hv.x, b - (float)hv.y);
+            return;
+        }
         o[0] = cvt_pk_bf16(a, b);
         if constexpr (NP > 1) {
             const float ra = a - __uint_as_float(o[0] << 16), rb = b - __uint_as_float(o[0] & 0xffff0000u);
@@ -95,15 +124,16 @@ struct X3Loader {
             o[2] = cvt_pk_bf16(sa, sb);
         }
     }
-    static __device__ __forceinline__ void store(const Regs& r, char* __restrict__ S, int tid) {
+    __device__ __forceinline__ void store(const Regs& r, char* __restrict__ S, int tid) const {
+        const float sc = scale;
         const float4 (&v)[2] = r.v;
         const u32x4 (&w)[NP] = r.w;
         if constexpr (MODE == X3_ROW) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 unsigned lo[3], hi[3];
-                split2(v[i].x, v[i].y, lo);
-                split2(v[i].z, v[i].w, hi);
+                split2(v[i].x, v[i].y, lo, sc);
+                split2(v[i].z, v[i].w, hi, sc);
                 char* d = S + ((tid >> 2) + 64 * i) * RM_ROW_BYTES + (tid & 3) * 8;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(d + p * RM_PLANE) = make_uint2(lo[p], hi[p]);
@@ -111,7 +141,7 @@ struct X3Loader {
         } else if constexpr (MODE == X3_KMAJ) {
             // v[0] = k even, v[1] = k odd, four consecutive rows each: pack the pair along k
             unsigned q[4][3];
-            split2(v[0].x, v[1].x, q[0]); split2(v[0].y, v[1].y, q[1]); split2(v[0].z, v[1].z, q[2]); split2(v[0].w, v[1].w, q[3]);
+            split2(v[0].x, v[1].x, q[0], sc); split2(v[0].y, v[1].y, q[1], sc); split2(v[0].z, v[1].z, q[2], sc); split2(v[0].w, v[1].w, q[3], sc);
             char* d = S + ((tid >> 5) * XB + (tid & 31) * 4) * 4;
 #pragma unroll
             for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d + p * KM_PLANE) = u32x4{q[0][p], q[1][p], q[2][p], q[3][p]};
@@ -148,7 +178,7 @@ static __device__ __forceinline__ void store_tile(const X3Args& p, f32x16 (&acc)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                img[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * EP_LD + j * 32 + fr] = acc[i][j][r];
+                img[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * EP_LD + j * 32 + fr] = PREC == 4 ? acc[i][j][r] * p.inv : acc[i][j][r];
     // (each wave reads back only what it wrote: no workgroup barrier needed, the LDS is in order per wave)
     const int c4 = (lane & 15) * 4;
     const int col = n_blk + wn * 64 + c4;
@@ -191,9 +221,10 @@ static __device__ __forceinline__ void store_tile(const X3Args& p, f32x16 (&acc)
 // two K steps ahead of the MFMAs (two register staging sets), the split + LDS store one step ahead (two LDS stages).
 template <int PREC, int A_MODE, int B_MODE>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args p, int n_items, int mt, int nt) {
-    constexpr int NP = PREC == 1 ? 1 : 3;
-    using LA = X3Loader<A_MODE, NP>;
-    using LB = X3Loader<B_MODE, NP>;
+    constexpr int NP = PREC == 1 ? 1 : (PREC == 4 ? 2 : 3);
+    constexpr bool F16 = PREC == 4;
+    using LA = X3Loader<A_MODE, NP, F16>;
+    using LB = X3Loader<B_MODE, NP, F16>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -236,9 +267,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args p, int n_items, 
         nk = (min(p.K, k_begin + p.k_per_split) - k_begin) / XK;
         // B of this column tile: the second operand of a pair behind n_split (workgroup-uniform)
         const bool second = p.n_split > 0 && n_blk >= p.n_split;
-        la.init(p.A, p.lda, p.a_plane, m_blk, p.M, k_begin, tid);
+        la.init(p.A, p.lda, p.a_plane, m_blk, p.M, k_begin, tid, p.sa);
         lb.init(second ? p.B2 : p.B, second ? p.ldb2 : p.ldb, second ? p.b2_plane : p.b_plane, second ? n_blk - p.n_split : n_blk,
-                p.n_split > 0 ? (second ? p.N - p.n_split : p.n_split) : p.N, k_begin, tid);
+                p.n_split > 0 ? (second ? p.N - p.n_split : p.n_split) : p.N, k_begin, tid, p.sb);
         la.load(ra0); lb.load(rb0);
         if (nk > 1) { la.load(ra1); lb.load(rb1); }
     };
@@ -264,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args p, int n_items, 
             }
         };
         if (do_cs) cs_add(ra0);
-        LA::store(ra0, smem, tid); LB::store(rb0, smem + OPER_BYTES, tid);
+        la.store(ra0, smem, tid); lb.store(rb0, smem + OPER_BYTES, tid);
         __syncthreads();
         // one K step: loads of step kt + 2 -> the staging set that step kt just vacated; MFMAs of step kt; split + store of kt + 1
         auto kstep = [&](int kt, typename LA::Regs& ra_cur, typename LB::Regs& rb_cur, const typename LA::Regs& ra_nxt,
@@ -285,13 +316,21 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args p, int n_items, 
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][X], b[j][Y], acc[i][j], 0, 0, 0);
+#define DC_X2H_P(X, Y)                                                                                            \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][X]), __builtin_bit_cast(f16x8, b[j][Y]), acc[i][j], 0, 0, 0);
+            if constexpr (PREC == 4) { DC_X2H_P(1, 1) DC_X2H_P(1, 0) DC_X2H_P(0, 1) DC_X2H_P(0, 0) }
+            else {
             if constexpr (PREC == 6) { DC_X3_P(2, 0) DC_X3_P(0, 2) DC_X3_P(1, 1) DC_X3_P(1, 0) DC_X3_P(0, 1) }
             DC_X3_P(0, 0)
+            }
+#undef DC_X2H_P
 #undef DC_X3_P
             if (kt + 1 < nk) {
                 char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
                 if (do_cs) cs_add(ra_nxt);
-                LA::store(ra_nxt, nxt, tid); LB::store(rb_nxt, nxt + OPER_BYTES, tid);
+                la.store(ra_nxt, nxt, tid); lb.store(rb_nxt, nxt + OPER_BYTES, tid);
             }
             __syncthreads();
         };
@@ -324,8 +363,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args p, int n_items, 
 
 // weights -> bf16 planes, in the orientation the consumer contracts over
 struct SplitJob { const float* src; uint16_t* dst; int rows, cols, ld, transpose, rows_pad; };
-struct SplitJobs { SplitJob j[8]; int n; };
-template <int NP>
+struct SplitJobs { SplitJob j[8]; int n; float scale; };
+template <int NP, bool F16 = false>
 __global__ __launch_bounds__(256) void split_planes_kernel(SplitJobs jobs) {
     const SplitJob jb = jobs.j[blockIdx.y];
     const int n_out_rows = jb.transpose ? jb.cols : jb.rows_pad, n_out_cols = jb.transpose ? jb.rows_pad : jb.cols;
@@ -339,7 +378,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(SplitJobs jobs) {
             x[i] = r < jb.rows ? jb.src[(size_t)r * jb.ld + c] : 0.f;   // rows_pad > rows: zero rows (K padding of dH)
         }
         unsigned o[3];
-        X3Loader<X3_ROW, NP>::split2(x[0], x[1], o);
+        X3Loader<X3_ROW, NP, F16>::split2(x[0], x[1], o, jobs.scale);
 #pragma unroll
         for (int p = 0; p < NP; ++p) *reinterpret_cast<unsigned*>(jb.dst + p * total + e) = o[p];
     }
@@ -387,6 +426,7 @@ int gemm_x3(const X3Gemm& g, hipStream_t stream) {
     a.M = g.M; a.N = g.N; a.K = g.K; a.lda = g.lda; a.ldb = g.ldb; a.ldb2 = g.ldb2; a.ldc = g.ldc; a.ldc2 = g.ldc2; a.ldaux = g.ldaux;
     a.n_split = g.n_split; a.relu = g.relu; a.accumulate = g.accumulate; a.nbias = g.bias ? g.nbias : 0;
     a.a_colsum = g.a_mode == X3_KMAJ ? g.a_colsum : nullptr;
+    a.sa = g.sa; a.sb = g.sb; a.inv = 1.f / (g.sa * g.sb);
     int splits = 1;
     const long tiles = (long)((g.M + XB - 1) / XB) * ((g.N + XB - 1) / XB);
     if (tiles < 256 && g.K >= 4096 && !g.relu && g.aux == nullptr && g.scratch.p != nullptr) {
@@ -405,8 +445,12 @@ int gemm_x3(const X3Gemm& g, hipStream_t stream) {
     const char* name = g.a_mode == X3_KMAJ ? "gemm_f32_dW(TN,split-K)" : (g.transposed_w ? "gemm_f32_dX(NN)" : "gemm_f32_fwd(NT)");
     ProfScope prof(name, 2.0 * g.M * (double)g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N), stream);
     int rc;
-    if (g.a_mode == X3_ROW && g.b_mode == X3_PLANES) rc = g.prec == 1 ? launch_x3<1, X3_ROW, X3_PLANES>(a, splits, stream) : launch_x3<6, X3_ROW, X3_PLANES>(a, splits, stream);
-    else if (g.a_mode == X3_KMAJ && g.b_mode == X3_KMAJ) rc = g.prec == 1 ? launch_x3<1, X3_KMAJ, X3_KMAJ>(a, splits, stream) : launch_x3<6, X3_KMAJ, X3_KMAJ>(a, splits, stream);
+    if (g.a_mode == X3_ROW && g.b_mode == X3_PLANES)
+        rc = g.prec == 1 ? launch_x3<1, X3_ROW, X3_PLANES>(a, splits, stream)
+                         : (g.prec == 4 ? launch_x3<4, X3_ROW, X3_PLANES>(a, splits, stream) : launch_x3<6, X3_ROW, X3_PLANES>(a, splits, stream));
+    else if (g.a_mode == X3_KMAJ && g.b_mode == X3_KMAJ)
+        rc = g.prec == 1 ? launch_x3<1, X3_KMAJ, X3_KMAJ>(a, splits, stream)
+                         : (g.prec == 4 ? launch_x3<4, X3_KMAJ, X3_KMAJ>(a, splits, stream) : launch_x3<6, X3_KMAJ, X3_KMAJ>(a, splits, stream));
     else { set_error("gemm_x3: operand layout combination not built", 1005); return 1005; }
     if (rc == 0 && splits > 1) {
         // C = (C +) sum_z slab[z]; the pair form scatters columns >= n_split into C2
@@ -415,16 +459,17 @@ int gemm_x3(const X3Gemm& g, hipStream_t stream) {
     return rc;
 }
 
-int split_weight_planes(const X3SplitJob* jobs, int n, int prec, hipStream_t s) {
+int split_weight_planes(const X3SplitJob* jobs, int n, int prec, hipStream_t s, float scale) {
     if (n <= 0) return 0;
     if (n > 8) { set_error("split_weight_planes: too many jobs", 1006); return 1006; }
     SplitJobs sj{};
-    sj.n = n;
+    sj.n = n; sj.scale = scale;
     for (int i = 0; i < n; ++i) {
         sj.j[i] = SplitJob{jobs[i].src, jobs[i].dst, jobs[i].rows, jobs[i].cols, jobs[i].ld, jobs[i].transpose,
                            jobs[i].rows_pad > jobs[i].rows ? jobs[i].rows_pad : jobs[i].rows};
     }
     if (prec == 1) hipLaunchKernelGGL(split_planes_kernel<1>, dim3(64, n), dim3(256), 0, s, sj);
+    else if (prec == 4) hipLaunchKernelGGL((split_planes_kernel<2, true>), dim3(64, n), dim3(256), 0, s, sj);
     else hipLaunchKernelGGL(split_planes_kernel<3>, dim3(64, n), dim3(256), 0, s, sj);
     return launch_check("split_weight_planes");
 }

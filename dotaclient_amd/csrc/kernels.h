@@ -81,7 +81,9 @@ struct X3Gemm {
     int M = 0, N = 0, K = 0;
     const float* bias = nullptr; int nbias = 0;                       // bias[col] for col < nbias
     int relu = 0; const float* aux = nullptr; int ldaux = 0;          // zero where aux <= 0
-    int accumulate = 0, prec = 6, transposed_w = 0;
+    int accumulate = 0, prec = 6, transposed_w = 0;     // prec 6: three bf16 pieces, six MFMAs; 4: two f16 pieces, four MFMAs; 1: bf16
+    float sa = 1.f, sb = 1.f;                           // prec 4: power-of-two pre-scales of A / B (an X3_PLANES operand was scaled by sb
+                                                        // when its planes were made); the product is scaled back by 1 / (sa sb)
     GemmScratch scratch;
     float* a_colsum = nullptr;    // X3_KMAJ A only: a_colsum[m] += sum_k A[k][m] (the bias gradient that goes with a weight gradient),
                                   // summed while the tiles pass through the loader - no second pass over A
@@ -90,7 +92,7 @@ bool gemm_x3_shape_ok(int M, int N, int K, int lda, int ldb, int a_mode, int b_m
 int gemm_x3(const X3Gemm& g, hipStream_t stream);
 // weight matrices -> bf16 planes [prec == 1 ? 1 : 3][rows_pad (zero rows past `rows`)][cols], or of the transpose
 struct X3SplitJob { const float* src; uint16_t* dst; int rows, cols, ld, transpose, rows_pad; };
-int split_weight_planes(const X3SplitJob* jobs, int n, int prec, hipStream_t s);
+int split_weight_planes(const X3SplitJob* jobs, int n, int prec, hipStream_t s, float scale = 1.f);   // prec 4: [2] f16 planes of w * scale
 // n_groups (<= 8) independent reductions in one launch: C[g] (dense M x N) = sum of slabs [begin[g], begin[g+1])
 int splitk_reduce_grouped(const float* slab, float* C, int M, int N, int n_groups, const int* begin, hipStream_t s);
 // embed.hip

@@ -7,6 +7,7 @@
 // workspace_layout() below (sizes depend only on dc_dims), so a whole epoch can be replayed as a
 // hipGraph by the caller.
 #include "../../include/dotaclient_hip.h"
+#include <math.h>
 #include <stdlib.h>
 #include "kernels.h"
 
@@ -29,6 +30,17 @@ struct Grads {
 };
 
 static inline int64_t align_up(int64_t x) { return (x + 255) / 256 * 256; }
+
+// DC_DIMS_F16X2 (gemm_x3.hip, PREC = 4): the fixed power-of-two pre-scales of the three kinds of operand.  Activations of this
+// network are O(1) (relu / tanh outputs, unit-variance inputs): 2^4 keeps their second f16 piece normal down to |x| ~ 2^-7 and
+// overflows beyond 4094; weights 2^8 (|w| < 255); gradients of a MEAN loss over `rows` env-steps are O(1 / rows): 2^(ceil(log2
+// rows) + 2) brings them to O(1) (overflow: an entry beyond ~ 16384 / rows).
+static constexpr float F16X2_S_ACT = 16.f, F16X2_S_W = 256.f;
+static inline float f16x2_grad_scale(long long rows) {
+    int e = 0;
+    while ((1LL << e) < rows && e < 40) ++e;
+    return ldexpf(1.f, e + 2);
+}
 
 // The fused embedding kernels work on 128-row tiles of the type-major emb / d(emb) blocks: the blocks are laid out for the row
 // count padded to a multiple of 128 (padding steps re-read the last real step; nobody reads their results, their gradients are
@@ -172,8 +184,9 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
     // (measured, tools/gemm_bench.py at 256 x 256: x W^T / dy W run at 145-150 TF on either kernel - the round-1 tile kernel with
     // its fragments split after the LDS reads needs no pre-pass and is the default there; the split-on-load kernel is 1.5x
     // faster on the weight-gradient products, 94 -> 146-152 TF, and is the only one with the bf16 mode)
-    const bool x3 = ((d->flags & DC_DIMS_BF16) || (d->flags & DC_DIMS_GEMM_X3_ALL)) && !(d->flags & DC_DIMS_GEMM_FASTTILE);
-    const int prec = (d->flags & DC_DIMS_BF16) ? 1 : 6;
+    const bool f16x2 = (d->flags & DC_DIMS_F16X2) && !(d->flags & DC_DIMS_BF16) && !(d->flags & DC_DIMS_GEMM_FASTTILE);
+    const bool x3 = ((d->flags & DC_DIMS_BF16) || (d->flags & DC_DIMS_GEMM_X3_ALL) || f16x2) && !(d->flags & DC_DIMS_GEMM_FASTTILE);
+    const int prec = (d->flags & DC_DIMS_BF16) ? 1 : (f16x2 ? 4 : 6);
     const WPlanes wp = wplanes_of(d, w.base, w.off);
     if (x3) {
         X3SplitJob jobs[2 + DC_MAX_LAYERS];
@@ -184,7 +197,7 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
             const int in = l == 0 ? PREW : H;
             jobs[nj++] = X3SplitJob{P.p(DC_P_RNN0 + 4 * l), wp.fwd(wp.ih[l]), G * H, in, in, 0, G * H};
         }
-        DC_TRY(split_weight_planes(jobs, nj, prec, s));
+        DC_TRY(split_weight_planes(jobs, nj, prec, s, F16X2_S_W));
     }
     // W_hh as bf16 for the recurrence steps; their step-major bf16 state copies (2 x n_seq x 4H) live in the layer's `hn` buffer
     // (rows x H floats, GRU only)
@@ -202,6 +215,7 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
         g.A = x; g.a_mode = X3_ROW; g.lda = K;
         g.B = Wp; g.b_mode = X3_PLANES; g.ldb = K; g.b_plane = (long long)Npad * K;
         g.C = y; g.ldc = ldy; g.M = (int)NR; g.N = Npad; g.K = K; g.bias = bias; g.nbias = N; g.relu = relu; g.prec = prec;
+        g.sa = F16X2_S_ACT; g.sb = F16X2_S_W;
         return gemm_x3(g, s);
     };
     // pre-rnn projection (policy.py:138)
@@ -267,8 +281,10 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
 
     // dense products: split-on-load bf16-plane kernel (gemm_x3.hip) or the round-1 kernel
     const bool x3_tn = !(d->flags & DC_DIMS_GEMM_FASTTILE);                                              // weight gradients
-    const bool x3 = ((d->flags & DC_DIMS_BF16) || (d->flags & DC_DIMS_GEMM_X3_ALL)) && x3_tn;              // input gradients (see policy_forward)
-    const int prec = (d->flags & DC_DIMS_BF16) ? 1 : 6;
+    const bool f16x2 = (d->flags & DC_DIMS_F16X2) && !(d->flags & DC_DIMS_BF16) && x3_tn;
+    const bool x3 = ((d->flags & DC_DIMS_BF16) || (d->flags & DC_DIMS_GEMM_X3_ALL) || f16x2) && x3_tn;    // input gradients (see policy_forward)
+    const int prec = (d->flags & DC_DIMS_BF16) ? 1 : (f16x2 ? 4 : 6);
+    const float s_grad = f16x2_grad_scale(NR);
     const WPlanes wp = wplanes_of(d, w.base, w.off);
     // dx[rows][N] = dy[rows][K] W[K][N] (optionally masked by aux > 0): reads W^T as bf16 planes [N][K]
     auto dgrad = [&](const float* dy, int K, const float* W, const uint16_t* WTp, int N, const float* aux, float* dx) -> int {
@@ -277,6 +293,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         g.A = dy; g.a_mode = X3_ROW; g.lda = K;
         g.B = WTp; g.b_mode = X3_PLANES; g.ldb = K; g.b_plane = (long long)N * K;
         g.C = dx; g.ldc = N; g.M = (int)NR; g.N = N; g.K = K; g.aux = aux; g.ldaux = N; g.prec = prec; g.transposed_w = 1;
+        g.sa = s_grad; g.sb = F16X2_S_W;
         return gemm_x3(g, s);
     };
     // dW[M][N] += dy[rows][lda: M]^T x[rows][ldb: N] (contraction over the env-steps, split-K); optional second x behind N
@@ -291,6 +308,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
             g.A = dy; g.a_mode = X3_KMAJ; g.lda = lda;
             g.B = x1; g.b_mode = X3_KMAJ; g.ldb = N1; g.B2 = x2; g.ldb2 = N2; g.n_split = pair ? N1 : 0;
             g.C = dW1; g.ldc = N1; g.C2 = dW2; g.ldc2 = N2; g.M = M; g.N = N1 + N2; g.K = (int)NR; g.accumulate = 1; g.prec = prec;
+            g.sa = s_grad; g.sb = F16X2_S_ACT;
             g.scratch = sc;
             return gemm_x3(g, s);
         }
@@ -308,7 +326,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
             const int in = l == 0 ? PREW : H;
             jobs[nj++] = X3SplitJob{P.p(DC_P_RNN0 + 4 * l), wp.bwd(wp.ih[l]), G * H, in, in, 1, G * H};  // -> [in][G*H]
         }
-        DC_TRY(split_weight_planes(jobs, nj, prec, s));
+        DC_TRY(split_weight_planes(jobs, nj, prec, s, F16X2_S_W));
     }
     const bool hh_bf = lstm_step_bf16_supported(d->cell, H, d->flags, wp.base) && 4 * (long long)B <= NR;     // W_hh^T as bf16 for the recurrence steps
     if (hh_bf) {

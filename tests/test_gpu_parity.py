@@ -493,3 +493,52 @@ def test_sparse_pool_backward_with_one_unit_taking_every_channel():
         outs[mode] = (eng.grads.cpu().numpy().copy(), res.cpu().numpy().copy())
     assert util.scaled_err(outs['sparse'][0], outs['dense'][0]) < 2e-5
     assert util.scaled_err(outs['sparse'][1][:11], outs['dense'][1][:11]) < 2e-5
+
+
+# ---- DC_DIMS_F16X2: f32-grade products from two f16 pieces and four MFMAs (gemm_x3.hip PREC = 4) -----------------------------------
+@pytest.mark.parametrize('case', util.CASES + util.BIG_CASES)
+def test_f16x2_products_match_reference_golden(case):
+    # the same 1e-4 bar (and bit-exact masked argmax) as the six-MFMA bf16 form, against the REAL reference's fixtures
+    from dotaclient_amd import engine as E
+    g, rollouts = util.load_case(case)
+    out, eng = run_hip(g, rollouts, kernel_flags=E.DC_DIMS_F16X2)
+    compare(out, g, int(g['epochs']), g['param_names'])
+    for ep in range(int(g['epochs'])):
+        assert np.array_equal(out['ep%d_steps' % ep] > 0, g['ep%d_has_grad' % ep])
+
+
+@pytest.mark.parametrize('cell,hidden,B', [('lstm', 256, 256), ('lstm', 128, 64)])
+def test_f16x2_products_match_oracle_at_baseline_configs(cell, hidden, B):
+    from dotaclient_amd import engine as E
+    S = 256
+    g = {'seq_len': S, 'lr': 5e-5, 'entropy_coef': 5e-4, 'vf_coef': 0.5, 'epochs': 1}
+    rollouts = synth.make_rollouts(1000, [S] * B)
+    ref = _oracle_cached((cell, hidden, B), g, rollouts, cell, hidden, 1, 1)
+    out, eng = run_hip(g, rollouts, cell, hidden, 1, epochs=1, kernel_flags=E.DC_DIMS_F16X2)
+    out.pop('hidden', None)
+    compare(out, ref, 1, ref['param_names'])
+    # and it really is another arithmetic than the default's
+    dflt, _ = run_hip(g, rollouts, cell, hidden, 1, epochs=1)
+    assert not np.array_equal(out['values'], dflt['values'])
+
+
+def test_f16x2_out_of_range_operand_trips_the_nan_guard_and_the_bf16_pieces_do_not():
+    # f16 has five exponent bits: an activation beyond 65504 / 2^4 becomes inf in its first piece.  That must surface as the
+    # reference's own NaN guard (status word, nothing updated) - never as a silently wrong step - and the three-bf16-piece form
+    # (f32's exponent range) must handle the same input.
+    from dotaclient_amd import engine as E
+    from dotaclient_amd.engine import Engine, pack_rollouts
+    dev = torch.device('cuda:0')
+    rollouts = synth.make_rollouts(5, [32, 32])
+    rollouts[0]['observations']['env'][3, 1] = 3.0e6          # -> env embedding ~1e5..1e6 in xcat: beyond 4094
+    res = {}
+    for name, flags in (('f16x2', E.DC_DIMS_F16X2), ('bf16x3', 0)):
+        eng = Engine('gru', 256, 1, dev)
+        eng.kernel_flags = flags
+        eng.load_state_dict(synth.init_state_dict(7))
+        before = eng.params.clone()
+        chunks = eng.rollout_pass(pack_rollouts(rollouts, 16, dev), 16)
+        eng.train_epoch(chunks, 5e-5, 5e-4, 0.5)
+        res[name] = (int(eng.status.item()), torch.equal(before, eng.params), bool(torch.isfinite(chunks.values).all()))
+    assert res['bf16x3'][0] == 0 and not res['bf16x3'][1] and res['bf16x3'][2]
+    assert res['f16x2'][0] != 0 and res['f16x2'][1]

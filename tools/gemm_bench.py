@@ -42,12 +42,16 @@ def case(name, M, N, K, a_km, b_km, relu=False, aux=False, bias=False, count=1, 
     ldb = N if b_km else K
     f = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, a_km, b_km, bias=bz, relu=relu, aux=ax, ldaux=N, scratch=SCRATCH)
     ms = t_ms(f)
-    ms3 = err3 = float('nan')
+    ms3 = err3 = ms4 = err4 = float('nan')
     if K % 16 == 0 and N % 4 == 0 and (a_km == b_km or not a_km) and not (a_km and (relu or aux)):
         f3 = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, a_km, b_km, bias=bz, relu=relu, aux=ax, ldaux=N, scratch=SCRATCH, x3=6)
         ms3 = t_ms(f3)
         f3()
         C3 = C.clone()
+        f4 = lambda: ops.gemm(A, B, C, M, N, K, lda, ldb, N, a_km, b_km, bias=bz, relu=relu, aux=ax, ldaux=N, scratch=SCRATCH, x3=4)
+        ms4 = t_ms(f4)
+        f4()
+        C4 = C.clone()
     Am = A[:, :M].t() if a_km else A
     Bm = B if b_km else B.t()
     ref = Am @ Bm
@@ -63,9 +67,14 @@ def case(name, M, N, K, a_km, b_km, relu=False, aux=False, bias=False, count=1, 
     fl = 2.0 * M * N * K
     if ms3 == ms3:
         err3 = ((C3 - ref).abs().max() / ref.abs().max()).item()
-    print('%-22s M=%7d N=%4d K=%7d %s%s  fasttile %8.1f us %6.1f TF | x3 %8.1f us %6.1f TF | rocblas %8.1f us %6.1f TF | x%d  err %.1e / %.1e'
-          % (name, M, N, K, 'T' if a_km else 'N', 'N' if b_km else 'T', ms * 1e3, fl / ms / 1e9, ms3 * 1e3, fl / ms3 / 1e9, ms_ref * 1e3,
-             fl / ms_ref / 1e9, count, err, err3))
+        ref64 = (Am.double() @ Bm.double()) + (bz.double() if bias else 0)
+        if relu: ref64 = ref64.clamp_min(0)
+        if aux: ref64 = torch.where(ax > 0, ref64, torch.zeros_like(ref64))
+        err3 = ((C3.double() - ref64).abs().max() / ref64.abs().max()).item()
+        err4 = ((C4.double() - ref64).abs().max() / ref64.abs().max()).item()
+    print('%-22s M=%7d N=%4d K=%7d %s%s  fasttile %8.1f us %6.1f TF | x3 %8.1f us %6.1f TF | f16x2 %8.1f us %6.1f TF | rocblas %8.1f us %6.1f TF | x%d  err fasttile(vs f32) %.1e, vs f64: x3 %.1e f16x2 %.1e'
+          % (name, M, N, K, 'T' if a_km else 'N', 'N' if b_km else 'T', ms * 1e3, fl / ms / 1e9, ms3 * 1e3, fl / ms3 / 1e9, ms4 * 1e3, fl / ms4 / 1e9, ms_ref * 1e3,
+             fl / ms_ref / 1e9, count, err, err3, err4))
     return (ms3 if ms3 == ms3 else ms) * count
 
 
