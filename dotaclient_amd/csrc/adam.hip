@@ -45,7 +45,7 @@ __device__ __forceinline__ void clip_finalize(const AdamSegs& sg, double* __rest
     for (int s = lane; s < sg.n_seg; s += 64) {
         const int nc = (sg.seg_len[s] + ADAM_CHUNK - 1) / ADAM_CHUNK;
         double sq = 0.0;
-        for (int c = 0; c < nc; ++c) sq += segsq[sg.n_seg + s * nchunk + c];
+        for (int c = 0; c < nc; ++c) sq += __hip_atomic_load(&segsq[sg.n_seg + s * nchunk + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         segsq[s] = sq;                                   // the total, for inspection
         if (!seg_active(sg, s, head_on, vf_coef)) continue;
         const float nrm = (float)sqrt(sq);
@@ -86,9 +86,16 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(AdamSegs sg, const flo
     const int seg = blockIdx.y;
     const long long len = sg.seg_len[seg];
     const long long c0 = (long long)blockIdx.x * ADAM_CHUNK;
+    if (c0 >= len) return;                       // only blocks with a chunk take part (and take a ticket)
     __shared__ double sh[4];
     __shared__ int sh_last;
-    if (c0 < len) {
+    // how many blocks take part: the chunks of all segments (every participating block computes the same number)
+    int my_chunks = 0;
+    for (int s2 = threadIdx.x; s2 < sg.n_seg; s2 += 256) my_chunks += (sg.seg_len[s2] + ADAM_CHUNK - 1) / ADAM_CHUNK;
+    my_chunks = (int)wave_sum((float)my_chunks);
+    __shared__ int sh_cnt[4];
+    if ((threadIdx.x & 63) == 0) sh_cnt[threadIdx.x >> 6] = my_chunks;
+    {
         const float* g = grad + sg.seg_off[seg];
         const long long c1 = min(len, c0 + ADAM_CHUNK);
         double s = 0.0;
@@ -99,19 +106,18 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(AdamSegs sg, const flo
         s = wave_sum(s);
         if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
         __syncthreads();
-        if (threadIdx.x == 0) segsq[sg.n_seg + seg * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-    }
-    // every block of the grid arrives (also the ones past their segment's end): the last one finalises
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned* cnt = reinterpret_cast<unsigned*>(ctl + 2);
-        const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = t == gridDim.x * gridDim.y - 1;
-        if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next call
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        sh_last = last;
+        // hand-off without fences: an 8-byte write-through (sc1) store, drained before the ticket; sc1 loads on the other side
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&segsq[sg.n_seg + seg * gridDim.x + blockIdx.x], (sh[0] + sh[1]) + (sh[2] + sh[3]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned total = (unsigned)(sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3]);
+            unsigned* cnt = reinterpret_cast<unsigned*>(ctl + 2);
+            const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = t == total - 1;
+            if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next call
+            sh_last = last;
+        }
     }
     __syncthreads();
     if (sh_last && threadIdx.x < 64)

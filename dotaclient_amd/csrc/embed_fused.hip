@@ -86,19 +86,23 @@ __device__ __forceinline__ const float* ef_record(const float* __restrict__ obs,
 // ---------------------------------------------------------------------------------------------------
 // BPL: W2 arrives as pre-split bf16 planes W2p [3][6 x 128][128] (split_weight_planes, once per pass) and goes to LDS as such:
 // its fragments need no split in the K loop (half of the loop's VALU work)
-template <bool TIMING, bool BPL>   // TIMING (DC_DEV_TIMING build): s_memtime phase sums of wave 0 of every workgroup -> dbg[wg][4]
+// F16 (DC_DIMS_F16X2, needs BPL): the 128 x 128 layer from two f16 pieces per operand and four MFMAs (gemm_x3.hip, PREC = 4).  W2p then
+// holds [2] f16 planes of W2 * 2^8, and the A operand is generated pre-scaled: basic * s_act = relu(x (W1 s_act)^T + b1 s_act) - exact
+// for a power of two - so neither operand needs a multiply in the K loop; emb = acc * inv + b2.
+template <bool TIMING, bool BPL, bool F16 = false>   // TIMING (DC_DEV_TIMING build): s_memtime phase sums of wave 0 of every workgroup -> dbg[wg][4]
 __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __restrict__ obs, const float* __restrict__ W1,
                                                                  const float* __restrict__ b1, const float* __restrict__ W2,
                                                                  const uint16_t* __restrict__ W2p,
                                                                  const float* __restrict__ b2, float* __restrict__ emb,
                                                                  float* __restrict__ xcat, uint8_t* __restrict__ amax,
-                                                                 EmbTypes ty, int n_tiles, long long* __restrict__ dbg) {
+                                                                 EmbTypes ty, int n_tiles, long long* __restrict__ dbg, float s_act, float inv) {
+    static_assert(!F16 || BPL, "the f16 pieces need the pre-split weight planes");
     long long tm_k = 0, tm_e = 0, tm_b = 0, tm0 = 0, tm_start = 0;
     if constexpr (TIMING) tm_start = __builtin_amdgcn_s_memtime();
     using LT = FastTile<128, false>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    using PT = PlaneTile<128>;
-    float* stage = smem;               // 2 x (A [128][32] f32 | B [128][32] f32, or three bf16 planes of it)
+    using PT = PlaneTile<128, F16 ? 2 : 3>;
+    float* stage = smem;               // 2 x (A [128][32] f32 | B [128][32] f32, or three bf16 / two f16 planes of it)
     constexpr int STAGE_FL = 4096 + (BPL ? PT::LDS_FLOATS : 4096);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -117,8 +121,8 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-        for (int kk = 0; kk < 6; ++kk) wb[kt][kk] = W1[(32 * kt + fr) * 12 + 2 * kk + fq];
-        b1v[kt] = b1[32 * kt + fr];
+        for (int kk = 0; kk < 6; ++kk) wb[kt][kk] = W1[(32 * kt + fr) * 12 + 2 * kk + fq] * (F16 ? s_act : 1.f);
+        b1v[kt] = b1[32 * kt + fr] * (F16 ? s_act : 1.f);
     }
     int aoff[16];   // LDS float index of D register r inside an A stage (row-major [128][32], 16-byte chunks XOR-swizzled)
 #pragma unroll
@@ -196,7 +200,8 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
                 issue_b(t1, 0, nxt + 4096);
                 gen_a(std::integral_constant<int, 0>{}, xn, nxt);
             }
-            if constexpr (BPL) mma_kstep_bplanes<LT, 128, 2, 2>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc);
+            if constexpr (F16) mma_kstep_bplanes_h<LT, 128, 2, 2, false>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc, 1.f);
+            else if constexpr (BPL) mma_kstep_bplanes<LT, 128, 2, 2>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc);
             else mma_kstep<LT, LT, 2, 2>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc);
             __syncthreads();
         }
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
                 float v[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    v[r] = acc[i][j][r] + bv;
+                    v[r] = (F16 ? acc[i][j][r] * inv : acc[i][j][r]) + bv;
                     tr[(8 * (r >> 2) + 4 * fq + (r & 3)) * 64 + j * 32 + fr] = v[r];
                 }
                 if (xcat == nullptr) continue;
@@ -289,9 +294,10 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
 // (k-major), B = basic generated k-major: thread (channel c, row half) with W1[c] in registers and the
 // unit records read through wave-uniform addresses.
 // ---------------------------------------------------------------------------------------------------
+template <bool F16>     // F16: A = d(emb) scaled by s_grad at the split, B = basic generated pre-scaled by s_act (through W1, b1), slab = acc * inv
 __global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restrict__ obs, const float* __restrict__ demb,
                                                             const float* __restrict__ W1, const float* __restrict__ b1,
-                                                            float* __restrict__ slab, EmbTypes ty) {
+                                                            float* __restrict__ slab, EmbTypes ty, float s_grad, float s_act, float inv) {
     using LT = FastTile<128, true>;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x (A [32][128] | B [32][128])
     constexpr int STAGE_FL = 2 * 4096;
@@ -314,8 +320,8 @@ __global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restr
     // (each wave its own copy - 1.5 KB per step).
     float wb[6];
 #pragma unroll
-    for (int kk = 0; kk < 6; ++kk) wb[kk] = W1[(32 * wave + fr) * 12 + 2 * kk + fq];
-    const float b1v = b1[32 * wave + fr];
+    for (int kk = 0; kk < 6; ++kk) wb[kk] = W1[(32 * wave + fr) * 12 + 2 * kk + fq] * (F16 ? s_act : 1.f);
+    const float b1v = b1[32 * wave + fr] * (F16 ? s_act : 1.f);
     int boff[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) boff[r] = (8 * (r >> 2) + 4 * fq + (r & 3)) * 128 + 32 * wave + fr;
@@ -365,7 +371,8 @@ __global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restr
             LT::issue(ga + (size_t)(s + 1) * GEMM_BK * EF_EMB, offa, nxt, wave);
             gen_b(xnext, nxt + 4096);
         }
-        mma_kstep<LT, LT, 2, 2>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc);
+        if constexpr (F16) mma_kstep_h<LT, LT, 2, 2, true, false>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc, s_grad, 1.f);
+        else mma_kstep<LT, LT, 2, 2>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc);
         __syncthreads();
     };
     for (int s = 0; s < ns; s += 2) {
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restr
         for (int j = 0; j < 2; ++j) {
             float* c = out + (size_t)(wm * 64 + i * 32 + 4 * fq) * EF_EMB + wn * 64 + j * 32 + fr;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c[(size_t)((r & 3) + 8 * (r >> 2)) * EF_EMB] = acc[i][j][r];
+            for (int r = 0; r < 16; ++r) c[(size_t)((r & 3) + 8 * (r >> 2)) * EF_EMB] = F16 ? acc[i][j][r] * inv : acc[i][j][r];
         }
 }
 
@@ -390,10 +397,11 @@ __global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restr
 // dW1[c][f] += g x[f], db1[c] += g in registers across tiles.  Output: partials[workgroup][13][128]
 // (12 features + bias), summed by unit_basic_reduce (embed.hip).
 // ---------------------------------------------------------------------------------------------------
+template <bool F16>     // F16: A = d(emb) scaled by s_grad, B = W2 (f32 tile) scaled by s_w, both at the split; d(basic) = acc * inv
 __global__ __launch_bounds__(256, 2) void embed_bwd_dw1_kernel(const float* __restrict__ obs, const float* __restrict__ demb,
                                                             const float* __restrict__ W1, const float* __restrict__ b1,
                                                             const float* __restrict__ W2, float* __restrict__ partials,
-                                                            EmbTypes ty, int n_tiles) {
+                                                            EmbTypes ty, int n_tiles, float s_grad, float s_w, float inv) {
     using LA = FastTile<128, false>;
     using LB = FastTile<128, true>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -453,7 +461,8 @@ __global__ __launch_bounds__(256, 2) void embed_bwd_dw1_kernel(const float* __re
                 LA::issue(ga + (kt + 1) * GEMM_BK, offa, nxt, wave);
                 LB::issue(gb + (size_t)(kt + 1) * GEMM_BK * EF_EMB, offb, nxt + 4096, wave);
             }
-            mma_kstep<LA, LB, 2, 2>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc);
+            if constexpr (F16) mma_kstep_h<LA, LB, 2, 2, true, true>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc, s_grad, s_w);
+            else mma_kstep<LA, LB, 2, 2>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc);
             __syncthreads();
         }
         // epilogue: rows of this lane = wm*64 + i*32 + 4*fq + (r&3) + 8*(r>>2)
@@ -481,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void embed_bwd_dw1_kernel(const float* __re
                 const float x[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const float g = (bs[j][r] + bias[j]) > 0.f ? acc[i][j][r] : 0.f;
+                    const float g = (bs[j][r] + bias[j]) > 0.f ? (F16 ? acc[i][j][r] * inv : acc[i][j][r]) : 0.f;
 #pragma unroll
                     for (int f = 0; f < 12; ++f) dw[j][f] = fmaf(g, x[f], dw[j][f]);
                     db[j] += g;
@@ -550,13 +559,15 @@ static int set_lds(K kernel, size_t bytes, bool* done) {
 }
 
 int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const float* W2, const uint16_t* W2p, const float* b2, float* emb,
-                    float* xcat, uint8_t* amax, long long nr_valid, long long nr, hipStream_t s) {
+                    float* xcat, uint8_t* amax, long long nr_valid, long long nr, hipStream_t s, F16x2Scales f16) {
     int nwg;
     const EmbTypes ty = make_types(nr, nr_valid, &nwg);
     const bool bpl = W2p != nullptr;
-    const size_t lds = (size_t)(2 * (4096 + (bpl ? PlaneTile<128>::LDS_FLOATS : 4096))) * sizeof(float);
-    static bool attr = false, attr_p = false;
-    if (bpl) { if (int e = set_lds(embed_fwd_fused_kernel<false, true>, lds, &attr_p)) return e; }
+    const bool h = f16.on && bpl;
+    const size_t lds = (size_t)(2 * (4096 + (bpl ? (h ? PlaneTile<128, 2>::LDS_FLOATS : PlaneTile<128>::LDS_FLOATS) : 4096))) * sizeof(float);
+    static bool attr = false, attr_p = false, attr_h = false;
+    if (h) { if (int e = set_lds(embed_fwd_fused_kernel<false, true, true>, lds, &attr_h)) return e; }
+    else if (bpl) { if (int e = set_lds(embed_fwd_fused_kernel<false, true>, lds, &attr_p)) return e; }
     else if (int e = set_lds(embed_fwd_fused_kernel<false, false>, lds, &attr)) return e;
     const int tiles = (int)(nr * 40 / EF_TILE);
     const int grid = tiles < 512 ? tiles : 512;      // two resident workgroups per CU
@@ -568,7 +579,7 @@ int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const fl
         static long long* dbg = nullptr;
         if (!dbg) (void)hipMalloc(&dbg, 512 * 4 * sizeof(long long));
         hipLaunchKernelGGL((embed_fwd_fused_kernel<true, false>), dim3(grid), dim3(256), (size_t)(4 * 4096) * sizeof(float), s, obs, W1, b1, W2,
-                           (const uint16_t*)nullptr, b2, emb, xcat, amax, ty, tiles, dbg);
+                           (const uint16_t*)nullptr, b2, emb, xcat, amax, ty, tiles, dbg, 1.f, 1.f);
         long long h[512 * 4];
         (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
         double ph[4] = {0, 0, 0, 0};
@@ -578,10 +589,12 @@ int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const fl
                 grid, ph[0] / tiles, ph[1] / tiles, ph[2] / tiles, ph[3] / grid, tiles / grid);
         return launch_check("embed_fwd_fused");
     }
-    if (bpl) hipLaunchKernelGGL((embed_fwd_fused_kernel<false, true>), dim3(grid), dim3(256), lds, s, obs, W1, b1, W2, W2p, b2, emb, xcat, amax, ty,
-                                tiles, (long long*)nullptr);
+    if (h) hipLaunchKernelGGL((embed_fwd_fused_kernel<false, true, true>), dim3(grid), dim3(256), lds, s, obs, W1, b1, W2, W2p, b2, emb, xcat, amax, ty,
+                              tiles, (long long*)nullptr, f16.s_act, 1.f / (f16.s_act * f16.s_w));
+    else if (bpl) hipLaunchKernelGGL((embed_fwd_fused_kernel<false, true>), dim3(grid), dim3(256), lds, s, obs, W1, b1, W2, W2p, b2, emb, xcat, amax, ty,
+                                tiles, (long long*)nullptr, 1.f, 1.f);
     else hipLaunchKernelGGL((embed_fwd_fused_kernel<false, false>), dim3(grid), dim3(256), lds, s, obs, W1, b1, W2, W2p, b2, emb, xcat, amax, ty,
-                            tiles, (long long*)nullptr);
+                            tiles, (long long*)nullptr, 1.f, 1.f);
     return launch_check("embed_fwd_fused");
 }
 
@@ -593,7 +606,7 @@ int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const fl
 // scratch: >= (dense + sparse workgroups) * 16384 + sparse partials floats
 int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const float* b1, const float* W2, float* dW2,
                     float* dW1, float* db1, float* scratch, long long scratch_floats, long long nr_valid, long long nr,
-                    const EmbSparseIn* sp, hipStream_t s) {
+                    const EmbSparseIn* sp, hipStream_t s, F16x2Scales f16) {
     int nwg;
     const bool sparse16 = sp != nullptr;
     const EmbTypes ty = make_types(nr, nr_valid, &nwg, sparse16);
@@ -611,27 +624,31 @@ int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const 
     }
     {
         const size_t lds = (size_t)(4 * 4096) * sizeof(float);
-        static bool attr = false;
-        if (int e = set_lds(embed_bwd_dw2_kernel, lds, &attr)) return e;
+        static bool attr = false, attr_h = false;
+        if (int e = f16.on ? set_lds(embed_bwd_dw2_kernel<true>, lds, &attr_h) : set_lds(embed_bwd_dw2_kernel<false>, lds, &attr)) return e;
         {
             const double units = sparse16 ? 8 : 40;
             ProfScope prof("embed_bwd_dw2", 2.0 * nr * units * 128 * (128 + 12), 4.0 * nr * units * (12 + 128), s);
-            hipLaunchKernelGGL(embed_bwd_dw2_kernel, dim3(nwg), dim3(256), lds, s, obs, demb, W1, b1, scratch, ty);
+            if (f16.on) hipLaunchKernelGGL(embed_bwd_dw2_kernel<true>, dim3(nwg), dim3(256), lds, s, obs, demb, W1, b1, scratch, ty, f16.s_grad, f16.s_act,
+                                           1.f / (f16.s_grad * f16.s_act));
+            else hipLaunchKernelGGL(embed_bwd_dw2_kernel<false>, dim3(nwg), dim3(256), lds, s, obs, demb, W1, b1, scratch, ty, 1.f, 1.f, 1.f);
         }
         if (int e = launch_check("embed_bwd_dw2")) return e;
         if (int e = splitk_reduce_grouped(scratch, dW2, EF_EMB, EF_EMB, 6, ty.wg_begin, s)) return e;   // one launch, six types
     }
     {
         const size_t lds = (size_t)(1536 + 4 * 4096) * sizeof(float);
-        static bool attr = false;
-        if (int e = set_lds(embed_bwd_dw1_kernel, lds, &attr)) return e;
+        static bool attr = false, attr_h = false;
+        if (int e = f16.on ? set_lds(embed_bwd_dw1_kernel<true>, lds, &attr_h) : set_lds(embed_bwd_dw1_kernel<false>, lds, &attr)) return e;
         const int tiles = (int)(nr * 40 / EF_TILE);
         const int dense_tiles = sparse16 ? tiles - (ty.tile_begin[4] - ty.tile_begin[2]) : tiles;
         const int grid = dense_tiles < 512 ? dense_tiles : 512;
         {
             const double units = sparse16 ? 8 : 40;
             ProfScope prof("embed_bwd_dw1", 2.0 * nr * units * 128 * (128 + 24), 4.0 * nr * units * (12 + 128), s);
-            hipLaunchKernelGGL(embed_bwd_dw1_kernel, dim3(grid), dim3(256), lds, s, obs, demb, W1, b1, W2, scratch, ty, tiles);
+            if (f16.on) hipLaunchKernelGGL(embed_bwd_dw1_kernel<true>, dim3(grid), dim3(256), lds, s, obs, demb, W1, b1, W2, scratch, ty, tiles, f16.s_grad,
+                                           f16.s_w, 1.f / (f16.s_grad * f16.s_w));
+            else hipLaunchKernelGGL(embed_bwd_dw1_kernel<false>, dim3(grid), dim3(256), lds, s, obs, demb, W1, b1, W2, scratch, ty, tiles, 1.f, 1.f, 1.f);
         }
         if (int e = launch_check("embed_bwd_dw1")) return e;
         // one launch: dW1/db1 from the dense and the sparse partials, db2 of types 2, 3 from the sparse bias partials

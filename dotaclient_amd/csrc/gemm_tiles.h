@@ -159,11 +159,11 @@ __device__ __forceinline__ void mma_kstep(const float* __restrict__ a_s, const f
 // SOURCE side with (row >> 2) & 3: the 16 rows of every ds_read_b128 lane group then hit 16 different 16-byte bank groups.
 // Its fragments need no VALU work at all.
 // ---------------------------------------------------------------------------------------------------
-template <int BR>
+template <int BR, int NPL = 3>     // NPL planes: 3 bf16 pieces, or 2 f16 pieces (mma_kstep_bplanes_h)
 struct PlaneTile {
     static constexpr int PLANE_FLOATS = BR * 16;            // BR x 32 bf16
-    static constexpr int LDS_FLOATS = 3 * PLANE_FLOATS;
-    static constexpr int NI = 3 * BR / 16 / 4;              // DMA pieces per wave per K step (4 waves): 6 at BR = 128
+    static constexpr int LDS_FLOATS = NPL * PLANE_FLOATS;
+    static constexpr int NI = NPL * BR / 16 / 4;            // DMA pieces per wave per K step (4 waves): 6 at BR = 128, 3 planes
     // per-lane source offsets (bf16 elements, relative to plane 0 at k = k_base) of this wave's pieces
     static __device__ __forceinline__ void src_offsets(size_t (&off)[NI], int ld, long long plane_elems, int r_base, int wave, int lane) {
 #pragma unroll
@@ -213,6 +213,86 @@ __device__ __forceinline__ void mma_kstep_bplanes(const float* __restrict__ a_s,
                 acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].X, Y[jn], acc[i][jn], 0, 0, 0);
         DC_MMA_Q(l, bh) DC_MMA_Q(h, bl) DC_MMA_Q(m, bm) DC_MMA_Q(m, bh) DC_MMA_Q(h, bm) DC_MMA_Q(h, bh)
 #undef DC_MMA_Q
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same products from TWO f16 pieces per operand and FOUR MFMAs (DC_DIMS_F16X2; rationale, accuracy and exponent-range
+// caveat: gemm_x3.hip, PREC = 4).  x * s = h + m (+ l, dropped) with h = f16(x s), m = f16(x s - h); s: the operand's power-of-two
+// pre-scale (1 when the producer already applied it); the caller scales the accumulators back by 1 / (sa sb).
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {      // {f16(hi), f16(lo)}, round to nearest even
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, f16x2_t));
+}
+struct Split2h { f16x8 h, m; };
+template <bool SCALE>
+__device__ __forceinline__ Split2h split2h(const float4& x0, const float4& x1, float s) {
+    float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    if constexpr (SCALE) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] *= s;
+    }
+    unsigned h[4], m[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = cvt_pk_f16(x[2 * i], x[2 * i + 1]);
+        const f16x2_t hv = __builtin_bit_cast(f16x2_t, h[i]);
+        m[i] = cvt_pk_f16(x[2 * i] - (float)hv.x, x[2 * i + 1] - (float)hv.y);
+    }
+    Split2h r;
+    r.h = __builtin_bit_cast(f16x8, u32x4{h[0], h[1], h[2], h[3]});
+    r.m = __builtin_bit_cast(f16x8, u32x4{m[0], m[1], m[2], m[3]});
+    return r;
+}
+
+// mma_kstep with f16 pieces: same fragment reads and k permutation, four MFMAs per (row tile, column tile), smallest term first
+template <class LA, class LB, int TM, int TN, bool SCALE_A, bool SCALE_B>
+__device__ __forceinline__ void mma_kstep_h(const float* __restrict__ a_s, const float* __restrict__ b_s, int a_row0, int b_row0,
+                                            int fr, int fq, f32x16 (&acc)[TM][TN], float sa, float sb) {
+#pragma unroll
+    for (int s = 0; s < GEMM_BK / 16; ++s) {
+        Split2h a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            a[i] = split2h<SCALE_A>(LA::frag(a_s, a_row0 + i * 32 + fr, 2 * s, fq), LA::frag(a_s, a_row0 + i * 32 + fr, 2 * s + 1, fq), sa);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+            b[i] = split2h<SCALE_B>(LB::frag(b_s, b_row0 + i * 32 + fr, 2 * s, fq), LB::frag(b_s, b_row0 + i * 32 + fr, 2 * s + 1, fq), sb);
+#define DC_MMA_H(X, Y)                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                          \
+            _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                                   \
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i].X, b[jn].Y, acc[i][jn], 0, 0, 0);
+        DC_MMA_H(m, m) DC_MMA_H(m, h) DC_MMA_H(h, m) DC_MMA_H(h, h)
+#undef DC_MMA_H
+    }
+}
+
+// mma_kstep_bplanes with f16 pieces: A image f32 (split after the fragment reads, scale sa), B two pre-scaled f16 planes
+template <class LA, int BRB, int TM, int TN, bool SCALE_A>
+__device__ __forceinline__ void mma_kstep_bplanes_h(const float* __restrict__ a_s, const float* __restrict__ b_s, int a_row0, int b_row0,
+                                                    int fr, int fq, f32x16 (&acc)[TM][TN], float sa) {
+    using LB = PlaneTile<BRB, 2>;
+#pragma unroll
+    for (int s = 0; s < GEMM_BK / 16; ++s) {
+        Split2h a[TM];
+        f16x8 bh[TN], bm[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            a[i] = split2h<SCALE_A>(LA::frag(a_s, a_row0 + i * 32 + fr, 2 * s + fq, 0), LA::frag(a_s, a_row0 + i * 32 + fr, 2 * s + fq, 1), sa);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bh[j] = __builtin_bit_cast(f16x8, LB::frag(b_s, b_row0 + j * 32 + fr, s, fq, 0));
+            bm[j] = __builtin_bit_cast(f16x8, LB::frag(b_s, b_row0 + j * 32 + fr, s, fq, 1));
+        }
+#define DC_MMA_HQ(X, Y)                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                          \
+            _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                                   \
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i].X, Y[jn], acc[i][jn], 0, 0, 0);
+        DC_MMA_HQ(m, bm) DC_MMA_HQ(m, bh) DC_MMA_HQ(h, bm) DC_MMA_HQ(h, bh)
+#undef DC_MMA_HQ
     }
 }
 

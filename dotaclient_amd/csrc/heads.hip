@@ -24,7 +24,7 @@ enum { ST_ADV_SUM = 0, ST_ADV_SQ = 1, ST_NSEL = 2 /*5*/, ST_POL = 7 /*5*/, ST_EN
 // for inspection), [ST_PART1, +ST_G1 * 8) batch_stats_kernel's per-block partial sums, [ST_PART2, +ST_G2 * 12) ppo_loss_kernel's,
 // [ST_TICKET] a 32-bit arrival counter.  Per-block partials summed in a fixed order instead of f64 atomics on eleven words:
 // 4 096 blocks x 11 same-address atomics serialised at one L2 channel (the kernel's tail), and made the sums order-dependent.
-enum { ST_G1 = 256, ST_G2 = 2048, ST_PART1 = 64, ST_PART2 = ST_PART1 + ST_G1 * 8, ST_TICKET = ST_PART2 + ST_G2 * 12, ST_DOUBLES = ST_TICKET + 8 };
+enum { ST_G1 = 256, ST_G2 = 1024, ST_PART1 = 64, ST_PART2 = ST_PART1 + ST_G1 * 8, ST_TICKET = ST_PART2 + ST_G2 * 12, ST_DOUBLES = ST_TICKET + 8 };
 
 // ---------------------------------------------------------------------------------------------------
 // target-unit logits: tu[n][u] = sum_c q[n][c] * emb[n][u][c];  16 lanes per unit, 4 units per wave pass
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
         const bool many = ((cnt >> (6 * kk)) & 63) != 0;
         if (!many) Hrow[kk] = 0.f;
         gent[kk] = (nselv[kk] > 0.f && p.entropy_coef > 0.f) ? (float)((double)p.entropy_coef / (double)nselv[kk]) : 0.f;
-        if (on && j == 0 && nselv[kk] > 0.f && many) ent[kk] = (double)Hrow[kk];
+        if (on && j == 0 && nselv[kk] > 0.f && many) ent[kk] += (double)Hrow[kk];
     }
     // d loss / d logit_c = g_lp * (delta_{c,a} - [mask_c] p_c) + g_ent * [mask_c] p_c (logp_c + Hrow)
 #pragma unroll
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
         const double N = (double)p.nr;
         const float v = ho[HO_VALUE];
         const float d = p.ret[n] - v;
-        val = (double)d * (double)d;
+        val += (double)d * (double)d;
         // value_loss = vf_coef * 0.5 * mean((R - V)^2)  (optimizer.py:658-661)
         p.dheadout[n * HO_LD + HO_VALUE] = (p.vf_coef > 0.f) ? (float)((double)p.vf_coef * (double)(v - p.ret[n]) / N) : 0.f;
 #pragma unroll
@@ -442,15 +442,18 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
     const double vs = wave_sum(val);
     if (lane == 0) sh[wave][10] = vs;
     __syncthreads();
-    if (threadIdx.x < 11)
-        p.stats[ST_PART2 + blockIdx.x * 12 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
-    // the last block to arrive sums all rows (fixed order) and finalises the losses: release our row, take a ticket, acquire
+    // The last block to arrive sums all rows (fixed order) and finalises the losses.  Hand-off without fences (an agent-scope release
+    // writes back every dirty line of the XCD's L2 - here the d(headout) rows the whole chip has just written - once per block):
+    // the row goes out as 8-byte write-through (sc1) stores, drained (vmcnt(0)) before the ticket is taken; the last block
+    // reads the rows with sc1 loads (MI355X_MICROARCH.md: "8-B agent atomics both sides").
+    if (threadIdx.x < 11) {
+        __hip_atomic_store(&p.stats[ST_PART2 + blockIdx.x * 12 + threadIdx.x],
+                           sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned t = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(p.stats + ST_TICKET), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         sh_last = t == gridDim.x - 1;
     }
     __syncthreads();
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
         double v[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int b = threadIdx.x; b < (int)gridDim.x; b += 256)
 #pragma unroll
-            for (int q = 0; q < 11; ++q) v[q] += p.stats[ST_PART2 + b * 12 + q];
+            for (int q = 0; q < 11; ++q) v[q] += __hip_atomic_load(&p.stats[ST_PART2 + b * 12 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int q = 0; q < 11; ++q) {
             const double r = wave_sum(v[q]);

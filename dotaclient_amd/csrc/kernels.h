@@ -115,14 +115,17 @@ bool embed_fused_supported(long long nr_padded);
 // xcat/amax != nullptr: the max-pools of the one-unit and 16-unit types are produced by the epilogue (then call
 // pool_env_fwd with residual = 1 for the env embedding and the 5-unit type only)
 // W2p != nullptr: W2 also as pre-split bf16 planes [3][6 x 128][128] (split_weight_planes): no fragment split for that operand
+// F16x2Scales (DC_DIMS_F16X2): the 128 x 128 layer and its two backward products from two f16 pieces per operand and four MFMAs; the
+// power-of-two pre-scales of activations, weights, gradients (policy.hip).  W2p then holds [2] f16 planes of W2 * s_w.
+struct F16x2Scales { bool on = false; float s_act = 1.f, s_w = 1.f, s_grad = 1.f; };
 int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const float* W2, const uint16_t* W2p, const float* b2, float* emb,
-                    float* xcat, uint8_t* amax, long long nr_valid, long long nr_padded, hipStream_t s);
+                    float* xcat, uint8_t* amax, long long nr_valid, long long nr_padded, hipStream_t s, F16x2Scales f16 = F16x2Scales());
 // inputs of the sparse max-pool backward of the two 16-unit types (embed_sparse.hip); db2 [6][128] is accumulated into
 // (prep: 2 * nr * 736 floats of scratch - it lives in the d(emb) rows of the two types, which the sparse path never writes)
 struct EmbSparseIn { const float* dxcat; const uint8_t* amax; const float* dtu; const float* q; int ldq; float* db2; float* prep; };
 int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const float* b1, const float* W2, float* dW2,
                     float* dW1, float* db1, float* scratch, long long scratch_floats, long long nr_valid, long long nr_padded,
-                    const EmbSparseIn* sp, hipStream_t s);
+                    const EmbSparseIn* sp, hipStream_t s, F16x2Scales f16 = F16x2Scales());
 // embed_sparse.hip
 int embed_bwd_pool16(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq,
                      const float* W1, const float* b1, const float* W2, float* slab, float* part1, float* part2, float* prep,

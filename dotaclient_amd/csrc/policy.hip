@@ -96,7 +96,7 @@ int64_t workspace_layout(const dc_dims* d, int64_t* out) {
     put(DC_WS_DTU, NR * 40 * 4);
     put(DC_WS_DPRE, NR * PREW * 4);
     put(DC_WS_DXCAT, NR * XCATW * 4);
-    put(DC_WS_STATS, 64 * 8 + 256 * 8 * 8 + 2048 * 12 * 8 + 64);   // totals + per-block partial sums of the two loss kernels + arrival counter (heads.hip: ST_*)
+    put(DC_WS_STATS, 64 * 8 + 256 * 8 * 8 + 1024 * 12 * 8 + 64);   // totals + per-block partial sums of the two loss kernels + arrival counter (heads.hip: ST_*)
     put(DC_WS_WHHT, H * G * H * 4);
     put(DC_WS_SCRATCH, (int64_t)DC_SCRATCH_FLOATS * 4);   // two-stage reductions / split-K slabs
     put(DC_WS_HEADW_PAD, (int64_t)HO_LD * H * 4);          // head weights zero-padded to 160 rows (K of dH)
@@ -162,12 +162,15 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
         // W2 of the six unit types as bf16 planes (one tiny pre-pass): the fused kernel's weight operand then needs no split
         const WPlanes wpe = wplanes_of(d, w.base, w.off);
         const bool bpl = !(d->flags & DC_DIMS_GEMM_FASTTILE);
+        const bool eh = (d->flags & DC_DIMS_F16X2) && bpl;        // (the embedding MLP stays f32-grade in bf16 mode, so it may take the f16 pieces there too)
         if (bpl) {
             X3SplitJob job{P.p(DC_P_UNIT_W), wpe.fwd(wpe.unit), 6 * EMBW, EMBW, EMBW, 0, 6 * EMBW};
-            DC_TRY(split_weight_planes(&job, 1, 6, s));
+            DC_TRY(split_weight_planes(&job, 1, eh ? 4 : 6, s, F16X2_S_W));
         }
+        F16x2Scales fs;
+        fs.on = eh; fs.s_act = F16X2_S_ACT; fs.s_w = F16X2_S_W;
         DC_TRY(embed_fwd_fused(obs, P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), P.p(DC_P_UNIT_W), bpl ? wpe.fwd(wpe.unit) : nullptr, P.p(DC_P_UNIT_B),
-                               w.f(DC_WS_EMB), w.f(DC_WS_XCAT), amax, NR, NRp, s));
+                               w.f(DC_WS_EMB), w.f(DC_WS_XCAT), amax, NR, NRp, s, fs));
     } else {
         DC_TRY(unit_basic_fwd(obs, P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), w.f(DC_WS_BASIC), NR, s));
         for (int t = 0; t < 6; ++t) {
@@ -409,9 +412,12 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         // step, never written on that path; the prepared blocks take 2 * 736)
         const EmbSparseIn sp{w.f(DC_WS_DXCAT), amaxp, w.f(DC_WS_DTU), w.f(DC_WS_HEADOUT), HO_LD, Gd.p(DC_P_UNIT_B),
                              w.f(DC_WS_DEMB) + (size_t)NRp * T_CUM[2] * EMBW};
+        F16x2Scales fs;
+        fs.on = (d->flags & DC_DIMS_F16X2) && !(d->flags & DC_DIMS_GEMM_FASTTILE);
+        fs.s_act = F16X2_S_ACT; fs.s_w = F16X2_S_W; fs.s_grad = s_grad;
         DC_TRY(embed_bwd_fused(obs, w.f(DC_WS_DEMB), P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), P.p(DC_P_UNIT_W), Gd.p(DC_P_UNIT_W),
                                Gd.p(DC_P_BASIC_W), Gd.p(DC_P_BASIC_B), w.f(DC_WS_SCRATCH), DC_SCRATCH_FLOATS, NR, NRp,
-                               sparse16 ? &sp : nullptr, s));
+                               sparse16 ? &sp : nullptr, s, fs));
     } else {
         for (int t = 0; t < 6; ++t) {
             const size_t ro = (size_t)NR * T_CUM[t] * EMBW;
