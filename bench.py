@@ -50,6 +50,9 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f
 # f32-grade products by exact 3-way bf16 splitting execute SIX bf16 MFMAs per f32 product (gemm_tiles.h): the matrix pipes'
 # ceiling for ALGORITHMIC f32 flops on that path
 PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+# ... and with TWO f16 pieces per operand (Engine.products 'f16x2', the default: csrc/gemm_x3.hip PREC = 4) FOUR f16 MFMAs (same rate as bf16)
+PEAK_X2H_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 4.0
+PRODUCTS = 'f16x2'        # --products
 PEAK_HBM_GBS = 8000.0
 
 
@@ -94,7 +97,9 @@ def pmc_traffic(path, kernel, workload_key):
     region_kernels = {'gru_fwd_team': ['team_mfma_fwd', 'rnn_team_fwd'], 'gru_bwd_team': ['team_mfma_bwd', 'rnn_team_bwd'],
                       'lstm_fwd_team': ['team_mfma_fwd', 'rnn_team_fwd'], 'lstm_bwd_team': ['team_mfma_bwd', 'rnn_team_bwd'],
                       'lstm_fwd_persist': ['lstm_fwd_valu'], 'lstm_bwd_persist': ['lstm_bwd_valu'],
-                      'gemm_f32_dW': ['gemm_x3'], 'gemm_f32_fwd': ['gemm_fast'], 'gemm_f32_dX': ['gemm_fast']}
+                      'gemm_f32_dW': ['gemm_x3'], 'gemm_f32_fwd': ['gemm_fast', 'gemm_x3'], 'gemm_f32_dX': ['gemm_fast', 'gemm_x3']}
+    if PRODUCTS == 'f16x2':       # every dense product runs the split-on-load kernel then (one PMC row: the average over its launches)
+        region_kernels['gemm_f32_fwd'] = region_kernels['gemm_f32_dX'] = ['gemm_x3', 'gemm_fast']
     for cand in region_kernels.get(kernel, [kernel]):
         k = j.get('kernels', {}).get(cand + '_kernel')
         if k:
@@ -257,14 +262,15 @@ def parity_report(got, ref, tol=1e-4, argmax_min_equal=None, sub_batch=None):
 # (K = 12 of the 12 + 128, resp. 24 of 24 + 128 flops per output) with f32 MFMAs and run the 128 x 128 layer as x3 products:
 # time-weighted harmonic peak.
 def _mixed_peak(f32_share):
-    return 1.0 / (f32_share / PEAK_F32_MFMA_TFLOPS + (1.0 - f32_share) / PEAK_X3_TFLOPS)
+    grade = PEAK_X2H_TFLOPS if PRODUCTS == 'f16x2' else PEAK_X3_TFLOPS
+    return 1.0 / (f32_share / PEAK_F32_MFMA_TFLOPS + (1.0 - f32_share) / grade)
 
 
 def mfma_peak(region, prec_bf16):
     if prec_bf16 and region.startswith('gemm_'):
         return PEAK_BF16_MFMA_TFLOPS
     return {'embed_fwd_fused': _mixed_peak(12.0 / 140.0), 'embed_bwd_dw2': _mixed_peak(12.0 / 140.0),
-            'embed_bwd_dw1': _mixed_peak(24.0 / 152.0)}.get(region, PEAK_X3_TFLOPS)
+            'embed_bwd_dw1': _mixed_peak(24.0 / 152.0)}.get(region, PEAK_X2H_TFLOPS if PRODUCTS == 'f16x2' else PEAK_X3_TFLOPS)
 
 
 def latency_peak(region, prec_bf16, hidden):
@@ -286,11 +292,12 @@ REGION_BOUND = {
     'gae_scan': 'hbm', 'select_logp': 'hbm', 'attn_logits': 'hbm', 'attn_bwd_q': 'hbm', 'colsum': 'hbm',
 }
 BOUND_NOTES = {
-    'mfma': 'f32-grade products on the bf16 matrix cores: every f32 operand is split exactly into three bf16 pieces and a product is six '
-            'v_mfma_f32_32x32x16_bf16 (gemm_tiles.h / gemm_x3.hip); `achieved` = ALGORITHMIC f32 flops / time, `peak` = the dense bf16 '
-            'MFMA peak / 6 = 416.7 TF (less for the embedding kernels, whose K = 12 first layer is regenerated with f32 MFMAs), so '
-            '`frac` is the share of the matrix pipes\' capacity on this path; `frac_of_f32_mfma_peak` prices the same rate against the '
-            '157.3 TF of the f32-input MFMA the products would otherwise run on',
+    'mfma': 'f32-grade products on the 16-bit matrix cores: every f32 operand is split into two f16 pieces (x 2^s = h + m, 23 of the 24 '
+            'significand bits; fixed power-of-two pre-scales) and a product is four v_mfma_f32_32x32x16_f16 (Engine.products f16x2, the '
+            'default; gemm_x3.hip PREC 4) - or into three bf16 pieces and six MFMAs (--products bf16x3); `achieved` = ALGORITHMIC f32 '
+            'flops / time, `peak` = the dense 16-bit MFMA peak / 4 = 625 TF (/ 6 = 416.7 TF for bf16x3; less for the embedding kernels, '
+            'whose K = 12 first layer is regenerated with f32 MFMAs), so `frac` is the share of the matrix pipes\' capacity on this path; '
+            '`frac_of_f32_mfma_peak` prices the same rate against the 157.3 TF of the f32-input MFMA the products would otherwise run on',
     'valu': 'packed-f32 VALU kernel (per-channel-scaled gathers of 512-byte W2 / basic rows; 1/16 of the dense MACs): priced against '
             'the f32 VALU peak, which equals the f32 MFMA peak (157.3 TF at 2.4 GHz); what limits it is VALU issue and LDS '
             'bandwidth at 2 waves/SIMD, not the matrix pipes',
@@ -311,6 +318,7 @@ def run_workload(cell, hidden, layers, B, S, E, steps, warmup, dev, rank, world,
     lr, ent, vf = 5e-5, 5e-4, 0.5
     eng = Engine(cell, hidden, layers, dev)
     eng.kernel_flags = KERNEL_FLAGS
+    eng.products = PRODUCTS
     eng.use_graphs = USE_GRAPHS
     eng.reuse_rollout_forward = REUSE_FORWARD
     eng.load_state_dict(synth.init_state_dict(7, cell, hidden, layers))
@@ -391,6 +399,8 @@ def parse_args():
     ap.add_argument('--extras-only', action='store_true', help='(what --extras runs in the subprocess) print only the side measurements')
     ap.add_argument('--extras-out', default=os.path.join(REPO, 'gpurun_out', 'bench_extras.json'))
     ap.add_argument('--kernel-flags', type=int, default=0, help='DC_DIMS_* kernel-selection overrides (A/B measurements)')
+    ap.add_argument('--products', default='f16x2', choices=['f16x2', 'bf16x3'],
+                    help='form of the f32-grade products (Engine.products): two f16 pieces / four MFMAs (default) or three bf16 pieces / six MFMAs')
     ap.add_argument('--epoch-graph', type=int, default=0, help='1: replay each epoch as ONE hipGraph launch (single GPU), 0: eager launches')
     ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'pmc_traffic_latest.json'),
                     help='per-kernel HBM bytes from the rocprofv3 PMC passes (tools/gpu_round.sh + tools/pmc_traffic.py); '
@@ -440,8 +450,9 @@ def self_launch(args):
 
 def main():
     args = parse_args()
-    global KERNEL_FLAGS, USE_GRAPHS, REUSE_FORWARD
+    global KERNEL_FLAGS, USE_GRAPHS, REUSE_FORWARD, PRODUCTS
     KERNEL_FLAGS = args.kernel_flags
+    PRODUCTS = args.products
     USE_GRAPHS = args.epoch_graph == 1
 
     if args.gpus < 1:
@@ -594,15 +605,20 @@ def main():
             'dtype': 'bf16' if KERNEL_FLAGS & 4096 else 'f32',
             'dtype_note': 'DC_DIMS_BF16: bf16 operands / f32 accumulate in the dense products and the recurrent products, f32 elsewhere' if KERNEL_FLAGS & 4096 else
                           'f32 end to end: inputs, weights, activations, gradients and optimizer state are f32 and every product is f32-grade '
-                          '(matrix products: exact 3-way bf16 splits of both f32 operands, six bf16 MFMAs, f32 accumulate - error vs f64 '
-                          '1.4e-7..5.5e-7 of max |C| on the network\'s shapes, the f32 fma chain 2.1e-7..3.7e-7; tools/ubench/gemm_x3.hip); '
-                          '`parity` checks the whole step against the fp32 oracle at 1e-4',
+                          '(matrix products, products=%s: %s; measured against f64 on the network\'s shapes: f16x2 1.2e-7..4.9e-7, bf16x3 1.4e-7..5.5e-7 of '
+                          'max |C|, the f32 fma chain 2.1e-7..3.7e-7 - tools/ubench/gemm_x3.hip, profiles/r04/ubench_gemm_f16_pieces.txt); '
+                          '`parity` checks the whole step against the fp32 oracle at 1e-4'
+                          % (PRODUCTS, 'two f16 pieces per f32 operand (23 of 24 significand bits) with power-of-two pre-scales, four f16 MFMAs, f32 '
+                                       'accumulate; an operand outside f16\'s exponent range trips the NaN guard and the consumer loop repeats the '
+                                       'iteration with the bf16 pieces' if PRODUCTS == 'f16x2' else
+                                       'exact 3-way bf16 splits of both f32 operands, six bf16 MFMAs, f32 accumulate'),
             'data': 'synthetic',
             'config': {'workload': '%s: synthetic trajectories, %s hidden=%d x%d layer, '
                                    'batch=%d trajectories x %d steps per GPU, %d epochs + rollout pass per step'
                                    % (which, args.cell.upper(), args.hidden, args.layers, B, S, E),
                        'cell': args.cell, 'hidden': args.hidden, 'layers': args.layers, 'batch_per_gpu': B,
-                       'seq_len': S, 'epochs': E, 'parallelism': 'dp%d' % world, 'epoch_launch': 'hipGraph replay' if USE_GRAPHS else 'eager'},
+                       'seq_len': S, 'epochs': E, 'parallelism': 'dp%d' % world, 'epoch_launch': 'hipGraph replay' if USE_GRAPHS else 'eager',
+                       'products': PRODUCTS},
             'phases': {'rollout_pass_ms': round(rollout_ms, 3), 'epoch_ms': round(epochs_ms / E, 3),
                        'train_only_env_steps_per_s_per_gpu': round(B * S / (epochs_ms / E * 1e-3), 1),
                        'note': 'one untimed iteration on rank 0: no-grad forward + old log-probs + GAE, then the mean of the %d '
@@ -641,6 +657,7 @@ def main():
                 sub = rollouts[:nsub]
                 eng2 = Engine(args.cell, args.hidden, args.layers, dev)
                 eng2.kernel_flags = KERNEL_FLAGS
+                eng2.products = PRODUCTS
                 eng2.load_state_dict(synth.init_state_dict(7, args.cell, args.hidden, args.layers))
                 got = hip_parity_iteration(eng2, pack_rollouts(sub, S, dev), S, E, lr, ent, vf)
                 st2 = int(eng2.status.item())
@@ -671,7 +688,7 @@ def run_extras_subprocess(args):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), '--extras-only', '--steps', str(args.steps), '--warmup', str(args.warmup),
            '--cell', args.cell, '--hidden', str(args.hidden), '--layers', str(args.layers), '--batch', str(args.batch),
-           '--seq-len', str(args.seq_len), '--epochs', str(args.epochs), '--kernel-flags', str(args.kernel_flags)]
+           '--seq-len', str(args.seq_len), '--epochs', str(args.epochs), '--kernel-flags', str(args.kernel_flags), '--products', args.products]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         out = (r.stdout.strip().splitlines() or [''])[-1]

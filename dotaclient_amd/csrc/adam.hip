@@ -37,18 +37,14 @@ __device__ __forceinline__ bool seg_active(const AdamSegs& sg, int seg, const in
 // The norms: every (segment, 4096-element chunk) block leaves its partial sum of squares in segsq[n_seg + seg * nchunk + chunk] - no
 // clear launch, no same-address atomics, a fixed summation order - and the LAST block to arrive (release / ticket / acquire) does
 // what used to be a launch of its own: per-segment norms in the reference's order, clip coefficient, the two NaN guards, step counters.
-__device__ __forceinline__ void clip_finalize(const AdamSegs& sg, double* __restrict__ segsq, int nchunk, const int32_t* __restrict__ head_on,
+__device__ __forceinline__ void clip_finalize(const AdamSegs& sg, const double* __restrict__ seg_tot, const int32_t* __restrict__ head_on,
                                               const float* __restrict__ losses, float* __restrict__ norms_out, float* __restrict__ ctl,
                                               int32_t* __restrict__ seg_step, int32_t* __restrict__ status, float max_norm, float vf_coef,
                                               int lane) {
     double sum_norm = 0.0, tot_sq = 0.0, n_act = 0.0;
     for (int s = lane; s < sg.n_seg; s += 64) {
-        const int nc = (sg.seg_len[s] + ADAM_CHUNK - 1) / ADAM_CHUNK;
-        double sq = 0.0;
-        for (int c = 0; c < nc; ++c) sq += __hip_atomic_load(&segsq[sg.n_seg + s * nchunk + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        segsq[s] = sq;                                   // the total, for inspection
         if (!seg_active(sg, s, head_on, vf_coef)) continue;
-        const float nrm = (float)sqrt(sq);
+        const float nrm = (float)sqrt(seg_tot[s]);
         sum_norm += (double)nrm;
         tot_sq += (double)nrm * (double)nrm;
         n_act += 1.0;
@@ -120,8 +116,22 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(AdamSegs sg, const flo
         }
     }
     __syncthreads();
-    if (sh_last && threadIdx.x < 64)
-        clip_finalize(sg, segsq, (int)gridDim.x, head_on, losses, norms_out, ctl, seg_step, status, max_norm, vf_coef, threadIdx.x);
+    if (!sh_last) return;
+    // the last block: per-segment totals - wave w takes segments w, w + 4, ...; lane c the partial of chunk c (+ 64, ...), all loads of a
+    // segment in flight together (one lane summing a segment's 64 partials one after the other is 64 dependent L2 round trips), then the
+    // fixed wave butterfly - into segsq[0 .. n_seg), then one wave finalises from there
+    {
+        const int nchunk = (int)gridDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int s2 = wave; s2 < sg.n_seg; s2 += 4) {
+            const int nc = (sg.seg_len[s2] + ADAM_CHUNK - 1) / ADAM_CHUNK;
+            double sq = 0.0;
+            for (int c = lane; c < nc; c += 64) sq += __hip_atomic_load(&segsq[sg.n_seg + s2 * nchunk + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sq = wave_sum(sq);
+            if (lane == 0) segsq[s2] = sq;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) clip_finalize(sg, segsq, head_on, losses, norms_out, ctl, seg_step, status, max_norm, vf_coef, threadIdx.x);
 }
 
 __global__ __launch_bounds__(256) void adam_update_kernel(AdamSegs sg, float* __restrict__ param, float* __restrict__ grad,

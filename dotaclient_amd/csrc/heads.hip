@@ -304,11 +304,16 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
             sh_norm[1] = (float)(sqrt(var) + (double)p.adv_eps);
         }
     }
+    if (threadIdx.x < 44) (&sh[0][0])[threadIdx.x] = 0.0;
     __syncthreads();
     const int j = threadIdx.x & 15;
-    double pol[5] = {0, 0, 0, 0, 0}, ent[5] = {0, 0, 0, 0, 0}, val = 0.0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long groups = (p.nr + 15) / 16;
-    for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {      // persistent blocks: one set of partial sums per block
+#pragma unroll 1
+    for (int grp_i = blockIdx.x; grp_i < (int)groups; grp_i += gridDim.x) {      // persistent blocks: one set of partial sums per block
+    const long long grp = __builtin_amdgcn_readfirstlane(grp_i);
+    double pol[5] = {0, 0, 0, 0, 0}, ent[5] = {0, 0, 0, 0, 0}, val = 0.0;   // this group's terms; the running sums live in LDS (sh[wave][..]:
+                                                                            // carried in registers across the loop they cost 60 VGPRs and a spill)
     const long long n = grp * 16 + (threadIdx.x >> 4);
     const bool on = n < p.nr;
     const long long nn = on ? n : p.nr - 1;     // idle rows of the last group recompute a valid step and store nothing
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
         const bool many = ((cnt >> (6 * kk)) & 63) != 0;
         if (!many) Hrow[kk] = 0.f;
         gent[kk] = (nselv[kk] > 0.f && p.entropy_coef > 0.f) ? (float)((double)p.entropy_coef / (double)nselv[kk]) : 0.f;
-        if (on && j == 0 && nselv[kk] > 0.f && many) ent[kk] += (double)Hrow[kk];
+        if (on && j == 0 && nselv[kk] > 0.f && many) ent[kk] = (double)Hrow[kk];
     }
     // d loss / d logit_c = g_lp * (delta_{c,a} - [mask_c] p_c) + g_ent * [mask_c] p_c (logp_c + Hrow)
 #pragma unroll
@@ -424,23 +429,22 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
         const double N = (double)p.nr;
         const float v = ho[HO_VALUE];
         const float d = p.ret[n] - v;
-        val += (double)d * (double)d;
+        val = (double)d * (double)d;
         // value_loss = vf_coef * 0.5 * mean((R - V)^2)  (optimizer.py:658-661)
         p.dheadout[n * HO_LD + HO_VALUE] = (p.vf_coef > 0.f) ? (float)((double)p.vf_coef * (double)(v - p.ret[n]) / N) : 0.f;
 #pragma unroll
         for (int c = HO_VALUE + 1; c < HO_LD; ++c) p.dheadout[n * HO_LD + c] = 0.f;
     }
-    }   // groups of this block
-    // block reduction: 5 policy sums + 5 entropy sums + value sum -> this block's row of partial sums
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // this group's 5 policy sums + 5 entropy sums + value sum -> the wave's running sums (lane 0 owns sh[wave][..])
 #pragma unroll
     for (int kk = 0; kk < 5; ++kk) {
         const double a = wave_sum(pol[kk]);
         const double b = wave_sum(ent[kk]);
-        if (lane == 0) { sh[wave][kk] = a; sh[wave][5 + kk] = b; }
+        if (lane == 0) { sh[wave][kk] += a; sh[wave][5 + kk] += b; }
     }
     const double vs = wave_sum(val);
-    if (lane == 0) sh[wave][10] = vs;
+    if (lane == 0) sh[wave][10] += vs;
+    }   // groups of this block
     __syncthreads();
     // The last block to arrive sums all rows (fixed order) and finalises the losses.  Hand-off without fences (an agent-scope release
     // writes back every dirty line of the XCD's L2 - here the d(headout) rows the whole chip has just written - once per block):

@@ -440,6 +440,11 @@ class Engine:
         self._ws_off = None
         self._ws_dims_key = None
         self.kernel_flags = 0          # DC_DIMS_* overrides OR-ed into every call's dims (0 = the library picks by shape)
+        # f32-grade products: 'f16x2' (default) = two f16 pieces per operand, four MFMAs, fixed power-of-two pre-scales (DC_DIMS_F16X2);
+        # 'bf16x3' = three bf16 pieces, six MFMAs (f32's exponent range).  An operand outside f16's range (activation > 4094, gradient
+        # entry > ~16384 / rows) turns the f16x2 loss NaN, the update is skipped on the device (sticky status word) and the caller
+        # falls back: use_safe_products() and a repeat of the iteration (DotaOptimizer does that by itself).
+        self.products = os.environ.get('DC_PRODUCTS', 'f16x2')
         self.use_graphs = os.environ.get('DC_EPOCH_GRAPH', '0') == '1'   # default of train_epoch(graph=None)
         # The first epoch of an iteration runs the policy on the weights the rollout pass has just used (optimizer.py:328-430 then
         # :581-689): the same function of the same inputs, whose activations are still in the workspace.  True: that epoch's forward
@@ -514,7 +519,18 @@ class Engine:
         """lazy_tu: DC_DIMS_LAZY_TU - the target-unit logits are produced by select_logp / loss for the unmasked
         units only (the optimizer's passes); False gives DC_WS_TU for every unit (Policy.forward)."""
         return DcDims(CELL_ID[self.cell], self.hidden, self.layers, batch.n_seq, batch.max_len,
-                      (DC_DIMS_LAZY_TU if lazy_tu else 0) | self.kernel_flags, batch.rows)
+                      (DC_DIMS_LAZY_TU if lazy_tu else 0) | self.kernel_flags | (DC_DIMS_F16X2 if self.products == 'f16x2' else 0), batch.rows)
+
+    def use_safe_products(self):
+        """Switches to the three-bf16-piece products (f32's exponent range) for good and clears the sticky status word: the caller repeats
+        what the NaN guard stopped (no parameter was touched).  Returns False if the engine was on them already."""
+        if self.products != 'f16x2':
+            return False
+        self.products = 'bf16x3'
+        self.status.zero_()
+        self._ws_holds = None
+        self._graphs.clear()
+        return True
 
     def _workspace(self, d):
         n = len(WS_FIXED) + len(WS_LAYER) * self.layers
@@ -556,7 +572,7 @@ class Engine:
         d = self.dims(batch, lazy_tu)
         ws = self._workspace(d)
         # what the workspace's activations are a function of (Engine.reuse_rollout_forward compares it)
-        self._ws_holds = (batch.rows, batch.obs.data_ptr(), self._param_version, bool(lazy_tu), self.kernel_flags)
+        self._ws_holds = (batch.rows, batch.obs.data_ptr(), self._param_version, bool(lazy_tu), self.kernel_flags, self.products)
         hT = cT = None
         if want_final:
             hT = device_empty((self.layers, batch.n_seq, self.hidden), torch.float32, self.device)
@@ -652,7 +668,7 @@ class Engine:
 
     def _train_epoch_eager(self, chunks, lr, entropy_coef, vf_coef, e_clip, grad_hook):
         if (self.reuse_rollout_forward and self._ws is not None
-                and self._ws_holds == (chunks.rows, chunks.obs.data_ptr(), self._param_version, True, self.kernel_flags)):
+                and self._ws_holds == (chunks.rows, chunks.obs.data_ptr(), self._param_version, True, self.kernel_flags, self.products)):
             # same rows, same weights: the rollout pass's activations are what this forward would write (a chunk's initial state is
             # the state the rollout pass carried into its first row)
             d = self.dims(chunks, True)
@@ -685,7 +701,7 @@ class Engine:
         ptr = lambda t: 0 if t is None else t.data_ptr()
         key = (ptr(chunks.obs), ptr(chunks.act), ptr(chunks.mask), ptr(chunks.old_logp), ptr(chunks.adv), ptr(chunks.ret),
                ptr(chunks.h0), ptr(chunks.c0), ptr(chunks.seq_off), ptr(chunks.seq_len), chunks.n_seq, chunks.rows,
-               chunks.max_len, float(lr), float(entropy_coef), float(vf_coef), float(e_clip), self.kernel_flags,
+               chunks.max_len, float(lr), float(entropy_coef), float(vf_coef), float(e_clip), self.kernel_flags, self.products,
                ptr(self._ws), ptr(self.grads))
         ent = self._graphs.get(key)
         if ent is None:

@@ -305,6 +305,14 @@ class DotaOptimizer:
                                               e_clip=self.e_clip, grad_hook=self.grad_hook)
         host = torch.cat([out[:11], status.to(torch.float32)]).cpu()      # the one sync of the epoch
         st = int(host[11].item())
+        if st != 0 and self.engine.use_safe_products():
+            # f16x2 products and a NaN: possibly an operand outside f16's range - repeat the epoch with the bf16x3 products
+            # (nothing was updated; the experiences' old log-probs / values are what experiences_from_rollout computed)
+            logger.warning('train: NaN with the f16x2 products - repeating the epoch with the bf16x3 products; they stay on from here')
+            out, status = self.engine.train_epoch(chunks, self.learning_rate, self.entropy_coef, self.vf_coef,
+                                                  e_clip=self.e_clip, grad_hook=self.grad_hook)
+            host = torch.cat([out[:11], status.to(torch.float32)]).cpu()
+            st = int(host[11].item())
         if st != 0:
             msg = describe_fault(self.engine)
             self.engine.status.zero_()                                      # sticky on the device (csrc/adam.hip): the caller clears it
@@ -347,6 +355,7 @@ class DotaOptimizer:
         batch = self._packer.finish()                                       # the rollout pass waits on the batch's `ready` event
         self._acc = self._new_gather()
         assert len(acc['rollouts']) == len(batch.host_lens), 'gather state and packed batch disagree'
+        acc['batch'] = batch                                                # kept for a repeat of the iteration (_retry_with_safe_products)
         experiences, chunks = self._experiences_from_batch(acc['rollouts'], batch)
         return acc, experiences, chunks
 
@@ -433,6 +442,23 @@ class DotaOptimizer:
                 self._ready = self._finish_batch()
         hist_done.synchronize()                                             # the one synchronisation of the iteration
         host = host.clone()
+        if int(host[:, 11].max().item()) != 0 and self.engine.products == 'f16x2':
+            # A NaN with the two-f16-piece products may be an operand outside f16's exponent range (Engine.products).  Nothing was
+            # updated (the status word is sticky on the device): switch to the three-bf16-piece products for good and repeat this
+            # iteration - rollout pass and epochs - on the same batch.  If it is NaN again, it is the data: raise like the reference.
+            logger.warning('iteration %d: NaN with the f16x2 products - repeating it with the bf16x3 products (f32 exponent range); '
+                           'they stay on from here', it)
+            self.engine.use_safe_products()
+            self._drop_ready()
+            experiences, chunks = self._experiences_from_batch(acc['rollouts'], acc['batch'])
+            for ep in range(self.epochs):
+                out, status = self.engine.train_epoch(chunks, self.learning_rate, self.entropy_coef, self.vf_coef,
+                                                      e_clip=self.e_clip, grad_hook=self.grad_hook)
+                hist[ep, :11].copy_(out[:11])
+                hist[ep, 11:].copy_(status)
+            if self.checkpoint:
+                self._snapshot = self.engine.start_param_snapshot()
+            host = hist.cpu()
         losses, entropies, grad_norms = [], [], []
         for ep in range(self.epochs):
             row = host[ep]

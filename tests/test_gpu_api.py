@@ -359,3 +359,28 @@ def test_mq_is_built_like_the_reference_when_none_is_passed(tmp_path, monkeypatc
         DotaOptimizer(**kw)
     with pytest.raises(ValueError, match='run_local'):
         DotaOptimizer(**dict(kw, run_local=False))
+
+
+def test_consumer_loop_falls_back_to_the_bf16_pieces_when_an_operand_leaves_the_f16_range(tmp_path):
+    # Engine.products: the default two-f16-piece products cannot represent an activation beyond 4094 (DC_DIMS_F16X2); the loss turns
+    # NaN, the device skips every update (sticky status), and run_iteration repeats the iteration with the three-bf16-piece products
+    # (f32's exponent range), which stay on from there.  The reference handles such an input without a hiccup - so must the drop-in.
+    g, _ = util.load_case('ragged_s16')
+    stream = synth.make_rollouts(31, [40, 64, 21, 33, 50, 16, 64, 48, 17, 80, 30, 64])
+    stream[2]['observations']['env'][5, 1] = 3.0e6
+    opt = make_opt([dict(r) for r in stream], g, tmp_path)
+    opt.min_seq_per_epoch = 9
+    assert opt.engine.products == 'f16x2'
+    before = opt.engine.params.clone()
+    m = opt.run_iteration(1)
+    assert opt.engine.products == 'bf16x3' and int(opt.engine.status.item()) == 0
+    assert np.isfinite(float(m['loss/sum'])) and not torch.equal(before, opt.engine.params)
+    # the same stream through an optimizer that was on the safe products from the start: same result
+    ref = make_opt([dict(r) for r in stream], g, tmp_path)
+    ref.engine.products = 'bf16x3'
+    ref.min_seq_per_epoch = 9
+    mr = ref.run_iteration(1)
+    assert abs(float(m['loss/sum']) - float(mr['loss/sum'])) <= 1e-6 * max(1.0, abs(float(mr['loss/sum'])))
+    assert torch.allclose(opt.engine.params, ref.engine.params, rtol=0, atol=1e-7)
+    m2 = opt.run_iteration(2)                       # and the loop carries on
+    assert np.isfinite(float(m2['loss/sum']))

@@ -12,12 +12,14 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4          # BASELINE.json north_star: losses/advantages within 1e-4 relative
 
 
-def run_hip(g, rollouts, cell='gru', hidden=256, layers=1, epochs=None, kernel_flags=0, reuse_forward=False):
+def run_hip(g, rollouts, cell='gru', hidden=256, layers=1, epochs=None, kernel_flags=0, reuse_forward=False, products=None):
     from dotaclient_amd.engine import Engine, pack_rollouts
     dev = torch.device('cuda:0')
     eng = Engine(cell, hidden, layers, dev)
     eng.kernel_flags = kernel_flags
     eng.reuse_rollout_forward = reuse_forward
+    if products is not None:
+        eng.products = products          # None: the engine's default ('f16x2')
     eng.load_state_dict(synth.init_state_dict(7, cell, hidden, layers))
     S = int(g['seq_len'])
     batch = pack_rollouts(rollouts, S, dev)
@@ -495,26 +497,26 @@ def test_sparse_pool_backward_with_one_unit_taking_every_channel():
     assert util.scaled_err(outs['sparse'][1][:11], outs['dense'][1][:11]) < 2e-5
 
 
-# ---- DC_DIMS_F16X2: f32-grade products from two f16 pieces and four MFMAs (gemm_x3.hip PREC = 4) -----------------------------------
+# ---- the two forms of f32-grade products: 'f16x2' (Engine default: two f16 pieces, four MFMAs, DC_DIMS_F16X2) is what every test above
+# ran; 'bf16x3' (three bf16 pieces, six MFMAs: f32's exponent range, the fallback) must meet the same bars ----------------------------------
 @pytest.mark.parametrize('case', util.CASES + util.BIG_CASES)
-def test_f16x2_products_match_reference_golden(case):
-    # the same 1e-4 bar (and bit-exact masked argmax) as the six-MFMA bf16 form, against the REAL reference's fixtures
-    from dotaclient_amd import engine as E
+def test_bf16x3_products_match_reference_golden(case):
+    from dotaclient_amd.engine import Engine
+    assert Engine('gru', 256, 1, torch.device('cuda:0')).products == 'f16x2'       # the default the other tests exercise
     g, rollouts = util.load_case(case)
-    out, eng = run_hip(g, rollouts, kernel_flags=E.DC_DIMS_F16X2)
+    out, eng = run_hip(g, rollouts, products='bf16x3')
     compare(out, g, int(g['epochs']), g['param_names'])
     for ep in range(int(g['epochs'])):
         assert np.array_equal(out['ep%d_steps' % ep] > 0, g['ep%d_has_grad' % ep])
 
 
 @pytest.mark.parametrize('cell,hidden,B', [('lstm', 256, 256), ('lstm', 128, 64)])
-def test_f16x2_products_match_oracle_at_baseline_configs(cell, hidden, B):
-    from dotaclient_amd import engine as E
+def test_bf16x3_products_match_oracle_at_baseline_configs(cell, hidden, B):
     S = 256
     g = {'seq_len': S, 'lr': 5e-5, 'entropy_coef': 5e-4, 'vf_coef': 0.5, 'epochs': 1}
     rollouts = synth.make_rollouts(1000, [S] * B)
     ref = _oracle_cached((cell, hidden, B), g, rollouts, cell, hidden, 1, 1)
-    out, eng = run_hip(g, rollouts, cell, hidden, 1, epochs=1, kernel_flags=E.DC_DIMS_F16X2)
+    out, eng = run_hip(g, rollouts, cell, hidden, 1, epochs=1, products='bf16x3')
     out.pop('hidden', None)
     compare(out, ref, 1, ref['param_names'])
     # and it really is another arithmetic than the default's
@@ -525,20 +527,25 @@ def test_f16x2_products_match_oracle_at_baseline_configs(cell, hidden, B):
 def test_f16x2_out_of_range_operand_trips_the_nan_guard_and_the_bf16_pieces_do_not():
     # f16 has five exponent bits: an activation beyond 65504 / 2^4 becomes inf in its first piece.  That must surface as the
     # reference's own NaN guard (status word, nothing updated) - never as a silently wrong step - and the three-bf16-piece form
-    # (f32's exponent range) must handle the same input.
-    from dotaclient_amd import engine as E
+    # (f32's exponent range) must handle the same input; Engine.use_safe_products() is the switch the consumer loop throws.
     from dotaclient_amd.engine import Engine, pack_rollouts
     dev = torch.device('cuda:0')
     rollouts = synth.make_rollouts(5, [32, 32])
     rollouts[0]['observations']['env'][3, 1] = 3.0e6          # -> env embedding ~1e5..1e6 in xcat: beyond 4094
     res = {}
-    for name, flags in (('f16x2', E.DC_DIMS_F16X2), ('bf16x3', 0)):
+    for name in ('f16x2', 'bf16x3'):
         eng = Engine('gru', 256, 1, dev)
-        eng.kernel_flags = flags
+        eng.products = name
         eng.load_state_dict(synth.init_state_dict(7))
         before = eng.params.clone()
         chunks = eng.rollout_pass(pack_rollouts(rollouts, 16, dev), 16)
         eng.train_epoch(chunks, 5e-5, 5e-4, 0.5)
         res[name] = (int(eng.status.item()), torch.equal(before, eng.params), bool(torch.isfinite(chunks.values).all()))
+        if name == 'f16x2':      # the fallback: same engine, safe products, the iteration repeated - now it steps
+            assert eng.use_safe_products() and eng.products == 'bf16x3' and int(eng.status.item()) == 0
+            chunks = eng.rollout_pass(pack_rollouts(rollouts, 16, dev), 16)
+            eng.train_epoch(chunks, 5e-5, 5e-4, 0.5)
+            assert int(eng.status.item()) == 0 and not torch.equal(before, eng.params)
+            assert not eng.use_safe_products()
     assert res['bf16x3'][0] == 0 and not res['bf16x3'][1] and res['bf16x3'][2]
     assert res['f16x2'][0] != 0 and res['f16x2'][1]
