@@ -32,7 +32,7 @@ SIGNATURES = {
     'dc_profile_enable': (c_int, [c_int]),
     'dc_profile_report': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int]),
     'dc_workspace_layout': (c_i64, [c_ptr, c_ptr]),
-    'dc_policy_forward': (c_int, [c_ptr] * 12),
+    'dc_policy_forward': (c_int, [c_ptr] * 13),
     'dc_chunk_initial_state': (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr]),
     'dc_select_logp': (c_int, [c_ptr] * 8),
     'dc_ppo_loss_fwd_bwd': (c_int, [c_ptr] * 9 + [c_flt, c_flt, c_flt, c_ptr]),

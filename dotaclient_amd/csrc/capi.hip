@@ -25,7 +25,7 @@ int launch_check(const char* what) {
 int64_t workspace_layout(const dc_dims* d, int64_t* out);
 long long emb_rows_of(const dc_dims* d);   // rows per unit of the type-major emb blocks (policy.hip)
 int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, const float* obs, const float* h0,
-                   const float* c0, const int64_t* seq_off, const int32_t* seq_len, void* ws_base, float* hT, float* cT,
+                   const float* c0, const int64_t* seq_off, const int32_t* seq_len, void* ws_base, float* hT, float* cT, const uint8_t* unit_mask,
                    hipStream_t s);
 int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, float* grads, int64_t total_floats,
                     const float* obs, const int64_t* seq_off, const int32_t* seq_len, void* ws_base, hipStream_t s);
@@ -96,9 +96,9 @@ int64_t dc_workspace_layout(const dc_dims* dims, int64_t* offsets) { return dc::
 
 int dc_policy_forward(const dc_dims* dims, const float* params, const int64_t* poff_host, const float* obs,
                       const float* h0, const float* c0, const int64_t* seq_off, const int32_t* seq_len, void* ws,
-                      float* hT, float* cT, dc_stream_t stream) {
+                      float* hT, float* cT, const uint8_t* unit_mask, dc_stream_t stream) {
     DC_ENTER();
-    return dc::policy_forward(dims, params, poff_host, obs, h0, c0, seq_off, seq_len, ws, hT, cT, (hipStream_t)stream);
+    return dc::policy_forward(dims, params, poff_host, obs, h0, c0, seq_off, seq_len, ws, hT, cT, unit_mask, (hipStream_t)stream);
 }
 
 static float* ws_f(const dc_dims* dims, const void* ws, int idx) {

@@ -30,6 +30,7 @@
 namespace dc {
 
 enum { EF_OBS = 483, EF_EMB = 128, EF_TILE = 128 };
+constexpr float F16_S_W1 = 256.f;      // DC_DIMS_F16X2: power-of-two pre-scale of the first-layer weights (the records take the activations' 2^4)
 
 struct EmbTypes {
     long long row_begin[7];   // type-major row where type t starts (nr * cum[t])
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
                                                                  const uint16_t* __restrict__ W2p,
                                                                  const float* __restrict__ b2, float* __restrict__ emb,
                                                                  float* __restrict__ xcat, uint8_t* __restrict__ amax,
-                                                                 EmbTypes ty, int n_tiles, long long* __restrict__ dbg, float s_act, float inv) {
+                                                                 EmbTypes ty, int n_tiles, long long* __restrict__ dbg, float s_act, float inv,
+                                                                 const uint8_t* __restrict__ umask) {
     static_assert(!F16 || BPL, "the f16 pieces need the pre-split weight planes");
     long long tm_k = 0, tm_e = 0, tm_b = 0, tm0 = 0, tm_start = 0;
     if constexpr (TIMING) tm_start = __builtin_amdgcn_s_memtime();
@@ -117,13 +119,31 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
     //   A operand of MFMA kk: lane (fr, fq) = x[row 32w + fr][feature 2kk + fq]
     //   B operand          : lane (fr, fq) = W1[channel 32kt + fr][feature 2kk + fq]
     //   D                  : lane (fr, fq), register r = basic[row 32w + 8(r>>2) + 4fq + (r&3)][channel 32kt + fr]
-    float wb[4][6], b1v[4];
+    // F16: the first layer too runs on the 16-bit matrix cores - K = 12 padded to 16 is ONE K step: four v_mfma_f32_32x32x16_f16 on
+    // two f16 pieces of the records (x 2^4, split once per tile when they are loaded) and of W1 (x 2^8, as two planes [128][16] in LDS,
+    // built once per workgroup) instead of six v_mfma_f32_32x32x2_f32 - 128 matrix-pipe cycles instead of 384 per 32 x 32 block, next
+    // to the 1 024 of the block's second-layer products.  (The backward kernels re-evaluate the relu mask with the exact-f32 MFMA:
+    // a pre-activation within ~1e-7 of zero may get the other sign there - as between any two implementations of this layer.)
+    float wb[F16 ? 1 : 4][F16 ? 1 : 6], b1v[4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
+        if constexpr (!F16) {
 #pragma unroll
-        for (int kk = 0; kk < 6; ++kk) wb[kt][kk] = W1[(32 * kt + fr) * 12 + 2 * kk + fq] * (F16 ? s_act : 1.f);
+            for (int kk = 0; kk < 6; ++kk) wb[kt][kk] = W1[(32 * kt + fr) * 12 + 2 * kk + fq];
+        }
         b1v[kt] = b1[32 * kt + fr] * (F16 ? s_act : 1.f);
     }
+    char* const w1p = reinterpret_cast<char*>(smem + 2 * STAGE_FL);     // F16: [2 planes][128 channels][16 features] f16
+    if constexpr (F16) {
+        const int ch = tid >> 1, f0 = 8 * (tid & 1);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = f0 + e < 12 ? W1[ch * 12 + f0 + e] : 0.f;
+        const Split2h sp = split2h<true>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), F16_S_W1);
+        *reinterpret_cast<f16x8*>(w1p + ch * 32 + f0 * 2) = sp.h;
+        *reinterpret_cast<f16x8*>(w1p + 4096 + ch * 32 + f0 * 2) = sp.m;
+    }
+    const float ginv = s_act / (s_act * F16_S_W1);     // (x s_act)(W1 s_w1) -> basic * s_act
     int aoff[16];   // LDS float index of D register r inside an A stage (row-major [128][32], 16-byte chunks XOR-swizzled)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -139,28 +159,58 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
         else LT::issue(W2 + (size_t)t * EF_EMB * EF_EMB + kt * GEMM_BK, offb, dst, wave);
     };
 
-    auto load_x = [&](int tile, float (&x)[6]) {
+    // the records of a tile in the registers of its consumer: six floats (f32 MFMA: features 2 kk + fq), or - F16 - the eight features
+    // 8 fq .. 8 fq + 7 (12 .. 15: zero) already split into two f16 pieces (floats 0..3 = h, 4..7 = m as bit patterns)
+    constexpr int XR = F16 ? 8 : 6;
+    auto load_x = [&](int tile, float (&x)[XR]) {
         const int tl = min(tile, n_tiles - 1);                      // past the end: a valid tile, never used
         const int tt = ef_type_of_tile(ty, tl);
-        const float* xp = ef_record(obs, tt, (long long)tl * EF_TILE + 32 * wave + fr - ty.row_begin[tt], ty.nr_valid) + fq;
+        if constexpr (F16) {
+            const float* xp = ef_record(obs, tt, (long long)tl * EF_TILE + 32 * wave + fr - ty.row_begin[tt], ty.nr_valid) + 8 * fq;
+            float v[8];
 #pragma unroll
-        for (int kk = 0; kk < 6; ++kk) x[kk] = xp[2 * kk];
+            for (int e = 0; e < 4; ++e) v[e] = xp[e];
+#pragma unroll
+            for (int e = 4; e < 8; ++e) v[e] = fq ? 0.f : xp[e];      // features 12..15 do not exist
+            const Split2h sp = split2h<true>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), s_act);
+            const u32x4 hh = __builtin_bit_cast(u32x4, sp.h), mm = __builtin_bit_cast(u32x4, sp.m);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[e] = __uint_as_float(hh[e]); x[4 + e] = __uint_as_float(mm[e]); }
+        } else {
+            const float* xp = ef_record(obs, tt, (long long)tl * EF_TILE + 32 * wave + fr - ty.row_begin[tt], ty.nr_valid) + fq;
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk) x[kk] = xp[2 * kk];
+        }
     };
-    auto gen_a = [&](auto KT, const float (&x)[6], float* a_s) {
+    auto gen_a = [&](auto KT, const float (&x)[XR], float* a_s) {
         constexpr int kt = decltype(KT)::value;
         f32x16 g;
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[r] = 0.f;
+        if constexpr (F16) {
+            const f16x8 xh = __builtin_bit_cast(f16x8, u32x4{__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])});
+            const f16x8 xm = __builtin_bit_cast(f16x8, u32x4{__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])});
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(w1p + (32 * kt + fr) * 32 + fq * 16);
+            const f16x8 wm = *reinterpret_cast<const f16x8*>(w1p + 4096 + (32 * kt + fr) * 32 + fq * 16);
+            g = __builtin_amdgcn_mfma_f32_32x32x16_f16(xm, wm, g, 0, 0, 0);
+            g = __builtin_amdgcn_mfma_f32_32x32x16_f16(xm, wh, g, 0, 0, 0);
+            g = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wm, g, 0, 0, 0);
+            g = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, g, 0, 0, 0);
 #pragma unroll
-        for (int kk = 0; kk < 6; ++kk) g = __builtin_amdgcn_mfma_f32_32x32x2f32(x[kk], wb[kt][kk], g, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) a_s[aoff[r]] = fmaxf(fmaf(g[r], ginv, b1v[kt]), 0.f);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a_s[aoff[r]] = fmaxf(g[r] + b1v[kt], 0.f);
+            for (int kk = 0; kk < 6; ++kk) g = __builtin_amdgcn_mfma_f32_32x32x2f32(x[kk], wb[kt][kk], g, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a_s[aoff[r]] = fmaxf(g[r] + b1v[kt], 0.f);
+        }
     };
 
     int tile = blockIdx.x;
     if (tile >= n_tiles) return;
-    float xa[6], xn[6];
+    float xa[XR], xn[XR];
     load_x(tile, xa);
+    if constexpr (F16) __syncthreads();            // the W1 planes
     {   // step-0 operands of the first tile
         const int t0 = ef_type_of_tile(ty, tile);
         issue_b(t0, 0, stage + 4096);
@@ -175,6 +225,20 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
         const bool more = ntile < n_tiles;
         load_x(ntile, xn);              // lands behind the K loop
         const float b2v[2] = {b2[t * EF_EMB + wn * 64 + fr], b2[t * EF_EMB + wn * 64 + 32 + fr]};   // epilogue operands: likewise
+        // Mask-aware emb stores (F16 variant - the others have no register to spare): the emb rows of the two 16-unit types are read by
+        // the target-unit attention only, and only for units whose mask byte is set (heads.hip: attn_logits_masked, attn_bwd_q via dtu).
+        // The 64 rows of this wave = four env-steps x sixteen units: lane l takes the byte of (step l >> 4, unit l & 15) of each half.
+        int mb[2] = {1, 1};
+        if constexpr (F16) {
+            if (umask != nullptr && (t == 2 || t == 3)) {
+                const long long lr = row0 - ty.row_begin[t] + wm * 64;            // type-local row of this wave's row 0: a multiple of 16
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const long long n = min((lr >> 4) + 2 * i + ((lane >> 4) & 1), ty.nr_valid - 1);
+                    mb[i] = umask[n * 65 + 22 + ef_cum(t) + (lane & 15)];
+                }
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (TIMING) tm0 = __builtin_amdgcn_s_memtime();
 
@@ -267,18 +331,19 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
             }
             // rows 4*it + lane/16 of the half, 16 bytes at column 4*(lane%16): one wave, LDS ops in order
             float* eo = emb + (size_t)(row0 + wm * 64 + i * 32) * EF_EMB + wn * 64;
+            const unsigned live = F16 ? (unsigned)__ballot(mb[i] != 0) : 0xffffffffu;      // bit rr: row rr of this half is read by someone
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int rr = 4 * it + (lane >> 4), c4 = lane & 15;
                 const float4 q = *reinterpret_cast<const float4*>(tr + rr * 64 + 4 * c4);
-                *reinterpret_cast<float4*>(eo + (size_t)rr * EF_EMB + 4 * c4) = q;
+                if (!F16 || ((live >> rr) & 1u)) *reinterpret_cast<float4*>(eo + (size_t)rr * EF_EMB + 4 * c4) = q;
             }
         }
         if constexpr (TIMING) { const long long x = __builtin_amdgcn_s_memtime(); tm_e += x - tm0; tm0 = x; }
         __syncthreads();            // buffer 1 is free again for step 1 of the next tile
         if constexpr (TIMING) { const long long x = __builtin_amdgcn_s_memtime(); tm_b += x - tm0; }
 #pragma unroll
-        for (int kk = 0; kk < 6; ++kk) xa[kk] = xn[kk];
+        for (int kk = 0; kk < XR; ++kk) xa[kk] = xn[kk];
     }
     if constexpr (TIMING) {
         if (tid == 0) {
@@ -318,10 +383,22 @@ __global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restr
     // channels 32w..32w+31 of the K step's 32 rows with six MFMAs.  B of those = W1 (six registers for the whole
     // kernel); A = the step's unit records, one register per MFMA, loaded two steps ahead straight from HBM/L2
     // (each wave its own copy - 1.5 KB per step).
-    float wb[6];
+    // F16: like the forward, the regenerated first layer is one K = 16 step of four f16 MFMAs (records x 2^4 split per step, this wave's
+    // 32 W1 rows x 2^8 split once into registers)
+    float wb[F16 ? 1 : 6];
+    f16x8 w1h, w1m;
+    if constexpr (F16) {
+        float v[8];
 #pragma unroll
-    for (int kk = 0; kk < 6; ++kk) wb[kk] = W1[(32 * wave + fr) * 12 + 2 * kk + fq] * (F16 ? s_act : 1.f);
+        for (int e = 0; e < 8; ++e) v[e] = 8 * fq + e < 12 ? W1[(32 * wave + fr) * 12 + 8 * fq + e] : 0.f;
+        const Split2h sp = split2h<true>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), F16_S_W1);
+        w1h = sp.h; w1m = sp.m;
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) wb[kk] = W1[(32 * wave + fr) * 12 + 2 * kk + fq];
+    }
     const float b1v = b1[32 * wave + fr] * (F16 ? s_act : 1.f);
+    const float ginv = 1.f / F16_S_W1;                 // (x s_act)(W1 s_w1) -> basic * s_act
     int boff[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) boff[r] = (8 * (r >> 2) + 4 * fq + (r & 3)) * 128 + 32 * wave + fr;
@@ -330,19 +407,37 @@ __global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restr
     LT::src_offsets<false>(offa, EF_EMB, 0, 128, wave, lane);
     const float* ga = demb + (size_t)(ty.row_begin[t] + s0 * GEMM_BK) * EF_EMB;
 
-    auto load_x = [&](int s, float (&x)[6]) {
-        const float* xp = ef_record(obs, t, (s0 + min(s, ns - 1)) * GEMM_BK + fr, ty.nr_valid) + fq;   // clamped: always a valid step
+    constexpr int XR = F16 ? 8 : 6;
+    auto load_x = [&](int s, float (&x)[XR]) {
+        const float* xp = ef_record(obs, t, (s0 + min(s, ns - 1)) * GEMM_BK + fr, ty.nr_valid) + (F16 ? 8 * fq : fq);   // clamped: always a valid step
+        if constexpr (F16) {
 #pragma unroll
-        for (int kk = 0; kk < 6; ++kk) x[kk] = xp[2 * kk];
+            for (int e = 0; e < 4; ++e) x[e] = xp[e];
+#pragma unroll
+            for (int e = 4; e < 8; ++e) x[e] = fq ? 0.f : xp[e];      // features 12..15 do not exist
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk) x[kk] = xp[2 * kk];
+        }
     };
-    auto gen_b = [&](const float (&x)[6], float* b_s) {
+    auto gen_b = [&](const float (&x)[XR], float* b_s) {
         f32x16 g;
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[r] = 0.f;
+        if constexpr (F16) {
+            const Split2h sp = split2h<true>(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), s_act);
+            g = __builtin_amdgcn_mfma_f32_32x32x16_f16(sp.m, w1m, g, 0, 0, 0);
+            g = __builtin_amdgcn_mfma_f32_32x32x16_f16(sp.m, w1h, g, 0, 0, 0);
+            g = __builtin_amdgcn_mfma_f32_32x32x16_f16(sp.h, w1m, g, 0, 0, 0);
+            g = __builtin_amdgcn_mfma_f32_32x32x16_f16(sp.h, w1h, g, 0, 0, 0);
 #pragma unroll
-        for (int kk = 0; kk < 6; ++kk) g = __builtin_amdgcn_mfma_f32_32x32x2f32(x[kk], wb[kk], g, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) b_s[boff[r]] = fmaxf(fmaf(g[r], ginv, b1v), 0.f);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) b_s[boff[r]] = fmaxf(g[r] + b1v, 0.f);
+            for (int kk = 0; kk < 6; ++kk) g = __builtin_amdgcn_mfma_f32_32x32x2f32(x[kk], wb[kk], g, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) b_s[boff[r]] = fmaxf(g[r] + b1v, 0.f);
+        }
     };
 
     f32x16 acc[2][2];
@@ -353,14 +448,14 @@ __global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float x0[6], x1[6];
+    float x0[XR], x1[XR];
     load_x(0, x0);
     load_x(1, x1);
     LT::issue(ga, offa, smem, wave);
     gen_b(x0, smem + 4096);
     __syncthreads();
     // steps unrolled by two with ping-pong record registers: x1 feeds gen_b(s+1) while x0 receives step s+2
-    auto step = [&](int s, float (&xnext)[6], float (&xfill)[6]) {
+    auto step = [&](int s, float (&xnext)[XR], float (&xfill)[XR]) {
         float* cur = smem + (s & 1) * STAGE_FL;
         // The barrier at the end of a step waits for the A DMA (vmcnt retires in order), hence for every load
         // of the step: the record loads go FIRST, so that they complete behind the 64 MFMAs.
@@ -559,12 +654,12 @@ static int set_lds(K kernel, size_t bytes, bool* done) {
 }
 
 int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const float* W2, const uint16_t* W2p, const float* b2, float* emb,
-                    float* xcat, uint8_t* amax, long long nr_valid, long long nr, hipStream_t s, F16x2Scales f16) {
+                    float* xcat, uint8_t* amax, long long nr_valid, long long nr, hipStream_t s, F16x2Scales f16, const uint8_t* unit_mask) {
     int nwg;
     const EmbTypes ty = make_types(nr, nr_valid, &nwg);
     const bool bpl = W2p != nullptr;
     const bool h = f16.on && bpl;
-    const size_t lds = (size_t)(2 * (4096 + (bpl ? (h ? PlaneTile<128, 2>::LDS_FLOATS : PlaneTile<128>::LDS_FLOATS) : 4096))) * sizeof(float);
+    const size_t lds = (size_t)(2 * (4096 + (bpl ? (h ? PlaneTile<128, 2>::LDS_FLOATS : PlaneTile<128>::LDS_FLOATS) : 4096)) + (h ? 2048 : 0)) * sizeof(float);
     static bool attr = false, attr_p = false, attr_h = false;
     if (h) { if (int e = set_lds(embed_fwd_fused_kernel<false, true, true>, lds, &attr_h)) return e; }
     else if (bpl) { if (int e = set_lds(embed_fwd_fused_kernel<false, true>, lds, &attr_p)) return e; }
@@ -579,7 +674,7 @@ int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const fl
         static long long* dbg = nullptr;
         if (!dbg) (void)hipMalloc(&dbg, 512 * 4 * sizeof(long long));
         hipLaunchKernelGGL((embed_fwd_fused_kernel<true, false>), dim3(grid), dim3(256), (size_t)(4 * 4096) * sizeof(float), s, obs, W1, b1, W2,
-                           (const uint16_t*)nullptr, b2, emb, xcat, amax, ty, tiles, dbg, 1.f, 1.f);
+                           (const uint16_t*)nullptr, b2, emb, xcat, amax, ty, tiles, dbg, 1.f, 1.f, (const uint8_t*)nullptr);
         long long h[512 * 4];
         (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
         double ph[4] = {0, 0, 0, 0};
@@ -590,11 +685,11 @@ int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const fl
         return launch_check("embed_fwd_fused");
     }
     if (h) hipLaunchKernelGGL((embed_fwd_fused_kernel<false, true, true>), dim3(grid), dim3(256), lds, s, obs, W1, b1, W2, W2p, b2, emb, xcat, amax, ty,
-                              tiles, (long long*)nullptr, f16.s_act, 1.f / (f16.s_act * f16.s_w));
+                              tiles, (long long*)nullptr, f16.s_act, 1.f / (f16.s_act * f16.s_w), unit_mask);
     else if (bpl) hipLaunchKernelGGL((embed_fwd_fused_kernel<false, true>), dim3(grid), dim3(256), lds, s, obs, W1, b1, W2, W2p, b2, emb, xcat, amax, ty,
-                                tiles, (long long*)nullptr, 1.f, 1.f);
+                                tiles, (long long*)nullptr, 1.f, 1.f, (const uint8_t*)nullptr);
     else hipLaunchKernelGGL((embed_fwd_fused_kernel<false, false>), dim3(grid), dim3(256), lds, s, obs, W1, b1, W2, W2p, b2, emb, xcat, amax, ty,
-                            tiles, (long long*)nullptr, 1.f, 1.f);
+                            tiles, (long long*)nullptr, 1.f, 1.f, (const uint8_t*)nullptr);
     return launch_check("embed_fwd_fused");
 }
 

@@ -420,7 +420,9 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
                 gl = k == kk ? glp[kk] : gl; ge = k == kk ? gent[kk] : ge; hr = k == kk ? Hrow[kk] : hr; amk = k == kk ? amin[kk] : amk;
             }
             float g = mk[m] ? (-gl * pc[m] + ge * pc[m] * (lp[m] + hr)) : 0.f;
-            if (c == amk) g += gl;
+            // (k == 3: an action on a masked-out unit - the actors never send one, agent.py:666-671 - gets no gradient, so that d(tu) is
+            // exactly zero outside the mask: the backward may then rely on "dtu != 0 => the unit's embedding row was stored")
+            if (c == amk && (k != 3 || mk[m])) g += gl;
             if (k == 3) p.dtu[n * NUNITS + (c - 22)] = g;
             else p.dheadout[n * HO_LD + (k == 4 ? 88 : 128) + c] = g;
         }

@@ -145,7 +145,7 @@ static bool embed_sparse_enabled(const dc_dims* d) { return !(d->flags & DC_DIMS
 
 int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, const float* obs, const float* h0,
                    const float* c0, const int64_t* seq_off, const int32_t* seq_len, void* ws_base, float* hT, float* cT,
-                   hipStream_t s) {
+                   const uint8_t* unit_mask, hipStream_t s) {
     DC_TRY(check_dims(d));
     if (d->rows <= 0 || d->n_seq <= 0) return 0;
     Ws w; w.base = (char*)ws_base; workspace_layout(d, w.off);
@@ -170,7 +170,7 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
         F16x2Scales fs;
         fs.on = eh; fs.s_act = F16X2_S_ACT; fs.s_w = F16X2_S_W;
         DC_TRY(embed_fwd_fused(obs, P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), P.p(DC_P_UNIT_W), bpl ? wpe.fwd(wpe.unit) : nullptr, P.p(DC_P_UNIT_B),
-                               w.f(DC_WS_EMB), w.f(DC_WS_XCAT), amax, NR, NRp, s, fs));
+                               w.f(DC_WS_EMB), w.f(DC_WS_XCAT), amax, NR, NRp, s, fs, (d->flags & DC_DIMS_LAZY_TU) ? unit_mask : nullptr));
     } else {
         DC_TRY(unit_basic_fwd(obs, P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), w.f(DC_WS_BASIC), NR, s));
         for (int t = 0; t < 6; ++t) {

@@ -579,7 +579,8 @@ class Engine:
             cT = device_empty((self.layers, batch.n_seq, self.hidden), torch.float32, self.device) if self.cell == 'lstm' else None
         _lib.check(self.lib.dc_policy_forward(ctypes.byref(d), _lib.ptr(self.params), self.poff, _lib.ptr(batch.obs),
                                               _lib.ptr(h0), _lib.ptr(c0), _lib.ptr(batch.seq_off), _lib.ptr(batch.seq_len),
-                                              _lib.ptr(ws), _lib.ptr(hT), _lib.ptr(cT), _lib.stream_ptr()),
+                                              _lib.ptr(ws), _lib.ptr(hT), _lib.ptr(cT), _lib.ptr(batch.mask if lazy_tu else None),
+                                              _lib.stream_ptr()),
                    'dc_policy_forward')
         return d, hT, cT
 

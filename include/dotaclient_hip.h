@@ -31,7 +31,7 @@ typedef void* dc_stream_t; /* hipStream_t */
 
 /* 3 (round 3): DC_WS_FAULT inserted at workspace index 0; round 2's unannounced changes (dc_gemm_f32's scratch arguments,
  * DC_WS_TEAM_XBUF / DC_WS_WPLANES) were version 2 in effect.
- * 4 (round 4): same signatures, changed contracts - dc_gradnorm_clip_adam's status word is sticky (a non-zero word makes later calls
+ * 4 (round 4): dc_policy_forward takes the action masks (unit_mask); otherwise same signatures, changed contracts - dc_gradnorm_clip_adam's status word is sticky (a non-zero word makes later calls
  * skip their update until the caller clears it); dc_gae_scan / dc_discount / dc_advantage_returns accept any length (error 1001 is gone).
  * The Python binding refuses any other value. */
 #define DC_ABI_VERSION 4
@@ -204,10 +204,14 @@ int64_t dc_workspace_layout(const dc_dims* dims, int64_t* offsets);
  *   obs [rows,483] f32; h0/c0 [layers,B,H] (NULL = zeros; c0 LSTM only); seq_off i64[B], seq_len i32[B];
  *   hT/cT [layers,B,H] out (may be NULL).  Results live in the workspace: DC_WS_HEADOUT [rows,160]
  *   (cols 0..127 attention query, 128..131 enum, 132..140 x, 141..149 y, 150..152 ability, 153 value)
- *   and DC_WS_TU [rows,40] (target_unit logits). */
+ *   and DC_WS_TU [rows,40] (target_unit logits).  *   unit_mask (may be NULL; only read with DC_DIMS_LAZY_TU and DC_DIMS_F16X2): the batch's action masks u8 [rows,65].  The per-unit
+ *   embeddings of the two 16-unit types (32 of the 40 units, 1.1 GB per configs[2] pass) have ONE consumer - the target-unit attention of
+ *   dc_select_logp / dc_ppo_loss_fwd_bwd / dc_policy_backward, which reads the rows of units whose mask byte (column 22 + unit) is set and
+ *   nothing else - so with the masks at hand DC_WS_EMB rows of masked-out units of those types are NOT written (they keep whatever the
+ *   buffer held).  NULL: every row is written. */
 int dc_policy_forward(const dc_dims* dims, const float* params, const int64_t* poff_host, const float* obs,
                       const float* h0, const float* c0, const int64_t* seq_off, const int32_t* seq_len, void* ws,
-                      float* hT, float* cT, dc_stream_t stream);
+                      float* hT, float* cT, const uint8_t* unit_mask, dc_stream_t stream);
 
 /* Hidden-state carry of the rollout pass, optimizer.py:384,408 (`hidden = hidden.detach()` handed from chunk to chunk) and
  * policy.py:77-78 (zeros for a rollout's first chunk): after dc_policy_forward over whole rollouts (`dims`, `ws` = that
