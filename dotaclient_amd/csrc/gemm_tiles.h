@@ -221,6 +221,13 @@ __device__ __forceinline__ void mma_kstep_bplanes(const float* __restrict__ a_s,
 // caveat: gemm_x3.hip, PREC = 4).  x * s = h + m (+ l, dropped) with h = f16(x s), m = f16(x s - h); s: the operand's power-of-two
 // pre-scale (1 when the producer already applied it); the caller scales the accumulators back by 1 / (sa sb).
 // ---------------------------------------------------------------------------------------------------
+// A/B build -DDC_X2H_SKIP_MM: without the m*m term (three MFMAs; what is dropped grows from ~2^-22 to ~2^-21 |ab| per product) - a
+// measurement aid for the power-limit question, not a shipped mode
+#ifdef DC_X2H_SKIP_MM
+#define DC_X2H_MM(x)
+#else
+#define DC_X2H_MM(x) x
+#endif
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
@@ -265,7 +272,7 @@ __device__ __forceinline__ void mma_kstep_h(const float* __restrict__ a_s, const
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                          \
             _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                                   \
                 acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i].X, b[jn].Y, acc[i][jn], 0, 0, 0);
-        DC_MMA_H(m, m) DC_MMA_H(m, h) DC_MMA_H(h, m) DC_MMA_H(h, h)
+        DC_X2H_MM(DC_MMA_H(m, m)) DC_MMA_H(m, h) DC_MMA_H(h, m) DC_MMA_H(h, h)
 #undef DC_MMA_H
     }
 }
@@ -291,7 +298,7 @@ __device__ __forceinline__ void mma_kstep_bplanes_h(const float* __restrict__ a_
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                          \
             _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                                   \
                 acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i].X, Y[jn], acc[i][jn], 0, 0, 0);
-        DC_MMA_HQ(m, bm) DC_MMA_HQ(m, bh) DC_MMA_HQ(h, bm) DC_MMA_HQ(h, bh)
+        DC_X2H_MM(DC_MMA_HQ(m, bm)) DC_MMA_HQ(m, bh) DC_MMA_HQ(h, bm) DC_MMA_HQ(h, bh)
 #undef DC_MMA_HQ
     }
 }

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args p, int n_items, 
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][X]), __builtin_bit_cast(f16x8, b[j][Y]), acc[i][j], 0, 0, 0);
-            if constexpr (PREC == 4) { DC_X2H_P(1, 1) DC_X2H_P(1, 0) DC_X2H_P(0, 1) DC_X2H_P(0, 0) }
+            if constexpr (PREC == 4) { DC_X2H_MM(DC_X2H_P(1, 1)) DC_X2H_P(1, 0) DC_X2H_P(0, 1) DC_X2H_P(0, 0) }
             else {
             if constexpr (PREC == 6) { DC_X3_P(2, 0) DC_X3_P(0, 2) DC_X3_P(1, 1) DC_X3_P(1, 0) DC_X3_P(0, 1) }
             DC_X3_P(0, 0)
