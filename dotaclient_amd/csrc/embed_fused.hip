@@ -714,7 +714,7 @@ int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const 
     float* part2 = part1 + 2LL * SPARSE_WG_PER_TYPE * 1664;
     if (sparse16) {
         if (int e = embed_bwd_pool16(obs, sp->dxcat, sp->amax, sp->dtu, sp->q, sp->ldq, W1, b1, W2,
-                                     scratch + (size_t)ty.wg_begin[2] * EF_EMB * EF_EMB, part1, part2, sp->prep, nr_valid, SPARSE_WG_PER_TYPE, s))
+                                     scratch + (size_t)ty.wg_begin[2] * EF_EMB * EF_EMB, part1, part2, sp->prep, nr_valid, SPARSE_WG_PER_TYPE, s, sp->eight_waves))
             return e;
     }
     {

@@ -456,11 +456,256 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
     for (int e = tid; e < 1664; e += SP_THREADS) o[e] = acc[e];
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Pass 2, sixteen-wave form (round 4; the default).  The eight-wave kernel above keeps BOTH step streams in every wave: 256 registers,
+// two waves per SIMD, and the counters say its waves are parked 51 % of their cycles (s_waitcnt on the LDS round trips of the gathers)
+// with the issue ports two-thirds busy - latency-bound, not throughput-bound.  Here a workgroup has 1 024 threads: waves 0..7 work on
+// stream 0, waves 8..15 on stream 1, each with the lane maps of the eight-wave kernel for ITS stream only - half the live state per
+// wave (<= 128 registers), FOUR waves per SIMD to hide the same round trips, the same one barrier per iteration, the same LDS
+// footprint (one workgroup per CU: W2 stays whole).  What changes with it:
+//   * the dW2 update is split over k, not over the streams: wave W owns dW2[.][8 W .. 8 W + 7] and takes the steps of BOTH streams (half the
+//     accumulators per wave, every entry has one owner);
+//   * a wave folds TWO (stream, unit) rows per iteration into dW1 / db1 (rows 2, 3 of the K = 4 MFMA read a shared zero row);
+//   * staging by DMA: piece j of stream s is issued by wave (s, j), j = 0..4.
+// ---------------------------------------------------------------------------------------------------
+enum { LW_T = L_STG + 3 * NS * STG_SIZE, LW_TZ = LW_T + 16 * 2 * T_LD, LW_TOTAL = LW_TZ + T_LD };
+
+__global__ __launch_bounds__(1024) void embed_bwd_pool16w_kernel(SparseArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int W = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int so = W >> 3, w = W & 7;                       // own stream, wave index inside the stream's group
+    const int hh = lane >> 5, l32 = lane & 31;
+    const int k4 = 4 * l32;
+    const int u_own = w + 8 * hh;                           // this half-wave's unit
+    const int t = 2 + blockIdx.x / p.wg_per_type;          // 2 = allied non-heroes, 3 = enemy non-heroes
+    const int wgi = blockIdx.x % p.wg_per_type;
+    const long long n0 = (long long)wgi * p.steps_per_wg;
+    const long long n1 = min(p.nr, n0 + p.steps_per_wg);
+    const int cum = t == 2 ? 6 : 22;
+    const float* prep_t = p.prep + (size_t)(t - 2) * p.nr * IMG_SIZE;
+
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.W2 + (size_t)t * 128 * 128);
+        for (int e = tid; e < 128 * 32; e += 1024) *reinterpret_cast<float4*>(smem + L_W2 + 4 * e) = src[e];
+    }
+    const int mi = lane & 15, mq = lane >> 4;
+    float w1b[3];
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) w1b[kk] = p.W1[(16 * w + mi) * 12 + 4 * kk + mq];
+    const float b1c = p.b1[16 * w + mi];
+    f32x4 accD[8];
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) accD[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x2 D[2][4];                 // dW2[c = lane + 64 h][8 W + 2 j, + 1]: the sixteen waves split k, each takes BOTH streams' steps
+    float db2a = 0.f;              // threads 0..127: second-layer bias gradient of channel tid (both streams)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { D[0][i] = mk2(0.f, 0.f); D[1][i] = mk2(0.f, 0.f); }
+
+    const long long half = (n1 - n0 + 1) / 2;
+    const long long nb[NS] = {n0, n0 + half}, ne[NS] = {min(n1, n0 + half), n1};
+    const long long iters = half;
+    const long long nbo = so ? nb[1] : nb[0], neo = so ? ne[1] : ne[0];     // own stream's step range
+    auto stg_of = [&](long long i, int s2) { return smem + L_STG + ((int)(i % 3) * NS + s2) * STG_SIZE; };
+    auto rec_off = [&](long long n) { return (size_t)n * SP_OBS + 3 + cum * 12; };
+    auto dma_issue = [&](long long i) {          // own stream; piece j = w: 0..2 image (3 x 1 KB), 3 q, 4 the unit records
+        const long long n = nbo + i;
+        if (n >= neo || w > 4) return;                             // wave-uniform
+        float* dst = stg_of(i, so);
+        if (w < 3) {
+            if (w * 1024 + lane * 16 < IMG_SIZE * 4)
+                __builtin_amdgcn_global_load_lds((gptr_t)(prep_t + (size_t)n * IMG_SIZE + w * 256 + lane * 4), (lptr_t)(dst + w * 256), 16, 0, 0);
+        } else if (w == 3) {
+            if (lane < 32) __builtin_amdgcn_global_load_lds((gptr_t)(p.q + (size_t)n * p.ldq + lane * 4), (lptr_t)(dst + STG_Q), 16, 0, 0);
+        } else {
+            if (lane < 49) __builtin_amdgcn_global_load_lds((gptr_t)(p.obs + (rec_off(n) & ~(size_t)3) + lane * 4), (lptr_t)(dst + STG_X), 16, 0, 0);
+        }
+    };
+    auto bas_of = [&](long long i, int s2) { return smem + L_BAS + ((int)(i & 1) * NS + s2) * 16 * SP_BLD; };
+    auto phase_a = [&](long long i) {             // basic[all units][16w .. 16w + 15] of the own stream's step of iteration i
+        if (nbo + i >= neo) return;
+        const float* xs = stg_of(i, so) + STG_X + (int)(rec_off(nbo + i) & 3) + mi * 12 + mq;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[4 * kk], w1b[kk], acc, 0, 0, 0);
+        float* bo = bas_of(i, so) + 4 * mq * SP_BLD + 16 * w + mi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bo[r * SP_BLD] = fmaxf(acc[r] + b1c, 0.f);
+    };
+
+    // the wave's two T rows (half-wave hh = unit w + 8 hh of the own stream) and the shared zero row behind rows 2, 3 of the fold's K = 4
+    float* T = smem + LW_T + W * (2 * T_LD);
+    for (int e = lane; e < 2 * T_LD; e += 64) T[e] = 0.f;
+    if (tid < T_LD) smem[LW_TZ + tid] = 0.f;
+    const float* tb = mq < 2 ? T + mq * T_LD : smem + LW_TZ;
+
+    dma_issue(0);
+    dma_issue(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();          // W2 / staging[0], staging[1] / T
+    phase_a(0);
+
+    const char* w2b = reinterpret_cast<const char*>(smem + L_W2 + k4);
+    float xa_prev = 0.f;
+    auto fold_prev = [&]() {
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) accD[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa_prev, tb[16 * kb + mi], accD[kb], 0, 0, 0);
+    };
+    for (long long i = 0; i < iters; ++i) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's piece of staging[i + 1] has landed
+        __syncthreads();
+        dma_issue(i + 2);
+        fold_prev();
+        phase_a(i + 1);
+        const bool on = nbo + i < neo;                                         // uniform over the stream's eight waves
+        const float* stg = stg_of(i, so);
+        const bool live = on && reinterpret_cast<const int*>(stg)[STG_FLAG] != 0;
+        f32x2 dbl = mk2(0.f, 0.f), dbh = mk2(0.f, 0.f);       // d(basic)[u_own][k4, k4 + 1] and [k4 + 2, k4 + 3]
+        float4 basic = make_float4(0.f, 0.f, 0.f, 0.f);
+        // phase B, channel per lane, BOTH streams: D[h][j] += d[c] * basic[a(c)][8 W + 2 j .. + 1], c = lane + 64 h
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) {
+            if (nb[s2] + i >= ne[s2]) continue;                                   // workgroup-uniform
+            const float* sg = stg_of(i, s2);
+            const char* brow = reinterpret_cast<const char*>(bas_of(i, s2)) + W * 32;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float2 e = *reinterpret_cast<const float2*>(sg + STG_PB + 2 * (lane + 64 * h));   // {d, row byte offset}
+                const float4* rp = reinterpret_cast<const float4*>(brow + __float_as_int(e.y));
+                const f32x2 dd = mk2(e.x, e.x);
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const float4 r4 = rp[v];
+                    D[h][2 * v] = __builtin_elementwise_fma(dd, mk2(r4.x, r4.y), D[h][2 * v]);
+                    D[h][2 * v + 1] = __builtin_elementwise_fma(dd, mk2(r4.z, r4.w), D[h][2 * v + 1]);
+                }
+            }
+        }
+        if (on) {
+            basic = *reinterpret_cast<const float4*>(bas_of(i, so) + u_own * SP_BLD + k4);
+            // phase C: {first entry, count} of the own unit, then its entries first .. first + 15 in every 16-lane row
+            const int2 sc = *reinterpret_cast<const int2*>(stg + STG_SC + 2 * u_own);
+            const int first = sc.x, cnt = sc.y;
+            const float2 ent = *reinterpret_cast<const float2*>(stg + STG_LIST + 2 * (first + (lane & 15)));
+            const float dvec = (lane & 15) < cnt ? ent.x : 0.f;
+            const int ovec = __float_as_int(ent.y);
+            f32x2 ol = mk2(0.f, 0.f), oh = mk2(0.f, 0.f);
+            auto slot = [&](auto JC) {
+                constexpr int J = decltype(JC)::value;
+                const float4 wv = *reinterpret_cast<const float4*>(w2b + bcast16_i<J>(ovec));
+                const float d = bcast16_f<J>(dvec);
+                const f32x2 dd = mk2(d, d);
+                if constexpr (J & 1) {
+                    ol = __builtin_elementwise_fma(dd, mk2(wv.x, wv.y), ol); oh = __builtin_elementwise_fma(dd, mk2(wv.z, wv.w), oh);
+                } else {
+                    dbl = __builtin_elementwise_fma(dd, mk2(wv.x, wv.y), dbl); dbh = __builtin_elementwise_fma(dd, mk2(wv.z, wv.w), dbh);
+                }
+            };
+            for_consts(slot, std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>{});
+            const int cmax = max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 32));
+            if (cmax > 8) for_consts(slot, std::integer_sequence<int, 8, 9, 10, 11>{});     // wave-uniform
+            for (int j = SP_SLOTS; j < cmax; ++j) {
+                const float2 e = *reinterpret_cast<const float2*>(stg + STG_LIST + 2 * (first + min(j, cnt - 1 < 0 ? 0 : cnt - 1)));
+                const float4 wv = *reinterpret_cast<const float4*>(w2b + __float_as_int(e.y));
+                const float d = j < cnt ? e.x : 0.f;
+                dbl = __builtin_elementwise_fma(mk2(d, d), mk2(wv.x, wv.y), dbl);
+                dbh = __builtin_elementwise_fma(mk2(d, d), mk2(wv.z, wv.w), dbh);
+            }
+            dbl += ol; dbh += oh;
+            if (live) {       // rank-one attention terms (see the eight-wave kernel)
+                const float dt = stg[STG_DT + u_own];
+                const float4 R = *reinterpret_cast<const float4*>(stg + STG_R + k4);
+                dbl = __builtin_elementwise_fma(mk2(dt, dt), mk2(R.x, R.y), dbl);
+                dbh = __builtin_elementwise_fma(mk2(dt, dt), mk2(R.z, R.w), dbh);
+            }
+        }
+        // dW2[c][k] += q[c] * s[k], s[k] = sum_u dtu[u] basic[u][k], for the live steps of BOTH streams over this wave's k range
+        // 8 W .. 8 W + 7: lane (u = lane & 15, g = lane >> 4; g < 2) takes dtu[u] * basic[u][8 W + 4 g .. + 3], sixteen-lane DPP sums
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) {
+            if (nb[s2] + i >= ne[s2]) continue;
+            const float* sg = stg_of(i, s2);
+            if (reinterpret_cast<const int*>(sg)[STG_FLAG] == 0) continue;        // workgroup-uniform
+            {
+                const float du = sg[STG_DT + (lane & 15)];
+                const float4 bv = *reinterpret_cast<const float4*>(bas_of(i, s2) + (lane & 15) * SP_BLD + 8 * W + 4 * ((lane >> 4) & 1));
+                float sv[4] = {du * bv.x, du * bv.y, du * bv.z, du * bv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sv[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv[e]), 0x128, 0xf, 0xf, true));
+                    sv[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv[e]), 0x124, 0xf, 0xf, true));
+                    sv[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv[e]), 0x122, 0xf, 0xf, true));
+                    sv[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv[e]), 0x121, 0xf, 0xf, true));
+                }
+                const float q0 = sg[STG_Q + lane], q1 = sg[STG_Q + lane + 64];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    auto rl = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16 * g)); };
+                    const float sa = rl(sv[0]), sb = rl(sv[1]), sc2 = rl(sv[2]), sd = rl(sv[3]);
+                    D[0][2 * g] = __builtin_elementwise_fma(mk2(q0, q0), mk2(sa, sb), D[0][2 * g]);
+                    D[0][2 * g + 1] = __builtin_elementwise_fma(mk2(q0, q0), mk2(sc2, sd), D[0][2 * g + 1]);
+                    D[1][2 * g] = __builtin_elementwise_fma(mk2(q1, q1), mk2(sa, sb), D[1][2 * g]);
+                    D[1][2 * g + 1] = __builtin_elementwise_fma(mk2(q1, q1), mk2(sc2, sd), D[1][2 * g + 1]);
+                }
+            }
+        }
+        // ---- phase D: through the relu into the wave's T row (folded at the top of the next iteration); the fold's A operand
+        *reinterpret_cast<float4*>(T + hh * T_LD + k4) =
+            make_float4(basic.x > 0.f ? dbl.x : 0.f, basic.y > 0.f ? dbl.y : 0.f, basic.z > 0.f ? dbh.x : 0.f, basic.w > 0.f ? dbh.y : 0.f);
+        {
+            // A[f][row mq]: rows 0, 1 = units w, w + 8 of the own stream (f = 12: ones -> db1), rows 2, 3 = nothing.  Read now: the
+            // next iteration's DMA reuses this staging slot
+            const float* sx = stg + STG_X + (int)(rec_off(nbo + i) & 3);
+            xa_prev = (mq < 2 && on) ? (mi < 12 ? sx[(w + 8 * mq) * 12 + mi] : (mi == 12 ? 1.f : 0.f)) : 0.f;
+        }
+        if (tid < 128) {      // column sum of d(emb) over both streams' steps (threads 0..127 = the first two waves)
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) {
+                if (nb[s2] + i >= ne[s2]) continue;
+                const float* sg = stg_of(i, s2);
+                const bool lv = reinterpret_cast<const int*>(sg)[STG_FLAG] != 0;
+                db2a += sg[STG_PB + 2 * tid] + (lv ? sg[STG_Q + tid] * sg[STG_DT + 16] : 0.f);
+            }
+        }
+    }
+    fold_prev();
+
+    // ---- results --------------------------------------------------------------------------------------
+    {
+        float* out = p.slab + (size_t)blockIdx.x * 128 * 128;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *reinterpret_cast<float4*>(out + (size_t)(lane + 64 * h) * 128 + 8 * W + 4 * j) =
+                    make_float4(D[h][2 * j].x, D[h][2 * j].y, D[h][2 * j + 1].x, D[h][2 * j + 1].y);
+        if (tid < 128) p.part2[(size_t)blockIdx.x * 128 + tid] = db2a;
+    }
+    // dW1 / db1: sum the 16 waves in fixed order through LDS -> part1[wg][f][k] (f = 12: db1)
+    __syncthreads();
+    float* acc = smem + L_RED;      // [13][128]
+    for (int e = tid; e < 13 * 128; e += 1024) acc[e] = 0.f;
+    __syncthreads();
+    for (int ww = 0; ww < 16; ++ww) {
+        if (W == ww) {
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * mq + r < 13) acc[(4 * mq + r) * 128 + 16 * kb + mi] += accD[kb][r];
+        }
+        __syncthreads();
+    }
+    float* o = p.part1 + (size_t)blockIdx.x * 1664;
+    for (int e = tid; e < 1664; e += 1024) o[e] = acc[e];
+}
+
 // slab: 2 * wg_per_type x [128][128]; part1: 2 * wg_per_type x [13][128]; part2: 2 * wg_per_type x [128];
 // prep: 2 * nr * 736 floats of scratch for the prepared staging blocks
 int embed_bwd_pool16(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq,
                      const float* W1, const float* b1, const float* W2, float* slab, float* part1, float* part2, float* prep,
-                     long long nr, int wg_per_type, hipStream_t s) {
+                     long long nr, int wg_per_type, hipStream_t s, int eight_waves) {
     SparseArgs a{obs, dxcat, amax, dtu, q, ldq, W1, b1, W2, slab, part1, part2, nr, wg_per_type,
                  (int)((nr + wg_per_type - 1) / wg_per_type), nullptr, prep};
     const size_t lds = (size_t)L_TOTAL * sizeof(float);
@@ -496,8 +741,19 @@ int embed_bwd_pool16(const float* obs, const float* dxcat, const uint8_t* amax, 
                     h[wv][0] / st, h[wv][1] / st, (h[wv][2] + h[wv][3]) / st, h[wv][4] / st, h[wv][5] / st);
         return launch_check("embed_bwd_pool16");
     }
-    hipLaunchKernelGGL(embed_bwd_pool16_kernel<false>, dim3(2 * wg_per_type), dim3(SP_THREADS), lds, s, a);
-    return launch_check("embed_bwd_pool16");
+    if (eight_waves) {
+        hipLaunchKernelGGL(embed_bwd_pool16_kernel<false>, dim3(2 * wg_per_type), dim3(SP_THREADS), lds, s, a);
+        return launch_check("embed_bwd_pool16");
+    }
+    const size_t ldsw = (size_t)LW_TOTAL * sizeof(float);
+    static bool attrw = false;
+    if (!attrw) {
+        hipError_t e = hipFuncSetAttribute((const void*)embed_bwd_pool16w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+        if (e != hipSuccess) { set_error("embed_bwd_pool16 (16 waves): hipFuncSetAttribute", (int)e); return (int)e; }
+        attrw = true;
+    }
+    hipLaunchKernelGGL(embed_bwd_pool16w_kernel, dim3(2 * wg_per_type), dim3(1024), ldsw, s, a);
+    return launch_check("embed_bwd_pool16 (16 waves)");
 }
 
 }  // namespace dc

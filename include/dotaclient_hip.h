@@ -156,6 +156,9 @@ typedef struct dc_dims {
  *                            0.25 * 65536 / rows) turns into inf -> NaN -> the status word of dc_gradnorm_clip_adam (nothing
  *                            updated); the caller then repeats the iteration without this flag.  Ignored with DC_DIMS_BF16. */
 #define DC_DIMS_F16X2 131072
+/*   DC_DIMS_POOL16_8W      : sparse max-pool backward of the 16-unit types with round 2's eight-wave kernel (both step streams in every
+ *                            wave, two waves per SIMD) instead of the sixteen-wave one (a stream per wave group, four waves per SIMD). */
+#define DC_DIMS_POOL16_8W 262144
 
 /* index into poff[]; policy.py:54-75 names in comments */
 enum dc_param_index {
