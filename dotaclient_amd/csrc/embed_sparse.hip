@@ -458,7 +458,8 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
 
 
 // ---------------------------------------------------------------------------------------------------
-// Pass 2, sixteen-wave form (round 4; the default).  The eight-wave kernel above keeps BOTH step streams in every wave: 256 registers,
+// Pass 2, sixteen-wave form (round 4; DC_DIMS_POOL16_16W - NOT the default: measured 839-872 us against the eight-wave kernel's 797-819 us on
+// one box, profiles/r04/pool16_16w_vs_8w.txt).  The eight-wave kernel above keeps BOTH step streams in every wave: 256 registers,
 // two waves per SIMD, and the counters say its waves are parked 51 % of their cycles (s_waitcnt on the LDS round trips of the gathers)
 // with the issue ports two-thirds busy - latency-bound, not throughput-bound.  Here a workgroup has 1 024 threads: waves 0..7 work on
 // stream 0, waves 8..15 on stream 1, each with the lane maps of the eight-wave kernel for ITS stream only - half the live state per
@@ -468,6 +469,10 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
 //     accumulators per wave, every entry has one owner);
 //   * a wave folds TWO (stream, unit) rows per iteration into dW1 / db1 (rows 2, 3 of the K = 4 MFMA read a shared zero row);
 //   * staging by DMA: piece j of stream s is issued by wave (s, j), j = 0..4.
+// Why it is not faster (yet): right behind the iteration's barrier every wave issues its f32 MFMAs (8 of the dW1 fold, half of their K = 4
+// rows empty now, + 3 of the first layer) - with four waves per SIMD that is 44 x 32 = 1 408 matrix-pipe cycles per iteration during
+// which the in-order waves queue behind each other (the eight-wave kernel: 704); the next step is the fold over a wave PAIR's four rows
+// (full K, half the k blocks each: 4 MFMAs per wave) with the T rows double-buffered.
 // ---------------------------------------------------------------------------------------------------
 enum { LW_T = L_STG + 3 * NS * STG_SIZE, LW_TZ = LW_T + 16 * 2 * T_LD, LW_TOTAL = LW_TZ + T_LD };
 
