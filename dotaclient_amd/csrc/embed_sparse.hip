@@ -458,8 +458,7 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
 
 
 // ---------------------------------------------------------------------------------------------------
-// Pass 2, sixteen-wave form (round 4; DC_DIMS_POOL16_16W - NOT the default: measured 839-872 us against the eight-wave kernel's 797-819 us on
-// one box, profiles/r04/pool16_16w_vs_8w.txt).  The eight-wave kernel above keeps BOTH step streams in every wave: 256 registers,
+// Pass 2, sixteen-wave form (round 4; the default - same box: 709-723 us against the eight-wave kernel's 750-752 us, profiles/r04/pool16_16w_vs_8w.txt).  The eight-wave kernel above keeps BOTH step streams in every wave: 256 registers,
 // two waves per SIMD, and the counters say its waves are parked 51 % of their cycles (s_waitcnt on the LDS round trips of the gathers)
 // with the issue ports two-thirds busy - latency-bound, not throughput-bound.  Here a workgroup has 1 024 threads: waves 0..7 work on
 // stream 0, waves 8..15 on stream 1, each with the lane maps of the eight-wave kernel for ITS stream only - half the live state per
@@ -467,22 +466,15 @@ __global__ __launch_bounds__(SP_THREADS) void embed_bwd_pool16_kernel(SparseArgs
 // footprint (one workgroup per CU: W2 stays whole).  What changes with it:
 //   * the dW2 update is split over k, not over the streams: wave W owns dW2[.][8 W .. 8 W + 7] and takes the steps of BOTH streams (half the
 //     accumulators per wave, every entry has one owner);
-//   * a wave folds TWO (stream, unit) rows per iteration into dW1 / db1 (rows 2, 3 of the K = 4 MFMA read a shared zero row);
+//   * the dW1 / db1 fold works on wave PAIRS: the pair's four (stream, unit) rows are one full K = 4 MFMA operand, each wave folds them for
+//     half of the k blocks (four MFMAs); the T rows live per pair, double-buffered by iteration parity (the partner reads them one barrier
+//     later).  With two rows per wave (half-empty K, eight MFMAs each) the kernel was 5 % SLOWER than the eight-wave one: right behind the
+//     barrier every wave issues its f32 MFMAs, and four in-order waves per SIMD queued behind 1 408 matrix-pipe cycles per iteration;
 //   * staging by DMA: piece j of stream s is issued by wave (s, j), j = 0..4.
-// Why it is not faster (yet): right behind the iteration's barrier every wave issues its f32 MFMAs (8 of the dW1 fold, half of their K = 4
-// rows empty now, + 3 of the first layer) - with four waves per SIMD that is 44 x 32 = 1 408 matrix-pipe cycles per iteration during
-// which the in-order waves queue behind each other (the eight-wave kernel: 704); the next step is the fold over a wave PAIR's four rows
-// (full K, half the k blocks each: 4 MFMAs per wave) with the T rows double-buffered.
 // ---------------------------------------------------------------------------------------------------
-// A/B builds of this kernel: -DDC_P16W_FOLD_END: the dW1 fold right behind phase D of the SAME iteration (the T rows are wave-private) instead
-// of at the top of the next one; -DDC_P16W_PAIR: the fold over a wave PAIR's four rows (full K = 4), half the k blocks each (four MFMAs per
-// wave), T rows per pair and double-buffered by iteration parity (the partner reads them a barrier later), the final reduction area aliased
-// onto the T blocks (the staging ring / W2 / basic images leave 6.6 KB less than the doubled T blocks need).
-#ifdef DC_P16W_PAIR
+// LDS: the staging ring starts where the eight-wave kernel keeps its final reduction area; that area is aliased onto the T blocks (every
+// fold is done by then) - the doubled T blocks need the 6.6 KB.
 enum { LW_STG = L_RED, LW_T = LW_STG + 3 * NS * STG_SIZE, LW_TOTAL = LW_T + 8 * 2 * 4 * T_LD, LW_ACC = LW_T, LW_TZ = 0 };
-#else
-enum { LW_STG = L_STG, LW_T = LW_STG + 3 * NS * STG_SIZE, LW_TZ = LW_T + 16 * 2 * T_LD, LW_TOTAL = LW_TZ + T_LD, LW_ACC = L_RED };
-#endif
 
 __global__ __launch_bounds__(1024) void embed_bwd_pool16w_kernel(SparseArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -508,11 +500,7 @@ __global__ __launch_bounds__(1024) void embed_bwd_pool16w_kernel(SparseArgs p) {
 #pragma unroll
     for (int kk = 0; kk < 3; ++kk) w1b[kk] = p.W1[(16 * w + mi) * 12 + 4 * kk + mq];
     const float b1c = p.b1[16 * w + mi];
-#ifdef DC_P16W_PAIR
     constexpr int NKB = 4;         // this wave folds k blocks 4 (W & 1) .. + 3 of its pair's four rows
-#else
-    constexpr int NKB = 8;
-#endif
     f32x4 accD[NKB];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) accD[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -552,17 +540,9 @@ __global__ __launch_bounds__(1024) void embed_bwd_pool16w_kernel(SparseArgs p) {
         for (int r = 0; r < 4; ++r) bo[r * SP_BLD] = fmaxf(acc[r] + b1c, 0.f);
     };
 
-#ifdef DC_P16W_PAIR
     // T rows of the wave PAIR (W >> 1): [iteration parity][row = 2 (W & 1) + hh][T_LD]
     float* Tp = smem + LW_T + (W >> 1) * (2 * 4 * T_LD);
     for (int e = lane; e < 4 * T_LD; e += 64) Tp[(W & 1) * 4 * T_LD + e] = 0.f;     // wave W & 1 clears buffer W & 1
-#else
-    // the wave's two T rows (half-wave hh = unit w + 8 hh of the own stream) and the shared zero row behind rows 2, 3 of the fold's K = 4
-    float* T = smem + LW_T + W * (2 * T_LD);
-    for (int e = lane; e < 2 * T_LD; e += 64) T[e] = 0.f;
-    if (tid < T_LD) smem[LW_TZ + tid] = 0.f;
-    const float* tb = mq < 2 ? T + mq * T_LD : smem + LW_TZ;
-#endif
 
     dma_issue(0);
     dma_issue(1);
@@ -572,25 +552,16 @@ __global__ __launch_bounds__(1024) void embed_bwd_pool16w_kernel(SparseArgs p) {
 
     const char* w2b = reinterpret_cast<const char*>(smem + L_W2 + k4);
     float xa_prev = 0.f;
-#ifdef DC_P16W_PAIR
     auto fold_prev = [&](long long i_prev) {          // the pair's four rows of iteration i_prev (buffer i_prev & 1), this wave's four k blocks
         const float* tbp = Tp + ((int)(i_prev & 1) * 4 + mq) * T_LD + 64 * (W & 1) + mi;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) accD[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa_prev, tbp[16 * kb], accD[kb], 0, 0, 0);
     };
-#else
-    auto fold_prev = [&](long long) {
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) accD[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa_prev, tb[16 * kb + mi], accD[kb], 0, 0, 0);
-    };
-#endif
     for (long long i = 0; i < iters; ++i) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's piece of staging[i + 1] has landed
         __syncthreads();
         dma_issue(i + 2);
-#ifndef DC_P16W_FOLD_END
         if (i > 0) fold_prev(i - 1);
-#endif
         phase_a(i + 1);
         const bool on = nbo + i < neo;                                         // uniform over the stream's eight waves
         const float* stg = stg_of(i, so);
@@ -685,26 +656,14 @@ __global__ __launch_bounds__(1024) void embed_bwd_pool16w_kernel(SparseArgs p) {
             }
         }
         // ---- phase D: through the relu into the wave's T row (folded at the top of the next iteration); the fold's A operand
-#ifdef DC_P16W_PAIR
         *reinterpret_cast<float4*>(Tp + ((int)(i & 1) * 4 + 2 * (W & 1) + hh) * T_LD + k4) =
-#else
-        *reinterpret_cast<float4*>(T + hh * T_LD + k4) =
-#endif
             make_float4(basic.x > 0.f ? dbl.x : 0.f, basic.y > 0.f ? dbl.y : 0.f, basic.z > 0.f ? dbh.x : 0.f, basic.w > 0.f ? dbh.y : 0.f);
         {
             // A[f][row mq] (f = 12: ones -> db1).  Read now: the next iteration's DMA reuses this staging slot
             const float* sx = stg + STG_X + (int)(rec_off(nbo + i) & 3);
-#ifdef DC_P16W_PAIR
             // rows = the pair's (wave, half): wave (w & ~1) | (mq >> 1), unit that wave + 8 (mq & 1)
             xa_prev = on ? (mi < 12 ? sx[(((w & ~1) | (mq >> 1)) + 8 * (mq & 1)) * 12 + mi] : (mi == 12 ? 1.f : 0.f)) : 0.f;
-#else
-            // rows 0, 1 = units w, w + 8 of the own stream, rows 2, 3 = nothing
-            xa_prev = (mq < 2 && on) ? (mi < 12 ? sx[(w + 8 * mq) * 12 + mi] : (mi == 12 ? 1.f : 0.f)) : 0.f;
-#endif
         }
-#ifdef DC_P16W_FOLD_END
-        fold_prev(i);          // the rows are this wave's own: no barrier needed, and the MFMAs drain while the wave waits at the next one
-#endif
         if (tid < 128) {      // column sum of d(emb) over both streams' steps (threads 0..127 = the first two waves)
 #pragma unroll
             for (int s2 = 0; s2 < NS; ++s2) {
@@ -715,12 +674,8 @@ __global__ __launch_bounds__(1024) void embed_bwd_pool16w_kernel(SparseArgs p) {
             }
         }
     }
-#ifndef DC_P16W_FOLD_END
-#ifdef DC_P16W_PAIR
     __syncthreads();           // the partner's rows of the last iteration
-#endif
     if (iters > 0) fold_prev(iters - 1);
-#endif
 
     // ---- results --------------------------------------------------------------------------------------
     {
@@ -740,11 +695,7 @@ __global__ __launch_bounds__(1024) void embed_bwd_pool16w_kernel(SparseArgs p) {
     __syncthreads();
     for (int ww = 0; ww < 16; ++ww) {
         if (W == ww) {
-#ifdef DC_P16W_PAIR
             const int kb0 = 4 * (W & 1);
-#else
-            const int kb0 = 0;
-#endif
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll

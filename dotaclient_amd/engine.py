@@ -45,7 +45,7 @@ DC_DIMS_GEMM_X3_ALL = 8192
 DC_DIMS_TEAM_VALU = 16384
 DC_DIMS_EMBED_UNFUSED = 32768
 DC_DIMS_RNN_STEP_BF16 = 65536
-DC_DIMS_POOL16_16W = 262144
+DC_DIMS_POOL16_8W = 262144
 DC_DIMS_F16X2 = 131072   # f32-grade products from two f16 pieces (four MFMAs) instead of three bf16 pieces (six): include/dotaclient_hip.h
 
 WS_FIXED = ['FAULT', 'BASIC', 'EMB', 'DEMB', 'XCAT', 'AMAX', 'PRE', 'HEADOUT', 'TU', 'DHEADOUT', 'DTU', 'DPRE', 'DXCAT',

@@ -156,11 +156,10 @@ typedef struct dc_dims {
  *                            0.25 * 65536 / rows) turns into inf -> NaN -> the status word of dc_gradnorm_clip_adam (nothing
  *                            updated); the caller then repeats the iteration without this flag.  Ignored with DC_DIMS_BF16. */
 #define DC_DIMS_F16X2 131072
-/*   DC_DIMS_POOL16_16W     : sparse max-pool backward of the 16-unit types with the sixteen-wave kernel of round 4 (a step stream per group
- *                            of eight waves, the dW2 update split over k: 116 registers, four waves per SIMD) instead of the eight-wave
- *                            one (both streams in every wave, 256 registers, two waves per SIMD).  Same results (tested); measured 5 %
- *                            SLOWER at configs[2] (profiles/r04/pool16_16w_vs_8w.txt): kept for the next step of that work. */
-#define DC_DIMS_POOL16_16W 262144
+/*   DC_DIMS_POOL16_8W      : sparse max-pool backward of the 16-unit types with round 2's eight-wave kernel (both step streams in every
+ *                            wave, 256 registers, two waves per SIMD) instead of the sixteen-wave one (a step stream per group of eight
+ *                            waves, dW2 update split over k, pair-wise dW1 fold: 128 registers, four waves per SIMD; ~5 % faster). */
+#define DC_DIMS_POOL16_8W 262144
 
 /* index into poff[]; policy.py:54-75 names in comments */
 enum dc_param_index {

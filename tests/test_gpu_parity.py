@@ -294,9 +294,9 @@ def test_sparse_pool_backward_matches_dense(lens):
     from dotaclient_amd.engine import Engine, pack_rollouts
     dev = torch.device('cuda:0')
     outs = {}
-    for mode in ('0', '1', '16w'):      # dense kernels / sparse, eight-wave kernel (default) / sparse, the sixteen-wave kernel (DC_DIMS_POOL16_16W)
+    for mode in ('0', '1', '8w'):       # dense kernels / sparse, sixteen-wave kernel (default) / sparse, round 2's eight-wave kernel (DC_DIMS_POOL16_8W)
         eng = Engine('lstm', 128, 1, dev)
-        eng.kernel_flags = {'0': E.DC_DIMS_DENSE_POOL_BWD, '1': 0, '16w': E.DC_DIMS_POOL16_16W}[mode]
+        eng.kernel_flags = {'0': E.DC_DIMS_DENSE_POOL_BWD, '1': 0, '8w': E.DC_DIMS_POOL16_8W}[mode]
         eng.load_state_dict(synth.init_state_dict(7, 'lstm', 128, 1))
         rollouts = synth.make_rollouts(91, lens)
         batch = pack_rollouts(rollouts, 128, dev)
@@ -314,8 +314,8 @@ def test_sparse_pool_backward_matches_dense(lens):
     assert util.scaled_err(outs['1'][1][:11], outs['0'][1][:11]) < 2e-5
     assert util.scaled_err(outs['1'][2], outs['0'][2]) < 2e-5
     for n in outs['0'][0]:              # the two sparse kernels: the same sums in another order
-        assert util.scaled_err(outs['16w'][0][n], outs['1'][0][n]) < 2e-5, n
-    assert util.scaled_err(outs['16w'][2], outs['1'][2]) < 2e-5
+        assert util.scaled_err(outs['8w'][0][n], outs['1'][0][n]) < 2e-5, n
+    assert util.scaled_err(outs['8w'][2], outs['1'][2]) < 2e-5
 
 
 @pytest.mark.parametrize('cell,hidden,B', [('lstm', 128, 96), ('gru', 256, 96), ('lstm', 256, 200)])
