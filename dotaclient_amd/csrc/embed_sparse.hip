@@ -529,8 +529,10 @@ __global__ __launch_bounds__(1024) void embed_bwd_pool16w_kernel(SparseArgs p) {
         }
     };
     auto bas_of = [&](long long i, int s2) { return smem + L_BAS + ((int)(i & 1) * NS + s2) * 16 * SP_BLD; };
-    auto phase_a = [&](long long i) {             // basic[all units][16w .. 16w + 15] of the own stream's step of iteration i
-        if (nbo + i >= neo) return;
+    // FULL (here and in the loop body): both streams have a step in this iteration and the next, known at compile time - no uniform
+    // branch splits the body into scheduling regions, so the f32 MFMAs of the fold / first layer can be placed among the gathers
+    auto phase_a = [&](long long i, auto full_c) {   // basic[all units][16w .. 16w + 15] of the own stream's step of iteration i
+        if (!decltype(full_c)::value && nbo + i >= neo) return;
         const float* xs = stg_of(i, so) + STG_X + (int)(rec_off(nbo + i) & 3) + mi * 12 + mq;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(1024) void embed_bwd_pool16w_kernel(SparseArgs p) {
     dma_issue(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();          // W2 / staging[0], staging[1] / T
-    phase_a(0);
+    phase_a(0, std::false_type{});
 
     const char* w2b = reinterpret_cast<const char*>(smem + L_W2 + k4);
     float xa_prev = 0.f;
@@ -557,13 +559,14 @@ __global__ __launch_bounds__(1024) void embed_bwd_pool16w_kernel(SparseArgs p) {
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) accD[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa_prev, tbp[16 * kb], accD[kb], 0, 0, 0);
     };
-    for (long long i = 0; i < iters; ++i) {
+    auto iteration = [&](long long i, auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's piece of staging[i + 1] has landed
         __syncthreads();
         dma_issue(i + 2);
-        if (i > 0) fold_prev(i - 1);
-        phase_a(i + 1);
-        const bool on = nbo + i < neo;                                         // uniform over the stream's eight waves
+        fold_prev(i - 1);                                      // (iteration 0: both T buffers are zero)
+        phase_a(i + 1, full_c);
+        const bool on = FULL || nbo + i < neo;                                 // uniform over the stream's eight waves
         const float* stg = stg_of(i, so);
         const bool live = on && reinterpret_cast<const int*>(stg)[STG_FLAG] != 0;
         f32x2 dbl = mk2(0.f, 0.f), dbh = mk2(0.f, 0.f);       // d(basic)[u_own][k4, k4 + 1] and [k4 + 2, k4 + 3]
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(1024) void embed_bwd_pool16w_kernel(SparseArgs p) {
         // phase B, channel per lane, BOTH streams: D[h][j] += d[c] * basic[a(c)][8 W + 2 j .. + 1], c = lane + 64 h
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) {
-            if (nb[s2] + i >= ne[s2]) continue;                                   // workgroup-uniform
+            if (!FULL && nb[s2] + i >= ne[s2]) continue;                          // workgroup-uniform
             const float* sg = stg_of(i, s2);
             const char* brow = reinterpret_cast<const char*>(bas_of(i, s2)) + W * 32;
 #pragma unroll
@@ -608,6 +611,18 @@ __global__ __launch_bounds__(1024) void embed_bwd_pool16w_kernel(SparseArgs p) {
                 }
             };
             for_consts(slot, std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>{});
+#ifdef DC_P16W_SCHED
+            // A/B build: ask the scheduler to SPREAD the seven f32 MFMAs of this block (four of the fold, three of the first layer) through
+            // its vector / LDS instructions instead of issuing them close together behind the barrier: with four waves per SIMD at the
+            // same point of the same code, back-to-back MFMAs of one wave wait for the other three's
+            if constexpr (FULL) {
+#pragma unroll
+                for (int gsb = 0; gsb < 7; ++gsb) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002 | 0x100 | 0x200, DC_P16W_SCHED, 0);
+                }
+            }
+#endif
             const int cmax = max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 32));
             if (cmax > 8) for_consts(slot, std::integer_sequence<int, 8, 9, 10, 11>{});     // wave-uniform
             for (int j = SP_SLOTS; j < cmax; ++j) {
@@ -629,7 +644,7 @@ __global__ __launch_bounds__(1024) void embed_bwd_pool16w_kernel(SparseArgs p) {
         // 8 W .. 8 W + 7: lane (u = lane & 15, g = lane >> 4; g < 2) takes dtu[u] * basic[u][8 W + 4 g .. + 3], sixteen-lane DPP sums
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) {
-            if (nb[s2] + i >= ne[s2]) continue;
+            if (!FULL && nb[s2] + i >= ne[s2]) continue;
             const float* sg = stg_of(i, s2);
             if (reinterpret_cast<const int*>(sg)[STG_FLAG] == 0) continue;        // workgroup-uniform
             {
@@ -667,12 +682,18 @@ __global__ __launch_bounds__(1024) void embed_bwd_pool16w_kernel(SparseArgs p) {
         if (tid < 128) {      // column sum of d(emb) over both streams' steps (threads 0..127 = the first two waves)
 #pragma unroll
             for (int s2 = 0; s2 < NS; ++s2) {
-                if (nb[s2] + i >= ne[s2]) continue;
+                if (!FULL && nb[s2] + i >= ne[s2]) continue;
                 const float* sg = stg_of(i, s2);
                 const bool lv = reinterpret_cast<const int*>(sg)[STG_FLAG] != 0;
                 db2a += sg[STG_PB + 2 * tid] + (lv ? sg[STG_Q + tid] * sg[STG_DT + 16] : 0.f);
             }
         }
+    };
+    {
+        const long long full = ne[1] - nb[1];       // stream 1 has as many steps as stream 0 or one fewer
+        long long i = 0;
+        for (; i + 1 < full; ++i) iteration(i, std::true_type{});
+        for (; i < iters; ++i) iteration(i, std::false_type{});
     }
     __syncthreads();           // the partner's rows of the last iteration
     if (iters > 0) fold_prev(iters - 1);
