@@ -151,51 +151,6 @@ struct FwdProduct {
     }
 };
 
-// FwdProduct<128> in two parts (rnn_team_mfma.hip, round 4): part 1 = the MFMAs on A registers 0 and 1 (the first 8 bytes of a lane's
-// 32-byte chunk: k positions 8 b + {0, 1}), part 2 = registers 2..7.  The team kernel lays its LDS image out so that positions
-// 8 b + {0, 1} of every block are the member's OWN 32 units of the k half: part 1 runs on what is local while the peers' granules are
-// still in flight.  Hooks 0..15 fall into part 1, 16..63 into part 2.
-struct FwdProductSplit128 {
-    struct Regs { float2 ra, rb; float4 r1; };
-    template <int J>
-    static __device__ __forceinline__ const float& areg(const Regs& r) {
-        if constexpr (J == 0) return r.ra.x;
-        else if constexpr (J == 1) return r.ra.y;
-        else if constexpr (J == 2) return r.rb.x;
-        else if constexpr (J == 3) return r.rb.y;
-        else if constexpr (J == 4) return r.r1.x;
-        else if constexpr (J == 5) return r.r1.y;
-        else if constexpr (J == 6) return r.r1.z;
-        else return r.r1.w;
-    }
-    template <int K2, class Hook>
-    static __device__ __forceinline__ void quad(const Regs& r, f32x4 (&acc)[4], const float (&w0)[128], const float (&w1)[128], Hook& hook) {
-        constexpr int k = 2 * K2;
-        mfma_pair_same<k == 0, k & 15>(acc[0], acc[1], areg<(k >> 4)>(r), w0[k], w1[k]);
-        mfma_pair_same<k == 0, (k + 1) & 15>(acc[2], acc[3], areg<((k + 1) >> 4)>(r), w0[k + 1], w1[k + 1]);
-        hook(std::integral_constant<int, K2>{});
-    }
-    template <int BASE, class Hook, int... Ks>
-    static __device__ __forceinline__ void quads(const Regs& r, f32x4 (&acc)[4], const float (&w0)[128], const float (&w1)[128], Hook& hook,
-                                                 std::integer_sequence<int, Ks...>) {
-        (quad<BASE + Ks>(r, acc, w0, w1, hook), ...);
-    }
-    template <class Hook>
-    static __device__ __forceinline__ void part1(Regs& r, f32x4 (&acc)[4], const float (&w0)[128], const float (&w1)[128], uint32_t addr, Hook& hook) {
-        asm volatile("ds_read_b64 %0, %1" : "=v"(r.ra) : "v"(addr));
-        wait_lgkm<0>();
-        quads<0>(r, acc, w0, w1, hook, std::make_integer_sequence<int, 16>{});
-    }
-    template <class Hook>
-    static __device__ __forceinline__ void part2(Regs& r, f32x4 (&acc)[4], const float (&w0)[128], const float (&w1)[128], uint32_t addr, Hook& hook) {
-        asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(r.rb) : "v"(addr));
-        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(r.r1) : "v"(addr));
-        wait_lgkm<0>();
-        quads<16>(r, acc, w0, w1, hook, std::make_integer_sequence<int, 48>{});
-        mfma_tail_pad(acc[0], acc[1], acc[2], acc[3]);
-    }
-};
-
 template <int KH>
 struct BwdProduct {
     // the two wave halves contract different k ranges, so the broadcast stays inside a half (cbsz:3):

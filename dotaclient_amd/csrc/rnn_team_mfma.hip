@@ -42,23 +42,8 @@ enum { TM_H = TEAM_H, TM_KH = 128, TM_HLD = TM_KH + 4, TM_THREADS = 256 };
 // into the registers in that order (tm_korder), once, and the per-step LDS stores of h (consecutive lanes = consecutive
 // units) are consecutive words instead of the 8-word stride of rnn_persist.hip's broadcast order (measured there: 48 % of
 // the LDS cycles were bank conflicts).
-// (backward / round 3 forward: [k half = k >> 7][seq][k & 127])
 __device__ __forceinline__ int tm_hpos(int seq, int k) { return ((k >> 7) * 4 + seq) * TM_HLD + (k & 127); }
 __device__ __forceinline__ constexpr int tm_korder(int kk) { return 8 * (kk & 15) + (kk >> 4); }
-// Round 4, forward: OWN UNITS FIRST.  The two k halves are cut through every member's 64 units (half = bit 5 of the unit's index inside
-// its member), and inside a half the position of hidden unit j (member mj = j >> 6, i = j & 31) is 8 (i >> 1) + 2 rel + (i & 1) with
-// rel = (mj - member) & 3: positions 8 b + {0, 1} of every broadcast block b - the A registers 0 and 1, i.e. the FIRST 32 MFMA pairs of
-// the product phase - are the member's own 32 units of that half.  They are in LDS one barrier after the cells produced them, so a
-// quarter of the next step's product runs while the peers' granules are still in flight (FwdProductSplit128, persist_util.h).
-__device__ __forceinline__ int tmf_pos(int member, int j) {
-    const int i = j & 31, rel = ((j >> 6) - member) & 3;
-    return 8 * (i >> 1) + 2 * rel + (i & 1);
-}
-__device__ __forceinline__ int tmf_hpos(int member, int seq, int j) { return (((j >> 5) & 1) * 4 + seq) * TM_HLD + tmf_pos(member, j); }
-// hidden unit at position p of k half kh, as seen by `member`
-__device__ __forceinline__ int tmf_unit(int member, int kh, int p) {
-    return 64 * ((member + ((p & 7) >> 1)) & 3) + 32 * kh + 2 * (p >> 3) + (p & 1);
-}
 
 template <int CELL>     // 1: LSTM, 0: GRU
 __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_kernel(RnnStepArgs p, u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
@@ -84,13 +69,10 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_kernel(RnnStepArg
     float w0[TM_KH], w1[TM_KH];
     {
         const bool has1 = 2 * hi + 1 < G;              // the GRU has no gate 3: zero weights in that slot
-        const float* r0 = p.Whh + (size_t)((2 * hi + 0) * H + u) * H;
-        const float* r1 = p.Whh + (size_t)((has1 ? 2 * hi + 1 : 0) * H + u) * H;
+        const float* r0 = p.Whh + (size_t)((2 * hi + 0) * H + u) * H + TM_KH * kh;
+        const float* r1 = p.Whh + (size_t)((has1 ? 2 * hi + 1 : 0) * H + u) * H + TM_KH * kh;
 #pragma unroll
-        for (int kk = 0; kk < TM_KH; ++kk) {
-            const int j = tmf_unit(member, kh, tm_korder(kk));       // MFMA kk contracts position tm_korder(kk) of this wave's k half
-            w0[kk] = r0[j]; w1[kk] = has1 ? r1[j] : 0.f;
-        }
+        for (int kk = 0; kk < TM_KH; ++kk) { w0[kk] = r0[tm_korder(kk)]; w1[kk] = has1 ? r1[tm_korder(kk)] : 0.f; }
     }
     float bh[4];
 #pragma unroll
@@ -117,7 +99,7 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_kernel(RnnStepArg
         for (int e = tid; e < 4 * H; e += TM_THREADS) {
             const int q = e >> 8, j = e & (H - 1);
             const int bq = q == 0 ? bmap[0] : (q == 1 ? bmap[1] : (q == 2 ? bmap[2] : bmap[3]));
-            h_lds[0][tmf_hpos(member, q, j)] = p.h0 ? p.h0[(size_t)bq * H + j] : 0.f;
+            h_lds[0][tm_hpos(q, j)] = p.h0 ? p.h0[(size_t)bq * H + j] : 0.f;
         }
         float xc[4] = {0.f, 0.f, 0.f, 0.f}, xn[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -125,11 +107,7 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_kernel(RnnStepArg
         u64* const xb = xbuf + (size_t)(team * 4 + slot) * (TEAM_SLOTS * H);      // ring of this lane's sequence slot
         __syncthreads();
 
-        // first reads of the three peers' granules of the step just published: issued at the END of a step, waited for in the MIDDLE of
-        // the next one - behind the part of its product that needs nothing from the peers (part 1: the member's own units)
-        u64 gr[3] = {0, 0, 0};
-        auto peer_addr = [&](unsigned tg, int j) { return xb + (tg & 3) * H + TEAM_US * ((member + j) & 3) + ul; };
-        auto step = [&](const int t, const bool first, float (&xcur)[4], float (&xnext)[4], auto CUR) {
+        auto step = [&](const int t, float (&xcur)[4], float (&xnext)[4], auto CUR) {
             constexpr int cur = decltype(CUR)::value;
             const bool on = t < len, on1 = t + 1 < len;
             const unsigned gnx = goff + (on1 ? GH : 0);
@@ -139,11 +117,9 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_kernel(RnnStepArg
             float* const hs = p.hseq + st_s;
             float* const cp = LSTM ? p.cprev + st_p : nullptr;
             float* const hp = p.hprev + st_p;
-            // between the MFMA pairs of PART 2 (hooks 16 ..): the loads of the next step's gate pre-activations, the stores of the previous
-            // step's results.  Not in part 1: vector memory operations complete in order, so anything issued between the granule reads
-            // and their wait in the middle of the step would have to land by then as well (the gate rows come from HBM)
+            // between the MFMA pairs: the loads of the next step's gate pre-activations, the stores of the previous step's results
             auto hook = [&](auto K) {
-                constexpr int k = decltype(K)::value - 16;     // part 2: 0 .. 47
+                constexpr int k = decltype(K)::value;          // 0 .. 63
                 if constexpr (k >= 1 && k <= G) xnext[k - 1] = lp[(k - 1) * H];
                 else if constexpr (k >= 8 && k < 8 + G) gs[(k - 8) * H] = sv[k - 8];
                 else if constexpr (k == 12) *cs = sv[LSTM ? 4 : 3];
@@ -152,25 +128,12 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_kernel(RnnStepArg
                 else if constexpr (k == 15) *hp = svp1;
             };
             f32x4 pa[4];
-            FwdProductSplit128::Regs ar;
-            const uint32_t a_addr = lds_addr(&h_lds[cur][(kh * 4 + (lane & 3)) * TM_HLD + (lane >> 2) * 8]);
-            // ---- part 1: the member's own 32 units of this k half (already in h_lds[cur]: written before the previous step's last barrier)
-            FwdProductSplit128::part1(ar, pa, w0, w1, a_addr, hook);
-            // ---- the same unit index of the three other members, same sequence, of the PREVIOUS step -> LDS (a group's first step
-            // starts from h0, which every member read from memory itself)
-            if (!first) {
-                const u64* ga[3] = {peer_addr(tag, 1), peer_addr(tag, 2), peer_addr(tag, 3)};
-                if (!granule_wait_all<3>(gr, ga, tag)) { dead = 1; team_report_timeout(p.fault, TEAM_K_MFMA_FWD, p.layer, team, member, t, b, tag); }
-#pragma unroll
-                for (int j = 1; j < TEAM_M; ++j)
-                    h_lds[cur][tmf_hpos(member, slot, TEAM_US * ((member + j) & 3) + ul)] = __uint_as_float((unsigned)gr[j - 1]);
-                __syncthreads();
-            }
-            // ---- part 2: the peers' units
-            FwdProductSplit128::part2(ar, pa, w0, w1, a_addr, hook);
+            FwdProduct<TM_KH>::run(pa, w0, w1, lds_addr(&h_lds[cur][(kh * 4 + (lane & 3)) * TM_HLD + (lane >> 2) * 8]), hook);
             f32x4 acc0 = pa[0] + pa[2], acc1 = pa[1] + pa[3];   // gate columns 2 hi, 2 hi + 1 of the four sequences, this k half
             // ---- k halves: hand the partner the partial sums of ITS two sequences, add its partials of mine -----------
+            const int other = 2 * (kh ^ 1);
             xch[kh][ub][lane] = kh ? make_float4(acc0[0], acc0[1], acc1[0], acc1[1]) : make_float4(acc0[2], acc0[3], acc1[2], acc1[3]);
+            (void)other;
             __syncthreads();
             const float4 pr = xch[kh ^ 1][ub][lane];
             float y0 = (kh ? acc0[2] : acc0[0]) + pr.x, x0 = (kh ? acc0[3] : acc0[1]) + pr.y;      // gate 2 hi     of sequences 2 kh, 2 kh + 1
@@ -188,7 +151,7 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_kernel(RnnStepArg
             const float hpub = on ? hn : 0.f;
             ++tag;
             granule_store(xb + (tag & 3) * H + u, hpub, tag, plain);      // publish first: the peers are waiting for it
-            h_lds[cur ^ 1][tmf_hpos(member, slot, u)] = hpub;
+            h_lds[cur ^ 1][tm_hpos(slot, u)] = hpub;
             c = on ? cn : c;
             sv[0] = on ? ig : sv[0]; sv[1] = on ? fg : sv[1]; sv[2] = on ? gg : sv[2];
             sv[3] = on ? og : sv[3]; sv[4] = on ? cn : sv[4]; sv[5] = on ? hn : sv[5];
@@ -199,17 +162,26 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_kernel(RnnStepArg
             st_p = on1 ? soff + H : st_p;
             goff = gnx;
             soff += on1 ? H : 0;
-            // ---- first reads of the peers' granules of THIS step: they fly during the barrier and part 1 of the next step
+            // ---- the same unit index of the three other members, same sequence -> LDS ------------------------------------
             if (t + 1 < tmax) {
+                u64 gr[3];
+                const u64* ga[3];
 #pragma unroll
-                for (int j = 1; j < TEAM_M; ++j) gr[j - 1] = granule_load(peer_addr(tag, j));
+                for (int j = 1; j < TEAM_M; ++j) {
+                    ga[j - 1] = xb + (tag & 3) * H + TEAM_US * ((member + j) & 3) + ul;
+                    gr[j - 1] = granule_load(ga[j - 1]);
+                }
+                if (!granule_wait_all<3>(gr, ga, tag)) { dead = 1; team_report_timeout(p.fault, TEAM_K_MFMA_FWD, p.layer, team, member, t, b, tag); }
+#pragma unroll
+                for (int j = 1; j < TEAM_M; ++j)
+                    h_lds[cur ^ 1][tm_hpos(slot, TEAM_US * ((member + j) & 3) + ul)] = __uint_as_float((unsigned)gr[j - 1]);
             }
-            __syncthreads();            // own h_t of all four waves is in h_lds[cur ^ 1]; xch may be rewritten
+            __syncthreads();
             return dead == 0;
         };
         for (int t = 0; t < tmax; t += 2) {
-            if (!step(t, t == 0, xc, xn, std::integral_constant<int, 0>{})) { failed = true; break; }
-            if (t + 1 < tmax && !step(t + 1, false, xn, xc, std::integral_constant<int, 1>{})) { failed = true; break; }
+            if (!step(t, xc, xn, std::integral_constant<int, 0>{})) { failed = true; break; }
+            if (t + 1 < tmax && !step(t + 1, xn, xc, std::integral_constant<int, 1>{})) { failed = true; break; }
         }
         // drain: the deferred stores of the group's last step
 #pragma unroll
