@@ -50,8 +50,9 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f
 # f32-grade products by exact 3-way bf16 splitting execute SIX bf16 MFMAs per f32 product (gemm_tiles.h): the matrix pipes'
 # ceiling for ALGORITHMIC f32 flops on that path
 PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
-# ... and with TWO f16 pieces per operand (Engine.products 'f16x2', the default: csrc/gemm_x3.hip PREC = 4) FOUR f16 MFMAs (same rate as bf16)
-PEAK_X2H_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 4.0
+# ... and with TWO f16 pieces per operand (Engine.products 'f16x2', the default: csrc/gemm_x3.hip PREC = 4) THREE f16 MFMAs (same rate as bf16):
+# hh, hm, mh - the m*m term is below what the two pieces can represent anyway (csrc/gemm_tiles.h, DC_X2H_MM)
+PEAK_X2H_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 PRODUCTS = 'f16x2'        # --products
 PEAK_HBM_GBS = 8000.0
 
@@ -260,9 +261,11 @@ def parity_report(got, ref, tol=1e-4, argmax_min_equal=None, sub_batch=None):
 # what bounds each timed region (the rates in `kernels` are priced against that resource's peak)
 # peak (TFLOP/s of algorithmic f32 flops) of the MFMA-bound regions.  The embedding kernels regenerate their first layer
 # (K = 12 of the 12 + 128, resp. 24 of 24 + 128 flops per output) with f32 MFMAs and run the 128 x 128 layer as x3 products:
-# time-weighted harmonic peak.
+# time-weighted harmonic peak.  With the f16x2 products the first layer runs on the f16 MFMAs as well: the plain f16x2 ceiling.
 def _mixed_peak(f32_share):
-    grade = PEAK_X2H_TFLOPS if PRODUCTS == 'f16x2' else PEAK_X3_TFLOPS
+    if PRODUCTS == 'f16x2':
+        return PEAK_X2H_TFLOPS
+    grade = PEAK_X3_TFLOPS
     return 1.0 / (f32_share / PEAK_F32_MFMA_TFLOPS + (1.0 - f32_share) / grade)
 
 
@@ -293,10 +296,10 @@ REGION_BOUND = {
 }
 BOUND_NOTES = {
     'mfma': 'f32-grade products on the 16-bit matrix cores: every f32 operand is split into two f16 pieces (x 2^s = h + m, 23 of the 24 '
-            'significand bits; fixed power-of-two pre-scales) and a product is four v_mfma_f32_32x32x16_f16 (Engine.products f16x2, the '
+            'significand bits; fixed power-of-two pre-scales) and a product is three v_mfma_f32_32x32x16_f16 (hh, hm, mh; Engine.products f16x2, the '
             'default; gemm_x3.hip PREC 4) - or into three bf16 pieces and six MFMAs (--products bf16x3); `achieved` = ALGORITHMIC f32 '
-            'flops / time, `peak` = the dense 16-bit MFMA peak / 4 = 625 TF (/ 6 = 416.7 TF for bf16x3; less for the embedding kernels, '
-            'whose K = 12 first layer is regenerated with f32 MFMAs), so `frac` is the share of the matrix pipes\' capacity on this path; '
+            'flops / time, `peak` = the dense 16-bit MFMA peak / 3 = 833 TF (/ 6 = 416.7 TF for bf16x3, where the embedding kernels\' K = 12 first layer '
+            'is regenerated with f32 MFMAs and priced so), so `frac` is the share of the matrix pipes\' capacity on this path; '
             '`frac_of_f32_mfma_peak` prices the same rate against the 157.3 TF of the f32-input MFMA the products would otherwise run on',
     'valu': 'packed-f32 VALU kernel (per-channel-scaled gathers of 512-byte W2 / basic rows; 1/16 of the dense MACs): priced against '
             'the f32 VALU peak, which equals the f32 MFMA peak (157.3 TF at 2.4 GHz); what limits it is VALU issue and LDS '
@@ -400,7 +403,7 @@ def parse_args():
     ap.add_argument('--extras-out', default=os.path.join(REPO, 'gpurun_out', 'bench_extras.json'))
     ap.add_argument('--kernel-flags', type=int, default=0, help='DC_DIMS_* kernel-selection overrides (A/B measurements)')
     ap.add_argument('--products', default='f16x2', choices=['f16x2', 'bf16x3'],
-                    help='form of the f32-grade products (Engine.products): two f16 pieces / four MFMAs (default) or three bf16 pieces / six MFMAs')
+                    help='form of the f32-grade products (Engine.products): two f16 pieces / three MFMAs (default) or three bf16 pieces / six MFMAs')
     ap.add_argument('--epoch-graph', type=int, default=0, help='1: replay each epoch as ONE hipGraph launch (single GPU), 0: eager launches')
     ap.add_argument('--traffic-json', default=os.path.join(REPO, 'profiles', 'pmc_traffic_latest.json'),
                     help='per-kernel HBM bytes from the rocprofv3 PMC passes (tools/gpu_round.sh + tools/pmc_traffic.py); '
@@ -608,7 +611,7 @@ def main():
                           '(matrix products, products=%s: %s; measured against f64 on the network\'s shapes: f16x2 1.2e-7..4.9e-7, bf16x3 1.4e-7..5.5e-7 of '
                           'max |C|, the f32 fma chain 2.1e-7..3.7e-7 - tools/ubench/gemm_x3.hip, profiles/r04/ubench_gemm_f16_pieces.txt); '
                           '`parity` checks the whole step against the fp32 oracle at 1e-4'
-                          % (PRODUCTS, 'two f16 pieces per f32 operand (23 of 24 significand bits) with power-of-two pre-scales, four f16 MFMAs, f32 '
+                          % (PRODUCTS, 'two f16 pieces per f32 operand (23 of 24 significand bits) with power-of-two pre-scales, three f16 MFMAs (hh, hm, mh), f32 '
                                        'accumulate; an operand outside f16\'s exponent range trips the NaN guard and the consumer loop repeats the '
                                        'iteration with the bf16 pieces' if PRODUCTS == 'f16x2' else
                                        'exact 3-way bf16 splits of both f32 operands, six bf16 MFMAs, f32 accumulate'),

@@ -87,7 +87,7 @@ __device__ __forceinline__ const float* ef_record(const float* __restrict__ obs,
 // ---------------------------------------------------------------------------------------------------
 // BPL: W2 arrives as pre-split bf16 planes W2p [3][6 x 128][128] (split_weight_planes, once per pass) and goes to LDS as such:
 // its fragments need no split in the K loop (half of the loop's VALU work)
-// F16 (DC_DIMS_F16X2, needs BPL): the 128 x 128 layer from two f16 pieces per operand and four MFMAs (gemm_x3.hip, PREC = 4).  W2p then
+// F16 (DC_DIMS_F16X2, needs BPL): the 128 x 128 layer from two f16 pieces per operand and three MFMAs (gemm_x3.hip, PREC = 4).  W2p then
 // holds [2] f16 planes of W2 * 2^8, and the A operand is generated pre-scaled: basic * s_act = relu(x (W1 s_act)^T + b1 s_act) - exact
 // for a power of two - so neither operand needs a multiply in the K loop; emb = acc * inv + b2.
 template <bool TIMING, bool BPL, bool F16 = false>   // TIMING (DC_DEV_TIMING build): s_memtime phase sums of wave 0 of every workgroup -> dbg[wg][4]
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
             const f16x8 xm = __builtin_bit_cast(f16x8, u32x4{__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])});
             const f16x8 wh = *reinterpret_cast<const f16x8*>(w1p + (32 * kt + fr) * 32 + fq * 16);
             const f16x8 wm = *reinterpret_cast<const f16x8*>(w1p + 4096 + (32 * kt + fr) * 32 + fq * 16);
-            g = __builtin_amdgcn_mfma_f32_32x32x16_f16(xm, wm, g, 0, 0, 0);
+            DC_X2H_MM(g = __builtin_amdgcn_mfma_f32_32x32x16_f16(xm, wm, g, 0, 0, 0);)
             g = __builtin_amdgcn_mfma_f32_32x32x16_f16(xm, wh, g, 0, 0, 0);
             g = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wm, g, 0, 0, 0);
             g = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, g, 0, 0, 0);
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restr
     // channels 32w..32w+31 of the K step's 32 rows with six MFMAs.  B of those = W1 (six registers for the whole
     // kernel); A = the step's unit records, one register per MFMA, loaded two steps ahead straight from HBM/L2
     // (each wave its own copy - 1.5 KB per step).
-    // F16: like the forward, the regenerated first layer is one K = 16 step of four f16 MFMAs (records x 2^4 split per step, this wave's
+    // F16: like the forward, the regenerated first layer is one K = 16 step of three f16 MFMAs (records x 2^4 split per step, this wave's
     // 32 W1 rows x 2^8 split once into registers)
     float wb[F16 ? 1 : 6];
     f16x8 w1h, w1m;
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void embed_bwd_dw2_kernel(const float* __restr
         for (int r = 0; r < 16; ++r) g[r] = 0.f;
         if constexpr (F16) {
             const Split2h sp = split2h<true>(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), s_act);
-            g = __builtin_amdgcn_mfma_f32_32x32x16_f16(sp.m, w1m, g, 0, 0, 0);
+            DC_X2H_MM(g = __builtin_amdgcn_mfma_f32_32x32x16_f16(sp.m, w1m, g, 0, 0, 0);)
             g = __builtin_amdgcn_mfma_f32_32x32x16_f16(sp.m, w1h, g, 0, 0, 0);
             g = __builtin_amdgcn_mfma_f32_32x32x16_f16(sp.h, w1m, g, 0, 0, 0);
             g = __builtin_amdgcn_mfma_f32_32x32x16_f16(sp.h, w1h, g, 0, 0, 0);

@@ -217,16 +217,23 @@ __device__ __forceinline__ void mma_kstep_bplanes(const float* __restrict__ a_s,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// The same products from TWO f16 pieces per operand and FOUR MFMAs (DC_DIMS_F16X2; rationale, accuracy and exponent-range
+// The same products from TWO f16 pieces per operand and THREE MFMAs (DC_DIMS_F16X2; rationale, accuracy and exponent-range
 // caveat: gemm_x3.hip, PREC = 4).  x * s = h + m (+ l, dropped) with h = f16(x s), m = f16(x s - h); s: the operand's power-of-two
 // pre-scale (1 when the producer already applied it); the caller scales the accumulators back by 1 / (sa sb).
 // ---------------------------------------------------------------------------------------------------
-// A/B build -DDC_X2H_SKIP_MM: without the m*m term (three MFMAs; what is dropped grows from ~2^-22 to ~2^-21 |ab| per product) - a
-// measurement aid for the power-limit question, not a shipped mode
-#ifdef DC_X2H_SKIP_MM
-#define DC_X2H_MM(x)
-#else
+// The m*m term.  With x 2^s = h + m + l (round to nearest even: |m| <= 2^-11 |x|, |l| <= 2^-23 |x|) a product is
+//     a b = hh + hm + mh + [mm] + (al b + a bl - al bl).
+// What the pieces cannot represent is <= 2^-22 |ab|; the m*m term is <= 2^-22 |ab| too, so dropping it takes the bound per term to
+// 2^-21 |ab| - below what an f32 fma chain of K >= 8 terms may lose to rounding (K 2^-24) - for 25 % fewer MFMAs on products that run
+// at the socket's power cap.  Measured against f64 on the network's shapes the two forms are indistinguishable, and both are at or
+// below the six-bf16-MFMA form (tools/ubench/gemm_x3.hip: identical to three digits; tools/gemm_bench.py, profiles/r04/
+// v12_gemm_bench_{three,four}_mfma.txt: 2.8e-7 .. 8.1e-7 against 2.7e-7 .. 8.3e-7 of max |C|; the f32 accumulation dominates), the
+// dense products are 5-10 % faster and the step 2.2 % (19.5 against 20.0 ms, same box, alternating).  Default: THREE MFMAs (hh, hm, mh);
+// -DDC_X2H_KEEP_MM builds the four-MFMA form (A/B).
+#ifdef DC_X2H_KEEP_MM
 #define DC_X2H_MM(x) x
+#else
+#define DC_X2H_MM(x)
 #endif
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
@@ -255,7 +262,7 @@ __device__ __forceinline__ Split2h split2h(const float4& x0, const float4& x1, f
     return r;
 }
 
-// mma_kstep with f16 pieces: same fragment reads and k permutation, four MFMAs per (row tile, column tile), smallest term first
+// mma_kstep with f16 pieces: same fragment reads and k permutation, three MFMAs per (row tile, column tile), smallest terms first
 template <class LA, class LB, int TM, int TN, bool SCALE_A, bool SCALE_B>
 __device__ __forceinline__ void mma_kstep_h(const float* __restrict__ a_s, const float* __restrict__ b_s, int a_row0, int b_row0,
                                             int fr, int fq, f32x16 (&acc)[TM][TN], float sa, float sb) {

@@ -24,8 +24,8 @@
 //
 // PREC = 4 (round 4, DC_DIMS_F16X2): TWO f16 pieces instead of three bf16 ones.  x 2^s = h + m + l with h = f16(x 2^s), m = f16(x 2^s - h):
 // 11 + 11 significand bits plus the sign of m carry 23 of the 24 bits of an f32, |l| <= 2^-23 |x|, and
-//     a b = hh + hm + mh + mm + (hl + lh + ...),   dropped: <= 2^-22 |ab|
-// is FOUR v_mfma_f32_32x32x16_f16 per K = 16 instead of six bf16 ones (measured against f64 on the network's shapes,
+//     a b = hh + hm + mh + (mm + hl + lh + ...),   dropped: <= 2^-21 |ab| (mm <= 2^-22, the l terms <= 2^-22: gemm_tiles.h, DC_X2H_MM)
+// is THREE v_mfma_f32_32x32x16_f16 per K = 16 instead of six bf16 ones (measured against f64 on the network's shapes,
 // tools/ubench/gemm_x3.hip: 1.2e-7 .. 4.9e-7 of max |C| - the six-bf16 form 1.4e-7 .. 5.5e-7, the f32 fma chain 2.1e-7 .. 3.7e-7), two
 // planes through the LDS instead of three, 3.5 instead of 5.5 VALU instructions per element split.  These products run at the
 // chip's power limit (profiles/r04/gemm_power_evidence.json), so fewer MFMAs and fewer LDS bytes per flop is what buys time.

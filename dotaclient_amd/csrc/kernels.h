@@ -81,7 +81,7 @@ struct X3Gemm {
     int M = 0, N = 0, K = 0;
     const float* bias = nullptr; int nbias = 0;                       // bias[col] for col < nbias
     int relu = 0; const float* aux = nullptr; int ldaux = 0;          // zero where aux <= 0
-    int accumulate = 0, prec = 6, transposed_w = 0;     // prec 6: three bf16 pieces, six MFMAs; 4: two f16 pieces, four MFMAs; 1: bf16
+    int accumulate = 0, prec = 6, transposed_w = 0;     // prec 6: three bf16 pieces, six MFMAs; 4: two f16 pieces, three MFMAs; 1: bf16
     float sa = 1.f, sb = 1.f;                           // prec 4: power-of-two pre-scales of A / B (an X3_PLANES operand was scaled by sb
                                                         // when its planes were made); the product is scaled back by 1 / (sa sb)
     GemmScratch scratch;
@@ -115,7 +115,7 @@ bool embed_fused_supported(long long nr_padded);
 // xcat/amax != nullptr: the max-pools of the one-unit and 16-unit types are produced by the epilogue (then call
 // pool_env_fwd with residual = 1 for the env embedding and the 5-unit type only)
 // W2p != nullptr: W2 also as pre-split bf16 planes [3][6 x 128][128] (split_weight_planes): no fragment split for that operand
-// F16x2Scales (DC_DIMS_F16X2): the 128 x 128 layer and its two backward products from two f16 pieces per operand and four MFMAs; the
+// F16x2Scales (DC_DIMS_F16X2): the 128 x 128 layer and its two backward products from two f16 pieces per operand and three MFMAs; the
 // power-of-two pre-scales of activations, weights, gradients (policy.hip).  W2p then holds [2] f16 planes of W2 * s_w.
 struct F16x2Scales { bool on = false; float s_act = 1.f, s_w = 1.f, s_grad = 1.f; };
 int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const float* W2, const uint16_t* W2p, const float* b2, float* emb,

@@ -46,7 +46,7 @@ DC_DIMS_TEAM_VALU = 16384
 DC_DIMS_EMBED_UNFUSED = 32768
 DC_DIMS_RNN_STEP_BF16 = 65536
 DC_DIMS_POOL16_8W = 262144
-DC_DIMS_F16X2 = 131072   # f32-grade products from two f16 pieces (four MFMAs) instead of three bf16 pieces (six): include/dotaclient_hip.h
+DC_DIMS_F16X2 = 131072   # f32-grade products from two f16 pieces (three MFMAs) instead of three bf16 pieces (six): include/dotaclient_hip.h
 
 WS_FIXED = ['FAULT', 'BASIC', 'EMB', 'DEMB', 'XCAT', 'AMAX', 'PRE', 'HEADOUT', 'TU', 'DHEADOUT', 'DTU', 'DPRE', 'DXCAT',
             'STATS', 'WHHT', 'SCRATCH', 'HEADW_PAD', 'TEAM_XBUF', 'WPLANES']
@@ -441,7 +441,7 @@ class Engine:
         self._ws_off = None
         self._ws_dims_key = None
         self.kernel_flags = 0          # DC_DIMS_* overrides OR-ed into every call's dims (0 = the library picks by shape)
-        # f32-grade products: 'f16x2' (default) = two f16 pieces per operand, four MFMAs, fixed power-of-two pre-scales (DC_DIMS_F16X2);
+        # f32-grade products: 'f16x2' (default) = two f16 pieces per operand, three MFMAs, fixed power-of-two pre-scales (DC_DIMS_F16X2);
         # 'bf16x3' = three bf16 pieces, six MFMAs (f32's exponent range).  An operand outside f16's range (activation > 4094, gradient
         # entry > ~16384 / rows) turns the f16x2 loss NaN, the update is skipped on the device (sticky status word) and the caller
         # falls back: use_safe_products() and a repeat of the iteration (DotaOptimizer does that by itself).
@@ -532,6 +532,32 @@ class Engine:
         self._ws_holds = None
         self._graphs.clear()
         return True
+
+    def use_safe_recurrent(self):
+        """If a team kernel recorded a timeout (DC_WS_FAULT: its workgroups wait for each other and assume a compute unit each - a CU
+        mask, a partitioned device or a co-tenant breaks that, and the launch poisons its outputs with NaN instead of hanging), switches
+        the recurrent core to the launch-per-step kernels for good (DC_DIMS_RNN_PER_STEP; LSTM-512 in bf16 mode:
+        DC_DIMS_RNN_STEP_BF16 - no workgroup waits for another), clears the record and the status word.  Returns True if it did."""
+        flag = DC_DIMS_RNN_STEP_BF16 if (self.kernel_flags & DC_DIMS_BF16) and self.hidden == 512 else DC_DIMS_RNN_PER_STEP
+        if (self.kernel_flags & flag) or self.fault() is None:
+            return False
+        self.kernel_flags |= flag
+        self.clear_fault()
+        self.status.zero_()
+        self._ws_holds = None
+        self._graphs.clear()
+        return True
+
+    def recover_from_nan(self):
+        """What the consumer loop tries ONCE when an iteration turned NaN (no parameter was touched: the status word is sticky) before
+        raising like the reference: a recorded team-kernel timeout -> the launch-per-step recurrent kernels; otherwise f16x2 products
+        -> the bf16x3 products.  Returns a line for the log, or '' when there is nothing left to try."""
+        what = describe_fault(self)
+        if self.use_safe_recurrent():
+            return 'launch-per-step recurrent kernels from here on (' + what.lstrip('; ') + ')'
+        if self.use_safe_products():
+            return 'bf16x3 products (f32 exponent range) from here on - an operand may have left f16\'s range'
+        return ''
 
     def _workspace(self, d):
         n = len(WS_FIXED) + len(WS_LAYER) * self.layers

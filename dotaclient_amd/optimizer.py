@@ -305,10 +305,11 @@ class DotaOptimizer:
                                               e_clip=self.e_clip, grad_hook=self.grad_hook)
         host = torch.cat([out[:11], status.to(torch.float32)]).cpu()      # the one sync of the epoch
         st = int(host[11].item())
-        if st != 0 and self.engine.use_safe_products():
-            # f16x2 products and a NaN: possibly an operand outside f16's range - repeat the epoch with the bf16x3 products
-            # (nothing was updated; the experiences' old log-probs / values are what experiences_from_rollout computed)
-            logger.warning('train: NaN with the f16x2 products - repeating the epoch with the bf16x3 products; they stay on from here')
+        how = self.engine.recover_from_nan() if st != 0 else ''
+        if how:
+            # a NaN that may be the kernels' doing (a team-kernel timeout; an operand outside the f16 pieces' range): repeat the epoch
+            # once on the safe path (nothing was updated; the experiences' old log-probs / values are what experiences_from_rollout computed)
+            logger.warning('train: NaN - repeating the epoch with the %s', how)
             out, status = self.engine.train_epoch(chunks, self.learning_rate, self.entropy_coef, self.vf_coef,
                                                   e_clip=self.e_clip, grad_hook=self.grad_hook)
             host = torch.cat([out[:11], status.to(torch.float32)]).cpu()
@@ -442,13 +443,13 @@ class DotaOptimizer:
                 self._ready = self._finish_batch()
         hist_done.synchronize()                                             # the one synchronisation of the iteration
         host = host.clone()
-        if int(host[:, 11].max().item()) != 0 and self.engine.products == 'f16x2':
-            # A NaN with the two-f16-piece products may be an operand outside f16's exponent range (Engine.products).  Nothing was
-            # updated (the status word is sticky on the device): switch to the three-bf16-piece products for good and repeat this
-            # iteration - rollout pass and epochs - on the same batch.  If it is NaN again, it is the data: raise like the reference.
-            logger.warning('iteration %d: NaN with the f16x2 products - repeating it with the bf16x3 products (f32 exponent range); '
-                           'they stay on from here', it)
-            self.engine.use_safe_products()
+        how = self.engine.recover_from_nan() if int(host[:, 11].max().item()) != 0 else ''
+        if how:
+            # The NaN may be the kernels' doing: a team kernel that timed out (DC_WS_FAULT), or an operand outside the exponent range of
+            # the two-f16-piece products (Engine.products).  Nothing was updated (the status word is sticky on the device): switch to the
+            # safe path for good and repeat this iteration - rollout pass and epochs - on the same batch.  If it is NaN again, it is the
+            # data: raise like the reference.
+            logger.warning('iteration %d: NaN - repeating it with the %s', it, how)
             self._drop_ready()
             experiences, chunks = self._experiences_from_batch(acc['rollouts'], acc['batch'])
             for ep in range(self.epochs):

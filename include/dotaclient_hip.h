@@ -70,7 +70,7 @@ int dc_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, i
                 int accumulate, int splits, float* scratch, int64_t scratch_floats, dc_stream_t stream);
 
 /* The same product through the split-on-load kernel the network's dense layers use (gemm_x3.hip): operands as exact 3-way bf16
- * splits on the bf16 matrix cores (prec 6: f32-grade results), as two f16 pieces with four MFMAs (prec 4: f32-grade while the operands
+ * splits on the bf16 matrix cores (prec 6: f32-grade results), as two f16 pieces with three MFMAs (prec 4: f32-grade while the operands
  * stay inside f16's exponent range, no pre-scaling through this entry point) or rounded to bf16 (prec 1), f32 accumulate.  Layouts:
  * a_kmajor = b_kmajor = 0 (x W^T), a_kmajor = 0 / b_kmajor = 1 (dy W), a_kmajor = b_kmajor = 1 (dy^T x, split-K).  B is a weight
  * matrix in the first two forms and is split into bf16 planes inside the call (into `scratch`, which must hold
@@ -147,7 +147,7 @@ typedef struct dc_dims {
 /*   DC_DIMS_RNN_STEP_BF16  : DC_DIMS_BF16 with H = 512: the launch-per-step bf16 recurrent kernels (rnn_step_bf16.hip) instead of the
  *                            persistent team kernel (rnn_team512.hip: sixteen workgroups hold W_hh as bf16 in their registers). */
 #define DC_DIMS_RNN_STEP_BF16 65536
-/*   DC_DIMS_F16X2          : f32-grade products from TWO f16 pieces per operand and four MFMAs (instead of three bf16 pieces and six):
+/*   DC_DIMS_F16X2          : f32-grade products from TWO f16 pieces per operand and three MFMAs (instead of three bf16 pieces and six):
  *                            x 2^s = h + m with h = f16(x 2^s), m = f16(x 2^s - h) carries 23 of the 24 significand bits; operands are
  *                            pre-scaled by fixed powers of two (activations 2^4, weights 2^8, gradients 2^(ceil(log2 rows) + 2)) and the
  *                            products scaled back - exact.  Same accuracy against f64 as the six-MFMA form (tools/ubench/gemm_x3.hip),

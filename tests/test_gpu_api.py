@@ -384,3 +384,40 @@ def test_consumer_loop_falls_back_to_the_bf16_pieces_when_an_operand_leaves_the_
     assert torch.allclose(opt.engine.params, ref.engine.params, rtol=0, atol=1e-7)
     m2 = opt.run_iteration(2)                       # and the loop carries on
     assert np.isfinite(float(m2['loss/sum']))
+
+
+def test_consumer_loop_leaves_the_team_kernels_after_a_recorded_timeout(tmp_path):
+    # The team kernels' workgroups wait for each other and assume a compute unit each; when that does not hold (CU mask, co-tenant) a wait
+    # times out, the launch records it in DC_WS_FAULT and poisons its outputs with NaN.  The consumer loop then repeats the iteration ONCE
+    # on the launch-per-step recurrent kernels (Engine.use_safe_recurrent) instead of dying of a ValueError on every batch.  A timeout
+    # cannot be provoked on a free GPU, so the record and the NaN status are planted here - what is tested is the recovery path.
+    from dotaclient_amd.engine import DC_DIMS_RNN_PER_STEP, DC_FAULT_TEAM_TIMEOUT
+    g, _ = util.load_case('ragged_s16')
+    stream = synth.make_rollouts(33, [40, 64, 21, 33, 50, 16, 64, 48, 17, 80, 30, 64, 25, 70, 41, 64, 18, 52])
+    opt = make_opt([dict(r) for r in stream], g, tmp_path)
+    opt.min_seq_per_epoch = 9
+    opt.pipeline_rollout_pass = False
+    m1 = opt.run_iteration(1)                                             # builds the workspace; default kernels
+    assert opt.engine.fault() is None and not (opt.engine.kernel_flags & DC_DIMS_RNN_PER_STEP)
+    opt.engine._ws[:32].view(torch.int32).copy_(torch.tensor([DC_FAULT_TEAM_TIMEOUT + 1, 0, 3, 1, 7, 12, 8, 0], dtype=torch.int32))
+    opt.engine.status.fill_(1)                                            # what the poisoned launch leads to (sticky: no update happens)
+    before = opt.engine.params.clone()
+    products = opt.engine.products
+    m2 = opt.run_iteration(2)
+    assert opt.engine.kernel_flags & DC_DIMS_RNN_PER_STEP and opt.engine.fault() is None and int(opt.engine.status.item()) == 0
+    assert opt.engine.products == products                                # the timeout was the cause on record: the products stay
+    assert np.isfinite(float(m2['loss/sum'])) and not torch.equal(before, opt.engine.params)
+    # same stream, per-step kernels from the start: the second iteration agrees (f32 rounding of a different kernel aside)
+    ref = make_opt([dict(r) for r in stream], g, tmp_path)
+    ref.min_seq_per_epoch = 9
+    ref.pipeline_rollout_pass = False
+    ref.run_iteration(1)
+    ref.engine.kernel_flags |= DC_DIMS_RNN_PER_STEP
+    r2 = ref.run_iteration(2)
+    assert abs(float(m2['loss/sum']) - float(r2['loss/sum'])) <= 1e-4 * max(1.0, abs(float(r2['loss/sum'])))
+    # a further NaN without a record: the products are what is left to try; after that it raises like the reference
+    opt.engine.status.fill_(1)
+    assert np.isfinite(float(opt.run_iteration(3)['loss/sum'])) and opt.engine.products == 'bf16x3'
+    opt.engine.status.fill_(1)
+    with pytest.raises(ValueError):
+        opt.run_iteration(4)

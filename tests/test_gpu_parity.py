@@ -500,7 +500,7 @@ def test_sparse_pool_backward_with_one_unit_taking_every_channel():
     assert util.scaled_err(outs['sparse'][1][:11], outs['dense'][1][:11]) < 2e-5
 
 
-# ---- the two forms of f32-grade products: 'f16x2' (Engine default: two f16 pieces, four MFMAs, DC_DIMS_F16X2) is what every test above
+# ---- the two forms of f32-grade products: 'f16x2' (Engine default: two f16 pieces, three MFMAs, DC_DIMS_F16X2) is what every test above
 # ran; 'bf16x3' (three bf16 pieces, six MFMAs: f32's exponent range, the fallback) must meet the same bars ----------------------------------
 @pytest.mark.parametrize('case', util.CASES + util.BIG_CASES)
 def test_bf16x3_products_match_reference_golden(case):
