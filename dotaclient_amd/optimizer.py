@@ -315,7 +315,7 @@ class DotaOptimizer:
             host = torch.cat([out[:11], status.to(torch.float32)]).cpu()
             st = int(host[11].item())
         if st != 0:
-            msg = describe_fault(self.engine)
+            msg = describe_fault(self.engine) + ('; already repeated with the ' + how if how else '')
             self.engine.status.zero_()                                      # sticky on the device (csrc/adam.hip): the caller clears it
         if st == 1:                                                         # optimizer.py:667-669
             raise ValueError('loss={}, policy_loss={}, entropy_loss={}, value_loss={}'.format(*host[:4].tolist()) + msg)
@@ -467,7 +467,7 @@ class DotaOptimizer:
             if st != 0:
                 # the status word is sticky on the device (csrc/adam.hip): epochs behind the first NaN one applied nothing, like the
                 # reference, which never reaches them; cleared here, with the early rollout pass of the next batch dropped
-                msg = describe_fault(self.engine)
+                msg = describe_fault(self.engine) + ('; already repeated with the ' + how if how else '')
                 self.engine.status.zero_()
                 self._drop_ready()
             if st == 1:                                                     # optimizer.py:667-669

@@ -421,3 +421,25 @@ def test_consumer_loop_leaves_the_team_kernels_after_a_recorded_timeout(tmp_path
     opt.engine.status.fill_(1)
     with pytest.raises(ValueError):
         opt.run_iteration(4)
+
+
+def test_incremental_packer_on_the_gpu_equals_pack_rollouts():
+    # the GPU form of tests/test_host_logic.py::test_incremental_packer_equals_pack_rollouts: page-locked staging, the H2D copies going
+    # out in pieces WHILE the batch is packed (IncrementalPacker.COPY_ROWS) - also when the staging set (and with it the device
+    # buffers) has to grow mid-batch after copies went out, when a batch is abandoned half-way, and when the sets are reused
+    from dotaclient_amd.engine import IncrementalPacker, pack_rollouts
+    dev = torch.device('cuda:0')
+    pk = IncrementalPacker(16, dev, expected_rows=32)
+    pk.COPY_ROWS = 64                                # several flushes per batch at these sizes
+    for seed, lens in [(5, [40, 64, 7, 300, 16]), (6, [16]), (7, [500, 3, 3, 90]), (8, [70, 70, 70, 70, 1200, 33, 16])]:
+        rollouts = synth.make_rollouts(seed, lens)
+        want = pack_rollouts(rollouts, 16, dev)
+        if seed == 7:                                # an abandoned batch: rows packed and copied, then dropped
+            pk.add(rollouts[0]); pk.add(rollouts[3]); pk._begin()
+        for d in rollouts:
+            pk.add(d)
+        got = pk.finish()
+        torch.cuda.current_stream().wait_event(got.ready)
+        assert got.rows == want.rows and got.max_len == want.max_len
+        for k in ('obs', 'act', 'mask', 'rew', 'seq_off', 'seq_len'):
+            assert torch.equal(getattr(got, k), getattr(want, k)), (seed, k)

@@ -12,7 +12,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dotaclient_amd.engine import Engine, IncrementalPacker, pack_rollouts, device_empty  # noqa: E402
-from oracle import synth  # noqa: E402  (synthetic trajectories only: the generator, not the checker)
+from dotaclient_amd import synth  # noqa: E402
 
 dev = torch.device('cuda:0')
 B, S, E, STEPS = 256, 256, 4, 15
