@@ -282,6 +282,9 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
     __shared__ float sh_norm[2];
     __shared__ double sh_tot[ST_COUNT];
     __shared__ double sh[4][11];
+    __shared__ double accs[16][12];      // running sums of the block: [row of the group][5 policy, 5 entropy, value]; the row's lane 0 owns its entry
+    __shared__ double sh_inv[7];         // loop invariants, one f64 division each per BLOCK: 1 / (5 nsel_k), 1 / sd, 1 / N
+    __shared__ float sh_gent[5], sh_nsel[5];
     __shared__ int sh_last;
     // batch statistics: every block sums batch_stats_kernel's partial rows itself, in one fixed order (lane-strided, then the wave
     // butterfly): bit-identical in every block and from run to run
@@ -302,9 +305,18 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
             if (var < 0.0) var = 0.0;
             sh_norm[0] = (float)mean;
             sh_norm[1] = (float)(sqrt(var) + (double)p.adv_eps);
+            sh_inv[5] = 1.0 / (double)sh_norm[1];
+            sh_inv[6] = 1.0 / N;
+#pragma unroll
+            for (int kk = 0; kk < 5; ++kk) {
+                const float ns = (float)sh_tot[ST_NSEL + kk];
+                sh_nsel[kk] = ns;
+                sh_inv[kk] = ns > 0.f ? 1.0 / (5.0 * (double)ns) : 0.0;
+                sh_gent[kk] = (ns > 0.f && p.entropy_coef > 0.f) ? (float)((double)p.entropy_coef / (double)ns) : 0.f;
+            }
         }
     }
-    if (threadIdx.x < 44) (&sh[0][0])[threadIdx.x] = 0.0;
+    if (threadIdx.x < 192) (&accs[0][0])[threadIdx.x] = 0.0;
     __syncthreads();
     const int j = threadIdx.x & 15;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -312,8 +324,10 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
 #pragma unroll 1
     for (int grp_i = blockIdx.x; grp_i < (int)groups; grp_i += gridDim.x) {      // persistent blocks: one set of partial sums per block
     const long long grp = __builtin_amdgcn_readfirstlane(grp_i);
-    double pol[5] = {0, 0, 0, 0, 0}, ent[5] = {0, 0, 0, 0, 0}, val = 0.0;   // this group's terms; the running sums live in LDS (sh[wave][..]:
-                                                                            // carried in registers across the loop they cost 60 VGPRs and a spill)
+    // this group's terms go into the block's running sums in LDS (accs): every one of them has ONE contributing lane per row (the
+    // selected action's owner / the row's lane 0), so a row's lane 0 adds them to its own entry - no cross-lane f64 reduction per group
+    // (eleven ds_bpermute wave sums per group were a fifth of the kernel's instructions), and nothing carried in registers across the loop.
+    float polc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     const long long n = grp * 16 + (threadIdx.x >> 4);
     const bool on = n < p.nr;
     const long long nn = on ? n : p.nr - 1;     // idle rows of the last group recompute a valid step and store nothing
@@ -323,7 +337,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
     const uint8_t* mrow = p.mask + nn * ACT;
     const uint8_t* arow = p.act + nn * ACT;
     // (double) like the reference's fp32 tensor op on a float64-free path: A is an fp32 value
-    const float A = (float)(((double)p.adv[nn] - (double)sh_norm[0]) / (double)sh_norm[1]);
+    const float A = (float)(((double)p.adv[nn] - (double)sh_norm[0]) * sh_inv[5]);
 
     float z[5], e[5];
     bool mk[5];
@@ -356,7 +370,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
     for (int kk = 0; kk < 5; ++kk) {
         lse[kk] = logf(row_sum16(se_c[kk]));
         amin[kk] = row_min16_i(amin_c[kk]);
-        nselv[kk] = (float)sh_tot[ST_NSEL + kk];
+        nselv[kk] = sh_nsel[kk];
     }
     // log-probs of this lane's columns, entropy terms, the selected action's surrogate
     float lp[5], pc[5];
@@ -383,17 +397,19 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
             const float s1 = ratio * A;
             const float rc = fminf(fmaxf(ratio, 1.f - p.e_clip), 1.f + p.e_clip);
             const float s2 = rc * A;
-            const double polv = -(double)fminf(s1, s2);
+            const float polv = -fminf(s1, s2);
             // d min(s1,s2)/d ratio: torch splits ties evenly; clamp passes gradient inside [lo,hi]
             const bool inr = (ratio >= 1.f - p.e_clip) && (ratio <= 1.f + p.e_clip);
             float w1, w2;
             if (s1 < s2) { w1 = 1.f; w2 = 0.f; } else if (s1 > s2) { w1 = 0.f; w2 = 1.f; } else { w1 = 0.5f; w2 = 0.5f; }
             const float dmin_dr = A * (w1 + (inr ? w2 : 0.f));
-            const float g = (float)(-(double)dmin_dr * (double)ratio / (5.0 * (double)nsk));
+            double i5n = sh_inv[4];
+            i5n = k == 3 ? sh_inv[3] : i5n; i5n = k == 2 ? sh_inv[2] : i5n; i5n = k == 1 ? sh_inv[1] : i5n; i5n = k == 0 ? sh_inv[0] : i5n;
+            const float g = (float)(-(double)dmin_dr * (double)ratio * i5n);
 #pragma unroll
             for (int kk = 0; kk < 5; ++kk) {
                 glp_c[kk] += k == kk ? g : 0.f;
-                if (on) pol[kk] += k == kk ? polv : 0.0;
+                polc[kk] += k == kk ? polv : 0.f;
             }
         }
     }
@@ -404,8 +420,13 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
         glp[kk] = row_sum16(glp_c[kk]);
         const bool many = ((cnt >> (6 * kk)) & 63) != 0;
         if (!many) Hrow[kk] = 0.f;
-        gent[kk] = (nselv[kk] > 0.f && p.entropy_coef > 0.f) ? (float)((double)p.entropy_coef / (double)nselv[kk]) : 0.f;
-        if (on && j == 0 && nselv[kk] > 0.f && many) ent[kk] = (double)Hrow[kk];
+        gent[kk] = sh_gent[kk];
+        const float polr = row_sum16(polc[kk]);                      // exact: one non-zero lane per head and row
+        if (on && j == 0) {
+            double* const a = &accs[threadIdx.x >> 4][0];
+            a[kk] += (double)polr;
+            if (nselv[kk] > 0.f && many) a[5 + kk] += (double)Hrow[kk];
+        }
     }
     // d loss / d logit_c = g_lp * (delta_{c,a} - [mask_c] p_c) + g_ent * [mask_c] p_c (logp_c + Hrow)
 #pragma unroll
@@ -428,24 +449,14 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
         }
     }
     if (on && j == 0) {
-        const double N = (double)p.nr;
         const float v = ho[HO_VALUE];
         const float d = p.ret[n] - v;
-        val = (double)d * (double)d;
+        accs[threadIdx.x >> 4][10] += (double)d * (double)d;
         // value_loss = vf_coef * 0.5 * mean((R - V)^2)  (optimizer.py:658-661)
-        p.dheadout[n * HO_LD + HO_VALUE] = (p.vf_coef > 0.f) ? (float)((double)p.vf_coef * (double)(v - p.ret[n]) / N) : 0.f;
+        p.dheadout[n * HO_LD + HO_VALUE] = (p.vf_coef > 0.f) ? (float)((double)p.vf_coef * (double)(v - p.ret[n]) * sh_inv[6]) : 0.f;
 #pragma unroll
         for (int c = HO_VALUE + 1; c < HO_LD; ++c) p.dheadout[n * HO_LD + c] = 0.f;
     }
-    // this group's 5 policy sums + 5 entropy sums + value sum -> the wave's running sums (lane 0 owns sh[wave][..])
-#pragma unroll
-    for (int kk = 0; kk < 5; ++kk) {
-        const double a = wave_sum(pol[kk]);
-        const double b = wave_sum(ent[kk]);
-        if (lane == 0) { sh[wave][kk] += a; sh[wave][5 + kk] += b; }
-    }
-    const double vs = wave_sum(val);
-    if (lane == 0) sh[wave][10] += vs;
     }   // groups of this block
     __syncthreads();
     // The last block to arrive sums all rows (fixed order) and finalises the losses.  Hand-off without fences (an agent-scope release
@@ -453,8 +464,10 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
     // the row goes out as 8-byte write-through (sc1) stores, drained (vmcnt(0)) before the ticket is taken; the last block
     // reads the rows with sc1 loads (MI355X_MICROARCH.md: "8-B agent atomics both sides").
     if (threadIdx.x < 11) {
-        __hip_atomic_store(&p.stats[ST_PART2 + blockIdx.x * 12 + threadIdx.x],
-                           sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += accs[r][threadIdx.x];     // fixed order
+        __hip_atomic_store(&p.stats[ST_PART2 + blockIdx.x * 12 + threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
