@@ -26,6 +26,26 @@ enum { ST_ADV_SUM = 0, ST_ADV_SQ = 1, ST_NSEL = 2 /*5*/, ST_POL = 7 /*5*/, ST_EN
 // 4 096 blocks x 11 same-address atomics serialised at one L2 channel (the kernel's tail), and made the sums order-dependent.
 enum { ST_G1 = 256, ST_G2 = 1024, ST_PART1 = 64, ST_PART2 = ST_PART1 + ST_G1 * 8, ST_TICKET = ST_PART2 + ST_G2 * 12, ST_DOUBLES = ST_TICKET + 8 };
 
+// sixteen-lane (DPP row) all-reduces
+template <int CTRL>
+__device__ __forceinline__ float row_dpp(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int row_dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ float row_sum16(float x) {      // all 16 lanes of the row get the sum
+    x += row_dpp<0x128>(x); x += row_dpp<0x124>(x); x += row_dpp<0x122>(x); x += row_dpp<0x121>(x);   // row_ror 8,4,2,1
+    return x;
+}
+__device__ __forceinline__ int row_sum16_i(int x) {
+    x += row_dpp_i<0x128>(x); x += row_dpp_i<0x124>(x); x += row_dpp_i<0x122>(x); x += row_dpp_i<0x121>(x);
+    return x;
+}
+__device__ __forceinline__ int row_min16_i(int x) {
+    x = min(x, row_dpp_i<0x128>(x)); x = min(x, row_dpp_i<0x124>(x)); x = min(x, row_dpp_i<0x122>(x)); x = min(x, row_dpp_i<0x121>(x));
+    return x;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // target-unit logits: tu[n][u] = sum_c q[n][c] * emb[n][u][c];  16 lanes per unit, 4 units per wave pass
 // ---------------------------------------------------------------------------------------------------
@@ -53,12 +73,16 @@ __global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restric
     }
 }
 
-// type-major row of unit u (0..39) of env-step n
+// type-major row of unit u (0..39) of env-step n.  Selects, not the c_t_* tables: a table entry at a run-time index is a memory
+// round trip (scalar or vector) in front of every embedding-row address.
 __device__ __forceinline__ long long unit_row(long long nr, long long n, int u) {
-    int t = 0;
-#pragma unroll
-    for (int i = 1; i < 6; ++i) if (u >= c_t_cum[i]) t = i;
-    return nr * c_t_cum[t] + n * c_t_units[t] + (u - c_t_cum[t]);
+    int cum = 0, un = 1;                              // types: 1, 5, 16, 16, 1, 1 units; first units 0, 1, 6, 22, 38, 39
+    if (u >= 1) { cum = 1; un = 5; }
+    if (u >= 6) { cum = 6; un = 16; }
+    if (u >= 22) cum = 22;
+    if (u >= 38) { cum = 38; un = 1; }
+    if (u >= 39) cum = 39;
+    return nr * cum + n * un + (u - cum);
 }
 
 // Mask-aware form (DC_DIMS_LAZY_TU): only units whose target_unit mask byte is set are read - the actors' masks
@@ -68,31 +92,51 @@ __device__ __forceinline__ long long unit_row(long long nr, long long n, int u) 
 __global__ __launch_bounds__(256) void attn_logits_masked_kernel(const float* __restrict__ headout, const float* __restrict__ emb,
                                                                  const uint8_t* __restrict__ mask, float* __restrict__ tu,
                                                                  long long nr, long long nrp) {
+    // A live step has ~24 units: taken four per trip (one per quarter) that was six dependent memory round trips per step.  Now the set
+    // lanes leave their unit numbers in a wave-private LDS list (rank by v_mbcnt), quarter `sub` takes entries sub, sub + 4, ... and ALL
+    // of its (up to ten) rows are requested before the first dot product.
+    __shared__ uint8_t list_s[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane >> 4, l16 = lane & 15;
+    uint8_t* const list = list_s[wave];
     for (long long n = (long long)blockIdx.x * 4 + wave; n < nr; n += (long long)gridDim.x * 4) {
         const bool set = lane < NUNITS && mask[n * ACT + 22 + lane] != 0;
-        unsigned long long bits = __ballot(set);
+        const unsigned long long bits = __ballot(set);
         if (lane < NUNITS && !set) tu[n * NUNITS + lane] = 0.f;
         if (bits == 0ull) continue;
+        const int cnt = __popcll(bits);
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bits, 0u));
+        if (set) list[rank] = (uint8_t)lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // LDS is in order per wave; this keeps the compiler from moving the reads up
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const float4* qp = reinterpret_cast<const float4*>(headout + n * HO_LD);
         const float4 q0 = qp[l16], q1 = qp[16 + l16];
-        while (bits) {
-            // this quarter's unit: the sub-th lowest set bit (wave-uniform loop, quarter-uniform choice)
-            unsigned long long b = bits;
-            for (int i = 0; i < sub; ++i) b &= b - 1;
-            const bool have = b != 0ull;
-            const int u = have ? __builtin_ctzll(b) : 0;
-            if (have) {
-                const float4* ep = reinterpret_cast<const float4*>(emb + unit_row(nrp, n, u) * EMBW);
-                const float4 e0 = ep[l16], e1 = ep[16 + l16];
-                float s = q0.x * e0.x + q0.y * e0.y + q0.z * e0.z + q0.w * e0.w + q1.x * e1.x + q1.y * e1.y + q1.z * e1.z +
-                          q1.w * e1.w;
-                s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
-                if (l16 == 0) tu[n * NUNITS + u] = s;
+        // two chunks of five entries per quarter (20 units each; the second only when the step has more).  No branch around a load:
+        // an entry past the end re-reads the last unit's row (an L1 hit) and is dropped - a conditional load makes the compiler wait
+        // for it at the end of its block, which is the serial chain again.
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            if (20 * ch < cnt) {                                      // wave-uniform
+                float4 e0[5], e1[5];
+                int u[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    u[i] = (int)list[min(20 * ch + 4 * i + sub, cnt - 1)];
+                    const float4* ep = reinterpret_cast<const float4*>(emb + unit_row(nrp, n, u[i]) * EMBW);
+                    e0[i] = ep[l16]; e1[i] = ep[16 + l16];
+                }
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    float s = q0.x * e0[i].x + q0.y * e0[i].y + q0.z * e0[i].z + q0.w * e0[i].w + q1.x * e1[i].x + q1.y * e1[i].y +
+                              q1.z * e1[i].z + q1.w * e1[i].w;
+                    s = row_sum16(s);                                 // (the same association as the xor butterfly it replaces)
+                    if (l16 == 0 && 20 * ch + 4 * i + sub < cnt) tu[n * NUNITS + u[i]] = s;
+                }
             }
-            bits &= bits - 1; bits &= bits - 1; bits &= bits - 1; bits &= bits - 1;   // drop the four lowest set bits
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the list is rewritten by the wave's next step
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -107,18 +151,19 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
         const float mine = lane < NUNITS ? dt[lane] : 0.f;
         unsigned long long bits = __ballot(mine != 0.f);        // the same in both waves of the step
         float acc = 0.f;
-        while (bits) {      // four units per trip: their rows are in flight together (the loop is a chain of memory round trips)
-            int u[4];
-            float w[4], e[4];
+        while (bits) {      // sixteen units per trip: their rows are in flight together (the loop is a chain of memory round trips;
+                            // a live step has ~24 units: two trips, where four per trip made six)
+            int u[16];
+            float w[16], e[16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 16; ++i) {
                 u[i] = bits ? __builtin_ctzll(bits) : -1;         // wave-uniform
                 bits &= bits - 1;
                 w[i] = u[i] >= 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), u[i] < 0 ? 0 : u[i])) : 0.f;
                 e[i] = u[i] >= 0 ? emb[unit_row(nrp, n, u[i]) * EMBW + c] : 0.f;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc = fmaf(w[i], e[i], acc);   // ascending unit order, as before
+            for (int i = 0; i < 16; ++i) acc = fmaf(w[i], e[i], acc);   // ascending unit order, as before
         }
         dheadout[n * HO_LD + c] = acc;
     }
@@ -234,24 +279,6 @@ struct LossArgs {
 // (step, head) form walked up to 40 logits three times in a serial loop while the other heads' lanes idled
 // (66 us per launch; this one is bound by its ~1 KB per step of traffic).  Same arithmetic per element:
 // no max-subtraction (policy.py:172), tie/clamp gradient rules of torch.min / clamp, batch sums in f64.
-template <int CTRL>
-__device__ __forceinline__ float row_dpp(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
-}
-template <int CTRL>
-__device__ __forceinline__ int row_dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
-__device__ __forceinline__ float row_sum16(float x) {      // all 16 lanes of the row get the sum
-    x += row_dpp<0x128>(x); x += row_dpp<0x124>(x); x += row_dpp<0x122>(x); x += row_dpp<0x121>(x);   // row_ror 8,4,2,1
-    return x;
-}
-__device__ __forceinline__ int row_sum16_i(int x) {
-    x += row_dpp_i<0x128>(x); x += row_dpp_i<0x124>(x); x += row_dpp_i<0x122>(x); x += row_dpp_i<0x121>(x);
-    return x;
-}
-__device__ __forceinline__ int row_min16_i(int x) {
-    x = min(x, row_dpp_i<0x128>(x)); x = min(x, row_dpp_i<0x124>(x)); x = min(x, row_dpp_i<0x122>(x)); x = min(x, row_dpp_i<0x121>(x));
-    return x;
-}
 __device__ __forceinline__ int head_of_col(int c) { return c < 4 ? 0 : (c < 13 ? 1 : (c < 22 ? 2 : (c < 62 ? 3 : 4))); }
 
 // losses[0..3] = loss, policy_loss, entropy_loss, value_loss ; losses[4..8] = entropies per head
