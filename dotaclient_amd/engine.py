@@ -406,12 +406,36 @@ class IncrementalPacker:
             seq_off.copy_(st.off[:n], non_blocking=True)
             seq_len.copy_(st.len[:n], non_blocking=True)
             dst += [seq_off, seq_len]
+            # the chunk view's layout tables (PackedBatch.as_chunks builds them with a handful of torch kernels, one of them a sort, per
+            # fresh batch: ~0.3 ms of the consumer loop's iteration - tools/ingest_probe.py B2): the host knows the lengths, so they
+            # come along with the batch
+            S = self.seq_len
+            nb = rows // S
+            starts_h = np.arange(nb, dtype=np.int64) * S
+            first_h = np.zeros(nb, dtype=np.bool_)
+            first_h[off // S] = True                                   # every rollout is stored padded to a multiple of S
+            prev_h = np.where(first_h, -1, starts_h - 1)
+            if getattr(st, 'm64', None) is None or st.m64.shape[1] < nb:
+                st.m64 = torch.empty((2, 2 * nb), dtype=torch.int64, pin_memory=True)
+                st.m32 = torch.empty(2 * nb, dtype=torch.int32, pin_memory=True)
+                st.mb = torch.empty(2 * nb, dtype=torch.bool, pin_memory=True)
+            st.m64[0, :nb] = torch.from_numpy(starts_h)
+            st.m64[1, :nb] = torch.from_numpy(prev_h)
+            st.m32[:nb] = S
+            st.mb[:nb] = torch.from_numpy(first_h)
+            meta = {'starts': device_empty((nb,), torch.int64, dev), 'prev_row': device_empty((nb,), torch.int64, dev),
+                    'lens': device_empty((nb,), torch.int32, dev), 'is_first': device_empty((nb,), torch.bool, dev)}
+            meta['starts'].copy_(st.m64[0, :nb], non_blocking=True)
+            meta['prev_row'].copy_(st.m64[1, :nb], non_blocking=True)
+            meta['lens'].copy_(st.m32[:nb], non_blocking=True)
+            meta['is_first'].copy_(st.mb[:nb], non_blocking=True)
             ready = torch.cuda.Event()
             ready.record(self.stream)
-        for t in base + [seq_off, seq_len]:
+        for t in base + [seq_off, seq_len] + list(meta.values()):
             t.record_stream(cur)
         st.event = ready
         batch = PackedBatch(dst[0], dst[1], dst[2], dst[3], seq_off, seq_len, int(lens_n.max()))
+        batch._chunk_meta[S] = meta
         batch.ready = ready
         batch.host_lens = [int(x) for x in self.lens]
         self._begin()

@@ -443,3 +443,9 @@ def test_incremental_packer_on_the_gpu_equals_pack_rollouts():
         assert got.rows == want.rows and got.max_len == want.max_len
         for k in ('obs', 'act', 'mask', 'rew', 'seq_off', 'seq_len'):
             assert torch.equal(getattr(got, k), getattr(want, k)), (seed, k)
+        # the chunk view's layout tables come with the batch (host-built); pack_rollouts' batch builds them with torch kernels
+        assert 16 in got._chunk_meta and 16 not in want._chunk_meta
+        cg, cw = got.as_chunks(16), want.as_chunks(16)
+        for k in ('seq_off', 'seq_len', 'is_first', 'prev_row'):
+            a, b = getattr(cg, k), getattr(cw, k)
+            assert a.dtype == b.dtype and torch.equal(a, b), (seed, k)
