@@ -177,6 +177,11 @@ long long lstm_team512_xbuf_bytes();   // size of DC_WS_TEAM_XBUF (H = 512)
 bool lstm_team_mfma_supported(int cell, int H, int n_seq, int flags, bool backward);
 int lstm_team_mfma_forward(int cell, RnnStepArgs a, int max_len, int n_teams, hipStream_t s);
 int lstm_team_mfma_backward(int cell, RnnStepArgs a, int max_len, int n_teams, hipStream_t s);
+// rnn_team8.hip (DC_DIMS_TEAM8: the same in teams of eight workgroups, two workgroups per CU)
+bool rnn_team8_supported(int cell, int H, int n_seq, int flags);
+int rnn_team8_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s);
+int rnn_team8_backward(int cell, RnnStepArgs a, int max_len, hipStream_t s);
+long long rnn_team8_xbuf_bytes();
 int rnn_team_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s);
 int rnn_team_backward(int cell, RnnStepArgs a, int max_len, hipStream_t s);
 // adam.hip

@@ -592,11 +592,15 @@ void launch_team_bwd(int ns, int nt, const RnnStepArgs& a, u64* xb, hipStream_t 
 
 }  // namespace
 
-long long rnn_team_xbuf_bytes() { return (long long)(TEAM_XBUF_WORDS * sizeof(u64)); }
+long long rnn_team_xbuf_bytes() {
+    const long long a = (long long)(TEAM_XBUF_WORDS * sizeof(u64)), b = rnn_team8_xbuf_bytes();
+    return a > b ? a : b;
+}
 
 // (DC_DIMS_RNN_PER_STEP, checked by the caller, forces the launch-per-step kernels)
 bool rnn_team_supported(int cell, int H, int n_seq, int flags) {
     if (H != TEAM_H || (cell != CELL_GRU && cell != CELL_LSTM) || team_capacity() < 1) return false;
+    if (rnn_team8_supported(cell, H, n_seq, flags)) return true;       // DC_DIMS_TEAM8: any number of sequences
     // The MFMA team kernels (rnn_team_mfma.hip, both cells) where their rounds of 64 x 4 sequences are cheaper than the alternative
     // (cost model there): no upper limit on the number of sequences - 1 065 chunks of 16 steps, the reference's default shape,
     // take 215 / 205 us per forward / backward pass against 16 launches of 17-27 us.
@@ -607,6 +611,7 @@ bool rnn_team_supported(int cell, int H, int n_seq, int flags) {
 }
 
 int rnn_team_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
+    if (rnn_team8_supported(cell, a.H, a.n_seq, a.flags)) return rnn_team8_forward(cell, a, max_len, s);
     if (lstm_team_mfma_supported(cell, a.H, a.n_seq, a.flags, false)) return lstm_team_mfma_forward(cell, a, max_len, team_capacity(), s);
     u64* xb = static_cast<u64*>(a.xbuf);
     if (!xb) { set_error("rnn_team_forward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }
@@ -636,6 +641,7 @@ int rnn_team_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
 }
 
 int rnn_team_backward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
+    if (rnn_team8_supported(cell, a.H, a.n_seq, a.flags)) return rnn_team8_backward(cell, a, max_len, s);
     if (lstm_team_mfma_supported(cell, a.H, a.n_seq, a.flags, true)) return lstm_team_mfma_backward(cell, a, max_len, team_capacity(), s);
     u64* xb = static_cast<u64*>(a.xbuf);
     if (!xb) { set_error("rnn_team_backward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }

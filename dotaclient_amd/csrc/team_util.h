@@ -51,7 +51,7 @@ __device__ __forceinline__ bool granule_wait_all(u64 (&g)[N], const u64* const (
 }
 
 // A wait timed out: first writer wins, the record stays until the workspace's owner clears it (include/dotaclient_hip.h, DC_WS_FAULT).
-enum { TEAM_K_VALU_FWD = 1, TEAM_K_VALU_BWD = 2, TEAM_K_MFMA_FWD = 3, TEAM_K_MFMA_BWD = 4 };
+enum { TEAM_K_VALU_FWD = 1, TEAM_K_VALU_BWD = 2, TEAM_K_MFMA_FWD = 3, TEAM_K_MFMA_BWD = 4, TEAM_K_T8_FWD = 7, TEAM_K_T8_BWD = 8 };   // (5, 6: rnn_team512.hip)
 __device__ __noinline__ void team_report_timeout(int* fault, int kernel_id, int layer, int team, int member, int step, int seq, unsigned tag) {
     if (fault == nullptr) return;
     if (atomicCAS(&fault[0], 0, DC_FAULT_TEAM_TIMEOUT + kernel_id) == 0) {
@@ -69,21 +69,22 @@ __device__ __noinline__ void team_report_timeout(int* fault, int kernel_id, int 
 // Speed only: with a multiple of 8 teams there is one ticket counter per XCD (the workgroup reads its XCC id), so a
 // team's members share an L2 under any placement; a workgroup whose XCD has no role left takes one of another XCD.
 enum { TEAM_HDR = 16 };   // u64 words in front of the handshake granules: ticket counters (u32 each)
-__device__ __forceinline__ void team_claim_role(unsigned* claim, int n_teams, int& team, int& member) {
+template <int M>     // members per team: 4 (rnn_team.hip, rnn_team_mfma.hip) or 8 (rnn_team8.hip)
+__device__ __forceinline__ void team_claim_role_m(unsigned* claim, int n_teams, int& team, int& member) {
     __shared__ int role_sh[2];
     if (threadIdx.x == 0) {
         int t = -1, m = 0;
         if ((n_teams & 7) == 0) {
-            const int quota = (n_teams >> 3) * TEAM_M;   // roles per XCD slice: teams x, x + 8, x + 16, ...
+            const int quota = (n_teams >> 3) * M;        // roles per XCD slice: teams x, x + 8, x + 16, ...
             const int x = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7);   // HW_REG_XCC_ID
             for (int k = 0; k < 8 && t < 0; ++k) {
                 const int y = (x + k) & 7;
                 const unsigned o = atomicAdd(&claim[y], 1u);
-                if ((int)o < quota) { t = (int)(o >> 2) * 8 + y; m = (int)(o & 3); }
+                if ((int)o < quota) { t = (int)(o / M) * 8 + y; m = (int)(o % M); }
             }
         } else {
             const unsigned o = atomicAdd(&claim[0], 1u);
-            if ((int)o < n_teams * TEAM_M) { t = (int)(o >> 2); m = (int)(o & 3); }
+            if ((int)o < n_teams * M) { t = (int)(o / M); m = (int)(o % M); }
         }
         role_sh[0] = t; role_sh[1] = m;
     }
@@ -91,18 +92,22 @@ __device__ __forceinline__ void team_claim_role(unsigned* claim, int n_teams, in
     team = __builtin_amdgcn_readfirstlane(role_sh[0]);      // uniform values: what is derived from them stays on the scalar unit
     member = __builtin_amdgcn_readfirstlane(role_sh[1]);
 }
+__device__ __forceinline__ void team_claim_role(unsigned* claim, int n_teams, int& team, int& member) {
+    team_claim_role_m<TEAM_M>(claim, n_teams, team, member);
+}
 
 // Once per launch: do the four members of this team share an XCD (hence an L2)?  Each publishes its XCC id as a granule
 // (device scope, like the ring) and reads the three others'.  All members see the same four ids, so they agree on the answer;
 // a member that cannot read a peer answers "no" (the ring will then time out and poison the outputs anyway).
 enum { TEAM_HS_TAG = 0xFFFFFFFFu };
-__device__ __forceinline__ int team_same_xcd(u64* hs, int member, int allow) {
+template <int M>
+__device__ __forceinline__ int team_same_xcd_m(u64* hs, int member, int allow) {
     __shared__ int same_sh;
     if (threadIdx.x == 0) {
         const unsigned my = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID[3:0]
         granule_store(hs + member, __uint_as_float(my), TEAM_HS_TAG);
         bool same = allow != 0;
-        for (int m = 0; m < TEAM_M; ++m) {
+        for (int m = 0; m < M; ++m) {
             if (m == member) continue;
             float v = 0.f;
             const bool ok = granule_wait(granule_load(hs + m), hs + m, TEAM_HS_TAG, v);
@@ -113,6 +118,7 @@ __device__ __forceinline__ int team_same_xcd(u64* hs, int member, int allow) {
     __syncthreads();
     return __builtin_amdgcn_readfirstlane(same_sh);
 }
+__device__ __forceinline__ int team_same_xcd(u64* hs, int member, int allow) { return team_same_xcd_m<TEAM_M>(hs, member, allow); }
 
 }  // namespace
 }  // namespace dc

@@ -46,6 +46,8 @@ DC_DIMS_TEAM_VALU = 16384
 DC_DIMS_EMBED_UNFUSED = 32768
 DC_DIMS_RNN_STEP_BF16 = 65536
 DC_DIMS_POOL16_8W = 262144
+DC_DIMS_TEAM8 = 524288      # H = 256 recurrent core in teams of eight workgroups (csrc/rnn_team8.hip): forced for any number of sequences
+DC_DIMS_TEAM4 = 1048576     # ... never (by itself the library takes them for 65 .. 128 sequences)
 DC_DIMS_F16X2 = 131072   # f32-grade products from two f16 pieces (three MFMAs) instead of three bf16 pieces (six): include/dotaclient_hip.h
 
 WS_FIXED = ['FAULT', 'BASIC', 'EMB', 'DEMB', 'XCAT', 'AMAX', 'PRE', 'HEADOUT', 'TU', 'DHEADOUT', 'DTU', 'DPRE', 'DXCAT',
@@ -78,7 +80,7 @@ def device_copy(t, device, non_blocking=False):
     return out
 
 
-FAULT_KERNELS = {1: 'rnn_team_fwd', 2: 'rnn_team_bwd', 3: 'team_mfma_fwd', 4: 'team_mfma_bwd', 5: 'lstm512_team_fwd', 6: 'lstm512_team_bwd'}
+FAULT_KERNELS = {1: 'rnn_team_fwd', 2: 'rnn_team_bwd', 3: 'team_mfma_fwd', 4: 'team_mfma_bwd', 5: 'lstm512_team_fwd', 6: 'lstm512_team_bwd', 7: 'team8_fwd', 8: 'team8_bwd'}
 DC_FAULT_TEAM_TIMEOUT = 16
 
 

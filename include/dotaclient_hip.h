@@ -160,6 +160,13 @@ typedef struct dc_dims {
  *                            wave, 256 registers, two waves per SIMD) instead of the sixteen-wave one (a step stream per group of eight
  *                            waves, dW2 update split over k, pair-wise dW1 fold: 128 registers, four waves per SIMD; ~5 % faster). */
 #define DC_DIMS_POOL16_8W 262144
+/*   DC_DIMS_TEAM8          : H = 256 recurrent core in teams of EIGHT workgroups, two workgroups per CU (csrc/rnn_team8.hip): a member
+ *                            holds the gate columns of 32 hidden units (128 AGPRs), the second workgroup on the CU works while the first
+ *                            waits for its peers.  The library takes these kernels by itself for 65 .. 128 sequences (one workgroup per
+ *                            CU then: BASELINE.json configs[3]'s per-GPU shard); the flag forces them for any number of sequences,
+ *                            DC_DIMS_TEAM4 keeps them off (A/B). */
+#define DC_DIMS_TEAM8 524288
+#define DC_DIMS_TEAM4 1048576
 
 /* index into poff[]; policy.py:54-75 names in comments */
 enum dc_param_index {

@@ -254,7 +254,7 @@ def test_lstm_persist_variants_agree(S, lens):
 
 @pytest.mark.parametrize('cell', ['gru', 'lstm'])
 @pytest.mark.parametrize('S,lens', [(256, [256] * 6), (7, [21, 7, 13, 30, 1, 44]), (5, [350]), (16, [50, 64, 33]), (3, [1200, 2]), (8, [8] * 131 + [24, 16]),
-                                    (2, [1100]), (4, [3600, 30])])
+                                    (2, [1100]), (4, [3600, 30]), (16, [16] * 70 + [48, 160, 33, 200])])
 def test_rnn_team_kernels_agree_with_per_step(cell, S, lens):
     # H = 256 (the reference's GRU, the LSTM-256 configs): the four-workgroups-per-sequence persistent kernels
     # (rnn_team.hip) against the launch-per-step kernels on the same batch.  6 / 17 / 70 / 11 / 401 chunk sequences:
@@ -269,16 +269,18 @@ def test_rnn_team_kernels_agree_with_per_step(cell, S, lens):
     outs = {}
     # mode '1' / None = the default selection (LSTM with more than 128 sequences: the MFMA team kernel, four sequences per
     # team step); 'v' = the VALU team kernels whatever the batch
-    for mode, ns in (('0', None), ('1', None), ('v', None), ('v', '1'), ('v', '2'), ('v', '4')):
+    # '8' = teams of eight workgroups (DC_DIMS_TEAM8, rnn_team8.hip: the default's choice for 65 .. 128 sequences only), '4' = never those
+    for mode, ns in (('0', None), ('1', None), ('8', None), ('4', None), ('v', None), ('v', '1'), ('v', '2'), ('v', '4')):
         eng = Engine(cell, 256, 1, dev)
         eng.kernel_flags = E.DC_DIMS_RNN_PER_STEP if mode == '0' else \
-            ((E.DC_DIMS_TEAM_VALU if mode == 'v' else 0) | (E.DC_DIMS_TEAM_NS(int(ns)) if ns else 0))
+            ((E.DC_DIMS_TEAM_VALU if mode == 'v' else 0) | (E.DC_DIMS_TEAM8 if mode == '8' else 0) | (E.DC_DIMS_TEAM4 if mode == '4' else 0) |
+             (E.DC_DIMS_TEAM_NS(int(ns)) if ns else 0))
         eng.load_state_dict(synth.init_state_dict(7, cell, 256, 1))
         rollouts = synth.make_rollouts(78, lens)
         batch = pack_rollouts(rollouts, S, dev)
         chunks = eng.rollout_pass(batch, S)
         res, status = eng.train_epoch(chunks, 5e-5, 5e-4, 0.5)
-        assert int(status.item()) == 0
+        assert int(status.item()) == 0 and eng.fault() is None, (mode, ns, E.describe_status(eng))
         outs[(mode, ns)] = (batch.values.cpu().numpy().copy(), batch.adv.cpu().numpy().copy(), res.cpu().numpy().copy(),
                             eng.grads.cpu().numpy().copy())
     for key in outs:
