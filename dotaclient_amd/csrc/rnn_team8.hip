@@ -365,407 +365,7 @@ __global__ __launch_bounds__(T8_THREADS, 2) void team8_bwd_kernel(RnnStepArgs p,
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Two groups of four sequences in flight per team (129 .. 256 sequences and beyond: 32 teams, ONE workgroup per CU).
-//
-// What two workgroups on a CU do not do by themselves - alternate - one workgroup does by construction: it advances group A, and while
-// A's granules travel (publish -> visible -> read, ~0.7 us) it advances group B, whose granules travel during A's next step:
-//     compute A(t) | collect B(t-1) | barrier | compute B(t) | collect A(t) | barrier
-// compute = product, k-quarter sums, gate math, publish, own h -> LDS;  collect = the other members' h of the step -> LDS.
-// Same weights for both groups (that is the point: the AGPRs are the scarce resource), same roles, same arithmetic per cell as
-// the one-group kernel; per-group state doubles in VGPRs (one wave per SIMD: there is room).
-// ---------------------------------------------------------------------------------------------------
-struct T8FwdGroup {
-    int b, len, tmax, live;
-    unsigned goff, soff, st_g, st_s, st_p, tag;
-    float c, svp0, svp1;
-    float sv[6];           // results of the last finished step: gates 0..3 (GRU: [3] = W_hn h + b_hn), c, h
-    float x[2][4];         // gate pre-activations: [t & 1] of the step at hand, the other being loaded for the next
-    u64* xb;
-};
-
-template <int CELL>     // 1: LSTM, 0: GRU
-__global__ __launch_bounds__(T8_THREADS, 1) void team8x2_fwd_kernel(RnnStepArgs p, u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
-    constexpr bool LSTM = CELL == 1;
-    constexpr int H = T8_H, G = LSTM ? 4 : 3, GH = G * H;
-    __shared__ __attribute__((aligned(16))) float h_lds[2][2][4 * 4 * T8_HLD];     // [group][buffer]
-    __shared__ float2 xch[2][4][4][64];                                             // [group][k quarter][sequence][lane]
-    __shared__ int dead;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hi = lane >> 5, ul = lane & 31;
-    int team, member;
-    team_claim_role_m<T8_M>(reinterpret_cast<unsigned*>(xbuf_all), n_teams, team, member);
-    if (team < 0) return;
-    u64* const xbuf = xbuf_all + TEAM_HDR + TEAM_MAX * T8_M;
-    const int plain = team_same_xcd_m<T8_M>(xbuf_all + TEAM_HDR + team * T8_M, member, allow_plain);
-    const int u = T8_US * member + ul;
-    const int slot = wave;
-    if (tid == 0) dead = 0;
-
-    float w0[T8_KQ], w1[T8_KQ];
-    {
-        const bool has1 = 2 * hi + 1 < G;
-        const float* r0 = p.Whh + (size_t)((2 * hi + 0) * H + u) * H + T8_KQ * wave;
-        const float* r1 = p.Whh + (size_t)((has1 ? 2 * hi + 1 : 0) * H + u) * H + T8_KQ * wave;
-#pragma unroll
-        for (int kk = 0; kk < T8_KQ; ++kk) { w0[kk] = r0[t8_korder(kk)]; w1[kk] = has1 ? r1[t8_korder(kk)] : 0.f; }
-    }
-    float bh[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bh[g] = g < G ? p.bhh[g * H + u] : 0.f;
-
-    T8FwdGroup S[2];
-    S[0].tag = S[1].tag = 0;                           // running step counters of the two rings (continue across pairs)
-    bool failed = false;
-    const int n_groups = (p.n_seq + 3) >> 2, n_pairs = (n_groups + 1) >> 1;
-
-    // product .. publish of one step of group GI (P = t & 1: LDS buffer and x set of the step)
-    auto compute = [&](auto GI, auto PAR, const int t) {
-        constexpr int gi = decltype(GI)::value, cur = decltype(PAR)::value;
-        T8FwdGroup& s = S[gi];
-        const bool on = t < s.len, on1 = t + 1 < s.len;
-        const unsigned gnx = s.goff + (on1 ? GH : 0);
-        const float* const lp = p.gates + gnx;
-        float* const gs = p.gates + s.st_g;
-        float* const cs = (LSTM ? p.cseq : p.hn) + s.st_s;
-        float* const hs = p.hseq + s.st_s;
-        float* const cp = LSTM ? p.cprev + s.st_p : nullptr;
-        float* const hp = p.hprev + s.st_p;
-        auto hook = [&](auto K) {
-            constexpr int k = decltype(K)::value;          // 0 .. 31
-            if constexpr (k >= 1 && k <= G) s.x[cur ^ 1][k - 1] = lp[(k - 1) * H];
-            else if constexpr (k >= 8 && k < 8 + G) gs[(k - 8) * H] = s.sv[k - 8];
-            else if constexpr (k == 12) *cs = s.sv[LSTM ? 4 : 3];
-            else if constexpr (k == 13) *hs = s.sv[5];
-            else if constexpr (k == 14 && LSTM) *cp = s.svp0;
-            else if constexpr (k == 15) *hp = s.svp1;
-        };
-        f32x4 pa[4];
-        FwdProduct<T8_KQ>::run(pa, w0, w1, lds_addr(&h_lds[gi][cur][(wave * 4 + (lane & 3)) * T8_HLD + (lane >> 2) * 4]), hook);
-        const f32x4 acc0 = pa[0] + pa[2], acc1 = pa[1] + pa[3];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xch[gi][wave][q][lane] = make_float2(acc0[q], acc1[q]);
-        __syncthreads();
-        float y0, y1;
-        {
-            const float2 a = xch[gi][0][slot][lane], bq = xch[gi][1][slot][lane], cq = xch[gi][2][slot][lane], dq = xch[gi][3][slot][lane];
-            y0 = ((a.x + bq.x) + cq.x) + dq.x;
-            y1 = ((a.y + bq.y) + cq.y) + dq.y;
-        }
-        float x0 = y0, x1 = y1;
-        half_swap(y0, x0);
-        half_swap(y1, x1);
-        const float ig = fast_sigmoid(s.x[cur][0] + (y0 + bh[0]));
-        const float fg = fast_sigmoid(s.x[cur][1] + (y1 + bh[1]));
-        const float og = LSTM ? fast_sigmoid(s.x[cur][3] + (x1 + bh[3])) : x0 + bh[2];
-        const float gg = LSTM ? fast_tanh(s.x[cur][2] + (x0 + bh[2])) : fast_tanh(s.x[cur][2] + ig * og);
-        const float cn = LSTM ? fg * s.c + ig * gg : (1.f - fg) * gg + fg * s.c;
-        const float hn = LSTM ? og * fast_tanh(cn) : cn;
-        const float hpub = on ? hn : 0.f;
-        ++s.tag;
-        if (hi == 0) granule_store(s.xb + (s.tag & 3) * H + u, hpub, s.tag, plain);
-        h_lds[gi][cur ^ 1][t8_hpos(slot, u)] = hpub;
-        s.c = on ? cn : s.c;
-        s.sv[0] = on ? ig : s.sv[0]; s.sv[1] = on ? fg : s.sv[1]; s.sv[2] = on ? gg : s.sv[2];
-        s.sv[3] = on ? og : s.sv[3]; s.sv[4] = on ? cn : s.sv[4]; s.sv[5] = on ? hn : s.sv[5];
-        s.st_g = on ? s.goff : s.st_g;
-        s.st_s = on ? s.soff : s.st_s;
-        s.svp0 = on1 ? cn : s.svp0;
-        s.svp1 = on1 ? hn : s.svp1;
-        s.st_p = on1 ? s.soff + H : s.st_p;
-        s.goff = gnx;
-        s.soff += on1 ? H : 0;
-    };
-    // the other members' h of group GI's step t (its tag is the group's current one) -> the LDS buffer of step t + 1
-    auto collect = [&](auto GI, auto PAR, const int t) {
-        constexpr int gi = decltype(GI)::value, cur = decltype(PAR)::value;     // cur: buffer step t read
-        T8FwdGroup& s = S[gi];
-        u64 gr[4];
-        const u64* ga[4];
-        int uu[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uu[j] = T8_US * ((member + 1 + 4 * hi + j) & 7) + ul;
-            ga[j] = s.xb + (s.tag & 3) * H + uu[j];
-            gr[j] = granule_load(ga[j]);
-        }
-        if (!granule_wait_all<4>(gr, ga, s.tag)) { dead = 1; team_report_timeout(p.fault, TEAM_K_T8_FWD, p.layer, team, member, t, s.b, s.tag); }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) h_lds[gi][cur ^ 1][t8_hpos(slot, uu[j])] = __uint_as_float((unsigned)gr[j]);
-    };
-    // one time step of both groups; P = t & 1
-    auto iteration = [&](auto PAR, const int t) {
-        constexpr int par = decltype(PAR)::value;
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        using Q = std::integral_constant<int, par ^ 1>;
-        if (S[0].live && t < S[0].tmax) compute(I0{}, PAR, t);
-        if (S[1].live && t >= 1 && t < S[1].tmax) collect(I1{}, Q{}, t - 1);      // B's step t - 1 read buffer par ^ 1
-        __syncthreads();
-        if (S[1].live && t < S[1].tmax) compute(I1{}, PAR, t);
-        if (S[0].live && t + 1 < S[0].tmax) collect(I0{}, PAR, t);
-        __syncthreads();
-        return dead == 0;
-    };
-
-    for (int pp = team; pp < n_pairs && !failed; pp += n_teams) {
-#pragma unroll
-        for (int gi = 0; gi < 2; ++gi) {
-            T8FwdGroup& s = S[gi];
-            int bmap[4], tmax = 0;
-            const int grp = 2 * pp + gi;
-            s.live = grp < n_groups && map_slots(p, 4 * grp, bmap, tmax);
-            s.tmax = s.live ? tmax : 0;
-            if (!s.live) { bmap[0] = bmap[1] = bmap[2] = bmap[3] = 0; }
-            s.b = slot == 0 ? bmap[0] : (slot == 1 ? bmap[1] : (slot == 2 ? bmap[2] : bmap[3]));
-            s.len = s.live ? p.seq_len[s.b] : 0;
-            const unsigned row0 = (unsigned)p.seq_off[s.b];
-            s.goff = row0 * GH + u; s.soff = row0 * H + u;
-            s.st_g = s.goff; s.st_s = s.soff; s.st_p = s.soff;
-            const float h0v = p.h0 ? p.h0[(size_t)s.b * H + u] : 0.f;
-            s.c = LSTM ? (p.c0 ? p.c0[(size_t)s.b * H + u] : 0.f) : h0v;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) s.sv[i] = 0.f;
-            s.svp0 = s.c; s.svp1 = h0v;
-            if (s.live) {
-                for (int e = tid; e < 4 * H; e += T8_THREADS) {
-                    const int q = e >> 8, j = e & (H - 1);
-                    const int bq = q == 0 ? bmap[0] : (q == 1 ? bmap[1] : (q == 2 ? bmap[2] : bmap[3]));
-                    h_lds[gi][0][t8_hpos(q, j)] = p.h0 ? p.h0[(size_t)bq * H + j] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) { s.x[0][g] = (g < G && s.live) ? p.gates[s.goff + g * H] : 0.f; s.x[1][g] = 0.f; }
-            s.xb = xbuf + (size_t)((team * 2 + gi) * 4 + slot) * (TEAM_SLOTS * H);
-        }
-        __syncthreads();
-        const int tm = max(S[0].tmax, S[1].tmax);
-        for (int t = 0; t < tm; t += 2) {
-            if (!iteration(std::integral_constant<int, 0>{}, t)) { failed = true; break; }
-            if (t + 1 < tm && !iteration(std::integral_constant<int, 1>{}, t + 1)) { failed = true; break; }
-        }
-        // drain: the deferred stores of each group's last step
-#pragma unroll
-        for (int gi = 0; gi < 2; ++gi) {
-            T8FwdGroup& s = S[gi];
-            if (s.live) {
-#pragma unroll
-                for (int g = 0; g < G; ++g) p.gates[s.st_g + g * H] = s.sv[g];
-                if constexpr (LSTM) { p.cseq[s.st_s] = s.sv[4]; p.cprev[s.st_p] = s.svp0; }
-                else p.hn[s.st_s] = s.sv[3];
-                p.hseq[s.st_s] = failed ? __builtin_nanf("") : s.sv[5];
-                p.hprev[s.st_p] = s.svp1;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-struct T8BwdGroup {
-    int b, len, tmax, live;
-    unsigned goff, soff, st_g, gnx, snx, tag;
-    float dc_next, f_next, svh2;
-    float v[2][7];         // [step parity] LSTM: i, f, g, o, c, c_prev, dh;  GRU: r, z, n, W_hn h + b_hn, -, h_prev, dh
-    float sv[4];           // gate gradients of the last finished step, stored one step late
-    u64* ring0;
-};
-
-// Backward, two groups in flight:  product + scatter A(t) | sources, cell math B(t') | barrier | product + scatter B(t) | sources, cell math A(t) | barrier
-// (t' = B's step of the previous iteration): a group's partial sums travel while the other group's product runs.
-template <int CELL>
-__global__ __launch_bounds__(T8_THREADS, 1) void team8x2_bwd_kernel(RnnStepArgs p, u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
-    constexpr bool LSTM = CELL == 1;
-    constexpr int H = T8_H, G = LSTM ? 4 : 3, GH = G * H, KH = T8B_KH;
-    __shared__ __attribute__((aligned(16))) float g_lds[2][2][4 * T8B_GLD];   // [group][buffer]
-    __shared__ float own[2][4][T8_US];
-    __shared__ int dead;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hi = lane >> 5, ul = lane & 31;
-    int team, member;
-    team_claim_role_m<T8_M>(reinterpret_cast<unsigned*>(xbuf_all), n_teams, team, member);
-    if (team < 0) return;
-    u64* const xbuf = xbuf_all + TEAM_HDR + TEAM_MAX * T8_M;
-    const int plain = team_same_xcd_m<T8_M>(xbuf_all + TEAM_HDR + team * T8_M, member, allow_plain);
-    const int up = tid, owner = tid >> 5;
-    const int slot = wave;
-    const int u = T8_US * member + ul;
-    if (tid == 0) dead = 0;
-
-    float w[KH];
-#pragma unroll
-    for (int kk = 0; kk < KH; ++kk) {
-        const int k = t8b_korder(kk);
-        w[kk] = (k >> 5) < G ? p.Whh[(size_t)((k >> 5) * H + T8_US * member + (k & 31)) * H + up] : 0.f;
-    }
-
-    T8BwdGroup S[2];
-    S[0].tag = S[1].tag = 0;
-    S[0].ring0 = xbuf + (size_t)(team * 2 + 0) * T8_BWD_RING;
-    S[1].ring0 = xbuf + (size_t)(team * 2 + 1) * T8_BWD_RING;
-    bool failed = false;
-    const int n_groups = (p.n_seq + 3) >> 2, n_pairs = (n_groups + 1) >> 1;
-
-    // product over the member's own gate gradients of step t + 1 (LDS buffer cur), partial sums to their owners
-    auto compute = [&](auto GI, auto PAR, const int t) {
-        constexpr int gi = decltype(GI)::value, cur = decltype(PAR)::value;
-        T8BwdGroup& s = S[gi];
-        const bool dec = t < s.len && t > 0;                                          // dec: the row below is next
-        const bool xchg = t + 1 < s.tmax;
-        s.gnx = s.goff - (dec ? GH : 0); s.snx = s.soff - (dec ? H : 0);
-        const float* const lg = p.gates + s.gnx;
-        const float* const lc = (LSTM ? p.cseq : p.hn) + s.snx;
-        const float* const lcp = (LSTM ? p.cprev : p.hprev) + s.snx;
-        const float* const ldh = p.dh + s.snx;
-        float* const gs = p.dgx + s.st_g;
-        float* const ghs = LSTM ? nullptr : p.dgh + s.st_g;
-        auto hook = [&](auto K) {
-            constexpr int k = decltype(K)::value;          // 0 .. 31
-            if constexpr (k >= 1 && k <= G) s.v[cur ^ 1][k - 1] = lg[(k - 1) * H];
-            else if constexpr (k == 5) s.v[cur ^ 1][LSTM ? 4 : 3] = *lc;
-            else if constexpr (k == 6) s.v[cur ^ 1][5] = *lcp;
-            else if constexpr (k == 7) s.v[cur ^ 1][6] = *ldh;
-            else if constexpr (k >= 10 && k < 10 + G) gs[(k - 10) * H] = s.sv[k - 10];
-            else if constexpr (!LSTM && (k == 14 || k == 15)) ghs[(k - 14) * H] = s.sv[k - 14];
-            else if constexpr (!LSTM && k == 16) ghs[2 * H] = s.svh2;
-        };
-        f32x4 pa[4];
-        BwdProduct<KH>::run(pa, w, lds_addr(&g_lds[gi][cur][(lane & 3) * T8B_GLD + ((lane >> 2) & 7) * T8B_BLK]), hook);
-        const f32x4 acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
-        ++s.tag;
-        if (xchg) {
-            u64* const ring = s.ring0 + (size_t)(s.tag & 3) * T8_BWD_STAGE;
-            if (owner == member) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) own[gi][q][ul] = acc[q];
-            } else {
-                u64* dst = ring + ((size_t)(owner * T8_M + member) * 4) * T8_US + ul;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) granule_store(dst + q * T8_US, acc[q], s.tag, plain);
-            }
-        }
-    };
-    // the seven other members' partial sums of step t, the cell's gate gradients, the image of the next product (buffer cur ^ 1)
-    auto finish = [&](auto GI, auto PAR, const int t) {
-        constexpr int gi = decltype(GI)::value, cur = decltype(PAR)::value;
-        T8BwdGroup& s = S[gi];
-        const bool on = t < s.len, has_next = t + 1 < s.len;
-        const bool xchg = t + 1 < s.tmax;
-        float rec = 0.f;
-        if (xchg) {
-            u64* const ring = s.ring0 + (size_t)(s.tag & 3) * T8_BWD_STAGE;
-            u64 gr[4];
-            const u64* ga[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int src = (member + 1 + 4 * hi + (hi && j == 3 ? 2 : j)) & 7;
-                ga[j] = ring + ((size_t)(member * T8_M + src) * 4 + slot) * T8_US + ul;
-                gr[j] = granule_load(ga[j]);
-            }
-            float part = hi ? 0.f : own[gi][slot][ul];
-            if (!granule_wait_all<4>(gr, ga, s.tag)) { dead = 1; team_report_timeout(p.fault, TEAM_K_T8_BWD, p.layer, team, member, t, s.b, s.tag); }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) part += (hi && j == 3) ? 0.f : __uint_as_float((unsigned)gr[j]);
-            float p0 = part, p1 = part;
-            half_swap(p0, p1);
-            rec = p0 + p1;
-        }
-        float dh = s.v[cur][6];
-        dh += has_next ? rec : 0.f;
-        const float ig = s.v[cur][0], fg = s.v[cur][1], gg = s.v[cur][2], og = s.v[cur][3];
-        float dgr[4];
-        if constexpr (LSTM) {
-            const float tc = fast_tanh(s.v[cur][4]);
-            float dcv = dh * og * (1.f - tc * tc);
-            dcv += has_next ? s.dc_next * s.f_next : 0.f;
-            dgr[0] = on ? dcv * gg * ig * (1.f - ig) : 0.f; dgr[1] = on ? dcv * s.v[cur][5] * fg * (1.f - fg) : 0.f;
-            dgr[2] = on ? dcv * ig * (1.f - gg * gg) : 0.f; dgr[3] = on ? dh * tc * og * (1.f - og) : 0.f;
-            s.sv[0] = on ? dgr[0] : s.sv[0]; s.sv[1] = on ? dgr[1] : s.sv[1]; s.sv[2] = on ? dgr[2] : s.sv[2]; s.sv[3] = on ? dgr[3] : s.sv[3];
-            s.dc_next = on ? dcv : s.dc_next;
-        } else {
-            dh += has_next ? s.dc_next * s.f_next : 0.f;
-            const float dn_pre = dh * (1.f - fg) * (1.f - gg * gg);
-            const float dz_pre = dh * (s.v[cur][5] - gg) * fg * (1.f - fg);
-            const float dr_pre = dn_pre * og * ig * (1.f - ig);
-            dgr[0] = on ? dr_pre : 0.f; dgr[1] = on ? dz_pre : 0.f; dgr[2] = on ? dn_pre * ig : 0.f; dgr[3] = 0.f;
-            s.sv[0] = on ? dr_pre : s.sv[0]; s.sv[1] = on ? dz_pre : s.sv[1]; s.sv[2] = on ? dn_pre : s.sv[2];
-            s.svh2 = on ? dn_pre * ig : s.svh2;
-            s.dc_next = on ? dh : s.dc_next;
-        }
-        if (hi == 0) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) g_lds[gi][cur ^ 1][slot * T8B_GLD + t8b_pos(T8_US * g + ul)] = dgr[g];
-        }
-        s.st_g = on ? s.goff : s.st_g;
-        s.f_next = on ? fg : s.f_next;
-        s.goff = s.gnx;
-        s.soff = s.snx;
-    };
-    // iteration i: group X works on step tmax_X - 1 - i; parity of a step = i & 1
-    auto iteration = [&](auto PAR, const int i) {
-        constexpr int par = decltype(PAR)::value;
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        using Q = std::integral_constant<int, par ^ 1>;
-        const int tA = S[0].tmax - 1 - i, tB = S[1].tmax - 1 - i;
-        if (S[0].live && tA >= 0) compute(I0{}, PAR, tA);
-        if (S[1].live && i >= 1 && tB + 1 >= 0) finish(I1{}, Q{}, tB + 1);
-        __syncthreads();
-        if (S[1].live && tB >= 0) compute(I1{}, PAR, tB);
-        if (S[0].live && tA >= 0) finish(I0{}, PAR, tA);
-        __syncthreads();
-        return dead == 0;
-    };
-
-    for (int pp = team; pp < n_pairs && !failed; pp += n_teams) {
-#pragma unroll
-        for (int gi = 0; gi < 2; ++gi) {
-            T8BwdGroup& s = S[gi];
-            int bmap[4], tmax = 0;
-            const int grp = 2 * pp + gi;
-            s.live = grp < n_groups && map_slots(p, 4 * grp, bmap, tmax);
-            s.tmax = s.live ? tmax : 0;
-            if (!s.live) { bmap[0] = bmap[1] = bmap[2] = bmap[3] = 0; }
-            s.b = slot == 0 ? bmap[0] : (slot == 1 ? bmap[1] : (slot == 2 ? bmap[2] : bmap[3]));
-            s.len = s.live ? p.seq_len[s.b] : 0;
-            const unsigned row = (unsigned)p.seq_off[s.b] + (unsigned)max(0, min(s.tmax - 1, s.len - 1));
-            s.goff = row * GH + u; s.soff = row * H + u; s.st_g = s.goff; s.gnx = s.goff; s.snx = s.soff;
-            s.dc_next = 0.f; s.f_next = 0.f; s.svh2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 7; ++i) { s.v[0][i] = 0.f; s.v[1][i] = 0.f; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s.sv[i] = 0.f;
-            if (s.live) {
-#pragma unroll
-                for (int g = 0; g < G; ++g) s.v[0][g] = p.gates[s.goff + g * H];
-                if constexpr (LSTM) { s.v[0][4] = p.cseq[s.soff]; s.v[0][5] = p.cprev[s.soff]; }
-                else { s.v[0][3] = p.hn[s.soff]; s.v[0][5] = p.hprev[s.soff]; }
-                s.v[0][6] = p.dh[s.soff];
-                for (int e = tid; e < 4 * T8B_GLD; e += T8_THREADS) g_lds[gi][0][e] = 0.f;      // "step tmax" has no gradient
-            }
-        }
-        __syncthreads();
-        const int tm = max(S[0].tmax, S[1].live ? S[1].tmax + 1 : 0);
-        for (int i = 0; i < tm; i += 2) {
-            if (!iteration(std::integral_constant<int, 0>{}, i)) { failed = true; break; }
-            if (i + 1 < tm && !iteration(std::integral_constant<int, 1>{}, i + 1)) { failed = true; break; }
-        }
-#pragma unroll
-        for (int gi = 0; gi < 2; ++gi) {
-            T8BwdGroup& s = S[gi];
-            if (s.live) {
-#pragma unroll
-                for (int g = 0; g < G; ++g) p.dgx[s.st_g + g * H] = failed ? __builtin_nanf("") : s.sv[g];
-                if constexpr (!LSTM) { p.dgh[s.st_g] = s.sv[0]; p.dgh[s.st_g + H] = s.sv[1]; p.dgh[s.st_g + 2 * H] = s.svh2; }
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// teams that can be resident together with ONE workgroup per CU (two would fit - 128 AGPRs + ~96 VGPRs per lane - but two workgroups on a
-// CU disturb each other: profiles/r04/team8_vs_team4.txt; more than a round of groups goes through the two-groups-in-flight kernels)
+// teams that can be resident together: two 256-thread workgroups per CU, eight per team
 int team8_capacity() {
     constexpr int MAXDEV = 64;
     static int cap_of[MAXDEV];             // 0 = not queried yet
@@ -773,20 +373,20 @@ int team8_capacity() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return 0;
     if (cap_of[dev] == 0) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        int t = cus / T8_M;
-        t = t > TEAM_MAX / 2 ? TEAM_MAX / 2 : t;
+        int t = 2 * cus / T8_M;
+        t = t > TEAM_MAX ? TEAM_MAX : t;
         cap_of[dev] = t >= 8 ? (t & ~7) : (t > 0 ? t : -1);
     }
     return cap_of[dev] > 0 ? cap_of[dev] : 0;
 }
 
-// teams to launch for `units` units of work (groups of four sequences, or pairs of groups), one after the other per team: as
-// rnn_team_mfma.hip's plan (a multiple of 8 teams keeps every team on one XCD)
-int team8_plan(int units) {
+// teams to launch: as rnn_team_mfma.hip's plan (a multiple of 8 teams keeps every team on one XCD)
+int team8_plan(int n_seq) {
     const int cap = team8_capacity();
-    const int nt_f = units < cap ? units : cap;
+    const int groups = (n_seq + 3) / 4;
+    const int nt_f = groups < cap ? groups : cap;
     const int nt_q = nt_f >= 8 ? (nt_f & ~7) : nt_f;
-    const int rounds_f = (units + nt_f - 1) / nt_f, rounds_q = (units + nt_q - 1) / nt_q;
+    const int rounds_f = (groups + nt_f - 1) / nt_f, rounds_q = (groups + nt_q - 1) / nt_q;
     return (nt_q != nt_f && rounds_f * 1.25 < rounds_q) ? nt_f : nt_q;
 }
 
@@ -804,48 +404,30 @@ long long rnn_team8_xbuf_bytes() {
 bool rnn_team8_supported(int cell, int H, int n_seq, int flags) {
     if (!((cell == 0 || cell == 1) && H == T8_H && n_seq >= 1) || (flags & (DC_DIMS_TEAM_VALU | DC_DIMS_TEAM4)) || team8_capacity() < 1) return false;
     if (flags & DC_DIMS_TEAM8) return true;
-    return n_seq > 64 && (n_seq + 3) / 4 <= team8_capacity();
+    return n_seq > 64 && (n_seq + 3) / 4 <= team8_capacity() / 2;
 }
 
 int rnn_team8_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     u64* xb = static_cast<u64*>(a.xbuf);
     if (!xb) { set_error("rnn_team8_forward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }
-    const int groups = (a.n_seq + 3) / 4;
-    const bool two = groups > team8_capacity();                  // more than one group per team: two in flight
-    const int nt = team8_plan(two ? (groups + 1) / 2 : groups);
+    const int nt = team8_plan(a.n_seq);
     const double G = cell == 1 ? 4.0 : 3.0;
     ProfScope prof(cell == 1 ? "lstm_fwd_team" : "gru_fwd_team", 2.0 * a.n_seq * G * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * (2.0 * G + 4.0), s);
-    if (int rc = zero_async(xb, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * T8_M + (size_t)nt * (two ? 2 : 1) * T8_FWD_RING) * sizeof(u64), s)) return rc;
-    const dim3 grid(nt * T8_M), block(T8_THREADS);
-    const int allow = !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE);
-    if (two) {
-        if (cell == 1) hipLaunchKernelGGL(team8x2_fwd_kernel<1>, grid, block, 0, s, a, xb, nt, allow);
-        else hipLaunchKernelGGL(team8x2_fwd_kernel<0>, grid, block, 0, s, a, xb, nt, allow);
-    } else {
-        if (cell == 1) hipLaunchKernelGGL(team8_fwd_kernel<1>, grid, block, 0, s, a, xb, nt, allow);
-        else hipLaunchKernelGGL(team8_fwd_kernel<0>, grid, block, 0, s, a, xb, nt, allow);
-    }
+    if (int rc = zero_async(xb, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * T8_M + (size_t)nt * T8_FWD_RING) * sizeof(u64), s)) return rc;
+    if (cell == 1) hipLaunchKernelGGL(team8_fwd_kernel<1>, dim3(nt * T8_M), dim3(T8_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+    else hipLaunchKernelGGL(team8_fwd_kernel<0>, dim3(nt * T8_M), dim3(T8_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
     return launch_check("rnn_team8_forward");
 }
 
 int rnn_team8_backward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     u64* xb = static_cast<u64*>(a.xbuf);
     if (!xb) { set_error("rnn_team8_backward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }
-    const int groups = (a.n_seq + 3) / 4;
-    const bool two = groups > team8_capacity();
-    const int nt = team8_plan(two ? (groups + 1) / 2 : groups);
+    const int nt = team8_plan(a.n_seq);
     const double G = cell == 1 ? 4.0 : 3.0;
     ProfScope prof(cell == 1 ? "lstm_bwd_team" : "gru_bwd_team", 2.0 * a.n_seq * G * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * (3.0 * G + 6.0), s);
-    if (int rc = zero_async(xb, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * T8_M + (size_t)nt * (two ? 2 : 1) * T8_BWD_RING) * sizeof(u64), s)) return rc;
-    const dim3 grid(nt * T8_M), block(T8_THREADS);
-    const int allow = !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE);
-    if (two) {
-        if (cell == 1) hipLaunchKernelGGL(team8x2_bwd_kernel<1>, grid, block, 0, s, a, xb, nt, allow);
-        else hipLaunchKernelGGL(team8x2_bwd_kernel<0>, grid, block, 0, s, a, xb, nt, allow);
-    } else {
-        if (cell == 1) hipLaunchKernelGGL(team8_bwd_kernel<1>, grid, block, 0, s, a, xb, nt, allow);
-        else hipLaunchKernelGGL(team8_bwd_kernel<0>, grid, block, 0, s, a, xb, nt, allow);
-    }
+    if (int rc = zero_async(xb, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * T8_M + (size_t)nt * T8_BWD_RING) * sizeof(u64), s)) return rc;
+    if (cell == 1) hipLaunchKernelGGL(team8_bwd_kernel<1>, dim3(nt * T8_M), dim3(T8_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+    else hipLaunchKernelGGL(team8_bwd_kernel<0>, dim3(nt * T8_M), dim3(T8_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
     return launch_check("rnn_team8_backward");
 }
 
