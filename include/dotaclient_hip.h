@@ -197,11 +197,11 @@ enum dc_ws_index {
     DC_WS_PER_LAYER
 };
 
-/* DC_WS_FAULT - where a failure of the team kernels (H = 256: four workgroups per team; LSTM-512 in bf16 mode: sixteen) is
+/* DC_WS_FAULT - where a failure of the team kernels (H = 256: four or eight workgroups per team; LSTM-512 in bf16 mode: sixteen) is
  * reported.  Those kernels hand state between the workgroups of a team through tagged granules; a member that polls one for ~1 s without seeing its tag gives up, NaN-poisons its outputs (the loss
  * turns NaN: status 1 of dc_gradnorm_clip_adam, the reference's own guard, optimizer.py:667-669) and - first writer wins - records
  *   [0] DC_FAULT_TEAM_TIMEOUT + kernel (1 rnn_team_fwd, 2 rnn_team_bwd, 3 team_mfma_fwd, 4 team_mfma_bwd, 5 lstm512_team_fwd,
- *   6 lstm512_team_bwd), [1] layer, [2] team,
+ *   6 lstm512_team_bwd, 7 team8_fwd, 8 team8_bwd), [1] layer, [2] team,
  *   [3] member, [4] time step, [5] sequence, [6] the tag it waited for, [7] reserved.
  * The record is STICKY: the library never clears it.  The owner of the workspace zeroes these 32 bytes once after allocating it
  * (and again after reading a fault, if it wants to carry on). */
