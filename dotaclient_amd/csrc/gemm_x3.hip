@@ -43,6 +43,18 @@ enum { XB = 128, XK = 16 };
 enum { RM_ROW_BYTES = 48, RM_PLANE = XB * RM_ROW_BYTES /* 6144 */, KM_PLANE = 8 * XB * 4 /* 4096 */ };
 enum { OPER_BYTES = 3 * RM_PLANE, STAGE_BYTES = 2 * OPER_BYTES, X3_LDS = 2 * STAGE_BYTES /* 73728 */ };
 enum { EP_LD = 68 };   // floats per row of a wave's 64 x 64 epilogue image (4 x 64 x 68 x 4 = 69632 <= X3_LDS)
+// PREC = 4 needs two planes per operand, not three: 48 KB of stage buffers per workgroup instead of 72 - room for a THIRD workgroup per CU
+// (150 / 164 VGPRs: three waves per SIMD fit) if the epilogue goes through a half-size image (32 rows at a time, 34 KB).  A/B switch:
+// -DDC_X3_OCC=2 keeps two workgroups per CU for every precision.
+#ifndef DC_X3_OCC
+#define DC_X3_OCC 3
+#endif
+template <int PREC> struct X3Cfg {
+    static constexpr bool kThree = PREC == 4 && DC_X3_OCC == 3;
+    static constexpr int kOcc = kThree ? 3 : 2;
+    static constexpr int kOper = (kThree ? 2 : 3) * RM_PLANE, kStage = 2 * kOper, kLds = 2 * kStage;   // 49152 / 73728
+    static constexpr int kImgRows = kThree ? 32 : 64;
+};
 
 struct X3Args {
     const void* A; const void* B; const void* B2;
@@ -171,14 +183,19 @@ static __device__ __forceinline__ void store_tile(const X3Args& p, f32x16 (&acc)
     const int fr = lane & 31, fg = lane >> 5;
     // ---- epilogue: accumulators -> this wave's 64 x 64 LDS image -> 16-byte rows ----------------------------------------
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    float* img = reinterpret_cast<float*>(smem) + wave * (64 * EP_LD);
+    constexpr int IMG_ROWS = X3Cfg<PREC>::kImgRows;      // 64: the whole 64 x 64 block at once; 32: its two row halves one after the other
+    float* img = reinterpret_cast<float*>(smem) + wave * (IMG_ROWS * EP_LD);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int half = 0; half < 64 / IMG_ROWS; ++half) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (IMG_ROWS == 32 && i != half) continue;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                img[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * EP_LD + j * 32 + fr] = PREC == 4 ? acc[i][j][r] * p.inv : acc[i][j][r];
+                img[((IMG_ROWS == 64 ? i * 32 : 0) + (r & 3) + 8 * (r >> 2) + 4 * fg) * EP_LD + j * 32 + fr] = PREC == 4 ? acc[i][j][r] * p.inv : acc[i][j][r];
+    }
     // (each wave reads back only what it wrote: no workgroup barrier needed, the LDS is in order per wave)
     const int c4 = (lane & 15) * 4;
     const int col = n_blk + wn * 64 + c4;
@@ -192,9 +209,9 @@ static __device__ __forceinline__ void store_tile(const X3Args& p, f32x16 (&acc)
     }
     const bool to_c2 = p.n_split > 0 && col >= p.n_split;
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < IMG_ROWS / 4; ++it) {
         const int rl = it * 4 + (lane >> 4);
-        const int row = m_blk + wm * 64 + rl;
+        const int row = m_blk + wm * 64 + half * IMG_ROWS + rl;
         float4 v = *reinterpret_cast<const float4*>(img + rl * EP_LD + c4);
         if (row >= p.M || !col_ok) continue;
         if (p.slab != nullptr) {
@@ -214,13 +231,15 @@ static __device__ __forceinline__ void store_tile(const X3Args& p, f32x16 (&acc)
         }
         *reinterpret_cast<float4*>(c) = v;
     }
+    }   // row halves
 }
 
 // Persistent: a workgroup walks the (row tile, column tile, K split) work items w = first, first + stride, ...; the loads
 // of the NEXT item's first two K steps are issued before the epilogue of the current one.  Inside an item the loads run
 // two K steps ahead of the MFMAs (two register staging sets), the split + LDS store one step ahead (two LDS stages).
 template <int PREC, int A_MODE, int B_MODE>
-__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args p, int n_items, int mt, int nt) {
+__global__ __launch_bounds__(256, X3Cfg<PREC>::kOcc) void gemm_x3_kernel(X3Args p, int n_items, int mt, int nt) {
+    constexpr int OPER_BYTES = X3Cfg<PREC>::kOper, STAGE_BYTES = X3Cfg<PREC>::kStage;      // (shadow the three-plane sizes)
     constexpr int NP = PREC == 1 ? 1 : (PREC == 4 ? 2 : 3);
     constexpr bool F16 = PREC == 4;
     using LA = X3Loader<A_MODE, NP, F16>;
@@ -341,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Args p, int n_items, 
 
         if (do_cs) {     // thread (kp = tid >> 5, c4 = tid & 31) holds the sums of rows m_blk + 4 c4 .. + 3 over its k of every pair: fold the
                          // eight k lanes through the 4 KB of LDS behind the epilogue images, one atomic per row (like colsum_kernel's)
-            float* red = reinterpret_cast<float*>(smem + 4 * 64 * EP_LD * 4);
+            float* red = reinterpret_cast<float*>(smem + 4 * X3Cfg<PREC>::kImgRows * EP_LD * 4);
             *reinterpret_cast<float4*>(red + (tid >> 5) * XB + (tid & 31) * 4) = cs;
             __syncthreads();
             if (tid < XB && m_blk + tid < p.M) {
@@ -399,19 +418,19 @@ template <int PREC, int AM, int BM_>
 static int launch_x3(const X3Args& a, int splits, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_x3_kernel<PREC, AM, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_x3_kernel<PREC, AM, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, X3Cfg<PREC>::kLds);
         if (e != hipSuccess) { set_error("gemm_x3: hipFuncSetAttribute", (int)e); return (int)e; }
         attr_done = true;
     }
     const int mt = (a.M + XB - 1) / XB, nt = (a.N + XB - 1) / XB;
     const int n_items = mt * nt * splits;
-    static const int slots = [] {      // two workgroups per CU (LDS-limited)
+    static const int slots = [] {      // two (three: X3Cfg) workgroups per CU (LDS-limited)
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-        return 2 * cus;
+        return X3Cfg<PREC>::kOcc * cus;
     }();
     const int grid = n_items < slots ? n_items : slots;
-    hipLaunchKernelGGL((gemm_x3_kernel<PREC, AM, BM_>), dim3(grid), dim3(256), X3_LDS, s, a, n_items, mt, nt);
+    hipLaunchKernelGGL((gemm_x3_kernel<PREC, AM, BM_>), dim3(grid), dim3(256), X3Cfg<PREC>::kLds, s, a, n_items, mt, nt);
     return launch_check("gemm_x3");
 }
 
@@ -430,7 +449,7 @@ int gemm_x3(const X3Gemm& g, hipStream_t stream) {
     int splits = 1;
     const long tiles = (long)((g.M + XB - 1) / XB) * ((g.N + XB - 1) / XB);
     if (tiles < 256 && g.K >= 4096 && !g.relu && g.aux == nullptr && g.scratch.p != nullptr) {
-        long want = 512 / tiles;                  // two workgroups per CU
+        long want = (g.prec == 4 && DC_X3_OCC == 3 ? 768 : 512) / tiles;      // two (three) workgroups per CU
         if (want < 1) want = 1;
         const long maxs = g.K / 512;
         splits = (int)(want < maxs ? want : maxs);
