@@ -91,6 +91,19 @@ __device__ __forceinline__ void mfma_pair_seq(f32x4& c0, f32x4& c1, float a, flo
                      : "v"(a), "a"(w0), "a"(w1), "i"(ABID0), "i"(ABID1));
     }
 }
+// c0 (+)= bcast_b0(a0) * w0 ; c1 (+)= bcast_b1(a1) * w1   (two different k of ONE column, whole-wave broadcast: cbsz:4)
+template <bool ZERO, int ABID0, int ABID1>
+__device__ __forceinline__ void mfma_pair_k(f32x4& c0, f32x4& c1, float a0, float a1, float w0, float w1) {
+    if constexpr (ZERO) {
+        asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %2, %4, 0 cbsz:4 abid:%6\n\tv_mfma_f32_4x4x1_16b_f32 %1, %3, %5, 0 cbsz:4 abid:%7"
+                     : "=&v"(c0), "=&v"(c1)
+                     : "v"(a0), "v"(a1), "a"(w0), "a"(w1), "i"(ABID0), "i"(ABID1));
+    } else {
+        asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %2, %4, %0 cbsz:4 abid:%6\n\tv_mfma_f32_4x4x1_16b_f32 %1, %3, %5, %1 cbsz:4 abid:%7"
+                     : "+v"(c0), "+v"(c1)
+                     : "v"(a0), "v"(a1), "a"(w0), "a"(w1), "i"(ABID0), "i"(ABID1));
+    }
+}
 // MFMA -> VALU read hazard, padded by hand (nothing after an asm is padded by the compiler)
 __device__ __forceinline__ void mfma_tail_pad(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
     asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
@@ -102,6 +115,22 @@ __device__ __forceinline__ void half_swap(float& lo, float& hi_) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi_), false, false);
     lo = __uint_as_float(r[0]);
     hi_ = __uint_as_float(r[1]);
+}
+
+// lanes 16..31 / 48..63 of `lo` <-> lanes 0..15 / 32..47 of `hi_` (v_permlane16_swap: inside each half of the wave, the upper
+// sixteen lanes of the first operand change places with the lower sixteen of the second)
+__device__ __forceinline__ void row_swap(float& lo, float& hi_) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi_), false, false);
+    lo = __uint_as_float(r[0]);
+    hi_ = __uint_as_float(r[1]);
+}
+// 4 x 4 transpose between the four 16-lane rows of a wave and four registers: afterwards row g' holds in a[s] what row s held in
+// a[g'] (two v_permlane32_swap for the distance-two pairs, two v_permlane16_swap for the neighbours)
+__device__ __forceinline__ void rows_transpose4(float (&a)[4]) {
+    half_swap(a[0], a[2]);
+    half_swap(a[1], a[3]);
+    row_swap(a[0], a[1]);
+    row_swap(a[2], a[3]);
 }
 
 // register j of the A operand = component (j & 3) of LDS read (j >> 2).  Components are named at the use
@@ -147,6 +176,40 @@ struct FwdProduct {
         lds_read16<0>(r[0], addr);
         if constexpr (NJ == 8) lds_read16<16>(r[1], addr);
         quads(r, acc, w0, w1, hook, std::make_integer_sequence<int, H / 2>{});
+        mfma_tail_pad(acc[0], acc[1], acc[2], acc[3]);
+    }
+};
+
+// One gate column per lane over the WHOLE K (no k split across waves, hence no cross-wave sum): lane 4b + i reads the K / 16
+// consecutive floats [i][(K / 16) b ..] of the state image (plain order); MFMA number kk' (abid = kk' & 15 of A register kk' >> 4)
+// contracts k = (K / 16) (kk' & 15) + (kk' >> 4) - the weights are loaded in that order.  Four accumulator chains.
+template <int K>
+struct FwdProductCol {
+    static constexpr int NJ = K / 16;        // A registers per step
+    static constexpr int NR = NJ / 4;        // ds_read_b128 per step
+    static constexpr int HOOKS = K / 4;      // one hook per MFMA quad (4 consecutive k')
+    template <int K4, class Hook>
+    static __device__ __forceinline__ void quad(const float4 (&r)[NR], f32x4 (&acc)[4], const float (&w)[K], Hook& hook) {
+        constexpr int k = 4 * K4;
+        if constexpr (k % 64 == 0) wait_lgkm<NR - 1 - k / 64>();
+        mfma_pair_k<k == 0, k & 15, (k + 1) & 15>(acc[0], acc[1], a_reg<(k >> 4)>(r), a_reg<((k + 1) >> 4)>(r), w[k], w[k + 1]);
+        mfma_pair_k<k == 0, (k + 2) & 15, (k + 3) & 15>(acc[2], acc[3], a_reg<((k + 2) >> 4)>(r), a_reg<((k + 3) >> 4)>(r), w[k + 2], w[k + 3]);
+        hook(std::integral_constant<int, K4>{});
+    }
+    template <class Hook, int... Ks>
+    static __device__ __forceinline__ void quads(const float4 (&r)[NR], f32x4 (&acc)[4], const float (&w)[K], Hook& hook,
+                                                 std::integer_sequence<int, Ks...>) {
+        (quad<Ks>(r, acc, w, hook), ...);
+    }
+    template <int... Rs>
+    static __device__ __forceinline__ void reads(float4 (&r)[NR], uint32_t addr, std::integer_sequence<int, Rs...>) {
+        (lds_read16<16 * Rs>(r[Rs], addr), ...);
+    }
+    template <class Hook>
+    static __device__ __forceinline__ void run(f32x4 (&acc)[4], const float (&w)[K], uint32_t addr, Hook& hook) {
+        float4 r[NR];
+        reads(r, addr, std::make_integer_sequence<int, NR>{});
+        quads(r, acc, w, hook, std::make_integer_sequence<int, K / 4>{});
         mfma_tail_pad(acc[0], acc[1], acc[2], acc[3]);
     }
 };

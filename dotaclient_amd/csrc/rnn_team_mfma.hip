@@ -199,6 +199,151 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_kernel(RnnStepArg
 
 
 // ---------------------------------------------------------------------------------------------------
+// Forward without the k split (round 4; the default - DC_DIMS_TEAM_NS(2) keeps the kernel above for A/B).  Above, a wave owns a k half of
+// 32 units' gate-column pairs, so every step the halves meet in LDS behind a barrier before anybody knows a gate.  Here a lane owns ONE gate
+// column over the whole K = 256 (still 256 AGPRs, still 256 MFMAs per wave and step): wave w, 16-lane row g, lane j = gate g of unit
+// 64 m + 16 w + j.  After the product a lane holds that gate's sums for the four sequences; a 4 x 4 transpose between the wave's four
+// rows and four registers (two v_permlane32_swap + two v_permlane16_swap) leaves row s with the four gates of (sequence s, unit j):
+// 64 cells per wave, one per lane.  One barrier per step instead of two, no LDS round trip between product and gate math.
+// ---------------------------------------------------------------------------------------------------
+enum { TN_HLD = 260 };     // floats per sequence row of the LDS image (k in plain order): lane 4b + i reads [i][16 b .. 16 b + 15] as four
+                           // ds_read_b128; 260 / 4 = 65 = 1 mod 16: the sixteen lanes of a read group start at 16-byte units i + 4 b - all different
+__device__ __forceinline__ constexpr int tn_korder(int kk) { return 16 * (kk & 15) + (kk >> 4); }
+
+template <int CELL>     // 1: LSTM, 0: GRU
+__global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_col_kernel(RnnStepArgs p, u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
+    constexpr bool LSTM = CELL == 1;
+    constexpr int H = TM_H, G = LSTM ? 4 : 3, GH = G * H;
+    __shared__ __attribute__((aligned(16))) float h_lds[2][4 * TN_HLD];
+    __shared__ int dead;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = lane >> 4, j = lane & 15;          // product role: gate `row`; cell role: sequence slot `row`
+    int team, member;
+    team_claim_role(reinterpret_cast<unsigned*>(xbuf_all), n_teams, team, member);
+    if (team < 0) return;
+    u64* const xbuf = xbuf_all + TEAM_HDR + TEAM_MAX * TEAM_M;
+    const int plain = team_same_xcd(xbuf_all + TEAM_HDR + team * TEAM_M, member, allow_plain);
+    const int ul = 16 * wave + j;                      // unit inside the member's 64
+    const int u = TEAM_US * member + ul;
+    const int slot = row;
+    if (tid == 0) dead = 0;
+
+    // ---- weights: row (gate H + u) of W_hh, all k, in the order the product contracts them ---------------------------
+    float w[H];
+    {
+        const bool has = row < G;                      // the GRU has no gate 3: zero weights in that row
+        const float* r0 = p.Whh + (size_t)((has ? row : 0) * H + u) * H;
+#pragma unroll
+        for (int kk = 0; kk < H; ++kk) w[kk] = has ? r0[tn_korder(kk)] : 0.f;
+    }
+    float bh[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bh[g] = g < G ? p.bhh[g * H + u] : 0.f;
+
+    unsigned tag = 0;
+    bool failed = false;
+    const int n_groups = (p.n_seq + 3) >> 2;
+    for (int grp = team; grp < n_groups && !failed; grp += n_teams) {
+        int bmap[4], tmax;
+        if (!map_slots(p, 4 * grp, bmap, tmax)) continue;
+        const int b = slot == 0 ? bmap[0] : (slot == 1 ? bmap[1] : (slot == 2 ? bmap[2] : bmap[3]));
+        const int len = p.seq_len[b];
+        const unsigned row0 = (unsigned)p.seq_off[b];
+        unsigned goff = row0 * GH + u, soff = row0 * H + u;
+        unsigned st_g = goff, st_s = soff, st_p = soff;
+        const float h0v = p.h0 ? p.h0[(size_t)b * H + u] : 0.f;
+        float c = LSTM ? (p.c0 ? p.c0[(size_t)b * H + u] : 0.f) : h0v;
+        float sv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float svp0 = c, svp1 = h0v;
+        for (int e = tid; e < 4 * H; e += TM_THREADS) {
+            const int q = e >> 8, jj = e & (H - 1);
+            const int bq = q == 0 ? bmap[0] : (q == 1 ? bmap[1] : (q == 2 ? bmap[2] : bmap[3]));
+            h_lds[0][q * TN_HLD + jj] = p.h0 ? p.h0[(size_t)bq * H + jj] : 0.f;
+        }
+        float xc[4] = {0.f, 0.f, 0.f, 0.f}, xn[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < G; ++g) xc[g] = p.gates[goff + g * H];
+        u64* const xb = xbuf + (size_t)(team * 4 + slot) * (TEAM_SLOTS * H);      // ring of this lane's sequence slot
+        __syncthreads();
+
+        auto step = [&](const int t, float (&xcur)[4], float (&xnext)[4], auto CUR) {
+            constexpr int cur = decltype(CUR)::value;
+            const bool on = t < len, on1 = t + 1 < len;
+            const unsigned gnx = goff + (on1 ? GH : 0);
+            const float* const lp = p.gates + gnx;
+            float* const gs = p.gates + st_g;
+            float* const cs = (LSTM ? p.cseq : p.hn) + st_s;
+            float* const hs = p.hseq + st_s;
+            float* const cp = LSTM ? p.cprev + st_p : nullptr;
+            float* const hp = p.hprev + st_p;
+            auto hook = [&](auto K) {
+                constexpr int k = decltype(K)::value;          // 0 .. 63
+                if constexpr (k >= 1 && k <= G) xnext[k - 1] = lp[(k - 1) * H];
+                else if constexpr (k >= 8 && k < 8 + G) gs[(k - 8) * H] = sv[k - 8];
+                else if constexpr (k == 12) *cs = sv[LSTM ? 4 : 3];
+                else if constexpr (k == 13) *hs = sv[5];
+                else if constexpr (k == 14 && LSTM) *cp = svp0;
+                else if constexpr (k == 15) *hp = svp1;
+            };
+            f32x4 pa[4];
+            FwdProductCol<H>::run(pa, w, lds_addr(&h_lds[cur][(lane & 3) * TN_HLD + (lane >> 2) * 16]), hook);
+            const f32x4 tot = (pa[0] + pa[1]) + (pa[2] + pa[3]);     // gate `row` of unit u for the four sequences
+            float a[4] = {tot[0], tot[1], tot[2], tot[3]};
+            rows_transpose4(a);                                      // a[g] = gate g of (sequence `row`, unit u)
+            const float y0 = a[0], y1 = a[1], x0 = a[2], x1 = a[3];
+            const float ig = fast_sigmoid(xcur[0] + (y0 + bh[0]));
+            const float fg = fast_sigmoid(xcur[1] + (y1 + bh[1]));
+            const float og = LSTM ? fast_sigmoid(xcur[3] + (x1 + bh[3])) : x0 + bh[2];
+            const float gg = LSTM ? fast_tanh(xcur[2] + (x0 + bh[2])) : fast_tanh(xcur[2] + ig * og);
+            const float cn = LSTM ? fg * c + ig * gg : (1.f - fg) * gg + fg * c;
+            const float hn = LSTM ? og * fast_tanh(cn) : cn;
+            const float hpub = on ? hn : 0.f;
+            ++tag;
+            granule_store(xb + (tag & 3) * H + u, hpub, tag, plain);
+            h_lds[cur ^ 1][slot * TN_HLD + u] = hpub;
+            c = on ? cn : c;
+            sv[0] = on ? ig : sv[0]; sv[1] = on ? fg : sv[1]; sv[2] = on ? gg : sv[2];
+            sv[3] = on ? og : sv[3]; sv[4] = on ? cn : sv[4]; sv[5] = on ? hn : sv[5];
+            st_g = on ? goff : st_g;
+            st_s = on ? soff : st_s;
+            svp0 = on1 ? cn : svp0;
+            svp1 = on1 ? hn : svp1;
+            st_p = on1 ? soff + H : st_p;
+            goff = gnx;
+            soff += on1 ? H : 0;
+            if (t + 1 < tmax) {
+                u64 gr[3];
+                const u64* ga[3];
+#pragma unroll
+                for (int q = 1; q < TEAM_M; ++q) {
+                    ga[q - 1] = xb + (tag & 3) * H + TEAM_US * ((member + q) & 3) + ul;
+                    gr[q - 1] = granule_load(ga[q - 1]);
+                }
+                if (!granule_wait_all<3>(gr, ga, tag)) { dead = 1; team_report_timeout(p.fault, TEAM_K_MFMA_FWD, p.layer, team, member, t, b, tag); }
+#pragma unroll
+                for (int q = 1; q < TEAM_M; ++q)
+                    h_lds[cur ^ 1][slot * TN_HLD + TEAM_US * ((member + q) & 3) + ul] = __uint_as_float((unsigned)gr[q - 1]);
+            }
+            __syncthreads();
+            return dead == 0;
+        };
+        for (int t = 0; t < tmax; t += 2) {
+            if (!step(t, xc, xn, std::integral_constant<int, 0>{})) { failed = true; break; }
+            if (t + 1 < tmax && !step(t + 1, xn, xc, std::integral_constant<int, 1>{})) { failed = true; break; }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) p.gates[st_g + g * H] = sv[g];
+        if constexpr (LSTM) { p.cseq[st_s] = sv[4]; p.cprev[st_p] = svp0; }
+        else p.hn[st_s] = sv[3];
+        p.hseq[st_s] = failed ? __builtin_nanf("") : sv[5];
+        p.hprev[st_p] = svp1;
+        __syncthreads();
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
 // backward through time.  The forward is COLUMN-parallel (a member owns the gate columns of its 64 units and needs all of
 // h_{t-1}: an all-gather of 192 foreign values per sequence).  Done the same way, the backward would need all 1 024 gate
 // gradients of every sequence in every member - 3 072 eight-byte reads per member and step, and that exchange, not the
@@ -409,8 +554,16 @@ int lstm_team_mfma_forward(int cell, RnnStepArgs a, int max_len, int n_teams, hi
     const double G = cell == 1 ? 4.0 : 3.0;
     ProfScope prof(cell == 1 ? "lstm_fwd_team" : "gru_fwd_team", 2.0 * a.n_seq * G * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * (2.0 * G + 4.0), s);
     if (int rc = zero_async(xb, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * TEAM_M + (size_t)nt * 4 * TEAM_SLOTS * TEAM_H) * sizeof(u64), s)) return rc;
-    if (cell == 1) hipLaunchKernelGGL(team_mfma_fwd_kernel<1>, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
-    else hipLaunchKernelGGL(team_mfma_fwd_kernel<0>, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+    const bool ksplit = ((a.flags >> DC_DIMS_TEAM_NS_SHIFT) & 7) == 2;      // DC_DIMS_TEAM_NS(2): round 2's forward with the k halves (A/B)
+    const dim3 grid(nt * TEAM_M), block(TM_THREADS);
+    const int allow = !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE);
+    if (ksplit) {
+        if (cell == 1) hipLaunchKernelGGL(team_mfma_fwd_kernel<1>, grid, block, 0, s, a, xb, nt, allow);
+        else hipLaunchKernelGGL(team_mfma_fwd_kernel<0>, grid, block, 0, s, a, xb, nt, allow);
+    } else {
+        if (cell == 1) hipLaunchKernelGGL(team_mfma_fwd_col_kernel<1>, grid, block, 0, s, a, xb, nt, allow);
+        else hipLaunchKernelGGL(team_mfma_fwd_col_kernel<0>, grid, block, 0, s, a, xb, nt, allow);
+    }
     return launch_check("lstm_team_mfma_forward");
 }
 
@@ -422,6 +575,8 @@ int lstm_team_mfma_backward(int cell, RnnStepArgs a, int max_len, int n_teams, h
     const double G = cell == 1 ? 4.0 : 3.0;
     ProfScope prof(cell == 1 ? "lstm_bwd_team" : "gru_bwd_team", 2.0 * a.n_seq * G * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * (3.0 * G + 6.0), s);
     if (int rc = zero_async(xb, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * TEAM_M + (size_t)nt * 4 * TEAM_SLOTS * 4 * TEAM_H) * sizeof(u64), s)) return rc;
+    // (the member's own partial sums through the ring instead of LDS + barrier - one barrier per step - was measured: 535-540 us against
+    // 517-518, profiles/r04/team_fwd_without_k_split.txt)
     if (cell == 1) hipLaunchKernelGGL(team_mfma_bwd_kernel<1>, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
     else hipLaunchKernelGGL(team_mfma_bwd_kernel<0>, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
     return launch_check("lstm_team_mfma_backward");
