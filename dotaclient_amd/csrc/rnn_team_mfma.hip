@@ -530,16 +530,16 @@ static int team_mfma_plan(int n_seq, int n_teams, double& cost_rounds) {
 }
 
 // MFMA team kernels or VALU team kernels (rnn_team.hip)?  Cost per 256 time steps in us, measured at the end of round 2 (GRU- and
-// LSTM-256 alike within 10 %).  Both are quantised: the MFMA kernels take a round of 620 (forward) / 550 (backward) per 64 x 4
+// LSTM-256 alike within 10 %; the MFMA figures: end of round 4).  Both are quantised: the MFMA kernels take a round of 480 (forward) / 510 (backward) per 64 x 4
 // sequences; the VALU kernels keep s = ceil(n / 64) sequences in flight per team - s = 1: 390 / 450, 2: 486 / 540, 3: 790 / 940,
 // 4: 883 / 1 050, and more than four one after the other (260 sequences: 1 650 / 1 890) - and stop at 768 sequences (per-step
-// launches instead: ~19 us per step).  E.g. 128 sequences: forward VALU (486 < 620), backward MFMA (550 > 540 is a tie: measured
-// 491 vs 539); 256: MFMA; 260: MFMA in two rounds; 1 065 chunks (the reference's default shape): MFMA in five.
+// launches instead: ~19 us per step).  E.g. 64 sequences: VALU (390 / 450); 65 .. 128: the eight-member kernels of rnn_team8.hip take them
+// before this model is asked (423 / 421); 129 .. 256: MFMA; 260: MFMA in two rounds; 1 065 chunks (the reference's default shape): MFMA in five.
 bool lstm_team_mfma_supported(int cell, int H, int n_seq, int flags, bool backward) {
     if ((cell != 1 && cell != 0) || H != TM_H || n_seq < 65 || (flags & DC_DIMS_TEAM_VALU)) return false;
     double rounds;
     (void)team_mfma_plan(n_seq, 64, rounds);
-    const double mfma = rounds * (backward ? 540.0 : 620.0);
+    const double mfma = rounds * (backward ? 510.0 : 480.0);      // round 4: forward without the k split 473-488 us, backward 490-518
     static const double kValu[2][4] = {{390.0, 486.0, 790.0, 883.0}, {450.0, 540.0, 940.0, 1050.0}};
     const int s = (n_seq + 63) / 64;
     const double valu = n_seq > 768 ? 256.0 * 19.0 : (s <= 4 ? kValu[backward][s - 1] : ((s + 3) / 4) * kValu[backward][3]);
