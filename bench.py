@@ -95,8 +95,9 @@ def pmc_traffic(path, kernel, workload_key):
     if j.get('meta', {}).get('workload') not in (None, workload_key):
         return None
     # profiling region -> kernel(s) that run inside it (the first one present in the summary wins)
-    region_kernels = {'embed_bwd_pool16': ['embed_bwd_pool16w', 'embed_bwd_pool16'], 'gru_fwd_team': ['team_mfma_fwd', 'rnn_team_fwd'], 'gru_bwd_team': ['team_mfma_bwd', 'rnn_team_bwd'],
-                      'lstm_fwd_team': ['team_mfma_fwd', 'rnn_team_fwd'], 'lstm_bwd_team': ['team_mfma_bwd', 'rnn_team_bwd'],
+    region_kernels = {'embed_bwd_pool16': ['embed_bwd_pool16w', 'embed_bwd_pool16'], 'gru_fwd_team': ['team_mfma_fwd_col', 'team_mfma_fwd', 'team8_fwd', 'rnn_team_fwd'],
+                      'gru_bwd_team': ['team_mfma_bwd', 'team8_bwd', 'rnn_team_bwd'],
+                      'lstm_fwd_team': ['team_mfma_fwd_col', 'team_mfma_fwd', 'team8_fwd', 'rnn_team_fwd'], 'lstm_bwd_team': ['team_mfma_bwd', 'team8_bwd', 'rnn_team_bwd'],
                       'lstm_fwd_persist': ['lstm_fwd_valu'], 'lstm_bwd_persist': ['lstm_bwd_valu'],
                       'gemm_f32_dW': ['gemm_x3'], 'gemm_f32_fwd': ['gemm_fast', 'gemm_x3'], 'gemm_f32_dX': ['gemm_fast', 'gemm_x3']}
     if PRODUCTS == 'f16x2':       # every dense product runs the split-on-load kernel then (one PMC row: the average over its launches)

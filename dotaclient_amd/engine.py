@@ -321,11 +321,24 @@ class IncrementalPacker:
         self.st = None
         self.rows, self.lens, self.n = 0, [], 0
         self.dst, self.copied = None, 0          # device buffers of the batch being packed / rows of it already on their way
+        self._items, self._keep, self.packed = [], [], 0     # copy descriptors of rollouts not yet in the staging set / rows that are
 
     # The H2D copies go out WHILE the batch is being packed (every COPY_ROWS rows), not behind its last rollout: a 256 x 256 batch is
     # ~140 MB = ~3 ms on the link, which otherwise sits between the host's last memcpy and the rollout pass (tools/ingest_probe.py:
     # 22.3 ms per step with the copies at the end against 19.5 for the step alone - host enqueue 0.9 + packing 17.4 + copy 3.3).
     COPY_ROWS = 4096
+    # ... and the host copies of the rollouts into the staging set are done PACK_ROWS rows at a time, not rollout by rollout: a rollout is
+    # ~0.5 MB in ~4 600 row pieces - too little for dc_pack_rows to start threads for, and on one thread a 256 x 256 batch takes 17-20 ms,
+    # more than its step takes on the GPU (the loop was then bound by the host: profiles/r04/v22_bench_extras.json, 20.4 ms per step
+    # against 17.9).  The descriptors are built (and the rollout validated) when it arrives; the bytes move in pieces of ~17 MB on
+    # PACK_THREADS threads.
+    PACK_ROWS = 8192
+
+    def _pack_pending(self):
+        if self._items:
+            _run_items(self._items, threads=PACK_THREADS)
+            self._items, self._keep = [], []
+        self.packed = self.rows
 
     def _flush(self, upto):
         """Enqueues the copies of staging rows [copied, upto) on the packer's stream."""
@@ -358,6 +371,7 @@ class IncrementalPacker:
             with self.pair.lock:
                 self.st = self.pair.take(max(need, self.expected_rows))
         elif self.st.capacity < need:                 # rare (a batch larger than any before): move what is packed into a larger set
+            self._pack_pending()
             old = self.st
             new = _StagingSet(max(need, old.capacity + old.capacity // 2), self.pin)
             for name in ('obs', 'act', 'msk', 'rew'):
@@ -365,19 +379,21 @@ class IncrementalPacker:
             with self.pair.lock:
                 self.pair.sets[self.pair.sets.index(old)] = new
             self.st = new
-        keep, items = [], []
-        _rollout_items(d, self.rows, lp, self.st, keep, items)
-        _run_items(items, threads=min(PACK_THREADS, 4))
+        self._keep.append(d)                          # the rollout's arrays stay alive until their bytes have moved
+        _rollout_items(d, self.rows, lp, self.st, self._keep, self._items)
         self.rows = need
         self.lens.append(lp)
         self.n += 1
         self.expected_rows = max(self.expected_rows, need)
-        if self.pin and need - self.copied >= self.COPY_ROWS:
-            self._flush(need)
+        if need - self.packed >= self.PACK_ROWS:
+            self._pack_pending()
+            if self.pin and self.packed - self.copied >= self.COPY_ROWS:
+                self._flush(self.packed)
 
     def finish(self):
         if self.n == 0:
             raise ValueError('IncrementalPacker.finish: no rollouts')
+        self._pack_pending()
         lens_n = np.asarray(self.lens, dtype=np.int64)
         off = np.concatenate([[0], np.cumsum(lens_n)[:-1]]).astype(np.int64)
         st, rows, dev = self.st, self.rows, self.dev

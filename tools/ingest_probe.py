@@ -59,6 +59,7 @@ def pack_only(i):
     one_step(ring[0])
     for d in rollouts:
         packer.add(d)
+    packer._pack_pending()
     packer._begin()                                  # drop it: host packing without the copies
 
 
@@ -99,6 +100,7 @@ out['host_enqueue_ms_of_one_step'] = ts
 t0 = time.perf_counter()
 for d in rollouts:
     packer.add(d)
+packer._pack_pending()
 out['host_pack_ms_of_one_batch'] = (time.perf_counter() - t0) * 1e3
 packer._begin()
 assert int(eng.status.item()) == 0
