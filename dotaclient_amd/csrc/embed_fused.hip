@@ -237,6 +237,16 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
                     const long long n = min((lr >> 4) + 2 * i + ((lane >> 4) & 1), ty.nr_valid - 1);
                     mb[i] = umask[n * 65 + 22 + ef_cum(t) + (lane & 15)];
                 }
+            } else if (umask != nullptr && t != 1) {
+                // the three one-unit types (own hero - never targetable, policy.py:255 - and the two towers): their pooled value is taken from
+                // the accumulators; the row itself is read by the attention only.  The 64 rows of this wave = 64 env-steps: lane l of half i
+                // takes the byte of step 32 i + (l & 31).  (The five-unit type keeps all rows: pool_env_fwd pools it from emb.)
+                const long long lr = row0 - ty.row_begin[t] + wm * 64;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const long long n = min(lr + 32 * i + (lane & 31), ty.nr_valid - 1);
+                    mb[i] = umask[n * 65 + 22 + ef_cum(t)];
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -216,10 +216,10 @@ int64_t dc_workspace_layout(const dc_dims* dims, int64_t* offsets);
  *   hT/cT [layers,B,H] out (may be NULL).  Results live in the workspace: DC_WS_HEADOUT [rows,160]
  *   (cols 0..127 attention query, 128..131 enum, 132..140 x, 141..149 y, 150..152 ability, 153 value)
  *   and DC_WS_TU [rows,40] (target_unit logits).  *   unit_mask (may be NULL; only read with DC_DIMS_LAZY_TU and DC_DIMS_F16X2): the batch's action masks u8 [rows,65].  The per-unit
- *   embeddings of the two 16-unit types (32 of the 40 units, 1.1 GB per configs[2] pass) have ONE consumer - the target-unit attention of
- *   dc_select_logp / dc_ppo_loss_fwd_bwd / dc_policy_backward, which reads the rows of units whose mask byte (column 22 + unit) is set and
- *   nothing else - so with the masks at hand DC_WS_EMB rows of masked-out units of those types are NOT written (they keep whatever the
- *   buffer held).  NULL: every row is written. */
+ *   embeddings of the two 16-unit types and of the three 1-unit types (35 of the 40 units, 1.2 GB per configs[2] pass) have ONE consumer -
+ *   the target-unit attention of dc_select_logp / dc_ppo_loss_fwd_bwd / dc_policy_backward, which reads the rows of units whose mask byte
+ *   (column 22 + unit) is set and nothing else - so with the masks at hand DC_WS_EMB rows of masked-out units of those types are NOT
+ *   written (they keep whatever the buffer held).  NULL: every row is written. */
 int dc_policy_forward(const dc_dims* dims, const float* params, const int64_t* poff_host, const float* obs,
                       const float* h0, const float* c0, const int64_t* seq_off, const int32_t* seq_len, void* ws,
                       float* hT, float* cT, const uint8_t* unit_mask, dc_stream_t stream);
