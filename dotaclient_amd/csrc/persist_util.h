@@ -133,6 +133,22 @@ __device__ __forceinline__ void rows_transpose4(float (&a)[4]) {
     row_swap(a[2], a[3]);
 }
 
+// the value of lane l ^ 8 (DPP row_ror:8: a rotation by eight inside each 16-lane row swaps its halves)
+__device__ __forceinline__ float lane_xor8(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, true));
+}
+// 4 x 4 transpose between the four 8-lane groups of each 32-lane half of a wave (group g = (lane >> 3) & 3) and four registers:
+// afterwards group g' holds in a[s] what group s held in a[g'] (two v_permlane16_swap for the groups sixteen lanes apart, DPP rotations
+// + selects for the neighbours)
+__device__ __forceinline__ void groups8_transpose4(float (&a)[4], int lane) {
+    row_swap(a[0], a[2]);
+    row_swap(a[1], a[3]);
+    const bool odd = (lane & 8) != 0;
+    const float p0 = lane_xor8(a[0]), p1 = lane_xor8(a[1]), p2 = lane_xor8(a[2]), p3 = lane_xor8(a[3]);
+    const float n0 = odd ? p1 : a[0], n1 = odd ? a[1] : p0, n2 = odd ? p3 : a[2], n3 = odd ? a[3] : p2;
+    a[0] = n0; a[1] = n1; a[2] = n2; a[3] = n3;
+}
+
 // register j of the A operand = component (j & 3) of LDS read (j >> 2).  Components are named at the use
 // site (a sub-register reference, no instruction): copying them earlier would read the destination of a
 // ds_read the compiler does not know is still in flight.

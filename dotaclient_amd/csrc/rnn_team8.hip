@@ -199,6 +199,160 @@ __global__ __launch_bounds__(T8_THREADS, 2) void team8_fwd_kernel(RnnStepArgs p,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Forward with the k split INSIDE the wave (the default; DC_DIMS_TEAM_NS(2) keeps the kernel above for A/B).  Above, four waves hold a k
+// quarter each and meet in LDS behind a barrier.  Here a wave owns 32 gate columns (8 units x 4 gates) and its two halves contract the two
+// k halves of the SAME columns (the 4x4x1 MFMA with the broadcast kept inside each half, cbsz:3 - rnn_persist.hip's BwdProduct): lane =
+// (k half, gate, unit), 128 AGPRs, 128 MFMAs per wave and step as before.  The halves are added by v_permlane32_swap, the four gates of a
+// cell brought together by a 4 x 4 transpose between the 8-lane groups and four registers (v_permlane16_swap + DPP): no LDS round trip, ONE
+// barrier per step.  Cell role: lane group s' = (lane >> 3) & 3 -> sequence slot s', unit 32 m + 8 w + (lane & 7); both wave halves
+// compute the same cell, the lower publishes; lower / upper half collect members m + 1 .. m + 4 / m + 5 .. m + 8.
+// ---------------------------------------------------------------------------------------------------
+// BwdProduct<128> hands MFMA number kk' (abid = kk' & 7 of A register kk' >> 3) the 16 consecutive floats lane 4b' + i read: it contracts
+// half-local k = 16 (kk' & 7) + (kk' >> 3)
+__device__ __forceinline__ constexpr int t8c_korder(int kk) { return 16 * (kk & 7) + (kk >> 3); }
+enum { T8C_HLD = 260 };    // floats per sequence row of the LDS image (plain k order): lane (half, b', i) reads [i][128 half + 16 b' ..] as four
+                           // ds_read_b128; 260 / 4 = 1 mod 16: the sixteen lanes of a read group start at 16-byte units i + 4 b' - all different
+
+template <int CELL>     // 1: LSTM, 0: GRU
+__global__ __launch_bounds__(T8_THREADS, 2) void team8_fwd_half_kernel(RnnStepArgs p, u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
+    constexpr bool LSTM = CELL == 1;
+    constexpr int H = T8_H, G = LSTM ? 4 : 3, GH = G * H, KH = 128;
+    __shared__ __attribute__((aligned(16))) float h_lds[2][4 * T8C_HLD];
+    __shared__ int dead;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = lane >> 5, grp = (lane >> 3) & 3, j = lane & 7;      // product role: k half, gate `grp`; cell role: sequence slot `grp`
+    int team, member;
+    team_claim_role_m<T8_M>(reinterpret_cast<unsigned*>(xbuf_all), n_teams, team, member);
+    if (team < 0) return;
+    u64* const xbuf = xbuf_all + TEAM_HDR + TEAM_MAX * T8_M;
+    const int plain = team_same_xcd_m<T8_M>(xbuf_all + TEAM_HDR + team * T8_M, member, allow_plain);
+    const int ul = 8 * wave + j;                       // unit inside the member's 32
+    const int u = T8_US * member + ul;
+    const int slot = grp;
+    if (tid == 0) dead = 0;
+
+    // ---- weights: row (gate H + u) of W_hh, k in [128 kh, 128 kh + 128), in the order the product contracts them ----
+    float w[KH];
+    {
+        const bool has = grp < G;                      // the GRU has no gate 3: zero weights there
+        const float* r0 = p.Whh + (size_t)((has ? grp : 0) * H + u) * H + KH * kh;
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) w[kk] = has ? r0[t8c_korder(kk)] : 0.f;
+    }
+    float bh[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bh[g] = g < G ? p.bhh[g * H + u] : 0.f;
+
+    unsigned tag = 0;
+    bool failed = false;
+    const int n_groups = (p.n_seq + 3) >> 2;
+    for (int gq = team; gq < n_groups && !failed; gq += n_teams) {
+        int bmap[4], tmax;
+        if (!map_slots(p, 4 * gq, bmap, tmax)) continue;
+        const int b = slot == 0 ? bmap[0] : (slot == 1 ? bmap[1] : (slot == 2 ? bmap[2] : bmap[3]));
+        const int len = p.seq_len[b];
+        const unsigned row0 = (unsigned)p.seq_off[b];
+        unsigned goff = row0 * GH + u, soff = row0 * H + u;
+        unsigned st_g = goff, st_s = soff, st_p = soff;
+        const float h0v = p.h0 ? p.h0[(size_t)b * H + u] : 0.f;
+        float c = LSTM ? (p.c0 ? p.c0[(size_t)b * H + u] : 0.f) : h0v;
+        float sv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float svp0 = c, svp1 = h0v;
+        for (int e = tid; e < 4 * H; e += T8_THREADS) {
+            const int q = e >> 8, jj = e & (H - 1);
+            const int bq = q == 0 ? bmap[0] : (q == 1 ? bmap[1] : (q == 2 ? bmap[2] : bmap[3]));
+            h_lds[0][q * T8C_HLD + jj] = p.h0 ? p.h0[(size_t)bq * H + jj] : 0.f;
+        }
+        float xc[4] = {0.f, 0.f, 0.f, 0.f}, xn[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < G; ++g) xc[g] = p.gates[goff + g * H];
+        u64* const xb = xbuf + (size_t)(team * 4 + slot) * (TEAM_SLOTS * H);
+        __syncthreads();
+
+        auto step = [&](const int t, float (&xcur)[4], float (&xnext)[4], auto CUR) {
+            constexpr int cur = decltype(CUR)::value;
+            const bool on = t < len, on1 = t + 1 < len;
+            const unsigned gnx = goff + (on1 ? GH : 0);
+            const float* const lp = p.gates + gnx;
+            float* const gs = p.gates + st_g;
+            float* const cs = (LSTM ? p.cseq : p.hn) + st_s;
+            float* const hs = p.hseq + st_s;
+            float* const cp = LSTM ? p.cprev + st_p : nullptr;
+            float* const hp = p.hprev + st_p;
+            auto hook = [&](auto K) {
+                constexpr int k = decltype(K)::value;          // 0 .. 31
+                if constexpr (k >= 1 && k <= G) xnext[k - 1] = lp[(k - 1) * H];
+                else if constexpr (k >= 8 && k < 8 + G) gs[(k - 8) * H] = sv[k - 8];
+                else if constexpr (k == 12) *cs = sv[LSTM ? 4 : 3];
+                else if constexpr (k == 13) *hs = sv[5];
+                else if constexpr (k == 14 && LSTM) *cp = svp0;
+                else if constexpr (k == 15) *hp = svp1;
+            };
+            f32x4 pa[4];
+            BwdProduct<KH>::run(pa, w, lds_addr(&h_lds[cur][(lane & 3) * T8C_HLD + KH * kh + ((lane >> 2) & 7) * 16]), hook);
+            const f32x4 part = (pa[0] + pa[1]) + (pa[2] + pa[3]);    // gate `grp` of unit u for the four sequences, this lane's k half
+            float a[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {                            // k halves: lower + upper, in that order, in every lane
+                float lo = part[s], hi2 = part[s];
+                half_swap(lo, hi2);
+                a[s] = lo + hi2;
+            }
+            groups8_transpose4(a, lane);                             // a[g] = gate g of (sequence `grp`, unit u)
+            const float y0 = a[0], y1 = a[1], x0 = a[2], x1 = a[3];
+            const float ig = fast_sigmoid(xcur[0] + (y0 + bh[0]));
+            const float fg = fast_sigmoid(xcur[1] + (y1 + bh[1]));
+            const float og = LSTM ? fast_sigmoid(xcur[3] + (x1 + bh[3])) : x0 + bh[2];
+            const float gg = LSTM ? fast_tanh(xcur[2] + (x0 + bh[2])) : fast_tanh(xcur[2] + ig * og);
+            const float cn = LSTM ? fg * c + ig * gg : (1.f - fg) * gg + fg * c;
+            const float hn = LSTM ? og * fast_tanh(cn) : cn;
+            const float hpub = on ? hn : 0.f;
+            ++tag;
+            if (kh == 0) granule_store(xb + (tag & 3) * H + u, hpub, tag, plain);
+            h_lds[cur ^ 1][slot * T8C_HLD + u] = hpub;
+            c = on ? cn : c;
+            sv[0] = on ? ig : sv[0]; sv[1] = on ? fg : sv[1]; sv[2] = on ? gg : sv[2];
+            sv[3] = on ? og : sv[3]; sv[4] = on ? cn : sv[4]; sv[5] = on ? hn : sv[5];
+            st_g = on ? goff : st_g;
+            st_s = on ? soff : st_s;
+            svp0 = on1 ? cn : svp0;
+            svp1 = on1 ? hn : svp1;
+            st_p = on1 ? soff + H : st_p;
+            goff = gnx;
+            soff += on1 ? H : 0;
+            if (t + 1 < tmax) {
+                u64 gr[4];
+                const u64* ga[4];
+                int uu[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uu[q] = T8_US * ((member + 1 + 4 * kh + q) & 7) + ul;
+                    ga[q] = xb + (tag & 3) * H + uu[q];
+                    gr[q] = granule_load(ga[q]);
+                }
+                if (!granule_wait_all<4>(gr, ga, tag)) { dead = 1; team_report_timeout(p.fault, TEAM_K_T8_FWD, p.layer, team, member, t, b, tag); }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) h_lds[cur ^ 1][slot * T8C_HLD + uu[q]] = __uint_as_float((unsigned)gr[q]);
+            }
+            __syncthreads();
+            return dead == 0;
+        };
+        for (int t = 0; t < tmax; t += 2) {
+            if (!step(t, xc, xn, std::integral_constant<int, 0>{})) { failed = true; break; }
+            if (t + 1 < tmax && !step(t + 1, xn, xc, std::integral_constant<int, 1>{})) { failed = true; break; }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) p.gates[st_g + g * H] = sv[g];
+        if constexpr (LSTM) { p.cseq[st_s] = sv[4]; p.cprev[st_p] = svp0; }
+        else p.hn[st_s] = sv[3];
+        p.hseq[st_s] = failed ? __builtin_nanf("") : sv[5];
+        p.hprev[st_p] = svp1;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // backward through time (row-parallel, see the header and rnn_team_mfma.hip)
 // ---------------------------------------------------------------------------------------------------
 // LDS image of the A operand: per sequence eight blocks of 16 floats (one per broadcast group b'), 20 floats apart, rows 208 floats
@@ -414,8 +568,16 @@ int rnn_team8_forward(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     const double G = cell == 1 ? 4.0 : 3.0;
     ProfScope prof(cell == 1 ? "lstm_fwd_team" : "gru_fwd_team", 2.0 * a.n_seq * G * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * (2.0 * G + 4.0), s);
     if (int rc = zero_async(xb, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * T8_M + (size_t)nt * T8_FWD_RING) * sizeof(u64), s)) return rc;
-    if (cell == 1) hipLaunchKernelGGL(team8_fwd_kernel<1>, dim3(nt * T8_M), dim3(T8_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
-    else hipLaunchKernelGGL(team8_fwd_kernel<0>, dim3(nt * T8_M), dim3(T8_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+    const bool quarters = ((a.flags >> DC_DIMS_TEAM_NS_SHIFT) & 7) == 2;    // DC_DIMS_TEAM_NS(2): the forward with k quarters across the waves (A/B)
+    const dim3 grid(nt * T8_M), block(T8_THREADS);
+    const int allow = !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE);
+    if (quarters) {
+        if (cell == 1) hipLaunchKernelGGL(team8_fwd_kernel<1>, grid, block, 0, s, a, xb, nt, allow);
+        else hipLaunchKernelGGL(team8_fwd_kernel<0>, grid, block, 0, s, a, xb, nt, allow);
+    } else {
+        if (cell == 1) hipLaunchKernelGGL(team8_fwd_half_kernel<1>, grid, block, 0, s, a, xb, nt, allow);
+        else hipLaunchKernelGGL(team8_fwd_half_kernel<0>, grid, block, 0, s, a, xb, nt, allow);
+    }
     return launch_check("rnn_team8_forward");
 }
 

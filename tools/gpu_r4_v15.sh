@@ -7,7 +7,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "rnn_team_kernels_agree" > $OUT/pytest_team.log 2>&1
 echo "pytest exit $?"; tail -5 $OUT/pytest_team.log
-for B in 0; do
+for B in 128; do
 for fl in 0 512 0 512; do
   timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-weak-unit --kernel-flags $fl --batch $B > $OUT/bench_${B}_$fl.json 2> $OUT/bench_${B}_$fl.err
   python - <<PY
