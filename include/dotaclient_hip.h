@@ -118,7 +118,8 @@ typedef struct dc_dims {
  *   DC_DIMS_RNN_PER_STEP   : one launch per time step instead of the persistent (register-resident / team) recurrent kernels;
  *   DC_DIMS_LSTM_MFMA/_VALU: H <= 128 LSTM: force the 4-sequences-per-workgroup MFMA / 1-sequence-per-workgroup VALU variant;
  *   DC_DIMS_TEAM_DEVICE_SCOPE : H = 256 team kernels: write-through granule stores even when a team shares an XCD;
- *   DC_DIMS_TEAM_NS(n)     : H = 256 team kernels: n = 1, 2 or 4 sequences in flight per team (0 = by batch size);
+ *   DC_DIMS_TEAM_NS(n)     : H = 256 VALU team kernels: n = 1, 2 or 4 sequences in flight per team (0 = by batch size); where the MFMA team
+ *                            kernels run, n = 2 selects their earlier forward forms (k split across the waves, meeting in LDS) for A/B;
  *                            H = 512 persistent bf16 kernels: n = 2 forces 32-sequence tiles (default: 16 while the batch fits one round). */
 #define DC_DIMS_DENSE_POOL_BWD 8
 #define DC_DIMS_RNN_PER_STEP 16
