@@ -50,7 +50,7 @@ enum { EP_LD = 68 };   // floats per row of a wave's 64 x 64 epilogue image (4 x
 #define DC_X3_OCC 3
 #endif
 template <int PREC> struct X3Cfg {
-    static constexpr bool kThree = PREC == 4 && DC_X3_OCC == 3;
+    static constexpr bool kThree = PREC != 6 && DC_X3_OCC == 3;      // two-plane (f16x2) and one-plane (bf16 mode) products
     static constexpr int kOcc = kThree ? 3 : 2;
     static constexpr int kOper = (kThree ? 2 : 3) * RM_PLANE, kStage = 2 * kOper, kLds = 2 * kStage;   // 49152 / 73728
     static constexpr int kImgRows = kThree ? 32 : 64;
@@ -449,7 +449,7 @@ int gemm_x3(const X3Gemm& g, hipStream_t stream) {
     int splits = 1;
     const long tiles = (long)((g.M + XB - 1) / XB) * ((g.N + XB - 1) / XB);
     if (tiles < 256 && g.K >= 4096 && !g.relu && g.aux == nullptr && g.scratch.p != nullptr) {
-        long want = (g.prec == 4 && DC_X3_OCC == 3 ? 768 : 512) / tiles;      // two (three) workgroups per CU
+        long want = (g.prec != 6 && DC_X3_OCC == 3 ? 768 : 512) / tiles;      // two (three) workgroups per CU
         if (want < 1) want = 1;
         const long maxs = g.K / 512;
         splits = (int)(want < maxs ? want : maxs);
