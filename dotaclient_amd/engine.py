@@ -329,8 +329,8 @@ class IncrementalPacker:
     COPY_ROWS = 4096
     # ... and the host copies of the rollouts into the staging set are done PACK_ROWS rows at a time, not rollout by rollout: a rollout is
     # ~0.5 MB in ~4 600 row pieces - too little for dc_pack_rows to start threads for, and on one thread a 256 x 256 batch takes 17-20 ms,
-    # more than its step takes on the GPU (the loop was then bound by the host: profiles/r04/v22_bench_extras.json, 20.4 ms per step
-    # against 17.9).  The descriptors are built (and the rollout validated) when it arrives; the bytes move in pieces of ~17 MB on
+    # more than its step takes on the GPU (the loop was then bound by the host: 20.4 ms per step against 17.9; now 18.1,
+    # profiles/r04/v29_bench_extras.json).  The descriptors are built (and the rollout validated) when it arrives; the bytes move in pieces of ~17 MB on
     # PACK_THREADS threads.
     PACK_ROWS = 8192
 
