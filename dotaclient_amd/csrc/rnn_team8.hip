@@ -1,17 +1,20 @@
-// LSTM / GRU with H = 256 in teams of EIGHT workgroups, two workgroups per CU (DC_DIMS_TEAM8).
+// LSTM / GRU with H = 256 in teams of EIGHT workgroups (taken for 65 .. 128 sequences; DC_DIMS_TEAM8 forces, DC_DIMS_TEAM4 forbids).
 //
 // Same job as rnn_team_mfma.hip (the S sequential cell steps of nn.LSTM / nn.GRU behind /root/reference/policy.py:66,141 in one
 // launch, W_hh resident in AGPRs, four sequences of a team on the rows of the 4x4x1 f32 MFMA, 8-byte {h, tag} granules between
 // the members) with the weights cut twice as fine: a member holds the gate columns of 32 hidden units (128 AGPRs per lane instead
-// of 256), so that TWO workgroups - members of two different teams - fit on a CU at two waves per SIMD.
+// of 256).
 //
-// Why.  A step of the four-member kernels is 0.85 us of MFMA issue and ~1.2 us of everything else (k-half swap, gate math,
-// publish, the hand-off's round trip through L2, two barriers), and with one wave per SIMD nothing overlaps: the matrix pipe
-// idles for 60 % of a step, and "every other instruction placed between two MFMAs costs ~5 cycles of its own" (persist_util.h).
-// Here a member's product is half as long, and the other workgroup on the CU issues its product while this one waits for its
-// peers, and its VALU / LDS / memory instructions in the shadow of this one's MFMAs.  With 128 sequences (BASELINE.json configs[3]'s
-// per-GPU shard) the 32 teams of four left half the chip idle; 32 teams of eight use every CU once.
+// Why.  A step of the four-member kernels is 0.85-0.9 us of MFMA issue and ~1 us of everything else (gate math, publish, the
+// hand-off's round trip through L2, barriers), and with one wave per SIMD nothing overlaps.  With 128 sequences (BASELINE.json
+// configs[3]'s per-GPU shard) 32 teams of four leave half the chip idle; 32 teams of eight use every CU once, and a member's product
+// is half as long: 1.5-1.6 us per step instead of 1.85-2.0.  (128 AGPRs would let TWO workgroups share a CU - which is what more than
+// 128 sequences get when the flag forces these kernels - but two workgroups on a CU disturb each other: 2.5 us per step.  That, the teams
+// claimed in pairs on shared CUs, and two groups in flight per team in one instruction stream were all measured and are slower than the
+// four-member kernels: profiles/r04/team8_vs_team4.txt.)
 //
+// Two forward kernels: team8_fwd_half_kernel (the default: k split inside the wave, described at the kernel) and team8_fwd_kernel
+// (the first form, DC_DIMS_TEAM_NS(2), described here).
 // Forward roles (256 threads; member m of a team = hidden units [32 m, 32 m + 32), all gates):
 //   product:  wave w = k quarter (k in [64 w, 64 w + 64)); lane l: gate pair hi = l >> 5 (0: i, f; 1: g, o), unit 32 m + (l & 31);
 //             the lane's two gate columns over its k quarter = 128 AGPRs; FwdProduct<64>, rnn_persist.hip's product phase.
@@ -27,7 +30,7 @@
 //   scatter:  lane u' publishes its four sums to member u' >> 5 (ring [owner][source][sequence][unit]); the owner's own go through LDS.
 //   cell:     wave w = sequence slot w, unit 32 m + (l & 31); lower half adds own + sources m + 1 .. m + 4, upper half m + 5 .. m + 7,
 //             v_permlane32_swap adds the halves (fixed order); both halves then compute the cell's gate gradients.
-// Timeouts, roles by ticket, same-XCD hand-off: team_util.h, with eight members (eight teams per XCD at two workgroups per CU).
+// Timeouts, roles by ticket, same-XCD hand-off: team_util.h, with eight members (four teams per XCD at one workgroup per CU).
 #include <stdio.h>
 #include <stdlib.h>
 #include "kernels.h"
