@@ -15,7 +15,9 @@
 // visible -> read, ~0.7 us): four sequences per team leave nothing to hide it behind, and eight would halve the number
 // of teams.
 //
-// Roles (256 threads, one workgroup per CU, member m of a team = hidden units [64m, 64m + 64), all four gates):
+// Roles of the FIRST forward form (team_mfma_fwd_kernel, now behind DC_DIMS_TEAM_NS(2); the default since round 4 is
+// team_mfma_fwd_col_kernel further down, without the k split) - 256 threads, one workgroup per CU, member m of a team = hidden units
+// [64m, 64m + 64), all four gates:
 //   wave w: k half kh = w >> 1 (k in [128 kh, 128 kh + 128)), unit block ub = w & 1;  lane l: gate pair hi = l >> 5
 //   (0: i, f; 1: g, o), unit u = 64 m + 32 ub + (l & 31).  A lane keeps the two gate columns of its unit over its k half
 //   in 256 AGPRs - rnn_persist.hip's register budget and its FwdProduct<128> product phase, unchanged.
