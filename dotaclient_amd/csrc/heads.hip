@@ -525,6 +525,11 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
     }
 }
 
+// blocks of the mask-aware attention kernels: a wave per env-step (a capped grid of 4 096 blocks walked four steps per wave one after the
+// other - a chain of dependent round trips each: 63 -> 56 us for the logits, profiles/r04: tools/gpu_r4_v30.sh)
+#ifndef ATTN_GRID_CAP
+#define ATTN_GRID_CAP 65536
+#endif
 static inline int grid1d(long long items, int per_block, int cap) {
     long long g = (items + per_block - 1) / per_block;
     if (g > cap) g = cap;
@@ -540,13 +545,13 @@ int attn_logits(const float* headout, const float* emb, float* tu, long long nr,
 
 int attn_logits_masked(const float* headout, const float* emb, const uint8_t* mask, float* tu, long long nr, long long nrp, hipStream_t s) {
     ProfScope prof("attn_logits", 2.0 * nr * 40 * 128, 4.0 * nr * (40 * 128 + 128 + 40), s);
-    hipLaunchKernelGGL(attn_logits_masked_kernel, dim3(grid1d(nr, 4, 256 * 16)), dim3(256), 0, s, headout, emb, mask, tu, nr, nrp);
+    hipLaunchKernelGGL(attn_logits_masked_kernel, dim3(grid1d(nr, 4, ATTN_GRID_CAP)), dim3(256), 0, s, headout, emb, mask, tu, nr, nrp);
     return launch_check("attn_logits_masked");
 }
 
 int attn_bwd_q(const float* dtu, const float* emb, float* dheadout, long long nr, long long nrp, hipStream_t s) {
     ProfScope prof("attn_bwd_q", 2.0 * nr * 40 * 128, 4.0 * nr * (40 * 128 + 128 + 40), s);
-    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(grid1d(nr, 2, 256 * 16)), dim3(256), 0, s, dtu, emb, dheadout, nr, nrp);
+    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(grid1d(nr, 2, ATTN_GRID_CAP)), dim3(256), 0, s, dtu, emb, dheadout, nr, nrp);
     return launch_check("attn_bwd_q");
 }
 
