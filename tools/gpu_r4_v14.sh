@@ -16,7 +16,7 @@ try:
     print('rep $rep: %.1f env-steps/s %.3f ms/step' % (j['value'], j['ms_per_step']))
     for k in j['roofline']['kernels']:
         if k['kernel'].startswith(('ppo_loss', 'gradnorm', 'embed_bwd_pool16', 'lstm')):
-            print('   %-34s n=%3d avg %8.1f us' % (k['kernel'], k['launches'], k['avg_us']))
+            print('   %-34s n=%3d avg %8.1f us' % (k['kernel'], k['launches_per_step'], k['avg_us']))
 except Exception as e:
     print('bench failed', e); print(open('$OUT/bench_$rep.err').read()[-800:])
 PY
