@@ -379,8 +379,13 @@ class IncrementalPacker:
             with self.pair.lock:
                 self.pair.sets[self.pair.sets.index(old)] = new
             self.st = new
-        self._keep.append(d)                          # the rollout's arrays stay alive until their bytes have moved
-        _rollout_items(d, self.rows, lp, self.st, self._keep, self._items)
+        # The descriptors of THIS rollout are built into local lists and joined to the pending ones only when the whole rollout has
+        # validated: a malformed rollout (ValueError half-way through its keys) leaves nothing queued, so the next good rollout - which
+        # targets the same staging rows - cannot race stale copies in dc_pack_rows.
+        keep, items = [d], []                         # the rollout's arrays stay alive until their bytes have moved
+        _rollout_items(d, self.rows, lp, self.st, keep, items)
+        self._keep += keep
+        self._items += items
         self.rows = need
         self.lens.append(lp)
         self.n += 1

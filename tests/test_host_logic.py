@@ -93,6 +93,31 @@ def test_incremental_packer_equals_pack_rollouts():
         pk.finish()
 
 
+def test_incremental_packer_drops_a_malformed_rollout_whole():
+    # a rollout that fails validation half-way through its keys must leave NO copy descriptor queued (its rows are not
+    # committed, so the next good rollout targets the same staging rows: a stale descriptor would race it in dc_pack_rows)
+    import copy
+    from dotaclient_amd.engine import IncrementalPacker, pack_rollouts
+    good = synth.make_rollouts(11, [40, 64, 7, 300])
+    bad = copy.deepcopy(synth.make_rollouts(12, [500])[0])       # longer than its successors: stale copies would spill into later rows
+    bad['actions']['ability'] = bad['actions']['ability'][:-3]    # a late key: the observations and most heads have queued their copies by then
+    worse = copy.deepcopy(synth.make_rollouts(13, [90])[0])
+    worse['masks']['ability'] = worse['masks']['ability'][:10]
+    pk = IncrementalPacker(16, torch.device('cpu'), expected_rows=32)
+    pk.add(good[0])
+    for b in (bad, worse):
+        n_items, n_keep, rows = len(pk._items), len(pk._keep), pk.rows
+        with pytest.raises(ValueError):
+            pk.add(b)
+        # (a rollout that needs a larger staging set packs what is pending before it is validated: then nothing is queued at all)
+        assert (len(pk._items), len(pk._keep)) in ((n_items, n_keep), (0, 0)) and (pk.rows, len(pk)) == (rows, 1)
+    for d in good[1:]:
+        pk.add(d)
+    got, want = pk.finish(), pack_rollouts(good, 16, torch.device('cpu'))
+    for k in ('obs', 'act', 'mask', 'rew', 'seq_off', 'seq_len'):
+        assert torch.equal(getattr(got, k), getattr(want, k)), k
+
+
 def test_staging_is_one_growing_pair_not_one_per_batch_size():
     # the consumer loop's row count changes almost every iteration: the page-locked staging must not accumulate a pair of
     # buffers per distinct size - one double-buffered pair, grown geometrically, a batch uses its leading rows
