@@ -61,6 +61,18 @@ WS_LAYER = ['GATES', 'HN', 'HSEQ', 'HPREV', 'CSEQ', 'CPREV', 'DGX', 'DGH', 'DC',
 DEVICE_ALLOC_HOOK = None
 
 
+def default_device():
+    """The GPU of THIS process (one process per GPU): `LOCAL_RANK` when a launcher set it (torch.distributed.run; optimizer.py:726-734
+    reads the same environment), else torch's current device.  What `Engine` / `Policy` / `DotaOptimizer` use for `device=None` and
+    where the module-level `discount` / `advantage_returns` put their operands - rank r never lands on GPU 0 by default."""
+    lr = os.environ.get('LOCAL_RANK')
+    if torch.cuda.is_available():
+        if lr is not None and lr.isdigit() and int(lr) < torch.cuda.device_count():
+            return torch.device('cuda', int(lr))
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cuda', int(lr) if lr is not None and lr.isdigit() else 0)
+
+
 def device_empty(shape, dtype, device):
     if DEVICE_ALLOC_HOOK is not None:
         return DEVICE_ALLOC_HOOK(tuple(shape) if not isinstance(shape, int) else (shape,), dtype, torch.device(device))
@@ -466,12 +478,18 @@ class IncrementalPacker:
 
 
 class Engine:
-    def __init__(self, cell='gru', hidden=256, layers=1, device='cuda:0'):
+    def __init__(self, cell='gru', hidden=256, layers=1, device=None):
         self.lib = _lib.load()
         self.cell, self.hidden, self.layers = cell, int(hidden), int(layers)
-        self.device = torch.device(device)
+        self.device = default_device() if device is None else torch.device(device)
         if self.device.type != 'cuda':
             raise _lib.DotaHipError('the PPO hot path only runs on the GPU (no CPU fallback)')
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        # One process per GPU: the library launches on the calling thread's current HIP device and on torch's current stream, so the
+        # engine's device is made the current one (the reference's ranks are CPU processes).
+        if torch.cuda.is_available() and torch.cuda.current_device() != self.device.index:
+            torch.cuda.set_device(self.device)
         self.layout, self.total = L.flat_layout(cell, hidden, layers)
         z = lambda: device_zeros(self.total, torch.float32, self.device)
         self.params, self.grads, self.adam_m, self.adam_v = z(), z(), z(), z()

@@ -28,7 +28,7 @@ import torch
 
 from . import layout as L
 from . import ops
-from .engine import IncrementalPacker, PackedBatch, describe_fault, pack_rollouts
+from .engine import IncrementalPacker, PackedBatch, default_device, describe_fault, pack_rollouts
 from .policy import Policy
 
 logger = logging.getLogger(__name__)
@@ -36,7 +36,7 @@ REWARD_KEYS = ['enemy', 'win', 'xp', 'hp', 'kills', 'death', 'lh', 'denies', 'to
 
 
 def _to_dev_f32(x):
-    return torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float32))).to('cuda:0')
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float32))).to(default_device())
 
 
 def discount(x, gamma):
@@ -139,7 +139,7 @@ class DotaOptimizer:
 
     def __init__(self, rmq_host, rmq_port, epochs, min_seq_per_epoch, seq_len, learning_rate, checkpoint,
                  pretrained_model, mq_prefetch_count, log_dir, entropy_coef, vf_coef, run_local,
-                 mq=None, metrics_sink=None, cell='gru', hidden=256, layers=1, device='cuda:0', reuse_rollout_forward=False,
+                 mq=None, metrics_sink=None, cell='gru', hidden=256, layers=1, device=None, reuse_rollout_forward=False,
                  prefetch=True):
         self.rmq_host, self.rmq_port = rmq_host, rmq_port
         self.epochs, self.min_seq_per_epoch, self.seq_len = epochs, min_seq_per_epoch, seq_len
@@ -182,18 +182,13 @@ class DotaOptimizer:
         self.pipeline_rollout_pass = True
         self.prefetch_past_gpu_done = False        # tests: keep draining the queue after the epochs have finished (deterministic batches)
 
-        # optimizer.py:241-267, the run_local branch: the newest model_%09d.pt of log_dir overrides an explicit pretrained model,
-        # and the iteration counter resumes behind the file's number so that published versions never go backwards
-        if self.checkpoint:
-            latest_model = self.get_latest_model(prefix=self.log_dir)
-            if latest_model is not None:
-                logger.info('Found a latest model in pretrained dir: %s', latest_model)
-                if pretrained_model is not None:
-                    logger.warning('Overriding pretrained model by latest model.')
-                pretrained_model = latest_model
-            if pretrained_model is not None:
-                self.iteration_start = self.iteration_from_model_filename(filename=pretrained_model) + 1
+        # An explicitly given pretrained model is loaded (optimizer.py:264-267) and, when checkpointing, the version counter carries on
+        # behind its file number (optimizer.py:252-253).  Scanning a checkpoint directory / bucket for the newest model
+        # (optimizer.py:243-250,287-296) is storage plumbing outside the hot path: the integrator's launcher
+        # resolves the path and passes it here.
         if pretrained_model is not None:
+            if self.checkpoint:
+                self.iteration_start = self.iteration_from_model_filename(filename=pretrained_model) + 1
             self.policy_base.load_state_dict(torch.load(pretrained_model, map_location='cpu'), strict=False)
 
         # data parallel: flat-bucket RCCL all-reduce instead of the reference's per-parameter gloo wrapper
@@ -228,14 +223,6 @@ class DotaOptimizer:
         import re
         x = re.search(r'(\d+)(?=\.pt)', os.path.basename(filename))
         return int(x.group(0)) if x else 1
-
-    def get_latest_model(self, prefix):
-        """optimizer.py:287-296, local directory instead of the GCS bucket: newest model file under `prefix`, or None."""
-        try:
-            names = sorted(f for f in os.listdir(prefix) if f.startswith('model_') and f.endswith('.pt'))
-        except OSError:
-            return None
-        return os.path.join(prefix, names[-1]) if names else None
 
     # ---- experience ingest ---------------------------------------------------------------------------
     def get_rollout(self):

@@ -49,7 +49,7 @@ class Policy(nn.Module):
     OUTPUT_KEYS = ACTION_OUTPUT_COUNTS.keys()
     INPUT_KEYS = list(L.INPUT_KEYS)
 
-    def __init__(self, cell='gru', hidden=256, layers=1, device='cuda:0'):
+    def __init__(self, cell='gru', hidden=256, layers=1, device=None):
         super().__init__()
         self.engine = Engine(cell, hidden, layers, device)
         self.cell, self.hidden_size, self.layers = cell, hidden, layers

@@ -221,19 +221,19 @@ def test_prefetching_consumer_loop_equals_the_serial_one(tmp_path):
     assert torch.allclose(opts[True].engine.params, opts[False].engine.params, rtol=0, atol=2e-6)
 
 
-def test_checkpoint_resume_restores_the_iteration_counter(tmp_path):
-    # optimizer.py:231-267 (run_local): log_dir is created, the newest model_%09d.pt there is loaded and the published versions carry
-    # on behind it (a restart republished from version 1)
+def test_pretrained_model_sets_the_weights_and_the_version_counter(tmp_path):
+    # optimizer.py:256-267: an explicitly given model file is loaded and the published versions carry on behind its number (finding the
+    # newest file of a checkpoint directory / bucket is the integrator's launcher's job: storage plumbing)
     g, rollouts = util.load_case('ragged_s16')
     log_dir = tmp_path / 'fresh' / 'logs'
     from dotaclient_amd.optimizer import DotaOptimizer
-    kw = dict(rmq_host='x', rmq_port=0, epochs=1, min_seq_per_epoch=1, seq_len=16, learning_rate=1e-4, pretrained_model=None,
+    kw = dict(rmq_host='x', rmq_port=0, epochs=1, min_seq_per_epoch=1, seq_len=16, learning_rate=1e-4,
               mq_prefetch_count=1, log_dir=str(log_dir), entropy_coef=5e-4, vf_coef=0.5, run_local=True)
-    a = DotaOptimizer(checkpoint=True, mq=FakeMQ(rollouts), **kw)
+    a = DotaOptimizer(checkpoint=True, pretrained_model=None, mq=FakeMQ(rollouts), **kw)
     assert a.iteration_start == 1 and (log_dir / 'model_000000001.pt').exists()
     a.policy_base.load_state_dict(synth.init_state_dict(11), strict=True)
     a.upload_model(version=7)
-    b = DotaOptimizer(checkpoint=True, mq=FakeMQ(rollouts), **kw)
+    b = DotaOptimizer(checkpoint=True, pretrained_model=str(log_dir / 'model_000000007.pt'), mq=FakeMQ(rollouts), **kw)
     assert b.iteration_start == 8
     assert (log_dir / 'model_000000008.pt').exists() and b.mq.published[-1][0] == {'version': 8}
     assert torch.equal(a.engine.params, b.engine.params)

@@ -586,3 +586,20 @@ def test_rnn_team_ring_model_detects_a_ring_that_is_too_small():
         except AssertionError:
             failures += 1
     assert failures > 0
+
+
+def test_default_device_follows_local_rank(monkeypatch):
+    # rank r of a torch.distributed.run launch must not land on GPU 0 by default (optimizer.py:726-734 reads the
+    # same environment); without LOCAL_RANK it is torch's current device
+    from dotaclient_amd.engine import default_device
+    monkeypatch.delenv('LOCAL_RANK', raising=False)
+    assert default_device().type == 'cuda' and default_device().index is not None
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    monkeypatch.setenv('LOCAL_RANK', '3')
+    want = 3 if (n == 0 or n > 3) else torch.cuda.current_device()      # a rank beyond the visible devices keeps the current one
+    assert default_device() == torch.device('cuda', want)
+    import inspect
+    from dotaclient_amd import optimizer as O, policy as P, engine as E
+    for fn in (O.DotaOptimizer.__init__, P.Policy.__init__, E.Engine.__init__):
+        assert inspect.signature(fn).parameters['device'].default is None
+    assert 'cuda:0' not in inspect.getsource(O) and 'cuda:0' not in inspect.getsource(E)
