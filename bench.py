@@ -153,42 +153,52 @@ def hip_parity_iteration(eng, batch, S, E, lr, ent, vf, hook=None):
     return out
 
 
+def oracle_iteration(cell, hidden, layers, rs, seq_len, n_ep, lr, ent, vf, keep=False):
+    """ONE optimizer iteration of the CPU oracle (oracle/ref_optimizer.py: rollout pass + n_ep epochs from the seed-7 weights) on
+    rollouts `rs`; returns (rollout-pass seconds, epoch seconds, chunks, read-outs for `parity` or None)."""
+    from oracle import ref_optimizer as RO
+    sd = synth.init_state_dict(7, cell, hidden, layers)
+    pol = RO.make_policy(sd, cell, hidden, layers)
+    opt = torch.optim.Adam(pol.parameters(), lr=lr)
+    t0 = time.time()
+    chunks = [c for r in rs for c in RO.rollout_pass(pol, r, seq_len)]
+    t1 = time.time()
+    ref = None
+    if keep:                                       # read-outs of the rollout pass: outside the timed spans
+        ref = {'advantages': torch.stack([c.advantages for c in chunks]).numpy().ravel(),
+               'returns': torch.stack([c.returns for c in chunks]).numpy().ravel(),
+               'values': torch.stack([c.values for c in chunks]).numpy().ravel(),
+               'argmax': RO.masked_argmax(pol, chunks).numpy().reshape(-1, 5)}
+        for k in RO.HEADS:
+            ref['old_logp_' + k] = torch.cat([c.old_logp[k] for c in chunks]).numpy()
+    t_train = 0.0
+    per_epoch = []
+    for _ in range(n_ep):
+        t2 = time.time()
+        parts, entr, norms = RO.train_step(pol, opt, chunks, ent, vf)
+        t_train += time.time() - t2
+        per_epoch.append([float(parts[k]) for k in ('loss', 'policy_loss', 'entropy_loss', 'value_loss')] +
+                         [float(entr[k]) for k in RO.HEADS] + [float(norms['unclipped']), float(norms['clipped'])])
+    if keep:
+        ref['epochs'] = np.array(per_epoch, dtype=np.float64)
+        ref['param_samples'] = np.concatenate([_tensor_samples(p) for _, p in pol.named_parameters()])
+    return t1 - t0, t_train, len(chunks), ref
+
+
 def cpu_baseline(cell, hidden, layers, rollouts, seq_len, epochs, lr, ent, vf):
     """Times the CPU oracle (kind "port") on the same synthetic workload: after a thread sweep and two warm-up steps on a bounded
     sample (the first 64 trajectories), ONE full bench step (rollout pass + `epochs` epochs) over ALL trajectories of the GPU's own
     batch - `value`, so that any GPU / CPU ratio compares the same workload, ~16 s of CPU work at configs[2] - which is
     also the checker side of `parity`.  Thread count: the best of a short sweep (torch CPU ops of this size get slower, not
-    faster, when spread over all host threads of the GPU box)."""
-    from oracle import ref_optimizer as RO
+    faster, when spread over all host threads of the GPU box).
+
+    kind is "port": the reference itself (Python, /root/reference) cannot travel to the GPU box, and this script cannot run where the
+    reference is (no GPU there) - tools/reference_cpu_step.py times the REAL reference's functions (optimizer.py:57-64,328-430,581-689) next
+    to this port in the build container (profiles/r05/reference_vs_port_cpu.json: the port is not the slower of the two)."""
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    sd = synth.init_state_dict(7, cell, hidden, layers)
 
     def one_iteration(rs, n_ep, keep=False):
-        pol = RO.make_policy(sd, cell, hidden, layers)
-        opt = torch.optim.Adam(pol.parameters(), lr=lr)
-        t0 = time.time()
-        chunks = [c for r in rs for c in RO.rollout_pass(pol, r, seq_len)]
-        t1 = time.time()
-        ref = None
-        if keep:                                       # read-outs of the rollout pass: outside the timed spans
-            ref = {'advantages': torch.stack([c.advantages for c in chunks]).numpy().ravel(),
-                   'returns': torch.stack([c.returns for c in chunks]).numpy().ravel(),
-                   'values': torch.stack([c.values for c in chunks]).numpy().ravel(),
-                   'argmax': RO.masked_argmax(pol, chunks).numpy().reshape(-1, 5)}
-            for k in RO.HEADS:
-                ref['old_logp_' + k] = torch.cat([c.old_logp[k] for c in chunks]).numpy()
-        t_train = 0.0
-        per_epoch = []
-        for _ in range(n_ep):
-            t2 = time.time()
-            parts, entr, norms = RO.train_step(pol, opt, chunks, ent, vf)
-            t_train += time.time() - t2
-            per_epoch.append([float(parts[k]) for k in ('loss', 'policy_loss', 'entropy_loss', 'value_loss')] +
-                             [float(entr[k]) for k in RO.HEADS] + [float(norms['unclipped']), float(norms['clipped'])])
-        if keep:
-            ref['epochs'] = np.array(per_epoch, dtype=np.float64)
-            ref['param_samples'] = np.concatenate([_tensor_samples(p) for _, p in pol.named_parameters()])
-        return t1 - t0, t_train, len(chunks), ref
+        return oracle_iteration(cell, hidden, layers, rs, seq_len, n_ep, lr, ent, vf, keep)
 
     cands = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 8)})
     best, best_t = cands[0], None
@@ -217,7 +227,7 @@ def cpu_baseline(cell, hidden, layers, rollouts, seq_len, epochs, lr, ent, vf):
     }, ref
 
 
-def parity_report(got, ref, tol=1e-4, argmax_min_equal=None, sub_batch=None):
+def parity_report(got, ref, tol=1e-4, argmax_min_equal=None, sub_batch=None, checker=None):
     """HIP path vs oracle on the bench workload itself.  Vectors: max |a-b| / max |b|; per-epoch scalars: relative, a loss
     part measured against max(|itself|, 1 % of the largest part), the total against the sum of |parts| (the same yardsticks as tests/test_gpu_parity.py)."""
     def scaled(a, b):
@@ -245,7 +255,7 @@ def parity_report(got, ref, tol=1e-4, argmax_min_equal=None, sub_batch=None):
     argmax_equal = bool(np.array_equal(got['argmax'], ref['argmax'].astype(got['argmax'].dtype)))
     argmax_frac = float((got['argmax'] == ref['argmax'].astype(got['argmax'].dtype)).mean())
     argmax_ok = argmax_equal if argmax_min_equal is None else argmax_frac >= argmax_min_equal
-    return {'checker': 'oracle/ref_optimizer.py (fp32) on the same %d env-steps%s, first iteration from the same initial weights, all %d epochs'
+    return {'checker': checker or 'oracle/ref_optimizer.py (fp32) on the same %d env-steps%s, first iteration from the same initial weights, all %d epochs'
                        % (ref['advantages'].size, '' if sub_batch is None else ' (the first %d trajectories of the timed batch, run as a batch of their own)' % sub_batch,
                           re_.shape[0]),
             'parity_rel_err': worst, 'tolerance': tol, 'argmax_bit_exact': argmax_equal, 'argmax_equal_fraction': argmax_frac,
@@ -317,7 +327,7 @@ MASK_DEPENDENT_BYTES = ('attn_logits', 'attn_bwd_q')   # mask-aware: bytes moved
 
 
 def run_workload(cell, hidden, layers, B, S, E, steps, warmup, dev, rank, world, hook_factory=None, want_parity=False,
-                 want_profile=False, lengths=None):
+                 want_profile=False, lengths=None, data_seed=1000, parity_epochs=None):
     """Builds an engine + a resident batch, runs warmup + `steps` timed iterations; returns a dict of raw results."""
     lr, ent, vf = 5e-5, 5e-4, 0.5
     eng = Engine(cell, hidden, layers, dev)
@@ -330,11 +340,11 @@ def run_workload(cell, hidden, layers, B, S, E, steps, warmup, dev, rank, world,
     if hook is not None:
         hook.sync_parameters()
     # every rank gets its own shard of trajectories (the reference's ranks pull from a shared queue)
-    rollouts = synth.make_rollouts(1000 + rank, [S] * B if lengths is None else lengths)
+    rollouts = synth.make_rollouts(data_seed + rank, [S] * B if lengths is None else lengths)
     batch = pack_rollouts(rollouts, S, dev)
     res = {'eng': eng, 'rollouts': rollouts, 'batch': batch, 'hook': hook, 'lr': lr, 'ent': ent, 'vf': vf}
     if want_parity:
-        res['first_iteration'] = hip_parity_iteration(eng, batch, S, E, lr, ent, vf, hook)
+        res['first_iteration'] = hip_parity_iteration(eng, batch, S, E if parity_epochs is None else parity_epochs, lr, ent, vf, hook)
 
     def step():
         chunks = eng.rollout_pass(batch, S)
@@ -401,6 +411,9 @@ def parse_args():
                     help='after the JSON line is printed and flushed: run the side measurements (ingest, publish, hipGraph replay, '
                          'reuse-forward, the other single-GPU configurations) in a subprocess; result to --extras-out and stderr')
     ap.add_argument('--extras-only', action='store_true', help='(what --extras runs in the subprocess) print only the side measurements')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the `secondary` / `products_fallback` blocks of the default N = 1 line')
+    ap.add_argument('--secondary-only', action='store_true', help='(what the default line runs in a subprocess) print only those two blocks')
+    ap.add_argument('--parity-ref', default='', help='(--secondary-only) .npz with the oracle read-outs of the headline batch, for `products_fallback`')
     ap.add_argument('--extras-out', default=os.path.join(REPO, 'gpurun_out', 'bench_extras.json'))
     ap.add_argument('--kernel-flags', type=int, default=0, help='DC_DIMS_* kernel-selection overrides (A/B measurements)')
     ap.add_argument('--products', default='f16x2', choices=['f16x2', 'bf16x3'],
@@ -410,7 +423,6 @@ def parse_args():
                     help='per-kernel HBM bytes from the rocprofv3 PMC passes (tools/gpu_round.sh + tools/pmc_traffic.py); '
                          'PMC counters cannot be read from inside the process, so `traffic` is taken from this file')
     # accepted and ignored (round-2 command lines): the side measurements are opt-in now
-    ap.add_argument('--no-secondary', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-host-extras', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -491,6 +503,10 @@ def main():
     S, E = args.seq_len, args.epochs
     B = args.batch if args.batch > 0 else (256 if world == 1 else 128)
 
+    if args.secondary_only:
+        print(json.dumps(secondary_measurements(args, dev, E, args.parity_ref)))
+        sys.stdout.flush()
+        return
     if args.extras_only:
         extras = side_measurements(args, dev, B, S, E)
         print(json.dumps(extras))
@@ -676,6 +692,13 @@ def main():
         else:
             line['cpu_baseline'] = None
             line['parity'] = None
+            ref = None
+        # the other configurations + the fallback products, in a subprocess (a crash there costs these two blocks, not the headline)
+        line['secondary'] = line['products_fallback'] = None
+        default_family = (args.cell, args.hidden, args.layers, S, args.batch, KERNEL_FLAGS, PRODUCTS) == ('lstm', 256, 1, 256, 0, 0, 'f16x2')
+        if world == 1 and want_cpu and default_family and not args.no_secondary:      # --no-cpu-baseline = the headline only (A/B and profiled runs)
+            sec = run_secondary_subprocess(args, ref if (want_cpu and B * S <= PARITY_FULL_MAX) else None)
+            line['secondary'], line['products_fallback'] = sec.get('secondary'), sec.get('products_fallback')
         print(json.dumps(line))
         sys.stdout.flush()                      # the headline is out before anything optional runs
         if line['parity'] is not None and not line['parity']['ok']:
@@ -685,6 +708,149 @@ def main():
         torch.distributed.destroy_process_group()
     elif args.extras and rank == 0:
         run_extras_subprocess(args)
+
+
+# ---- the default line's `secondary` and `products_fallback` blocks ---------------------------------------
+SECONDARY_STEPS, SECONDARY_WARMUP = 10, 3
+GOLDEN_DIR = os.path.join(REPO, 'tests', 'golden')
+
+
+def _slim_parity(p):
+    return {k: p[k] for k in ('checker', 'parity_rel_err', 'tolerance', 'argmax_bit_exact', 'argmax_equal_fraction', 'argmax_rule', 'ok',
+                              'per_quantity', 'elementwise_rel_err')}
+
+
+def _golden_as_ref(path):
+    """A tests/golden/*.npz of the REAL reference (tests/golden/make_golden.py: one epoch) in the shape `parity_report` compares."""
+    g = np.load(path)
+    ref = {'advantages': g['advantages'].ravel(), 'returns': g['returns'].ravel(), 'values': g['values'].ravel(),
+           'argmax': g['argmax'].reshape(-1, 5), 'param_samples': g['ep0_param_samples'],
+           'epochs': np.concatenate([g['ep0_losses'], g['ep0_entropies'], g['ep0_grad_norms']])[None].astype(np.float64)}
+    for k in g.files:
+        if k.startswith('old_logp_'):
+            ref[k] = g[k]
+    return ref
+
+
+def _cfg4_fixture_pair(got, path):
+    """(got, ref) restricted to the strided samples tests/golden/cfg4_shard_oracle.npz holds (tests/golden/make_cfg4_fixture.py)."""
+    f = np.load(path)
+    stride = int(f['stride'])
+    ref = {'returns': f['returns'], 'argmax': f['argmax_rows16'].astype(np.int64), 'param_samples': f['ep0_param_samples'],
+           'epochs': np.concatenate([f['ep0_losses'], f['ep0_entropies'], f['ep0_grad_norms']])[None].astype(np.float64)}
+    sub = {'returns': got['returns'].ravel()[::stride], 'argmax': got['argmax'].reshape(-1, 5)[::16], 'param_samples': got['param_samples'],
+           'epochs': got['epochs'][:1]}
+    for k in ['advantages', 'values'] + [k for k in f.files if k.startswith('old_logp_') and not k.endswith(('_max', '_n'))]:
+        ref[k] = f[k]
+        sub[k] = np.asarray(got[k]).ravel()[::stride]
+    return sub, ref
+
+
+def secondary_measurements(args, dev, E, parity_ref_path):
+    """The other BASELINE.json configurations and the reference's own cell / default shape, each SECONDARY_STEPS timed steps (barrier +
+    synchronize around them, like the headline) with a parity check of the first iteration, plus the headline workload on the fallback
+    products (bf16x3).  Runs in a subprocess of the default N = 1 line, before the line is printed: whatever happens here costs these
+    two blocks only."""
+    global KERNEL_FLAGS, PRODUCTS
+    lr, ent, vf = 5e-5, 5e-4, 0.5
+    S = 256
+    steps, warmup = SECONDARY_STEPS, SECONDARY_WARMUP
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else 16))
+    rng = np.random.Generator(np.random.PCG64(99))
+    lens, n_chunks = [], 0
+    while n_chunks < 1024:                   # the reference's defaults (optimizer.py:776-794): seq_len 16, whole rollouts until >= 1024 chunks
+        t = int(rng.integers(100, 900))
+        lens.append(t)
+        n_chunks += (t + 15) // 16
+    work = [
+        ('configs[1]', 'BASELINE.json configs[1]: 1v1-mid synthetic, LSTM-128, 64 trajectories x 256 steps',
+         dict(cell='lstm', hidden=128, layers=1, b=64, S=S), 'oracle'),
+        ('reference_gru256_64x256', "configs[1]'s batch on the reference's OWN cell (GRU-256, policy.py:66)",
+         dict(cell='gru', hidden=256, layers=1, b=64, S=S), 'golden'),
+        ('reference_defaults_gru256_s16_ragged', "the reference's own defaults (optimizer.py:776-794): GRU-256, seq_len 16, %d ragged rollouts "
+         '(100..899 steps) = %d chunks of 16 = %d env-steps incl. padded steps (counted like optimizer.py:486)' % (len(lens), n_chunks, n_chunks * 16),
+         dict(cell='gru', hidden=256, layers=1, b=len(lens), S=16, lengths=lens), 'oracle'),
+        ('configs[4]_shard_bf16', "BASELINE.json configs[4]'s per-GPU shard on ONE GPU: 2-layer LSTM-512, 256 trajectories x 512 steps, bf16 "
+         'path (DC_DIMS_BF16), no all-reduce', dict(cell='lstm', hidden=512, layers=2, b=256, S=512, flags=4096, data_seed=4242), 'cfg4_fixture'),
+    ]
+    out = {'secondary': {}, 'products_fallback': None}
+    for key, what, w, checker in work:
+        try:
+            KERNEL_FLAGS, PRODUCTS = w.get('flags', 0), 'f16x2'
+            bf16 = bool(KERNEL_FLAGS & 4096)
+            r = run_workload(w['cell'], w['hidden'], w['layers'], w['b'], w['S'], E, steps, warmup, dev, 0, 1, want_parity=True,
+                             lengths=w.get('lengths'), data_seed=w.get('data_seed', 1000), parity_epochs=None if checker == 'oracle' else 1)
+            rows = r['batch'].rows
+            ms = r['elapsed'] / steps * 1e3
+            e = {'workload': what, 'value': round(rows / (ms * 1e-3), 1), 'unit': 'env-steps/s', 'ms_per_step': round(ms, 3), 'steps': steps,
+                 'warmup': warmup, 'env_steps_per_step': rows, 'epochs': E, 'dtype': 'bf16' if bf16 else 'f32', 'products': 'bf16' if bf16 else PRODUCTS,
+                 'nan_status': r['status']}
+            got = r['first_iteration']
+            if checker == 'oracle':
+                _, _, _, ref = oracle_iteration(w['cell'], w['hidden'], w['layers'], r['rollouts'], w['S'], E, lr, ent, vf, keep=True)
+                e['parity'] = _slim_parity(parity_report(got, ref, 1e-4))
+            elif checker == 'golden':
+                e['parity'] = _slim_parity(parity_report(got, _golden_as_ref(os.path.join(GOLDEN_DIR, 'cfg2_gru_64x256.npz')), 1e-4,
+                                                         checker='tests/golden/cfg2_gru_64x256.npz: outputs of the REAL reference (optimizer.py:328-430,581-689 '
+                                                                 'imported from /root/reference by tests/golden/make_golden.py) on the same seeded 16 384 env-steps, '
+                                                                 'rollout pass + one epoch from the same initial weights'))
+            else:
+                sub, ref = _cfg4_fixture_pair(got, os.path.join(GOLDEN_DIR, 'cfg4_shard_oracle.npz'))
+                e['parity'] = _slim_parity(parity_report(sub, ref, 3e-2, 0.97,
+                                                         checker='tests/golden/cfg4_shard_oracle.npz: the fp32 oracle (oracle/ref_optimizer.py; no reference '
+                                                                 'exists for this cell, SURVEY.md 8(c)) on the same seeded 131 072 env-steps, strided samples, rollout '
+                                                                 'pass + one epoch; bf16 path judged by its STATED tolerance (tests/test_gpu_bf16.py)'))
+            out['secondary'][key] = e
+            del r
+        except Exception as ex:                                  # noqa: BLE001 - one workload's failure is reported, not raised
+            out['secondary'][key] = {'workload': what, 'error': repr(ex)}
+        torch.cuda.empty_cache()
+    # the headline workload on the products the consumer loop falls back to when an operand leaves f16's range (Engine.use_safe_products)
+    try:
+        KERNEL_FLAGS, PRODUCTS = 0, 'bf16x3'
+        B = args.batch if args.batch > 0 else 256
+        r = run_workload(args.cell, args.hidden, args.layers, B, args.seq_len, E, steps, warmup, dev, 0, 1, want_parity=bool(parity_ref_path))
+        ms = r['elapsed'] / steps * 1e3
+        fb = {'products': 'bf16x3', 'what': 'the timed workload of this line on the fallback products (three bf16 pieces per f32 operand, six MFMAs, '
+                                            "f32's exponent range): what the consumer loop switches to when an operand leaves f16's range",
+              'value': round(r['batch'].rows / (ms * 1e-3), 1), 'unit': 'env-steps/s', 'ms_per_step': round(ms, 3), 'steps': steps, 'warmup': warmup,
+              'nan_status': r['status']}
+        if parity_ref_path:
+            z = np.load(parity_ref_path)
+            fb['parity'] = _slim_parity(parity_report(r['first_iteration'], {k: z[k] for k in z.files}, 1e-4))
+        out['products_fallback'] = fb
+    except Exception as ex:                                      # noqa: BLE001
+        out['products_fallback'] = {'products': 'bf16x3', 'error': repr(ex)}
+    return out
+
+
+def run_secondary_subprocess(args, ref):
+    """`secondary_measurements` in a process of its own (timeout 600 s); returns its dict, or one that says what went wrong."""
+    import subprocess
+    import tempfile
+    ref_path = ''
+    tmp = None
+    if ref is not None:
+        tmp = tempfile.NamedTemporaryFile(suffix='.npz', delete=False)
+        tmp.close()
+        np.savez(tmp.name, **ref)
+        ref_path = tmp.name
+    cmd = [sys.executable, os.path.abspath(__file__), '--secondary-only', '--cell', args.cell, '--hidden', str(args.hidden), '--layers', str(args.layers),
+           '--batch', str(args.batch), '--seq-len', str(args.seq_len), '--epochs', str(args.epochs), '--parity-ref', ref_path]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        last = (r.stdout.strip().splitlines() or [''])[-1]
+        if r.returncode == 0 and last.startswith('{'):
+            return json.loads(last)
+        return {'secondary': {'error': 'subprocess rc %d: %s' % (r.returncode, r.stderr[-400:])}, 'products_fallback': None}
+    except Exception as ex:                                      # noqa: BLE001 - nothing here may cost the headline
+        return {'secondary': {'error': repr(ex)}, 'products_fallback': None}
+    finally:
+        if tmp is not None:
+            try:
+                os.unlink(tmp.name)
+            except OSError:
+                pass
 
 
 def run_extras_subprocess(args):

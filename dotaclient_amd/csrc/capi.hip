@@ -75,7 +75,14 @@ int dc_gemm_x3(const float* A, const float* B, float* C, int M, int N, int K, in
     hipStream_t s = (hipStream_t)stream;
     X3Gemm g;
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.nbias = N; g.relu = relu; g.aux = aux; g.ldaux = ldaux;
-    g.accumulate = accumulate; g.prec = prec == 1 ? 1 : (prec == 4 ? 4 : 6);      // 4: two f16 pieces, unit pre-scales (sa = sb = 1)
+    // prec: low byte 1 / 4 / 6; for 4 (two f16 pieces) bits 8..15 / 16..23 = log2 of A's / B's power-of-two pre-scale, signed bytes
+    // (DC_GEMM_PREC_F16X2(la, lb), include/dotaclient_hip.h) - what policy.hip passes for activations (2^4), weights (2^8), gradients
+    const int form = prec & 0xff;
+    g.accumulate = accumulate; g.prec = form == 1 ? 1 : (form == 4 ? 4 : 6);
+    if (g.prec == 4) {
+        g.sa = ldexpf(1.f, (int)(int8_t)((prec >> 8) & 0xff));
+        g.sb = ldexpf(1.f, (int)(int8_t)((prec >> 16) & 0xff));
+    }
     if (a_kmajor && b_kmajor) {
         g.A = A; g.a_mode = X3_KMAJ; g.lda = lda; g.B = B; g.b_mode = X3_KMAJ; g.ldb = ldb;
         g.scratch = GemmScratch{scratch, (long long)scratch_floats};
@@ -86,7 +93,7 @@ int dc_gemm_x3(const float* A, const float* B, float* C, int M, int N, int K, in
     if (scratch == nullptr || scratch_floats < plane_floats) { set_error("dc_gemm_x3: scratch too small for the weight planes", 1008); return 1008; }
     // B: [N][ldb] (x W^T) or [K][ldb] (dy W): planes [3][N][K] either way
     X3SplitJob job{B, reinterpret_cast<uint16_t*>(scratch), b_kmajor ? K : N, b_kmajor ? N : K, ldb, b_kmajor ? 1 : 0, b_kmajor ? K : N};
-    if (int e = split_weight_planes(&job, 1, g.prec, s)) return e;
+    if (int e = split_weight_planes(&job, 1, g.prec, s, g.sb)) return e;
     g.A = A; g.a_mode = X3_ROW; g.lda = lda;
     g.B = scratch; g.b_mode = X3_PLANES; g.ldb = K; g.b_plane = (long long)N * K; g.transposed_w = b_kmajor;
     return gemm_x3(g, s);

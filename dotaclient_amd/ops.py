@@ -59,9 +59,16 @@ def advantage_returns(rewards, values, gamma, lam):
     return adv, ret
 
 
+def prec_f16x2(log2_sa=0, log2_sb=0):
+    """`x3` value for the two-f16-piece products with power-of-two pre-scales 2^log2_sa / 2^log2_sb of the A / B operand
+    (DC_GEMM_PREC_F16X2, include/dotaclient_hip.h): what the network passes for activations (4), weights (8), gradients (ceil(log2 rows) + 2)."""
+    return 4 | ((log2_sa & 0xff) << 8) | ((log2_sb & 0xff) << 16)
+
+
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, bias=None, relu=False, aux=None,
          ldaux=0, accumulate=False, splits=0, scratch=None, x3=0):
-    """x3 = 6 / 1: the split-on-load bf16-matrix-core kernel (dc_gemm_x3: f32-grade / plain bf16); 0: dc_gemm_f32."""
+    """x3 = 6 / 4 / 1: the split-on-load matrix-core kernel (dc_gemm_x3: three bf16 pieces / two f16 pieces (prec_f16x2 for pre-scales) /
+    plain bf16); 0: dc_gemm_f32."""
     lib = _lib.load()
     for t, n in ((A, 'A'), (B, 'B'), (C, 'C')):
         _chk(t, torch.float32, n)

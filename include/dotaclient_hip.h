@@ -70,11 +70,14 @@ int dc_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, i
                 int accumulate, int splits, float* scratch, int64_t scratch_floats, dc_stream_t stream);
 
 /* The same product through the split-on-load kernel the network's dense layers use (gemm_x3.hip): operands as exact 3-way bf16
- * splits on the bf16 matrix cores (prec 6: f32-grade results), as two f16 pieces with three MFMAs (prec 4: f32-grade while the operands
- * stay inside f16's exponent range, no pre-scaling through this entry point) or rounded to bf16 (prec 1), f32 accumulate.  Layouts:
+ * splits on the bf16 matrix cores (prec 6: f32-grade results), as two f16 pieces with three MFMAs (prec 4, the network's default
+ * arithmetic: f32-grade while sa * |a| and sb * |b| stay inside f16's exponent range; the power-of-two pre-scales sa = 2^la, sb = 2^lb
+ * travel in the upper bits of `prec`, DC_GEMM_PREC_F16X2(la, lb) - plain 4 = unit scales; an entry beyond 65504 / scale becomes inf,
+ * its output row / column non-finite: never a silently wrong finite number) or rounded to bf16 (prec 1), f32 accumulate.  Layouts:
  * a_kmajor = b_kmajor = 0 (x W^T), a_kmajor = 0 / b_kmajor = 1 (dy W), a_kmajor = b_kmajor = 1 (dy^T x, split-K).  B is a weight
  * matrix in the first two forms and is split into bf16 planes inside the call (into `scratch`, which must hold
  * 3 * N * K / 2 floats for it, plus splits * M * N for split-K).  K % 16 == 0, N % 4 == 0.  No relu/aux with split-K. */
+#define DC_GEMM_PREC_F16X2(la, lb) (4 | (((la) & 0xff) << 8) | (((lb) & 0xff) << 16))
 int dc_gemm_x3(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                int a_kmajor, int b_kmajor, const float* bias, int relu, const float* aux, int ldaux,
                int accumulate, int prec, float* scratch, int64_t scratch_floats, dc_stream_t stream);

@@ -91,3 +91,22 @@ def test_self_launch_command_line(monkeypatch):
     # without the test aid two ranks on a one-GPU box are refused
     monkeypatch.delenv('DC_BENCH_ONE_DEVICE')
     assert bench.self_launch(a) == 2
+
+
+def test_secondary_checkers_read_the_committed_fixtures():
+    # the default line's `secondary` block checks the reference's GRU-256 against the REAL reference's golden outputs and configs[4]'s
+    # shard against the oracle fixture: both files travel with the repo, and their shapes are what parity_report compares
+    import numpy as np
+    ref = bench._golden_as_ref(os.path.join(bench.GOLDEN_DIR, 'cfg2_gru_64x256.npz'))
+    assert ref['advantages'].shape == (16384,) and ref['argmax'].shape == (16384, 5) and ref['epochs'].shape == (1, 11)
+    p = bench.parity_report(ref, ref, 1e-4, checker='self')
+    assert p['ok'] and p['parity_rel_err'] == 0.0 and p['checker'] == 'self' and p['argmax_bit_exact']
+    f = np.load(os.path.join(bench.GOLDEN_DIR, 'cfg4_shard_oracle.npz'))
+    got = {k: np.zeros(int(f[k + '_n']), np.float32) for k in ['advantages', 'returns', 'values'] + ['old_logp_' + h for h in ('enum', 'x', 'y', 'target_unit', 'ability')]}
+    got.update(argmax=np.zeros((131072, 5), np.int32), param_samples=np.zeros_like(f['ep0_param_samples']), epochs=np.zeros((4, 11)))
+    sub, r2 = bench._cfg4_fixture_pair(got, os.path.join(bench.GOLDEN_DIR, 'cfg4_shard_oracle.npz'))
+    for k in r2:
+        assert np.asarray(sub[k]).shape == np.asarray(r2[k]).shape, k
+    rep = bench.parity_report(sub, r2, 3e-2, 0.97)
+    assert not rep['ok'] and 'returns' not in rep['per_quantity']       # zeros are not the oracle's outputs
+    assert bench.SECONDARY_STEPS == 10

@@ -130,18 +130,20 @@ def test_gemm_layouts(akm, bkm, M, N, K):
     assert err < 2e-6, err
 
 
-@pytest.mark.parametrize('prec,tol', [(6, 2e-6), (1, 2e-2)])
+@pytest.mark.parametrize('prec,tol', [(6, 2e-6), (4, 2e-6), (1, 2e-2)])
 @pytest.mark.parametrize('akm,bkm', [(False, False), (False, True), (True, True)])
 @pytest.mark.parametrize('M,N,K', [(64, 64, 32), (200, 160, 256), (1000, 256, 896), (130, 72, 160), (768, 256, 5008),
                                    (33, 12, 16), (2048, 768, 256), (154, 256, 8192)])
 def test_gemm_x3_layouts(prec, tol, akm, bkm, M, N, K):
-    # the split-on-load kernel of gemm_x3.hip (dc_gemm_x3): f32-grade at prec 6 (the same bar as the f32 kernel), operands
+    # the split-on-load kernel of gemm_x3.hip (dc_gemm_x3): f32-grade at prec 6 (the same bar as the f32 kernel) and at prec 4 - the
+    # two-f16-piece / three-MFMA form that is the network's DEFAULT arithmetic (Engine.products 'f16x2'; unit pre-scales here, the
+    # operand classes with their pre-scales and the range edges are below) -, operands
     # rounded to bf16 at prec 1 (error ~ 2^-9 sqrt(K)-ish of the operand scale: 2e-2 of max |C| is loose but catches layout bugs);
     # ragged M / N (row clamp + masked 16-byte stores), padded leading dimensions, split-K on the long-K k-major shapes
     from dotaclient_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K + prec)
-    if prec == 6 and K > 4096:
+    if prec in (4, 6) and K > 4096:
         tol = 5e-6                               # f32 accumulation over K > 4096 terms (the f32 fma chain is at 3.5e-6 there as well)
     lda = ((M + 3) // 4 * 4 if akm else K) + 4   # k-major rows are read 16 bytes at a time: leading dimension % 4 == 0
     ldb = (N if bkm else K) + 8
@@ -160,20 +162,131 @@ def test_gemm_x3_layouts(prec, tol, akm, bkm, M, N, K):
     assert torch.all(out[:, N:] == 7.0), 'wrote outside the N columns'
     err = (out[:, :N].double() - ref).abs().max().item() / ref.abs().max().item()
     assert err < tol, err
-    if prec == 6 and not tn:                      # epilogues: relu, mask, accumulate
+    if prec in (4, 6) and not tn:                 # epilogues: relu, mask, accumulate
         aux = torch.randn(M, N, generator=g)
         C2 = torch.empty(M, N, device=dev)
-        ops.gemm(A.to(dev), B.to(dev), C2, M, N, K, lda, ldb, N, akm, bkm, bias=bias.to(dev), relu=True, scratch=scratch, x3=6)
+        ops.gemm(A.to(dev), B.to(dev), C2, M, N, K, lda, ldb, N, akm, bkm, bias=bias.to(dev), relu=True, scratch=scratch, x3=prec)
         assert (C2.cpu().double() - ref.clamp(min=0)).abs().max() / ref.abs().max() < tol
-        ops.gemm(A.to(dev), B.to(dev), C2, M, N, K, lda, ldb, N, akm, bkm, bias=bias.to(dev), aux=aux.to(dev), ldaux=N, scratch=scratch, x3=6)
+        ops.gemm(A.to(dev), B.to(dev), C2, M, N, K, lda, ldb, N, akm, bkm, bias=bias.to(dev), aux=aux.to(dev), ldaux=N, scratch=scratch, x3=prec)
         assert (C2.cpu().double() - ref * (aux > 0)).abs().max() / ref.abs().max() < tol
         C2.fill_(1.0)
-        ops.gemm(A.to(dev), B.to(dev), C2, M, N, K, lda, ldb, N, akm, bkm, bias=bias.to(dev), accumulate=True, scratch=scratch, x3=6)
+        ops.gemm(A.to(dev), B.to(dev), C2, M, N, K, lda, ldb, N, akm, bkm, bias=bias.to(dev), accumulate=True, scratch=scratch, x3=prec)
         assert (C2.cpu().double() - (ref + 1)).abs().max() / ref.abs().max() < tol
     if tn:                                        # accumulate into live data through the split-K reduce
         C3 = torch.full((M, N), 2.0, device=dev)
         ops.gemm(A.to(dev), B.to(dev), C3, M, N, K, lda, ldb, N, True, True, accumulate=True, scratch=scratch, x3=prec)
         assert (C3.cpu().double() - (ref + 2)).abs().max() / ref.abs().max() < tol
+
+
+# ---- the default arithmetic at its edges (VERDICT r4 missing 3): prec 4 with the pre-scales policy.hip passes --------------------------
+# activations 2^4 (limit 65504 / 16 = 4094), weights 2^8 (limit 255.9), gradients 2^(ceil(log2 rows) + 2) (limit ~16384 / rows).
+F16_MAX = 65504.0
+FORMS = {                                   # name: (a_kmajor, b_kmajor, class of A, class of B) - the three products of every nn.Linear
+    'x W^T': (False, False, 'act', 'w'),    # policy.py:54-75,138-155 forward
+    'dy W': (False, True, 'grad', 'w'),     # autograd: input gradient
+    'dy^T x': (True, True, 'grad', 'act'),  # autograd: weight gradient (split-K)
+}
+ROWS = 65536                                # the batch the gradient pre-scale is derived from (configs[2])
+LOG2 = {'act': 4, 'w': 8, 'grad': 16 + 2}
+
+
+def _operand(cls, shape, g):
+    if cls == 'act':                        # relu / tanh outputs and unit-variance inputs, a few large entries
+        return torch.randn(shape, generator=g) * (1.0 + 30.0 * (torch.rand(shape, generator=g) < 0.01))
+    if cls == 'w':                          # U(-1/sqrt(fan_in), 1/sqrt(fan_in)) like nn.Linear's init
+        return (torch.rand(shape, generator=g) * 2 - 1) / 16.0
+    return torch.randn(shape, generator=g) / ROWS        # gradients of a mean loss over ROWS env-steps
+
+
+def _x3_product(A, B, M, N, K, akm, bkm, prec):
+    from dotaclient_amd import ops
+    dev = _dev()
+    C = torch.full((M, N), 7.0, device=dev)
+    scratch = torch.empty(max(2 * N * K, 16 * M * N) + 1024, device=dev)
+    ops.gemm(A.to(dev), B.to(dev), C, M, N, K, A.shape[1], B.shape[1], N, akm, bkm, scratch=scratch, x3=prec)
+    return C.cpu()
+
+
+def _ref(A, B, akm, bkm):
+    return (A.t() if akm else A).double() @ (B if bkm else B.t()).double()
+
+
+@pytest.mark.parametrize('form', list(FORMS))
+@pytest.mark.parametrize('M,N,K', [(1000, 256, 896), (130, 72, 160), (2048, 768, 256), (152, 256, 8192)])
+def test_gemm_x3_f16x2_operand_classes_with_their_prescales(form, M, N, K):
+    # every product class of the network at its own pre-scales, ragged M / N, against f64 at the f32 kernel's bar
+    from dotaclient_amd import ops
+    akm, bkm, ca, cb = FORMS[form]
+    if akm:
+        M = (M + 3) // 4 * 4
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K + len(form))
+    A = _operand(ca, (K, M) if akm else (M, K), g)
+    B = _operand(cb, (K, N) if bkm else (N, K), g)
+    ref = _ref(A, B, akm, bkm)
+    out = _x3_product(A, B, M, N, K, akm, bkm, ops.prec_f16x2(LOG2[ca], LOG2[cb]))
+    err = (out.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < (5e-6 if K > 4096 else 2e-6), (form, err)
+
+
+@pytest.mark.parametrize('form', list(FORMS))
+def test_gemm_x3_f16x2_at_the_range_edge_and_beyond(form):
+    # 0.9 x the documented limit of each operand class: still f32-grade.  Just over it: the entry becomes inf in its first f16 piece and
+    # every output that depends on it is NON-FINITE (-> NaN loss -> the reference's own NaN guard -> Engine.use_safe_products), the rest
+    # of C stays accurate: never a silently wrong finite number.
+    from dotaclient_amd import ops
+    akm, bkm, ca, cb = FORMS[form]
+    M, N, K = 256, 128, 512
+    g = torch.Generator().manual_seed(11 + len(form))
+    A0 = _operand(ca, (K, M) if akm else (M, K), g)
+    B0 = _operand(cb, (K, N) if bkm else (N, K), g)
+    prec = ops.prec_f16x2(LOG2[ca], LOG2[cb])
+    lim_a, lim_b = F16_MAX / 2.0 ** LOG2[ca], F16_MAX / 2.0 ** LOG2[cb]
+    m, n, k = 37, 19, 301
+    for which, factor in [('a', 0.9), ('b', 0.9), ('a', 1.01), ('b', 1.01)]:
+        A, B = A0.clone(), B0.clone()
+        if which == 'a':
+            A[(k, m) if akm else (m, k)] = -factor * lim_a
+        else:
+            B[(k, n) if bkm else (n, k)] = factor * lim_b
+        out = _x3_product(A, B, M, N, K, akm, bkm, prec)
+        ref = _ref(A, B, akm, bkm)
+        if factor < 1:
+            assert torch.isfinite(out).all(), (form, which)
+            assert (out.double() - ref).abs().max().item() / ref.abs().max().item() < 2e-6, (form, which)
+        else:
+            hit = torch.zeros(M, N, dtype=torch.bool)
+            if which == 'a':
+                hit[m, :] = True
+            else:
+                hit[:, n] = True
+            assert not torch.isfinite(out[hit]).any(), (form, which, 'an out-of-range operand produced finite outputs')
+            assert torch.isfinite(out[~hit]).all()
+            ref0 = _ref(A0, B0, akm, bkm)
+            assert (out[~hit].double() - ref0[~hit]).abs().max().item() / ref0.abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize('form', ['dy W', 'dy^T x'])
+def test_gemm_x3_f16x2_small_gradients_second_piece_subnormal(form):
+    # gradient entries of 1e-9 .. 1e-7 at rows = 65 536: after the 2^18 pre-scale their FIRST f16 piece is normal, the second falls into
+    # f16's subnormal band (absolute resolution 2^-24 / 2^18 = 2.3e-13 per entry instead of 2^-23 relative).  The product must still be
+    # f32-grade against the largest result, and no worse than ~2^-12 relative even for an all-tiny operand.
+    from dotaclient_amd import ops
+    akm, bkm, ca, cb = FORMS[form]
+    M, N, K = 256, 256, 4096 if akm else 256
+    g = torch.Generator().manual_seed(5 + len(form))
+    shape = (K, M) if akm else (M, K)
+    mag = 10.0 ** (-9.0 + 2.0 * torch.rand(shape, generator=g))
+    A = mag * (torch.randint(0, 2, shape, generator=g) * 2 - 1)
+    B = _operand(cb, (K, N) if bkm else (N, K), g)
+    ref = _ref(A, B, akm, bkm)
+    out = _x3_product(A, B, M, N, K, akm, bkm, ops.prec_f16x2(LOG2['grad'], LOG2[cb]))
+    err = (out.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 5e-6, (form, err)
+    # mixed with ordinary gradient entries (the realistic case: a few heads act rarely, most entries are O(1 / rows)): f32-grade
+    A2 = torch.where(torch.rand(shape, generator=g) < 0.5, A, _operand('grad', shape, g))
+    ref2 = _ref(A2, B, akm, bkm)
+    out2 = _x3_product(A2, B, M, N, K, akm, bkm, ops.prec_f16x2(LOG2['grad'], LOG2[cb]))
+    assert (out2.double() - ref2).abs().max().item() / ref2.abs().max().item() < 2e-6
 
 
 def test_gemm_epilogues():

@@ -69,8 +69,12 @@ def _loss_err(a, b, key):
     return float(np.max(np.abs(a - b) / (np.abs(b) + 1e-30)))
 
 
-ELEM_TOL = 2e-2     # element-wise relative error on entries above 1e-3 * max|ref| (util.elementwise_rel_err): recorded for every
-                    # compare() into gpurun_out/elementwise_parity.json (tests/conftest.py) and bounded here; the 1e-4 bar is the scaled one
+ELEM_TOL = 2e-3     # element-wise relative error on entries above 1e-3 * max|ref| (util.elementwise_rel_err): recorded for every
+                    # compare() into gpurun_out/elementwise_parity.json (tests/conftest.py) and bounded here; the 1e-4 bar is the scaled
+                    # one.  Measured worst over the suite: 1.3e-3 (values), 3.9e-5 (advantages).  Where it comes from: an entry of
+                    # 1e-3 * max that is a sum of O(max) f32 terms - not one layer's summation order: the fp32 ORACLE itself sits 4.3e-4
+                    # (values) / 2.9e-4 (pre-rnn activations, K = 896) element-wise from its own fp64 evaluation on a quarter of the bench
+                    # batch while its scaled error is 7.7e-7 (tools/values_error_budget.py, profiles/r05/values_error_budget_*.json).
 
 
 def compare(out, ref, n_ep, names_ref, tol=TOL):
@@ -555,3 +559,39 @@ def test_f16x2_out_of_range_operand_trips_the_nan_guard_and_the_bf16_pieces_do_n
             assert not eng.use_safe_products()
     assert res['bf16x3'][0] == 0 and not res['bf16x3'][1] and res['bf16x3'][2]
     assert res['f16x2'][0] != 0 and res['f16x2'][1]
+
+
+@pytest.mark.parametrize('key,unit', [('allied_nonheroes', 3), ('enemy_heroes', 2), ('allied_towers', 0)])
+def test_f16x2_fused_embedding_first_layer_at_the_range_edge(key, unit):
+    # VERDICT r4 missing 3: the fused embedding kernels regenerate their FIRST layer on the f16 matrix cores from two-piece splits of the
+    # unit records (x 2^4) and of W1 (x 2^8) - policy.py:100-127.  A record entry at 0.9 x the activation limit (65504 / 16 = 4094) must
+    # give the same numbers as the layer-by-layer path (DC_DIMS_EMBED_UNFUSED, dense products) and as the bf16x3 products (f32's
+    # exponent range); one just over the limit must turn that env-step's outputs NON-FINITE in both f16x2 paths (-> NaN loss -> the
+    # reference's NaN guard -> Engine.use_safe_products), never finite and wrong.  A 16-unit type (max-pool from the accumulators), a
+    # 5-unit type and a 1-unit type.
+    from dotaclient_amd import engine as E
+    dev = torch.device('cuda:0')
+    S, row = 16, 21
+    LIMIT = 65504.0 / 16.0
+
+    def values_for(x, products, flags):
+        rollouts = synth.make_rollouts(5, [32, 32])
+        rollouts[0]['observations'][key][row, unit, 7] = x
+        eng = E.Engine('gru', 256, 1, dev)
+        eng.products, eng.kernel_flags = products, flags
+        eng.load_state_dict(synth.init_state_dict(7))
+        batch = E.pack_rollouts(rollouts, S, dev)
+        eng.rollout_pass(batch, S)
+        return batch.values.cpu().numpy().copy(), batch.old_logp.cpu().numpy().copy()
+
+    ref_v, ref_lp = values_for(0.9 * LIMIT, 'bf16x3', 0)
+    assert np.isfinite(ref_v).all()
+    for flags in (0, E.DC_DIMS_EMBED_UNFUSED):
+        v, lp = values_for(0.9 * LIMIT, 'f16x2', flags)
+        assert np.isfinite(v).all() and np.isfinite(lp).all()
+        assert util.scaled_err(v, ref_v) < 1e-5 and util.scaled_err(lp, ref_lp) < 1e-5, (flags, util.scaled_err(v, ref_v))
+        v, lp = values_for(1.01 * LIMIT, 'f16x2', flags)
+        assert not np.isfinite(v[row]), (flags, 'an out-of-range record entry gave a finite value')
+        assert np.isfinite(v[:row]).all() and np.isfinite(v[32:]).all()        # steps before it and the other rollout are untouched
+    v, _ = values_for(1.01 * LIMIT, 'bf16x3', 0)
+    assert np.isfinite(v).all()
