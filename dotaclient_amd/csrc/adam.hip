@@ -57,7 +57,10 @@ __device__ __forceinline__ void clip_finalize(const AdamSegs& sg, const double* 
     float coef = max_norm / (total + 1e-6f);
     if (coef > 1.f) coef = 1.f;
     const bool loss_nan = losses[0] != losses[0];
-    const bool norm_nan = unclipped != unclipped;
+    // NaN like the reference (optimizer.py:678-679) - and an INFINITE norm too: with the two-f16-piece products an out-of-range gradient
+    // operand becomes inf where the reference holds a finite number; the reference's clip would scale by 0.5 / inf = 0 and write
+    // inf * 0 = NaN into the parameters.  Same status word (2), nothing updated.
+    const bool norm_nan = unclipped != unclipped || !(total <= 3.0e38f);
     int st = *status;             // sticky: once an epoch tripped a guard, later epochs skip their update too until the caller
     if (st == 0) {                // clears the word (the reference raises at the first NaN epoch: nothing runs after it)
         if (loss_nan) st = 1; else if (norm_nan) st = 2;

@@ -44,6 +44,13 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// max / relu that PROPAGATE NaN (v_maximum3_f32, IEEE-754-2019 maximum; fmaxf = maxNum returns the other operand).  torch.max and
+// torch.relu propagate NaN too (policy.py:97-138), and the f16x2 products rely on it: an operand beyond f16's range becomes inf, its
+// products NaN, and that NaN has to REACH the loss (the reference's own NaN guard, optimizer.py:667-669) - a relu or a max-pool that
+// swallows it would turn an out-of-range input into a finite, wrong step (tests/test_gpu_parity.py::..._at_the_range_edge).
+__device__ __forceinline__ float max_nan(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+__device__ __forceinline__ float relu_nan(float a) { return __builtin_elementwise_maximum(a, 0.f); }
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 }  // namespace dc

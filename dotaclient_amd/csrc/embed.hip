@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void unit_basic_fwd_kernel(const float* __rest
         float acc = b;
 #pragma unroll
         for (int f = 0; f < 12; ++f) acc = fmaf(x[f], w[f], acc);
-        basic[row * EMB + c] = fmaxf(acc, 0.f);
+        basic[row * EMB + c] = relu_nan(acc);
         ++row;
         cur.advance(row, nr);
     }
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void pool_env_fwd_kernel(const float* __restri
     for (long long n = (long long)blockIdx.x * 2 + sub; n < nr; n += (long long)gridDim.x * 2) {
         const float* e = obs + n * OBS_DIM;
         float* xo = xcat + n * XCAT;
-        xo[c] = fmaxf(fmaf(e[2], w2, fmaf(e[1], w1, fmaf(e[0], w0, be))), 0.f);  // policy.py:97
+        xo[c] = relu_nan(fmaf(e[2], w2, fmaf(e[1], w1, fmaf(e[0], w0, be))));  // policy.py:97
         if (residual) {
             const float* p = emb + (nrp * c_type_cum[1] + n * 5) * EMB + c;
             float m = p[0];
@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void pool_env_fwd_kernel(const float* __restri
 #pragma unroll
             for (int u = 1; u < 5; ++u) {
                 const float v = p[(long long)u * EMB];
-                if (v > m) { m = v; am = u; }
+                am = v > m ? u : am;
+                m = max_nan(m, v);                  // a NaN unit makes the pooled value NaN, like torch.max
             }
             amax[(n * 3 + 0) * EMB + c] = (uint8_t)am;
             xo[2 * EMB + c] = m;
@@ -125,7 +126,8 @@ __global__ __launch_bounds__(256) void pool_env_fwd_kernel(const float* __restri
             int am = 0;
             for (int u = 1; u < U; ++u) {
                 const float v = p[(long long)u * EMB];
-                if (v > m) { m = v; am = u; }   // first maximum wins, like torch.max
+                am = v > m ? u : am;            // first maximum wins, like torch.max
+                m = max_nan(m, v);              // ... and a NaN unit makes the pooled value NaN, like torch.max
             }
             if (t == 3) enh_max = m;
             if (t >= 1 && t <= 3) amax[(n * 3 + (t - 1)) * EMB + c] = (uint8_t)am;

@@ -197,12 +197,12 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
             g = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wm, g, 0, 0, 0);
             g = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, g, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a_s[aoff[r]] = fmaxf(fmaf(g[r], ginv, b1v[kt]), 0.f);
+            for (int r = 0; r < 16; ++r) a_s[aoff[r]] = relu_nan(fmaf(g[r], ginv, b1v[kt]));      // NaN-propagating: common.h
         } else {
 #pragma unroll
             for (int kk = 0; kk < 6; ++kk) g = __builtin_amdgcn_mfma_f32_32x32x2f32(x[kk], wb[kt][kk], g, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a_s[aoff[r]] = fmaxf(g[r] + b1v[kt], 0.f);
+            for (int r = 0; r < 16; ++r) a_s[aoff[r]] = relu_nan(g[r] + b1v[kt]);
         }
     };
 
@@ -316,7 +316,8 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
                         for (int rr = 1; rr < 8; ++rr) {
                             const float x = v[8 * h + rr];
                             const int u = (rr & 3) + 8 * (rr >> 2) + 4 * fq;
-                            if (x > m) { m = x; am = u; }
+                            am = x > m ? u : am;
+                            m = max_nan(m, x);                            // a NaN unit makes the pooled value NaN, like torch.max
                         }
                         // partner lane^32 through v_permlane32_swap (VALU; a ds_bpermute costs an LDS round trip):
                         // swap(x, x) = {[x.low | x.low], [x.high | x.high]} -> the other half's value is r[1 - fq]
@@ -324,7 +325,8 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
                         const auto sa = __builtin_amdgcn_permlane32_swap((unsigned)am, (unsigned)am, false, false);
                         const float pm = __uint_as_float(fq ? sm[0] : sm[1]);
                         const int pam = (int)(fq ? sa[0] : sa[1]);
-                        if (pm > m || (pm == m && pam < am)) { m = pm; am = pam; }
+                        if (pm > m || (pm == m && pam < am)) am = pam;
+                        m = max_nan(m, pm);
                         if (fq == h) {
                             const long long n = (lr >> 4) + h;
                             float* xo = xcat + n * 896;

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
                 const int row = m_blk + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                 if (row >= p.M) continue;
                 float v = acc[i][j][r] + bv;
-                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.relu) v = relu_nan(v);
                 if (p.aux != nullptr && !(p.aux[(size_t)row * p.ldaux + col] > 0.f)) v = 0.f;
                 if (p.slab != nullptr) {
                     p.slab[((size_t)blockIdx.z * p.M + row) * p.N + col] = acc[i][j][r];
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[i][j][r] + bv;
-                    if constexpr (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+                    if constexpr (EPI == EPI_RELU) v = relu_nan(v);
                     if constexpr (EPI == EPI_MASK) v = mk[r] > 0.f ? v : 0.f;
                     if constexpr (EPI == EPI_ACC) v += mk[r];
                     float* cr = c + (size_t)((r & 3) + 8 * (r >> 2)) * p.ldc;

@@ -219,7 +219,7 @@ static __device__ __forceinline__ void store_tile(const X3Args& p, f32x16 (&acc)
             continue;
         }
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (p.relu) { v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w); }      // NaN-propagating (common.h)
         if (p.aux != nullptr) {
             const float4 m = *reinterpret_cast<const float4*>(p.aux + (size_t)row * p.ldaux + col);
             v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;

@@ -261,7 +261,7 @@ int dc_policy_backward(const dc_dims* dims, const float* params, const int64_t* 
  *   buffer; seg_gate -1 = always has a gradient, 0..4 = only when head k acted, 5 = only if vf_coef>0;
  *   m, v: Adam moments (flat); segsq f64[n_seg * (1 + ceil(max_seg_len / 4096))] (scratch: per-segment totals, then the
  *   per-chunk partial sums), ctl f32[4] (ZERO before the first call; [2] is an arrival counter the call leaves at zero),
- *   seg_step i32[n_seg] (persistent step counters), status i32[1] (0 ok, 1 NaN loss, 2 NaN grad norm: nothing updated; STICKY - while it is non-zero every
+ *   seg_step i32[n_seg] (persistent step counters), status i32[1] (0 ok, 1 NaN loss, 2 NaN or infinite grad norm: nothing updated; STICKY - while it is non-zero every
  *   later call skips its update too, the caller clears it after handling the error) - all device;
  *   norms_out f32[2] = unclipped, clipped mean gradient norm. */
 int dc_gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const int32_t* seg_gate, int n_seg,
