@@ -639,16 +639,37 @@ class Engine:
         self._graphs.clear()
         return True
 
-    def recover_from_nan(self):
+    def recover_from_nan(self, fault_on_any_rank=None):
         """What the consumer loop tries ONCE when an iteration turned NaN (no parameter was touched: the status word is sticky) before
         raising like the reference: a recorded team-kernel timeout -> the launch-per-step recurrent kernels; otherwise f16x2 products
-        -> the bf16x3 products.  Returns a line for the log, or '' when there is nothing left to try."""
+        -> the bf16x3 products.  Returns a line for the log, or '' when there is nothing left to try.
+
+        fault_on_any_rank (data parallel): whether ANY rank recorded a team-kernel timeout - every rank then takes the same branch (the
+        fault record is rank-local; ranks on different kernels / products would still be correct, but not reproducible)."""
         what = describe_fault(self)
+        if fault_on_any_rank and self.fault() is None:
+            flag = DC_DIMS_RNN_STEP_BF16 if (self.kernel_flags & DC_DIMS_BF16) and self.hidden == 512 else DC_DIMS_RNN_PER_STEP
+            if not (self.kernel_flags & flag):
+                self.kernel_flags |= flag
+                self.status.zero_()
+                self._ws_holds = None
+                self._graphs.clear()
+                return 'launch-per-step recurrent kernels from here on (a team kernel timed out on another rank)'
         if self.use_safe_recurrent():
             return 'launch-per-step recurrent kernels from here on (' + what.lstrip('; ') + ')'
         if self.use_safe_products():
-            return 'bf16x3 products (f32 exponent range) from here on - an operand may have left f16\'s range'
+            return 'bf16x3 products (f32 exponent range) - an operand may have left f16\'s range'
         return ''
+
+    def use_fast_products(self):
+        """Back to the default two-f16-piece products (the consumer loop probes them again some iterations after a fallback: one
+        out-of-range batch should not cost the fast path for the rest of the run).  Returns False if they were on already."""
+        if self.products == 'f16x2':
+            return False
+        self.products = 'f16x2'
+        self._ws_holds = None
+        self._graphs.clear()
+        return True
 
     def _workspace(self, d):
         n = len(WS_FIXED) + len(WS_LAYER) * self.layers

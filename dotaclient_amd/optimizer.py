@@ -180,6 +180,10 @@ class DotaOptimizer:
         self._ready = None
         self._hist_host = None
         self.pipeline_rollout_pass = True
+        # f16x2 -> bf16x3 fallback (Engine.recover_from_nan) is held for `_safe_hold` iterations, then the fast products are probed again;
+        # every further fallback doubles the hold (one rare-head batch must not cost the fast path for the rest of the run,
+        # data that overflows every time must not run every iteration twice)
+        self._safe_hold, self._safe_left, self._auto_safe = 8, 0, False
         self.prefetch_past_gpu_done = False        # tests: keep draining the queue after the epochs have finished (deterministic batches)
 
         # An explicitly given pretrained model is loaded (optimizer.py:264-267) and, when checkpointing, the version counter carries on
@@ -286,7 +290,12 @@ class DotaOptimizer:
     # ---- the optimizer step ----------------------------------------------------------------------------
     def train(self, experiences):
         """optimizer.py:581-689: one epoch on the full batch; returns (losses, entropies, grad_norms) as
-        dicts of 0-d tensors with the reference's keys (optimizer.py:682-689)."""
+        dicts of 0-d tensors with the reference's keys (optimizer.py:682-689).
+
+        NaN: like the reference a ValueError, parameters untouched.  Before raising, the epoch is repeated ONCE on the safe kernels /
+        products (Engine.recover_from_nan).  That repeat can only help when the experiences themselves are sound: if the overflow or
+        timeout happened in `experiences_from_rollout`, their old log-probs / values / advantages are NaN already and the caller has to
+        recompute them (run() / run_iteration do: they repeat the rollout pass as well)."""
         chunks = self._gather(experiences)
         out, status = self.engine.train_epoch(chunks, self.learning_rate, self.entropy_coef, self.vf_coef,
                                               e_clip=self.e_clip, grad_hook=self.grad_hook)
@@ -380,6 +389,12 @@ class DotaOptimizer:
         the next batch's staging (`prefetch`).  NaN guards (optimizer.py:667-669,678-679): the optimizer step of a NaN epoch is skipped
         on the device, so raising after the last epoch leaves the same parameters behind as raising in the middle."""
         start_xp = time.time()
+        if self._auto_safe and self.engine.products == 'bf16x3':
+            self._safe_left -= 1
+            if self._safe_left <= 0:        # (a rollout pass already pipelined on bf16x3 is as good: both forms are f32-grade)
+                self.engine.use_fast_products()
+                self._auto_safe = False
+                logger.info('iteration %d: probing the f16x2 products again', it)
         if self._ready is not None:                                         # rollout pass already enqueued during the last iteration
             acc, experiences, chunks = self._ready
             self._ready = None
@@ -430,7 +445,21 @@ class DotaOptimizer:
                 self._ready = self._finish_batch()
         hist_done.synchronize()                                             # the one synchronisation of the iteration
         host = host.clone()
-        how = self.engine.recover_from_nan() if int(host[:, 11].max().item()) != 0 else ''
+        how = ''
+        if int(host[:, 11].max().item()) != 0:
+            # data parallel: the all-reduced gradient of a NaN rank is NaN on every rank, so every rank is here; what they do next is
+            # agreed on (the team kernels' fault record is rank-local)
+            any_fault = None
+            if self.grad_hook is not None and getattr(self.grad_hook, 'world', 1) > 1:
+                flag = torch.tensor([1.0 if self.engine.fault() is not None else 0.0], device=self.device)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=self.grad_hook.group)
+                any_fault = bool(flag.item() > 0)
+            was_fast = self.engine.products == 'f16x2'
+            how = self.engine.recover_from_nan(any_fault)
+            if how and was_fast and self.engine.products == 'bf16x3':
+                self._auto_safe, self._safe_left = True, self._safe_hold
+                self._safe_hold = min(2 * self._safe_hold, 1024)
+                how += ' for the next %d iterations' % self._safe_left
         if how:
             # The NaN may be the kernels' doing: a team kernel that timed out (DC_WS_FAULT), or an operand outside the exponent range of
             # the two-f16-piece products (Engine.products).  Nothing was updated (the status word is sticky on the device): switch to the
@@ -512,8 +541,9 @@ class DotaOptimizer:
         if self._snapshot is None:
             self._snapshot = self.engine.start_param_snapshot()
         buf = io.BytesIO()
-        # serialised at once, so views of the page-locked snapshot buffer do (no 34 clones); the buffer is reused two publishes later
-        torch.save(self.engine.snapshot_state_dict(self._snapshot, clone=False), buf)
+        # 34 tensors that own their storage, like the reference's state_dict (a blob of 34 views would serialise ONE shared 3 MB storage:
+        # loads fine with strict=True, but in-place edits / per-tensor slicing of the file would behave differently - ADVICE r4)
+        torch.save(self.engine.snapshot_state_dict(self._snapshot, clone=True), buf)
         self._snapshot = None
         blob = buf.getvalue()
         if self.checkpoint:

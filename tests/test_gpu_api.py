@@ -262,6 +262,9 @@ def test_model_publish_is_the_reference_wire_format(tmp_path):
     for k, v in sd.items():
         assert v.dtype == torch.float32 and v.device.type == 'cpu' and torch.equal(v, want[k]), k
     RO.make_policy(sd).load_state_dict(sd, strict=True)      # what an actor does with it
+    # 34 independent storages like the reference's blob (views of one flat buffer would serialise one shared storage)
+    ptrs = {v.untyped_storage().data_ptr() for v in sd.values()}
+    assert len(ptrs) == len(sd) and all(v.untyped_storage().nbytes() == v.numel() * 4 for v in sd.values())
     # a later optimizer step must not leak into a snapshot that was already taken (double buffering)
     i = opt.engine.start_param_snapshot()
     before = {k: v.clone() for k, v in opt.engine.snapshot_state_dict(i).items()}
@@ -384,6 +387,55 @@ def test_consumer_loop_falls_back_to_the_bf16_pieces_when_an_operand_leaves_the_
     assert torch.allclose(opt.engine.params, ref.engine.params, rtol=0, atol=1e-7)
     m2 = opt.run_iteration(2)                       # and the loop carries on
     assert np.isfinite(float(m2['loss/sum']))
+
+
+def test_nan_recovery_with_a_pipelined_rollout_pass_loses_and_duplicates_nothing(tmp_path):
+    # the riskiest host logic - sticky status + the NEXT batch's rollout pass already enqueued (pipeline_rollout_pass) + the
+    # repeat of the poisoned iteration.  A stream whose first batch holds an out-of-range observation, consumed by the pipelined loop and
+    # by a plain serial loop that was on the safe products from the start: same batches (every rollout exactly once, in order), same
+    # metrics, same parameters; the fallback is held for a few iterations, then the fast products are probed again and stay.
+    g, _ = util.load_case('ragged_s16')
+    lens = [40, 64, 21, 33, 50, 16, 64, 48, 17, 80, 30, 64, 25, 70, 41, 64, 18, 52, 33, 47, 64, 29, 55, 38, 61, 20, 44, 36, 58, 27]
+    stream = synth.make_rollouts(35, lens)
+    stream[1]['observations']['env'][5, 1] = 3.0e6
+    n_it = 4
+
+    def run(pipelined):
+        opt = make_opt([dict(r) for r in stream], g, tmp_path, prefetch=pipelined)
+        opt.min_seq_per_epoch = 9
+        opt.pipeline_rollout_pass = pipelined
+        opt.prefetch_past_gpu_done = True                   # deterministic batches: keep draining the queue
+        opt._safe_hold = 2                                  # probe the fast products again after two iterations
+        if not pipelined:
+            opt.engine.products = 'bf16x3'
+        seen, ms, prods, snaps = [], [], [], []
+        orig = opt._experiences_from_batch
+        opt._experiences_from_batch = lambda rollouts, batch: (seen.append([r['game_id'] for r in rollouts]), orig(rollouts, batch))[1]
+        for it in range(1, n_it + 1):
+            ms.append(opt.run_iteration(it))
+            prods.append(opt.engine.products)
+            snaps.append(opt.engine.params.clone())
+        return opt, seen, ms, prods, snaps
+
+    a, seen_a, ms_a, prods_a, snaps_a = run(True)
+    b, seen_b, ms_b, prods_b, snaps_b = run(False)
+    # iteration 1 was repeated on bf16x3 (its batch appears twice in a row among the rollout passes), then two held iterations, then f16x2 again
+    assert prods_a == ['bf16x3', 'bf16x3', 'f16x2', 'f16x2'] and a._safe_hold == 4, (prods_a, a._safe_hold)
+    assert ms_a[0]['xp_rollout_pass_pipelined'] == 0 and any(m['xp_rollout_pass_pipelined'] == 1 for m in ms_a[1:])
+    dedup = [x for i, x in enumerate(seen_a) if i == 0 or x != seen_a[i - 1]]
+    assert len(dedup) < len(seen_a), 'the poisoned iteration was not repeated'
+    flat = [gid for batch in dedup[:n_it] for gid in batch]
+    assert flat == [r['game_id'] for r in stream[:len(flat)]], 'a rollout was lost, duplicated or reordered'
+    assert dedup[:n_it] == seen_b[:n_it]
+    for it, (ma, mb) in enumerate(zip(ms_a, ms_b)):
+        # iterations 1-2: the same arithmetic (bf16x3) in both loops -> tight; 3-4: f16x2 against bf16x3, both f32-grade, but Adam turns
+        # rounding noise on near-zero gradients into +-lr steps, so only the metrics are compared there
+        tol = 2e-5 if it < 2 else 2e-3
+        for k in ('loss/sum', 'loss/policy', 'loss/value', 'entropy', 'grad_norm/unclipped', 'avg_rollout_len'):
+            assert abs(float(ma[k]) - float(mb[k])) <= tol * max(1.0, abs(float(mb[k]))), (it, k, float(ma[k]), float(mb[k]))
+    for it in range(2):
+        assert torch.allclose(snaps_a[it], snaps_b[it], rtol=0, atol=2e-6), it
+    assert int(a.engine.status.item()) == 0 and torch.isfinite(a.engine.params).all()
 
 
 def test_consumer_loop_leaves_the_team_kernels_after_a_recorded_timeout(tmp_path):
