@@ -123,7 +123,8 @@ int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const fl
                     const uint8_t* unit_mask = nullptr);   // unit_mask (f16 variant only): emb rows of masked-out units of the 16-unit types are not stored
 // inputs of the sparse max-pool backward of the two 16-unit types (embed_sparse.hip); db2 [6][128] is accumulated into
 // (prep: 2 * nr * 736 floats of scratch - it lives in the d(emb) rows of the two types, which the sparse path never writes)
-struct EmbSparseIn { const float* dxcat; const uint8_t* amax; const float* dtu; const float* q; int ldq; float* db2; float* prep; int eight_waves = 0; };
+struct EmbSparseIn { const float* dxcat; const uint8_t* amax; const float* dtu; const float* q; int ldq; float* db2; float* prep;
+                     int eight_waves = 0; int valu = 0; };      // valu: keep embed_sparse.hip's kernels in f16x2 mode too (DC_DIMS_POOL16_VALU)
 int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const float* b1, const float* W2, float* dW2,
                     float* dW1, float* db1, float* scratch, long long scratch_floats, long long nr_valid, long long nr_padded,
                     const EmbSparseIn* sp, hipStream_t s, F16x2Scales f16 = F16x2Scales());
@@ -131,6 +132,10 @@ int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const 
 int embed_bwd_pool16(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq,
                      const float* W1, const float* b1, const float* W2, float* slab, float* part1, float* part2, float* prep,
                      long long nr, int wg_per_type, hipStream_t s, int eight_waves = 0);   // eight_waves: round 2's 512-thread kernel (DC_DIMS_POOL16_8W)
+// embed_pool16m.hip: the same gradient as dense f16x2 products with on-chip operands (same partial formats; needs F16x2Scales.on)
+int embed_bwd_pool16m(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq,
+                      const float* W1, const float* b1, const float* W2, float* slab, float* part1, float* part2,
+                      long long nr, int wg_per_type, hipStream_t s, const F16x2Scales& f16);
 // heads.hip
 int attn_logits(const float* headout, const float* emb, float* tu, long long nr, long long nrp, hipStream_t s);
 // target-unit logits of the units whose mask byte (mask[n][22 + u]) is set; 0 elsewhere

@@ -411,7 +411,8 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         // the prepared staging blocks of the sparse path live in the d(emb) rows of the two 16-unit types (2 * 16 * 128 floats per
         // step, never written on that path; the prepared blocks take 2 * 736)
         const EmbSparseIn sp{w.f(DC_WS_DXCAT), amaxp, w.f(DC_WS_DTU), w.f(DC_WS_HEADOUT), HO_LD, Gd.p(DC_P_UNIT_B),
-                             w.f(DC_WS_DEMB) + (size_t)NRp * T_CUM[2] * EMBW, (d->flags & DC_DIMS_POOL16_8W) ? 1 : 0};
+                             w.f(DC_WS_DEMB) + (size_t)NRp * T_CUM[2] * EMBW, (d->flags & DC_DIMS_POOL16_8W) ? 1 : 0,
+                             (d->flags & DC_DIMS_POOL16_VALU) ? 1 : 0};
         F16x2Scales fs;
         fs.on = (d->flags & DC_DIMS_F16X2) && !(d->flags & DC_DIMS_GEMM_FASTTILE);
         fs.s_act = F16X2_S_ACT; fs.s_w = F16X2_S_W; fs.s_grad = s_grad;

@@ -164,6 +164,11 @@ typedef struct dc_dims {
  *                            wave, 256 registers, two waves per SIMD) instead of the sixteen-wave one (a step stream per group of eight
  *                            waves, dW2 update split over k, pair-wise dW1 fold: 128 registers, four waves per SIMD; ~5 % faster). */
 #define DC_DIMS_POOL16_8W 262144
+/*   DC_DIMS_POOL16_VALU    : with DC_DIMS_F16X2 the max-pool backward of the 16-unit types runs as DENSE products on the f16 matrix cores with
+ *                            every operand generated on chip (csrc/embed_pool16m.hip, round 5: no prepare pass, no gathers, no barrier per
+ *                            step); this flag keeps the sparse VALU kernels of csrc/embed_sparse.hip (what the bf16x3 products always use:
+ *                            f32's exponent range). */
+#define DC_DIMS_POOL16_VALU 2097152
 /*   DC_DIMS_TEAM8          : H = 256 recurrent core in teams of EIGHT workgroups, two workgroups per CU (csrc/rnn_team8.hip): a member
  *                            holds the gate columns of 32 hidden units (128 AGPRs), the second workgroup on the CU works while the first
  *                            waits for its peers.  The library takes these kernels by itself for 65 .. 128 sequences (one workgroup per

@@ -293,17 +293,19 @@ def test_rnn_team_kernels_agree_with_per_step(cell, S, lens):
             assert util.scaled_err(a, b) < 2e-5, (key, util.scaled_err(a, b))
 
 
-@pytest.mark.parametrize('lens', [[128] * 4, [256] * 6, [384, 128, 256]])
+@pytest.mark.parametrize('lens', [[128] * 4, [256] * 6, [384, 128, 256], [128] * 3])
 def test_sparse_pool_backward_matches_dense(lens):
-    # fused embedding path (rows % 128 == 0): the sparse max-pool backward of the two 16-unit types
-    # (embed_sparse.hip) against the dense MFMA kernels on the same batch - gradients and post-step parameters
+    # fused embedding path (rows % 128 == 0): the max-pool backward of the two 16-unit types - default (f16x2 products): dense products on
+    # the f16 matrix cores with on-chip operands (embed_pool16m.hip); DC_DIMS_POOL16_VALU / _8W: the sparse VALU kernels (embed_sparse.hip) -
+    # against the dense MFMA kernels that read d(emb) from HBM, on the same batch: gradients and post-step parameters.  [128] * 3: 384 steps
+    # over 128 workgroups = an odd number of steps per workgroup (the matrix-core kernel works on PAIRS of steps)
     from dotaclient_amd import engine as E
     from dotaclient_amd.engine import Engine, pack_rollouts
     dev = torch.device('cuda:0')
     outs = {}
-    for mode in ('0', '1', '8w'):       # dense kernels / sparse, sixteen-wave kernel (default) / sparse, round 2's eight-wave kernel (DC_DIMS_POOL16_8W)
+    for mode in ('0', '1', '16w', '8w'):   # dense kernels / on-chip dense (default) / sparse sixteen-wave kernel / sparse eight-wave kernel
         eng = Engine('lstm', 128, 1, dev)
-        eng.kernel_flags = {'0': E.DC_DIMS_DENSE_POOL_BWD, '1': 0, '8w': E.DC_DIMS_POOL16_8W}[mode]
+        eng.kernel_flags = {'0': E.DC_DIMS_DENSE_POOL_BWD, '1': 0, '16w': E.DC_DIMS_POOL16_VALU, '8w': E.DC_DIMS_POOL16_8W}[mode]
         eng.load_state_dict(synth.init_state_dict(7, 'lstm', 128, 1))
         rollouts = synth.make_rollouts(91, lens)
         batch = pack_rollouts(rollouts, 128, dev)
@@ -320,9 +322,11 @@ def test_sparse_pool_backward_matches_dense(lens):
         assert util.scaled_err(a, b) < 2e-5, (n, util.scaled_err(a, b))
     assert util.scaled_err(outs['1'][1][:11], outs['0'][1][:11]) < 2e-5
     assert util.scaled_err(outs['1'][2], outs['0'][2]) < 2e-5
-    for n in outs['0'][0]:              # the two sparse kernels: the same sums in another order
+    for n in outs['0'][0]:              # the sparse kernels: the same sums in another order / on another pipe
         assert util.scaled_err(outs['8w'][0][n], outs['1'][0][n]) < 2e-5, n
-    assert util.scaled_err(outs['8w'][2], outs['1'][2]) < 2e-5
+        assert util.scaled_err(outs['16w'][0][n], outs['0'][0][n]) < 2e-5, n
+    assert util.scaled_err(outs['8w'][2], outs['1'][2]) < 2e-5 and util.scaled_err(outs['16w'][2], outs['0'][2]) < 2e-5
+    assert not np.array_equal(outs['16w'][0]['affine_unit_anh.weight'], outs['1'][0]['affine_unit_anh.weight'])   # really another kernel
 
 
 @pytest.mark.parametrize('cell,hidden,B', [('lstm', 128, 96), ('gru', 256, 96), ('lstm', 256, 200)])
@@ -494,17 +498,18 @@ def test_sparse_pool_backward_with_one_unit_taking_every_channel():
             x[(ri + 2) % 4::8, 1::2] = x[(ri + 2) % 4::8, 1:2]        # and some steps with eight copies of unit 1 among the others
             data['observations'][key] = x
     outs = {}
-    for mode in ('dense', 'sparse'):
+    for mode in ('dense', 'sparse', 'valu'):
         eng = Engine('lstm', 128, 1, dev)
-        eng.kernel_flags = E.DC_DIMS_DENSE_POOL_BWD if mode == 'dense' else 0
+        eng.kernel_flags = {'dense': E.DC_DIMS_DENSE_POOL_BWD, 'sparse': 0, 'valu': E.DC_DIMS_POOL16_VALU}[mode]
         eng.load_state_dict(synth.init_state_dict(7, 'lstm', 128, 1))
         batch = pack_rollouts(rollouts, 128, dev)
         chunks = eng.rollout_pass(batch, 128)
         res, status = eng.train_epoch(chunks, 5e-5, 5e-4, 0.5)
         assert int(status.item()) == 0
         outs[mode] = (eng.grads.cpu().numpy().copy(), res.cpu().numpy().copy())
-    assert util.scaled_err(outs['sparse'][0], outs['dense'][0]) < 2e-5
-    assert util.scaled_err(outs['sparse'][1][:11], outs['dense'][1][:11]) < 2e-5
+    for mode in ('sparse', 'valu'):
+        assert util.scaled_err(outs[mode][0], outs['dense'][0]) < 2e-5, mode
+        assert util.scaled_err(outs[mode][1][:11], outs['dense'][1][:11]) < 2e-5, mode
 
 
 # ---- the two forms of f32-grade products: 'f16x2' (Engine default: two f16 pieces, three MFMAs, DC_DIMS_F16X2) is what every test above
