@@ -40,7 +40,8 @@ enum : int {   // LDS (bytes)
     PM_RED_ACC = 0,                  // at the end, over it: stream 1's dW2^T tiles [kq 4][64 registers][64 lanes] f32
     PM_RED_F = 65536,                // ... its fold tiles [kq 4][16][64] f32
     PM_RED_B = PM_RED_F + 16384,     // ... its bias-gradient sums [4][64] f32
-    PM_LDS = PM_RED_B + 1024
+    PM_STG = 65536,                  // in the loop: every wave's own staging block, 2 buffers x 2 items x 2.5 KB (8 waves x 10 KB; the end-of-kernel
+    PM_LDS = PM_STG + 8 * 10240      // areas above lie over it and the W2 image)
 };
 
 struct PoolMArgs {
@@ -49,6 +50,7 @@ struct PoolMArgs {
     float* slab; float* part1; float* part2;
     long long nr; int wg_per_type; int steps_per_wg;
     float s_act, s_w, s_grad;
+    const float* R;           // [2][nr][128]: R = q W2_t of every step and type (a dense product, launched ahead of the kernel)
 };
 
 __device__ __forceinline__ int sigma_unit(int fq, int j) { return 4 * fq + (j & 3) + 8 * (j >> 2); }
@@ -112,44 +114,90 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
     f32x16 facc;                                             // dW1^T[f = row][k = 32 kq + col] x s_act s_grad; row 12: db1
 #pragma unroll
     for (int r = 0; r < 16; ++r) { facc[r] = 0.f; acc[0][r] = 0.f; acc[1][r] = 0.f; acc[2][r] = 0.f; acc[3][r] = 0.f; }
-    float db2a[4] = {0.f, 0.f, 0.f, 0.f};                    // kq == 0: sum over steps of demb's column sums, channel 32 cb + fr
     __syncthreads();                                         // the W2 image
 
+    // ---- per pair: raw inputs global -> registers (a pair ahead) -> this wave's own LDS block -> operand builds --------------------------
+    // Every wave stages what IT needs (the four waves of a stream read the same lines: L1 / L2 serve three of them); the loads of pair i + 1
+    // are in flight while pair i computes, so no operand build ever waits for HBM, and no wave ever waits for another.  What costs VALU
+    // time in the builds is done ONCE, here: d(xcat) is scaled and split into its two f16 pieces when it is staged (one dword per channel:
+    // h | m << 16), so an operand element is a SELECT of a staged dword by "arg-max unit == my unit" - no arithmetic per element.  The
+    // attention term dtu[u] q[c] would make the operands dense; it is rank one, so it stays out of them:
+    //     d(basic)[u][k] += dtu[u] R[k], R = q W2 (a dense product over all steps, like embed_sparse.hip's), added to the accumulators in f32
+    //     dW2^T[k][c]   += s[k] q[c],   s[k] = sum_u dtu[u] basic[u][k]: one K slot of three more MFMAs per column block, live steps only
+    // Block of an item (dwords): d(xcat) pieces [128] | R [128] | q [128] | arg-max bytes [128 B] | unit records [16][12] | dtu [16] | live
+    enum { ST_D = 0, ST_R = 128, ST_Q = 256, ST_A = 384, ST_X = 416, ST_DTU = 608, ST_LIVE = 624, ST_ITEM = 640 };
+    float* const stg = reinterpret_cast<float*>(smem + PM_STG) + (size_t)W * (2 * 2 * ST_ITEM);
     const long long n_pairs = (n1 - n0 + 1) / 2;
     const int e_row = fr >> 4, u_row = fr & 15;              // as a ROW of the pair's tile this lane is unit u_row of item e_row
-    float sink = 0.f, pf = 0.f;
-    for (long long pi = st; pi < n_pairs; pi += 2) {
-        const long long nA = n0 + 2 * pi, nB = nA + 1;
-        const bool validB = nB < n1;                         // wave-uniform
-        const long long itB = validB ? nB : nA;
-        const long long n_of[2] = {nA, itB};
-        const long long n_row = e_row ? itB : nA;
-        const bool row_valid = e_row == 0 || validB;
-
-        // pull the NEXT pair's lines towards the caches: one load instruction, a different 128-byte line per lane
-        {
-            const long long nn = min(n0 + 2 * (pi + 2) + (lane >= 32 ? 1 : 0), n1 - 1);
-            const int l5 = lane & 31;
-            const float* a = l5 < 4 ? p.dxcat + nn * PM_XCAT + slot0 * 128 + 32 * l5
-                           : l5 < 8 ? p.dxcat + nn * PM_XCAT + 6 * 128 + 32 * (l5 - 4)
-                           : l5 < 12 ? p.q + nn * p.ldq + 32 * (l5 - 8)
-                           : l5 < 19 ? p.obs + nn * PM_OBS + 3 + cum * 12 + 32 * (l5 - 12) - (l5 == 18 ? 5 : 0)
-                           : l5 == 19 ? p.dtu + nn * 40 + cum
-                           : reinterpret_cast<const float*>(p.amax + (nn * 3 + (t - 1)) * 128);
-            sink += pf;                                       // last iteration's: waited for a whole pair later
-            pf = l5 < 21 ? *a : 0.f;
+    const float* Rt = p.R + (size_t)(t - 2) * p.nr * 128;
+    float db2a[2] = {0.f, 0.f};                              // kq == 0: sum over steps of demb's column sums, channels 2 lane, 2 lane + 1
+    struct Raw { float2 d, d2, q, r; float x0, x1, x2, dt; unsigned a; };
+    auto load_raw = [&](long long pi, int e) {
+        Raw r;
+        long long n = n0 + 2 * pi + e;
+        const bool valid = n < n1;                           // wave-uniform; an absent item (odd range) contributes zeros
+        n = valid ? n : n1 - 1;
+        const float* dx = p.dxcat + n * PM_XCAT + slot0 * 128 + 2 * lane;
+        r.d = *reinterpret_cast<const float2*>(dx);
+        r.d2 = t == 3 ? *reinterpret_cast<const float2*>(dx + 2 * 128) : make_float2(0.f, 0.f);
+        r.q = *reinterpret_cast<const float2*>(p.q + n * p.ldq + 2 * lane);
+        r.r = *reinterpret_cast<const float2*>(Rt + n * 128 + 2 * lane);
+        const float* xr = p.obs + n * PM_OBS + 3 + cum * 12 + lane;
+        r.x0 = xr[0]; r.x1 = xr[64]; r.x2 = xr[128];
+        r.dt = lane < 16 ? p.dtu[n * 40 + cum + lane] : 0.f;
+        r.a = lane < 32 ? reinterpret_cast<const unsigned*>(p.amax + (n * 3 + (t - 1)) * 128)[lane] : 0u;
+        if (!valid) { r.d = make_float2(0.f, 0.f); r.d2 = r.d; r.dt = 0.f; }
+        return r;
+    };
+    auto store_raw = [&](const Raw& r, int buf, int e) {
+        float* b = stg + (buf * 2 + e) * ST_ITEM;
+        const float d0 = r.d.x + r.d2.x, d1 = r.d.y + r.d2.y;              // policy.py:127: enh feeds two slots
+        {   // the two f16 pieces of d x s_grad, one dword per channel
+            const float x0 = d0 * s_grad, x1 = d1 * s_grad;
+            const unsigned hh = cvt_pk_f16(x0, x1);
+            const f16x2_t hv = __builtin_bit_cast(f16x2_t, hh);
+            const unsigned mm = cvt_pk_f16(x0 - (float)hv.x, x1 - (float)hv.y);
+            *reinterpret_cast<uint2*>(b + ST_D + 2 * lane) = make_uint2((hh & 0xffffu) | (mm << 16), (hh >> 16) | (mm & 0xffff0000u));
         }
+        *reinterpret_cast<float2*>(b + ST_R + 2 * lane) = r.r;
+        *reinterpret_cast<float2*>(b + ST_Q + 2 * lane) = r.q;
+        b[ST_X + lane] = r.x0; b[ST_X + 64 + lane] = r.x1; b[ST_X + 128 + lane] = r.x2;
+        if (lane < 16) b[ST_DTU + lane] = r.dt;
+        if (lane < 32) reinterpret_cast<unsigned*>(b + ST_A)[lane] = r.a;
+        const unsigned long long nz = __ballot(r.dt != 0.f);               // lanes 0..15 hold the sixteen dtu
+        if (lane == 0) reinterpret_cast<int*>(b)[ST_LIVE] = nz != 0ull;
+        if (kq == 0) {                                                       // wave-uniform: the bias gradient rides on wave (st, 0)
+            float sum = r.dt;                                                // row 0 of the wave = lanes 0..15: their sum in each of them
+            sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x128, 0xf, 0xf, true));
+            sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x124, 0xf, 0xf, true));
+            sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x122, 0xf, 0xf, true));
+            sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x121, 0xf, 0xf, true));
+            const float sumdtu = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sum)));
+            db2a[0] += fmaf(r.q.x, sumdtu, d0);
+            db2a[1] += fmaf(r.q.y, sumdtu, d1);
+        }
+    };
+    if (st < n_pairs) {
+        const Raw r0 = load_raw(st, 0), r1 = load_raw(st, 1);
+        store_raw(r0, 0, 0); store_raw(r1, 0, 1);
+    }
+    const float rs = s_grad * p.s_w;                         // scale of the d(basic) accumulators
+    int buf = 0;
+    for (long long pi = st; pi < n_pairs; pi += 2, buf ^= 1) {
+        const bool more = pi + 2 < n_pairs;                  // wave-uniform
+        Raw nx0, nx1;
+        if (more) { nx0 = load_raw(pi + 2, 0); nx1 = load_raw(pi + 2, 1); }
+        __builtin_amdgcn_wave_barrier();
+        const float* it0 = stg + (buf * 2) * ST_ITEM;        // item e of the pair: it0 + e * ST_ITEM
+        const float* itr = it0 + e_row * ST_ITEM;            // the item this lane's ROW belongs to
 
         // ---- first layer: basic x s_act of the pair's 32 rows, this wave's 32 hidden units ----------------------------------------
         f32x16 basic;
         {
-            const float* xp = p.obs + n_row * PM_OBS + 3 + (cum + u_row) * 12 + 8 * fq;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = xp[e];
-#pragma unroll
-            for (int e = 4; e < 8; ++e) v[e] = fq ? 0.f : xp[e];                   // features 12..15 do not exist
-            const Split2h x = split8(v, s_act);
+            const float* xp = itr + ST_X + u_row * 12 + 8 * fq;
+            const float4 x0 = *reinterpret_cast<const float4*>(xp);
+            const float4 x1 = fq ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(xp + 4);   // features 12..15 do not exist
+            const Split2h x = split2h<true>(x0, x1, s_act);
             f32x16 g;
 #pragma unroll
             for (int r = 0; r < 16; ++r) g[r] = 0.f;
@@ -163,42 +211,51 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
         // ---- dW2^T += basic^T demb, item by item (K = the item's 16 units) -------------------------------------------------------------
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const long long n = n_of[e];
-            const bool valid = e == 0 || validB;
+            const float* it = it0 + e * ST_ITEM;
             float bv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) bv[j] = basic[8 * e + j];                  // K slot 8 fq + j <-> unit sigma(fq, j): as they lie
             const Split2h A = split8_noscale(bv);
-            float du[8];                                                           // dtu of the lane group's eight units
-            {
-                const float* dp = p.dtu + n * 40 + cum + 4 * fq;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) du[j] = valid ? dp[(j & 3) + 8 * (j >> 2)] : 0.f;
-            }
-            float sumdtu = 0.f;
-            if (kq == 0) {                                                         // wave-uniform: the bias gradient rides on wave (st, 0)
-                const float v = p.dtu[n * 40 + cum + (lane & 15)];
-                float sum = v;
-                sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x128, 0xf, 0xf, true));
-                sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x124, 0xf, 0xf, true));
-                sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x122, 0xf, 0xf, true));
-                sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x121, 0xf, 0xf, true));
-                sumdtu = valid ? sum : 0.f;
-            }
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
                 const int c = 32 * cb + fr;
-                const float* dx = p.dxcat + n * PM_XCAT + c;
-                float d = dx[slot0 * 128];
-                if (t == 3) d += dx[6 * 128];
-                d = valid ? d : 0.f;
-                const float qc = p.q[n * p.ldq + c];
-                const int a = p.amax[(n * 3 + (t - 1)) * 128 + c];
-                float v[8];
+                const unsigned d2 = reinterpret_cast<const unsigned*>(it + ST_D)[c];
+                const int a = reinterpret_cast<const uint8_t*>(it + ST_A)[c];
+                // one-hot over the lane group's eight K slots: unit a sits in group (a >> 2) & 1 at slot jj = (a & 3) + 4 (a >> 3)
+                const int jj = (a & 3) + 4 * (a >> 3);
+                const int rsel = (((a >> 2) & 1) == fq) ? (jj >> 1) : -1;
+                const unsigned hv = (jj & 1) ? (d2 << 16) : (d2 & 0xffffu), mv = (jj & 1) ? (d2 & 0xffff0000u) : (d2 >> 16);
+                u32x4 bh, bm;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaf(du[j], qc, a == sigma_unit(fq, j) ? d : 0.f);
-                acc[cb] = mma3(A, split8(v, s_grad), acc[cb]);
-                if (kq == 0) db2a[cb] += fmaf(qc, sumdtu, d);
+                for (int r = 0; r < 4; ++r) { bh[r] = rsel == r ? hv : 0u; bm[r] = rsel == r ? mv : 0u; }
+                Split2h B;
+                B.h = __builtin_bit_cast(f16x8, bh);
+                B.m = __builtin_bit_cast(f16x8, bm);
+                acc[cb] = mma3(A, B, acc[cb]);
+            }
+            if (reinterpret_cast<const int*>(it)[ST_LIVE] != 0) {                  // wave-uniform: the rank-one attention term of a live step
+                const float4 du0 = *reinterpret_cast<const float4*>(it + ST_DTU + 4 * fq), du1 = *reinterpret_cast<const float4*>(it + ST_DTU + 8 + 4 * fq);
+                float sk = du0.x * bv[0];                                          // s[k] x s_act over the lane group's eight units ...
+                sk = fmaf(du0.y, bv[1], sk); sk = fmaf(du0.z, bv[2], sk); sk = fmaf(du0.w, bv[3], sk);
+                sk = fmaf(du1.x, bv[4], sk); sk = fmaf(du1.y, bv[5], sk); sk = fmaf(du1.z, bv[6], sk); sk = fmaf(du1.w, bv[7], sk);
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sk), __float_as_uint(sk), false, false);
+                sk = (sk + __uint_as_float(fq ? sw[0] : sw[1])) * s_grad;           // ... plus the other group's (lane ^ 32); dtu is a gradient
+                // K slot 0 (lanes fq == 0, element 0) carries the term: A[k][0] = s[k], B[0][c] = q[c]
+                const unsigned sh = cvt_pk_f16(sk, 0.f);
+                const unsigned sm = cvt_pk_f16(sk - (float)__builtin_bit_cast(f16x2_t, sh).x, 0.f);
+                Split2h A1;
+                A1.h = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : sh, 0u, 0u, 0u});
+                A1.m = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : sm, 0u, 0u, 0u});
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    const float qx = it[ST_Q + 32 * cb + fr];                        // O(1): the gradient pre-scale went into s
+                    const unsigned qh = cvt_pk_f16(qx, 0.f);
+                    const unsigned qm = cvt_pk_f16(qx - (float)__builtin_bit_cast(f16x2_t, qh).x, 0.f);
+                    Split2h B1;
+                    B1.h = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : qh, 0u, 0u, 0u});
+                    B1.m = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : qm, 0u, 0u, 0u});
+                    acc[cb] = mma3(A1, B1, acc[cb]);
+                }
             }
         }
 
@@ -207,48 +264,63 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
         {
-            const float du = row_valid ? p.dtu[n_row * 40 + cum + u_row] : 0.f;
-            const float* dxr = p.dxcat + n_row * PM_XCAT + slot0 * 128 + 8 * fq;
-            const float* qr = p.q + n_row * p.ldq + 8 * fq;
-            const uint8_t* ar = p.amax + (n_row * 3 + (t - 1)) * 128 + 8 * fq;
+            const unsigned* dr = reinterpret_cast<const unsigned*>(itr + ST_D) + 8 * fq;
+            const uint8_t* ar = reinterpret_cast<const uint8_t*>(itr + ST_A) + 8 * fq;
             const char* w2l = smem + PM_W2P + (fq * 128 + 32 * kq + fr) * 16;
 #pragma unroll 2
             for (int ks = 0; ks < 8; ++ks) {
-                const float4 d0 = *reinterpret_cast<const float4*>(dxr + 16 * ks), d1 = *reinterpret_cast<const float4*>(dxr + 16 * ks + 4);
-                float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-                if (t == 3) {
-                    const float4 e0 = *reinterpret_cast<const float4*>(dxr + 16 * ks + 2 * 128), e1 = *reinterpret_cast<const float4*>(dxr + 16 * ks + 2 * 128 + 4);
-                    d[0] += e0.x; d[1] += e0.y; d[2] += e0.z; d[3] += e0.w; d[4] += e1.x; d[5] += e1.y; d[6] += e1.z; d[7] += e1.w;
-                }
-                const float4 q0 = *reinterpret_cast<const float4*>(qr + 16 * ks), q1 = *reinterpret_cast<const float4*>(qr + 16 * ks + 4);
-                const float qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                const uint4 d0 = *reinterpret_cast<const uint4*>(dr + 16 * ks), d1 = *reinterpret_cast<const uint4*>(dr + 16 * ks + 4);
+                const unsigned d2[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
                 const uint2 ab = *reinterpret_cast<const uint2*>(ar + 16 * ks);
-                float v[8];
+                unsigned sel[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int a = (int)(((j < 4 ? ab.x : ab.y) >> (8 * (j & 3))) & 0xffu);
-                    v[j] = row_valid ? fmaf(du, qv[j], a == u_row ? d[j] : 0.f) : 0.f;
+                    sel[j] = a == u_row ? d2[j] : 0u;
                 }
-                Split2h B;
+                u32x4 ah, am;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ah[i] = __builtin_amdgcn_perm(sel[2 * i + 1], sel[2 * i], 0x05040100u);      // the h halves of two channels
+                    am[i] = __builtin_amdgcn_perm(sel[2 * i + 1], sel[2 * i], 0x07060302u);      // the m halves
+                }
+                Split2h Aop, B;
+                Aop.h = __builtin_bit_cast(f16x8, ah);
+                Aop.m = __builtin_bit_cast(f16x8, am);
                 B.h = *reinterpret_cast<const f16x8*>(w2l + ks * 4096);
                 B.m = *reinterpret_cast<const f16x8*>(w2l + 32768 + ks * 4096);
-                cacc = mma3(split8(v, s_grad), B, cacc);
+                cacc = mma3(Aop, B, cacc);
             }
         }
-        // ---- through the relu, then dW1^T / db1 += x^T d(basic): K step e = item e's 16 units ----------------------------------------------
+        // the attention term of d(basic), in f32: + dtu[u] R[k] (zero for a step whose head is off); then through the relu
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float* it = it0 + e * ST_ITEM;
+            const float Rk = it[ST_R + 32 * kq + fr] * rs;
+            const float4 du0 = *reinterpret_cast<const float4*>(it + ST_DTU + 4 * fq), du1 = *reinterpret_cast<const float4*>(it + ST_DTU + 8 + 4 * fq);
+            const float du[8] = {du0.x, du0.y, du0.z, du0.w, du1.x, du1.y, du1.z, du1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cacc[8 * e + j] = fmaf(du[j], Rk, cacc[8 * e + j]);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) cacc[r] = basic[r] > 0.f ? cacc[r] * inv_w : 0.f;      // = relu'(.) d(basic) x s_grad
+        // ---- dW1^T / db1 += x^T d(basic): K step e = item e's 16 units ---------------------------------------------------------------------
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             float bv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) bv[j] = cacc[8 * e + j];
-            const float* xr = p.obs + n_of[e] * PM_OBS + 3 + (cum + 4 * fq) * 12 + fr;     // x[unit 4 fq + ..][feature fr]
+            const float* xr = it0 + e * ST_ITEM + ST_X + (4 * fq) * 12 + min(fr, 11);      // x[unit 4 fq + ..][feature fr]
             float xv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xv[j] = fr < 12 ? xr[((j & 3) + 8 * (j >> 2)) * 12] : (fr == 12 ? 1.f : 0.f);
+            for (int j = 0; j < 8; ++j) {
+                const float xx = xr[((j & 3) + 8 * (j >> 2)) * 12];
+                xv[j] = fr < 12 ? xx : (fr == 12 ? 1.f : 0.f);
+            }
             facc = mma3(split8(xv, s_act), split8_noscale(bv), facc);
         }
+        __builtin_amdgcn_wave_barrier();
+        if (more) { store_raw(nx0, buf ^ 1, 0); store_raw(nx1, buf ^ 1, 1); }
     }
 
     // ---- results: the two streams meet through LDS (stream 1 writes, stream 0 adds and stores) ---------------------------------------------
@@ -263,10 +335,7 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
             for (int r = 0; r < 16; ++r) racc[(16 * cb + r) * 64] = acc[cb][r];
 #pragma unroll
         for (int r = 0; r < 16; ++r) rf[r * 64] = facc[r];
-        if (kq == 0) {
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) rb[cb * 64 + lane] = db2a[cb];
-        }
+        if (kq == 0) { rb[lane] = db2a[0]; rb[64 + lane] = db2a[1]; }
     }
     __syncthreads();
     if (st == 0) {
@@ -289,28 +358,30 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
             const int f = 8 * (r >> 2) + 4 * fq + (r & 3);
             if (f < 13) o1[f * 128 + 32 * kq + fr] = (facc[r] + rf[r * 64]) * inv;
         }
-        if (kq == 0 && fq == 0) {
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) p.part2[(size_t)blockIdx.x * 128 + 32 * cb + fr] = db2a[cb] + rb[cb * 64 + lane];
-        }
+        if (kq == 0)
+            *reinterpret_cast<float2*>(p.part2 + (size_t)blockIdx.x * 128 + 2 * lane) = make_float2(db2a[0] + rb[lane], db2a[1] + rb[64 + lane]);
     }
-    if (sink + pf == 1.2345e-33f && p.nr < 0) p.part2[0] = sink;             // keeps the cache-warming loads alive; never true
 }
 
 // Same outputs as embed_bwd_pool16 (embed_sparse.hip): slab 2 * wg_per_type x [128][128], part1 2 * wg_per_type x [13][128],
 // part2 2 * wg_per_type x [128] - per-workgroup partials in the formats the dense path's reducers take.
 int embed_bwd_pool16m(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq,
-                      const float* W1, const float* b1, const float* W2, float* slab, float* part1, float* part2,
+                      const float* W1, const float* b1, const float* W2, float* slab, float* part1, float* part2, float* scratch_r,
                       long long nr, int wg_per_type, hipStream_t s, const F16x2Scales& f16) {
     PoolMArgs a{obs, dxcat, amax, dtu, q, ldq, W1, b1, W2, slab, part1, part2, nr, wg_per_type,
                 (int)(((nr + wg_per_type - 1) / wg_per_type + 1) / 2 * 2),      // even: a pair never straddles two workgroups
-                f16.s_act, f16.s_w, f16.s_grad};
+                f16.s_act, f16.s_w, f16.s_grad, scratch_r};
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)embed_bwd_pool16m_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PM_LDS);
         if (e != hipSuccess) { set_error("embed_bwd_pool16m: hipFuncSetAttribute", (int)e); return (int)e; }
         attr = true;
     }
+    // R[n][k] = sum_c q[n][c] W2_t[c][k] of every step and type: the attention term of d(basic) is dtu[u] R[k] (2 x 2 GFLOP, f32)
+    for (int t = 2; t < 4; ++t)
+        if (int e = gemm_f32(q, W2 + (size_t)t * 128 * 128, scratch_r + (size_t)(t - 2) * nr * 128, (int)nr, 128, 128, ldq, 128, 128, 0, 1,
+                             nullptr, 0, nullptr, 0, 0, 1, s))
+            return e;
     // algorithmic work = the sparse form's (embed_sparse.hip counts the same): basic + dW1 fold 2 x 16 x 128 x 12 MACs, the two gathers
     // 2 x 128 x 128 MACs per step and type; what EXECUTES is the dense form, 16 x the gathers' MACs, on the matrix cores
     ProfScope prof("embed_bwd_pool16", 2.0 * 2.0 * nr * (2.0 * 16 * 128 * 12 + 2.0 * 128 * 128),

@@ -134,8 +134,8 @@ int embed_bwd_pool16(const float* obs, const float* dxcat, const uint8_t* amax, 
                      long long nr, int wg_per_type, hipStream_t s, int eight_waves = 0);   // eight_waves: round 2's 512-thread kernel (DC_DIMS_POOL16_8W)
 // embed_pool16m.hip: the same gradient as dense f16x2 products with on-chip operands (same partial formats; needs F16x2Scales.on)
 int embed_bwd_pool16m(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq,
-                      const float* W1, const float* b1, const float* W2, float* slab, float* part1, float* part2,
-                      long long nr, int wg_per_type, hipStream_t s, const F16x2Scales& f16);
+                      const float* W1, const float* b1, const float* W2, float* slab, float* part1, float* part2, float* scratch_r,
+                      long long nr, int wg_per_type, hipStream_t s, const F16x2Scales& f16);      // scratch_r: 2 * nr * 128 floats
 // heads.hip
 int attn_logits(const float* headout, const float* emb, float* tu, long long nr, long long nrp, hipStream_t s);
 // target-unit logits of the units whose mask byte (mask[n][22 + u]) is set; 0 elsewhere

@@ -422,8 +422,12 @@ def test_nan_recovery_with_a_pipelined_rollout_pass_loses_and_duplicates_nothing
     # iteration 1 was repeated on bf16x3 (its batch appears twice in a row among the rollout passes), then two held iterations, then f16x2 again
     assert prods_a == ['bf16x3', 'bf16x3', 'f16x2', 'f16x2'] and a._safe_hold == 4, (prods_a, a._safe_hold)
     assert ms_a[0]['xp_rollout_pass_pipelined'] == 0 and any(m['xp_rollout_pass_pipelined'] == 1 for m in ms_a[1:])
-    dedup = [x for i, x in enumerate(seen_a) if i == 0 or x != seen_a[i - 1]]
-    assert len(dedup) < len(seen_a), 'the poisoned iteration was not repeated'
+    # rollout passes in order: batch 1, (batch 2: pipelined behind iteration 1's epochs, then dropped), batch 1 again on bf16x3, batch 2 again, ...
+    dedup = []
+    for x in seen_a:
+        if x not in dedup:
+            dedup.append(x)
+    assert seen_a.count(seen_a[0]) == 2, 'the poisoned iteration was not repeated'
     flat = [gid for batch in dedup[:n_it] for gid in batch]
     assert flat == [r['game_id'] for r in stream[:len(flat)]], 'a rollout was lost, duplicated or reordered'
     assert dedup[:n_it] == seen_b[:n_it]

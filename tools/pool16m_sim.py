@@ -59,24 +59,36 @@ def kernel(x, W1, b1, W2, amax, d, dtu, q):
                     xa[l, j] = x[itc[e], u, f] if f < 12 else 0.0
             g = mfma(xa, w1, np.zeros((64, 16)))
             basic = np.maximum(g + b1[32 * kq + FR][:, None], 0.0)          # reg r: row 8(r>>2)+4fq+(r&3), k = 32 kq + fr
-            # ---- phase B, per item e
+            # ---- phase B, per item e: the operand is ONE-HOT (a select of the staged d pieces); the rank-one attention term goes through K slot 0
             for e in range(2):
                 A = basic[:, 8 * e:8 * e + 8]                                 # K slot j <-> unit sigma(fq, j): exactly registers 8 e + j
+                live = valid[e] and np.any(dtu[itc[e]] != 0)
+                if live:                                                      # s[k] = sum_u dtu[u] basic[u][k]: own eight units + lane ^ 32's
+                    part = np.array([sum(dtu[itc[e], sigma(FQ[l], j)] * A[l, j] for j in range(8)) for l in range(64)])
+                    sk = part + part[LANES ^ 32]
                 for cb in range(4):
                     Bop = np.zeros((64, 8))
                     for l in range(64):
                         c = 32 * cb + FR[l]
-                        for j in range(8):
-                            un = sigma(FQ[l], j)
-                            v = (d[itc[e], c] if amax[itc[e], c] == un else 0.0) + dtu[itc[e], un] * q[itc[e], c]
-                            Bop[l, j] = v if valid[e] else 0.0
+                        a = amax[itc[e], c]
+                        jj = (a & 3) + 4 * (a >> 3)
+                        if ((a >> 2) & 1) == FQ[l] and valid[e]:
+                            Bop[l, jj] = d[itc[e], c]
                     acc[cb] = mfma(A, Bop, acc[cb])
-                    if kq == 0:
+                    if live:
+                        A1 = np.zeros((64, 8)); B1 = np.zeros((64, 8))
                         for l in range(64):
-                            c = 32 * cb + FR[l]
-                            if valid[e]:
+                            if FQ[l] == 0:
+                                A1[l, 0] = sk[l]
+                                B1[l, 0] = q[itc[e], 32 * cb + FR[l]]
+                        acc[cb] = mfma(A1, B1, acc[cb])
+                if kq == 0 and valid[e]:                                      # (the kernel sums these when it stages the item: channels 2 lane, 2 lane + 1)
+                    for l in range(64):
+                        if FQ[l] == 0:
+                            for cb in range(4):
+                                c = 32 * cb + FR[l]
                                 db2acc[l, cb] += d[itc[e], c] + q[itc[e], c] * dtu[itc[e]].sum()
-            # ---- phase C: 8 K steps of 16 channels
+            # ---- phase C: 8 K steps of 16 channels, one-hot rows; then + dtu[u] R[k] in the accumulators (R = q W2: a dense product of its own)
             cacc = np.zeros((64, 16))
             for ks in range(8):
                 A = np.zeros((64, 8)); Bop = np.zeros((64, 8))
@@ -84,10 +96,15 @@ def kernel(x, W1, b1, W2, amax, d, dtu, q):
                     e, u = FR[l] >> 4, FR[l] & 15
                     for j in range(8):
                         c = 16 * ks + 8 * FQ[l] + j
-                        v = (d[itc[e], c] if amax[itc[e], c] == u else 0.0) + dtu[itc[e], u] * q[itc[e], c]
-                        A[l, j] = v if valid[e] else 0.0
+                        A[l, j] = d[itc[e], c] if (amax[itc[e], c] == u and valid[e]) else 0.0
                         Bop[l, j] = W2[c, 32 * kq + FR[l]]                   # LDS image [ks][fq][k][j]
                 cacc = mfma(A, Bop, cacc)
+            for e in range(2):
+                R = q[itc[e]] @ W2                                            # [128]
+                for l in range(64):
+                    for j in range(8):
+                        if valid[e]:
+                            cacc[l, 8 * e + j] += dtu[itc[e], sigma(FQ[l], j)] * R[32 * kq + FR[l]]
             dbm = np.where(basic > 0, cacc, 0.0)
             # ---- fold: K step e, slots <-> sigma
             for e in range(2):
