@@ -40,8 +40,9 @@ enum : int {   // LDS (bytes)
     PM_RED_ACC = 0,                  // at the end, over it: stream 1's dW2^T tiles [kq 4][64 registers][64 lanes] f32
     PM_RED_F = 65536,                // ... its fold tiles [kq 4][16][64] f32
     PM_RED_B = PM_RED_F + 16384,     // ... its bias-gradient sums [4][64] f32
-    PM_STG = 65536,                  // in the loop: every wave's own staging block, 2 buffers x 2 items x 2.5 KB (8 waves x 10 KB; the end-of-kernel
-    PM_LDS = PM_STG + 8 * 10240      // areas above lie over it and the W2 image)
+    PM_STG = 65536,                  // in the loop: every wave's own staging block, 2 buffers x 2 items x 2.8 KB (8 waves x 11.25 KB; the end-of-kernel
+    PM_TAB = PM_STG + 8 * 11520,     // areas above lie over it and the W2 image); one-hot table: entry i < 8 = f16 1.0 at element i, 8..15 = zeros
+    PM_LDS = PM_TAB + 256
 };
 
 struct PoolMArgs {
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
             *reinterpret_cast<f16x8*>(smem + PM_W2P + 32768 + off) = sp.m;
         }
     }
+    if (tid < 16 * 8) reinterpret_cast<uint16_t*>(smem + PM_TAB)[tid] = (tid >> 3) < 8 && (tid & 7) == (tid >> 3) ? 0x3C00u : 0u;   // f16 1.0
     // ---- W1 rows of this wave's k block as the first layer's B operand (the forward's: x 2^8, features 12..15 zero), b1 x s_act ----------
     Split2h w1;
     {
@@ -125,8 +127,10 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
     //     d(basic)[u][k] += dtu[u] R[k], R = q W2 (a dense product over all steps, like embed_sparse.hip's), added to the accumulators in f32
     //     dW2^T[k][c]   += s[k] q[c],   s[k] = sum_u dtu[u] basic[u][k]: one K slot of three more MFMAs per column block, live steps only
     // Block of an item (dwords): d(xcat) pieces [128] | R [128] | q [128] | arg-max bytes [128 B] | unit records [16][12] | dtu [16] | live
-    enum { ST_D = 0, ST_R = 128, ST_Q = 256, ST_A = 384, ST_X = 416, ST_DTU = 608, ST_LIVE = 624, ST_ITEM = 640 };
-    float* const stg = reinterpret_cast<float*>(smem + PM_STG) + (size_t)W * (2 * 2 * ST_ITEM);
+    // | per channel and lane group, the one-hot table entry of the arg-max unit: slot (a & 3) + 4 (a >> 3) if the unit is of the group, else >= 8
+    enum { ST_D = 0, ST_R = 128, ST_Q = 256, ST_A = 384, ST_X = 416, ST_DTU = 608, ST_IDX = 624,
+           ST_ITEM = 720 };      // 720 = 16 mod 64: the two items of a pair start 16 banks apart (their rows are read side by side)
+    float* const stg = reinterpret_cast<float*>(smem + PM_STG) + (size_t)W * (2 * 2 * ST_ITEM);       // 4 x 2 880 B per wave
     const long long n_pairs = (n1 - n0 + 1) / 2;
     const int e_row = fr >> 4, u_row = fr & 15;              // as a ROW of the pair's tile this lane is unit u_row of item e_row
     const float* Rt = p.R + (size_t)(t - 2) * p.nr * 128;
@@ -163,9 +167,13 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
         *reinterpret_cast<float2*>(b + ST_Q + 2 * lane) = r.q;
         b[ST_X + lane] = r.x0; b[ST_X + 64 + lane] = r.x1; b[ST_X + 128 + lane] = r.x2;
         if (lane < 16) b[ST_DTU + lane] = r.dt;
-        if (lane < 32) reinterpret_cast<unsigned*>(b + ST_A)[lane] = r.a;
-        const unsigned long long nz = __ballot(r.dt != 0.f);               // lanes 0..15 hold the sixteen dtu
-        if (lane == 0) reinterpret_cast<int*>(b)[ST_LIVE] = nz != 0ull;
+        if (lane < 32) {
+            reinterpret_cast<unsigned*>(b + ST_A)[lane] = r.a;
+            // four channels at once: slot = (a & 3) | ((a >> 1) & 4), group = (a >> 2) & 1; entry = slot | 8 for the OTHER group
+            const unsigned jj = (r.a & 0x03030303u) | ((r.a >> 1) & 0x04040404u), g1 = (r.a >> 2) & 0x01010101u;
+            reinterpret_cast<unsigned*>(b + ST_IDX)[lane] = jj | (g1 << 3);                          // lane group 0
+            reinterpret_cast<unsigned*>(b + ST_IDX)[32 + lane] = jj | ((g1 ^ 0x01010101u) << 3);     // lane group 1
+        }
         if (kq == 0) {                                                       // wave-uniform: the bias gradient rides on wave (st, 0)
             float sum = r.dt;                                                // row 0 of the wave = lanes 0..15: their sum in each of them
             sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x128, 0xf, 0xf, true));
@@ -198,10 +206,7 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
             const float4 x0 = *reinterpret_cast<const float4*>(xp);
             const float4 x1 = fq ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(xp + 4);   // features 12..15 do not exist
             const Split2h x = split2h<true>(x0, x1, s_act);
-            f32x16 g;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g[r] = 0.f;
-            g = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.m, w1.h, g, 0, 0, 0);     // the forward's sequence
+            f32x16 g = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.m, w1.h, f32x16{}, 0, 0, 0);     // the forward's sequence
             g = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.h, w1.m, g, 0, 0, 0);
             g = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.h, w1.h, g, 0, 0, 0);
 #pragma unroll
@@ -209,6 +214,7 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
         }
 
         // ---- dW2^T += basic^T demb, item by item (K = the item's 16 units) -------------------------------------------------------------
+        float s_att[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const float* it = it0 + e * ST_ITEM;
@@ -220,49 +226,48 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
             for (int cb = 0; cb < 4; ++cb) {
                 const int c = 32 * cb + fr;
                 const unsigned d2 = reinterpret_cast<const unsigned*>(it + ST_D)[c];
-                const int a = reinterpret_cast<const uint8_t*>(it + ST_A)[c];
-                // one-hot over the lane group's eight K slots: unit a sits in group (a >> 2) & 1 at slot jj = (a & 3) + 4 (a >> 3)
-                const int jj = (a & 3) + 4 * (a >> 3);
-                const int rsel = (((a >> 2) & 1) == fq) ? (jj >> 1) : -1;
-                const unsigned hv = (jj & 1) ? (d2 << 16) : (d2 & 0xffffu), mv = (jj & 1) ? (d2 & 0xffff0000u) : (d2 >> 16);
-                u32x4 bh, bm;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { bh[r] = rsel == r ? hv : 0u; bm[r] = rsel == r ? mv : 0u; }
+                // one-hot over the lane group's eight K slots: the table entry (f16 1.0 at the unit's slot, or zeros) times the piece -
+                // eight packed f16 multiplies by exactly 0 or 1 instead of compares and selects per register
+                const int idx = reinterpret_cast<const uint8_t*>(it + ST_IDX)[128 * fq + c];
+                const f16x8 hot = *reinterpret_cast<const f16x8*>(smem + PM_TAB + idx * 16);
+                const f16x2_t dd = __builtin_bit_cast(f16x2_t, d2);
                 Split2h B;
-                B.h = __builtin_bit_cast(f16x8, bh);
-                B.m = __builtin_bit_cast(f16x8, bm);
+                B.h = hot * dd.x;
+                B.m = hot * dd.y;
                 acc[cb] = mma3(A, B, acc[cb]);
             }
-            if (reinterpret_cast<const int*>(it)[ST_LIVE] != 0) {                  // wave-uniform: the rank-one attention term of a live step
+            {   // s[k] x s_act s_grad of the rank-one attention term (below), over the lane group's eight units ...
                 const float4 du0 = *reinterpret_cast<const float4*>(it + ST_DTU + 4 * fq), du1 = *reinterpret_cast<const float4*>(it + ST_DTU + 8 + 4 * fq);
-                float sk = du0.x * bv[0];                                          // s[k] x s_act over the lane group's eight units ...
+                float sk = du0.x * bv[0];
                 sk = fmaf(du0.y, bv[1], sk); sk = fmaf(du0.z, bv[2], sk); sk = fmaf(du0.w, bv[3], sk);
                 sk = fmaf(du1.x, bv[4], sk); sk = fmaf(du1.y, bv[5], sk); sk = fmaf(du1.z, bv[6], sk); sk = fmaf(du1.w, bv[7], sk);
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sk), __float_as_uint(sk), false, false);
-                sk = (sk + __uint_as_float(fq ? sw[0] : sw[1])) * s_grad;           // ... plus the other group's (lane ^ 32); dtu is a gradient
-                // K slot 0 (lanes fq == 0, element 0) carries the term: A[k][0] = s[k], B[0][c] = q[c]
-                const unsigned sh = cvt_pk_f16(sk, 0.f);
-                const unsigned sm = cvt_pk_f16(sk - (float)__builtin_bit_cast(f16x2_t, sh).x, 0.f);
-                Split2h A1;
-                A1.h = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : sh, 0u, 0u, 0u});
-                A1.m = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : sm, 0u, 0u, 0u});
+                s_att[e] = (sk + __uint_as_float(fq ? sw[0] : sw[1])) * s_grad;    // ... plus the other group's (lane ^ 32); dtu is a gradient
+            }
+        }
+        {   // the rank-one attention term of BOTH items (s = 0 for a step whose head is off: no branch - a branch that touches the
+            // accumulators costs a copy of them): K slots 0 and 1 of lane group 0 carry A[k][e] = s_e[k], B[e][c] = q_e[c]
+            const unsigned sh = cvt_pk_f16(s_att[0], s_att[1]);
+            const f16x2_t shv = __builtin_bit_cast(f16x2_t, sh);
+            const unsigned sm = cvt_pk_f16(s_att[0] - (float)shv.x, s_att[1] - (float)shv.y);
+            Split2h A1;
+            A1.h = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : sh, 0u, 0u, 0u});
+            A1.m = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : sm, 0u, 0u, 0u});
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    const float qx = it[ST_Q + 32 * cb + fr];                        // O(1): the gradient pre-scale went into s
-                    const unsigned qh = cvt_pk_f16(qx, 0.f);
-                    const unsigned qm = cvt_pk_f16(qx - (float)__builtin_bit_cast(f16x2_t, qh).x, 0.f);
-                    Split2h B1;
-                    B1.h = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : qh, 0u, 0u, 0u});
-                    B1.m = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : qm, 0u, 0u, 0u});
-                    acc[cb] = mma3(A1, B1, acc[cb]);
-                }
+            for (int cb = 0; cb < 4; ++cb) {
+                const float q0 = it0[ST_Q + 32 * cb + fr], q1 = it0[ST_ITEM + ST_Q + 32 * cb + fr];      // O(1): the gradient pre-scale went into s
+                const unsigned qh = cvt_pk_f16(q0, q1);
+                const f16x2_t qhv = __builtin_bit_cast(f16x2_t, qh);
+                const unsigned qm = cvt_pk_f16(q0 - (float)qhv.x, q1 - (float)qhv.y);
+                Split2h B1;
+                B1.h = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : qh, 0u, 0u, 0u});
+                B1.m = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : qm, 0u, 0u, 0u});
+                acc[cb] = mma3(A1, B1, acc[cb]);
             }
         }
 
         // ---- d(basic) x s_grad s_w = demb W2: eight K steps of 16 channels, the pair's 32 rows ------------------------------------------
-        f32x16 cacc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
+        f32x16 cacc = {};
         {
             const unsigned* dr = reinterpret_cast<const unsigned*>(itr + ST_D) + 8 * fq;
             const uint8_t* ar = reinterpret_cast<const uint8_t*>(itr + ST_A) + 8 * fq;

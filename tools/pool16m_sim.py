@@ -60,12 +60,12 @@ def kernel(x, W1, b1, W2, amax, d, dtu, q):
             g = mfma(xa, w1, np.zeros((64, 16)))
             basic = np.maximum(g + b1[32 * kq + FR][:, None], 0.0)          # reg r: row 8(r>>2)+4fq+(r&3), k = 32 kq + fr
             # ---- phase B, per item e: the operand is ONE-HOT (a select of the staged d pieces); the rank-one attention term goes through K slot 0
+            sk = [None, None]
             for e in range(2):
                 A = basic[:, 8 * e:8 * e + 8]                                 # K slot j <-> unit sigma(fq, j): exactly registers 8 e + j
-                live = valid[e] and np.any(dtu[itc[e]] != 0)
-                if live:                                                      # s[k] = sum_u dtu[u] basic[u][k]: own eight units + lane ^ 32's
-                    part = np.array([sum(dtu[itc[e], sigma(FQ[l], j)] * A[l, j] for j in range(8)) for l in range(64)])
-                    sk = part + part[LANES ^ 32]
+                # s[k] = sum_u dtu[u] basic[u][k]: own eight units + lane ^ 32's (zero for a step whose head is off, or an absent item)
+                part = np.array([sum(dtu[itc[e], sigma(FQ[l], j)] * A[l, j] for j in range(8)) for l in range(64)]) * (1.0 if valid[e] else 0.0)
+                sk[e] = part + part[LANES ^ 32]
                 for cb in range(4):
                     Bop = np.zeros((64, 8))
                     for l in range(64):
@@ -75,19 +75,20 @@ def kernel(x, W1, b1, W2, amax, d, dtu, q):
                         if ((a >> 2) & 1) == FQ[l] and valid[e]:
                             Bop[l, jj] = d[itc[e], c]
                     acc[cb] = mfma(A, Bop, acc[cb])
-                    if live:
-                        A1 = np.zeros((64, 8)); B1 = np.zeros((64, 8))
-                        for l in range(64):
-                            if FQ[l] == 0:
-                                A1[l, 0] = sk[l]
-                                B1[l, 0] = q[itc[e], 32 * cb + FR[l]]
-                        acc[cb] = mfma(A1, B1, acc[cb])
                 if kq == 0 and valid[e]:                                      # (the kernel sums these when it stages the item: channels 2 lane, 2 lane + 1)
                     for l in range(64):
                         if FQ[l] == 0:
                             for cb in range(4):
                                 c = 32 * cb + FR[l]
                                 db2acc[l, cb] += d[itc[e], c] + q[itc[e], c] * dtu[itc[e]].sum()
+            for cb in range(4):                                               # rank-one attention term of both items: K slots 0, 1 of lane group 0
+                A1 = np.zeros((64, 8)); B1 = np.zeros((64, 8))
+                for l in range(64):
+                    if FQ[l] == 0:
+                        for e in range(2):
+                            A1[l, e] = sk[e][l]
+                            B1[l, e] = q[itc[e], 32 * cb + FR[l]]
+                acc[cb] = mfma(A1, B1, acc[cb])
             # ---- phase C: 8 K steps of 16 channels, one-hot rows; then + dtu[u] R[k] in the accumulators (R = q W2: a dense product of its own)
             cacc = np.zeros((64, 16))
             for ks in range(8):
