@@ -16,8 +16,8 @@
 // gathers, no barrier inside the loop: a wave only ever consumes what it computed itself or what is read-only.
 //
 // Arithmetic: two f16 pieces per f32 operand, three v_mfma_f32_32x32x16_f16 per product (hh, hm, mh), f32 accumulate - gemm_x3.hip's
-// PREC 4 with the same power-of-two pre-scales (activations and records s_act, weights s_w, gradients s_grad); the first layer is
-// the forward's instruction sequence (embed_fused.hip, F16), so the relu mask is the forward's bit for bit.
+// PREC 4 with the same power-of-two pre-scales (activations and records s_act, weights s_w, gradients s_grad); the first layer (K = 12)
+// alone runs on the f32-input MFMA, like the dense backward kernels' mask evaluation: the relu mask is theirs bit for bit.
 //
 // Work split.  Workgroup = one type x a contiguous range of env-steps, 512 threads.  Wave W = (stream st = W >> 2, k quarter kq = W & 3):
 // a stream takes every other PAIR of env-steps (a pair's 2 x 16 units are the 32 rows of an MFMA tile), a wave owns the 32 hidden units
@@ -100,16 +100,15 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
         }
     }
     if (tid < 16 * 8) reinterpret_cast<uint16_t*>(smem + PM_TAB)[tid] = (tid >> 3) < 8 && (tid & 7) == (tid >> 3) ? 0x3C00u : 0u;   // f16 1.0
-    // ---- W1 rows of this wave's k block as the first layer's B operand (the forward's: x 2^8, features 12..15 zero), b1 x s_act ----------
-    Split2h w1;
-    {
-        float v[8];
+    // ---- W1 rows of this wave's k block as the first layer's B operand.  The first layer runs on the f32-input MFMA (six
+    // v_mfma_f32_32x32x2_f32, K = 12): exactly what the dense backward kernels (embed_fused.hip) evaluate the relu mask with, and - like
+    // the oracle's torch f32 - exact products, so a pre-activation must be within ~1e-7 of zero to get another sign than the oracle's; the
+    // forward's two-f16-piece sequence flips five times as many of the 2.7 x 10^8 pre-activations of a bench pass, each a whole term of a
+    // dW1 row (measured: one flip = 3.6e-3 of the largest entry at 1 536 steps).  384 matrix-pipe cycles per pair instead of 96.
+    float w1f[6];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 8 * fq + j < 12 ? p.W1[(32 * kq + fr) * 12 + 8 * fq + j] : 0.f;
-        w1 = split8(v, 256.f);
-    }
-    const float b1s = p.b1[32 * kq + fr] * s_act;
-    const float ginv = 1.f / 256.f;                          // (x s_act)(W1 2^8) -> basic x s_act  (embed_fused.hip, F16)
+    for (int kk = 0; kk < 6; ++kk) w1f[kk] = p.W1[(32 * kq + fr) * 12 + 2 * kk + fq];
+    const float b1v = p.b1[32 * kq + fr];
     const float inv_w = 1.f / p.s_w;
 
     f32x16 acc[4];                                           // dW2^T[k = 32 kq + row][c = 32 cb + col] x s_act s_grad
@@ -135,7 +134,7 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
     const int e_row = fr >> 4, u_row = fr & 15;              // as a ROW of the pair's tile this lane is unit u_row of item e_row
     const float* Rt = p.R + (size_t)(t - 2) * p.nr * 128;
     float db2a[2] = {0.f, 0.f};                              // kq == 0: sum over steps of demb's column sums, channels 2 lane, 2 lane + 1
-    struct Raw { float2 d, d2, q, r; float x0, x1, x2, dt; unsigned a; };
+    struct Raw { float2 d, d2, q, r; float x0, x1, x2, dt; unsigned a; bool valid; };
     auto load_raw = [&](long long pi, int e) {
         Raw r;
         long long n = n0 + 2 * pi + e;
@@ -150,12 +149,13 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
         r.x0 = xr[0]; r.x1 = xr[64]; r.x2 = xr[128];
         r.dt = lane < 16 ? p.dtu[n * 40 + cum + lane] : 0.f;
         r.a = lane < 32 ? reinterpret_cast<const unsigned*>(p.amax + (n * 3 + (t - 1)) * 128)[lane] : 0u;
-        if (!valid) { r.d = make_float2(0.f, 0.f); r.d2 = r.d; r.dt = 0.f; }
+        r.valid = valid;               // applied when the item is STAGED: a select here would wait for the loads a pair too early
         return r;
     };
     auto store_raw = [&](const Raw& r, int buf, int e) {
         float* b = stg + (buf * 2 + e) * ST_ITEM;
-        const float d0 = r.d.x + r.d2.x, d1 = r.d.y + r.d2.y;              // policy.py:127: enh feeds two slots
+        const float d0 = r.valid ? r.d.x + r.d2.x : 0.f, d1 = r.valid ? r.d.y + r.d2.y : 0.f;      // policy.py:127: enh feeds two slots
+        const float dt = r.valid ? r.dt : 0.f;
         {   // the two f16 pieces of d x s_grad, one dword per channel
             const float x0 = d0 * s_grad, x1 = d1 * s_grad;
             const unsigned hh = cvt_pk_f16(x0, x1);
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
         *reinterpret_cast<float2*>(b + ST_R + 2 * lane) = r.r;
         *reinterpret_cast<float2*>(b + ST_Q + 2 * lane) = r.q;
         b[ST_X + lane] = r.x0; b[ST_X + 64 + lane] = r.x1; b[ST_X + 128 + lane] = r.x2;
-        if (lane < 16) b[ST_DTU + lane] = r.dt;
+        if (lane < 16) b[ST_DTU + lane] = dt;
         if (lane < 32) {
             reinterpret_cast<unsigned*>(b + ST_A)[lane] = r.a;
             // four channels at once: slot = (a & 3) | ((a >> 1) & 4), group = (a >> 2) & 1; entry = slot | 8 for the OTHER group
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
             reinterpret_cast<unsigned*>(b + ST_IDX)[32 + lane] = jj | ((g1 ^ 0x01010101u) << 3);     // lane group 1
         }
         if (kq == 0) {                                                       // wave-uniform: the bias gradient rides on wave (st, 0)
-            float sum = r.dt;                                                // row 0 of the wave = lanes 0..15: their sum in each of them
+            float sum = dt;                                                  // row 0 of the wave = lanes 0..15: their sum in each of them
             sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x128, 0xf, 0xf, true));
             sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x124, 0xf, 0xf, true));
             sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x122, 0xf, 0xf, true));
@@ -190,29 +190,34 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
         store_raw(r0, 0, 0); store_raw(r1, 0, 1);
     }
     const float rs = s_grad * p.s_w;                         // scale of the d(basic) accumulators
+#ifdef DC_PM_TIMING      // A/B build: s_memtime sums per phase of every wave of workgroup 0 -> p.slab (garbage results; a measuring aid only)
+    long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm0 = __builtin_amdgcn_s_memtime();
+#define PM_STAMP(i) { const long long x_ = __builtin_amdgcn_s_memtime(); tm[i] += x_ - tm0; tm0 = x_; }
+#else
+#define PM_STAMP(i)
+#endif
     int buf = 0;
     for (long long pi = st; pi < n_pairs; pi += 2, buf ^= 1) {
         const bool more = pi + 2 < n_pairs;                  // wave-uniform
         Raw nx0, nx1;
         if (more) { nx0 = load_raw(pi + 2, 0); nx1 = load_raw(pi + 2, 1); }
         __builtin_amdgcn_wave_barrier();
+        PM_STAMP(0)
         const float* it0 = stg + (buf * 2) * ST_ITEM;        // item e of the pair: it0 + e * ST_ITEM
         const float* itr = it0 + e_row * ST_ITEM;            // the item this lane's ROW belongs to
 
         // ---- first layer: basic x s_act of the pair's 32 rows, this wave's 32 hidden units ----------------------------------------
-        f32x16 basic;
+        f32x16 basic;                                        // relu(x W1^T + b1), unscaled: row 8 (r >> 2) + 4 fq + (r & 3), hidden unit 32 kq + fr
         {
-            const float* xp = itr + ST_X + u_row * 12 + 8 * fq;
-            const float4 x0 = *reinterpret_cast<const float4*>(xp);
-            const float4 x1 = fq ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(xp + 4);   // features 12..15 do not exist
-            const Split2h x = split2h<true>(x0, x1, s_act);
-            f32x16 g = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.m, w1.h, f32x16{}, 0, 0, 0);     // the forward's sequence
-            g = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.h, w1.m, g, 0, 0, 0);
-            g = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.h, w1.h, g, 0, 0, 0);
+            const float* xp = itr + ST_X + u_row * 12 + fq;  // A operand of MFMA kk: x[row][feature 2 kk + fq]
+            f32x16 g = {};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) basic[r] = relu_nan(fmaf(g[r], ginv, b1s));
+            for (int kk = 0; kk < 6; ++kk) g = __builtin_amdgcn_mfma_f32_32x32x2f32(xp[2 * kk], w1f[kk], g, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) basic[r] = relu_nan(g[r] + b1v);
         }
 
+        PM_STAMP(1)
         // ---- dW2^T += basic^T demb, item by item (K = the item's 16 units) -------------------------------------------------------------
         float s_att[2];
 #pragma unroll
@@ -221,30 +226,45 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
             float bv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) bv[j] = basic[8 * e + j];                  // K slot 8 fq + j <-> unit sigma(fq, j): as they lie
-            const Split2h A = split8_noscale(bv);
+            const Split2h A = split8(bv, s_act);
+            // reads first (two dependent LDS round trips: entry index, then the table entry), then the four operands, then the products -
+            // spelled out in that order so that the round trips of the four column blocks overlap
+            unsigned d2[4];
+            int idx[4];
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
-                const int c = 32 * cb + fr;
-                const unsigned d2 = reinterpret_cast<const unsigned*>(it + ST_D)[c];
-                // one-hot over the lane group's eight K slots: the table entry (f16 1.0 at the unit's slot, or zeros) times the piece -
-                // eight packed f16 multiplies by exactly 0 or 1 instead of compares and selects per register
-                const int idx = reinterpret_cast<const uint8_t*>(it + ST_IDX)[128 * fq + c];
-                const f16x8 hot = *reinterpret_cast<const f16x8*>(smem + PM_TAB + idx * 16);
-                const f16x2_t dd = __builtin_bit_cast(f16x2_t, d2);
-                Split2h B;
-                B.h = hot * dd.x;
-                B.m = hot * dd.y;
-                acc[cb] = mma3(A, B, acc[cb]);
+                d2[cb] = reinterpret_cast<const unsigned*>(it + ST_D)[32 * cb + fr];
+                idx[cb] = reinterpret_cast<const uint8_t*>(it + ST_IDX)[128 * fq + 32 * cb + fr];
             }
-            {   // s[k] x s_act s_grad of the rank-one attention term (below), over the lane group's eight units ...
+            f16x8 hot[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) hot[cb] = *reinterpret_cast<const f16x8*>(smem + PM_TAB + idx[cb] * 16);
+            // one-hot over the lane group's eight K slots: the table entry (f16 1.0 at the unit's slot, or zeros) times the piece - eight
+            // packed f16 multiplies by exactly 0 or 1 instead of compares and selects per register
+            Split2h B[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const f16x2_t dd = __builtin_bit_cast(f16x2_t, d2[cb]);
+                B[cb].h = hot[cb] * dd.x;
+                B[cb].m = hot[cb] * dd.y;
+            }
+            // (independent accumulators: term by term across the four blocks, not three dependent MFMAs per block)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.m, B[cb].h, acc[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.h, B[cb].m, acc[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.h, B[cb].h, acc[cb], 0, 0, 0);
+            {   // s[k] (x s_act s_grad) of the rank-one attention term (below), over the lane group's eight units ...
                 const float4 du0 = *reinterpret_cast<const float4*>(it + ST_DTU + 4 * fq), du1 = *reinterpret_cast<const float4*>(it + ST_DTU + 8 + 4 * fq);
                 float sk = du0.x * bv[0];
                 sk = fmaf(du0.y, bv[1], sk); sk = fmaf(du0.z, bv[2], sk); sk = fmaf(du0.w, bv[3], sk);
                 sk = fmaf(du1.x, bv[4], sk); sk = fmaf(du1.y, bv[5], sk); sk = fmaf(du1.z, bv[6], sk); sk = fmaf(du1.w, bv[7], sk);
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sk), __float_as_uint(sk), false, false);
-                s_att[e] = (sk + __uint_as_float(fq ? sw[0] : sw[1])) * s_grad;    // ... plus the other group's (lane ^ 32); dtu is a gradient
+                s_att[e] = (sk + __uint_as_float(fq ? sw[0] : sw[1])) * (s_grad * s_act);   // ... plus the other group's (lane ^ 32); dtu is a gradient
             }
         }
+        PM_STAMP(2)
         {   // the rank-one attention term of BOTH items (s = 0 for a step whose head is off: no branch - a branch that touches the
             // accumulators costs a copy of them): K slots 0 and 1 of lane group 0 carry A[k][e] = s_e[k], B[e][c] = q_e[c]
             const unsigned sh = cvt_pk_f16(s_att[0], s_att[1]);
@@ -253,27 +273,32 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
             Split2h A1;
             A1.h = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : sh, 0u, 0u, 0u});
             A1.m = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : sm, 0u, 0u, 0u});
+            Split2h B1[4];
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
                 const float q0 = it0[ST_Q + 32 * cb + fr], q1 = it0[ST_ITEM + ST_Q + 32 * cb + fr];      // O(1): the gradient pre-scale went into s
                 const unsigned qh = cvt_pk_f16(q0, q1);
                 const f16x2_t qhv = __builtin_bit_cast(f16x2_t, qh);
                 const unsigned qm = cvt_pk_f16(q0 - (float)qhv.x, q1 - (float)qhv.y);
-                Split2h B1;
-                B1.h = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : qh, 0u, 0u, 0u});
-                B1.m = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : qm, 0u, 0u, 0u});
-                acc[cb] = mma3(A1, B1, acc[cb]);
+                B1[cb].h = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : qh, 0u, 0u, 0u});
+                B1[cb].m = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : qm, 0u, 0u, 0u});
             }
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1.m, B1[cb].h, acc[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1.h, B1[cb].m, acc[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1.h, B1[cb].h, acc[cb], 0, 0, 0);
         }
 
+        PM_STAMP(3)
         // ---- d(basic) x s_grad s_w = demb W2: eight K steps of 16 channels, the pair's 32 rows ------------------------------------------
         f32x16 cacc = {};
         {
             const unsigned* dr = reinterpret_cast<const unsigned*>(itr + ST_D) + 8 * fq;
             const uint8_t* ar = reinterpret_cast<const uint8_t*>(itr + ST_A) + 8 * fq;
             const char* w2l = smem + PM_W2P + (fq * 128 + 32 * kq + fr) * 16;
-#pragma unroll 2
-            for (int ks = 0; ks < 8; ++ks) {
+            auto build = [&](int ks) {             // the A operand of K step ks: selects of the staged pieces, re-packed h with h, m with m
                 const uint4 d0 = *reinterpret_cast<const uint4*>(dr + 16 * ks), d1 = *reinterpret_cast<const uint4*>(dr + 16 * ks + 4);
                 const unsigned d2[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
                 const uint2 ab = *reinterpret_cast<const uint2*>(ar + 16 * ks);
@@ -289,14 +314,24 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
                     ah[i] = __builtin_amdgcn_perm(sel[2 * i + 1], sel[2 * i], 0x05040100u);      // the h halves of two channels
                     am[i] = __builtin_amdgcn_perm(sel[2 * i + 1], sel[2 * i], 0x07060302u);      // the m halves
                 }
-                Split2h Aop, B;
-                Aop.h = __builtin_bit_cast(f16x8, ah);
-                Aop.m = __builtin_bit_cast(f16x8, am);
+                Split2h o;
+                o.h = __builtin_bit_cast(f16x8, ah);
+                o.m = __builtin_bit_cast(f16x8, am);
+                return o;
+            };
+            // software pipeline: the operand of K step ks + 1 is built (LDS round trip + selects) while the three dependent MFMAs of K step ks run
+            Split2h Aop = build(0);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                Split2h B;
                 B.h = *reinterpret_cast<const f16x8*>(w2l + ks * 4096);
                 B.m = *reinterpret_cast<const f16x8*>(w2l + 32768 + ks * 4096);
-                cacc = mma3(Aop, B, cacc);
+                const Split2h cur = Aop;
+                if (ks + 1 < 8) Aop = build(ks + 1);
+                cacc = mma3(cur, B, cacc);
             }
         }
+        PM_STAMP(4)
         // the attention term of d(basic), in f32: + dtu[u] R[k] (zero for a step whose head is off); then through the relu
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -324,9 +359,23 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
             }
             facc = mma3(split8(xv, s_act), split8_noscale(bv), facc);
         }
+        PM_STAMP(5)
         __builtin_amdgcn_wave_barrier();
         if (more) { store_raw(nx0, buf ^ 1, 0); store_raw(nx1, buf ^ 1, 1); }
+        PM_STAMP(6)
     }
+#ifdef DC_PM_TIMING
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) reinterpret_cast<long long*>(p.part1)[W * 8 + i] = tm[i];
+    __syncthreads();
+    if (blockIdx.x == 0 && tid == 0) {
+        const long long* tt = reinterpret_cast<const long long*>(p.part1);
+        for (int w = 0; w < 8; ++w)
+            printf("pool16m wave %d (cycles per pair): loads+wait %lld  first layer %lld  dW2 %lld  rank-one %lld  d(basic) %lld  fixup+fold %lld  stage %lld\n", w,
+                   tt[w * 8 + 0] / (n_pairs / 2), tt[w * 8 + 1] / (n_pairs / 2), tt[w * 8 + 2] / (n_pairs / 2), tt[w * 8 + 3] / (n_pairs / 2),
+                   tt[w * 8 + 4] / (n_pairs / 2), tt[w * 8 + 5] / (n_pairs / 2), tt[w * 8 + 6] / (n_pairs / 2));
+    }
+#endif
 
     // ---- results: the two streams meet through LDS (stream 1 writes, stream 0 adds and stores) ---------------------------------------------
     __syncthreads();                                         // every wave is done with the W2 image

@@ -317,15 +317,15 @@ def test_sparse_pool_backward_matches_dense(lens):
               'affine_unit_enh.weight', 'affine_unit_anh.bias', 'affine_unit_enh.bias', 'affine_unit_eh.weight',
               'affine_unit_ah.bias', 'affine_env.weight')}
         outs[mode] = (g, res.cpu().numpy().copy(), eng.params.cpu().numpy().copy())
-    # The on-chip kernel evaluates the relu mask with the FORWARD's first layer (two f16 pieces, the forward's instruction sequence); the
-    # dense and the VALU kernels re-evaluate it with exact-f32 MFMAs.  A pre-activation within ~1e-6 of zero (a couple among the 2 x 10^6
-    # of these batches) gets the other sign there - one term of ONE hidden unit's row of dW1 / db1, visible at 5e-4 of the largest entry
-    # on a 512-step batch.  So: every tensor at 2e-5, except that up to two hidden units' rows of dW1 / db1 may sit at 2e-3.
+    # All variants evaluate the relu mask of the first layer with exact-f32 MFMAs (a first version of the on-chip kernel took the forward's
+    # two-f16-piece sequence: one pre-activation in ~10^6 got the other sign, a whole term of ONE hidden unit's row of dW1 / db1 - 3.6e-3 of
+    # the largest entry at 1 536 steps).  The check stays tolerant of such a flip (different f32 summation orders can still produce one):
+    # every tensor at 2e-5, except that up to two hidden units' rows of dW1 / db1 may sit at 1e-2.
     for n in outs['0'][0]:
         a, b = outs['1'][0][n], outs['0'][0][n]
         if n.startswith('affine_unit_basic_stats'):
             row_err = np.abs(a - b).reshape(128, -1).max(axis=1) / np.abs(b).max()
-            assert (row_err >= 2e-5).sum() <= 2 and row_err.max() < 2e-3, (n, np.sort(row_err)[-4:])
+            assert (row_err >= 2e-5).sum() <= 2 and row_err.max() < 1e-2, (n, np.sort(row_err)[-4:])
         else:
             assert util.scaled_err(a, b) < 2e-5, (n, util.scaled_err(a, b))
     assert util.scaled_err(outs['1'][1][:11], outs['0'][1][:11]) < 2e-5
