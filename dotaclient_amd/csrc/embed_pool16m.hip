@@ -6,28 +6,42 @@
 // and channel: 1/16 of the dense MACs) as per-channel gathers on the packed-f32 VALU and is bound by their latency: sorted channel lists,
 // dependent LDS round trips, a barrier per step, 0.20 of the vector peak after three rounds of tuning.  The matrix cores do sixteen
 // times the VALU's MACs per cycle, so here the DENSE form runs instead - per env-step and type
-//     dW2^T[k][c]  += sum_u basic[u][k] demb[u][c]          K = 16 units
-//     dbasic[u][k]  = sum_c demb[u][c] W2[c][k]             K = 128 channels
-//     dW1^T[f][k]  += sum_u x[u][f] relu'(.) dbasic[u][k]   K = 16 units, f = 12: ones (db1)
+//     dW2^T[k][c]  += sum_u basic[u][k] demb[u][c]          K = 16 units                          (kernel 1)
+//     dbasic[u][k]  = sum_c demb[u][c] W2[c][k]             K = 128 channels                      (kernel 2)
+//     dW1^T[f][k]  += sum_u x[u][f] relu'(.) dbasic[u][k]   K = 16 units, f = 12: ones (db1)      (kernel 2)
 // with demb[u][c] = [amax(c) == u] d(xcat)[c] + dtu[u] q[c] - and NOTHING of it ever exists in memory: a lane builds the 8 operand
-// elements an MFMA wants from it out of the arg-max bytes, d(xcat), dtu and the attention query (all read where the forward / the loss
-// left them), basic comes out of the first-layer MFMA in exactly the register layout the next product takes as its A operand, the
-// relu-masked d(basic) in the layout the fold takes as its B operand.  No prepare pass, no R = q W2 product, no sorted lists, no LDS
-// gathers, no barrier inside the loop: a wave only ever consumes what it computed itself or what is read-only.
+// elements an MFMA wants from it out of the arg-max bytes and d(xcat) (read where the forward / the loss left them), basic comes out
+// of the first-layer MFMA in exactly the register layout the next product takes as its A operand, the relu-masked d(basic) in the
+// layout the fold takes as its B operand.  No prepare pass, no sorted lists, no LDS gathers, no barrier inside a loop: a wave only ever
+// consumes what it computed itself or what is read-only.
+//
+// The rank-one attention term dtu[u] q[c] would make the one-hot operands dense, so it stays out of them:
+//     dW2^T[k][c]   += s[k] q[c],  s[k] = sum_u dtu[u] basic[u][k]: two K slots (the pair's two steps) of three more MFMAs per column block
+//     d(basic)[u][k] += dtu[u] R[k], R = q W2 - a dense product over all steps launched ahead (like embed_sparse.hip's), added in f32
 //
 // Arithmetic: two f16 pieces per f32 operand, three v_mfma_f32_32x32x16_f16 per product (hh, hm, mh), f32 accumulate - gemm_x3.hip's
-// PREC 4 with the same power-of-two pre-scales (activations and records s_act, weights s_w, gradients s_grad); the first layer (K = 12)
-// alone runs on the f32-input MFMA, like the dense backward kernels' mask evaluation: the relu mask is theirs bit for bit.
+// PREC 4 with the same power-of-two pre-scales (activations and records s_act, weights s_w, gradients s_grad); d(xcat) is scaled and
+// split ONCE, when a step is staged (one dword per channel: h | m << 16), so an operand element is a select of a staged dword - no
+// arithmetic per element.  The first layer (K = 12) alone runs on the f32-input MFMA, like the dense backward kernels' mask evaluation:
+// the relu mask is theirs bit for bit, and - like the oracle's torch f32 - a pre-activation must be within ~1e-7 of zero to get another
+// sign (the forward's two-f16-piece sequence flips five times as many of the 2.7 x 10^8 pre-activations of a bench pass, each a whole
+// term of a dW1 row: one flip measured 3.6e-3 of the largest entry at 1 536 steps).
 //
-// Work split.  Workgroup = one type x a contiguous range of env-steps, 512 threads.  Wave W = (stream st = W >> 2, k quarter kq = W & 3):
-// a stream takes every other PAIR of env-steps (a pair's 2 x 16 units are the 32 rows of an MFMA tile), a wave owns the 32 hidden units
-// k = 32 kq .. 32 kq + 31 for everything - its slice of basic, of dW2^T (4 accumulator tiles, the whole kernel), of d(basic) and of the
-// dW1 fold.  The four waves of a stream build the same demb operands redundantly (VALU work in the shadow of their own MFMAs); the two
-// streams' accumulators meet once, at the end, through LDS.  Register layouts (lane = (fr = lane & 31, fq = lane >> 5)):
+// Two kernels, because the two halves want different splits of the work (measured as ONE kernel with k-quarter waves doing everything:
+// 727 us, four waves building the same d(basic) operands):
+//   1. embed_pool16m_dw2_kernel: workgroup = one type x a range of steps; wave = (stream, k quarter): a stream takes every other PAIR of
+//      steps (a pair's 2 x 16 units are the 32 rows of an MFMA tile), a wave owns the 32 hidden units k = 32 kq .. + 31: its slice of basic
+//      (first layer), the relu masks (written out as 16 bits per lane, 128 B per wave and pair), and its 32 x 128 slice of dW2^T - four
+//      accumulator tiles for the whole kernel.
+//   2. embed_pool16m_dw1_kernel: a wave takes whole pairs for ALL 128 hidden units: the one-hot operand of a K step is built once and
+//      meets four W2 column blocks (LDS image) in four independent accumulator chains; the masks come from kernel 1, the fold
+//      accumulates dW1^T / db1 in four tiles per wave.
+// Register layouts (lane = (fr = lane & 31, fq = lane >> 5)):
 //     A operand: A[row fr][K slot 8 fq + j], B operand: B[K slot 8 fq + j][col fr], D: register r = D[row 8 (r >> 2) + 4 fq + (r & 3)][col fr]
 // The first layer's D registers hold, for item e of the pair, units sigma(fq, j) = 4 fq + (j & 3) + 8 (j >> 2) in registers 8 e + j: K slot
 // 8 fq + j of the unit-contracting products stands for unit sigma(fq, j), and those products take D registers as operands as they are.
 // tools/pool16m_sim.py models exactly this index math lane by lane against a dense float64 evaluation.
+#include <stdio.h>
 #include "kernels.h"
 #include "gemm_tiles.h"
 
@@ -35,15 +49,6 @@ namespace dc {
 namespace {
 
 enum { PM_THREADS = 512, PM_OBS = 483, PM_XCAT = 896 };
-enum : int {   // LDS (bytes)
-    PM_W2P = 0,                      // [piece 2][K step 8][fq 2][k 128][8 channels] f16: the B operand of the d(basic) product (W2 x s_w)
-    PM_RED_ACC = 0,                  // at the end, over it: stream 1's dW2^T tiles [kq 4][64 registers][64 lanes] f32
-    PM_RED_F = 65536,                // ... its fold tiles [kq 4][16][64] f32
-    PM_RED_B = PM_RED_F + 16384,     // ... its bias-gradient sums [4][64] f32
-    PM_STG = 65536,                  // in the loop: every wave's own staging block, 2 buffers x 2 items x 2.8 KB (8 waves x 11.25 KB; the end-of-kernel
-    PM_TAB = PM_STG + 8 * 11520,     // areas above lie over it and the W2 image); one-hot table: entry i < 8 = f16 1.0 at element i, 8..15 = zeros
-    PM_LDS = PM_TAB + 256
-};
 
 struct PoolMArgs {
     const float* obs; const float* dxcat; const uint8_t* amax; const float* dtu; const float* q; int ldq;
@@ -51,10 +56,9 @@ struct PoolMArgs {
     float* slab; float* part1; float* part2;
     long long nr; int wg_per_type; int steps_per_wg;
     float s_act, s_w, s_grad;
-    const float* R;           // [2][nr][128]: R = q W2_t of every step and type (a dense product, launched ahead of the kernel)
+    const float* R;           // [2][nr][128]: R = q W2_t of every step and type (a dense product, launched ahead of the kernels)
+    uint16_t* mask;           // [2][nr / 2 rounded up][64 lanes][4 k blocks]: relu masks of a pair's first layer, bit r = D register r of the lane
 };
-
-__device__ __forceinline__ int sigma_unit(int fq, int j) { return 4 * fq + (j & 3) + 8 * (j >> 2); }
 
 __device__ __forceinline__ Split2h split8(const float (&v)[8], float s) {
     return split2h<true>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), s);
@@ -68,10 +72,30 @@ __device__ __forceinline__ f32x16 mma3(const Split2h& a, const Split2h& b, f32x1
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.m, acc, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.h, acc, 0, 0, 0);
 }
+// (d0, d1) x s_grad as two staged dwords h | m << 16
+__device__ __forceinline__ uint2 stage_pieces(float d0, float d1, float s_grad) {
+    const float x0 = d0 * s_grad, x1 = d1 * s_grad;
+    const unsigned hh = cvt_pk_f16(x0, x1);
+    const f16x2_t hv = __builtin_bit_cast(f16x2_t, hh);
+    const unsigned mm = cvt_pk_f16(x0 - (float)hv.x, x1 - (float)hv.y);
+    return make_uint2((hh & 0xffffu) | (mm << 16), (hh >> 16) | (mm & 0xffff0000u));
+}
 
 }  // namespace
 
-__global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs p) {
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Kernel 1: first layer, relu masks, dW2^T (+ the second-layer bias gradient)
+// ---------------------------------------------------------------------------------------------------------------------------------------
+enum : int {   // LDS (bytes)
+    P1_STG = 0,                      // every wave's own staging block: 2 buffers x 2 items x 2.4 KB
+    P1_ITEM = 592,                   // dwords per item; 592 = 16 mod 64: the two items of a pair start 16 banks apart
+    P1_TAB = P1_STG + 8 * 4 * P1_ITEM * 4,   // one-hot table: entry i < 8 = f16 1.0 at element i, entries 8..15 = zeros
+    P1_RED_ACC = 0,                  // at the end, over the staging blocks: stream 1's dW2^T tiles [kq 4][64 registers][64 lanes] f32
+    P1_RED_B = 65536,                // ... and its bias-gradient sums [2][64] f32
+    P1_LDS = 65536 + 1024 > P1_TAB + 256 ? 65536 + 1024 : P1_TAB + 256
+};
+
+__global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw2_kernel(PoolMArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int W = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,56 +109,30 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
     const int slot0 = t == 2 ? 3 : 4;                       // xcat slot the type's max feeds; enh feeds slot 6 as well (policy.py:127)
     const float s_act = p.s_act, s_grad = p.s_grad;
 
-    // ---- W2 of the type -> LDS as the d(basic) product's B operand: element (c, k) at [piece][c >> 4][(c >> 3) & 1][k][c & 7] ----------
-    {
-        const float* W2t = p.W2 + (size_t)t * 128 * 128;     // [c][k]
-        for (int e = tid; e < 128 * 16; e += PM_THREADS) {
-            const int k = e & 127, oct = e >> 7;             // channels 8 oct .. 8 oct + 7
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = W2t[(size_t)(8 * oct + j) * 128 + k];
-            const Split2h sp = split8(v, p.s_w);
-            const int off = (((oct >> 1) * 2 + (oct & 1)) * 128 + k) * 16;
-            *reinterpret_cast<f16x8*>(smem + PM_W2P + off) = sp.h;
-            *reinterpret_cast<f16x8*>(smem + PM_W2P + 32768 + off) = sp.m;
-        }
-    }
-    if (tid < 16 * 8) reinterpret_cast<uint16_t*>(smem + PM_TAB)[tid] = (tid >> 3) < 8 && (tid & 7) == (tid >> 3) ? 0x3C00u : 0u;   // f16 1.0
-    // ---- W1 rows of this wave's k block as the first layer's B operand.  The first layer runs on the f32-input MFMA (six
-    // v_mfma_f32_32x32x2_f32, K = 12): exactly what the dense backward kernels (embed_fused.hip) evaluate the relu mask with, and - like
-    // the oracle's torch f32 - exact products, so a pre-activation must be within ~1e-7 of zero to get another sign than the oracle's; the
-    // forward's two-f16-piece sequence flips five times as many of the 2.7 x 10^8 pre-activations of a bench pass, each a whole term of a
-    // dW1 row (measured: one flip = 3.6e-3 of the largest entry at 1 536 steps).  384 matrix-pipe cycles per pair instead of 96.
+    if (tid < 16 * 8) reinterpret_cast<uint16_t*>(smem + P1_TAB)[tid] = (tid >> 3) < 8 && (tid & 7) == (tid >> 3) ? 0x3C00u : 0u;   // f16 1.0
+    // W1 rows of this wave's k block as the first layer's B operand (six v_mfma_f32_32x32x2_f32, K = 12: file header)
     float w1f[6];
 #pragma unroll
     for (int kk = 0; kk < 6; ++kk) w1f[kk] = p.W1[(32 * kq + fr) * 12 + 2 * kk + fq];
     const float b1v = p.b1[32 * kq + fr];
-    const float inv_w = 1.f / p.s_w;
 
     f32x16 acc[4];                                           // dW2^T[k = 32 kq + row][c = 32 cb + col] x s_act s_grad
-    f32x16 facc;                                             // dW1^T[f = row][k = 32 kq + col] x s_act s_grad; row 12: db1
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { facc[r] = 0.f; acc[0][r] = 0.f; acc[1][r] = 0.f; acc[2][r] = 0.f; acc[3][r] = 0.f; }
-    __syncthreads();                                         // the W2 image
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; acc[2][r] = 0.f; acc[3][r] = 0.f; }
+    __syncthreads();                                         // the table
 
     // ---- per pair: raw inputs global -> registers (a pair ahead) -> this wave's own LDS block -> operand builds --------------------------
     // Every wave stages what IT needs (the four waves of a stream read the same lines: L1 / L2 serve three of them); the loads of pair i + 1
-    // are in flight while pair i computes, so no operand build ever waits for HBM, and no wave ever waits for another.  What costs VALU
-    // time in the builds is done ONCE, here: d(xcat) is scaled and split into its two f16 pieces when it is staged (one dword per channel:
-    // h | m << 16), so an operand element is a SELECT of a staged dword by "arg-max unit == my unit" - no arithmetic per element.  The
-    // attention term dtu[u] q[c] would make the operands dense; it is rank one, so it stays out of them:
-    //     d(basic)[u][k] += dtu[u] R[k], R = q W2 (a dense product over all steps, like embed_sparse.hip's), added to the accumulators in f32
-    //     dW2^T[k][c]   += s[k] q[c],   s[k] = sum_u dtu[u] basic[u][k]: one K slot of three more MFMAs per column block, live steps only
-    // Block of an item (dwords): d(xcat) pieces [128] | R [128] | q [128] | arg-max bytes [128 B] | unit records [16][12] | dtu [16] | live
-    // | per channel and lane group, the one-hot table entry of the arg-max unit: slot (a & 3) + 4 (a >> 3) if the unit is of the group, else >= 8
-    enum { ST_D = 0, ST_R = 128, ST_Q = 256, ST_A = 384, ST_X = 416, ST_DTU = 608, ST_IDX = 624,
-           ST_ITEM = 720 };      // 720 = 16 mod 64: the two items of a pair start 16 banks apart (their rows are read side by side)
-    float* const stg = reinterpret_cast<float*>(smem + PM_STG) + (size_t)W * (2 * 2 * ST_ITEM);       // 4 x 2 880 B per wave
+    // are in flight while pair i computes, so no operand build ever waits for HBM, and no wave ever waits for another.
+    // Block of an item (dwords): d(xcat) pieces [128] | q [128] | unit records [16][12] | dtu [16] | per channel and lane group, the
+    // one-hot table entry of the arg-max unit: slot (a & 3) + 4 (a >> 3) if the unit is of the group, else >= 8 [2][128 B]
+    enum { ST_D = 0, ST_Q = 128, ST_X = 256, ST_DTU = 448, ST_IDX = 464, ST_ITEM = P1_ITEM };
+    float* const stg = reinterpret_cast<float*>(smem + P1_STG) + (size_t)W * (2 * 2 * ST_ITEM);
     const long long n_pairs = (n1 - n0 + 1) / 2;
     const int e_row = fr >> 4, u_row = fr & 15;              // as a ROW of the pair's tile this lane is unit u_row of item e_row
-    const float* Rt = p.R + (size_t)(t - 2) * p.nr * 128;
+    uint16_t* const mask_t = p.mask + ((size_t)(t - 2) * ((p.nr + 1) / 2)) * 256;
     float db2a[2] = {0.f, 0.f};                              // kq == 0: sum over steps of demb's column sums, channels 2 lane, 2 lane + 1
-    struct Raw { float2 d, d2, q, r; float x0, x1, x2, dt; unsigned a; bool valid; };
+    struct Raw { float2 d, d2, q; float x0, x1, x2, dt; unsigned a; bool valid; };
     auto load_raw = [&](long long pi, int e) {
         Raw r;
         long long n = n0 + 2 * pi + e;
@@ -144,7 +142,6 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
         r.d = *reinterpret_cast<const float2*>(dx);
         r.d2 = t == 3 ? *reinterpret_cast<const float2*>(dx + 2 * 128) : make_float2(0.f, 0.f);
         r.q = *reinterpret_cast<const float2*>(p.q + n * p.ldq + 2 * lane);
-        r.r = *reinterpret_cast<const float2*>(Rt + n * 128 + 2 * lane);
         const float* xr = p.obs + n * PM_OBS + 3 + cum * 12 + lane;
         r.x0 = xr[0]; r.x1 = xr[64]; r.x2 = xr[128];
         r.dt = lane < 16 ? p.dtu[n * 40 + cum + lane] : 0.f;
@@ -156,19 +153,11 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
         float* b = stg + (buf * 2 + e) * ST_ITEM;
         const float d0 = r.valid ? r.d.x + r.d2.x : 0.f, d1 = r.valid ? r.d.y + r.d2.y : 0.f;      // policy.py:127: enh feeds two slots
         const float dt = r.valid ? r.dt : 0.f;
-        {   // the two f16 pieces of d x s_grad, one dword per channel
-            const float x0 = d0 * s_grad, x1 = d1 * s_grad;
-            const unsigned hh = cvt_pk_f16(x0, x1);
-            const f16x2_t hv = __builtin_bit_cast(f16x2_t, hh);
-            const unsigned mm = cvt_pk_f16(x0 - (float)hv.x, x1 - (float)hv.y);
-            *reinterpret_cast<uint2*>(b + ST_D + 2 * lane) = make_uint2((hh & 0xffffu) | (mm << 16), (hh >> 16) | (mm & 0xffff0000u));
-        }
-        *reinterpret_cast<float2*>(b + ST_R + 2 * lane) = r.r;
+        *reinterpret_cast<uint2*>(b + ST_D + 2 * lane) = stage_pieces(d0, d1, s_grad);
         *reinterpret_cast<float2*>(b + ST_Q + 2 * lane) = r.q;
         b[ST_X + lane] = r.x0; b[ST_X + 64 + lane] = r.x1; b[ST_X + 128 + lane] = r.x2;
         if (lane < 16) b[ST_DTU + lane] = dt;
         if (lane < 32) {
-            reinterpret_cast<unsigned*>(b + ST_A)[lane] = r.a;
             // four channels at once: slot = (a & 3) | ((a >> 1) & 4), group = (a >> 2) & 1; entry = slot | 8 for the OTHER group
             const unsigned jj = (r.a & 0x03030303u) | ((r.a >> 1) & 0x04040404u), g1 = (r.a >> 2) & 0x01010101u;
             reinterpret_cast<unsigned*>(b + ST_IDX)[lane] = jj | (g1 << 3);                          // lane group 0
@@ -189,35 +178,31 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
         const Raw r0 = load_raw(st, 0), r1 = load_raw(st, 1);
         store_raw(r0, 0, 0); store_raw(r1, 0, 1);
     }
-    const float rs = s_grad * p.s_w;                         // scale of the d(basic) accumulators
-#ifdef DC_PM_TIMING      // A/B build: s_memtime sums per phase of every wave of workgroup 0 -> p.slab (garbage results; a measuring aid only)
-    long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm0 = __builtin_amdgcn_s_memtime();
-#define PM_STAMP(i) { const long long x_ = __builtin_amdgcn_s_memtime(); tm[i] += x_ - tm0; tm0 = x_; }
-#else
-#define PM_STAMP(i)
-#endif
     int buf = 0;
     for (long long pi = st; pi < n_pairs; pi += 2, buf ^= 1) {
         const bool more = pi + 2 < n_pairs;                  // wave-uniform
         Raw nx0, nx1;
         if (more) { nx0 = load_raw(pi + 2, 0); nx1 = load_raw(pi + 2, 1); }
         __builtin_amdgcn_wave_barrier();
-        PM_STAMP(0)
         const float* it0 = stg + (buf * 2) * ST_ITEM;        // item e of the pair: it0 + e * ST_ITEM
         const float* itr = it0 + e_row * ST_ITEM;            // the item this lane's ROW belongs to
 
-        // ---- first layer: basic x s_act of the pair's 32 rows, this wave's 32 hidden units ----------------------------------------
+        // ---- first layer: basic of the pair's 32 rows, this wave's 32 hidden units; its relu masks for kernel 2 -----------------------
         f32x16 basic;                                        // relu(x W1^T + b1), unscaled: row 8 (r >> 2) + 4 fq + (r & 3), hidden unit 32 kq + fr
         {
             const float* xp = itr + ST_X + u_row * 12 + fq;  // A operand of MFMA kk: x[row][feature 2 kk + fq]
             f32x16 g = {};
 #pragma unroll
             for (int kk = 0; kk < 6; ++kk) g = __builtin_amdgcn_mfma_f32_32x32x2f32(xp[2 * kk], w1f[kk], g, 0, 0, 0);
+            unsigned bits = 0u;                              // bit r: D register r of this lane is past the relu
 #pragma unroll
-            for (int r = 0; r < 16; ++r) basic[r] = relu_nan(g[r] + b1v);
+            for (int r = 0; r < 16; ++r) {
+                basic[r] = relu_nan(g[r] + b1v);
+                bits |= (basic[r] > 0.f ? 1u : 0u) << r;
+            }
+            mask_t[((size_t)((n0 >> 1) + pi) * 64 + lane) * 4 + kq] = (uint16_t)bits;
         }
 
-        PM_STAMP(1)
         // ---- dW2^T += basic^T demb, item by item (K = the item's 16 units) -------------------------------------------------------------
         float s_att[2];
 #pragma unroll
@@ -238,7 +223,7 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
             }
             f16x8 hot[4];
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) hot[cb] = *reinterpret_cast<const f16x8*>(smem + PM_TAB + idx[cb] * 16);
+            for (int cb = 0; cb < 4; ++cb) hot[cb] = *reinterpret_cast<const f16x8*>(smem + P1_TAB + idx[cb] * 16);
             // one-hot over the lane group's eight K slots: the table entry (f16 1.0 at the unit's slot, or zeros) times the piece - eight
             // packed f16 multiplies by exactly 0 or 1 instead of compares and selects per register
             Split2h B[4];
@@ -264,7 +249,6 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
                 s_att[e] = (sk + __uint_as_float(fq ? sw[0] : sw[1])) * (s_grad * s_act);   // ... plus the other group's (lane ^ 32); dtu is a gradient
             }
         }
-        PM_STAMP(2)
         {   // the rank-one attention term of BOTH items (s = 0 for a step whose head is off: no branch - a branch that touches the
             // accumulators costs a copy of them): K slots 0 and 1 of lane group 0 carry A[k][e] = s_e[k], B[e][c] = q_e[c]
             const unsigned sh = cvt_pk_f16(s_att[0], s_att[1]);
@@ -290,14 +274,145 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1.h, B1[cb].h, acc[cb], 0, 0, 0);
         }
+        __builtin_amdgcn_wave_barrier();
+        if (more) { store_raw(nx0, buf ^ 1, 0); store_raw(nx1, buf ^ 1, 1); }
+    }
 
-        PM_STAMP(3)
-        // ---- d(basic) x s_grad s_w = demb W2: eight K steps of 16 channels, the pair's 32 rows ------------------------------------------
-        f32x16 cacc = {};
+    // ---- results: the two streams meet through LDS (stream 1 writes, stream 0 adds and stores) ---------------------------------------------
+    __syncthreads();                                         // every wave is done with its staging block
+    float* racc = reinterpret_cast<float*>(smem + P1_RED_ACC) + (size_t)kq * 64 * 64 + lane;
+    float* rb = reinterpret_cast<float*>(smem + P1_RED_B);
+    if (st == 1) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) racc[(16 * cb + r) * 64] = acc[cb][r];
+        if (kq == 0) { rb[lane] = db2a[0]; rb[64 + lane] = db2a[1]; }
+    }
+    __syncthreads();
+    if (st == 0) {
+        const float inv = 1.f / (s_act * s_grad);
+        float* out = p.slab + (size_t)blockIdx.x * 128 * 128;            // [c][k]
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 v;
+                v.x = (acc[cb][4 * g4 + 0] + racc[(16 * cb + 4 * g4 + 0) * 64]) * inv;
+                v.y = (acc[cb][4 * g4 + 1] + racc[(16 * cb + 4 * g4 + 1) * 64]) * inv;
+                v.z = (acc[cb][4 * g4 + 2] + racc[(16 * cb + 4 * g4 + 2) * 64]) * inv;
+                v.w = (acc[cb][4 * g4 + 3] + racc[(16 * cb + 4 * g4 + 3) * 64]) * inv;
+                *reinterpret_cast<float4*>(out + (size_t)(32 * cb + fr) * 128 + 32 * kq + 8 * g4 + 4 * fq) = v;
+            }
+        if (kq == 0)
+            *reinterpret_cast<float2*>(p.part2 + (size_t)blockIdx.x * 128 + 2 * lane) = make_float2(db2a[0] + rb[lane], db2a[1] + rb[64 + lane]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Kernel 2: d(basic) = demb W2 for all 128 hidden units, through kernel 1's relu masks, folded into dW1^T / db1
+// ---------------------------------------------------------------------------------------------------------------------------------------
+enum : int {   // LDS (bytes)
+    P2_W2P = 0,                      // [piece 2][K step 8][fq 2][k 128][8 channels] f16: the B operand of the d(basic) product (W2 x s_w)
+    P2_STG = 65536,                  // every wave's own staging block: 2 buffers x 2 items x 2.1 KB
+    P2_ITEM = 528,                   // dwords per item; 528 = 16 mod 64
+    P2_RED = 0,                      // at the end, over the W2 image: the running sum [13][128] f32 of the waves' fold tiles
+    P2_LDS = P2_STG + 8 * 4 * P2_ITEM * 4
+};
+
+// bit `pos` of `bits` ? x : 0 - a sign-extended one-bit field (all ones or zero) and an AND: two instructions
+__device__ __forceinline__ float keep_if(float x, unsigned bits, int pos) {
+    return __uint_as_float(__float_as_uint(x) & (unsigned)__builtin_amdgcn_sbfe((int)bits, pos, 1));
+}
+
+__global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw1_kernel(PoolMArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int W = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fq = lane >> 5;
+    const int t = 2 + blockIdx.x / p.wg_per_type;
+    const int wgi = blockIdx.x % p.wg_per_type;
+    const long long n0 = (long long)wgi * p.steps_per_wg;
+    const long long n1 = min(p.nr, n0 + p.steps_per_wg);
+    const int cum = t == 2 ? 6 : 22;
+    const int slot0 = t == 2 ? 3 : 4;
+    const float s_act = p.s_act, s_grad = p.s_grad;
+
+    // ---- W2 of the type -> LDS as the d(basic) product's B operand: element (c, k) at [piece][c >> 4][(c >> 3) & 1][k][c & 7] ----------
+    {
+        const float* W2t = p.W2 + (size_t)t * 128 * 128;     // [c][k]
+        for (int e = tid; e < 128 * 16; e += PM_THREADS) {
+            const int k = e & 127, oct = e >> 7;             // channels 8 oct .. 8 oct + 7
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = W2t[(size_t)(8 * oct + j) * 128 + k];
+            const Split2h sp = split8(v, p.s_w);
+            const int off = (((oct >> 1) * 2 + (oct & 1)) * 128 + k) * 16;
+            *reinterpret_cast<f16x8*>(smem + P2_W2P + off) = sp.h;
+            *reinterpret_cast<f16x8*>(smem + P2_W2P + 32768 + off) = sp.m;
+        }
+    }
+    const float inv_w = 1.f / p.s_w;
+    const float rs = s_grad * p.s_w;                         // scale of the d(basic) accumulators
+    f32x16 facc[4];                                          // dW1^T[f = row][k = 32 kb + col] x s_act s_grad; row 12: db1
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { facc[0][r] = 0.f; facc[1][r] = 0.f; facc[2][r] = 0.f; facc[3][r] = 0.f; }
+    __syncthreads();                                         // the W2 image
+
+    // Block of an item (dwords): d(xcat) pieces [128] | R [128] | arg-max bytes [128 B] | unit records [16][12] | dtu [16]
+    enum { ST_D = 0, ST_R = 128, ST_A = 256, ST_X = 288, ST_DTU = 480, ST_ITEM = P2_ITEM };
+    float* const stg = reinterpret_cast<float*>(smem + P2_STG) + (size_t)W * (2 * 2 * ST_ITEM);
+    const long long n_pairs = (n1 - n0 + 1) / 2;
+    const int e_row = fr >> 4, u_row = fr & 15;
+    const float* Rt = p.R + (size_t)(t - 2) * p.nr * 128;
+    const uint16_t* const mask_t = p.mask + ((size_t)(t - 2) * ((p.nr + 1) / 2)) * 256;
+    struct Raw { float2 d, d2, r; float x0, x1, x2, dt; unsigned a; bool valid; };
+    auto load_raw = [&](long long pi, int e) {
+        Raw r;
+        long long n = n0 + 2 * pi + e;
+        const bool valid = n < n1;
+        n = valid ? n : n1 - 1;
+        const float* dx = p.dxcat + n * PM_XCAT + slot0 * 128 + 2 * lane;
+        r.d = *reinterpret_cast<const float2*>(dx);
+        r.d2 = t == 3 ? *reinterpret_cast<const float2*>(dx + 2 * 128) : make_float2(0.f, 0.f);
+        r.r = *reinterpret_cast<const float2*>(Rt + n * 128 + 2 * lane);
+        const float* xr = p.obs + n * PM_OBS + 3 + cum * 12 + lane;
+        r.x0 = xr[0]; r.x1 = xr[64]; r.x2 = xr[128];
+        r.dt = lane < 16 ? p.dtu[n * 40 + cum + lane] : 0.f;
+        r.a = lane < 32 ? reinterpret_cast<const unsigned*>(p.amax + (n * 3 + (t - 1)) * 128)[lane] : 0u;
+        r.valid = valid;
+        return r;
+    };
+    auto store_raw = [&](const Raw& r, int buf, int e) {
+        float* b = stg + (buf * 2 + e) * ST_ITEM;
+        const float d0 = r.valid ? r.d.x + r.d2.x : 0.f, d1 = r.valid ? r.d.y + r.d2.y : 0.f;
+        *reinterpret_cast<uint2*>(b + ST_D + 2 * lane) = stage_pieces(d0, d1, s_grad);
+        *reinterpret_cast<float2*>(b + ST_R + 2 * lane) = r.r;
+        b[ST_X + lane] = r.x0; b[ST_X + 64 + lane] = r.x1; b[ST_X + 128 + lane] = r.x2;
+        if (lane < 16) b[ST_DTU + lane] = r.valid ? r.dt : 0.f;
+        if (lane < 32) reinterpret_cast<unsigned*>(b + ST_A)[lane] = r.a;
+    };
+    if (W < n_pairs) {
+        const Raw r0 = load_raw(W, 0), r1 = load_raw(W, 1);
+        store_raw(r0, 0, 0); store_raw(r1, 0, 1);
+    }
+    int buf = 0;
+    for (long long pi = W; pi < n_pairs; pi += 8, buf ^= 1) {           // a wave takes whole pairs
+        const bool more = pi + 8 < n_pairs;
+        Raw nx0, nx1;
+        if (more) { nx0 = load_raw(pi + 8, 0); nx1 = load_raw(pi + 8, 1); }
+        __builtin_amdgcn_wave_barrier();
+        const float* it0 = stg + (buf * 2) * ST_ITEM;
+        const float* itr = it0 + e_row * ST_ITEM;
+
+        // ---- d(basic) x s_grad s_w = demb W2: eight K steps of 16 channels, the pair's 32 rows x all 128 hidden units ---------------------
+        f32x16 cacc[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) cacc[kb] = f32x16{};
         {
             const unsigned* dr = reinterpret_cast<const unsigned*>(itr + ST_D) + 8 * fq;
             const uint8_t* ar = reinterpret_cast<const uint8_t*>(itr + ST_A) + 8 * fq;
-            const char* w2l = smem + PM_W2P + (fq * 128 + 32 * kq + fr) * 16;
+            const char* w2l = smem + P2_W2P + (fq * 128 + fr) * 16;
             auto build = [&](int ks) {             // the A operand of K step ks: selects of the staged pieces, re-packed h with h, m with m
                 const uint4 d0 = *reinterpret_cast<const uint4*>(dr + 16 * ks), d1 = *reinterpret_cast<const uint4*>(dr + 16 * ks + 4);
                 const unsigned d2[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
@@ -319,129 +434,105 @@ __global__ __launch_bounds__(PM_THREADS) void embed_bwd_pool16m_kernel(PoolMArgs
                 o.m = __builtin_bit_cast(f16x8, am);
                 return o;
             };
-            // software pipeline: the operand of K step ks + 1 is built (LDS round trip + selects) while the three dependent MFMAs of K step ks run
+            // software pipeline: the operand of K step ks + 1 is built while the twelve MFMAs of K step ks run (four independent chains)
             Split2h Aop = build(0);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                Split2h B;
-                B.h = *reinterpret_cast<const f16x8*>(w2l + ks * 4096);
-                B.m = *reinterpret_cast<const f16x8*>(w2l + 32768 + ks * 4096);
+                f16x8 Bh[4], Bm[4];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    Bh[kb] = *reinterpret_cast<const f16x8*>(w2l + ks * 4096 + kb * 512);
+                    Bm[kb] = *reinterpret_cast<const f16x8*>(w2l + 32768 + ks * 4096 + kb * 512);
+                }
                 const Split2h cur = Aop;
                 if (ks + 1 < 8) Aop = build(ks + 1);
-                cacc = mma3(cur, B, cacc);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) cacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.m, Bh[kb], cacc[kb], 0, 0, 0);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) cacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.h, Bm[kb], cacc[kb], 0, 0, 0);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) cacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.h, Bh[kb], cacc[kb], 0, 0, 0);
             }
         }
-        PM_STAMP(4)
-        // the attention term of d(basic), in f32: + dtu[u] R[k] (zero for a step whose head is off); then through the relu
+        // ---- + dtu[u] R[k] (the attention term, f32), through the relu (kernel 1's masks), into dW1^T / db1: K step e = item e's 16 units ----
+        const uint2 mbits = *reinterpret_cast<const uint2*>(mask_t + ((size_t)((n0 >> 1) + pi) * 64 + lane) * 4);     // this lane's 4 x 16 bits
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const float* it = it0 + e * ST_ITEM;
-            const float Rk = it[ST_R + 32 * kq + fr] * rs;
             const float4 du0 = *reinterpret_cast<const float4*>(it + ST_DTU + 4 * fq), du1 = *reinterpret_cast<const float4*>(it + ST_DTU + 8 + 4 * fq);
             const float du[8] = {du0.x, du0.y, du0.z, du0.w, du1.x, du1.y, du1.z, du1.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) cacc[8 * e + j] = fmaf(du[j], Rk, cacc[8 * e + j]);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cacc[r] = basic[r] > 0.f ? cacc[r] * inv_w : 0.f;      // = relu'(.) d(basic) x s_grad
-        // ---- dW1^T / db1 += x^T d(basic): K step e = item e's 16 units ---------------------------------------------------------------------
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float bv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) bv[j] = cacc[8 * e + j];
-            const float* xr = it0 + e * ST_ITEM + ST_X + (4 * fq) * 12 + min(fr, 11);      // x[unit 4 fq + ..][feature fr]
+            const float* xr = it + ST_X + (4 * fq) * 12 + min(fr, 11);               // x[unit 4 fq + ..][feature fr]
             float xv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float xx = xr[((j & 3) + 8 * (j >> 2)) * 12];
                 xv[j] = fr < 12 ? xx : (fr == 12 ? 1.f : 0.f);
             }
-            facc = mma3(split8(xv, s_act), split8_noscale(bv), facc);
+            const Split2h X = split8(xv, s_act);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const float Rk = it[ST_R + 32 * kb + fr] * rs;
+                float bv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bv[j] = keep_if(fmaf(du[j], Rk, cacc[kb][8 * e + j]), kb < 2 ? mbits.x : mbits.y, 16 * (kb & 1) + 8 * e + j);
+                facc[kb] = mma3(X, split8(bv, inv_w), facc[kb]);                    // (the accumulators carry s_w: taken out in the split)
+            }
         }
-        PM_STAMP(5)
         __builtin_amdgcn_wave_barrier();
         if (more) { store_raw(nx0, buf ^ 1, 0); store_raw(nx1, buf ^ 1, 1); }
-        PM_STAMP(6)
     }
-#ifdef DC_PM_TIMING
-    if (blockIdx.x == 0 && lane == 0)
-        for (int i = 0; i < 8; ++i) reinterpret_cast<long long*>(p.part1)[W * 8 + i] = tm[i];
-    __syncthreads();
-    if (blockIdx.x == 0 && tid == 0) {
-        const long long* tt = reinterpret_cast<const long long*>(p.part1);
-        for (int w = 0; w < 8; ++w)
-            printf("pool16m wave %d (cycles per pair): loads+wait %lld  first layer %lld  dW2 %lld  rank-one %lld  d(basic) %lld  fixup+fold %lld  stage %lld\n", w,
-                   tt[w * 8 + 0] / (n_pairs / 2), tt[w * 8 + 1] / (n_pairs / 2), tt[w * 8 + 2] / (n_pairs / 2), tt[w * 8 + 3] / (n_pairs / 2),
-                   tt[w * 8 + 4] / (n_pairs / 2), tt[w * 8 + 5] / (n_pairs / 2), tt[w * 8 + 6] / (n_pairs / 2));
-    }
-#endif
 
-    // ---- results: the two streams meet through LDS (stream 1 writes, stream 0 adds and stores) ---------------------------------------------
+    // ---- results: the eight waves' fold tiles summed in a fixed order through LDS -> part1[wg][13][128] ---------------------------------
     __syncthreads();                                         // every wave is done with the W2 image
-    float* racc = reinterpret_cast<float*>(smem + PM_RED_ACC) + (size_t)kq * 64 * 64 + lane;
-    float* rf = reinterpret_cast<float*>(smem + PM_RED_F) + (size_t)kq * 16 * 64 + lane;
-    float* rb = reinterpret_cast<float*>(smem + PM_RED_B);
-    if (st == 1) {
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) racc[(16 * cb + r) * 64] = acc[cb][r];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rf[r * 64] = facc[r];
-        if (kq == 0) { rb[lane] = db2a[0]; rb[64 + lane] = db2a[1]; }
-    }
+    float* red = reinterpret_cast<float*>(smem + P2_RED);   // [13][128]
+    for (int e = tid; e < 13 * 128; e += PM_THREADS) red[e] = 0.f;
     __syncthreads();
-    if (st == 0) {
-        const float inv = 1.f / (s_act * s_grad);
-        float* out = p.slab + (size_t)blockIdx.x * 128 * 128;            // [c][k]
+    for (int ww = 0; ww < 8; ++ww) {
+        if (W == ww) {
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+            for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                float4 v;
-                v.x = (acc[cb][4 * g4 + 0] + racc[(16 * cb + 4 * g4 + 0) * 64]) * inv;
-                v.y = (acc[cb][4 * g4 + 1] + racc[(16 * cb + 4 * g4 + 1) * 64]) * inv;
-                v.z = (acc[cb][4 * g4 + 2] + racc[(16 * cb + 4 * g4 + 2) * 64]) * inv;
-                v.w = (acc[cb][4 * g4 + 3] + racc[(16 * cb + 4 * g4 + 3) * 64]) * inv;
-                *reinterpret_cast<float4*>(out + (size_t)(32 * cb + fr) * 128 + 32 * kq + 8 * g4 + 4 * fq) = v;
-            }
-        float* o1 = p.part1 + (size_t)blockIdx.x * 1664;                  // [13][128]
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = 8 * (r >> 2) + 4 * fq + (r & 3);
-            if (f < 13) o1[f * 128 + 32 * kq + fr] = (facc[r] + rf[r * 64]) * inv;
+                for (int r = 0; r < 16; ++r) {
+                    const int f = 8 * (r >> 2) + 4 * fq + (r & 3);
+                    if (f < 13) red[f * 128 + 32 * kb + fr] += facc[kb][r];
+                }
         }
-        if (kq == 0)
-            *reinterpret_cast<float2*>(p.part2 + (size_t)blockIdx.x * 128 + 2 * lane) = make_float2(db2a[0] + rb[lane], db2a[1] + rb[64 + lane]);
+        __syncthreads();
     }
+    const float inv = 1.f / (s_act * s_grad);
+    float* o1 = p.part1 + (size_t)blockIdx.x * 1664;
+    for (int e = tid; e < 1664; e += PM_THREADS) o1[e] = red[e] * inv;
 }
 
 // Same outputs as embed_bwd_pool16 (embed_sparse.hip): slab 2 * wg_per_type x [128][128], part1 2 * wg_per_type x [13][128],
 // part2 2 * wg_per_type x [128] - per-workgroup partials in the formats the dense path's reducers take.
+// scratch: 2 * nr * 128 floats (R) + 2 * ceil(nr / 2) * 64 lanes x 8 bytes (the relu masks) = 384 floats per step
 int embed_bwd_pool16m(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq,
-                      const float* W1, const float* b1, const float* W2, float* slab, float* part1, float* part2, float* scratch_r,
+                      const float* W1, const float* b1, const float* W2, float* slab, float* part1, float* part2, float* scratch,
                       long long nr, int wg_per_type, hipStream_t s, const F16x2Scales& f16) {
     PoolMArgs a{obs, dxcat, amax, dtu, q, ldq, W1, b1, W2, slab, part1, part2, nr, wg_per_type,
                 (int)(((nr + wg_per_type - 1) / wg_per_type + 1) / 2 * 2),      // even: a pair never straddles two workgroups
-                f16.s_act, f16.s_w, f16.s_grad, scratch_r};
+                f16.s_act, f16.s_w, f16.s_grad, scratch, reinterpret_cast<uint16_t*>(scratch + 2 * nr * 128)};
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)embed_bwd_pool16m_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PM_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)embed_pool16m_dw2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P1_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)embed_pool16m_dw1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P2_LDS);
         if (e != hipSuccess) { set_error("embed_bwd_pool16m: hipFuncSetAttribute", (int)e); return (int)e; }
         attr = true;
     }
     // R[n][k] = sum_c q[n][c] W2_t[c][k] of every step and type: the attention term of d(basic) is dtu[u] R[k] (2 x 2 GFLOP, f32)
     for (int t = 2; t < 4; ++t)
-        if (int e = gemm_f32(q, W2 + (size_t)t * 128 * 128, scratch_r + (size_t)(t - 2) * nr * 128, (int)nr, 128, 128, ldq, 128, 128, 0, 1,
+        if (int e = gemm_f32(q, W2 + (size_t)t * 128 * 128, scratch + (size_t)(t - 2) * nr * 128, (int)nr, 128, 128, ldq, 128, 128, 0, 1,
                              nullptr, 0, nullptr, 0, 0, 1, s))
             return e;
     // algorithmic work = the sparse form's (embed_sparse.hip counts the same): basic + dW1 fold 2 x 16 x 128 x 12 MACs, the two gathers
     // 2 x 128 x 128 MACs per step and type; what EXECUTES is the dense form, 16 x the gathers' MACs, on the matrix cores
     ProfScope prof("embed_bwd_pool16", 2.0 * 2.0 * nr * (2.0 * 16 * 128 * 12 + 2.0 * 128 * 128),
                    4.0 * 2.0 * nr * (16 * 12 + 3 * 128 + 16 + 32), s);
-    hipLaunchKernelGGL(embed_bwd_pool16m_kernel, dim3(2 * wg_per_type), dim3(PM_THREADS), PM_LDS, s, a);
-    return launch_check("embed_bwd_pool16m");
+    hipLaunchKernelGGL(embed_pool16m_dw2_kernel, dim3(2 * wg_per_type), dim3(PM_THREADS), P1_LDS, s, a);
+    if (int e = launch_check("embed_pool16m_dw2")) return e;
+    hipLaunchKernelGGL(embed_pool16m_dw1_kernel, dim3(2 * wg_per_type), dim3(PM_THREADS), P2_LDS, s, a);
+    return launch_check("embed_pool16m_dw1");
 }
 
 }  // namespace dc
