@@ -126,7 +126,7 @@ __global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw2_kernel(PoolMArgs
     // are in flight while pair i computes, so no operand build ever waits for HBM, and no wave ever waits for another.
     // Block of an item (dwords): d(xcat) pieces [128] | q [128] | unit records [16][12] | dtu [16] | per channel and lane group, the
     // one-hot table entry of the arg-max unit: slot (a & 3) + 4 (a >> 3) if the unit is of the group, else >= 8 [2][128 B]
-    enum { ST_D = 0, ST_Q = 128, ST_X = 256, ST_DTU = 448, ST_IDX = 464, ST_ITEM = P1_ITEM };
+    enum { ST_D = 0, ST_Q = 128, ST_X = 256, ST_DTU = 448, ST_IDX = 464, ST_LIVE = 528, ST_ITEM = P1_ITEM };     // ... | 1 if any dtu != 0
     float* const stg = reinterpret_cast<float*>(smem + P1_STG) + (size_t)W * (2 * 2 * ST_ITEM);
     const long long n_pairs = (n1 - n0 + 1) / 2;
     const int e_row = fr >> 4, u_row = fr & 15;              // as a ROW of the pair's tile this lane is unit u_row of item e_row
@@ -157,6 +157,8 @@ __global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw2_kernel(PoolMArgs
         *reinterpret_cast<float2*>(b + ST_Q + 2 * lane) = r.q;
         b[ST_X + lane] = r.x0; b[ST_X + 64 + lane] = r.x1; b[ST_X + 128 + lane] = r.x2;
         if (lane < 16) b[ST_DTU + lane] = dt;
+        const unsigned long long nz = __ballot(dt != 0.f);
+        if (lane == 0) reinterpret_cast<int*>(b)[ST_LIVE] = nz != 0ull;
         if (lane < 32) {
             // four channels at once: slot = (a & 3) | ((a >> 1) & 4), group = (a >> 2) & 1; entry = slot | 8 for the OTHER group
             const unsigned jj = (r.a & 0x03030303u) | ((r.a >> 1) & 0x04040404u), g1 = (r.a >> 2) & 0x01010101u;
@@ -174,34 +176,45 @@ __global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw2_kernel(PoolMArgs
             db2a[1] += fmaf(r.q.y, sumdtu, d1);
         }
     };
+    // first layer of the pair staged in buffer b: basic of its 32 rows, this wave's 32 hidden units (unscaled: row 8 (r >> 2) + 4 fq + (r & 3))
+    auto first_layer = [&](int b) {
+        const float* xp = stg + (b * 2 + e_row) * ST_ITEM + ST_X + u_row * 12 + fq;     // A operand of MFMA kk: x[row][feature 2 kk + fq]
+        f32x16 g = {};
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) g = __builtin_amdgcn_mfma_f32_32x32x2f32(xp[2 * kk], w1f[kk], g, 0, 0, 0);
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = relu_nan(g[r] + b1v);
+        return o;
+    };
+    // Software pipeline over the pairs of the stream: while pair i's products run, pair i + 1 is staged (its loads were issued an iteration
+    // ago) and goes through the first layer (six dependent f32 MFMAs whose results nobody waits for), and pair i + 2's loads are issued.
+    Raw nx0, nx1;
+    f32x16 basic_next = {};
     if (st < n_pairs) {
         const Raw r0 = load_raw(st, 0), r1 = load_raw(st, 1);
         store_raw(r0, 0, 0); store_raw(r1, 0, 1);
+        if (st + 2 < n_pairs) { nx0 = load_raw(st + 2, 0); nx1 = load_raw(st + 2, 1); }
+        __builtin_amdgcn_wave_barrier();
+        basic_next = first_layer(0);
     }
     int buf = 0;
     for (long long pi = st; pi < n_pairs; pi += 2, buf ^= 1) {
         const bool more = pi + 2 < n_pairs;                  // wave-uniform
-        Raw nx0, nx1;
-        if (more) { nx0 = load_raw(pi + 2, 0); nx1 = load_raw(pi + 2, 1); }
-        __builtin_amdgcn_wave_barrier();
-        const float* it0 = stg + (buf * 2) * ST_ITEM;        // item e of the pair: it0 + e * ST_ITEM
-        const float* itr = it0 + e_row * ST_ITEM;            // the item this lane's ROW belongs to
-
-        // ---- first layer: basic of the pair's 32 rows, this wave's 32 hidden units; its relu masks for kernel 2 -----------------------
-        f32x16 basic;                                        // relu(x W1^T + b1), unscaled: row 8 (r >> 2) + 4 fq + (r & 3), hidden unit 32 kq + fr
-        {
-            const float* xp = itr + ST_X + u_row * 12 + fq;  // A operand of MFMA kk: x[row][feature 2 kk + fq]
-            f32x16 g = {};
+        const f32x16 basic = basic_next;
+        {   // its relu masks for kernel 2: bit r = D register r of this lane is past the relu
+            unsigned bits = 0u;
 #pragma unroll
-            for (int kk = 0; kk < 6; ++kk) g = __builtin_amdgcn_mfma_f32_32x32x2f32(xp[2 * kk], w1f[kk], g, 0, 0, 0);
-            unsigned bits = 0u;                              // bit r: D register r of this lane is past the relu
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                basic[r] = relu_nan(g[r] + b1v);
-                bits |= (basic[r] > 0.f ? 1u : 0u) << r;
-            }
+            for (int r = 0; r < 16; ++r) bits |= (basic[r] > 0.f ? 1u : 0u) << r;
             mask_t[((size_t)((n0 >> 1) + pi) * 64 + lane) * 4 + kq] = (uint16_t)bits;
         }
+        if (more) {
+            store_raw(nx0, buf ^ 1, 0); store_raw(nx1, buf ^ 1, 1);
+            if (pi + 4 < n_pairs) { nx0 = load_raw(pi + 4, 0); nx1 = load_raw(pi + 4, 1); }
+            __builtin_amdgcn_wave_barrier();
+            basic_next = first_layer(buf ^ 1);
+        }
+        const float* it0 = stg + (buf * 2) * ST_ITEM;        // item e of the pair: it0 + e * ST_ITEM
 
         // ---- dW2^T += basic^T demb, item by item (K = the item's 16 units) -------------------------------------------------------------
         float s_att[2];
@@ -249,8 +262,9 @@ __global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw2_kernel(PoolMArgs
                 s_att[e] = (sk + __uint_as_float(fq ? sw[0] : sw[1])) * (s_grad * s_act);   // ... plus the other group's (lane ^ 32); dtu is a gradient
             }
         }
-        {   // the rank-one attention term of BOTH items (s = 0 for a step whose head is off: no branch - a branch that touches the
-            // accumulators costs a copy of them): K slots 0 and 1 of lane group 0 carry A[k][e] = s_e[k], B[e][c] = q_e[c]
+        if (__builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(it0)[ST_LIVE] | reinterpret_cast<const int*>(it0)[ST_ITEM + ST_LIVE]) != 0) {
+            // the rank-one attention term of BOTH items, for a pair with a live target-unit head (about half of them; s = 0 for the
+            // other step of such a pair): K slots 0 and 1 of lane group 0 carry A[k][e] = s_e[k], B[e][c] = q_e[c]
             const unsigned sh = cvt_pk_f16(s_att[0], s_att[1]);
             const f16x2_t shv = __builtin_bit_cast(f16x2_t, sh);
             const unsigned sm = cvt_pk_f16(s_att[0] - (float)shv.x, s_att[1] - (float)shv.y);
@@ -275,7 +289,6 @@ __global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw2_kernel(PoolMArgs
             for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1.h, B1[cb].h, acc[cb], 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
-        if (more) { store_raw(nx0, buf ^ 1, 0); store_raw(nx1, buf ^ 1, 1); }
     }
 
     // ---- results: the two streams meet through LDS (stream 1 writes, stream 0 adds and stores) ---------------------------------------------
