@@ -95,7 +95,7 @@ def pmc_traffic(path, kernel, workload_key):
     if j.get('meta', {}).get('workload') not in (None, workload_key):
         return None
     # profiling region -> kernel(s) that run inside it (the first one present in the summary wins)
-    region_kernels = {'embed_bwd_pool16': ['embed_bwd_pool16w', 'embed_bwd_pool16'], 'gru_fwd_team': ['team_mfma_fwd_col', 'team_mfma_fwd', 'team8_fwd', 'rnn_team_fwd'],
+    region_kernels = {'embed_bwd_pool16': ['embed_bwd_pool16w', 'embed_bwd_pool16'], 'embed_bwd_pool16m': [('embed_pool16m_dw2', 'embed_pool16m_dw1')], 'gru_fwd_team': ['team_mfma_fwd_col', 'team_mfma_fwd', 'team8_fwd', 'rnn_team_fwd'],
                       'gru_bwd_team': ['team_mfma_bwd', 'team8_bwd', 'rnn_team_bwd'],
                       'lstm_fwd_team': ['team_mfma_fwd_col', 'team_mfma_fwd', 'team8_fwd', 'rnn_team_fwd'], 'lstm_bwd_team': ['team_mfma_bwd', 'team8_bwd', 'rnn_team_bwd'],
                       'lstm_fwd_persist': ['lstm_fwd_valu'], 'lstm_bwd_persist': ['lstm_bwd_valu'],
@@ -103,6 +103,11 @@ def pmc_traffic(path, kernel, workload_key):
     if PRODUCTS == 'f16x2':       # every dense product runs the split-on-load kernel then (one PMC row: the average over its launches)
         region_kernels['gemm_f32_fwd'] = region_kernels['gemm_f32_dX'] = ['gemm_x3', 'gemm_fast']
     for cand in region_kernels.get(kernel, [kernel]):
+        if isinstance(cand, tuple):                   # a region of several kernels, each launched once per pass: the sum
+            ks = [j.get('kernels', {}).get(c + '_kernel') for c in cand]
+            if all(ks):
+                return int(sum(k['bytes'] for k in ks))
+            continue
         k = j.get('kernels', {}).get(cand + '_kernel')
         if k:
             return int(k['bytes'])
@@ -299,7 +304,7 @@ def latency_peak(region, prec_bf16, hidden):
 REGION_BOUND = {
     'embed_fwd_fused': 'mfma', 'embed_bwd_dw2': 'mfma', 'embed_bwd_dw1': 'mfma', 'gemm_f32_fwd(NT)': 'mfma', 'gemm_f32_dX(NN)': 'mfma',
     'gemm_f32_dW(TN,split-K)': 'mfma',
-    'embed_bwd_pool16': 'valu',
+    'embed_bwd_pool16': 'valu', 'embed_bwd_pool16m': 'mfma',
     'lstm_fwd_persist': 'latency', 'lstm_bwd_persist': 'latency', 'gru_fwd_team': 'latency', 'gru_bwd_team': 'latency',
     'lstm_fwd_team': 'latency', 'lstm_bwd_team': 'latency', 'rnn_fwd_steps': 'latency', 'rnn_bwd_steps': 'latency',
     'pool_env_fwd': 'hbm', 'embed_scatter_bwd(+reduce)': 'hbm', 'ppo_loss(stats+loss+finalize)': 'hbm', 'gradnorm_clip_adam': 'hbm',
@@ -318,6 +323,12 @@ BOUND_NOTES = {
     'latency': 'recurrence, serial in time: bound by the per-step dependency chain (and, for the H=256 team kernels, the hand-off '
                'between the four CUs that share a sequence), not by arithmetic or HBM',
     'hbm': 'streams its operands once: priced against the 8 TB/s HBM peak',
+}
+REGION_NOTES = {
+    'embed_bwd_pool16m': 'max-pool backward of the two 16-unit types as the DENSE products of the reference\'s autograd (policy.py:102-136 under '
+                         'optimizer.py:672) on the f16 matrix cores, every operand generated on chip (csrc/embed_pool16m.hip: two kernels, dW2 and '
+                         'd(basic) -> dW1): flops = the dense count SURVEY.md 8(d) uses; round 4 ran the sparse form on the vector unit '
+                         '(embed_bwd_pool16: 21.5 GFLOP per launch in 683-719 us + a 110 us prepare pass, 0.19-0.20 of the 157 TF vector peak)',
 }
 PARITY_FULL_MAX = 65536   # env-steps per GPU up to which `parity` / `cpu_baseline` run the oracle on the whole timed batch
 KERNEL_FLAGS = 0      # --kernel-flags: DC_DIMS_* kernel-selection overrides for A/B runs (include/dotaclient_hip.h)
@@ -590,7 +601,7 @@ def main():
         P = eng.total
         alg_step_bytes = 2100.0 * (1 + E) * B * S + 28.0 * P * E            # 2.1 KB per env-step and pass + 28 B per parameter and optimizer step
         step_traffic = pmc_whole_step(args.traffic_json, workload_key, 1 + E)
-        roofline = {'bound': dom_bound, 'bound_note': BOUND_NOTES[dom_bound], 'kernel': dom['kernel'],
+        roofline = {'bound': dom_bound, 'bound_note': BOUND_NOTES[dom_bound], 'kernel': dom['kernel'], 'kernel_note': REGION_NOTES.get(dom['kernel']),
                     'achieved': round(achieved, 3), 'peak': round(dom_peak, 1),
                     'unit': 'TFLOP/s', 'frac': round(achieved / dom_peak, 4),
                     'traffic': pmc_traffic(args.traffic_json, dom['kernel'], workload_key),

@@ -538,10 +538,11 @@ int embed_bwd_pool16m(const float* obs, const float* dxcat, const uint8_t* amax,
         if (int e = gemm_f32(q, W2 + (size_t)t * 128 * 128, scratch + (size_t)(t - 2) * nr * 128, (int)nr, 128, 128, ldq, 128, 128, 0, 1,
                              nullptr, 0, nullptr, 0, 0, 1, s))
             return e;
-    // algorithmic work = the sparse form's (embed_sparse.hip counts the same): basic + dW1 fold 2 x 16 x 128 x 12 MACs, the two gathers
-    // 2 x 128 x 128 MACs per step and type; what EXECUTES is the dense form, 16 x the gathers' MACs, on the matrix cores
-    ProfScope prof("embed_bwd_pool16", 2.0 * 2.0 * nr * (2.0 * 16 * 128 * 12 + 2.0 * 128 * 128),
-                   4.0 * 2.0 * nr * (16 * 12 + 3 * 128 + 16 + 32), s);
+    // work = the DENSE form (what the reference's autograd computes for these units, what SURVEY.md 8(d) counts, and what executes here):
+    // per step and type the two 16 x 128 x 128 products, the first layer (K = 12) and the fold (13 rows); bytes: each kernel reads the
+    // step's records, d(xcat) slot(s), arg-max bytes, dtu and q or R once, plus the 256 B of relu masks written and read
+    ProfScope prof("embed_bwd_pool16m", 2.0 * 2.0 * nr * (2.0 * 16 * 128 * 128 + 16.0 * 128 * 12 + 16.0 * 128 * 13),
+                   2.0 * nr * (2.0 * (768 + 768 + 128 + 64) + 512 + 512 + 512), s);
     hipLaunchKernelGGL(embed_pool16m_dw2_kernel, dim3(2 * wg_per_type), dim3(PM_THREADS), P1_LDS, s, a);
     if (int e = launch_check("embed_pool16m_dw2")) return e;
     hipLaunchKernelGGL(embed_pool16m_dw1_kernel, dim3(2 * wg_per_type), dim3(PM_THREADS), P2_LDS, s, a);
