@@ -327,21 +327,27 @@ __global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw2_kernel(PoolMArgs
 // ---------------------------------------------------------------------------------------------------------------------------------------
 enum : int {   // LDS (bytes)
     P2_W2P = 0,                      // [piece 2][K step 8][fq 2][k 128][8 channels] f16: the B operand of the d(basic) product (W2 x s_w)
-    P2_STG = 65536,                  // every wave's own staging block: 2 buffers x 2 items x 2.1 KB
+    P2_STG = 65536,                  // every wave's own staging block: 2 items x 2.1 KB
     P2_ITEM = 528,                   // dwords per item; 528 = 16 mod 64
-    P2_RED = 0,                      // at the end, over the W2 image: the running sum [13][128] f32 of the waves' fold tiles
-    P2_LDS = P2_STG + 8 * 4 * P2_ITEM * 4
+    P2_RED = 0                       // at the end, over the W2 image: the running sum [13][128] f32 of the waves' fold tiles
 };
+constexpr int p2_lds(int waves) { return P2_STG + waves * 2 * P2_ITEM * 4; }
 
 // bit `pos` of `bits` ? x : 0 - a sign-extended one-bit field (all ones or zero) and an AND: two instructions
 __device__ __forceinline__ float keep_if(float x, unsigned bits, int pos) {
     return __uint_as_float(__float_as_uint(x) & (unsigned)__builtin_amdgcn_sbfe((int)bits, pos, 1));
 }
 
-__global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw1_kernel(PoolMArgs p) {
+// KSPLIT = 1, NSTREAM = 8 (the default): eight waves, all four k blocks each, two waves per SIMD.  KSPLIT = 2, NSTREAM = 6 (-DDC_PM_K2_SPLIT):
+// twelve waves, wave = (tile stream, k half) - half the accumulators, three waves per SIMD (four would need <= 128 registers: the compiler
+// spills 40) - measured 3 % SLOWER on the same box: the one-hot operand of a K step is then built twice, and occupancy was not the limit.
+template <int KSPLIT, int NSTREAM>
+__global__ __launch_bounds__(64 * KSPLIT * NSTREAM) void embed_pool16m_dw1_kernel(PoolMArgs p) {
+    constexpr int NT = 64 * KSPLIT * NSTREAM, NKB = 4 / KSPLIT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int W = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sw = W / KSPLIT, kb0 = (W % KSPLIT) * NKB;      // tile stream, first k block of this wave
     const int fr = lane & 31, fq = lane >> 5;
     const int t = 2 + blockIdx.x / p.wg_per_type;
     const int wgi = blockIdx.x % p.wg_per_type;
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw1_kernel(PoolMArgs
     // ---- W2 of the type -> LDS as the d(basic) product's B operand: element (c, k) at [piece][c >> 4][(c >> 3) & 1][k][c & 7] ----------
     {
         const float* W2t = p.W2 + (size_t)t * 128 * 128;     // [c][k]
-        for (int e = tid; e < 128 * 16; e += PM_THREADS) {
+        for (int e = tid; e < 128 * 16; e += NT) {
             const int k = e & 127, oct = e >> 7;             // channels 8 oct .. 8 oct + 7
             float v[8];
 #pragma unroll
@@ -367,14 +373,14 @@ __global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw1_kernel(PoolMArgs
     }
     const float inv_w = 1.f / p.s_w;
     const float rs = s_grad * p.s_w;                         // scale of the d(basic) accumulators
-    f32x16 facc[4];                                          // dW1^T[f = row][k = 32 kb + col] x s_act s_grad; row 12: db1
+    f32x16 facc[NKB];                                        // dW1^T[f = row][k = 32 (kb0 + i) + col] x s_act s_grad; row 12: db1
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { facc[0][r] = 0.f; facc[1][r] = 0.f; facc[2][r] = 0.f; facc[3][r] = 0.f; }
+    for (int i = 0; i < NKB; ++i) facc[i] = f32x16{};
     __syncthreads();                                         // the W2 image
 
     // Block of an item (dwords): d(xcat) pieces [128] | R [128] | arg-max bytes [128 B] | unit records [16][12] | dtu [16]
     enum { ST_D = 0, ST_R = 128, ST_A = 256, ST_X = 288, ST_DTU = 480, ST_ITEM = P2_ITEM };
-    float* const stg = reinterpret_cast<float*>(smem + P2_STG) + (size_t)W * (2 * 2 * ST_ITEM);
+    float* const stg = reinterpret_cast<float*>(smem + P2_STG) + (size_t)W * (2 * ST_ITEM);
     const long long n_pairs = (n1 - n0 + 1) / 2;
     const int e_row = fr >> 4, u_row = fr & 15;
     const float* Rt = p.R + (size_t)(t - 2) * p.nr * 128;
@@ -396,8 +402,8 @@ __global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw1_kernel(PoolMArgs
         r.valid = valid;
         return r;
     };
-    auto store_raw = [&](const Raw& r, int buf, int e) {
-        float* b = stg + (buf * 2 + e) * ST_ITEM;
+    auto store_raw = [&](const Raw& r, int e) {
+        float* b = stg + e * ST_ITEM;
         const float d0 = r.valid ? r.d.x + r.d2.x : 0.f, d1 = r.valid ? r.d.y + r.d2.y : 0.f;
         *reinterpret_cast<uint2*>(b + ST_D + 2 * lane) = stage_pieces(d0, d1, s_grad);
         *reinterpret_cast<float2*>(b + ST_R + 2 * lane) = r.r;
@@ -405,27 +411,26 @@ __global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw1_kernel(PoolMArgs
         if (lane < 16) b[ST_DTU + lane] = r.valid ? r.dt : 0.f;
         if (lane < 32) reinterpret_cast<unsigned*>(b + ST_A)[lane] = r.a;
     };
-    if (W < n_pairs) {
-        const Raw r0 = load_raw(W, 0), r1 = load_raw(W, 1);
-        store_raw(r0, 0, 0); store_raw(r1, 0, 1);
+    if (sw < n_pairs) {
+        const Raw r0 = load_raw(sw, 0), r1 = load_raw(sw, 1);
+        store_raw(r0, 0); store_raw(r1, 1);
     }
-    int buf = 0;
-    for (long long pi = W; pi < n_pairs; pi += 8, buf ^= 1) {           // a wave takes whole pairs
-        const bool more = pi + 8 < n_pairs;
+    for (long long pi = sw; pi < n_pairs; pi += NSTREAM) {              // a wave (a wave pair) takes whole pairs
+        const bool more = pi + NSTREAM < n_pairs;
         Raw nx0, nx1;
-        if (more) { nx0 = load_raw(pi + 8, 0); nx1 = load_raw(pi + 8, 1); }
+        if (more) { nx0 = load_raw(pi + NSTREAM, 0); nx1 = load_raw(pi + NSTREAM, 1); }      // in flight while this pair computes; staged at the bottom
         __builtin_amdgcn_wave_barrier();
-        const float* it0 = stg + (buf * 2) * ST_ITEM;
+        const float* it0 = stg;
         const float* itr = it0 + e_row * ST_ITEM;
 
         // ---- d(basic) x s_grad s_w = demb W2: eight K steps of 16 channels, the pair's 32 rows x all 128 hidden units ---------------------
-        f32x16 cacc[4];
+        f32x16 cacc[NKB];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) cacc[kb] = f32x16{};
+        for (int i = 0; i < NKB; ++i) cacc[i] = f32x16{};
         {
             const unsigned* dr = reinterpret_cast<const unsigned*>(itr + ST_D) + 8 * fq;
             const uint8_t* ar = reinterpret_cast<const uint8_t*>(itr + ST_A) + 8 * fq;
-            const char* w2l = smem + P2_W2P + (fq * 128 + fr) * 16;
+            const char* w2l = smem + P2_W2P + (fq * 128 + 32 * kb0 + fr) * 16;
             auto build = [&](int ks) {             // the A operand of K step ks: selects of the staged pieces, re-packed h with h, m with m
                 const uint4 d0 = *reinterpret_cast<const uint4*>(dr + 16 * ks), d1 = *reinterpret_cast<const uint4*>(dr + 16 * ks + 4);
                 const unsigned d2[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
@@ -447,24 +452,24 @@ __global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw1_kernel(PoolMArgs
                 o.m = __builtin_bit_cast(f16x8, am);
                 return o;
             };
-            // software pipeline: the operand of K step ks + 1 is built while the twelve MFMAs of K step ks run (four independent chains)
+            // software pipeline: the operand of K step ks + 1 is built while the 3 NKB MFMAs of K step ks run (NKB independent chains)
             Split2h Aop = build(0);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                f16x8 Bh[4], Bm[4];
+                f16x8 Bh[NKB], Bm[NKB];
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
+                for (int kb = 0; kb < NKB; ++kb) {
                     Bh[kb] = *reinterpret_cast<const f16x8*>(w2l + ks * 4096 + kb * 512);
                     Bm[kb] = *reinterpret_cast<const f16x8*>(w2l + 32768 + ks * 4096 + kb * 512);
                 }
                 const Split2h cur = Aop;
                 if (ks + 1 < 8) Aop = build(ks + 1);
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) cacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.m, Bh[kb], cacc[kb], 0, 0, 0);
+                for (int kb = 0; kb < NKB; ++kb) cacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.m, Bh[kb], cacc[kb], 0, 0, 0);
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) cacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.h, Bm[kb], cacc[kb], 0, 0, 0);
+                for (int kb = 0; kb < NKB; ++kb) cacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.h, Bm[kb], cacc[kb], 0, 0, 0);
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) cacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.h, Bh[kb], cacc[kb], 0, 0, 0);
+                for (int kb = 0; kb < NKB; ++kb) cacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.h, Bh[kb], cacc[kb], 0, 0, 0);
             }
         }
         // ---- + dtu[u] R[k] (the attention term, f32), through the relu (kernel 1's masks), into dW1^T / db1: K step e = item e's 16 units ----
@@ -483,38 +488,40 @@ __global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw1_kernel(PoolMArgs
             }
             const Split2h X = split8(xv, s_act);
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
+            for (int i = 0; i < NKB; ++i) {
+                const int kb = kb0 + i;
                 const float Rk = it[ST_R + 32 * kb + fr] * rs;
+                const unsigned mb = (kb < 2 ? mbits.x : mbits.y) >> (16 * (kb & 1));
                 float bv[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bv[j] = keep_if(fmaf(du[j], Rk, cacc[kb][8 * e + j]), kb < 2 ? mbits.x : mbits.y, 16 * (kb & 1) + 8 * e + j);
-                facc[kb] = mma3(X, split8(bv, inv_w), facc[kb]);                    // (the accumulators carry s_w: taken out in the split)
+                for (int j = 0; j < 8; ++j) bv[j] = keep_if(fmaf(du[j], Rk, cacc[i][8 * e + j]), mb, 8 * e + j);
+                facc[i] = mma3(X, split8(bv, inv_w), facc[i]);                      // (the accumulators carry s_w: taken out in the split)
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (more) { store_raw(nx0, buf ^ 1, 0); store_raw(nx1, buf ^ 1, 1); }
+        if (more) { store_raw(nx0, 0); store_raw(nx1, 1); }
     }
 
-    // ---- results: the eight waves' fold tiles summed in a fixed order through LDS -> part1[wg][13][128] ---------------------------------
+    // ---- results: the waves' fold tiles summed in a fixed order through LDS -> part1[wg][13][128] ---------------------------------
     __syncthreads();                                         // every wave is done with the W2 image
     float* red = reinterpret_cast<float*>(smem + P2_RED);   // [13][128]
-    for (int e = tid; e < 13 * 128; e += PM_THREADS) red[e] = 0.f;
+    for (int e = tid; e < 13 * 128; e += NT) red[e] = 0.f;
     __syncthreads();
-    for (int ww = 0; ww < 8; ++ww) {
-        if (W == ww) {
+    for (int ww = 0; ww < NSTREAM; ++ww) {                    // the KSPLIT waves of a stream own different k blocks: together
+        if (sw == ww) {
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+            for (int i = 0; i < NKB; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int f = 8 * (r >> 2) + 4 * fq + (r & 3);
-                    if (f < 13) red[f * 128 + 32 * kb + fr] += facc[kb][r];
+                    if (f < 13) red[f * 128 + 32 * (kb0 + i) + fr] += facc[i][r];
                 }
         }
         __syncthreads();
     }
     const float inv = 1.f / (s_act * s_grad);
     float* o1 = p.part1 + (size_t)blockIdx.x * 1664;
-    for (int e = tid; e < 1664; e += PM_THREADS) o1[e] = red[e] * inv;
+    for (int e = tid; e < 1664; e += NT) o1[e] = red[e] * inv;
 }
 
 // Same outputs as embed_bwd_pool16 (embed_sparse.hip): slab 2 * wg_per_type x [128][128], part1 2 * wg_per_type x [13][128],
@@ -529,7 +536,8 @@ int embed_bwd_pool16m(const float* obs, const float* dxcat, const uint8_t* amax,
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)embed_pool16m_dw2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P1_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)embed_pool16m_dw1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P2_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)embed_pool16m_dw1_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, p2_lds(8));
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)embed_pool16m_dw1_kernel<2, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, p2_lds(12));
         if (e != hipSuccess) { set_error("embed_bwd_pool16m: hipFuncSetAttribute", (int)e); return (int)e; }
         attr = true;
     }
@@ -545,7 +553,11 @@ int embed_bwd_pool16m(const float* obs, const float* dxcat, const uint8_t* amax,
                    2.0 * nr * (2.0 * (768 + 768 + 128 + 64) + 512 + 512 + 512), s);
     hipLaunchKernelGGL(embed_pool16m_dw2_kernel, dim3(2 * wg_per_type), dim3(PM_THREADS), P1_LDS, s, a);
     if (int e = launch_check("embed_pool16m_dw2")) return e;
-    hipLaunchKernelGGL(embed_pool16m_dw1_kernel, dim3(2 * wg_per_type), dim3(PM_THREADS), P2_LDS, s, a);
+#ifdef DC_PM_K2_SPLIT      // A/B build: twelve waves of half the accumulators, three per SIMD: 666-677 us for both kernels against 645-654 (same box)
+    hipLaunchKernelGGL((embed_pool16m_dw1_kernel<2, 6>), dim3(2 * wg_per_type), dim3(768), p2_lds(12), s, a);
+#else
+    hipLaunchKernelGGL((embed_pool16m_dw1_kernel<1, 8>), dim3(2 * wg_per_type), dim3(512), p2_lds(8), s, a);
+#endif
     return launch_check("embed_pool16m_dw1");
 }
 
