@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round 5: same-box A/B of two builds of the library (DC_LIB): bench without the CPU legs, alternating, two repetitions
-# usage: ALT=dotaclient_amd/libdotaclient_hip_<variant>.so [KEYS="embed_bwd_pool16m ..."] bash tools/gpu_r5_ab.sh <tag>
+# Same-box A/B of two builds of the library (DC_LIB): bench without the CPU legs, alternating, two repetitions
+# usage: ALT=dotaclient_amd/libdotaclient_hip_<variant>.so [KEYS="embed_bwd_pool16m ..."] bash tools/gpu_ab.sh <tag>
 OUT=gpurun_out/${1:-r5ab}; mkdir -p $OUT; export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "${TESTS:-sparse_pool}" 2>&1 | tail -2
 for rep in 1 2; do

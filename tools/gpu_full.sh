@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5: whole GPU suite + the driver's bench command (what the driver runs at round end)
+# Whole GPU suite + the driver's bench command (what the driver runs at round end)
 OUT=gpurun_out/${1:-r5full}; mkdir -p $OUT; export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -12 $OUT/pytest_gpu.log
 timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc $?"; tail -3 $OUT/bench.err

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5: quick look - the pool16 variants' correctness test, the bench without the CPU legs, rocprofv3 kernel stats of the interesting kernels
+# Quick look - the pool16 variants' correctness test, the bench without the CPU legs, rocprofv3 kernel stats of the interesting kernels
 OUT=gpurun_out/${1:-r5q}; mkdir -p $OUT; export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "sparse_pool" 2>&1 | tail -2
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-weak-unit ${BENCH_ARGS} > $OUT/bench.json 2> $OUT/bench.err
