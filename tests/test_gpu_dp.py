@@ -139,3 +139,73 @@ def test_two_rank_engines_match_reference_wrapper_gloo_one_device(tmp_path, over
 @pytest.mark.parametrize('overlap', [False, True])
 def test_two_rank_engines_match_reference_wrapper_rccl(tmp_path, overlap):
     _run_two_ranks(tmp_path, 'nccl', overlap)
+
+
+def test_overlapped_reduce_call_order_and_stream_ordering(monkeypatch):
+    # the overlapped data-parallel epoch (Engine.train_epoch with a FlatGradAllReducer, dotaclient_amd/distributed.py:53-68)
+    # has only ever met gloo, where "async" is synchronous.  What must hold on RCCL - checked here with a recording stand-in for
+    # torch.distributed on ONE process, real engine, real kernels:
+    #   1. order of the calls: backward(UPPER) -> async all-reduce of bucket[embed_floats:] (incl. the head flags) -> backward(EMBED) ->
+    #      all-reduce of bucket[:embed_floats] -> wait() of the first -> average kernel -> Adam;
+    #   2. stream ordering: at the moment the asynchronous all-reduce is CALLED, everything that writes its slice (the upper backward)
+    #      is already enqueued on the calling stream - RCCL's collective stream waits on exactly that - and nothing that writes the slice
+    #      is enqueued between the call and its wait(): an event recorded at the call is complete before the slice's checksum, taken on
+    #      the stream at wait() time, is read back, and that checksum equals the one taken right after the upper backward;
+    #   3. the two slices are disjoint and cover the bucket.
+    from dotaclient_amd import distributed as D
+    from dotaclient_amd import engine as E
+    dev = torch.device('cuda:0')
+    log = []
+
+    class Work:
+        def __init__(self, t):
+            self.t = t
+        def wait(self):
+            log.append(('wait', float(self.t.double().sum().item())))
+            return True
+
+    class FakeDist:
+        ReduceOp = dist.ReduceOp
+        def is_available(self): return True
+        def is_initialized(self): return True
+        def get_world_size(self, group=None): return 2
+        def broadcast(self, t, src=0, group=None): log.append(('broadcast', t.numel()))
+        def all_reduce(self, t, op=None, group=None, async_op=False):
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            log.append(('all_reduce', t.data_ptr(), t.numel(), bool(async_op), float(t.double().sum().item()), ev))
+            t.mul_(2.0)                                                   # "sum over two identical ranks"
+            return Work(t) if async_op else None
+
+    monkeypatch.setattr(D, 'dist', FakeDist())
+    eng = E.Engine('gru', 256, 1, dev)
+    eng.load_state_dict(synth.init_state_dict(7))
+    hook = D.FlatGradAllReducer(eng, overlap=True)
+    hook.sync_parameters()
+    orig_backward = eng.backward
+    eng.backward = lambda d, b, part=0: (log.append(('backward', part)), orig_backward(d, b, part))[1]
+    orig_avg = hook._average
+    hook._average = lambda e: (log.append(('average',)), orig_avg(e))[1]
+    orig_adam = eng.adam
+    eng.adam = lambda lr, vf: (log.append(('adam',)), orig_adam(lr, vf))[1]
+    rollouts = synth.make_rollouts(3, [48, 64, 32])
+    chunks = eng.rollout_pass(E.pack_rollouts(rollouts, 16, dev), 16)
+    eng.train_epoch(chunks, 1e-4, 5e-4, 0.5, grad_hook=hook)
+    torch.cuda.synchronize()
+    kinds = [x[0] for x in log]
+    assert kinds == ['broadcast', 'backward', 'all_reduce', 'backward', 'all_reduce', 'wait', 'average', 'adam'], kinds
+    (_, part0), ar0, (_, part1), ar1, wait = log[1], log[2], log[3], log[4], log[5]
+    assert part0 == E.DC_DIMS_BWD_UPPER and part1 == E.DC_DIMS_BWD_EMBED
+    base = hook.bucket.data_ptr()
+    assert ar0[3] is True and ar0[1] == base + 4 * eng.embed_floats and ar0[2] == eng.total + 8 - eng.embed_floats     # upper slice + flags, async
+    assert ar1[3] is False and ar1[1] == base and ar1[2] == eng.embed_floats                                            # embedding slice, blocking
+    assert ar0[5].query()                                                  # the event behind the upper backward has completed ...
+    assert abs(wait[1] - 2.0 * ar0[4]) <= 1e-9 * abs(ar0[4]) and ar0[4] != 0.0     # ... and nothing touched that slice between the call and its wait()
+    assert int(eng.status.item()) == 0 and torch.isfinite(eng.params).all()
+    # the non-overlapped form: one collective over the whole bucket
+    log.clear()
+    hook2 = D.FlatGradAllReducer(eng, overlap=False)
+    eng.backward, eng.adam = orig_backward, orig_adam
+    eng.train_epoch(chunks, 1e-4, 5e-4, 0.5, grad_hook=hook2)
+    ars = [x for x in log if x[0] == 'all_reduce']
+    assert len(ars) == 1 and ars[0][2] == eng.total + 8 and ars[0][3] is False
