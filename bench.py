@@ -973,6 +973,35 @@ def side_measurements(args, dev, B, S, E):
     del eng
     torch.cuda.empty_cache()
 
+    # ---- (f4) actor-side inference: one env-step of one hero (agent.py:652 -> policy.py:80-84), CPU observation tensors in, value read back --
+    try:
+        from dotaclient_amd.policy import Policy
+        from dotaclient_amd import layout as L_
+        lat = {}
+        for cell_, hid_ in (('gru', 256), (args.cell, args.hidden)):
+            pol = Policy(cell_, hid_, args.layers if cell_ == args.cell else 1, dev)
+            r0 = rollouts[0]
+            for mode in (True, False):
+                pol.single_graph = mode
+                h = pol.init_hidden()
+                for t in range(4):
+                    _, _, h = pol.single(**{k: r0['observations'][k][t] for k in L_.INPUT_KEYS}, hidden=h)
+                torch.cuda.synchronize()
+                ts = []
+                for t in range(100):
+                    t0 = time.perf_counter()
+                    _, v, h = pol.single(**{k: r0['observations'][k][t % S] for k in L_.INPUT_KEYS}, hidden=h)
+                    v.cpu()
+                    ts.append((time.perf_counter() - t0) * 1e6)
+                lat['%s-%d %s' % (cell_, hid_, 'graph_replay' if mode else 'eager')] = round(float(np.median(ts)), 1)
+            del pol
+        out['actor_single_step_latency_us'] = dict(lat, note='Policy.single, B = 1, S = 1, CPU observation tensors in, value read back on the host every step '
+                                                             '(median of 100): graph_replay = the step\'s launches replayed as ONE hipGraph over static buffers '
+                                                             '(Policy.single_graph, the default), eager = the same kernels launched one by one')
+    except Exception as e:                                  # noqa: BLE001
+        out['actor_single_step_latency_us'] = {'error': repr(e)}
+    torch.cuda.empty_cache()
+
     # ---- epochs as hipGraph replays; first epoch on the rollout pass's activations ---------------------------------------------------
     USE_GRAPHS = True
     g_ms, _, _ = timed(args.cell, args.hidden, args.layers, B)

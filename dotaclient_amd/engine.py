@@ -708,15 +708,17 @@ class Engine:
         return self._ws[offs[idx]:nxt].view(dtype)
 
     # ---- C-ABI calls -----------------------------------------------------------------------------
-    def forward(self, batch, h0=None, c0=None, want_final=False, lazy_tu=False):
+    def forward(self, batch, h0=None, c0=None, want_final=False, lazy_tu=False, hT_out=None, cT_out=None):
         d = self.dims(batch, lazy_tu)
         ws = self._workspace(d)
         # what the workspace's activations are a function of (Engine.reuse_rollout_forward compares it)
         self._ws_holds = (batch.rows, batch.obs.data_ptr(), self._param_version, bool(lazy_tu), self.kernel_flags, self.products)
         hT = cT = None
-        if want_final:
-            hT = device_empty((self.layers, batch.n_seq, self.hidden), torch.float32, self.device)
-            cT = device_empty((self.layers, batch.n_seq, self.hidden), torch.float32, self.device) if self.cell == 'lstm' else None
+        if want_final:       # (hT_out / cT_out: caller-owned result buffers - nothing is allocated, e.g. inside a graph capture)
+            hT = hT_out if hT_out is not None else device_empty((self.layers, batch.n_seq, self.hidden), torch.float32, self.device)
+            cT = None
+            if self.cell == 'lstm':
+                cT = cT_out if cT_out is not None else device_empty((self.layers, batch.n_seq, self.hidden), torch.float32, self.device)
         _lib.check(self.lib.dc_policy_forward(ctypes.byref(d), _lib.ptr(self.params), self.poff, _lib.ptr(batch.obs),
                                               _lib.ptr(h0), _lib.ptr(c0), _lib.ptr(batch.seq_off), _lib.ptr(batch.seq_len),
                                               _lib.ptr(ws), _lib.ptr(hT), _lib.ptr(cT), _lib.ptr(batch.mask if lazy_tu else None),

@@ -102,7 +102,73 @@ class Policy(nn.Module):
         return z if self.cell == 'gru' else (z, z.clone())
 
     def single(self, hidden, **kwargs):                                # policy.py:80-84
+        """One env-step of one hero (what the rollout actor calls every 0.5 s of game time, agent.py:652).  `single_graph` (default on):
+        the actor-latency path - the step's ~14 kernel launches are captured ONCE into a hipGraph over static buffers and replayed:
+        one host->device copy of the 483-float observation row, the hidden state into its static buffer, ONE graph launch, one copy of
+        the 200 result floats.  Same kernels, same results as the eager forward (tests/test_gpu_api.py)."""
+        if self.single_graph:
+            return self._single_graphed(hidden, kwargs)
         return self.__call__(**{k: v.unsqueeze(0).unsqueeze(0) for k, v in kwargs.items()}, hidden=hidden)
+
+    single_graph = True
+
+    @torch.no_grad()
+    def _single_graphed(self, hidden, kw):
+        e, dev = self.engine, self.engine.device
+        st = getattr(self, '_single_state', None)
+        if st is None:
+            st = self._single_state = {
+                'obs_host': torch.empty(1, L.OBS_DIM, dtype=torch.float32).pin_memory(),
+                'obs': torch.empty(1, L.OBS_DIM, dtype=torch.float32, device=dev),
+                'h0': torch.zeros(self.layers, 1, self.hidden_size, dtype=torch.float32, device=dev),
+                'c0': torch.zeros(self.layers, 1, self.hidden_size, dtype=torch.float32, device=dev) if self.cell == 'lstm' else None,
+                'hT': torch.zeros(self.layers, 1, self.hidden_size, dtype=torch.float32, device=dev),
+                'cT': torch.zeros(self.layers, 1, self.hidden_size, dtype=torch.float32, device=dev) if self.cell == 'lstm' else None,
+                'out': torch.zeros(L.HEADOUT_LD + L.MAX_UNITS, dtype=torch.float32, device=dev),
+                'off': torch.zeros(1, dtype=torch.int64, device=dev), 'len': torch.ones(1, dtype=torch.int32, device=dev),
+                'graph': None, 'key': None, 'calls': 0}
+            st['batch'] = PackedBatch(st['obs'], None, None, None, st['off'], st['len'], 1)
+        # the observation row on the host (the actor's tensors are CPU tensors, agent.py:640-650), one pinned H2D copy
+        if all(not kw[k].is_cuda for k in L.INPUT_KEYS):
+            row, o = st['obs_host'][0], 0
+            for k in L.INPUT_KEYS:
+                v = kw[k].reshape(-1)
+                row[o:o + v.numel()].copy_(v)
+                o += v.numel()
+            st['obs'].copy_(st['obs_host'], non_blocking=True)
+        else:                                             # observation tensors already on the device: assembled there
+            st['obs'].copy_(torch.cat([kw[k].reshape(1, -1).to(dev, torch.float32) for k in L.INPUT_KEYS], dim=1))
+        if self.cell == 'gru':
+            st['h0'].copy_(hidden)
+        else:
+            st['h0'].copy_(hidden[0]); st['c0'].copy_(hidden[1])
+
+        def run():
+            d, _, _ = e.forward(st['batch'], st['h0'], st['c0'], want_final=True, hT_out=st['hT'], cT_out=st['cT'])
+            st['out'][:L.HEADOUT_LD].copy_(e.ws_view(d, 'HEADOUT')[:L.HEADOUT_LD])
+            st['out'][L.HEADOUT_LD:].copy_(e.ws_view(d, 'TU')[:L.MAX_UNITS])
+
+        key = (0 if e._ws is None else e._ws.data_ptr(), e.params.data_ptr(), e.kernel_flags, e.products)
+        if st['graph'] is None or st['key'] != key:
+            run()                                        # eager: the first call also allocates the workspace and sets kernel attributes
+            st['calls'] += 1
+            key = (e._ws.data_ptr(), e.params.data_ptr(), e.kernel_flags, e.products)
+            if st['calls'] >= 2 or st['key'] is not None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    run()
+                st['graph'] = g
+            st['key'] = key
+        else:
+            st['graph'].replay()
+        out = st['out'].clone()
+        ho, tu = out[:L.HEADOUT_LD].view(1, 1, -1), out[L.HEADOUT_LD:].view(1, 1, -1)
+        logits = {'enum': ho[..., L.HEADOUT_ENUM:L.HEADOUT_ENUM + 4], 'x': ho[..., L.HEADOUT_X:L.HEADOUT_X + 9],
+                  'y': ho[..., L.HEADOUT_Y:L.HEADOUT_Y + 9], 'target_unit': tu,
+                  'ability': ho[..., L.HEADOUT_ABILITY:L.HEADOUT_ABILITY + 3]}
+        value = ho[..., L.HEADOUT_VALUE:L.HEADOUT_VALUE + 1]
+        hid = st['hT'].clone() if self.cell == 'gru' else (st['hT'].clone(), st['cT'].clone())
+        return logits, value, hid
 
     def sequence(self, hidden, **kwargs):                              # policy.py:86-90
         return self.__call__(**{k: v.unsqueeze(0) for k, v in kwargs.items()}, hidden=hidden)

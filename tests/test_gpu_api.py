@@ -109,6 +109,46 @@ def test_policy_single_step_matches_oracle(cell, hidden):
         assert h_got.shape == (1, 1, hidden) and util.scaled_err(h_got.cpu().numpy(), h_ref.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('cell,hidden', [('gru', 256), ('lstm', 256)])
+def test_policy_single_graph_replay_equals_eager(cell, hidden):
+    # (f4) the actor-latency path: Policy.single replays ONE hipGraph over static buffers (CPU observation tensors in, like the
+    # actor's, agent.py:640-652) - bit-identical to the eager forward, step after step with the hidden state carried by the caller,
+    # across a weight update (Policy.load_state_dict: same buffers, new values) - and faster
+    import time
+    from dotaclient_amd.policy import Policy
+    pol = Policy(cell, hidden, 1)
+    pol.load_state_dict(synth.init_state_dict(7, cell, hidden, 1))
+    r = synth.make_rollouts(13, [40])[0]
+    outs = {}
+    for mode in (True, False):
+        pol.single_graph = mode
+        hid = pol.init_hidden()
+        seq = []
+        for t in range(12):
+            if t == 6:
+                pol.load_state_dict(synth.init_state_dict(8, cell, hidden, 1))      # the model exchange delivers new weights mid-game
+            lg, v, hid = pol.single(**{k: r['observations'][k][t] for k in L.INPUT_KEYS}, hidden=hid)
+            seq.append(torch.cat([lg[k].flatten() for k in L.OUTPUT_KEYS] + [v.flatten(), (hid if cell == 'gru' else hid[0]).flatten()]).cpu())
+        pol.load_state_dict(synth.init_state_dict(7, cell, hidden, 1))
+        outs[mode] = torch.stack(seq)
+    assert torch.equal(outs[True], outs[False])
+    assert pol._single_state['graph'] is not None
+    lat = {}
+    for mode in (True, False):
+        pol.single_graph = mode
+        hid = pol.init_hidden()
+        for t in range(3):
+            _, _, hid = pol.single(**{k: r['observations'][k][t] for k in L.INPUT_KEYS}, hidden=hid)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(30):
+            lg, v, hid = pol.single(**{k: r['observations'][k][t] for k in L.INPUT_KEYS}, hidden=hid)
+            v.cpu()                                                                 # the actor reads the result every step
+        lat[mode] = (time.perf_counter() - t0) / 30 * 1e6
+    print('Policy.single latency per env-step (%s-%d): graph replay %.0f us, eager %.0f us' % (cell, hidden, lat[True], lat[False]))
+    assert lat[True] < lat[False]
+
+
 @pytest.mark.parametrize('case', ['ragged_s16', 'clip_s16'])
 def test_optimizer_surface_matches_golden(case, tmp_path):
     g, rollouts = util.load_case(case)
