@@ -199,7 +199,8 @@ def cpu_baseline(cell, hidden, layers, rollouts, seq_len, epochs, lr, ent, vf):
 
     kind is "port": the reference itself (Python, /root/reference) cannot travel to the GPU box, and this script cannot run where the
     reference is (no GPU there) - tools/reference_cpu_step.py times the REAL reference's functions (optimizer.py:57-64,328-430,581-689) next
-    to this port in the build container (profiles/r05/reference_vs_port_cpu.json: the port is not the slower of the two)."""
+    to this port in the build container (profiles/r05/reference_vs_port_cpu.json: 489.2 against 486.9 env-steps/s on the same cores, the same final loss
+    to the last digit - the port is a faithful stand-in for the reference's CPU speed)."""
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
 
     def one_iteration(rs, n_ep, keep=False):
