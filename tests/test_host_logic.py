@@ -603,3 +603,18 @@ def test_default_device_follows_local_rank(monkeypatch):
     for fn in (O.DotaOptimizer.__init__, P.Policy.__init__, E.Engine.__init__):
         assert inspect.signature(fn).parameters['device'].default is None
     assert 'cuda:0' not in inspect.getsource(O) and 'cuda:0' not in inspect.getsource(E)
+
+
+def test_pool16m_lane_level_index_model():
+    # tools/pool16m_sim.py models csrc/embed_pool16m.hip lane by lane (which lane builds which MFMA operand element, which accumulator
+    # register holds which output, K slot <-> unit mapping, the rank-one attention term through two K slots, the R fix-up) against a dense
+    # float64 evaluation of the same gradient; an odd number of env-steps exercises the half-empty last pair
+    from tools import pool16m_sim as sim
+    rng = np.random.default_rng(11)
+    n = 3
+    x = rng.standard_normal((n, 16, 12)); W1 = rng.standard_normal((128, 12)) * 0.3; b1 = rng.standard_normal(128) * 0.3
+    W2 = rng.standard_normal((128, 128)) * 0.1; amax = rng.integers(0, 16, (n, 128)); d = rng.standard_normal((n, 128))
+    dtu = rng.standard_normal((n, 16)) * np.array([[1.0], [0.0], [1.0]]); q = rng.standard_normal((n, 128))
+    got, ref = sim.kernel(x, W1, b1, W2, amax, d, dtu, q), sim.reference(x, W1, b1, W2, amax, d, dtu, q)
+    for name, a, b in zip(('dW2', 'part1', 'db2'), got, ref):
+        assert np.abs(a - b).max() / np.abs(b).max() < 1e-12, name
