@@ -89,13 +89,17 @@ __device__ __forceinline__ uint2 stage_pieces(float d0, float d1, float s_grad) 
 enum : int {   // LDS (bytes)
     P1_STG = 0,                      // every wave's own staging block: 2 buffers x 2 items x 2.4 KB
     P1_ITEM = 592,                   // dwords per item; 592 = 16 mod 64: the two items of a pair start 16 banks apart
-    P1_TAB = P1_STG + 8 * 4 * P1_ITEM * 4,   // one-hot table: entry i < 8 = f16 1.0 at element i, entries 8..15 = zeros
-    P1_RED_ACC = 0,                  // at the end, over the staging blocks: stream 1's dW2^T tiles [kq 4][64 registers][64 lanes] f32
-    P1_RED_B = 65536,                // ... and its bias-gradient sums [2][64] f32
-    P1_LDS = 65536 + 1024 > P1_TAB + 256 ? 65536 + 1024 : P1_TAB + 256
+    P1_RED_ACC = 0,                  // at the end, over the staging blocks: another stream's dW2^T tiles [kq 4][64 registers][64 lanes] f32
+    P1_RED_B = 65536                 // ... and its bias-gradient sums [2][64] f32
 };
+// one-hot table behind the staging blocks: entry i < 8 = f16 1.0 at element i, entries 8..15 = zeros
+constexpr int p1_tab(int nstream) { return P1_STG + 4 * nstream * (nstream == 2 ? 4 : 2) * P1_ITEM * 4; }      // two staging buffers with two streams, one with three
+constexpr int p1_lds(int nstream) { return (65536 + 1024 > p1_tab(nstream) + 256) ? 65536 + 1024 : p1_tab(nstream) + 256; }
 
-__global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw2_kernel(PoolMArgs p) {
+// NSTREAM streams of pairs x 4 k quarters = 4 NSTREAM waves; NSTREAM = 3: three waves per SIMD (<= 168 registers)
+template <int NSTREAM>
+__global__ __launch_bounds__(256 * NSTREAM) void embed_pool16m_dw2_kernel(PoolMArgs p) {
+    constexpr int P1_TAB = p1_tab(NSTREAM);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int W = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw2_kernel(PoolMArgs
     // Block of an item (dwords): d(xcat) pieces [128] | q [128] | unit records [16][12] | dtu [16] | per channel and lane group, the
     // one-hot table entry of the arg-max unit: slot (a & 3) + 4 (a >> 3) if the unit is of the group, else >= 8 [2][128 B]
     enum { ST_D = 0, ST_Q = 128, ST_X = 256, ST_DTU = 448, ST_IDX = 464, ST_LIVE = 528, ST_ITEM = P1_ITEM };     // ... | 1 if any dtu != 0
-    float* const stg = reinterpret_cast<float*>(smem + P1_STG) + (size_t)W * (2 * 2 * ST_ITEM);
+    float* const stg = reinterpret_cast<float*>(smem + P1_STG) + (size_t)W * ((NSTREAM == 2 ? 2 : 1) * 2 * ST_ITEM);
     const long long n_pairs = (n1 - n0 + 1) / 2;
     const int e_row = fr >> 4, u_row = fr & 15;              // as a ROW of the pair's tile this lane is unit u_row of item e_row
     uint16_t* const mask_t = p.mask + ((size_t)(t - 2) * ((p.nr + 1) / 2)) * 256;
@@ -189,18 +193,28 @@ __global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw2_kernel(PoolMArgs
     };
     // Software pipeline over the pairs of the stream: while pair i's products run, pair i + 1 is staged (its loads were issued an iteration
     // ago) and goes through the first layer (six dependent f32 MFMAs whose results nobody waits for), and pair i + 2's loads are issued.
+    // (PIPE, two streams: 213 registers.  Three streams - three waves per SIMD, <= 168 registers - do without it: the next pair's
+    // loads are in flight while the pair computes and are staged at the bottom, into the same block.)
+    constexpr bool PIPE = NSTREAM == 2;
     Raw nx0, nx1;
     f32x16 basic_next = {};
     if (st < n_pairs) {
         const Raw r0 = load_raw(st, 0), r1 = load_raw(st, 1);
         store_raw(r0, 0, 0); store_raw(r1, 0, 1);
-        if (st + 2 < n_pairs) { nx0 = load_raw(st + 2, 0); nx1 = load_raw(st + 2, 1); }
-        __builtin_amdgcn_wave_barrier();
-        basic_next = first_layer(0);
+        if constexpr (PIPE) {
+            if (st + NSTREAM < n_pairs) { nx0 = load_raw(st + NSTREAM, 0); nx1 = load_raw(st + NSTREAM, 1); }
+            __builtin_amdgcn_wave_barrier();
+            basic_next = first_layer(0);
+        }
     }
     int buf = 0;
-    for (long long pi = st; pi < n_pairs; pi += 2, buf ^= 1) {
-        const bool more = pi + 2 < n_pairs;                  // wave-uniform
+    for (long long pi = st; pi < n_pairs; pi += NSTREAM, buf ^= PIPE ? 1 : 0) {
+        const bool more = pi + NSTREAM < n_pairs;            // wave-uniform
+        if constexpr (!PIPE) {
+            if (more) { nx0 = load_raw(pi + NSTREAM, 0); nx1 = load_raw(pi + NSTREAM, 1); }
+            __builtin_amdgcn_wave_barrier();
+            basic_next = first_layer(0);
+        }
         const f32x16 basic = basic_next;
         {   // its relu masks for kernel 2: bit r = D register r of this lane is past the relu
             unsigned bits = 0u;
@@ -208,11 +222,13 @@ __global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw2_kernel(PoolMArgs
             for (int r = 0; r < 16; ++r) bits |= (basic[r] > 0.f ? 1u : 0u) << r;
             mask_t[((size_t)((n0 >> 1) + pi) * 64 + lane) * 4 + kq] = (uint16_t)bits;
         }
-        if (more) {
-            store_raw(nx0, buf ^ 1, 0); store_raw(nx1, buf ^ 1, 1);
-            if (pi + 4 < n_pairs) { nx0 = load_raw(pi + 4, 0); nx1 = load_raw(pi + 4, 1); }
-            __builtin_amdgcn_wave_barrier();
-            basic_next = first_layer(buf ^ 1);
+        if constexpr (PIPE) {
+            if (more) {
+                store_raw(nx0, buf ^ 1, 0); store_raw(nx1, buf ^ 1, 1);
+                if (pi + 2 * NSTREAM < n_pairs) { nx0 = load_raw(pi + 2 * NSTREAM, 0); nx1 = load_raw(pi + 2 * NSTREAM, 1); }
+                __builtin_amdgcn_wave_barrier();
+                basic_next = first_layer(buf ^ 1);
+            }
         }
         const float* it0 = stg + (buf * 2) * ST_ITEM;        // item e of the pair: it0 + e * ST_ITEM
 
@@ -225,34 +241,48 @@ __global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw2_kernel(PoolMArgs
 #pragma unroll
             for (int j = 0; j < 8; ++j) bv[j] = basic[8 * e + j];                  // K slot 8 fq + j <-> unit sigma(fq, j): as they lie
             const Split2h A = split8(bv, s_act);
-            // reads first (two dependent LDS round trips: entry index, then the table entry), then the four operands, then the products -
-            // spelled out in that order so that the round trips of the four column blocks overlap
-            unsigned d2[4];
-            int idx[4];
+            if constexpr (!PIPE) {      // three streams: one column block at a time (16 live operand registers instead of 48)
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                d2[cb] = reinterpret_cast<const unsigned*>(it + ST_D)[32 * cb + fr];
-                idx[cb] = reinterpret_cast<const uint8_t*>(it + ST_IDX)[128 * fq + 32 * cb + fr];
+                for (int cb = 0; cb < 4; ++cb) {
+                    const unsigned d2 = reinterpret_cast<const unsigned*>(it + ST_D)[32 * cb + fr];
+                    const int idx = reinterpret_cast<const uint8_t*>(it + ST_IDX)[128 * fq + 32 * cb + fr];
+                    const f16x8 hot = *reinterpret_cast<const f16x8*>(smem + P1_TAB + idx * 16);
+                    const f16x2_t dd = __builtin_bit_cast(f16x2_t, d2);
+                    Split2h B;
+                    B.h = hot * dd.x;
+                    B.m = hot * dd.y;
+                    acc[cb] = mma3(A, B, acc[cb]);
+                }
+            } else {
+                // reads first (two dependent LDS round trips: entry index, then the table entry), then the four operands, then the products -
+                // spelled out in that order so that the round trips of the four column blocks overlap
+                unsigned d2[4];
+                int idx[4];
+    #pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    d2[cb] = reinterpret_cast<const unsigned*>(it + ST_D)[32 * cb + fr];
+                    idx[cb] = reinterpret_cast<const uint8_t*>(it + ST_IDX)[128 * fq + 32 * cb + fr];
+                }
+                f16x8 hot[4];
+    #pragma unroll
+                for (int cb = 0; cb < 4; ++cb) hot[cb] = *reinterpret_cast<const f16x8*>(smem + P1_TAB + idx[cb] * 16);
+                // one-hot over the lane group's eight K slots: the table entry (f16 1.0 at the unit's slot, or zeros) times the piece - eight
+                // packed f16 multiplies by exactly 0 or 1 instead of compares and selects per register
+                Split2h B[4];
+    #pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    const f16x2_t dd = __builtin_bit_cast(f16x2_t, d2[cb]);
+                    B[cb].h = hot[cb] * dd.x;
+                    B[cb].m = hot[cb] * dd.y;
+                }
+                // (independent accumulators: term by term across the four blocks, not three dependent MFMAs per block)
+    #pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.m, B[cb].h, acc[cb], 0, 0, 0);
+    #pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.h, B[cb].m, acc[cb], 0, 0, 0);
+    #pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.h, B[cb].h, acc[cb], 0, 0, 0);
             }
-            f16x8 hot[4];
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) hot[cb] = *reinterpret_cast<const f16x8*>(smem + P1_TAB + idx[cb] * 16);
-            // one-hot over the lane group's eight K slots: the table entry (f16 1.0 at the unit's slot, or zeros) times the piece - eight
-            // packed f16 multiplies by exactly 0 or 1 instead of compares and selects per register
-            Split2h B[4];
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                const f16x2_t dd = __builtin_bit_cast(f16x2_t, d2[cb]);
-                B[cb].h = hot[cb] * dd.x;
-                B[cb].m = hot[cb] * dd.y;
-            }
-            // (independent accumulators: term by term across the four blocks, not three dependent MFMAs per block)
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.m, B[cb].h, acc[cb], 0, 0, 0);
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.h, B[cb].m, acc[cb], 0, 0, 0);
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.h, B[cb].h, acc[cb], 0, 0, 0);
             {   // s[k] (x s_act s_grad) of the rank-one attention term (below), over the lane group's eight units ...
                 const float4 du0 = *reinterpret_cast<const float4*>(it + ST_DTU + 4 * fq), du1 = *reinterpret_cast<const float4*>(it + ST_DTU + 8 + 4 * fq);
                 float sk = du0.x * bv[0];
@@ -271,38 +301,67 @@ __global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw2_kernel(PoolMArgs
             Split2h A1;
             A1.h = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : sh, 0u, 0u, 0u});
             A1.m = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : sm, 0u, 0u, 0u});
-            Split2h B1[4];
+            if constexpr (!PIPE) {
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                const float q0 = it0[ST_Q + 32 * cb + fr], q1 = it0[ST_ITEM + ST_Q + 32 * cb + fr];      // O(1): the gradient pre-scale went into s
-                const unsigned qh = cvt_pk_f16(q0, q1);
-                const f16x2_t qhv = __builtin_bit_cast(f16x2_t, qh);
-                const unsigned qm = cvt_pk_f16(q0 - (float)qhv.x, q1 - (float)qhv.y);
-                B1[cb].h = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : qh, 0u, 0u, 0u});
-                B1[cb].m = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : qm, 0u, 0u, 0u});
+                for (int cb = 0; cb < 4; ++cb) {
+                    const float q0 = it0[ST_Q + 32 * cb + fr], q1 = it0[ST_ITEM + ST_Q + 32 * cb + fr];
+                    const unsigned qh = cvt_pk_f16(q0, q1);
+                    const f16x2_t qhv = __builtin_bit_cast(f16x2_t, qh);
+                    const unsigned qm = cvt_pk_f16(q0 - (float)qhv.x, q1 - (float)qhv.y);
+                    Split2h B1;
+                    B1.h = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : qh, 0u, 0u, 0u});
+                    B1.m = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : qm, 0u, 0u, 0u});
+                    acc[cb] = mma3(A1, B1, acc[cb]);
+                }
+            } else {
+                Split2h B1[4];
+    #pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    const float q0 = it0[ST_Q + 32 * cb + fr], q1 = it0[ST_ITEM + ST_Q + 32 * cb + fr];      // O(1): the gradient pre-scale went into s
+                    const unsigned qh = cvt_pk_f16(q0, q1);
+                    const f16x2_t qhv = __builtin_bit_cast(f16x2_t, qh);
+                    const unsigned qm = cvt_pk_f16(q0 - (float)qhv.x, q1 - (float)qhv.y);
+                    B1[cb].h = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : qh, 0u, 0u, 0u});
+                    B1[cb].m = __builtin_bit_cast(f16x8, u32x4{fq ? 0u : qm, 0u, 0u, 0u});
+                }
+    #pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1.m, B1[cb].h, acc[cb], 0, 0, 0);
+    #pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1.h, B1[cb].m, acc[cb], 0, 0, 0);
+    #pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1.h, B1[cb].h, acc[cb], 0, 0, 0);
+        
             }
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1.m, B1[cb].h, acc[cb], 0, 0, 0);
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1.h, B1[cb].m, acc[cb], 0, 0, 0);
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1.h, B1[cb].h, acc[cb], 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
+        if constexpr (!PIPE) {
+            if (more) { store_raw(nx0, 0, 0); store_raw(nx1, 0, 1); }
+        }
     }
 
-    // ---- results: the two streams meet through LDS (stream 1 writes, stream 0 adds and stores) ---------------------------------------------
+    // ---- results: the streams meet through LDS (streams 1 .. NSTREAM - 1 write one after the other, stream 0 adds them in that order) --------
     __syncthreads();                                         // every wave is done with its staging block
     float* racc = reinterpret_cast<float*>(smem + P1_RED_ACC) + (size_t)kq * 64 * 64 + lane;
     float* rb = reinterpret_cast<float*>(smem + P1_RED_B);
-    if (st == 1) {
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+    for (int other = 1; other < NSTREAM; ++other) {
+        if (st == other) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) racc[(16 * cb + r) * 64] = acc[cb][r];
-        if (kq == 0) { rb[lane] = db2a[0]; rb[64 + lane] = db2a[1]; }
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) racc[(16 * cb + r) * 64] = acc[cb][r];
+            if (kq == 0) { rb[lane] = db2a[0]; rb[64 + lane] = db2a[1]; }
+        }
+        __syncthreads();
+        if (st == 0) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cb][r] += racc[(16 * cb + r) * 64];
+            if (kq == 0) { db2a[0] += rb[lane]; db2a[1] += rb[64 + lane]; }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (st == 0) {
         const float inv = 1.f / (s_act * s_grad);
         float* out = p.slab + (size_t)blockIdx.x * 128 * 128;            // [c][k]
@@ -311,14 +370,14 @@ __global__ __launch_bounds__(PM_THREADS) void embed_pool16m_dw2_kernel(PoolMArgs
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 float4 v;
-                v.x = (acc[cb][4 * g4 + 0] + racc[(16 * cb + 4 * g4 + 0) * 64]) * inv;
-                v.y = (acc[cb][4 * g4 + 1] + racc[(16 * cb + 4 * g4 + 1) * 64]) * inv;
-                v.z = (acc[cb][4 * g4 + 2] + racc[(16 * cb + 4 * g4 + 2) * 64]) * inv;
-                v.w = (acc[cb][4 * g4 + 3] + racc[(16 * cb + 4 * g4 + 3) * 64]) * inv;
+                v.x = acc[cb][4 * g4 + 0] * inv;
+                v.y = acc[cb][4 * g4 + 1] * inv;
+                v.z = acc[cb][4 * g4 + 2] * inv;
+                v.w = acc[cb][4 * g4 + 3] * inv;
                 *reinterpret_cast<float4*>(out + (size_t)(32 * cb + fr) * 128 + 32 * kq + 8 * g4 + 4 * fq) = v;
             }
         if (kq == 0)
-            *reinterpret_cast<float2*>(p.part2 + (size_t)blockIdx.x * 128 + 2 * lane) = make_float2(db2a[0] + rb[lane], db2a[1] + rb[64 + lane]);
+            *reinterpret_cast<float2*>(p.part2 + (size_t)blockIdx.x * 128 + 2 * lane) = make_float2(db2a[0], db2a[1]);
     }
 }
 
@@ -535,7 +594,8 @@ int embed_bwd_pool16m(const float* obs, const float* dxcat, const uint8_t* amax,
                 f16.s_act, f16.s_w, f16.s_grad, scratch, reinterpret_cast<uint16_t*>(scratch + 2 * nr * 128)};
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)embed_pool16m_dw2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P1_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)embed_pool16m_dw2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, p1_lds(2));
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)embed_pool16m_dw2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, p1_lds(3));
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)embed_pool16m_dw1_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, p2_lds(8));
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)embed_pool16m_dw1_kernel<2, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, p2_lds(12));
         if (e != hipSuccess) { set_error("embed_bwd_pool16m: hipFuncSetAttribute", (int)e); return (int)e; }
@@ -551,7 +611,11 @@ int embed_bwd_pool16m(const float* obs, const float* dxcat, const uint8_t* amax,
     // step's records, d(xcat) slot(s), arg-max bytes, dtu and q or R once, plus the 256 B of relu masks written and read
     ProfScope prof("embed_bwd_pool16m", 2.0 * 2.0 * nr * (2.0 * 16 * 128 * 128 + 16.0 * 128 * 12 + 16.0 * 128 * 13),
                    2.0 * nr * (2.0 * (768 + 768 + 128 + 64) + 512 + 512 + 512), s);
-    hipLaunchKernelGGL(embed_pool16m_dw2_kernel, dim3(2 * wg_per_type), dim3(PM_THREADS), P1_LDS, s, a);
+#ifdef DC_PM_K1_TWO
+    hipLaunchKernelGGL(embed_pool16m_dw2_kernel<2>, dim3(2 * wg_per_type), dim3(512), p1_lds(2), s, a);
+#else
+    hipLaunchKernelGGL(embed_pool16m_dw2_kernel<3>, dim3(2 * wg_per_type), dim3(768), p1_lds(3), s, a);
+#endif
     if (int e = launch_check("embed_pool16m_dw2")) return e;
 #ifdef DC_PM_K2_SPLIT      // A/B build: twelve waves of half the accumulators, three per SIMD: 666-677 us for both kernels against 645-654 (same box)
     hipLaunchKernelGGL((embed_pool16m_dw1_kernel<2, 6>), dim3(2 * wg_per_type), dim3(768), p2_lds(12), s, a);
