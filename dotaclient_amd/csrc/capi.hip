@@ -83,9 +83,13 @@ int dc_gemm_x3(const float* A, const float* B, float* C, int M, int N, int K, in
         g.sa = ldexpf(1.f, (int)(int8_t)((prec >> 8) & 0xff));
         g.sb = ldexpf(1.f, (int)(int8_t)((prec >> 16) & 0xff));
     }
+    if (g.prec == 1) {      // bf16 storage of an operand / the output / the mask (DC_GEMM_PREC_BF16_STORE): same shapes and ld, 2-byte elements
+        g.a_bf16 = (prec >> 8) & 1; g.b_bf16 = (prec >> 9) & 1; g.c_bf16 = (prec >> 10) & 1; g.aux_bf16 = (prec >> 11) & 1;
+        if (g.b_bf16 && !(a_kmajor && b_kmajor)) { set_error("dc_gemm_x3: a bf16-stored B is built for the k-major form only", 1005); return 1005; }
+    }
     if (a_kmajor && b_kmajor) {
         g.A = A; g.a_mode = X3_KMAJ; g.lda = lda; g.B = B; g.b_mode = X3_KMAJ; g.ldb = ldb;
-        g.scratch = GemmScratch{scratch, (long long)scratch_floats};
+        if (!g.c_bf16) g.scratch = GemmScratch{scratch, (long long)scratch_floats};
         return gemm_x3(g, s);
     }
     if (a_kmajor) { set_error("dc_gemm_x3: a_kmajor needs b_kmajor", 1007); return 1007; }

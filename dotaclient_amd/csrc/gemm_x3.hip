@@ -62,6 +62,7 @@ struct X3Args {
     long long a_plane, b_plane, b2_plane;   // plane strides (elements) of pre-split operands
     int M, N, K, lda, ldb, ldb2, ldc, ldc2, ldaux, n_split, k_per_split, relu, accumulate, nbias;
     float sa, sb, inv;      // PREC = 4: power-of-two pre-scales of the A / B operands and 1 / (sa sb)
+    int c_bf16, aux_bf16;   // bf16 storage (configs[4]): C written as bf16 [M][ldc]; aux read as bf16 [M][ldaux]
 };
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -74,10 +75,13 @@ __device__ __forceinline__ unsigned pk_f16(float a, float b) {      // {f16(b), 
 // ---- operand loaders: global -> registers (issued one K step ahead) -> split -> LDS planes ---------------------------
 // MODE X3_ROW   : f32 [rows][ld], k contiguous           -> planes [row][16 k] bf16, 48-byte rows
 // MODE X3_KMAJ  : f32 [k][ld], rows contiguous           -> planes [8 kpairs][128 rows] u32
-// MODE X3_PLANES: bf16 [NP][rows][ld] pre-split weights  -> planes [row][16 k] bf16 (no arithmetic)
+// MODE X3_PLANES: bf16 [NP][rows][ld] pre-split weights  -> planes [row][16 k] bf16 (no arithmetic); NP = 1 is also an ACTIVATION
+//                 stored as bf16 [rows][ld] (bf16 storage of configs[4]: X3Gemm::a_bf16)
+// MODE X3_KMAJ16: bf16 [k][ld], rows contiguous          -> planes [8 kpairs][128 rows] u32 (PREC = 1; the pairs along k are packed
+//                 with two v_perm - no conversion)
 template <int MODE, int NP, bool F16 = false>
 struct X3Loader {
-    struct Regs { float4 v[2]; u32x4 w[NP]; };   // one staged K step of this thread (only the members its MODE uses are live)
+    struct Regs { float4 v[2]; u32x4 w[NP]; uint2 h[2]; };   // one staged K step of this thread (only the members its MODE uses are live)
     const char* src[2];
     long long step;        // bytes per K step
     long long plane;       // bytes between planes (X3_PLANES)
@@ -100,6 +104,13 @@ struct X3Loader {
             for (int i = 0; i < 2; ++i)
                 src[i] = reinterpret_cast<const char*>(static_cast<const float*>(P) + (size_t)(k0 + 2 * kp + i) * ld + c);
             step = (long long)XK * ld * 4;
+        } else if constexpr (MODE == X3_KMAJ16) {
+            const int kp = tid >> 5;
+            const int c = min(r_base + (tid & 31) * 4, ld - 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                src[i] = reinterpret_cast<const char*>(static_cast<const uint16_t*>(P) + (size_t)(k0 + 2 * kp + i) * ld + c);
+            step = (long long)XK * ld * 2;
         } else {
             const int row = min(r_base + (tid >> 1), R - 1);
             src[0] = reinterpret_cast<const char*>(static_cast<const uint16_t*>(P) + (size_t)row * ld + k0 + (tid & 1) * 8);
@@ -113,6 +124,10 @@ struct X3Loader {
 #pragma unroll
             for (int p = 0; p < NP; ++p) r.w[p] = *reinterpret_cast<const u32x4*>(src[0] + p * plane);
             src[0] += step;
+        } else if constexpr (MODE == X3_KMAJ16) {
+            r.h[0] = *reinterpret_cast<const uint2*>(src[0]);
+            r.h[1] = *reinterpret_cast<const uint2*>(src[1]);
+            src[0] += step; src[1] += step;
         } else {
             r.v[0] = *reinterpret_cast<const float4*>(src[0]);
             r.v[1] = *reinterpret_cast<const float4*>(src[1]);
@@ -157,6 +172,13 @@ struct X3Loader {
             char* d = S + ((tid >> 5) * XB + (tid & 31) * 4) * 4;
 #pragma unroll
             for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d + p * KM_PLANE) = u32x4{q[0][p], q[1][p], q[2][p], q[3][p]};
+        } else if constexpr (MODE == X3_KMAJ16) {
+            // h[0] = k even, h[1] = k odd, four consecutive rows (bf16) each: {even, odd} of a row share a dword
+            static_assert(MODE != X3_KMAJ16 || NP == 1, "bf16 storage goes with PREC = 1");
+            const uint2 e = r.h[0], o = r.h[1];
+            char* d = S + ((tid >> 5) * XB + (tid & 31) * 4) * 4;
+            *reinterpret_cast<u32x4*>(d) = u32x4{__builtin_amdgcn_perm(o.x, e.x, 0x05040100u), __builtin_amdgcn_perm(o.x, e.x, 0x07060302u),
+                                                  __builtin_amdgcn_perm(o.y, e.y, 0x05040100u), __builtin_amdgcn_perm(o.y, e.y, 0x07060302u)};
         } else {
             char* d = S + (tid >> 1) * RM_ROW_BYTES + (tid & 1) * 16;
 #pragma unroll
@@ -165,7 +187,7 @@ struct X3Loader {
     }
     // the 8 k values (8g .. 8g+7) of tile row r, plane p, as an MFMA operand
     static __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, int r, int g, int p) {
-        if constexpr (MODE == X3_KMAJ) {
+        if constexpr (MODE == X3_KMAJ || MODE == X3_KMAJ16) {
             const unsigned* s = reinterpret_cast<const unsigned*>(S + p * KM_PLANE) + (4 * g) * XB + r;
             return __builtin_bit_cast(bf16x8, u32x4{s[0], s[XB], s[2 * XB], s[3 * XB]});
         } else {
@@ -221,8 +243,18 @@ static __device__ __forceinline__ void store_tile(const X3Args& p, f32x16 (&acc)
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
         if (p.relu) { v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w); }      // NaN-propagating (common.h)
         if (p.aux != nullptr) {
-            const float4 m = *reinterpret_cast<const float4*>(p.aux + (size_t)row * p.ldaux + col);
+            float4 m;
+            if (p.aux_bf16) {
+                const uint2 mb = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.aux) + (size_t)row * p.ldaux + col);
+                m = make_float4(__uint_as_float(mb.x << 16), __uint_as_float(mb.x & 0xffff0000u), __uint_as_float(mb.y << 16), __uint_as_float(mb.y & 0xffff0000u));
+            } else {
+                m = *reinterpret_cast<const float4*>(p.aux + (size_t)row * p.ldaux + col);
+            }
             v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        }
+        if (p.c_bf16) {       // bf16 storage: 8 bytes per lane (no accumulate / second output on this form: host check)
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + (size_t)row * p.ldc + col) = make_uint2(cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w));
+            continue;
         }
         float* c = to_c2 ? p.C2 + (size_t)row * p.ldc2 + (col - p.n_split) : p.C + (size_t)row * p.ldc + col;
         if (p.accumulate) {
@@ -306,11 +338,16 @@ __global__ __launch_bounds__(256, X3Cfg<PREC>::kOcc) void gemm_x3_kernel(X3Args 
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         // column sums of A (k-major A only): the work items of column tile 0 add up what passes through their loader
-        const bool do_cs = A_MODE == X3_KMAJ && p.a_colsum != nullptr && n_blk == 0;
+        const bool do_cs = (A_MODE == X3_KMAJ || A_MODE == X3_KMAJ16) && p.a_colsum != nullptr && n_blk == 0;
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
         auto cs_add = [&](const typename LA::Regs& r) {
             if constexpr (A_MODE == X3_KMAJ) {
                 cs.x += r.v[0].x + r.v[1].x; cs.y += r.v[0].y + r.v[1].y; cs.z += r.v[0].z + r.v[1].z; cs.w += r.v[0].w + r.v[1].w;
+            } else if constexpr (A_MODE == X3_KMAJ16) {
+                cs.x += __uint_as_float(r.h[0].x << 16) + __uint_as_float(r.h[1].x << 16);
+                cs.y += __uint_as_float(r.h[0].x & 0xffff0000u) + __uint_as_float(r.h[1].x & 0xffff0000u);
+                cs.z += __uint_as_float(r.h[0].y << 16) + __uint_as_float(r.h[1].y << 16);
+                cs.w += __uint_as_float(r.h[0].y & 0xffff0000u) + __uint_as_float(r.h[1].y & 0xffff0000u);
             }
         };
         if (do_cs) cs_add(ra0);
@@ -408,8 +445,9 @@ __global__ __launch_bounds__(256) void split_planes_kernel(SplitJobs jobs) {
 bool gemm_x3_shape_ok(int M, int N, int K, int lda, int ldb, int a_mode, int b_mode) {
     if (K % XK || (N & 3) || M <= 0 || N <= 0) return false;
     if (a_mode == X3_ROW && (lda & 3)) return false;
-    if (a_mode == X3_KMAJ && ((lda & 3) || lda < 4)) return false;
-    if (b_mode == X3_KMAJ && ((ldb & 3) || ldb < 4)) return false;
+    if ((a_mode == X3_KMAJ || a_mode == X3_KMAJ16) && ((lda & 3) || lda < 4)) return false;
+    if ((b_mode == X3_KMAJ || b_mode == X3_KMAJ16) && ((ldb & 3) || ldb < 4)) return false;
+    if (a_mode == X3_PLANES && (lda & 7)) return false;
     if (b_mode == X3_PLANES && (ldb & 7)) return false;
     return true;
 }
@@ -444,7 +482,18 @@ int gemm_x3(const X3Gemm& g, hipStream_t stream) {
     a.a_plane = 0; a.b_plane = g.b_plane; a.b2_plane = g.b2_plane;
     a.M = g.M; a.N = g.N; a.K = g.K; a.lda = g.lda; a.ldb = g.ldb; a.ldb2 = g.ldb2; a.ldc = g.ldc; a.ldc2 = g.ldc2; a.ldaux = g.ldaux;
     a.n_split = g.n_split; a.relu = g.relu; a.accumulate = g.accumulate; a.nbias = g.bias ? g.nbias : 0;
-    a.a_colsum = g.a_mode == X3_KMAJ ? g.a_colsum : nullptr;
+    // bf16 storage of configs[4] (prec 1 only): an activation / gradient operand that lives in HBM as bf16 takes the loader of its layout
+    // that does no arithmetic; the output and the relu mask may be bf16 as well
+    const int a_mode = g.a_bf16 ? (g.a_mode == X3_ROW ? X3_PLANES : X3_KMAJ16) : g.a_mode;
+    const int b_mode = g.b_bf16 ? X3_KMAJ16 : g.b_mode;
+    if ((g.a_bf16 || g.b_bf16 || g.c_bf16 || g.aux_bf16) &&
+        (g.prec != 1 || (g.a_bf16 && g.a_mode == X3_PLANES) || (g.b_bf16 && (g.b_mode != X3_KMAJ || g.B2 != nullptr)) ||
+         (g.c_bf16 && (g.accumulate || g.C2 != nullptr || g.scratch.p != nullptr)) || (a_mode == X3_PLANES && (g.lda & 7)))) {
+        set_error("gemm_x3: bf16 storage asked for a form that is not built", 1005);
+        return 1005;
+    }
+    a.a_colsum = (g.a_mode == X3_KMAJ) ? g.a_colsum : nullptr;
+    a.c_bf16 = g.c_bf16; a.aux_bf16 = g.aux_bf16;
     a.sa = g.sa; a.sb = g.sb; a.inv = 1.f / (g.sa * g.sb);
     int splits = 1;
     const long tiles = (long)((g.M + XB - 1) / XB) * ((g.N + XB - 1) / XB);
@@ -462,9 +511,14 @@ int gemm_x3(const X3Gemm& g, hipStream_t stream) {
     a.k_per_split = kper;
     if (splits > 1) a.slab = g.scratch.p;
     const char* name = g.a_mode == X3_KMAJ ? "gemm_f32_dW(TN,split-K)" : (g.transposed_w ? "gemm_f32_dX(NN)" : "gemm_f32_fwd(NT)");
-    ProfScope prof(name, 2.0 * g.M * (double)g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N), stream);
+    ProfScope prof(name, 2.0 * g.M * (double)g.N * g.K,
+                   (g.a_bf16 ? 2.0 : 4.0) * g.M * g.K + (g.b_bf16 || g.b_mode == X3_PLANES ? 2.0 : 4.0) * g.N * g.K + (g.c_bf16 ? 2.0 : 4.0) * g.M * g.N, stream);
     int rc;
-    if (g.a_mode == X3_ROW && g.b_mode == X3_PLANES)
+    if (a_mode == X3_PLANES && b_mode == X3_PLANES) rc = launch_x3<1, X3_PLANES, X3_PLANES>(a, splits, stream);
+    else if (a_mode == X3_KMAJ16 && b_mode == X3_KMAJ) rc = launch_x3<1, X3_KMAJ16, X3_KMAJ>(a, splits, stream);
+    else if (a_mode == X3_KMAJ16 && b_mode == X3_KMAJ16) rc = launch_x3<1, X3_KMAJ16, X3_KMAJ16>(a, splits, stream);
+    else if (a_mode == X3_KMAJ && b_mode == X3_KMAJ16) rc = launch_x3<1, X3_KMAJ, X3_KMAJ16>(a, splits, stream);
+    else if (g.a_mode == X3_ROW && g.b_mode == X3_PLANES)
         rc = g.prec == 1 ? launch_x3<1, X3_ROW, X3_PLANES>(a, splits, stream)
                          : (g.prec == 4 ? launch_x3<4, X3_ROW, X3_PLANES>(a, splits, stream) : launch_x3<6, X3_ROW, X3_PLANES>(a, splits, stream));
     else if (g.a_mode == X3_KMAJ && g.b_mode == X3_KMAJ)

@@ -33,6 +33,7 @@ struct RnnStepArgs {
     float* dc;             // [rows][H]  LSTM: total dL/dc_t
     float* dgx;            // [rows][G*H] grad wrt (W_ih x + b_ih)
     float* dgh;            // [rows][G*H] grad wrt (W_hh h + b_hh)   (GRU; LSTM: == dgx)
+    int bf16_store;        // rnn_team512.hip only (configs[4]): `gates` and `dgx` are bf16 [rows][G*H] buffers (policy.hip: bf16_store())
     long long* dbg;        // DC_LSTM_TIMING=1: phase cycle sums of workgroup 0 (else nullptr)
 };
 
@@ -71,7 +72,7 @@ int splitk_reduce(const float* slab, float* C, int M, int N, int ldc, int splits
 int splitk_reduce_pair(const float* slab, float* C, int M, int N, int ldc, int splits, int accumulate, float* C2, int ldc2,
                        int n_split, hipStream_t s);
 // gemm_x3.hip: the dense products on the bf16 matrix cores (prec 6: f32-grade by exact 3-way splitting; prec 1: plain bf16)
-enum { X3_ROW = 0, X3_KMAJ = 1, X3_PLANES = 2 };
+enum { X3_ROW = 0, X3_KMAJ = 1, X3_PLANES = 2, X3_KMAJ16 = 3 /* internal: a k-major operand stored as bf16 */ };
 struct X3Gemm {
     const void* A = nullptr; int a_mode = X3_ROW, lda = 0;             // X3_ROW: f32 [M][lda]; X3_KMAJ: f32 [K][lda]
     const void* B = nullptr; int b_mode = X3_PLANES, ldb = 0;          // X3_PLANES: bf16 [planes][N][ldb]; X3_KMAJ: f32 [K][ldb]
@@ -85,6 +86,9 @@ struct X3Gemm {
     float sa = 1.f, sb = 1.f;                           // prec 4: power-of-two pre-scales of A / B (an X3_PLANES operand was scaled by sb
                                                         // when its planes were made); the product is scaled back by 1 / (sa sb)
     GemmScratch scratch;
+    // bf16 storage (prec 1; configs[4]): the operand / the output / the relu mask `aux` live in HBM as bf16 with the same shape and ld
+    // (elements).  b_bf16: X3_KMAJ B only, no second B; c_bf16: no accumulate, no C2, no split-K (no scratch).
+    int a_bf16 = 0, b_bf16 = 0, c_bf16 = 0, aux_bf16 = 0;
     float* a_colsum = nullptr;    // X3_KMAJ A only: a_colsum[m] += sum_k A[k][m] (the bias gradient that goes with a weight gradient),
                                   // summed while the tiles pass through the loader - no second pass over A
 };

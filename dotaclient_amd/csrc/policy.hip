@@ -48,6 +48,16 @@ static inline float f16x2_grad_scale(long long rows) {
 static inline bool embed_fused_on(const dc_dims* d) { return !(d->flags & DC_DIMS_EMBED_UNFUSED) && d->rows > 0; }
 static inline int64_t emb_rows(const dc_dims* d) { return embed_fused_on(d) ? (d->rows + 127) / 128 * 128 : d->rows; }
 
+// bf16 STORAGE on configs[4]'s path (DC_DIMS_BF16, LSTM-512 on the persistent team kernels): the gate pre-activations / activated gates
+// and the gate gradients - [rows][4H] each, two thirds of the bytes the dense products and the recurrent kernels move - live in HBM as
+// bf16 (in the lower half of their f32-sized workspace buffers: the layout does not change).  Their consumers round them to bf16 anyway
+// (they are MFMA operands); what is new is the rounding of the stored gate activations the backward's cell maths reads.
+// DC_DIMS_BF16_F32_STORE keeps f32 storage (A/B, and the comparison with the launch-per-step kernels).
+static inline bool bf16_store(const dc_dims* d) {
+    return (d->flags & DC_DIMS_BF16) && !(d->flags & (DC_DIMS_BF16_F32_STORE | DC_DIMS_RNN_PER_STEP | DC_DIMS_RNN_STEP_BF16 | DC_DIMS_GEMM_FASTTILE)) &&
+           d->cell == 1 && d->hidden == 512 && 4 * (long long)d->n_seq <= d->rows && lstm_team512_supported(1, 512, d->flags, d);
+}
+
 // Weight matrices the dense products read as pre-split bf16 planes (gemm_x3.hip), in this order: affine_pre_rnn [256][896],
 // the recurrent input projections [G*H][in_l], the head block zero-padded to [160][H].  Elements of one orientation.
 static inline int64_t wplane_elems(const dc_dims* d) {
@@ -211,14 +221,16 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
         DC_TRY(split_weight_planes(jobs, d->layers, 1, s));
     }
     // y[rows][N] = x[rows][K] W[N][K]^T + b, through the split-on-load kernel (or the round-1 kernel)
+    const bool bs = bf16_store(d);
     auto linear = [&](const float* x, int K, const float* W, const uint16_t* Wp, int N, int Npad, const float* bias, int relu, float* y,
-                      int ldy) -> int {
+                      int ldy, int y_bf16 = 0) -> int {
         if (!x3) return gemm_f32(x, W, y, (int)NR, N, K, K, K, ldy, 0, 0, bias, relu, nullptr, 0, 0, 1, s);
         X3Gemm g;
         g.A = x; g.a_mode = X3_ROW; g.lda = K;
         g.B = Wp; g.b_mode = X3_PLANES; g.ldb = K; g.b_plane = (long long)Npad * K;
         g.C = y; g.ldc = ldy; g.M = (int)NR; g.N = Npad; g.K = K; g.bias = bias; g.nbias = N; g.relu = relu; g.prec = prec;
         g.sa = F16X2_S_ACT; g.sb = F16X2_S_W;
+        g.c_bf16 = y_bf16;
         return gemm_x3(g, s);
     };
     // pre-rnn projection (policy.py:138)
@@ -228,8 +240,9 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
     int in = PREW;
     for (int l = 0; l < d->layers; ++l) {
         const int pb = DC_P_RNN0 + 4 * l;
-        DC_TRY(linear(x, in, P.p(pb + 0), wp.fwd(wp.ih[l]), G * H, G * H, P.p(pb + 2), 0, w.fl(l, DC_WSL_GATES), G * H));
+        DC_TRY(linear(x, in, P.p(pb + 0), wp.fwd(wp.ih[l]), G * H, G * H, P.p(pb + 2), 0, w.fl(l, DC_WSL_GATES), G * H, bs));
         RnnStepArgs a{};
+        a.bf16_store = bs;
         a.h0 = h0 ? h0 + (size_t)l * B * H : nullptr;
         a.c0 = (c0 && d->cell == 1) ? c0 + (size_t)l * B * H : nullptr;
         a.seq_off = seq_off; a.seq_len = seq_len; a.n_seq = B; a.H = H;
@@ -290,20 +303,22 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     const float s_grad = f16x2_grad_scale(NR);
     const WPlanes wp = wplanes_of(d, w.base, w.off);
     // dx[rows][N] = dy[rows][K] W[K][N] (optionally masked by aux > 0): reads W^T as bf16 planes [N][K]
-    auto dgrad = [&](const float* dy, int K, const float* W, const uint16_t* WTp, int N, const float* aux, float* dx) -> int {
+    const bool bs = bf16_store(d);
+    auto dgrad = [&](const float* dy, int K, const float* W, const uint16_t* WTp, int N, const float* aux, float* dx, int dy_bf16 = 0) -> int {
         if (!x3) return gemm_f32(dy, W, dx, (int)NR, N, K, K, N, N, 0, 1, nullptr, 0, aux, N, 0, 1, s);
         X3Gemm g;
         g.A = dy; g.a_mode = X3_ROW; g.lda = K;
         g.B = WTp; g.b_mode = X3_PLANES; g.ldb = K; g.b_plane = (long long)N * K;
         g.C = dx; g.ldc = N; g.M = (int)NR; g.N = N; g.K = K; g.aux = aux; g.ldaux = N; g.prec = prec; g.transposed_w = 1;
         g.sa = s_grad; g.sb = F16X2_S_W;
+        g.a_bf16 = dy_bf16;
         return gemm_x3(g, s);
     };
     // dW[M][N] += dy[rows][lda: M]^T x[rows][ldb: N] (contraction over the env-steps, split-K); optional second x behind N
     // db (optional): the bias gradient that goes with dW, db[m] += sum over the env-steps of dy[.][m] - summed by the same kernel as dy
     // passes through its loader (a separate column-sum pass re-reads dy: 12 launches, 0.44 ms per configs[2] step)
     auto wgrad = [&](const float* dy, int lda, int M, const float* x1, int N1, float* dW1, const float* x2, int N2, float* dW2,
-                     float* db = nullptr) -> int {
+                     float* db = nullptr, int dy_bf16 = 0) -> int {
         const bool pair = x2 != nullptr;
         if (x3_tn && gemm_x3_shape_ok(M, N1 + N2, (int)NR, lda, N1, X3_KMAJ, X3_KMAJ) && (!pair || (N1 % 128 == 0 && !(N2 & 3)))) {
             X3Gemm g;
@@ -313,8 +328,10 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
             g.C = dW1; g.ldc = N1; g.C2 = dW2; g.ldc2 = N2; g.M = M; g.N = N1 + N2; g.K = (int)NR; g.accumulate = 1; g.prec = prec;
             g.sa = s_grad; g.sb = F16X2_S_ACT;
             g.scratch = sc;
+            g.a_bf16 = dy_bf16;
             return gemm_x3(g, s);
         }
+        if (dy_bf16) { set_error("policy_backward: bf16 storage needs the split-on-load products", 1005); return 1005; }
         if (db != nullptr) DC_TRY(colsum(dy, lda, NR, M, db, s));
         if (pair) return gemm_f32_tn_pair(dy, lda, x1, N1, N1, x2, N2, N2, dW1, N1, dW2, N2, M, (int)NR, s, sc);
         return gemm_f32(dy, x1, dW1, M, N1, (int)NR, lda, N1, N1, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s, sc);
@@ -363,12 +380,13 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         a.Whh = P.p(pb + 1); a.WhhT = w.f(DC_WS_WHHT); a.dh = w.fl(l, DC_WSL_DH); a.dc = w.fl(l, DC_WSL_DC);
         a.dgx = w.fl(l, DC_WSL_DGX);
         a.dgh = d->cell == 0 ? w.fl(l, DC_WSL_DGH) : w.fl(l, DC_WSL_DGX);
+        a.bf16_store = bs;
         DC_TRY(rnn_backward_layer(d->cell, a, d->max_len, s));
         const float* xin = l == 0 ? w.f(DC_WS_PRE) : w.fl(l - 1, DC_WSL_HSEQ);
         const int in = l == 0 ? PREW : H;
         // dW_ih = dgx^T x ; dW_hh = dgh^T h_prev ; biases = column sums
         if (a.dgh == a.dgx) {   // LSTM: both products contract the same gate gradients - one launch
-            DC_TRY(wgrad(a.dgx, G * H, G * H, xin, in, Gd.p(pb + 0), a.hprev, H, Gd.p(pb + 1), Gd.p(pb + 2)));
+            DC_TRY(wgrad(a.dgx, G * H, G * H, xin, in, Gd.p(pb + 0), a.hprev, H, Gd.p(pb + 1), Gd.p(pb + 2), bs));
             // dgh is dgx, so d(b_hh) = d(b_ih): copy 2 KB
             DC_TRY(copy_f32_async(Gd.p(pb + 3), Gd.p(pb + 2), (long long)G * H, s));
         } else {
@@ -376,10 +394,10 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
             DC_TRY(wgrad(a.dgh, G * H, G * H, a.hprev, H, Gd.p(pb + 1), nullptr, 0, nullptr, Gd.p(pb + 3)));
         }
         if (l > 0) {
-            DC_TRY(dgrad(a.dgx, G * H, P.p(pb + 0), wp.bwd(wp.ih[l]), H, nullptr, w.fl(l - 1, DC_WSL_DH)));
+            DC_TRY(dgrad(a.dgx, G * H, P.p(pb + 0), wp.bwd(wp.ih[l]), H, nullptr, w.fl(l - 1, DC_WSL_DH), bs));
         } else {
             // through relu(affine_pre_rnn) (policy.py:138): mask with the stored activation
-            DC_TRY(dgrad(a.dgx, G * H, P.p(pb + 0), wp.bwd(wp.ih[0]), PREW, w.f(DC_WS_PRE), w.f(DC_WS_DPRE)));
+            DC_TRY(dgrad(a.dgx, G * H, P.p(pb + 0), wp.bwd(wp.ih[0]), PREW, w.f(DC_WS_PRE), w.f(DC_WS_DPRE), bs));
         }
     }
     DC_TRY(wgrad(w.f(DC_WS_DPRE), PREW, PREW, w.f(DC_WS_XCAT), XCATW, Gd.p(DC_P_PRE_W), nullptr, 0, nullptr, Gd.p(DC_P_PRE_B)));

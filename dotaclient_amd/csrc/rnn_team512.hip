@@ -169,7 +169,9 @@ __device__ __forceinline__ int t5_tile_tmax(const RnnStepArgs& p, int b0, int ns
 // the step is as long as its instruction stream.  Hence: a thread's cells are FOUR CONSECUTIVE UNITS OF ONE SEQUENCE (one row
 // address, 16-byte loads and stores), row pointers advance by a stride, transcendental gates on v_exp / v_rcp.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int NS>
+// BS (RnnStepArgs::bf16_store, configs[4]'s bf16 storage): `gates` is a bf16 [rows][4H] buffer - the input projections arrive rounded to
+// bf16 (gemm_x3's epilogue) and the activated gates are left as bf16 for the backward: 8-byte instead of 16-byte accesses per thread.
+template <int NS, bool BS>
 __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStepArgs p, const uint16_t* __restrict__ Wb,
                                                                           u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -218,7 +220,17 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
         const int bq = b0 + cs_;
         const int len = (has_cell && bq < p.n_seq) ? p.seq_len[bq] : 0;
         const size_t row0 = len > 0 ? (size_t)p.seq_off[bq] : 0;
-        float* const gbase = p.gates + row0 * GH + j0;                 // row t: + t * GH
+        using GT = std::conditional_t<BS, uint16_t, float>;
+        GT* const gbase = reinterpret_cast<GT*>(p.gates) + row0 * GH + j0;      // row t: + t * GH
+        // (the prefetched row stays RAW in its registers until the step that uses it: any arithmetic on it at the point of the load
+        //  would wait for the load there - measured: + 3 600 clocks per step in the prefetch phase)
+        using GR = std::conditional_t<BS, uint2, float4>;
+        auto gload = [](const GT* q) -> GR { return *reinterpret_cast<const GR*>(q); };
+        auto gdecode = [](const GR& w) -> float4 {
+            if constexpr (BS) return make_float4(t5_bf16_lo(w.x), t5_bf16_hi(w.x), t5_bf16_lo(w.y), t5_bf16_hi(w.y));
+            else return w;
+        };
+        const GR gzero = GR{};
         float* const sbase = p.cseq + row0 * H + j0;                   // cseq; hseq / cprev / hprev at the same offset of their buffers
         const ptrdiff_t d_h = p.hseq - p.cseq, d_cp = p.cprev - p.cseq, d_hp = p.hprev - p.cseq;
         float4 c = len > 0 ? *reinterpret_cast<const float4*>(sbase + d_cp) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -240,9 +252,12 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
         int pt = 0;
         auto flush = [&]() {
             if (!pend) return;
-            float* gt = gbase + (size_t)pt * GH;
+            GT* gt = gbase + (size_t)pt * GH;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(gt + g * H) = pact[g];
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (BS) *reinterpret_cast<uint2*>(gt + g * H) = make_uint2(cvt_pk_bf16(pact[g].x, pact[g].y), cvt_pk_bf16(pact[g].z, pact[g].w));
+                else *reinterpret_cast<float4*>(gt + g * H) = pact[g];
+            }
             float* st = sbase + (size_t)pt * H;
             *reinterpret_cast<float4*>(st) = pc;
             *reinterpret_cast<float4*>(st + d_h) = ph;
@@ -254,9 +269,9 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
         };
         // ... and the input projections W_ih x + b_ih of a step are fetched ONE STEP AHEAD, for the same reason (a load from HBM
         // issued right before the granule loads would sit in front of every one of them)
-        float4 gxn[4];
+        GR gxn[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) gxn[g] = len > 0 ? *reinterpret_cast<const float4*>(gbase + g * H) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < 4; ++g) gxn[g] = len > 0 ? gload(gbase + g * H) : gzero;
         __syncthreads();
 
 #pragma unroll 1
@@ -268,7 +283,7 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
             const bool on = t < len;
             float4 gx[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) gx[g] = gxn[g];
+            for (int g = 0; g < 4; ++g) gx[g] = gdecode(gxn[g]);
             // (b) the fifteen peers' h_{t-1}: NPOLL granules per thread (granule nn: peer 256 nn / PAIRS, pair 256 nn % PAIRS + tid)
             if (t > 0) {
                 const unsigned rt = tag - 1;
@@ -293,9 +308,9 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
             flush();       // the previous step's results
             {              // the next step's input projections
                 const bool onn = t + 1 < len;
-                const float* gt = gbase + (size_t)(t + 1) * GH;
+                const GT* gt = gbase + (size_t)(t + 1) * GH;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) gxn[g] = onn ? *reinterpret_cast<const float4*>(gt + g * H) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int g = 0; g < 4; ++g) gxn[g] = onn ? gload(gt + g * H) : gzero;
             }
             __syncthreads();
             stamp(1);      // stores + prefetch issue + barrier
@@ -373,7 +388,9 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
 // backward through time.  In: dh (from the layer above / the heads), the forward's gates / cseq / cprev; out: dgx (gradient w.r.t.
 // W_ih x + b_ih = w.r.t. W_hh h + b_hh), dh (total), dc.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int NS>
+// BS: the forward's gates and this kernel's gate gradients `dgx` are bf16 [rows][4H] buffers (the weight- and input-gradient products
+// read dgx as a bf16 operand anyway)
+template <int NS, bool BS>
 __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStepArgs p, const uint16_t* __restrict__ WTb,
                                                                           u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -433,16 +450,25 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
         // The cells' operands of a step are fetched TWO STEPS AHEAD into one of two register sets (static indices: the loop is unrolled by
         // two).  Two, not one: the loads come from HBM (> 2 us) and are issued behind a step's granule loads; a set loaded during step
         // t + 1 and copied out at the top of step t was waited for there (about 1 us per step).
-        float gvn[2][NC][4], dhn[2][NC], csn[2][NC], cpn[2][NC];
+        // (BS: the gates stay the raw 16 bits until the step that uses them - a shift at the point of the load would wait for it there)
+        using GV = std::conditional_t<BS, unsigned, float>;
+        GV gvn[2][NC][4];
+        float dhn[2][NC], csn[2][NC], cpn[2][NC];
         auto fetch = [&](int tt, auto PAR) {
             constexpr int P = decltype(PAR)::value;
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
                 const bool o = tt >= 0 && tt < len[q];
                 const size_t rr = row0[q] + (size_t)(tt < 0 ? 0 : tt);
-                const float* gt = p.gates + rr * GH + j;
+                if constexpr (BS) {
+                    const uint16_t* gt = reinterpret_cast<const uint16_t*>(p.gates) + rr * GH + j;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) gvn[P][q][g] = o ? gt[g * H] : 0.f;
+                    for (int g = 0; g < 4; ++g) gvn[P][q][g] = o ? (unsigned)gt[g * H] : 0u;
+                } else {
+                    const float* gt = p.gates + rr * GH + j;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) gvn[P][q][g] = o ? gt[g * H] : 0.f;
+                }
                 dhn[P][q] = o ? p.dh[rr * H + j] : 0.f;
                 csn[P][q] = o ? p.cseq[rr * H + j] : 0.f;
                 cpn[P][q] = o ? p.cprev[rr * H + j] : 0.f;
@@ -462,9 +488,15 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
                 if (!pend[q]) continue;
                 p.dh[prow[q] * H + j] = pd[q][4];
                 p.dc[prow[q] * H + j] = pd[q][5];
-                float* gx = p.dgx + prow[q] * GH + j;
+                if constexpr (BS) {
+                    uint16_t* gx = reinterpret_cast<uint16_t*>(p.dgx) + prow[q] * GH + j;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) gx[g * H] = pd[q][g];
+                    for (int g = 0; g < 4; ++g) gx[g * H] = (uint16_t)(cvt_pk_bf16(pd[q][g], 0.f) & 0xffffu);
+                } else {
+                    float* gx = p.dgx + prow[q] * GH + j;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) gx[g * H] = pd[q][g];
+                }
                 pend[q] = false;
             }
         };
@@ -487,7 +519,10 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
                 has_next[q] = t + 1 < len[q];
                 r[q] = row0[q] + (size_t)t;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) gv[q][g] = gvn[P][q][g];
+                for (int g = 0; g < 4; ++g) {
+                    if constexpr (BS) gv[q][g] = __uint_as_float(gvn[P][q][g] << 16);
+                    else gv[q][g] = gvn[P][q][g];
+                }
                 dhv[q] = dhn[P][q]; cs[q] = csn[P][q]; cp[q] = cpn[P][q];
             }
             float rec[NC];
@@ -603,7 +638,8 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
     if (DC_DEV_TIMING && timing) { tm[7] = plain; for (int k = 0; k < 8; ++k) p.dbg[k] = tm[k]; }
     if (failed && tid < T5_US) {
         const int b = min(team * NS, p.n_seq - 1);
-        p.dgx[(size_t)p.seq_off[b] * GH + U0 + tid] = __builtin_nanf("");
+        if constexpr (BS) reinterpret_cast<uint16_t*>(p.dgx)[(size_t)p.seq_off[b] * GH + U0 + tid] = 0x7fc0u;      // bf16 NaN
+        else p.dgx[(size_t)p.seq_off[b] * GH + U0 + tid] = __builtin_nanf("");
     }
 }
 
@@ -656,12 +692,15 @@ bool lstm_team512_supported(int cell, int H, int flags, const void* Wb) {
 int lstm_team512_forward(RnnStepArgs a, int max_len, hipStream_t s) {
     u64* xb = static_cast<u64*>(a.xbuf);
     if (!xb) { set_error("lstm_team512_forward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }
-    static bool attr16 = false, attr32 = false;
-    if (int e = t5_attr(lstm512_team_fwd_kernel<16>, t5_fwd_lds(16), &attr16)) return e;
-    if (int e = t5_attr(lstm512_team_fwd_kernel<32>, t5_fwd_lds(32), &attr32)) return e;
+    static bool attr[4] = {false, false, false, false};
+    if (int e = t5_attr(lstm512_team_fwd_kernel<16, false>, t5_fwd_lds(16), &attr[0])) return e;
+    if (int e = t5_attr(lstm512_team_fwd_kernel<32, false>, t5_fwd_lds(32), &attr[1])) return e;
+    if (int e = t5_attr(lstm512_team_fwd_kernel<16, true>, t5_fwd_lds(16), &attr[2])) return e;
+    if (int e = t5_attr(lstm512_team_fwd_kernel<32, true>, t5_fwd_lds(32), &attr[3])) return e;
     const int ns = (a.flags & DC_DIMS_TEAM_NS(2)) ? 32 : t5_tile_seqs(a.n_seq);     // DC_DIMS_TEAM_NS(2): force 32-sequence tiles (A/B)
     const int nt = t5_teams(a.n_seq, ns);
-    ProfScope prof("lstm_fwd_team", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * 12.0, s);
+    // per cell: gates in + out (4 + 4 values, f32 or bf16), c, h, cprev, hprev (f32)
+    ProfScope prof("lstm_fwd_team", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len, (double)a.n_seq * max_len * a.H * (a.bf16_store ? 8 * 2.0 + 16.0 : 48.0), s);
     if (int rc = zero_async(xb, ((size_t)T5_HDR + T5_HS + (size_t)nt * (ns == 16 ? t5_fwd_ring(16) : t5_fwd_ring(32))) * sizeof(u64), s)) return rc;
 #if DC_DEV_TIMING
     static long long* dbg = nullptr;
@@ -669,10 +708,12 @@ int lstm_team512_forward(RnnStepArgs a, int max_len, hipStream_t s) {
     (void)hipMemsetAsync(dbg, 0, 64, s);
     a.dbg = dbg;
 #endif
-    if (ns == 16) hipLaunchKernelGGL(lstm512_team_fwd_kernel<16>, dim3(nt * T5_M), dim3(T5_THREADS), t5_fwd_lds(16), s, a, a.Whh_bf, xb, nt,
-                                     !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
-    else hipLaunchKernelGGL(lstm512_team_fwd_kernel<32>, dim3(nt * T5_M), dim3(T5_THREADS), t5_fwd_lds(32), s, a, a.Whh_bf, xb, nt,
-                            !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+    const int plain_ok = !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE);
+    const dim3 grid(nt * T5_M), block(T5_THREADS);
+    if (ns == 16 && a.bf16_store) hipLaunchKernelGGL((lstm512_team_fwd_kernel<16, true>), grid, block, t5_fwd_lds(16), s, a, a.Whh_bf, xb, nt, plain_ok);
+    else if (ns == 16) hipLaunchKernelGGL((lstm512_team_fwd_kernel<16, false>), grid, block, t5_fwd_lds(16), s, a, a.Whh_bf, xb, nt, plain_ok);
+    else if (a.bf16_store) hipLaunchKernelGGL((lstm512_team_fwd_kernel<32, true>), grid, block, t5_fwd_lds(32), s, a, a.Whh_bf, xb, nt, plain_ok);
+    else hipLaunchKernelGGL((lstm512_team_fwd_kernel<32, false>), grid, block, t5_fwd_lds(32), s, a, a.Whh_bf, xb, nt, plain_ok);
 #if DC_DEV_TIMING
     {
         long long h[8];
@@ -688,9 +729,11 @@ int lstm_team512_forward(RnnStepArgs a, int max_len, hipStream_t s) {
 int lstm_team512_backward(RnnStepArgs a, int max_len, hipStream_t s) {
     u64* xb = static_cast<u64*>(a.xbuf);
     if (!xb) { set_error("lstm_team512_backward: no exchange buffer (RnnStepArgs::xbuf)", 1012); return 1012; }
-    static bool attr16 = false, attr32 = false;
-    if (int e = t5_attr(lstm512_team_bwd_kernel<16>, t5_bwd_lds(16), &attr16)) return e;
-    if (int e = t5_attr(lstm512_team_bwd_kernel<32>, t5_bwd_lds(32), &attr32)) return e;
+    static bool attr[4] = {false, false, false, false};
+    if (int e = t5_attr(lstm512_team_bwd_kernel<16, false>, t5_bwd_lds(16), &attr[0])) return e;
+    if (int e = t5_attr(lstm512_team_bwd_kernel<32, false>, t5_bwd_lds(32), &attr[1])) return e;
+    if (int e = t5_attr(lstm512_team_bwd_kernel<16, true>, t5_bwd_lds(16), &attr[2])) return e;
+    if (int e = t5_attr(lstm512_team_bwd_kernel<32, true>, t5_bwd_lds(32), &attr[3])) return e;
     const int ns = (a.flags & DC_DIMS_TEAM_NS(2)) ? 32 : t5_tile_seqs(a.n_seq);
     const int nt = t5_teams(a.n_seq, ns);
 #if DC_DEV_TIMING
@@ -699,12 +742,15 @@ int lstm_team512_backward(RnnStepArgs a, int max_len, hipStream_t s) {
     (void)hipMemsetAsync(dbg, 0, 64, s);
     a.dbg = dbg;
 #endif
-    ProfScope prof("lstm_bwd_team", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len, 4.0 * a.n_seq * max_len * a.H * 18.0, s);
+    // per cell: gates in, dgx out (4 + 4 values, f32 or bf16), dh in + out, dc out, c, cprev (f32)
+    ProfScope prof("lstm_bwd_team", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len, (double)a.n_seq * max_len * a.H * (a.bf16_store ? 8 * 2.0 + 20.0 : 52.0), s);
     if (int rc = zero_async(xb, ((size_t)T5_HDR + T5_HS + (size_t)nt * (ns == 16 ? t5_bwd_ring(16) : t5_bwd_ring(32))) * sizeof(u64), s)) return rc;
-    if (ns == 16) hipLaunchKernelGGL(lstm512_team_bwd_kernel<16>, dim3(nt * T5_M), dim3(T5_THREADS), t5_bwd_lds(16), s, a, a.WhhT_bf, xb, nt,
-                                     !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
-    else hipLaunchKernelGGL(lstm512_team_bwd_kernel<32>, dim3(nt * T5_M), dim3(T5_THREADS), t5_bwd_lds(32), s, a, a.WhhT_bf, xb, nt,
-                            !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+    const int plain_ok = !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE);
+    const dim3 grid(nt * T5_M), block(T5_THREADS);
+    if (ns == 16 && a.bf16_store) hipLaunchKernelGGL((lstm512_team_bwd_kernel<16, true>), grid, block, t5_bwd_lds(16), s, a, a.WhhT_bf, xb, nt, plain_ok);
+    else if (ns == 16) hipLaunchKernelGGL((lstm512_team_bwd_kernel<16, false>), grid, block, t5_bwd_lds(16), s, a, a.WhhT_bf, xb, nt, plain_ok);
+    else if (a.bf16_store) hipLaunchKernelGGL((lstm512_team_bwd_kernel<32, true>), grid, block, t5_bwd_lds(32), s, a, a.WhhT_bf, xb, nt, plain_ok);
+    else hipLaunchKernelGGL((lstm512_team_bwd_kernel<32, false>), grid, block, t5_bwd_lds(32), s, a, a.WhhT_bf, xb, nt, plain_ok);
 #if DC_DEV_TIMING
     {
         long long h[8];

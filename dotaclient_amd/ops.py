@@ -65,13 +65,22 @@ def prec_f16x2(log2_sa=0, log2_sb=0):
     return 4 | ((log2_sa & 0xff) << 8) | ((log2_sb & 0xff) << 16)
 
 
+def prec_bf16_store(a=False, b=False, c=False, aux=False):
+    """`x3` value for the plain-bf16 products (prec 1) with A / B / C / aux STORED as bf16 tensors of the same shape and leading dimension
+    (DC_GEMM_PREC_BF16_STORE, include/dotaclient_hip.h): configs[4]'s gate buffers."""
+    return 1 | (int(a) << 8) | (int(b) << 9) | (int(c) << 10) | (int(aux) << 11)
+
+
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, bias=None, relu=False, aux=None,
          ldaux=0, accumulate=False, splits=0, scratch=None, x3=0):
     """x3 = 6 / 4 / 1: the split-on-load matrix-core kernel (dc_gemm_x3: three bf16 pieces / two f16 pieces (prec_f16x2 for pre-scales) /
     plain bf16); 0: dc_gemm_f32."""
     lib = _lib.load()
-    for t, n in ((A, 'A'), (B, 'B'), (C, 'C')):
-        _chk(t, torch.float32, n)
+    stored = (x3 >> 8) & 0xf if (x3 & 0xff) == 1 else 0         # bf16-stored operands (prec_bf16_store)
+    for i, (t, n) in enumerate(((A, 'A'), (B, 'B'), (C, 'C'))):
+        _chk(t, torch.bfloat16 if (stored >> i) & 1 else torch.float32, n)
+    if aux is not None:
+        _chk(aux, torch.bfloat16 if stored & 8 else torch.float32, 'aux')
     if x3:
         _lib.check(lib.dc_gemm_x3(_lib.ptr(A), _lib.ptr(B), _lib.ptr(C), M, N, K, lda, ldb, ldc, int(a_kmajor), int(b_kmajor),
                                   _lib.ptr(bias), int(relu), _lib.ptr(aux), ldaux, int(accumulate), int(x3), _lib.ptr(scratch),

@@ -78,6 +78,9 @@ int dc_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, i
  * matrix in the first two forms and is split into bf16 planes inside the call (into `scratch`, which must hold
  * 3 * N * K / 2 floats for it, plus splits * M * N for split-K).  K % 16 == 0, N % 4 == 0.  No relu/aux with split-K. */
 #define DC_GEMM_PREC_F16X2(la, lb) (4 | (((la) & 0xff) << 8) | (((lb) & 0xff) << 16))
+/* prec 1 with operands / results STORED as bf16 (BASELINE.json configs[4]'s path keeps its gate buffers that way): a, b, c, aux = 1 when
+ * A, B, C, aux point at bf16 elements of the same shape and ld (in elements).  b: the k-major form only; c: no accumulate, no split-K. */
+#define DC_GEMM_PREC_BF16_STORE(a, b, c, aux) (1 | ((a) << 8) | ((b) << 9) | ((c) << 10) | ((aux) << 11))
 int dc_gemm_x3(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                int a_kmajor, int b_kmajor, const float* bias, int relu, const float* aux, int ldaux,
                int accumulate, int prec, float* scratch, int64_t scratch_floats, dc_stream_t stream);
@@ -176,6 +179,10 @@ typedef struct dc_dims {
  *                            DC_DIMS_TEAM4 keeps them off (A/B). */
 #define DC_DIMS_TEAM8 524288
 #define DC_DIMS_TEAM4 1048576
+/*   DC_DIMS_BF16_F32_STORE : with DC_DIMS_BF16 on the persistent LSTM-512 kernels (BASELINE.json configs[4]) the gate pre-activations /
+ *                            activated gates and the gate gradients are STORED as bf16 (round 5: csrc/policy.hip bf16_store()); this flag
+ *                            keeps them f32 (A/B; the comparison with the launch-per-step kernels, whose buffers are f32). */
+#define DC_DIMS_BF16_F32_STORE 4194304
 
 /* index into poff[]; policy.py:54-75 names in comments */
 enum dc_param_index {

@@ -178,6 +178,61 @@ def test_gemm_x3_layouts(prec, tol, akm, bkm, M, N, K):
         assert (C3.cpu().double() - (ref + 2)).abs().max() / ref.abs().max() < tol
 
 
+@pytest.mark.parametrize('form', ['x W^T', 'dy W', 'dy^T x', 'dy^T x (both stored)', 'dy^T x (B stored)'])
+@pytest.mark.parametrize('M,N,K', [(1000, 256, 896), (130, 72, 160), (2048, 768, 256), (152, 256, 8192), (33, 12, 16)])
+def test_gemm_x3_bf16_storage(form, M, N, K):
+    # BASELINE.json configs[4]'s path keeps its gate buffers in HBM as bf16 (policy.hip bf16_store()): the prec-1 products then read an
+    # operand with the loader that does no arithmetic (row-major: as one pre-split plane; k-major: pairs along k packed by two v_perm)
+    # and may write C / read the relu mask as bf16.  Against f64 on the SAME bf16-rounded operands the only error left is the f32
+    # accumulation (1e-5 of max |C| up to K = 8192); a bf16 C must be that result rounded once (<= 2^-8 relative per entry).
+    from dotaclient_amd import ops
+    dev = _dev()
+    akm = form.startswith('dy^T x')
+    bkm = form != 'x W^T'
+    a_st = form != 'dy^T x (B stored)'
+    b_st = form in ('dy^T x (both stored)', 'dy^T x (B stored)')
+    g = torch.Generator().manual_seed(M + 3 * N + 5 * K + len(form))
+    lda = ((M + 7) // 8 * 8 if akm else K) + 8          # bf16 rows are read 16 / 8 bytes at a time
+    ldb = (N if bkm else K) + 8
+    A = torch.randn((K if akm else M), lda, generator=g)
+    B = torch.randn((K if bkm else N), ldb, generator=g) / 16.0
+    bias = torch.randn(N, generator=g)
+    A16, B16 = A.bfloat16(), B.bfloat16()
+    Am = (A16[:, :M].t() if akm else A16[:, :K]).double()
+    Bm = (B16[:, :N] if bkm else B16[:, :K].t()).double()
+    tn = akm and bkm
+    ref = Am @ Bm + (0 if tn else bias.double())
+    scale = ref.abs().max().item()
+    scratch = torch.empty(max(2 * N * K, 16 * M * N) + 1024, device=dev)
+    Ad = A16.to(dev) if a_st else A.to(dev)
+    Bd = B16.to(dev) if b_st else B.to(dev)
+    ldc = N + 4
+    C = torch.full((M, ldc), 7.0, device=dev)
+    ops.gemm(Ad, Bd, C, M, N, K, lda, ldb, ldc, akm, bkm, bias=None if tn else bias.to(dev), scratch=scratch,
+             x3=ops.prec_bf16_store(a=a_st, b=b_st))
+    out = C.cpu()
+    assert torch.all(out[:, N:] == 7.0), 'wrote outside the N columns'
+    err = (out[:, :N].double() - ref).abs().max().item() / scale
+    assert err < 1e-5, err
+    if tn:                                               # accumulate into live data through the split-K reduce
+        C3 = torch.full((M, N), 2.0, device=dev)
+        ops.gemm(Ad, Bd, C3, M, N, K, lda, ldb, N, True, True, accumulate=True, scratch=scratch, x3=ops.prec_bf16_store(a=a_st, b=b_st))
+        assert (C3.cpu().double() - (ref + 2)).abs().max() / scale < 1e-5
+        return
+    # bf16 output (+ relu), and the relu mask read as bf16 (values around zero: the sign is what matters, bf16 keeps it)
+    C16 = torch.full((M, ldc), 7.0, device=dev, dtype=torch.bfloat16)
+    ops.gemm(Ad, Bd, C16, M, N, K, lda, ldb, ldc, akm, bkm, bias=bias.to(dev), relu=True, scratch=scratch, x3=ops.prec_bf16_store(a=True, c=True))
+    o16 = C16.cpu().float()
+    assert torch.all(o16[:, N:] == 7.0), 'wrote outside the N columns'
+    want = ref.clamp(min=0)
+    assert ((o16[:, :N].double() - want).abs() <= want.abs() * 2.0 ** -8 + 1e-5 * scale).all()
+    aux = torch.randn(M, N, generator=g)
+    C2 = torch.empty(M, N, device=dev)
+    ops.gemm(Ad, Bd, C2, M, N, K, lda, ldb, N, akm, bkm, bias=bias.to(dev), aux=aux.bfloat16().to(dev), ldaux=N, scratch=scratch,
+             x3=ops.prec_bf16_store(a=True, aux=True))
+    assert (C2.cpu().double() - ref * (aux > 0)).abs().max() / scale < 1e-5
+
+
 # ---- the default arithmetic at its edges (VERDICT r4 missing 3): prec 4 with the pre-scales policy.hip passes --------------------------
 # activations 2^4 (limit 65504 / 16 = 4094), weights 2^8 (limit 255.9), gradients 2^(ceil(log2 rows) + 2) (limit ~16384 / rows).
 F16_MAX = 65504.0
