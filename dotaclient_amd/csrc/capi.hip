@@ -125,7 +125,7 @@ int dc_chunk_initial_state(const dc_dims* dims, const void* ws, const int64_t* p
     for (int l = 0; l < dims->layers; ++l) {
         const int b = DC_WS_FIXED + l * DC_WS_PER_LAYER;
         if (int e = dc::rnn_gather_state(ws_f(dims, ws, b + DC_WSL_HSEQ), prev_row, h0 + (size_t)l * n_chunks * dims->hidden, n_chunks,
-                                         dims->hidden, (hipStream_t)stream))
+                                         dims->hidden, (hipStream_t)stream, dc::policy_bf16_store(dims) ? 1 : 0))
             return e;
         if (dims->cell == 1 && c0 != nullptr)
             if (int e = dc::rnn_gather_state(ws_f(dims, ws, b + DC_WSL_CSEQ), prev_row, c0 + (size_t)l * n_chunks * dims->hidden, n_chunks,

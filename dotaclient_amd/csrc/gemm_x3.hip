@@ -54,6 +54,10 @@ template <int PREC> struct X3Cfg {
     static constexpr int kOcc = kThree ? 3 : 2;
     static constexpr int kOper = (kThree ? 2 : 3) * RM_PLANE, kStage = 2 * kOper, kLds = 2 * kStage;   // 49152 / 73728
     static constexpr int kImgRows = kThree ? 32 : 64;
+    // PREC = 1 has ONE piece per operand: the second LDS plane of the two-plane budget holds the NEXT sixteen k instead, so a step
+    // between two barriers is K = 32 - eight MFMAs per wave instead of four (with four the step was all barrier and LDS latency:
+    // 0.24 of the bf16 peak on configs[4]'s products)
+    static constexpr int kKH = (PREC == 1 && kThree) ? 2 : 1;
 };
 
 struct X3Args {
@@ -79,11 +83,13 @@ __device__ __forceinline__ unsigned pk_f16(float a, float b) {      // {f16(b), 
 //                 stored as bf16 [rows][ld] (bf16 storage of configs[4]: X3Gemm::a_bf16)
 // MODE X3_KMAJ16: bf16 [k][ld], rows contiguous          -> planes [8 kpairs][128 rows] u32 (PREC = 1; the pairs along k are packed
 //                 with two v_perm - no conversion)
-template <int MODE, int NP, bool F16 = false>
+// KH: sub-steps of sixteen k per staged step (X3Cfg::kKH); sub-step h of piece p lives in LDS plane h * NP + p
+template <int MODE, int NP, bool F16 = false, int KH = 1>
 struct X3Loader {
-    struct Regs { float4 v[2]; u32x4 w[NP]; uint2 h[2]; };   // one staged K step of this thread (only the members its MODE uses are live)
+    struct Regs { float4 v[2 * KH]; u32x4 w[NP * KH]; uint2 h[2 * KH]; };   // one staged K step of this thread (only the members its MODE uses are live)
     const char* src[2];
     long long step;        // bytes per K step
+    long long sub;         // bytes between the sub-steps of a step
     long long plane;       // bytes between planes (X3_PLANES)
     float scale;           // F16: power-of-two pre-scale of this operand
 
@@ -96,43 +102,49 @@ struct X3Loader {
                 const int row = min(r_base + (tid >> 2) + 64 * i, R - 1);
                 src[i] = reinterpret_cast<const char*>(static_cast<const float*>(P) + (size_t)row * ld + k0 + kc);
             }
-            step = XK * 4;
+            sub = XK * 4;
         } else if constexpr (MODE == X3_KMAJ) {
             const int kp = tid >> 5;
             const int c = min(r_base + (tid & 31) * 4, ld - 4);   // stay inside the physical row (columns past R are never stored)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 src[i] = reinterpret_cast<const char*>(static_cast<const float*>(P) + (size_t)(k0 + 2 * kp + i) * ld + c);
-            step = (long long)XK * ld * 4;
+            sub = (long long)XK * ld * 4;
         } else if constexpr (MODE == X3_KMAJ16) {
             const int kp = tid >> 5;
             const int c = min(r_base + (tid & 31) * 4, ld - 4);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 src[i] = reinterpret_cast<const char*>(static_cast<const uint16_t*>(P) + (size_t)(k0 + 2 * kp + i) * ld + c);
-            step = (long long)XK * ld * 2;
+            sub = (long long)XK * ld * 2;
         } else {
             const int row = min(r_base + (tid >> 1), R - 1);
             src[0] = reinterpret_cast<const char*>(static_cast<const uint16_t*>(P) + (size_t)row * ld + k0 + (tid & 1) * 8);
             src[1] = nullptr;
-            step = XK * 2;
+            sub = XK * 2;
             plane = plane_elems * 2;
         }
+        step = KH * sub;
     }
-    __device__ __forceinline__ void load(Regs& r) {
-        if constexpr (MODE == X3_PLANES) {
+    // nsub (workgroup-uniform): sub-steps of this step that exist (the last step of a K that is an odd multiple of 16 has one): the
+    // others are staged as zeros
+    __device__ __forceinline__ void load(Regs& r, int nsub = KH) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p) r.w[p] = *reinterpret_cast<const u32x4*>(src[0] + p * plane);
-            src[0] += step;
-        } else if constexpr (MODE == X3_KMAJ16) {
-            r.h[0] = *reinterpret_cast<const uint2*>(src[0]);
-            r.h[1] = *reinterpret_cast<const uint2*>(src[1]);
-            src[0] += step; src[1] += step;
-        } else {
-            r.v[0] = *reinterpret_cast<const float4*>(src[0]);
-            r.v[1] = *reinterpret_cast<const float4*>(src[1]);
-            src[0] += step; src[1] += step;
+        for (int h = 0; h < KH; ++h) {
+            const bool on = KH == 1 || h < nsub;
+            if constexpr (MODE == X3_PLANES) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) r.w[h * NP + p] = on ? *reinterpret_cast<const u32x4*>(src[0] + p * plane + h * sub) : u32x4{0u, 0u, 0u, 0u};
+            } else if constexpr (MODE == X3_KMAJ16) {
+                r.h[2 * h] = on ? *reinterpret_cast<const uint2*>(src[0] + h * sub) : make_uint2(0u, 0u);
+                r.h[2 * h + 1] = on ? *reinterpret_cast<const uint2*>(src[1] + h * sub) : make_uint2(0u, 0u);
+            } else {
+                r.v[2 * h] = on ? *reinterpret_cast<const float4*>(src[0] + h * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+                r.v[2 * h + 1] = on ? *reinterpret_cast<const float4*>(src[1] + h * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
+        src[0] += step;
+        if constexpr (MODE != X3_PLANES) src[1] += step;
     }
     // split2: two f32 -> packed bf16 pairs of the three pieces (low half = first argument); F16: scaled, two f16 pieces
     static __device__ __forceinline__ void split2(float a, float b, unsigned (&o)[3], float sc = 1.f) {
@@ -153,36 +165,39 @@ struct X3Loader {
     }
     __device__ __forceinline__ void store(const Regs& r, char* __restrict__ S, int tid) const {
         const float sc = scale;
-        const float4 (&v)[2] = r.v;
-        const u32x4 (&w)[NP] = r.w;
+#pragma unroll
+        for (int hh = 0; hh < KH; ++hh) {
         if constexpr (MODE == X3_ROW) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+                const float4 v = r.v[2 * hh + i];
                 unsigned lo[3], hi[3];
-                split2(v[i].x, v[i].y, lo, sc);
-                split2(v[i].z, v[i].w, hi, sc);
+                split2(v.x, v.y, lo, sc);
+                split2(v.z, v.w, hi, sc);
                 char* d = S + ((tid >> 2) + 64 * i) * RM_ROW_BYTES + (tid & 3) * 8;
 #pragma unroll
-                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(d + p * RM_PLANE) = make_uint2(lo[p], hi[p]);
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(d + (hh * NP + p) * RM_PLANE) = make_uint2(lo[p], hi[p]);
             }
         } else if constexpr (MODE == X3_KMAJ) {
             // v[0] = k even, v[1] = k odd, four consecutive rows each: pack the pair along k
+            const float4 v0 = r.v[2 * hh], v1 = r.v[2 * hh + 1];
             unsigned q[4][3];
-            split2(v[0].x, v[1].x, q[0], sc); split2(v[0].y, v[1].y, q[1], sc); split2(v[0].z, v[1].z, q[2], sc); split2(v[0].w, v[1].w, q[3], sc);
+            split2(v0.x, v1.x, q[0], sc); split2(v0.y, v1.y, q[1], sc); split2(v0.z, v1.z, q[2], sc); split2(v0.w, v1.w, q[3], sc);
             char* d = S + ((tid >> 5) * XB + (tid & 31) * 4) * 4;
 #pragma unroll
-            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d + p * KM_PLANE) = u32x4{q[0][p], q[1][p], q[2][p], q[3][p]};
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d + (hh * NP + p) * KM_PLANE) = u32x4{q[0][p], q[1][p], q[2][p], q[3][p]};
         } else if constexpr (MODE == X3_KMAJ16) {
             // h[0] = k even, h[1] = k odd, four consecutive rows (bf16) each: {even, odd} of a row share a dword
             static_assert(MODE != X3_KMAJ16 || NP == 1, "bf16 storage goes with PREC = 1");
-            const uint2 e = r.h[0], o = r.h[1];
-            char* d = S + ((tid >> 5) * XB + (tid & 31) * 4) * 4;
+            const uint2 e = r.h[2 * hh], o = r.h[2 * hh + 1];
+            char* d = S + ((tid >> 5) * XB + (tid & 31) * 4) * 4 + hh * KM_PLANE;
             *reinterpret_cast<u32x4*>(d) = u32x4{__builtin_amdgcn_perm(o.x, e.x, 0x05040100u), __builtin_amdgcn_perm(o.x, e.x, 0x07060302u),
                                                   __builtin_amdgcn_perm(o.y, e.y, 0x05040100u), __builtin_amdgcn_perm(o.y, e.y, 0x07060302u)};
         } else {
             char* d = S + (tid >> 1) * RM_ROW_BYTES + (tid & 1) * 16;
 #pragma unroll
-            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d + p * RM_PLANE) = w[p];
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d + (hh * NP + p) * RM_PLANE) = r.w[hh * NP + p];
+        }
         }
     }
     // the 8 k values (8g .. 8g+7) of tile row r, plane p, as an MFMA operand
@@ -269,13 +284,19 @@ static __device__ __forceinline__ void store_tile(const X3Args& p, f32x16 (&acc)
 // Persistent: a workgroup walks the (row tile, column tile, K split) work items w = first, first + stride, ...; the loads
 // of the NEXT item's first two K steps are issued before the epilogue of the current one.  Inside an item the loads run
 // two K steps ahead of the MFMAs (two register staging sets), the split + LDS store one step ahead (two LDS stages).
+// workgroups per CU: the LDS budget's (X3Cfg), except for the K = 32 steps of PREC = 1 with an f32 k-major operand - two staged steps
+// of two sub-steps of f32 rows do not fit 168 registers (measured: 20 - 80 bytes of scratch in the loop)
 template <int PREC, int A_MODE, int B_MODE>
-__global__ __launch_bounds__(256, X3Cfg<PREC>::kOcc) void gemm_x3_kernel(X3Args p, int n_items, int mt, int nt) {
+constexpr int x3_occ() { return (X3Cfg<PREC>::kKH == 2 && (A_MODE == X3_KMAJ || B_MODE == X3_KMAJ)) ? 2 : X3Cfg<PREC>::kOcc; }
+
+template <int PREC, int A_MODE, int B_MODE>
+__global__ __launch_bounds__(256, (x3_occ<PREC, A_MODE, B_MODE>())) void gemm_x3_kernel(X3Args p, int n_items, int mt, int nt) {
     constexpr int OPER_BYTES = X3Cfg<PREC>::kOper, STAGE_BYTES = X3Cfg<PREC>::kStage;      // (shadow the three-plane sizes)
     constexpr int NP = PREC == 1 ? 1 : (PREC == 4 ? 2 : 3);
     constexpr bool F16 = PREC == 4;
-    using LA = X3Loader<A_MODE, NP, F16>;
-    using LB = X3Loader<B_MODE, NP, F16>;
+    constexpr int KH = X3Cfg<PREC>::kKH, NPL = NP * KH;                 // sub-steps of 16 k per step; LDS planes per operand
+    using LA = X3Loader<A_MODE, NP, F16, KH>;
+    using LB = X3Loader<B_MODE, NP, F16, KH>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -312,17 +333,19 @@ __global__ __launch_bounds__(256, X3Cfg<PREC>::kOcc) void gemm_x3_kernel(X3Args 
     LB lb;
     typename LA::Regs ra0, ra1;
     typename LB::Regs rb0, rb1;
-    int nk = 0;
+    int nk = 0, n16 = 0;                                      // steps / sub-steps of sixteen k of the open item
+    auto nsub = [&](int kt) { return min(KH, n16 - kt * KH); };
     auto open_item = [&](int m_blk, int n_blk, int z) {       // address state + the loads of K steps 0 and 1
         const int k_begin = z * p.k_per_split;
-        nk = (min(p.K, k_begin + p.k_per_split) - k_begin) / XK;
+        n16 = (min(p.K, k_begin + p.k_per_split) - k_begin) / XK;
+        nk = (n16 + KH - 1) / KH;
         // B of this column tile: the second operand of a pair behind n_split (workgroup-uniform)
         const bool second = p.n_split > 0 && n_blk >= p.n_split;
         la.init(p.A, p.lda, p.a_plane, m_blk, p.M, k_begin, tid, p.sa);
         lb.init(second ? p.B2 : p.B, second ? p.ldb2 : p.ldb, second ? p.b2_plane : p.b_plane, second ? n_blk - p.n_split : n_blk,
                 p.n_split > 0 ? (second ? p.N - p.n_split : p.n_split) : p.N, k_begin, tid, p.sb);
-        la.load(ra0); lb.load(rb0);
-        if (nk > 1) { la.load(ra1); lb.load(rb1); }
+        la.load(ra0, nsub(0)); lb.load(rb0, nsub(0));
+        if (nk > 1) { la.load(ra1, nsub(1)); lb.load(rb1, nsub(1)); }
     };
 
     int m_blk, n_blk, z;
@@ -341,13 +364,14 @@ __global__ __launch_bounds__(256, X3Cfg<PREC>::kOcc) void gemm_x3_kernel(X3Args 
         const bool do_cs = (A_MODE == X3_KMAJ || A_MODE == X3_KMAJ16) && p.a_colsum != nullptr && n_blk == 0;
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
         auto cs_add = [&](const typename LA::Regs& r) {
-            if constexpr (A_MODE == X3_KMAJ) {
-                cs.x += r.v[0].x + r.v[1].x; cs.y += r.v[0].y + r.v[1].y; cs.z += r.v[0].z + r.v[1].z; cs.w += r.v[0].w + r.v[1].w;
-            } else if constexpr (A_MODE == X3_KMAJ16) {
-                cs.x += __uint_as_float(r.h[0].x << 16) + __uint_as_float(r.h[1].x << 16);
-                cs.y += __uint_as_float(r.h[0].x & 0xffff0000u) + __uint_as_float(r.h[1].x & 0xffff0000u);
-                cs.z += __uint_as_float(r.h[0].y << 16) + __uint_as_float(r.h[1].y << 16);
-                cs.w += __uint_as_float(r.h[0].y & 0xffff0000u) + __uint_as_float(r.h[1].y & 0xffff0000u);
+#pragma unroll
+            for (int h = 0; h < 2 * KH; ++h) {
+                if constexpr (A_MODE == X3_KMAJ) {
+                    cs.x += r.v[h].x; cs.y += r.v[h].y; cs.z += r.v[h].z; cs.w += r.v[h].w;
+                } else if constexpr (A_MODE == X3_KMAJ16) {
+                    cs.x += __uint_as_float(r.h[h].x << 16); cs.y += __uint_as_float(r.h[h].x & 0xffff0000u);
+                    cs.z += __uint_as_float(r.h[h].y << 16); cs.w += __uint_as_float(r.h[h].y & 0xffff0000u);
+                }
             }
         };
         if (do_cs) cs_add(ra0);
@@ -356,14 +380,14 @@ __global__ __launch_bounds__(256, X3Cfg<PREC>::kOcc) void gemm_x3_kernel(X3Args 
         // one K step: loads of step kt + 2 -> the staging set that step kt just vacated; MFMAs of step kt; split + store of kt + 1
         auto kstep = [&](int kt, typename LA::Regs& ra_cur, typename LB::Regs& rb_cur, const typename LA::Regs& ra_nxt,
                          const typename LB::Regs& rb_nxt) {
-            if (kt + 2 < nk) { la.load(ra_cur); lb.load(rb_cur); }
+            if (kt + 2 < nk) { la.load(ra_cur, nsub(kt + 2)); lb.load(rb_cur, nsub(kt + 2)); }
             const char* a_s = smem + (kt & 1) * STAGE_BYTES;
             const char* b_s = a_s + OPER_BYTES;
-            bf16x8 a[2][NP], b[2][NP];
+            bf16x8 a[2][NPL], b[2][NPL];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int q = 0; q < NP; ++q) {
+                for (int q = 0; q < NPL; ++q) {
                     a[i][q] = LA::frag(a_s, wm * 64 + i * 32 + fr, fg, q);
                     b[i][q] = LB::frag(b_s, wn * 64 + i * 32 + fr, fg, q);
                 }
@@ -380,6 +404,7 @@ __global__ __launch_bounds__(256, X3Cfg<PREC>::kOcc) void gemm_x3_kernel(X3Args 
             else {
             if constexpr (PREC == 6) { DC_X3_P(2, 0) DC_X3_P(0, 2) DC_X3_P(1, 1) DC_X3_P(1, 0) DC_X3_P(0, 1) }
             DC_X3_P(0, 0)
+            if constexpr (KH == 2) { DC_X3_P(1, 1) }      // PREC = 1: plane 1 = the next sixteen k
             }
 #undef DC_X2H_P
 #undef DC_X3_P
@@ -465,7 +490,7 @@ static int launch_x3(const X3Args& a, int splits, hipStream_t s) {
     static const int slots = [] {      // two (three: X3Cfg) workgroups per CU (LDS-limited)
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-        return X3Cfg<PREC>::kOcc * cus;
+        return x3_occ<PREC, AM, BM_>() * cus;
     }();
     const int grid = n_items < slots ? n_items : slots;
     hipLaunchKernelGGL((gemm_x3_kernel<PREC, AM, BM_>), dim3(grid), dim3(256), X3Cfg<PREC>::kLds, s, a, n_items, mt, nt);
@@ -487,7 +512,7 @@ int gemm_x3(const X3Gemm& g, hipStream_t stream) {
     const int a_mode = g.a_bf16 ? (g.a_mode == X3_ROW ? X3_PLANES : X3_KMAJ16) : g.a_mode;
     const int b_mode = g.b_bf16 ? X3_KMAJ16 : g.b_mode;
     if ((g.a_bf16 || g.b_bf16 || g.c_bf16 || g.aux_bf16) &&
-        (g.prec != 1 || (g.a_bf16 && g.a_mode == X3_PLANES) || (g.b_bf16 && (g.b_mode != X3_KMAJ || g.B2 != nullptr)) ||
+        (g.prec != 1 || (g.a_bf16 && g.a_mode == X3_PLANES) || (g.b_bf16 && g.b_mode != X3_KMAJ) ||
          (g.c_bf16 && (g.accumulate || g.C2 != nullptr || g.scratch.p != nullptr)) || (a_mode == X3_PLANES && (g.lda & 7)))) {
         set_error("gemm_x3: bf16 storage asked for a form that is not built", 1005);
         return 1005;
@@ -506,7 +531,8 @@ int gemm_x3(const X3Gemm& g, hipStream_t stream) {
         while (splits > 1 && (long long)splits * g.M * g.N > g.scratch.floats) --splits;
     }
     int kper = (g.K + splits - 1) / splits;
-    kper = (kper + XK - 1) / XK * XK;
+    const int kgran = g.prec == 1 ? XK * X3Cfg<1>::kKH : XK;         // whole steps per split
+    kper = (kper + kgran - 1) / kgran * kgran;
     splits = (g.K + kper - 1) / kper;
     a.k_per_split = kper;
     if (splits > 1) a.slab = g.scratch.p;

@@ -33,7 +33,7 @@ struct RnnStepArgs {
     float* dc;             // [rows][H]  LSTM: total dL/dc_t
     float* dgx;            // [rows][G*H] grad wrt (W_ih x + b_ih)
     float* dgh;            // [rows][G*H] grad wrt (W_hh h + b_hh)   (GRU; LSTM: == dgx)
-    int bf16_store;        // rnn_team512.hip only (configs[4]): `gates` and `dgx` are bf16 [rows][G*H] buffers (policy.hip: bf16_store())
+    int bf16_store;        // rnn_team512.hip only (configs[4]): `gates`, `dgx` [rows][G*H] and `hseq`, `hprev` [rows][H] are bf16 buffers (policy.hip: bf16_store())
     long long* dbg;        // DC_LSTM_TIMING=1: phase cycle sums of workgroup 0 (else nullptr)
 };
 
@@ -87,7 +87,7 @@ struct X3Gemm {
                                                         // when its planes were made); the product is scaled back by 1 / (sa sb)
     GemmScratch scratch;
     // bf16 storage (prec 1; configs[4]): the operand / the output / the relu mask `aux` live in HBM as bf16 with the same shape and ld
-    // (elements).  b_bf16: X3_KMAJ B only, no second B; c_bf16: no accumulate, no C2, no split-K (no scratch).
+    // (elements).  b_bf16: X3_KMAJ B only (a second B is bf16 as well); c_bf16: no accumulate, no C2, no split-K (no scratch).
     int a_bf16 = 0, b_bf16 = 0, c_bf16 = 0, aux_bf16 = 0;
     float* a_colsum = nullptr;    // X3_KMAJ A only: a_colsum[m] += sum_k A[k][m] (the bias gradient that goes with a weight gradient),
                                   // summed while the tiles pass through the loader - no second pass over A
@@ -152,11 +152,13 @@ int ppo_loss_fwd_bwd(const float* headout, const float* tu, const uint8_t* act, 
                      int32_t* head_on, long long nr, float e_clip, float entropy_coef, float vf_coef, hipStream_t s);
 // rnn.hip
 int transpose(const float* in, float* out, int rows, int cols, hipStream_t s);
+// bf16 (here and below): the state buffer (hprev / hseq / seq) holds bf16 elements - configs[4]'s bf16 storage (policy.hip)
 int rnn_seed_state(const float* h0, float* hprev, const int64_t* seq_off, const int32_t* seq_len, int n_seq, int H,
-                   hipStream_t s);
+                   hipStream_t s, int bf16 = 0);
 int rnn_final_state(const float* hseq, float* hT, const int64_t* seq_off, const int32_t* seq_len, int n_seq, int H,
-                    hipStream_t s);
-int rnn_gather_state(const float* seq, const int64_t* prev_row, float* out, int n, int H, hipStream_t s);
+                    hipStream_t s, int bf16 = 0);
+int rnn_gather_state(const float* seq, const int64_t* prev_row, float* out, int n, int H, hipStream_t s, int bf16 = 0);
+bool policy_bf16_store(const dc_dims* d);      // policy.hip: gate buffers, pre, hseq / hprev stored as bf16 for these dims
 bool rnn_uses_persistent(int cell, int H, int flags);   // register-resident LSTM kernels: W_hh^T is not needed
 int rnn_forward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s);
 int rnn_backward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s);

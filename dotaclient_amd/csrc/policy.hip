@@ -49,14 +49,17 @@ static inline bool embed_fused_on(const dc_dims* d) { return !(d->flags & DC_DIM
 static inline int64_t emb_rows(const dc_dims* d) { return embed_fused_on(d) ? (d->rows + 127) / 128 * 128 : d->rows; }
 
 // bf16 STORAGE on configs[4]'s path (DC_DIMS_BF16, LSTM-512 on the persistent team kernels): the gate pre-activations / activated gates
-// and the gate gradients - [rows][4H] each, two thirds of the bytes the dense products and the recurrent kernels move - live in HBM as
-// bf16 (in the lower half of their f32-sized workspace buffers: the layout does not change).  Their consumers round them to bf16 anyway
-// (they are MFMA operands); what is new is the rounding of the stored gate activations the backward's cell maths reads.
+// and the gate gradients - [rows][4H] each, two thirds of the bytes the dense products and the recurrent kernels move - and `pre`,
+// `hseq`, `hprev` live in HBM as bf16 (in the lower half of their f32-sized workspace buffers: the layout does not change).  Their
+// consumers round them to bf16 anyway (they are MFMA operands: for pre / hseq / hprev the stored form changes no result at all); what is
+// new is the rounding of the input projections before the cell adds W_hh h, and of the gate activations / gate gradients the backward reads.
 // DC_DIMS_BF16_F32_STORE keeps f32 storage (A/B, and the comparison with the launch-per-step kernels).
 static inline bool bf16_store(const dc_dims* d) {
     return (d->flags & DC_DIMS_BF16) && !(d->flags & (DC_DIMS_BF16_F32_STORE | DC_DIMS_RNN_PER_STEP | DC_DIMS_RNN_STEP_BF16 | DC_DIMS_GEMM_FASTTILE)) &&
            d->cell == 1 && d->hidden == 512 && 4 * (long long)d->n_seq <= d->rows && lstm_team512_supported(1, 512, d->flags, d);
 }
+
+bool policy_bf16_store(const dc_dims* d) { return bf16_store(d); }
 
 // Weight matrices the dense products read as pre-split bf16 planes (gemm_x3.hip), in this order: affine_pre_rnn [256][896],
 // the recurrent input projections [G*H][in_l], the head block zero-padded to [160][H].  Elements of one orientation.
@@ -223,24 +226,24 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
     // y[rows][N] = x[rows][K] W[N][K]^T + b, through the split-on-load kernel (or the round-1 kernel)
     const bool bs = bf16_store(d);
     auto linear = [&](const float* x, int K, const float* W, const uint16_t* Wp, int N, int Npad, const float* bias, int relu, float* y,
-                      int ldy, int y_bf16 = 0) -> int {
+                      int ldy, int y_bf16 = 0, int x_bf16 = 0) -> int {
         if (!x3) return gemm_f32(x, W, y, (int)NR, N, K, K, K, ldy, 0, 0, bias, relu, nullptr, 0, 0, 1, s);
         X3Gemm g;
         g.A = x; g.a_mode = X3_ROW; g.lda = K;
         g.B = Wp; g.b_mode = X3_PLANES; g.ldb = K; g.b_plane = (long long)Npad * K;
         g.C = y; g.ldc = ldy; g.M = (int)NR; g.N = Npad; g.K = K; g.bias = bias; g.nbias = N; g.relu = relu; g.prec = prec;
         g.sa = F16X2_S_ACT; g.sb = F16X2_S_W;
-        g.c_bf16 = y_bf16;
+        g.c_bf16 = y_bf16; g.a_bf16 = x_bf16;
         return gemm_x3(g, s);
     };
     // pre-rnn projection (policy.py:138)
-    DC_TRY(linear(w.f(DC_WS_XCAT), XCATW, P.p(DC_P_PRE_W), wp.fwd(wp.pre), PREW, PREW, P.p(DC_P_PRE_B), 1, w.f(DC_WS_PRE), PREW));
+    DC_TRY(linear(w.f(DC_WS_XCAT), XCATW, P.p(DC_P_PRE_W), wp.fwd(wp.pre), PREW, PREW, P.p(DC_P_PRE_B), 1, w.f(DC_WS_PRE), PREW, bs));
     // recurrent core (policy.py:141)
     const float* x = w.f(DC_WS_PRE);
     int in = PREW;
     for (int l = 0; l < d->layers; ++l) {
         const int pb = DC_P_RNN0 + 4 * l;
-        DC_TRY(linear(x, in, P.p(pb + 0), wp.fwd(wp.ih[l]), G * H, G * H, P.p(pb + 2), 0, w.fl(l, DC_WSL_GATES), G * H, bs));
+        DC_TRY(linear(x, in, P.p(pb + 0), wp.fwd(wp.ih[l]), G * H, G * H, P.p(pb + 2), 0, w.fl(l, DC_WSL_GATES), G * H, bs, bs));
         RnnStepArgs a{};
         a.bf16_store = bs;
         a.h0 = h0 ? h0 + (size_t)l * B * H : nullptr;
@@ -254,7 +257,7 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
         a.gates = w.fl(l, DC_WSL_GATES); a.hn = w.fl(l, DC_WSL_HN); a.hseq = w.fl(l, DC_WSL_HSEQ);
         a.hprev = w.fl(l, DC_WSL_HPREV); a.cseq = w.fl(l, DC_WSL_CSEQ); a.cprev = w.fl(l, DC_WSL_CPREV);
         DC_TRY(rnn_forward_layer(d->cell, a, d->max_len, s));
-        if (hT) DC_TRY(rnn_final_state(w.fl(l, DC_WSL_HSEQ), hT + (size_t)l * B * H, seq_off, seq_len, B, H, s));
+        if (hT) DC_TRY(rnn_final_state(w.fl(l, DC_WSL_HSEQ), hT + (size_t)l * B * H, seq_off, seq_len, B, H, s, bs));
         if (cT && d->cell == 1)
             DC_TRY(rnn_final_state(w.fl(l, DC_WSL_CSEQ), cT + (size_t)l * B * H, seq_off, seq_len, B, H, s));
         x = w.fl(l, DC_WSL_HSEQ);
@@ -262,7 +265,7 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
     }
     // all head projections as one GEMM (policy.py:144-155), then the attention logits (policy.py:152)
     // (x3: the weight planes are zero-padded to 160 rows, so the pad columns 154..159 of headout are written as zeros)
-    DC_TRY(linear(x, H, P.p(DC_P_HEADS_W), wp.fwd(wp.heads), HO_N, HO_LD, P.p(DC_P_HEADS_B), 0, w.f(DC_WS_HEADOUT), HO_LD));
+    DC_TRY(linear(x, H, P.p(DC_P_HEADS_W), wp.fwd(wp.heads), HO_N, HO_LD, P.p(DC_P_HEADS_B), 0, w.f(DC_WS_HEADOUT), HO_LD, 0, bs));
     // (DC_DIMS_LAZY_TU: left to dc_select_logp / dc_ppo_loss_fwd_bwd, which know which units are unmasked)
     if (!(d->flags & DC_DIMS_LAZY_TU)) DC_TRY(attn_logits(w.f(DC_WS_HEADOUT), w.f(DC_WS_EMB), w.f(DC_WS_TU), NR, NRp, s));
     return 0;
@@ -304,21 +307,22 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     const WPlanes wp = wplanes_of(d, w.base, w.off);
     // dx[rows][N] = dy[rows][K] W[K][N] (optionally masked by aux > 0): reads W^T as bf16 planes [N][K]
     const bool bs = bf16_store(d);
-    auto dgrad = [&](const float* dy, int K, const float* W, const uint16_t* WTp, int N, const float* aux, float* dx, int dy_bf16 = 0) -> int {
+    auto dgrad = [&](const float* dy, int K, const float* W, const uint16_t* WTp, int N, const float* aux, float* dx, int dy_bf16 = 0,
+                     int aux_bf16 = 0) -> int {
         if (!x3) return gemm_f32(dy, W, dx, (int)NR, N, K, K, N, N, 0, 1, nullptr, 0, aux, N, 0, 1, s);
         X3Gemm g;
         g.A = dy; g.a_mode = X3_ROW; g.lda = K;
         g.B = WTp; g.b_mode = X3_PLANES; g.ldb = K; g.b_plane = (long long)N * K;
         g.C = dx; g.ldc = N; g.M = (int)NR; g.N = N; g.K = K; g.aux = aux; g.ldaux = N; g.prec = prec; g.transposed_w = 1;
         g.sa = s_grad; g.sb = F16X2_S_W;
-        g.a_bf16 = dy_bf16;
+        g.a_bf16 = dy_bf16; g.aux_bf16 = aux_bf16;
         return gemm_x3(g, s);
     };
     // dW[M][N] += dy[rows][lda: M]^T x[rows][ldb: N] (contraction over the env-steps, split-K); optional second x behind N
     // db (optional): the bias gradient that goes with dW, db[m] += sum over the env-steps of dy[.][m] - summed by the same kernel as dy
     // passes through its loader (a separate column-sum pass re-reads dy: 12 launches, 0.44 ms per configs[2] step)
     auto wgrad = [&](const float* dy, int lda, int M, const float* x1, int N1, float* dW1, const float* x2, int N2, float* dW2,
-                     float* db = nullptr, int dy_bf16 = 0) -> int {
+                     float* db = nullptr, int dy_bf16 = 0, int x_bf16 = 0) -> int {
         const bool pair = x2 != nullptr;
         if (x3_tn && gemm_x3_shape_ok(M, N1 + N2, (int)NR, lda, N1, X3_KMAJ, X3_KMAJ) && (!pair || (N1 % 128 == 0 && !(N2 & 3)))) {
             X3Gemm g;
@@ -328,10 +332,10 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
             g.C = dW1; g.ldc = N1; g.C2 = dW2; g.ldc2 = N2; g.M = M; g.N = N1 + N2; g.K = (int)NR; g.accumulate = 1; g.prec = prec;
             g.sa = s_grad; g.sb = F16X2_S_ACT;
             g.scratch = sc;
-            g.a_bf16 = dy_bf16;
+            g.a_bf16 = dy_bf16; g.b_bf16 = x_bf16;
             return gemm_x3(g, s);
         }
-        if (dy_bf16) { set_error("policy_backward: bf16 storage needs the split-on-load products", 1005); return 1005; }
+        if (dy_bf16 || x_bf16) { set_error("policy_backward: bf16 storage needs the split-on-load products", 1005); return 1005; }
         if (db != nullptr) DC_TRY(colsum(dy, lda, NR, M, db, s));
         if (pair) return gemm_f32_tn_pair(dy, lda, x1, N1, N1, x2, N2, N2, dW1, N1, dW2, N2, M, (int)NR, s, sc);
         return gemm_f32(dy, x1, dW1, M, N1, (int)NR, lda, N1, N1, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s, sc);
@@ -363,7 +367,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         DC_TRY(launch_check("policy_backward: head weight pad"));
     }
     DC_TRY(dgrad(w.f(DC_WS_DHEADOUT), HO_LD, w.f(DC_WS_HEADW_PAD), wp.bwd(wp.heads), H, nullptr, w.fl(TOP, DC_WSL_DH)));
-    DC_TRY(wgrad(w.f(DC_WS_DHEADOUT), HO_LD, HO_N, w.fl(TOP, DC_WSL_HSEQ), H, Gd.p(DC_P_HEADS_W), nullptr, 0, nullptr, Gd.p(DC_P_HEADS_B)));
+    DC_TRY(wgrad(w.f(DC_WS_DHEADOUT), HO_LD, HO_N, w.fl(TOP, DC_WSL_HSEQ), H, Gd.p(DC_P_HEADS_W), nullptr, 0, nullptr, Gd.p(DC_P_HEADS_B), 0, bs));
 
     // recurrent core, top layer first
     for (int l = TOP; l >= 0; --l) {
@@ -386,7 +390,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         const int in = l == 0 ? PREW : H;
         // dW_ih = dgx^T x ; dW_hh = dgh^T h_prev ; biases = column sums
         if (a.dgh == a.dgx) {   // LSTM: both products contract the same gate gradients - one launch
-            DC_TRY(wgrad(a.dgx, G * H, G * H, xin, in, Gd.p(pb + 0), a.hprev, H, Gd.p(pb + 1), Gd.p(pb + 2), bs));
+            DC_TRY(wgrad(a.dgx, G * H, G * H, xin, in, Gd.p(pb + 0), a.hprev, H, Gd.p(pb + 1), Gd.p(pb + 2), bs, bs));
             // dgh is dgx, so d(b_hh) = d(b_ih): copy 2 KB
             DC_TRY(copy_f32_async(Gd.p(pb + 3), Gd.p(pb + 2), (long long)G * H, s));
         } else {
@@ -397,7 +401,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
             DC_TRY(dgrad(a.dgx, G * H, P.p(pb + 0), wp.bwd(wp.ih[l]), H, nullptr, w.fl(l - 1, DC_WSL_DH), bs));
         } else {
             // through relu(affine_pre_rnn) (policy.py:138): mask with the stored activation
-            DC_TRY(dgrad(a.dgx, G * H, P.p(pb + 0), wp.bwd(wp.ih[0]), PREW, w.f(DC_WS_PRE), w.f(DC_WS_DPRE), bs));
+            DC_TRY(dgrad(a.dgx, G * H, P.p(pb + 0), wp.bwd(wp.ih[0]), PREW, w.f(DC_WS_PRE), w.f(DC_WS_DPRE), bs, bs));
         }
     }
     DC_TRY(wgrad(w.f(DC_WS_DPRE), PREW, PREW, w.f(DC_WS_XCAT), XCATW, Gd.p(DC_P_PRE_W), nullptr, 0, nullptr, Gd.p(DC_P_PRE_B)));

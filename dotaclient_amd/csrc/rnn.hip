@@ -21,6 +21,7 @@
 // h_t; the forward writes h_t to both hseq[row] and hprev[row+1].
 #include <stdlib.h>
 #include "kernels.h"
+#include "gemm_tiles.h"
 
 namespace dc {
 
@@ -233,22 +234,28 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 }
 
 // hprev[first row of sequence b] = h0[b]   (and cprev likewise)
+// (bf16: the state buffer holds bf16 elements - configs[4]'s bf16 storage, policy.hip bf16_store())
 __global__ void seed_state_kernel(const float* __restrict__ h0, float* __restrict__ hprev,
                                   const int64_t* __restrict__ seq_off, const int32_t* __restrict__ seq_len, int n_seq,
-                                  int H) {
+                                  int H, int bf16) {
     const int b = blockIdx.x;
     if (b >= n_seq || seq_len[b] <= 0) return;
-    for (int j = threadIdx.x; j < H; j += blockDim.x) hprev[(size_t)seq_off[b] * H + j] = h0 ? h0[(size_t)b * H + j] : 0.f;
+    for (int j = threadIdx.x; j < H; j += blockDim.x) {
+        const float v = h0 ? h0[(size_t)b * H + j] : 0.f;
+        if (bf16) reinterpret_cast<uint16_t*>(hprev)[(size_t)seq_off[b] * H + j] = (uint16_t)(cvt_pk_bf16(v, 0.f) & 0xffffu);
+        else hprev[(size_t)seq_off[b] * H + j] = v;
+    }
 }
 
 // hT[b] = hseq[last row of sequence b]
 __global__ void final_state_kernel(const float* __restrict__ hseq, float* __restrict__ hT,
                                    const int64_t* __restrict__ seq_off, const int32_t* __restrict__ seq_len, int n_seq,
-                                   int H) {
+                                   int H, int bf16) {
     const int b = blockIdx.x;
     if (b >= n_seq || seq_len[b] <= 0) return;
+    const size_t r = (size_t)(seq_off[b] + seq_len[b] - 1) * H;
     for (int j = threadIdx.x; j < H; j += blockDim.x)
-        hT[(size_t)b * H + j] = hseq[(size_t)(seq_off[b] + seq_len[b] - 1) * H + j];
+        hT[(size_t)b * H + j] = bf16 ? __uint_as_float((unsigned)reinterpret_cast<const uint16_t*>(hseq)[r + j] << 16) : hseq[r + j];
 }
 
 int transpose(const float* in, float* out, int rows, int cols, hipStream_t s) {
@@ -257,32 +264,38 @@ int transpose(const float* in, float* out, int rows, int cols, hipStream_t s) {
 }
 
 int rnn_seed_state(const float* h0, float* hprev, const int64_t* seq_off, const int32_t* seq_len, int n_seq, int H,
-                   hipStream_t s) {
-    hipLaunchKernelGGL(seed_state_kernel, dim3(n_seq), dim3(128), 0, s, h0, hprev, seq_off, seq_len, n_seq, H);
+                   hipStream_t s, int bf16) {
+    hipLaunchKernelGGL(seed_state_kernel, dim3(n_seq), dim3(128), 0, s, h0, hprev, seq_off, seq_len, n_seq, H, bf16);
     return launch_check("rnn_seed_state");
 }
 
 int rnn_final_state(const float* hseq, float* hT, const int64_t* seq_off, const int32_t* seq_len, int n_seq, int H,
-                    hipStream_t s) {
-    hipLaunchKernelGGL(final_state_kernel, dim3(n_seq), dim3(128), 0, s, hseq, hT, seq_off, seq_len, n_seq, H);
+                    hipStream_t s, int bf16) {
+    hipLaunchKernelGGL(final_state_kernel, dim3(n_seq), dim3(128), 0, s, hseq, hT, seq_off, seq_len, n_seq, H, bf16);
     return launch_check("rnn_final_state");
 }
 
 // out[b][:] = seq[prev_row[b]][:] (zeros when prev_row[b] < 0): the initial state of chunk b = the state after the last
 // step of the previous chunk of the same rollout (optimizer.py:384,408), zeros for a rollout's first chunk (policy.py:77-78)
 __global__ __launch_bounds__(128) void gather_state_kernel(const float* __restrict__ seq, const int64_t* __restrict__ prev_row,
-                                                           float* __restrict__ out, int H) {
+                                                           float* __restrict__ out, int H, int bf16) {
     const int b = blockIdx.x;
     const int64_t r = prev_row[b];
     for (int j = threadIdx.x * 4; j < H; j += 128 * 4) {
-        const float4 v = r >= 0 ? *reinterpret_cast<const float4*>(seq + r * H + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r >= 0 && bf16) {
+            const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(seq) + r * H + j);
+            v = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u));
+        } else if (r >= 0) {
+            v = *reinterpret_cast<const float4*>(seq + r * H + j);
+        }
         *reinterpret_cast<float4*>(out + (size_t)b * H + j) = v;
     }
 }
 
-int rnn_gather_state(const float* seq, const int64_t* prev_row, float* out, int n, int H, hipStream_t s) {
+int rnn_gather_state(const float* seq, const int64_t* prev_row, float* out, int n, int H, hipStream_t s, int bf16) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(gather_state_kernel, dim3(n), dim3(128), 0, s, seq, prev_row, out, H);
+    hipLaunchKernelGGL(gather_state_kernel, dim3(n), dim3(128), 0, s, seq, prev_row, out, H, bf16);
     return launch_check("rnn_gather_state");
 }
 
@@ -330,7 +343,7 @@ int rnn_forward_layer(int cell, RnnStepArgs a, int max_len, hipStream_t s) {
     const bool team = !lstm_persist && persist_enabled(a.flags) && rnn_team_supported(cell, a.H, a.n_seq, a.flags);
     const bool self_seeding = (lstm_persist && lstm_persist_use_valu(a.n_seq, a.flags)) || team;
     if (!self_seeding) {
-        if (int e = rnn_seed_state(a.h0, a.hprev, a.seq_off, a.seq_len, a.n_seq, a.H, s)) return e;
+        if (int e = rnn_seed_state(a.h0, a.hprev, a.seq_off, a.seq_len, a.n_seq, a.H, s, a.bf16_store)) return e;
         if (cell == CELL_LSTM)
             if (int e = rnn_seed_state(a.c0, a.cprev, a.seq_off, a.seq_len, a.n_seq, a.H, s)) return e;
     }

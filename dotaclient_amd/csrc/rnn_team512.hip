@@ -240,8 +240,12 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
             const int b = b0 + s;
             u32x4 v = u32x4{0, 0, 0, 0};
             if (b < p.n_seq && p.seq_len[b] > 0) {
-                const float* src = p.hprev + (size_t)p.seq_off[b] * H + k8;
-                v = t5_to_bf16x8(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 4));
+                if constexpr (BS) {
+                    v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(p.hprev) + (size_t)p.seq_off[b] * H + k8);
+                } else {
+                    const float* src = p.hprev + (size_t)p.seq_off[b] * H + k8;
+                    v = t5_to_bf16x8(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 4));
+                }
             }
             *reinterpret_cast<u32x4*>(ht0 + s * T5_HROW + k8 * 2) = v;
         }
@@ -260,10 +264,15 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
             }
             float* st = sbase + (size_t)pt * H;
             *reinterpret_cast<float4*>(st) = pc;
-            *reinterpret_cast<float4*>(st + d_h) = ph;
-            if (pnext) {
-                *reinterpret_cast<float4*>(st + H + d_cp) = pc;
-                *reinterpret_cast<float4*>(st + H + d_hp) = ph;
+            if (pnext) *reinterpret_cast<float4*>(st + H + d_cp) = pc;
+            if constexpr (BS) {      // hseq / hprev as bf16: the values the next product and the peers get anyway
+                const uint2 hb = make_uint2(cvt_pk_bf16(ph.x, ph.y), cvt_pk_bf16(ph.z, ph.w));
+                const size_t e = (row0 + (size_t)pt) * H + j0;
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.hseq) + e) = hb;
+                if (pnext) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.hprev) + e + H) = hb;
+            } else {
+                *reinterpret_cast<float4*>(st + d_h) = ph;
+                if (pnext) *reinterpret_cast<float4*>(st + H + d_hp) = ph;
             }
             pend = false;
         };
@@ -380,7 +389,8 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
     if (DC_DEV_TIMING && timing) { tm[7] = plain; for (int k = 0; k < 8; ++k) p.dbg[k] = tm[k]; }
     if (failed && tid < T5_US) {        // a peer never answered: make the failure visible downstream (NaN loss -> status 1)
         const int b = min(team * NS, p.n_seq - 1);
-        p.hseq[(size_t)p.seq_off[b] * H + U0 + tid] = __builtin_nanf("");
+        if constexpr (BS) reinterpret_cast<uint16_t*>(p.hseq)[(size_t)p.seq_off[b] * H + U0 + tid] = 0x7fc0u;      // bf16 NaN
+        else p.hseq[(size_t)p.seq_off[b] * H + U0 + tid] = __builtin_nanf("");
     }
 }
 
@@ -699,8 +709,8 @@ int lstm_team512_forward(RnnStepArgs a, int max_len, hipStream_t s) {
     if (int e = t5_attr(lstm512_team_fwd_kernel<32, true>, t5_fwd_lds(32), &attr[3])) return e;
     const int ns = (a.flags & DC_DIMS_TEAM_NS(2)) ? 32 : t5_tile_seqs(a.n_seq);     // DC_DIMS_TEAM_NS(2): force 32-sequence tiles (A/B)
     const int nt = t5_teams(a.n_seq, ns);
-    // per cell: gates in + out (4 + 4 values, f32 or bf16), c, h, cprev, hprev (f32)
-    ProfScope prof("lstm_fwd_team", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len, (double)a.n_seq * max_len * a.H * (a.bf16_store ? 8 * 2.0 + 16.0 : 48.0), s);
+    // per cell: gates in + out (4 + 4 values), h, hprev (f32 or bf16), c, cprev (f32)
+    ProfScope prof("lstm_fwd_team", 2.0 * a.n_seq * 4.0 * a.H * a.H * max_len, (double)a.n_seq * max_len * a.H * (a.bf16_store ? 10 * 2.0 + 8.0 : 48.0), s);
     if (int rc = zero_async(xb, ((size_t)T5_HDR + T5_HS + (size_t)nt * (ns == 16 ? t5_fwd_ring(16) : t5_fwd_ring(32))) * sizeof(u64), s)) return rc;
 #if DC_DEV_TIMING
     static long long* dbg = nullptr;
