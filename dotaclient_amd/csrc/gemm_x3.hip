@@ -55,10 +55,13 @@ template <int PREC> struct X3Cfg {
     static constexpr int kOper = (kThree ? 2 : 3) * RM_PLANE, kStage = 2 * kOper, kLds = 2 * kStage;   // 49152 / 73728
     static constexpr int kImgRows = kThree ? 32 : 64;
     // PREC = 1 has ONE piece per operand: the second LDS plane of the two-plane budget holds the NEXT sixteen k instead, so a step
-    // between two barriers is K = 32 - eight MFMAs per wave instead of four (with four the step was all barrier and LDS latency:
-    // 0.24 of the bf16 peak on configs[4]'s products)
-    static constexpr int kKH = (PREC == 1 && kThree) ? 2 : 1;
+    // between two barriers is K = 32 - eight MFMAs per wave instead of four (x3_kh below)
+    static constexpr int kKHmax = (PREC == 1 && kThree) ? 2 : 1;
 };
+// ... except with an f32 k-major operand: two staged steps of two sub-steps of f32 rows do not fit the 168 registers of three workgroups
+// per CU, and at two per CU the K = 32 form was slower than K = 16 at three (configs[4]'s dW with f32 x: 912 -> 1 400 us)
+template <int PREC, int A_MODE, int B_MODE>
+constexpr int x3_kh() { return (A_MODE == X3_KMAJ || B_MODE == X3_KMAJ) ? 1 : X3Cfg<PREC>::kKHmax; }
 
 struct X3Args {
     const void* A; const void* B; const void* B2;
@@ -87,6 +90,11 @@ __device__ __forceinline__ unsigned pk_f16(float a, float b) {      // {f16(b), 
 template <int MODE, int NP, bool F16 = false, int KH = 1>
 struct X3Loader {
     struct Regs { float4 v[2 * KH]; u32x4 w[NP * KH]; uint2 h[2 * KH]; };   // one staged K step of this thread (only the members its MODE uses are live)
+    // Which tile row a thread stages (row-major modes).  A ds_write_b64 / _b128 is serviced in contiguous groups of 16 / 8 lanes = four
+    // row slots, over 32 banks; with 48-byte rows four CONSECUTIVE rows put rows 0 and 3 on the same banks (two cycles per group: the
+    // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.32 of these kernels, all of it from the stores); rows r, r + 2, r + 4, r + 6 tile the 32
+    // banks exactly.  Slot p -> row: groups of four slots take the even / the odd rows of a block of eight.
+    static __device__ __forceinline__ int lrow(int p) { const int m = p >> 2; return 8 * (m >> 1) + (m & 1) + 2 * (p & 3); }
     const char* src[2];
     long long step;        // bytes per K step
     long long sub;         // bytes between the sub-steps of a step
@@ -99,7 +107,7 @@ struct X3Loader {
             const int kc = (tid & 3) * 4;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int row = min(r_base + (tid >> 2) + 64 * i, R - 1);
+                const int row = min(r_base + lrow(tid >> 2) + 64 * i, R - 1);
                 src[i] = reinterpret_cast<const char*>(static_cast<const float*>(P) + (size_t)row * ld + k0 + kc);
             }
             sub = XK * 4;
@@ -118,7 +126,7 @@ struct X3Loader {
                 src[i] = reinterpret_cast<const char*>(static_cast<const uint16_t*>(P) + (size_t)(k0 + 2 * kp + i) * ld + c);
             sub = (long long)XK * ld * 2;
         } else {
-            const int row = min(r_base + (tid >> 1), R - 1);
+            const int row = min(r_base + lrow(tid >> 1), R - 1);
             src[0] = reinterpret_cast<const char*>(static_cast<const uint16_t*>(P) + (size_t)row * ld + k0 + (tid & 1) * 8);
             src[1] = nullptr;
             sub = XK * 2;
@@ -174,7 +182,7 @@ struct X3Loader {
                 unsigned lo[3], hi[3];
                 split2(v.x, v.y, lo, sc);
                 split2(v.z, v.w, hi, sc);
-                char* d = S + ((tid >> 2) + 64 * i) * RM_ROW_BYTES + (tid & 3) * 8;
+                char* d = S + (lrow(tid >> 2) + 64 * i) * RM_ROW_BYTES + (tid & 3) * 8;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(d + (hh * NP + p) * RM_PLANE) = make_uint2(lo[p], hi[p]);
             }
@@ -194,7 +202,7 @@ struct X3Loader {
             *reinterpret_cast<u32x4*>(d) = u32x4{__builtin_amdgcn_perm(o.x, e.x, 0x05040100u), __builtin_amdgcn_perm(o.x, e.x, 0x07060302u),
                                                   __builtin_amdgcn_perm(o.y, e.y, 0x05040100u), __builtin_amdgcn_perm(o.y, e.y, 0x07060302u)};
         } else {
-            char* d = S + (tid >> 1) * RM_ROW_BYTES + (tid & 1) * 16;
+            char* d = S + lrow(tid >> 1) * RM_ROW_BYTES + (tid & 1) * 16;
 #pragma unroll
             for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d + (hh * NP + p) * RM_PLANE) = r.w[hh * NP + p];
         }
@@ -284,17 +292,12 @@ static __device__ __forceinline__ void store_tile(const X3Args& p, f32x16 (&acc)
 // Persistent: a workgroup walks the (row tile, column tile, K split) work items w = first, first + stride, ...; the loads
 // of the NEXT item's first two K steps are issued before the epilogue of the current one.  Inside an item the loads run
 // two K steps ahead of the MFMAs (two register staging sets), the split + LDS store one step ahead (two LDS stages).
-// workgroups per CU: the LDS budget's (X3Cfg), except for the K = 32 steps of PREC = 1 with an f32 k-major operand - two staged steps
-// of two sub-steps of f32 rows do not fit 168 registers (measured: 20 - 80 bytes of scratch in the loop)
 template <int PREC, int A_MODE, int B_MODE>
-constexpr int x3_occ() { return (X3Cfg<PREC>::kKH == 2 && (A_MODE == X3_KMAJ || B_MODE == X3_KMAJ)) ? 2 : X3Cfg<PREC>::kOcc; }
-
-template <int PREC, int A_MODE, int B_MODE>
-__global__ __launch_bounds__(256, (x3_occ<PREC, A_MODE, B_MODE>())) void gemm_x3_kernel(X3Args p, int n_items, int mt, int nt) {
+__global__ __launch_bounds__(256, X3Cfg<PREC>::kOcc) void gemm_x3_kernel(X3Args p, int n_items, int mt, int nt) {
     constexpr int OPER_BYTES = X3Cfg<PREC>::kOper, STAGE_BYTES = X3Cfg<PREC>::kStage;      // (shadow the three-plane sizes)
     constexpr int NP = PREC == 1 ? 1 : (PREC == 4 ? 2 : 3);
     constexpr bool F16 = PREC == 4;
-    constexpr int KH = X3Cfg<PREC>::kKH, NPL = NP * KH;                 // sub-steps of 16 k per step; LDS planes per operand
+    constexpr int KH = x3_kh<PREC, A_MODE, B_MODE>(), NPL = NP * KH;    // sub-steps of 16 k per step; LDS planes per operand
     using LA = X3Loader<A_MODE, NP, F16, KH>;
     using LB = X3Loader<B_MODE, NP, F16, KH>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -490,7 +493,7 @@ static int launch_x3(const X3Args& a, int splits, hipStream_t s) {
     static const int slots = [] {      // two (three: X3Cfg) workgroups per CU (LDS-limited)
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-        return x3_occ<PREC, AM, BM_>() * cus;
+        return X3Cfg<PREC>::kOcc * cus;
     }();
     const int grid = n_items < slots ? n_items : slots;
     hipLaunchKernelGGL((gemm_x3_kernel<PREC, AM, BM_>), dim3(grid), dim3(256), X3Cfg<PREC>::kLds, s, a, n_items, mt, nt);
@@ -531,7 +534,7 @@ int gemm_x3(const X3Gemm& g, hipStream_t stream) {
         while (splits > 1 && (long long)splits * g.M * g.N > g.scratch.floats) --splits;
     }
     int kper = (g.K + splits - 1) / splits;
-    const int kgran = g.prec == 1 ? XK * X3Cfg<1>::kKH : XK;         // whole steps per split
+    const int kgran = g.prec == 1 ? XK * X3Cfg<1>::kKHmax : XK;      // whole steps per split
     kper = (kper + kgran - 1) / kgran * kgran;
     splits = (g.K + kper - 1) / kper;
     a.k_per_split = kper;

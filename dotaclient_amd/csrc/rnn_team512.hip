@@ -62,6 +62,7 @@ constexpr int t5_bwd_lds(int ns) { return 2 * ns * T5_GROW + ns * T5_RED_LD * 4;
 __device__ __forceinline__ u32x4 t5_to_bf16x8(const float4& a, const float4& b) {
     return u32x4{cvt_pk_bf16(a.x, a.y), cvt_pk_bf16(a.z, a.w), cvt_pk_bf16(b.x, b.y), cvt_pk_bf16(b.z, b.w)};
 }
+typedef __attribute__((ext_vector_type(4))) float t5_f32x4;
 __device__ __forceinline__ float t5_bf16_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float t5_bf16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
@@ -191,8 +192,19 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
     if (tid == 0) dead = 0;
 
     // ---- weights: rows (gate = wave, unit U0 + fr) of W_hh, all of K, as MFMA operands -------------------------------------------------
+    // NS = 16: v_mfma_f32_16x16x32_bf16 - the sixteen sequences are ALL of the tile's rows (the 32 x 32 form spent half of its 32 cycles on
+    // rows nobody reads, and read every h row twice): two column tiles ct (units U0 + 16 ct + (lane & 15)) x sixteen K = 32 steps, a lane
+    // holds B[k = 32 ks + 8 (lane >> 4) + j][column lane & 15] and A[row lane & 15][the same k]
+    const int l15 = lane & 15, l4 = lane >> 4;
     bf16x8 wreg[32];
-    {
+    if constexpr (NS == 16) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const uint16_t* wrow = Wb + (size_t)(wave * H + U0 + 16 * ct + l15) * H + l4 * 8;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) wreg[ct * 16 + ks] = *reinterpret_cast<const bf16x8*>(wrow + ks * 32);
+        }
+    } else {
         const uint16_t* wrow = Wb + (size_t)(wave * H + U0 + fr) * H + fq * 8;
 #pragma unroll
         for (int ks = 0; ks < 32; ++ks) wreg[ks] = *reinterpret_cast<const bf16x8*>(wrow + ks * 16);
@@ -294,6 +306,8 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
 #pragma unroll
             for (int g = 0; g < 4; ++g) gx[g] = gdecode(gxn[g]);
             // (b) the fifteen peers' h_{t-1}: NPOLL granules per thread (granule nn: peer 256 nn / PAIRS, pair 256 nn % PAIRS + tid)
+            // (issuing the stores and the prefetch below BETWEEN the poll's loads and the wait for them, as the backward does, was measured
+            //  here: 1 354 -> 1 680 us per pass - the wait then sits behind thirteen more queue entries)
             if (t > 0) {
                 const unsigned rt = tag - 1;
                 const u64* const slot = ring + (size_t)(rt & (T5_SLOTS - 1)) * (T5_M * PAIRS);
@@ -314,6 +328,8 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
                 }
             }
             stamp(0);      // poll + LDS writes
+            // (ablation, round 5, 256 x 512: without these stores 1 363 -> 1 170 us per pass, without the prefetch 1 173, without both 1 134:
+            //  the exchange / product / cell chain itself is 2.2 us per step, the HBM traffic costs 0.45 us on top)
             flush();       // the previous step's results
             {              // the next step's input projections
                 const bool onn = t + 1 < len;
@@ -324,14 +340,34 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
             __syncthreads();
             stamp(1);      // stores + prefetch issue + barrier
             if (dead) { failed = true; break; }
-            // (c) [32 seq] x [32 gate columns] += h_{t-1} W_hh^T over K = 512: two accumulator chains
+            // (c) [NS seq] x [32 gate columns] += h_{t-1} W_hh^T over K = 512
+            if constexpr (NS == 16) {
+                t5_f32x4 acc[2][2];                      // [column tile][chain]
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { acc[ct][0][q] = 0.f; acc[ct][1][q] = 0.f; }
+                const char* arow = hcur + l15 * T5_HROW + l4 * 16;
+                bf16x8 af[16];              // every fragment read is issued before the first MFMA (one wave per SIMD: nothing else hides LDS latency)
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(arow + ks * 64);
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    acc[0][ks & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], wreg[ks], acc[0][ks & 1], 0, 0, 0);
+                    acc[1][ks & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], wreg[16 + ks], acc[1][ks & 1], 0, 0, 0);
+                }
+                // (d) C layout: column (= unit 16 ct + (lane & 15)), row (= sequence) 4 (lane >> 4) + r
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[(wave * NS + 4 * l4 + r) * T5_RED_LD + 16 * ct + l15] = acc[ct][0][r] + acc[ct][1][r];
+            } else {
+            // two accumulator chains of v_mfma_f32_32x32x16_bf16
             f32x16 acc0, acc1;
 #pragma unroll
             for (int q = 0; q < 16; ++q) { acc0[q] = 0.f; acc1[q] = 0.f; }
-            // (NS = 16: rows 16..31 of the MFMA tile are no sequences - their lanes read rows 0..15 again and their results are never
-            //  looked at; a predicate here cost ~200 exec-mask / zero-fill instructions per step)
-            const char* arow = hcur + (fr & (NS - 1)) * T5_HROW + fq * 16;
-            bf16x8 af[32];              // every fragment read is issued before the first MFMA (one wave per SIMD: nothing else hides LDS latency)
+            const char* arow = hcur + fr * T5_HROW + fq * 16;
+            bf16x8 af[32];
 #pragma unroll
             for (int ks = 0; ks < 32; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(arow + ks * 32);
 #pragma unroll
@@ -341,8 +377,8 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
             }
             // (d) C layout: column (= unit) lane & 31, row (= sequence) (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if ((r >> 2) < NS / 8) red[(wave * NS + (r & 3) + 8 * (r >> 2) + 4 * fq) * T5_RED_LD + fr] = acc0[r] + acc1[r];
+            for (int r = 0; r < 16; ++r) red[(wave * NS + (r & 3) + 8 * (r >> 2) + 4 * fq) * T5_RED_LD + fr] = acc0[r] + acc1[r];
+            }
             stamp(2);      // product + spill
             __syncthreads();
             stamp(3);      // barrier
@@ -420,19 +456,33 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
     if (tid == 0) dead = 0;
 
     // ---- weights: for the four owners o = 4 wave + i: rows W_hh^T[unit 32 o + fr][own columns], K = 128 own gate columns ----------------
+    // NS = 16: v_mfma_f32_16x16x32_bf16 (see the forward): per owner two column tiles ct (units 16 ct + (lane & 15) of the owner) x four
+    // K = 32 steps g (the own 32 columns of gate g: k = 8 (lane >> 4) + j)
+    const int l15 = lane & 15, l4 = lane >> 4;
     bf16x8 wreg[4][8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const uint16_t* wrow = WTb + (size_t)(T5_US * (4 * wave + i) + fr) * GH + U0 + fq * 8;
+        if constexpr (NS == 16) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) wreg[i][ks] = *reinterpret_cast<const bf16x8*>(wrow + (ks >> 1) * H + (ks & 1) * 16);
+            for (int ct = 0; ct < 2; ++ct) {
+                const uint16_t* wrow = WTb + (size_t)(T5_US * (4 * wave + i) + 16 * ct + l15) * GH + U0 + l4 * 8;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) wreg[i][ct * 4 + g] = *reinterpret_cast<const bf16x8*>(wrow + g * H);
+            }
+        } else {
+            const uint16_t* wrow = WTb + (size_t)(T5_US * (4 * wave + i) + fr) * GH + U0 + fq * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) wreg[i][ks] = *reinterpret_cast<const bf16x8*>(wrow + (ks >> 1) * H + (ks & 1) * 16);
+        }
     }
     // ---- this thread's cells: unit U0 + (lane & 31); sequence pairs sb[k], sb[k] + 1 where the granule (register pair rp = wave + 4 k,
     //      lane) of a source's 32 x 32 block lands: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) with r = 2 rp --------------------------------
-    const int u = fr, j = U0 + u;
+    //      (NS = 16, 16 x 16 accumulators: granule (column tile ct, register pair rp) of a lane = rows 4 (lane >> 4) + 2 rp, + 1 of column
+    //      16 ct + (lane & 15); the thread that receives granule index 64 (2 ct + rp) + lane is (wave = 2 ct + rp, lane))
+    const int u = NS == 16 ? 16 * (wave >> 1) + l15 : fr, j = U0 + u;
     int sb[KP];
 #pragma unroll
-    for (int k = 0; k < KP; ++k) { const int r = 2 * (wave + 4 * k); sb[k] = (r & 3) + 8 * (r >> 2) + 4 * fq; }
+    for (int k = 0; k < KP; ++k) { const int r = 2 * (wave + 4 * k); sb[k] = NS == 16 ? 4 * l4 + 2 * (wave & 1) : (r & 3) + 8 * (r >> 2) + 4 * fq; }
 
     long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
     const bool timing = DC_DEV_TIMING && p.dbg != nullptr && team == 0 && member == 0 && tid == 0;
@@ -539,13 +589,50 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
 #pragma unroll
             for (int q = 0; q < NC; ++q) rec[q] = 0.f;
             if (t + 1 < tmax) {
-                // (b) partial dh_rec[32 seq][32 units of owner o] over the 128 own gate columns, o = 4 wave + i
+                // (b) partial dh_rec[NS seq][32 units of owner o] over the 128 own gate columns, o = 4 wave + i
+                u64* const out_slot = ring + (size_t)(tag & (T5_SLOTS - 1)) * (T5_M * T5_M * PAIRS);
+                if constexpr (NS == 16) {
+                    t5_f32x4 acc[4][2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { acc[i][0][q] = 0.f; acc[i][1][q] = 0.f; }
+                    const char* arow = dcur + l15 * T5_GROW + l4 * 16;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + g * 64);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wreg[i][g], acc[i][0], 0, 0, 0);
+                            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wreg[i][4 + g], acc[i][1], 0, 0, 0);
+                        }
+                    }
+                    stamp(0);      // operand copies + product
+                    // (c) to the owners: own block through LDS, the others as granules [slot][owner][source = member][64 (2 ct + rp) + lane]
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int o = 4 * wave + i;
+                        if (o == member) {
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) own[(4 * l4 + q) * T5_RED_LD + 16 * ct + l15] = acc[i][ct][q];
+                        } else {
+                            u64* dst = out_slot + ((size_t)o * T5_M + member) * PAIRS + lane;
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                                for (int rp = 0; rp < 2; ++rp)
+                                    granule_store(dst + (2 * ct + rp) * 64, __uint_as_float(cvt_pk_bf16(acc[i][ct][2 * rp], acc[i][ct][2 * rp + 1])), tag, plain);
+                        }
+                    }
+                } else {
                 f32x16 acc[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
-                const char* arow = dcur + (fr & (NS - 1)) * T5_GROW + fq * 16;        // (NS = 16: lanes 16..31 re-read rows 0..15, results unused)
+                const char* arow = dcur + fr * T5_GROW + fq * 16;
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
                     const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + ks * 32);
@@ -554,20 +641,19 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
                 }
                 stamp(0);      // operand copies + product
                 // (c) to the owners: own block through LDS, the others as granules [slot][owner][source = member][rp * 64 + lane]
-                u64* const out_slot = ring + (size_t)(tag & (T5_SLOTS - 1)) * (T5_M * T5_M * PAIRS);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int o = 4 * wave + i;
                     if (o == member) {
 #pragma unroll
-                        for (int q = 0; q < 16; ++q)
-                            if ((q >> 2) < NS / 8) own[((q & 3) + 8 * (q >> 2) + 4 * fq) * T5_RED_LD + fr] = acc[i][q];
+                        for (int q = 0; q < 16; ++q) own[((q & 3) + 8 * (q >> 2) + 4 * fq) * T5_RED_LD + fr] = acc[i][q];
                     } else {
                         u64* dst = out_slot + ((size_t)o * T5_M + member) * PAIRS + lane;
 #pragma unroll
-                        for (int rp = 0; rp < 4 * KP; ++rp)       // register pairs whose rows are sequences of the tile
+                        for (int rp = 0; rp < 8; ++rp)
                             granule_store(dst + rp * 64, __uint_as_float(cvt_pk_bf16(acc[i][2 * rp], acc[i][2 * rp + 1])), tag, plain);
                     }
+                }
                 }
                 stamp(1);      // publish
                 __syncthreads();
