@@ -635,7 +635,10 @@ def main():
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None,
             'dtype': 'bf16' if KERNEL_FLAGS & 4096 else 'f32',
-            'dtype_note': 'DC_DIMS_BF16: bf16 operands / f32 accumulate in the dense products and the recurrent products, f32 elsewhere' if KERNEL_FLAGS & 4096 else
+            'dtype_note': ('DC_DIMS_BF16: bf16 operands / f32 accumulate in the dense products and the recurrent products; on the LSTM-512 path the gate '
+                           'pre-activations / activations, the gate gradients, `pre`, `hseq` and `hprev` are also STORED as bf16 (round 5; '
+                           'DC_DIMS_BF16_F32_STORE keeps them f32); cell state, embeddings, loss, norms, Adam and the master weights stay f32')
+                          if KERNEL_FLAGS & 4096 else
                           'f32 end to end: inputs, weights, activations, gradients and optimizer state are f32 and every product is f32-grade '
                           '(matrix products, products=%s: %s; measured against f64 on the network\'s shapes: f16x2 1.2e-7..4.9e-7, bf16x3 1.4e-7..5.5e-7 of '
                           'max |C|, the f32 fma chain 2.1e-7..3.7e-7 - tools/ubench/gemm_x3.hip, profiles/r04/ubench_gemm_f16_pieces.txt); '

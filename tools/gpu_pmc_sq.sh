@@ -6,7 +6,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$(pwd)
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $REPO/$OUT/pmc -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $REPO/$OUT/pmc.log 2>&1
+timeout 180 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $REPO/$OUT/pmc -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $REPO/$OUT/pmc.log 2>&1
 echo "rocprof exit $?"; tail -3 $REPO/$OUT/pmc.log
 cd $REPO
 python tools/pmc_sq.py $OUT/pmc $OUT/sq.json

@@ -18,9 +18,9 @@ tail -c 1500 $OUT/bench.json
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/$OUT/prof -o trace -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-weak-unit $BENCH_ARGS > $REPO/$OUT/prof_bench.log 2>&1
 # PMC passes, each on its own (no trace domains besides kernel-trace)
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $REPO/$OUT/pmc_fetch -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-weak-unit $BENCH_ARGS > $REPO/$OUT/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $REPO/$OUT/pmc_write -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-weak-unit $BENCH_ARGS > $REPO/$OUT/pmc_write.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $REPO/$OUT/pmc_sq -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-weak-unit $BENCH_ARGS > $REPO/$OUT/pmc_sq.log 2>&1
+timeout 180 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $REPO/$OUT/pmc_fetch -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-weak-unit $BENCH_ARGS > $REPO/$OUT/pmc_fetch.log 2>&1
+timeout 180 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $REPO/$OUT/pmc_write -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-weak-unit $BENCH_ARGS > $REPO/$OUT/pmc_write.log 2>&1
+timeout 180 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $REPO/$OUT/pmc_sq -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-weak-unit $BENCH_ARGS > $REPO/$OUT/pmc_sq.log 2>&1
 cd $REPO
 python tools/pmc_sq.py $OUT/pmc_sq $OUT/pmc_sq.json > $OUT/pmc_sq.txt 2>&1
 DB=$(find $OUT/prof -name '*.db' | head -1)
