@@ -33,6 +33,7 @@
 // gradients 2^(ceil(log2 rows) + 2)) so that the m pieces stay normal, and the accumulators are scaled back in the epilogue.
 // An operand entry beyond 65504 / scale becomes inf -> NaN downstream -> the optimizer's own NaN guard (status word) stops the
 // update: the host then re-runs with the bf16 pieces (Engine: DC_DIMS_F16X2 cleared), whose exponent range is f32's.
+#include <cstdio>
 #include "kernels.h"
 #include "gemm_tiles.h"
 
@@ -70,6 +71,7 @@ struct X3Args {
     int M, N, K, lda, ldb, ldb2, ldc, ldc2, ldaux, n_split, k_per_split, relu, accumulate, nbias;
     float sa, sb, inv;      // PREC = 4: power-of-two pre-scales of the A / B operands and 1 / (sa sb)
     int c_bf16, aux_bf16;   // bf16 storage (configs[4]): C written as bf16 [M][ldc]; aux read as bf16 [M][ldaux]
+    long long* dbg;         // developer builds (DC_DEV_TIMING): phase clocks of workgroup 0, thread 0
 };
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -351,9 +353,17 @@ __global__ __launch_bounds__(256, X3Cfg<PREC>::kOcc) void gemm_x3_kernel(X3Args 
         if (nk > 1) { la.load(ra1, nsub(1)); lb.load(rb1, nsub(1)); }
     };
 
+    // developer builds (DC_DEV_TIMING): s_memtime stamps of (workgroup 0, thread 0), summed per phase (a stamp waits for the LDS
+    // operations in flight: the phases are serialised in that wave)
+    long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    const bool timing = DC_DEV_TIMING && p.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+    auto stamp = [&](int k) {
+        if (DC_DEV_TIMING && timing) { const long long now = (long long)__builtin_amdgcn_s_memtime(); tm[k] += now - tlast; tlast = now; }
+    };
     int m_blk, n_blk, z;
     if (!decode(0, m_blk, n_blk, z)) return;
     open_item(m_blk, n_blk, z);
+    if (DC_DEV_TIMING && timing) tlast = (long long)__builtin_amdgcn_s_memtime();
     for (int it = 0;; ++it) {
         f32x16 acc[2][2];
 #pragma unroll
@@ -383,7 +393,9 @@ __global__ __launch_bounds__(256, X3Cfg<PREC>::kOcc) void gemm_x3_kernel(X3Args 
         // one K step: loads of step kt + 2 -> the staging set that step kt just vacated; MFMAs of step kt; split + store of kt + 1
         auto kstep = [&](int kt, typename LA::Regs& ra_cur, typename LB::Regs& rb_cur, const typename LA::Regs& ra_nxt,
                          const typename LB::Regs& rb_nxt) {
+            stamp(7);      // (loop control)
             if (kt + 2 < nk) { la.load(ra_cur, nsub(kt + 2)); lb.load(rb_cur, nsub(kt + 2)); }
+            stamp(0);      // global loads issued
             const char* a_s = smem + (kt & 1) * STAGE_BYTES;
             const char* b_s = a_s + OPER_BYTES;
             bf16x8 a[2][NPL], b[2][NPL];
@@ -394,6 +406,7 @@ __global__ __launch_bounds__(256, X3Cfg<PREC>::kOcc) void gemm_x3_kernel(X3Args 
                     a[i][q] = LA::frag(a_s, wm * 64 + i * 32 + fr, fg, q);
                     b[i][q] = LB::frag(b_s, wn * 64 + i * 32 + fr, fg, q);
                 }
+            stamp(1);      // fragment reads (+ the wait for them)
             // piece-major order, smallest terms first: the four accumulators take turns, consecutive MFMAs never chain
 #define DC_X3_P(X, Y)                                                                                             \
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
@@ -411,12 +424,15 @@ __global__ __launch_bounds__(256, X3Cfg<PREC>::kOcc) void gemm_x3_kernel(X3Args 
             }
 #undef DC_X2H_P
 #undef DC_X3_P
+            stamp(2);      // MFMAs issued
             if (kt + 1 < nk) {
                 char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
                 if (do_cs) cs_add(ra_nxt);
                 la.store(ra_nxt, nxt, tid); lb.store(rb_nxt, nxt + OPER_BYTES, tid);
             }
+            stamp(3);      // wait for the next step's global loads + split + LDS stores
             __syncthreads();
+            stamp(4);      // barrier
         };
         for (int kt = 0; kt < nk; kt += 2) {
             kstep(kt, ra0, rb0, ra1, rb1);
@@ -439,10 +455,16 @@ __global__ __launch_bounds__(256, X3Cfg<PREC>::kOcc) void gemm_x3_kernel(X3Args 
         const int cm = m_blk, cn = n_blk, cz = z;
         const bool have_next = decode(it + 1, m_blk, n_blk, z);
         if (have_next) open_item(m_blk, n_blk, z);
+        stamp(5);      // item switch: first store + barrier of the item, next item's first loads
+        // (round 5 ablations on the network's shapes, profiles/r05/gemm_x3_ablation.txt: without this epilogue the x W^T product of the gates
+        //  runs 180 -> 133 us (prec 4) and configs[4]'s 680 -> 405 us (prec 1, f32 C): the K loop alone reaches 0.28-0.31 of the f16x2
+        //  ceiling / 0.27 of the bf16 peak; starting the workgroups of a CU a third of an item apart changed nothing)
         store_tile<PREC>(p, acc, smem, cm, cn, cz, wave, wm, wn, lane);
         if (!have_next) break;
         __syncthreads();          // the epilogue images live in the stage buffers the next item is about to fill
+        stamp(6);      // epilogue
     }
+    if (DC_DEV_TIMING && timing) { for (int k = 0; k < 8; ++k) p.dbg[k] = tm[k]; }
 }
 
 // weights -> bf16 planes, in the orientation the consumer contracts over
@@ -496,7 +518,25 @@ static int launch_x3(const X3Args& a, int splits, hipStream_t s) {
         return X3Cfg<PREC>::kOcc * cus;
     }();
     const int grid = n_items < slots ? n_items : slots;
+#if DC_DEV_TIMING
+    static long long* dbg = nullptr;
+    if (!dbg) (void)hipMalloc(&dbg, 64);
+    (void)hipMemsetAsync(dbg, 0, 64, s);
+    X3Args at = a;
+    at.dbg = dbg;
+    hipLaunchKernelGGL((gemm_x3_kernel<PREC, AM, BM_>), dim3(grid), dim3(256), X3Cfg<PREC>::kLds, s, at, n_items, mt, nt);
+    {
+        long long h[8];
+        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        const int kh = x3_kh<PREC, AM, BM_>();
+        const double items = (double)((n_items + grid - 1) / grid), steps = items * ((a.k_per_split / XK + kh - 1) / kh);
+        fprintf(stderr, "gemm_x3<%d,%d,%d> M %d N %d K %d items/wg %.0f steps/item %.0f | clocks per step: loads %.0f  frag reads %.0f  mfma issue %.0f  split+store %.0f  "
+                        "barrier %.0f  loop %.0f | per item: switch %.0f  epilogue %.0f\n", PREC, AM, BM_, a.M, a.N, a.K, items, steps / items, h[0] / steps, h[1] / steps,
+                h[2] / steps, h[3] / steps, h[4] / steps, h[7] / steps, h[5] / items, h[6] / items);
+    }
+#else
     hipLaunchKernelGGL((gemm_x3_kernel<PREC, AM, BM_>), dim3(grid), dim3(256), X3Cfg<PREC>::kLds, s, a, n_items, mt, nt);
+#endif
     return launch_check("gemm_x3");
 }
 
