@@ -311,9 +311,28 @@ __global__ __launch_bounds__(256, X3Cfg<PREC>::kOcc) void gemm_x3_kernel(X3Args 
     // work item -> (m tile, n tile, split).  With a multiple of 8 row tiles, the workgroups of one XCD (blockIdx & 7 under the
     // usual round-robin placement - a speed hint only) take the column tiles of the same row tile one after the other, so
     // the A rows they share stay in that XCD's L2.
-    const bool xcd_map = (mt & 7) == 0 && (gridDim.x & 7) == 0;
+    // Split-K products (the weight gradients) with a multiple of 8 splits: an XCD takes whole SPLITS (z = x, x + 8, ...) - every tile
+    // of a K range runs in the same XCD, so both operands of that range are fetched from HBM once (by row tile, the x rows of a range
+    // went through all eight L2s: the gates' weight gradient read 1.3 GB instead of 0.4).
+    const int n_splits = p_splits(p);
+#ifdef DC_X3_NO_ZMAP          // A/B build
+    const bool z_map = false;
+#else
+    const bool z_map = n_splits >= 8 && (n_splits & 7) == 0 && (gridDim.x & 7) == 0;
+#endif
+    const bool xcd_map = !z_map && (mt & 7) == 0 && (gridDim.x & 7) == 0;
     auto decode = [&](int it, int& m_blk, int& n_blk, int& z) -> bool {
         int w;
+        if (z_map) {
+            const int per = n_items >> 3;                                   // items per XCD slice
+            const int wi = it * (gridDim.x >> 3) + (blockIdx.x >> 3);
+            if (wi >= per) return false;
+            const int tiles = mt * nt;
+            const int zl = wi / tiles, t = wi - zl * tiles;
+            z = zl * 8 + (int)(blockIdx.x & 7);
+            m_blk = (t / nt) * XB; n_blk = (t % nt) * XB;
+            return true;
+        }
         if (xcd_map) {
             const int per = n_items >> 3;                                   // items per XCD slice
             const int wi = it * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -572,6 +591,7 @@ int gemm_x3(const X3Gemm& g, hipStream_t stream) {
         splits = (int)(want < maxs ? want : maxs);
         if (splits < 1) splits = 1;
         while (splits > 1 && (long long)splits * g.M * g.N > g.scratch.floats) --splits;
+        if (splits >= 8) splits = splits / 8 * 8;       // whole splits per XCD (the kernel's z_map)
     }
     int kper = (g.K + splits - 1) / splits;
     const int kgran = g.prec == 1 ? XK * X3Cfg<1>::kKHmax : XK;      // whole steps per split
