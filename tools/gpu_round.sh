@@ -25,6 +25,7 @@ cd $REPO
 python tools/pmc_sq.py $OUT/pmc_sq $OUT/pmc_sq.json > $OUT/pmc_sq.txt 2>&1
 DB=$(find $OUT/prof -name '*.db' | head -1)
 [ -n "$DB" ] && python tools/rocpd_stats.py $DB $OUT/kernel_stats.csv
+[ -n "$DB" ] && python tools/rocpd_dispatches.py $DB gemm_x3 39 > $OUT/gemm_dispatches.txt 2>&1    # one step's products, in launch order
 python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json $WORKLOAD 2>&1 | tail -15
 # keep the merge-back small: drop raw traces
 find $OUT/prof -name '*.db' -size +20M -delete

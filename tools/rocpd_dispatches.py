@@ -16,5 +16,5 @@ grid = [x for x in cols if x.startswith('grid') and x.endswith('x')]
 q = 'select %s, %s, %s%s from %s where %s like ? order by %s' % (name, start, end, (', ' + grid[0]) if grid else '', v, name, start)
 rows = c.execute(q, ('%' + pat + '%',)).fetchall()
 for r in rows[-n:]:
-    short = r[0].split('(')[0][-60:]
+    short = r[0].replace('(anonymous namespace)::', '').split('(')[0][-60:]
     print('%-60s %9.1f us%s' % (short, (r[2] - r[1]) / 1e3, ('  grid %d' % r[3]) if grid else ''))
