@@ -607,7 +607,11 @@ def main():
         P = eng.total
         alg_step_bytes = 2100.0 * (1 + E) * B * S + 28.0 * P * E            # 2.1 KB per env-step and pass + 28 B per parameter and optimizer step
         step_traffic = pmc_whole_step(args.traffic_json, workload_key, 1 + E)
-        roofline = {'bound': dom_bound, 'bound_note': BOUND_NOTES[dom_bound], 'kernel': dom['kernel'], 'kernel_note': REGION_NOTES.get(dom['kernel']),
+        bound_note = BOUND_NOTES[dom_bound]
+        if dom_bound == 'mfma' and (KERNEL_FLAGS & 4096) and dom['kernel'].startswith('gemm_'):
+            bound_note = ('DC_DIMS_BF16: bf16 operands (stored as bf16 on the LSTM-512 path), f32 accumulate, one v_mfma_f32_32x32x16_bf16 per K = 16 and '
+                          'tile pair; `peak` = the dense bf16 MFMA peak (2 500 TF)')
+        roofline = {'bound': dom_bound, 'bound_note': bound_note, 'kernel': dom['kernel'], 'kernel_note': REGION_NOTES.get(dom['kernel']),
                     'achieved': round(achieved, 3), 'peak': round(dom_peak, 1),
                     'unit': 'TFLOP/s', 'frac': round(achieved / dom_peak, 4),
                     'traffic': pmc_traffic(args.traffic_json, dom['kernel'], workload_key),
