@@ -4,7 +4,9 @@ DC_DIMS_BF16 rounds the operands of the dense products - affine_pre_rnn, the rec
 projections and all their gradient products (policy.py:138-155 and autograd's products for them) - to bf16 (8 mantissa bits),
 one v_mfma_f32_32x32x16_bf16 per K = 16 with f32 accumulation; at H = 512 (no register-resident recurrent kernel) the
 recurrent products W_hh h and their BPTT counterparts too (csrc/rnn_step_bf16.hip: bf16 operands, f32 accumulate, f32 state
-and gate maths); the unit embeddings, the H <= 256 recurrences, the loss, the norms and Adam stay f32.  There is no bf16 reference ("compared to this fp32 oracle with a looser,
+and gate maths; since round 5 on the persistent LSTM-512 kernels the gate pre-activations / activations, the gate gradients, `pre`,
+`hseq` and `hprev` are also STORED as bf16 - DC_DIMS_BF16_F32_STORE keeps them f32); the unit embeddings, the cell state, the
+H <= 256 recurrences, the loss, the norms and Adam stay f32.  There is no bf16 reference ("compared to this fp32 oracle with a looser,
 separately-stated tolerance"), so the tolerances below ARE the statement:
 
   quantity (one epoch from the same weights, oracle fp32)          tolerance      why
@@ -12,6 +14,8 @@ separately-stated tolerance"), so the tolerances below ARE the statement:
   losses (util.loss_rel_err), entropies, gradient norms            3e-2           means over >= 10^3 steps of the above
   masked argmax indices                                            >= 97 % equal  near-ties flip under a 2^-9 perturbation of the logits
   post-step parameters (scaled)                                    1e-3           one Adam step moves a parameter by <= lr = 5e-5 whatever the gradient
+  bf16 storage against f32 storage of the same kernels             1e-2           one more bf16 rounding of the input projections, the stored gates and gate gradients
+  persistent LSTM-512 kernels against the launch-per-step ones      5e-3           same arithmetic (both f32-stored), another summation order
 """
 import numpy as np
 import pytest
