@@ -57,12 +57,42 @@ constexpr int t5_pairs(int ns) { return ns * T5_US / 2; }                       
 constexpr size_t t5_fwd_ring(int ns) { return (size_t)T5_SLOTS * T5_M * t5_pairs(ns); }          // u64 words per team
 constexpr size_t t5_bwd_ring(int ns) { return (size_t)T5_SLOTS * T5_M * T5_M * t5_pairs(ns); }   // [slot][owner][source][pairs]
 constexpr int t5_fwd_lds(int ns) { return 2 * ns * T5_HROW + 4 * ns * T5_RED_LD * 4; }
-constexpr int t5_bwd_lds(int ns) { return 2 * ns * T5_GROW + ns * T5_RED_LD * 4; }
+// (16-sequence tiles: + the staging images of the backward's wide HBM accesses: gates 4 KB, dh / c / c_prev 2 KB each, dh / dc out 2 x 2 KB each)
+constexpr int t5_bwd_wide(int ns) { return ns == 16 ? 4096 + 3 * 2048 + 4 * 2048 : 0; }
+constexpr int t5_bwd_lds(int ns) { return 2 * ns * T5_GROW + ns * T5_RED_LD * 4 + t5_bwd_wide(ns); }
 
 __device__ __forceinline__ u32x4 t5_to_bf16x8(const float4& a, const float4& b) {
     return u32x4{cvt_pk_bf16(a.x, a.y), cvt_pk_bf16(a.z, a.w), cvt_pk_bf16(b.x, b.y), cvt_pk_bf16(b.z, b.w)};
 }
 typedef __attribute__((ext_vector_type(4))) float t5_f32x4;
+// The activation streams (gate rows, states, gradients: each byte touched once per launch) are marked NON-TEMPORAL: they pass through
+// the L2 the team's granules live in, and as ordinary accesses they evict them - measured on the backward, 256 x 512: 2 216 -> 1 917 us
+// per pass (-DT5_NT=0: ordinary accesses, for A/B).
+#ifndef T5_NT
+#define T5_NT 1
+#endif
+typedef __attribute__((ext_vector_type(2))) unsigned t5_u32x2;
+template <class T> __device__ __forceinline__ T t5_ld(const T* p) {
+#if T5_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <class T> __device__ __forceinline__ void t5_st(T* p, T v) {
+#if T5_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+// (HIP's float4 / uint2 are structs: through the matching ext vectors)
+__device__ __forceinline__ float4 t5_ld(const float4* p) { const t5_f32x4 v = t5_ld(reinterpret_cast<const t5_f32x4*>(p)); return make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ uint2 t5_ld(const uint2* p) { const t5_u32x2 v = t5_ld(reinterpret_cast<const t5_u32x2*>(p)); return make_uint2(v[0], v[1]); }
+__device__ __forceinline__ void t5_st(float4* p, float4 v) { t5_st(reinterpret_cast<t5_f32x4*>(p), t5_f32x4{v.x, v.y, v.z, v.w}); }
+__device__ __forceinline__ void t5_st(uint2* p, uint2 v) { t5_st(reinterpret_cast<t5_u32x2*>(p), t5_u32x2{v.x, v.y}); }
+#define T5_LD(p) t5_ld(p)
+#define T5_ST(p, v) t5_st(p, v)
 __device__ __forceinline__ float t5_bf16_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float t5_bf16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
@@ -237,7 +267,7 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
         // (the prefetched row stays RAW in its registers until the step that uses it: any arithmetic on it at the point of the load
         //  would wait for the load there - measured: + 3 600 clocks per step in the prefetch phase)
         using GR = std::conditional_t<BS, uint2, float4>;
-        auto gload = [](const GT* q) -> GR { return *reinterpret_cast<const GR*>(q); };
+        auto gload = [](const GT* q) -> GR { return T5_LD(reinterpret_cast<const GR*>(q)); };
         auto gdecode = [](const GR& w) -> float4 {
             if constexpr (BS) return make_float4(t5_bf16_lo(w.x), t5_bf16_hi(w.x), t5_bf16_lo(w.y), t5_bf16_hi(w.y));
             else return w;
@@ -271,20 +301,20 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_fwd_kernel(RnnStep
             GT* gt = gbase + (size_t)pt * GH;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                if constexpr (BS) *reinterpret_cast<uint2*>(gt + g * H) = make_uint2(cvt_pk_bf16(pact[g].x, pact[g].y), cvt_pk_bf16(pact[g].z, pact[g].w));
-                else *reinterpret_cast<float4*>(gt + g * H) = pact[g];
+                if constexpr (BS) T5_ST(reinterpret_cast<uint2*>(gt + g * H), make_uint2(cvt_pk_bf16(pact[g].x, pact[g].y), cvt_pk_bf16(pact[g].z, pact[g].w)));
+                else T5_ST(reinterpret_cast<float4*>(gt + g * H), pact[g]);
             }
             float* st = sbase + (size_t)pt * H;
-            *reinterpret_cast<float4*>(st) = pc;
-            if (pnext) *reinterpret_cast<float4*>(st + H + d_cp) = pc;
+            T5_ST(reinterpret_cast<float4*>(st), pc);
+            if (pnext) T5_ST(reinterpret_cast<float4*>(st + H + d_cp), pc);
             if constexpr (BS) {      // hseq / hprev as bf16: the values the next product and the peers get anyway
                 const uint2 hb = make_uint2(cvt_pk_bf16(ph.x, ph.y), cvt_pk_bf16(ph.z, ph.w));
                 const size_t e = (row0 + (size_t)pt) * H + j0;
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.hseq) + e) = hb;
-                if (pnext) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.hprev) + e + H) = hb;
+                T5_ST(reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.hseq) + e), hb);
+                if (pnext) T5_ST(reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.hprev) + e + H), hb);
             } else {
-                *reinterpret_cast<float4*>(st + d_h) = ph;
-                if (pnext) *reinterpret_cast<float4*>(st + H + d_hp) = ph;
+                T5_ST(reinterpret_cast<float4*>(st + d_h), ph);
+                if (pnext) T5_ST(reinterpret_cast<float4*>(st + H + d_hp), ph);
             }
             pend = false;
         };
@@ -444,6 +474,20 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
     float* const own = reinterpret_cast<float*>(smem + 2 * NS * T5_GROW);   // own partial sums [seq][unit]
     __shared__ int dead;
     constexpr int H = T5_H, GH = 4 * T5_H, PAIRS = t5_pairs(NS), NPOLL = 15 * PAIRS / T5_THREADS, KP = NS / 16, NC = 2 * KP;   // NC cells per thread
+    // WIDE (bf16 storage, 16-sequence tiles - configs[4]'s case): every HBM access of a step is a 16-byte-per-lane access of a whole
+    // 64 / 128-byte row segment, staged through LDS images - three loads and two stores per thread and step instead of fourteen 2 / 4-byte
+    // loads and twelve stores (measured by ablation, 256 x 512: the narrow loads cost 900 us and the stores 370 us of a 2 260 us pass).
+    //   gates / dgx image [seq 16][gate 4][unit 32] bf16: chunk tid = 16 bytes = (seq tid >> 4, gate (tid >> 2) & 3, units 8 (tid & 3) ..)
+    //   dh / c / c_prev / dh out / dc out images [seq 16][unit 32] f32: chunk cf = tid & 127 = (seq cf >> 3, units 4 (cf & 7) ..);
+    //   waves 0, 1 move dh and c_prev in and dh out, waves 2, 3 move c in and dc out.
+    constexpr bool WIDE = BS && NS == 16;
+    char* const wbase = smem + 2 * NS * T5_GROW + NS * T5_RED_LD * 4;
+    uint16_t* const SG = reinterpret_cast<uint16_t*>(wbase);                 // the step's gates
+    float* const SD = reinterpret_cast<float*>(wbase + 4096);               // dh (in), c, c_prev
+    float* const SC = SD + 512;
+    float* const SP = SC + 512;
+    float* const OD = SP + 512;                                             // dh (total), dc: [parity of t][seq][unit]
+    float* const OC = OD + 1024;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fq = lane >> 5;
@@ -505,6 +549,12 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
             row0[q] = len[q] > 0 ? (size_t)p.seq_off[b] : 0;
             nf[q] = 0.f; ndc[q] = 0.f;
         }
+        // WIDE: the sequences of this thread's chunks
+        const int cf = tid & 127;
+        const int bG = b0 + (tid >> 4), bF = b0 + (cf >> 3);
+        const int lenG = (WIDE && bG < p.n_seq) ? p.seq_len[bG] : 0, lenF = (WIDE && bF < p.n_seq) ? p.seq_len[bF] : 0;
+        const size_t rowG = lenG > 0 ? (size_t)p.seq_off[bG] : 0, rowF = lenF > 0 ? (size_t)p.seq_off[bF] : 0;
+        const int gcol = ((tid >> 2) & 3) * H + U0 + 8 * (tid & 3), fcol = U0 + 4 * (cf & 7);
         // no gate gradients yet: the first product (skipped) would read zeros
         for (int e = tid; e < 2 * NS * T5_GROW / 4; e += T5_THREADS) reinterpret_cast<unsigned*>(dg0)[e] = 0u;
         // The cells' operands of a step are fetched TWO STEPS AHEAD into one of two register sets (static indices: the loop is unrolled by
@@ -514,8 +564,22 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
         using GV = std::conditional_t<BS, unsigned, float>;
         GV gvn[2][NC][4];
         float dhn[2][NC], csn[2][NC], cpn[2][NC];
+        u32x4 rg[2], ra[2], rb[2];                           // WIDE: the raw chunks of a step, by parity (they stay raw until they are staged)
         auto fetch = [&](int tt, auto PAR) {
             constexpr int P = decltype(PAR)::value;
+            if constexpr (WIDE) {
+                // NO select on the loaded data (it would wait for the load right here): a step outside the sequence re-reads a row inside it
+                // (the first row of the buffer for an absent sequence) - the cells ignore what is staged for a step they are not `on`
+                const size_t tG = (size_t)max(min(tt, lenG - 1), 0), tF = (size_t)max(min(tt, lenF - 1), 0);
+                rg[P] = T5_LD(reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(p.gates) + (rowG + tG) * GH + gcol));
+                if (wave < 2) {
+                    ra[P] = T5_LD(reinterpret_cast<const u32x4*>(p.dh + (rowF + tF) * H + fcol));
+                    rb[P] = T5_LD(reinterpret_cast<const u32x4*>(p.cprev + (rowF + tF) * H + fcol));
+                } else {
+                    ra[P] = T5_LD(reinterpret_cast<const u32x4*>(p.cseq + (rowF + tF) * H + fcol));
+                }
+                return;
+            }
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
                 const bool o = tt >= 0 && tt < len[q];
@@ -523,15 +587,15 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
                 if constexpr (BS) {
                     const uint16_t* gt = reinterpret_cast<const uint16_t*>(p.gates) + rr * GH + j;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) gvn[P][q][g] = o ? (unsigned)gt[g * H] : 0u;
+                    for (int g = 0; g < 4; ++g) gvn[P][q][g] = o ? (unsigned)T5_LD(gt + g * H) : 0u;
                 } else {
                     const float* gt = p.gates + rr * GH + j;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) gvn[P][q][g] = o ? gt[g * H] : 0.f;
+                    for (int g = 0; g < 4; ++g) gvn[P][q][g] = o ? T5_LD(gt + g * H) : 0.f;
                 }
-                dhn[P][q] = o ? p.dh[rr * H + j] : 0.f;
-                csn[P][q] = o ? p.cseq[rr * H + j] : 0.f;
-                cpn[P][q] = o ? p.cprev[rr * H + j] : 0.f;
+                dhn[P][q] = o ? T5_LD(p.dh + rr * H + j) : 0.f;
+                csn[P][q] = o ? T5_LD(p.cseq + rr * H + j) : 0.f;
+                cpn[P][q] = o ? T5_LD(p.cprev + rr * H + j) : 0.f;
             }
         };
         fetch(tmax - 1, std::integral_constant<int, 0>{});
@@ -542,20 +606,33 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
         bool pend[NC];
 #pragma unroll
         for (int q = 0; q < NC; ++q) { pend[q] = false; prow[q] = 0; }
+        // WIDE: the results of step tt from their LDS images (the gate-gradient tile the next product reads; the dh / dc images)
+        auto flush_wide = [&](int tt) {
+            if (tt < lenG) {
+                const char* tile = dg0 + ((tt + 1) & 1) * (NS * T5_GROW);
+                const u32x4 v = *reinterpret_cast<const u32x4*>(tile + (tid >> 4) * T5_GROW + (((tid >> 2) & 3) * T5_US + 8 * (tid & 3)) * 2);
+                T5_ST(reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.dgx) + (rowG + (size_t)tt) * GH + gcol), v);
+            }
+            if (tt < lenF) {
+                const float* img = (wave < 2 ? OD : OC) + (tt & 1) * 512 + cf * 4;
+                float* dst = (wave < 2 ? p.dh : p.dc) + (rowF + (size_t)tt) * H + fcol;
+                T5_ST(reinterpret_cast<u32x4*>(dst), *reinterpret_cast<const u32x4*>(img));
+            }
+        };
         auto flush = [&]() {
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
                 if (!pend[q]) continue;
-                p.dh[prow[q] * H + j] = pd[q][4];
-                p.dc[prow[q] * H + j] = pd[q][5];
+                T5_ST(p.dh + prow[q] * H + j, pd[q][4]);
+                T5_ST(p.dc + prow[q] * H + j, pd[q][5]);
                 if constexpr (BS) {
                     uint16_t* gx = reinterpret_cast<uint16_t*>(p.dgx) + prow[q] * GH + j;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) gx[g * H] = (uint16_t)(cvt_pk_bf16(pd[q][g], 0.f) & 0xffffu);
+                    for (int g = 0; g < 4; ++g) T5_ST(gx + g * H, (uint16_t)(cvt_pk_bf16(pd[q][g], 0.f) & 0xffffu));
                 } else {
                     float* gx = p.dgx + prow[q] * GH + j;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) gx[g * H] = pd[q][g];
+                    for (int g = 0; g < 4; ++g) T5_ST(gx + g * H, pd[q][g]);
                 }
                 pend[q] = false;
             }
@@ -573,17 +650,24 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
             bool on[NC], has_next[NC];
             float gv[NC][4], dhv[NC], cs[NC], cp[NC];
             size_t r[NC];
+            if constexpr (WIDE) {      // the step's chunks (fetched two steps ago) -> their images; the cells read them behind the next barrier
+                reinterpret_cast<u32x4*>(SG)[tid] = rg[P];
+                if (wave < 2) { reinterpret_cast<u32x4*>(SD)[cf] = ra[P]; reinterpret_cast<u32x4*>(SP)[cf] = rb[P]; }
+                else reinterpret_cast<u32x4*>(SC)[cf] = ra[P];
+            }
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
                 on[q] = t < len[q];
                 has_next[q] = t + 1 < len[q];
                 r[q] = row0[q] + (size_t)t;
+                if constexpr (!WIDE) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if constexpr (BS) gv[q][g] = __uint_as_float(gvn[P][q][g] << 16);
-                    else gv[q][g] = gvn[P][q][g];
+                    for (int g = 0; g < 4; ++g) {
+                        if constexpr (BS) gv[q][g] = __uint_as_float(gvn[P][q][g] << 16);
+                        else gv[q][g] = gvn[P][q][g];
+                    }
+                    dhv[q] = dhn[P][q]; cs[q] = csn[P][q]; cp[q] = cpn[P][q];
                 }
-                dhv[q] = dhn[P][q]; cs[q] = csn[P][q]; cp[q] = cpn[P][q];
             }
             float rec[NC];
 #pragma unroll
@@ -668,7 +752,8 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
                 t5_poll_issue<NPOLL>(addr, g);
                 // ... meanwhile: the previous step's stores, the operand fetch for two steps ahead, and everything of the cells that does
                 // not need the received sums
-                flush();
+                if constexpr (WIDE) flush_wide(t + 1);
+                else flush();
                 fetch(t - 2, PAR);
 #pragma unroll
                 for (int k = 0; k < KP; ++k) {
@@ -687,8 +772,18 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
                     rec[2 * k + 1] += t5_bf16_hi(w);
                 }
             } else {
-                flush();
+                if constexpr (WIDE) __syncthreads();      // (the images; with an exchange the barrier behind the publish has done it)
+                else flush();
                 fetch(t - 2, PAR);
+            }
+            if constexpr (WIDE) {
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+                    const int e = (sb[q >> 1] + (q & 1)) * T5_US + u;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) gv[q][g] = __uint_as_float((unsigned)SG[e + (3 * (sb[q >> 1] + (q & 1)) + g) * T5_US] << 16);
+                    dhv[q] = SD[e]; cs[q] = SC[e]; cp[q] = SP[e];
+                }
             }
             stamp(3);      // poll (+ stores, prefetch under it) + sum
             // (e) the cells (rnn_step_bf16.hip's epilogue)
@@ -707,11 +802,16 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
                     d4[1] = dcv * cp[q] * fg * (1.f - fg);
                     d4[2] = dcv * ig * (1.f - gg * gg);
                     d4[3] = dh * tc * og * (1.f - og);
+                    if constexpr (WIDE) {
+                        OD[(t & 1) * 512 + s * T5_US + u] = dh;
+                        OC[(t & 1) * 512 + s * T5_US + u] = dcv;
+                    } else {
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) pd[q][g4] = d4[g4];
-                    pd[q][4] = dh; pd[q][5] = dcv;
-                    prow[q] = r[q];
-                    pend[q] = true;
+                        for (int g4 = 0; g4 < 4; ++g4) pd[q][g4] = d4[g4];
+                        pd[q][4] = dh; pd[q][5] = dcv;
+                        prow[q] = r[q];
+                        pend[q] = true;
+                    }
                     nf[q] = fg; ndc[q] = dcv;
                 }
 #pragma unroll
@@ -728,7 +828,8 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
             if (!step(t, std::integral_constant<int, 0>{})) { failed = true; break; }
             if (t - 1 >= 0 && !step(t - 1, std::integral_constant<int, 1>{})) { failed = true; break; }
         }
-        flush();
+        if constexpr (WIDE) { if (!failed) flush_wide(0); }
+        else flush();
         __syncthreads();
     }
     if (DC_DEV_TIMING && timing) { tm[7] = plain; for (int k = 0; k < 8; ++k) p.dbg[k] = tm[k]; }
