@@ -286,7 +286,7 @@ static __device__ __forceinline__ void store_tile(const X3Args& p, f32x16 (&acc)
             const float4 o = *reinterpret_cast<const float4*>(c);
             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         }
-        *reinterpret_cast<float4*>(c) = v;
+        *reinterpret_cast<float4*>(c) = v;      // (as non-temporal stores: no change, +- 2 %, measured round 5)
     }
     }   // row halves
 }

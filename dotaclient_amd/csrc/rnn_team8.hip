@@ -123,12 +123,12 @@ __global__ __launch_bounds__(T8_THREADS, 2) void team8_fwd_kernel(RnnStepArgs p,
             // (both wave halves: the same addresses, the same values)
             auto hook = [&](auto K) {
                 constexpr int k = decltype(K)::value;          // 0 .. 31
-                if constexpr (k >= 1 && k <= G) xnext[k - 1] = lp[(k - 1) * H];
-                else if constexpr (k >= 8 && k < 8 + G) gs[(k - 8) * H] = sv[k - 8];
-                else if constexpr (k == 12) *cs = sv[LSTM ? 4 : 3];
-                else if constexpr (k == 13) *hs = sv[5];
-                else if constexpr (k == 14 && LSTM) *cp = svp0;
-                else if constexpr (k == 15) *hp = svp1;
+                if constexpr (k >= 1 && k <= G) xnext[k - 1] = tm_ld(lp + (k - 1) * H);
+                else if constexpr (k >= 8 && k < 8 + G) tm_st(gs + (k - 8) * H, sv[k - 8]);
+                else if constexpr (k == 12) tm_st(cs, sv[LSTM ? 4 : 3]);
+                else if constexpr (k == 13) tm_st(hs, sv[5]);
+                else if constexpr (k == 14 && LSTM) tm_st(cp, svp0);
+                else if constexpr (k == 15) tm_st(hp, svp1);
             };
             f32x4 pa[4];
             FwdProduct<T8_KQ>::run(pa, w0, w1, lds_addr(&h_lds[cur][(wave * 4 + (lane & 3)) * T8_HLD + (lane >> 2) * 4]), hook);
@@ -285,12 +285,12 @@ __global__ __launch_bounds__(T8_THREADS, 2) void team8_fwd_half_kernel(RnnStepAr
             float* const hp = p.hprev + st_p;
             auto hook = [&](auto K) {
                 constexpr int k = decltype(K)::value;          // 0 .. 31
-                if constexpr (k >= 1 && k <= G) xnext[k - 1] = lp[(k - 1) * H];
-                else if constexpr (k >= 8 && k < 8 + G) gs[(k - 8) * H] = sv[k - 8];
-                else if constexpr (k == 12) *cs = sv[LSTM ? 4 : 3];
-                else if constexpr (k == 13) *hs = sv[5];
-                else if constexpr (k == 14 && LSTM) *cp = svp0;
-                else if constexpr (k == 15) *hp = svp1;
+                if constexpr (k >= 1 && k <= G) xnext[k - 1] = tm_ld(lp + (k - 1) * H);
+                else if constexpr (k >= 8 && k < 8 + G) tm_st(gs + (k - 8) * H, sv[k - 8]);
+                else if constexpr (k == 12) tm_st(cs, sv[LSTM ? 4 : 3]);
+                else if constexpr (k == 13) tm_st(hs, sv[5]);
+                else if constexpr (k == 14 && LSTM) tm_st(cp, svp0);
+                else if constexpr (k == 15) tm_st(hp, svp1);
             };
             f32x4 pa[4];
             BwdProduct<KH>::run(pa, w, lds_addr(&h_lds[cur][(lane & 3) * T8C_HLD + KH * kh + ((lane >> 2) & 7) * 16]), hook);
@@ -433,13 +433,13 @@ __global__ __launch_bounds__(T8_THREADS, 2) void team8_bwd_kernel(RnnStepArgs p,
             float* const ghs = LSTM ? nullptr : p.dgh + st_g;
             auto hook = [&](auto K) {
                 constexpr int k = decltype(K)::value;          // 0 .. 31
-                if constexpr (k >= 1 && k <= G) nv[k - 1] = lg[(k - 1) * H];
-                else if constexpr (k == 5) nv[LSTM ? 4 : 3] = *lc;
-                else if constexpr (k == 6) nv[5] = *lcp;
-                else if constexpr (k == 7) nv[6] = *ldh;
-                else if constexpr (k >= 10 && k < 10 + G) gs[(k - 10) * H] = sv[k - 10];
-                else if constexpr (!LSTM && (k == 14 || k == 15)) ghs[(k - 14) * H] = sv[k - 14];
-                else if constexpr (!LSTM && k == 16) ghs[2 * H] = svh2;
+                if constexpr (k >= 1 && k <= G) nv[k - 1] = tm_ld(lg + (k - 1) * H);
+                else if constexpr (k == 5) nv[LSTM ? 4 : 3] = tm_ld(lc);
+                else if constexpr (k == 6) nv[5] = tm_ld(lcp);
+                else if constexpr (k == 7) nv[6] = tm_ld(ldh);
+                else if constexpr (k >= 10 && k < 10 + G) tm_st(gs + (k - 10) * H, sv[k - 10]);
+                else if constexpr (!LSTM && (k == 14 || k == 15)) tm_st(ghs + (k - 14) * H, sv[k - 14]);
+                else if constexpr (!LSTM && k == 16) tm_st(ghs + 2 * H, svh2);
             };
             // ---- partial dh_rec[seq 0..3][u'] over this member's 128 gate columns ------------------------------------------
             f32x4 pa[4];

@@ -35,26 +35,6 @@
 
 namespace dc {
 namespace {
-// The activation streams (gate rows, states, gradients: each byte touched once per launch) are NON-TEMPORAL accesses: as ordinary ones
-// they pass through - and evict from - the L2 the team's granules live in (rnn_team512.hip measured it: 2 216 -> 1 917 us per pass).
-// -DTM_NT=0: ordinary accesses (A/B).
-#ifndef TM_NT
-#define TM_NT 1
-#endif
-__device__ __forceinline__ float tm_ld(const float* p) {
-#if TM_NT
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ void tm_st(float* p, float v) {
-#if TM_NT
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
 
 
 enum { TM_H = TEAM_H, TM_KH = 128, TM_HLD = TM_KH + 4, TM_THREADS = 256 };
