@@ -630,10 +630,10 @@ def main():
                                            'PMC bytes x launches per step, algorithmic_bytes = SURVEY.md 8(d)\'s per-unit figures x this batch'},
                     'kernels': kernels}
         if regions[0] is not dom:
-            lr = regions[0]
-            roofline['largest_region'] = {'kernel': lr['kernel'], 'bound': REGION_BOUND.get(lr['kernel'], 'mfma'),
-                                          'bound_note': BOUND_NOTES.get(REGION_BOUND.get(lr['kernel'], 'mfma')),
-                                          'ms_per_step': round(lr['total_ms'], 3), 'avg_launch_us': round(lr['total_ms'] * 1e3 / lr['launches'], 3),
+            big = regions[0]
+            roofline['largest_region'] = {'kernel': big['kernel'], 'bound': REGION_BOUND.get(big['kernel'], 'mfma'),
+                                          'bound_note': BOUND_NOTES.get(REGION_BOUND.get(big['kernel'], 'mfma')),
+                                          'ms_per_step': round(big['total_ms'], 3), 'avg_launch_us': round(big['total_ms'] * 1e3 / big['launches'], 3),
                                           'priced_region_ms_per_step': round(dom['total_ms'], 3)}
         key = (args.cell, args.hidden, args.layers, B, S, world > 1)
         which = {('lstm', 256, 1, 256, 256, False): 'BASELINE.json configs[2] (5v5 synthetic, LSTM hidden=256, batch=256x256 steps, 1xMI355X)',
