@@ -751,7 +751,10 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
                 u64 g[NPOLL];      // granule nn: source 256 nn / PAIRS (skipping this member), register-pair block k = (256 nn % PAIRS) / 256
                 t5_poll_issue<NPOLL>(addr, g);
                 // ... meanwhile: the previous step's stores, the operand fetch for two steps ahead, and everything of the cells that does
-                // not need the received sums
+                // not need the received sums.  (Round 5, 256 x 512, per pass: with these accesses AFTER the wait 2 240 us, here 1 922, without the
+                // stores 1 726, without any of them 1 177.  What they cost is not their count (16-byte staged accesses: - 2 %) and no longer the
+                // L2 (non-temporal: - 13 %); the working hypothesis is the in-order vector-memory queue: an HBM load that is still out when the
+                // next step's sixty granule stores are issued holds the queue's head, and the later it is issued the likelier that is.)
                 if constexpr (WIDE) flush_wide(t + 1);
                 else flush();
                 fetch(t - 2, PAR);
