@@ -618,3 +618,76 @@ def test_pool16m_lane_level_index_model():
     got, ref = sim.kernel(x, W1, b1, W2, amax, d, dtu, q), sim.reference(x, W1, b1, W2, amax, d, dtu, q)
     for name, a, b in zip(('dW2', 'part1', 'db2'), got, ref):
         assert np.abs(a - b).max() / np.abs(b).max() < 1e-12, name
+
+
+def _x3_lrow(p):
+    # csrc/gemm_x3.hip X3Loader::lrow: the tile row a thread slot stages
+    m = p >> 2
+    return 8 * (m >> 1) + (m & 1) + 2 * (p & 3)
+
+
+@pytest.mark.parametrize('slots,lanes_per_slot,dwords_per_lane', [(128, 2, 4), (64, 4, 2)])
+def test_gemm_x3_store_rows_tile_the_lds_banks(slots, lanes_per_slot, dwords_per_lane):
+    # csrc/gemm_x3.hip (round 5): the row-major operand images have 48-byte rows (12 dwords: conflict-free fragment READS); a
+    # ds_write_b128 / ds_write_b64 is serviced in contiguous groups of 8 / 16 lanes = four row slots over 32 banks.  Four CONSECUTIVE rows
+    # put rows 0 and 3 on the same banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE was 0.32); lrow() makes every group's rows tile the banks.
+    rows = [_x3_lrow(p) for p in range(slots)]
+    assert sorted(rows) == list(range(slots))                      # every row staged exactly once
+    for g0 in range(0, slots, 4):                                  # one lane group = four consecutive slots
+        banks = []
+        for p in range(g0, g0 + 4):
+            for lane in range(lanes_per_slot):
+                a = _x3_lrow(p) * 12 + lane * dwords_per_lane      # dword address of the lane's store inside the plane
+                banks += [(a + i) % 32 for i in range(dwords_per_lane)]
+        assert sorted(banks) == list(range(32)), (g0, sorted(banks))
+    consecutive = [(p * 12 + i) % 32 for p in range(4) for i in range(8)]
+    assert len(set(consecutive)) < 32                               # what the kernel did before: rows 0 and 3 collide
+
+
+def _x3_decode(block, it, grid, mt, nt, splits):
+    # csrc/gemm_x3.hip gemm_x3_kernel::decode: work item `it` of workgroup `block` -> (m tile, n tile, split), or None
+    n_items = mt * nt * splits
+    z_map = splits >= 8 and splits % 8 == 0 and grid % 8 == 0
+    xcd_map = (not z_map) and mt % 8 == 0 and grid % 8 == 0
+    if z_map:
+        per, wi = n_items >> 3, it * (grid >> 3) + (block >> 3)
+        if wi >= per:
+            return None
+        tiles = mt * nt
+        zl, t = divmod(wi, tiles)
+        return t // nt, t % nt, zl * 8 + (block & 7)
+    if xcd_map:
+        per, wi = n_items >> 3, it * (grid >> 3) + (block >> 3)
+        if wi >= per:
+            return None
+        per_m = nt * splits
+        ml, rest = divmod(wi, per_m)
+        return ml * 8 + (block & 7), rest % nt, rest // nt
+    w = it * grid + block
+    if w >= n_items:
+        return None
+    z, t = divmod(w, mt * nt)
+    return t // nt, t % nt, z
+
+
+@pytest.mark.parametrize('mt,nt,splits', [(8, 4, 24), (2, 7, 48), (2, 2, 128), (16, 8, 6), (512, 8, 1), (1024, 16, 1), (3, 5, 9), (8, 1, 8)])
+def test_gemm_x3_work_items_are_covered_once_and_splits_stay_in_one_xcd(mt, nt, splits):
+    # every (m tile, n tile, split) exactly once whatever the mapping; with a multiple of 8 splits (round 5, the weight gradients) all
+    # tiles of a split run on workgroups of ONE XCD (blockIdx & 7), so both operands of its K range are fetched from HBM once
+    n_items = mt * nt * splits
+    grid = min(n_items, 768)
+    seen, xcd_of_split = {}, {}
+    for block in range(grid):
+        it = 0
+        while True:
+            d = _x3_decode(block, it, grid, mt, nt, splits)
+            if d is None:
+                break
+            assert d not in seen, d
+            assert 0 <= d[0] < mt and 0 <= d[1] < nt and 0 <= d[2] < splits
+            seen[d] = block
+            xcd_of_split.setdefault(d[2], set()).add(block & 7)
+            it += 1
+    assert len(seen) == n_items
+    if splits >= 8 and splits % 8 == 0 and grid % 8 == 0:
+        assert all(len(x) == 1 for x in xcd_of_split.values())
