@@ -753,8 +753,8 @@ __global__ __launch_bounds__(T5_THREADS, 1) void lstm512_team_bwd_kernel(RnnStep
                 // ... meanwhile: the previous step's stores, the operand fetch for two steps ahead, and everything of the cells that does
                 // not need the received sums.  (Round 5, 256 x 512, per pass: with these accesses AFTER the wait 2 240 us, here 1 922, without the
                 // stores 1 726, without any of them 1 177.  What they cost is not their count (16-byte staged accesses: - 2 %) and no longer the
-                // L2 (non-temporal: - 13 %); the working hypothesis is the in-order vector-memory queue: an HBM load that is still out when the
-                // next step's sixty granule stores are issued holds the queue's head, and the later it is issued the likelier that is.)
+                // L2 (non-temporal: - 13 %); cause unknown.  Also tried: fetching for a PAIR of steps in its first step, none in its second: 1 898 - within noise, so it is
+                // not an HBM load holding the in-order queue's head while a step's sixty granule stores are issued.)
                 if constexpr (WIDE) flush_wide(t + 1);
                 else flush();
                 fetch(t - 2, PAR);
