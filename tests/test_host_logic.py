@@ -691,3 +691,43 @@ def test_gemm_x3_work_items_are_covered_once_and_splits_stay_in_one_xcd(mt, nt, 
     assert len(seen) == n_items
     if splits >= 8 and splits % 8 == 0 and grid % 8 == 0:
         assert all(len(x) == 1 for x in xcd_of_split.values())
+
+
+def test_lstm512_backward_wide_access_chunk_maps():
+    # csrc/rnn_team512.hip (round 5, WIDE): a member moves its share of a step - 16 sequences x 32 units - between HBM rows and LDS images in
+    # 16-byte chunks: chunk tid of the gates / dgx image = (sequence tid >> 4, gate (tid >> 2) & 3, units 8 (tid & 3) ..), chunk cf = tid & 127
+    # of an f32 image = (sequence cf >> 3, units 4 (cf & 7) ..).  Every element exactly once, where the cells look for it.
+    H, US, member = 512, 32, 5
+    U0 = US * member
+    GROW = (4 * US * 2 + 16) // 2                    # T5_GROW in bf16 elements: the gate-gradient tile's row pitch
+    image = {}                                       # gates image: element index -> (sequence, column of the [4H] row)
+    for tid in range(256):
+        s, g, c = tid >> 4, (tid >> 2) & 3, tid & 3
+        gcol = g * H + U0 + 8 * c
+        for j in range(8):
+            assert tid * 8 + j not in image
+            image[tid * 8 + j] = (s, gcol + j)
+    for s in range(16):                              # what a cell (sequence s, unit u) reads for gate g
+        for u in range(US):
+            for g in range(4):
+                e = s * US + u
+                assert image[e + (3 * s + g) * US] == (s, g * H + U0 + u)
+    assert len(image) == 16 * 4 * US
+    tile = {}                                        # dgx: the LDS tile the next product reads -> the dgx row
+    for tid in range(256):
+        s, g, c = tid >> 4, (tid >> 2) & 3, tid & 3
+        src = s * GROW + g * US + 8 * c              # bf16 element offset inside the tile
+        for j in range(8):
+            tile[(s, src + j - s * GROW)] = g * H + U0 + 8 * c + j
+    for s in range(16):
+        for g in range(4):
+            for u in range(US):
+                assert tile[(s, g * US + u)] == g * H + U0 + u      # the cells wrote d4[g] of (s, u) at column g * 32 + u of row s
+    f32 = {}
+    for cf in range(128):
+        s, c = cf >> 3, cf & 7
+        for j in range(4):
+            f32[cf * 4 + j] = (s, U0 + 4 * c + j)
+    for s in range(16):
+        for u in range(US):
+            assert f32[s * US + u] == (s, U0 + u)
