@@ -549,7 +549,12 @@ __global__ __launch_bounds__(256, 2) void embed_bwd_dw1_kernel(const float* __re
             const int r = e / 12, f = e - r * 12;
             xs[e] = ef_record(obs, t, row0 + r - ty.row_begin[t], ty.nr_valid)[f];
         }
-        LA::issue(ga, offa, stage, wave);
+        // d(emb) is read once; W2 of the type by every tile: as ordinary loads the 268 MB stream pushed W2 out of the L2 between two tiles
+        // (FETCH_SIZE: 654 MB per launch = d(emb) + records + 64 KB of W2 PER TILE) - hence non-temporal (DC_DW1_NT=0: ordinary, A/B)
+#ifndef DC_DW1_NT
+#define DC_DW1_NT 2
+#endif
+        LA::template issue<DC_DW1_NT>(ga, offa, stage, wave);
         LB::issue(gb, offb, stage + 4096, wave);
         __syncthreads();
 
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void embed_bwd_dw1_kernel(const float* __re
             float* cur = stage + (kt & 1) * STAGE_FL;
             if (kt < 3) {
                 float* nxt = stage + ((kt + 1) & 1) * STAGE_FL;
-                LA::issue(ga + (kt + 1) * GEMM_BK, offa, nxt, wave);
+                LA::template issue<DC_DW1_NT>(ga + (kt + 1) * GEMM_BK, offa, nxt, wave);
                 LB::issue(gb + (size_t)(kt + 1) * GEMM_BK * EF_EMB, offb, nxt + 4096, wave);
             }
             if constexpr (F16) mma_kstep_h<LA, LB, 2, 2, true, true>(cur, cur + 4096, wm * 64, wn * 64, fr, fq, acc, s_grad, s_w);

@@ -39,11 +39,13 @@ struct FastTile {
             }
         }
     }
+    // AUX: cache policy of the DMA (2 = non-temporal: an operand that is read once and would otherwise push a re-read one out of the L2)
+    template <int AUX = 0>
     static __device__ __forceinline__ void issue(const float* __restrict__ origin, const size_t (&off)[NI],
                                                  float* __restrict__ S, int wave) {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(origin + off[i]), (lptr_t)(S + (wave * NI + i) * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(origin + off[i]), (lptr_t)(S + (wave * NI + i) * 256), 16, 0, AUX);
     }
     // the four k values (8j+4q+e, e = 0..3) of row r for this lane
     static __device__ __forceinline__ float4 frag(const float* __restrict__ S, int r, int j, int q) {
