@@ -110,3 +110,29 @@ def test_secondary_checkers_read_the_committed_fixtures():
     rep = bench.parity_report(sub, r2, 3e-2, 0.97)
     assert not rep['ok'] and 'returns' not in rep['per_quantity']       # zeros are not the oracle's outputs
     assert bench.SECONDARY_STEPS == 10
+
+
+def test_committed_driver_line_carries_the_contract_keys():
+    # the line the driver's command printed at the final HEAD (profiles/r05/v14_bench.json, one MI355X): every key of the bench contract, the
+    # two extra objects, the secondary workloads with their parity verdicts, and a roofline priced against a throughput peak
+    import json
+    path = os.path.join(REPO, 'profiles', 'r05', 'v14_bench.json')
+    line = json.loads([l for l in open(path) if l.startswith('{')][0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+              'config', 'roofline', 'cpu_baseline', 'parity', 'secondary', 'products_fallback'):
+        assert k in line, k
+    assert line['n_gpus'] == 1 and line['steps'] == 20 and line['warmup'] == 5 and line['higher_is_better'] is True and line['vs_baseline'] is None
+    assert 'workload' in line['config'] and 'model' not in line['config']
+    assert abs(line['value'] - 256 * 256 / (line['ms_per_step'] * 1e-3)) / line['value'] < 1e-3
+    r = line['roofline']
+    assert r['bound'] in ('mfma', 'hbm', 'valu') and 0 < r['frac'] < 1 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    assert r['traffic'] is not None and r['whole_step']['hbm_traffic_bytes'] < 40e9          # <= 40 GB per step
+    if 'largest_region' in r:                                                               # a latency-bound recurrence may lead by a hair
+        assert r['largest_region']['bound'] == 'latency' and r['largest_region']['ms_per_step'] >= r['largest_region']['priced_region_ms_per_step']
+    c = line['cpu_baseline']
+    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
+    assert line['parity']['ok'] is True and line['parity']['parity_rel_err'] < 1e-4
+    assert set(line['secondary']) >= {'configs[1]', 'reference_gru256_64x256', 'reference_defaults_gru256_s16_ragged', 'configs[4]_shard_bf16'}
+    for k, v in line['secondary'].items():
+        assert v['parity']['ok'] is True, k
+    assert line['products_fallback']['parity']['ok'] is True
