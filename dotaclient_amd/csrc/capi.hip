@@ -79,6 +79,7 @@ int dc_gemm_x3(const float* A, const float* B, float* C, int M, int N, int K, in
     // (DC_GEMM_PREC_F16X2(la, lb), include/dotaclient_hip.h) - what policy.hip passes for activations (2^4), weights (2^8), gradients
     const int form = prec & 0xff;
     g.accumulate = accumulate; g.prec = form == 1 ? 1 : (form == 4 ? 4 : 6);
+    g.tile128 = (prec >> 24) & 1;
     if (g.prec == 4) {
         g.sa = ldexpf(1.f, (int)(int8_t)((prec >> 8) & 0xff));
         g.sb = ldexpf(1.f, (int)(int8_t)((prec >> 16) & 0xff));

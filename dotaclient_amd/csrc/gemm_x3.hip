@@ -602,6 +602,7 @@ int gemm_x3(const X3Gemm& g, hipStream_t stream) {
     const char* name = g.a_mode == X3_KMAJ ? "gemm_f32_dW(TN,split-K)" : (g.transposed_w ? "gemm_f32_dX(NN)" : "gemm_f32_fwd(NT)");
     ProfScope prof(name, 2.0 * g.M * (double)g.N * g.K,
                    (g.a_bf16 ? 2.0 : 4.0) * g.M * g.K + (g.b_bf16 || g.b_mode == X3_PLANES ? 2.0 : 4.0) * g.N * g.K + (g.c_bf16 ? 2.0 : 4.0) * g.M * g.N, stream);
+    if (!g.tile128 && gemm_x3s_eligible(g)) return gemm_x3s(g, stream);      // x W^T / dy W in f16x2 mode: the row-streaming kernel (gemm_x3s.hip)
     int rc;
     if (a_mode == X3_PLANES && b_mode == X3_PLANES) rc = launch_x3<1, X3_PLANES, X3_PLANES>(a, splits, stream);
     else if (a_mode == X3_KMAJ16 && b_mode == X3_KMAJ) rc = launch_x3<1, X3_KMAJ16, X3_KMAJ>(a, splits, stream);

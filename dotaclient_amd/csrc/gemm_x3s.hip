@@ -1,0 +1,434 @@
+// Row-streaming form of the f16x2 dense products x W^T / dy W (round 6): the default kernel for the activations-times-weights
+// products of /root/reference/policy.py:54-75,138-155 (affine_pre_rnn, the recurrent input projection, the head block) and of their
+// input gradients (torch autograd at /root/reference/optimizer.py:672) whenever the shape fills the chip; gemm_x3.hip's 128 x 128
+// split-on-load kernel keeps the weight gradients, the bf16 mode, the bf16x3 fallback and the small shapes.
+//
+// Why another kernel.  gemm_x3.hip (PREC 4) sits at 0.23-0.27 of the three-MFMA ceiling with its matrix pipes ~30 % busy: per K = 16 step
+// a workgroup stages both operands through registers (split VALU + ds_write at ~80 B/clk) and meets at a barrier after only twelve MFMAs
+// per wave; LDS stores, LDS reads, VALU and MFMA each take about as long as the others and do not overlap (profiles/r05/
+// gemm_x3_ablation.txt).  This kernel removes the LDS stores and the register staging altogether and does twice the MFMAs per barrier:
+//   * BOTH operands go global -> LDS by DMA (global_load_lds_dwordx4: no VGPRs, no ds_write): the activations as the f32 they are in HBM
+//     (FastTile's lane-linear [row][32 k] image, XOR-swizzled on the source side), the weights as their pre-split f16 planes
+//     (PlaneTile<128, 2>);
+//   * the eight waves of a workgroup split the 256 ROWS of its tile and each takes all 128 columns: an activation element is read from
+//     LDS, scaled and split into its two f16 pieces by exactly ONE wave (16 elements per lane and stage), in registers, right before the
+//     MFMAs that consume it - the weight fragments need no arithmetic at all;
+//   * three LDS stages of 48 KB (K = 32 each), DMA two stages ahead, ONE raw s_barrier per stage with a COUNTED vmcnt (the DMA of the
+//     stage after next stays in flight across the barrier), 24 MFMAs per wave and barrier;
+//   * the MFMA operands are swapped (D = W_tile x_tile^T): a lane then holds FOUR CONSECUTIVE output columns of one output row in four
+//     consecutive accumulator registers - the epilogue is bias / relu / mask on registers and 16-byte stores, no LDS round trip, so
+//     the next item's first two stages are already in flight while the tile is written;
+//   * persistent workgroups (one per CU: 144 KB of LDS, two waves per SIMD) walk the (row tile, column tile) items of an XCD in
+//     row-tile order, so the column tiles of a row tile meet in that XCD's L2.
+// Arithmetic is gemm_x3.hip's PREC 4 exactly: x sa = h + m (two f16 pieces), a b = (hh + hm + mh) / (sa sb), f32 accumulate.
+#include <cstdio>
+#include "kernels.h"
+#include "gemm_tiles.h"
+
+#ifndef X3S_TIMING
+#define X3S_TIMING 0      // developer build: s_memtime stamps of (workgroup 0, wave 0), summed per phase; a blocking read-back and a line on stderr per launch
+#endif
+
+namespace dc {
+namespace {
+
+enum { SB_M = 256, SB_N = 128, SB_K = 32, SB_WAVES = 8, SB_THREADS = 512, SB_NST = 3 };
+enum { SA_BYTES = SB_M * SB_K * 4 /* 32768 */, SPLANE_BYTES = SB_N * SB_K * 2 /* 8192 */, SB_BYTES = 2 * SPLANE_BYTES,
+       SSTAGE_BYTES = SA_BYTES + SB_BYTES /* 49152 */, X3S_LDS = SB_NST * SSTAGE_BYTES /* 147456 */ };
+enum { SA_PIECES = SA_BYTES / 1024 / SB_WAVES /* 4 */, SB_PIECES = SB_BYTES / 1024 / SB_WAVES /* 2 */, S_DMA = SA_PIECES + SB_PIECES /* 6 per lane and stage */ };
+
+struct X3SArgs {
+    const float* A; const uint16_t* B;
+    float* C; const float* bias; const float* aux;
+    long long b_plane;
+    int M, N, K, lda, ldb, ldc, ldaux, relu, nbias;
+    float sa, inv;
+    long long* dbg;
+};
+
+// (row tile, column tile) of the n-th item this workgroup takes; false past the end.  With a multiple of 8 row tiles XCD x (blockIdx & 7
+// under the usual round-robin placement - a speed hint only) owns the row tiles x, x + 8, ...; its workgroups walk that list in row-tile
+// order, `run` consecutive items each (run = the column tiles of a row tile when there are at most two: both tiles of a row tile then
+// run on one CU back to back - that also balances the 128 + 32 column split of the head block).
+struct ItemMap {
+    int mt, nt, n_items, run, xcd;
+    __device__ __forceinline__ bool decode(int n, int& m_blk, int& n_blk) const {
+        const int r = n / run, i = n - r * run;
+        if (xcd) {
+            const int per = n_items >> 3;
+            const int li = (r * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3)) * run + i;
+            if (li >= per) return false;
+            const int ml = li / nt;
+            m_blk = (ml * 8 + (int)(blockIdx.x & 7)) * SB_M; n_blk = (li - ml * nt) * SB_N;
+            return true;
+        }
+        const int w = (r * (int)gridDim.x + (int)blockIdx.x) * run + i;
+        if (w >= n_items) return false;
+        const int ml = w / nt;
+        m_blk = ml * SB_M; n_blk = (w - ml * nt) * SB_N;
+        return true;
+    }
+};
+
+// One stage's six DMA pieces of this wave (4 KB of the activation image, 2 KB of the weight planes) as ONE asm statement: hipcc must not
+// know that these are LDS writes - it would drain the whole DMA queue (vmcnt(0)) in front of the next ds_read, whatever buffer that read
+// touches (seen in the .s of the builtin form of this kernel) - so the counting is done by hand below (cdna_hip_programming.md 5.7).
+// Source = 64-bit scalar base (advanced per stage on the SALU) + this lane's 32-bit byte offset (constant per item); M0 = LDS base of
+// the piece, lane l lands at M0 + 16 l.
+__device__ __forceinline__ void dma_stage(const float* a_base, const uint16_t* b_base, const unsigned (&ao)[SA_PIECES], const unsigned (&bo)[SB_PIECES],
+                                          unsigned lds_a, unsigned lds_b) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %9\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %7\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %7\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %7\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, %7\n\t"
+        "s_mov_b32 m0, %10\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %5, %8\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %6, %8\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(ao[0]), "v"(ao[1]), "v"(ao[2]), "v"(ao[3]), "v"(bo[0]), "v"(bo[1]), "s"(a_base), "s"(b_base), "s"(lds_a), "s"(lds_b)
+        : "memory", "scc");
+}
+// One piece, issued BETWEEN the MFMA groups of a stage.  All eight waves issuing their six pieces together right behind the barrier block for
+// ~1 000 cycles each - 48 wave-instructions of 1 KB through a 64 B/clk address path - with the matrix pipes idle, and reach the next
+// barrier ~1 000 cycles apart (phase clocks of the first version: DMA issue 800-1 200, barrier 900-1 400 of ~4 100 cycles per stage); one
+// piece per four MFMAs keeps the address path at half load and the waves in step.  `pin` (an accumulator, untouched) orders the statement
+// between the MFMA that last wrote it and the one that reads it next: hipcc moves register-only instructions across an asm otherwise.
+__device__ __forceinline__ void dma_piece(const void* base, unsigned voff, unsigned lds, f32x16& pin) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %3\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "+v"(pin)
+        : "v"(voff), "s"(base), "s"(lds)
+        : "memory");
+}
+static_assert(SA_PIECES == 4 && SB_PIECES == 2, "dma_stage is written for 4 + 2 pieces per wave");
+
+// PARTIAL: N is not a multiple of 128 - the last column tile multiplies only its live 32-column blocks
+template <bool PARTIAL>
+__global__ __launch_bounds__(SB_THREADS, 2) void gemm_x3s_kernel(X3SArgs p, ItemMap im) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fg = lane >> 5;
+    const int nk = p.K / SB_K;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
+
+    // ---- DMA side: a stream of stages (item, k step) that runs two stages ahead of the MFMAs ----------------------------------------
+    // A piece n = wave * 4 + i: tile rows 8 n .. 8 n + 7, lane = (row & 7) * 8 + slot; slot holds k chunk slot ^ ((row >> 1) & 7)
+    // B piece n = wave * 2 + i: plane n >> 3, tile rows 16 (n & 7) .. + 15, lane = (row & 15) * 4 + slot; chunk slot ^ ((row >> 2) & 3)
+    unsigned a_voff[SA_PIECES], b_voff[SB_PIECES];      // byte offsets of this lane's pieces from A / B at k = 0 (per item)
+    int d_item = 0, d_kt = 0;                           // next stage to issue
+    bool d_on;
+    auto d_open = [&]() {
+        int m_blk, n_blk;
+        d_on = im.decode(d_item, m_blk, n_blk);
+        if (!d_on) return;
+#pragma unroll
+        for (int i = 0; i < SA_PIECES; ++i) {
+            const int row = (wave * SA_PIECES + i) * 8 + (lane >> 3);
+            const int rg = min(m_blk + row, p.M - 1);      // rows past M re-read the last one (never stored)
+            a_voff[i] = ((unsigned)rg * (unsigned)p.lda + 4u * ((lane & 7) ^ ((row >> 1) & 7))) * 4u;
+        }
+#pragma unroll
+        for (int i = 0; i < SB_PIECES; ++i) {
+            const int n = wave * SB_PIECES + i;
+            const int row = (n & 7) * 16 + (lane >> 2);
+            const int rg = min(n_blk + row, p.N - 1);      // columns past N likewise
+            b_voff[i] = (unsigned)((n >> 3) * p.b_plane * 2) + ((unsigned)rg * (unsigned)p.ldb + 8u * ((lane & 3) ^ ((row >> 2) & 3))) * 2u;
+        }
+    };
+    auto d_issue = [&](int buf) {        // one stage into LDS buffer `buf`; advances the stream
+        const unsigned st = lds0 + (unsigned)buf * SSTAGE_BYTES;
+#ifndef X3S_NO_DMA           // ablation build: timing only
+        dma_stage(p.A + d_kt * SB_K, p.B + d_kt * SB_K, a_voff, b_voff, st + wave * (SA_PIECES * 1024), st + SA_BYTES + wave * (SB_PIECES * 1024));
+#endif
+        if (++d_kt == nk) { d_kt = 0; ++d_item; d_open(); }
+    };
+
+    // ---- MFMA side ---------------------------------------------------------------------------------------------------------------------
+    // activation fragment of sub-step s: row 32 wave + fr, k = 16 s + 8 fg .. + 7 = k chunks 4 s + 2 fg, + 1 (two float4);
+    // weight fragment of block j, plane pl: row 32 j + fr, chunk (2 s + fg) ^ ((fr >> 2) & 3)
+    int a_off[2][2], b_off[2];
+    {
+        const int r = wave * 32 + fr, sw = (r >> 1) & 7;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) a_off[s][e] = r * 128 + 16 * ((4 * s + 2 * fg + e) ^ sw);
+            b_off[s] = SA_BYTES + fr * 64 + 16 * ((2 * s + fg) ^ ((fr >> 2) & 3));
+        }
+    }
+
+    int m_blk, n_blk;
+    if (!im.decode(0, m_blk, n_blk)) return;
+    d_open();
+    d_issue(0);
+    {
+        const bool second = d_on;        // a second stage exists (K > 32 or another item)
+        if (second) d_issue(1);
+        // stage 0 has landed (this wave's pieces; the barrier makes it everybody's)
+        if (second) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_DMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    long long tm[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+    const bool timing = X3S_TIMING && p.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+    auto stamp = [&](int k) {
+        if (X3S_TIMING && timing) { const long long now = (long long)__builtin_amdgcn_s_memtime(); tm[k] += now - tlast; tlast = now; }
+    };
+    if (X3S_TIMING && timing) tlast = (long long)__builtin_amdgcn_s_memtime();
+    int buf = 0;
+    f32x16 acc[4];
+    int nj = 4;
+    // One stage: the MFMAs of LDS buffer `buf`; inside an item (LAST = false) the six DMA pieces of the stage after next go out one
+    // behind each MFMA group, into the buffer the previous stage vacated (every wave passed that stage's closing barrier).
+    auto compute = [&](bool spread) {
+        const unsigned nst = lds0 + (unsigned)(buf >= 1 ? buf - 1 : SB_NST - 1) * SSTAGE_BYTES;
+        const float* da = p.A + d_kt * SB_K;
+        const uint16_t* db = p.B + d_kt * SB_K;
+        auto piece = [&](int i, f32x16& pin) {
+            if (!spread) return;
+#ifndef X3S_NO_DMA
+            if (i < SA_PIECES) dma_piece(da, a_voff[i], nst + (wave * SA_PIECES + i) * 1024, pin);
+            else dma_piece(db, b_voff[i - SA_PIECES], nst + SA_BYTES + (wave * SB_PIECES + i - SA_PIECES) * 1024, pin);
+#endif
+        };
+        const char* st = smem + buf * SSTAGE_BYTES;
+#ifndef X3S_NO_MFMA          // ablation build: timing only
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float4 x0 = *reinterpret_cast<const float4*>(st + a_off[s][0]);
+            const float4 x1 = *reinterpret_cast<const float4*>(st + a_off[s][1]);
+            f16x8 wh[4], wm[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                wh[j] = *reinterpret_cast<const f16x8*>(st + b_off[s] + j * 2048);
+                wm[j] = *reinterpret_cast<const f16x8*>(st + b_off[s] + j * 2048 + SPLANE_BYTES);
+            }
+            const Split2h a = split2h<true>(x0, x1, p.sa);
+            // piece-major, smallest terms first: the four accumulators take turns
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (!PARTIAL || j < nj) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm[j], a.h, acc[j], 0, 0, 0);
+            piece(3 * s + 0, acc[0]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (!PARTIAL || j < nj) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], a.m, acc[j], 0, 0, 0);
+            piece(3 * s + 1, acc[0]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (!PARTIAL || j < nj) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], a.h, acc[j], 0, 0, 0);
+            piece(3 * s + 2, acc[0]);
+        }
+#else
+#pragma unroll
+        for (int i = 0; i < S_DMA; ++i) piece(i, acc[0]);
+#endif
+        if (spread && ++d_kt == nk) { d_kt = 0; ++d_item; d_open(); }      // the stream moves on (as d_issue does)
+    };
+    auto close_stage = [&]() {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stamp(5);      // barrier
+        buf = buf == SB_NST - 1 ? 0 : buf + 1;
+    };
+
+    for (int c_item = 0;; ++c_item) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        nj = PARTIAL ? min(4, (p.N - n_blk + 31) >> 5) : 4;
+
+        // ---- the item's stages but the last -------------------------------------------------------------------------------------------
+        for (int kt = 0; kt < nk - 1; ++kt) {
+            const bool ahead = d_on;
+            stamp(0);      // loop control
+            compute(ahead);
+            stamp(2);      // fragment reads, split, MFMAs (+ the spread DMA pieces)
+            // the next stage (issued one iteration ago) has landed: at most the stage just issued may still be in flight.  (The first wait
+            // of an item also covers the previous item's stores: "at most S_DMA operations outstanding" with the S_DMA youngest being
+            // loads, which return in order, means everything older is done.)
+            if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_DMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(4);      // wait for the next stage's DMA
+            close_stage();
+        }
+
+        // ---- the last stage and the epilogue -------------------------------------------------------------------------------------------
+        {
+            const bool ahead = d_on;
+            stamp(0);
+            compute(false);
+            stamp(2);
+            // the bias values of this lane's 4 x 4 float4 (whole-tile shapes: every column has a bias and the vector is 16-byte aligned -
+            // gemm_x3s_eligible; the PARTIAL form loads them below, guarded).  Issued HERE, consumed right below: fetched under the last
+            // stage's MFMAs they left a load pending across the loop in hipcc's bookkeeping, and it answered with a vmcnt(0) in the K
+            // loop's header (tools/x3s_isa_check.py) - one L2 round trip per item is the cheaper evil.
+            float4 bv[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!PARTIAL && p.bias != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const float4*>(p.bias + n_blk + fg * 4 + j * 32 + q * 8);
+            }
+            // nothing but the next stage's DMA (and the bias loads) is in flight here: wait for it now, start the stage after next, and only
+            // then store - the stores are never waited for inside this item
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(4);
+            if (ahead) d_issue(buf >= 1 ? buf - 1 : SB_NST - 1);
+            // ---- epilogue from the registers: D[n][m] of the 32x32 MFMA has col = lane & 31 (an output ROW here), row = (reg & 3) +
+            // 8 (reg >> 2) + 4 (lane >> 5): registers 4 q .. 4 q + 3 are output columns n0 + 8 q + 4 fg .. + 3 of row m
+            int fge = fg;
+            asm volatile("" : "+v"(fge));      // (opaque here: keeps the per-column predicates below out of the K loop's live ranges)
+            // (rows past M compute on a clamped row and skip only the store itself: every load below is consumed on every path - a load
+            //  whose use a lane-divergent branch skips stays "pending" in hipcc's bookkeeping and drew a vmcnt(0) into the K loop's header)
+            const int row = m_blk + wave * 32 + fr;
+            const bool row_ok = row < p.M;
+            const int rowc = min(row, p.M - 1);
+            float* crow = p.C + (size_t)rowc * p.ldc;
+            const float* xrow = p.aux != nullptr ? p.aux + (size_t)rowc * p.ldaux : nullptr;
+#pragma unroll
+            for (int jh = 0; jh < 4; jh += 2) {
+                // two 32-column blocks at a time: their mask loads all in flight together (workgroup-uniform branches only), then the stores
+                float4 mv[2][4];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) mv[jj][q] = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (xrow != nullptr) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int col = n_blk + (jh + jj) * 32 + q * 8 + fge * 4;
+                            mv[jj][q] = *reinterpret_cast<const float4*>(xrow + (PARTIAL ? min(col, p.N - 4) : col));
+                        }
+                }
+                if (PARTIAL && p.bias != nullptr) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int col = n_blk + (jh + jj) * 32 + q * 8 + fge * 4;
+                            const int nb = p.nbias - 1;          // (clamped addresses, selected values: no load under a lane-divergent branch)
+                            const float b0 = p.bias[min(col, nb)], b1 = p.bias[min(col + 1, nb)], b2 = p.bias[min(col + 2, nb)], b3 = p.bias[min(col + 3, nb)];
+                            bv[jh + jj][q] = make_float4(col <= nb ? b0 : 0.f, col + 1 <= nb ? b1 : 0.f, col + 2 <= nb ? b2 : 0.f, col + 3 <= nb ? b3 : 0.f);
+                        }
+                }
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = jh + jj;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int col = n_blk + j * 32 + q * 8 + fge * 4;
+                        float4 v = make_float4(acc[j][4 * q] * p.inv + bv[j][q].x, acc[j][4 * q + 1] * p.inv + bv[j][q].y,
+                                               acc[j][4 * q + 2] * p.inv + bv[j][q].z, acc[j][4 * q + 3] * p.inv + bv[j][q].w);
+                        if (p.relu) { v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w); }      // NaN-propagating (common.h)
+                        v.x = mv[jj][q].x > 0.f ? v.x : 0.f; v.y = mv[jj][q].y > 0.f ? v.y : 0.f;
+                        v.z = mv[jj][q].z > 0.f ? v.z : 0.f; v.w = mv[jj][q].w > 0.f ? v.w : 0.f;
+#ifdef X3S_NO_STORE          // ablation build: timing only
+                        if (v.x == 12345.678f) *reinterpret_cast<float4*>(crow + col) = v;
+#else
+                        if (row_ok && (!PARTIAL || col < p.N)) *reinterpret_cast<float4*>(crow + col) = v;      // N % 4 == 0 (host check)
+#endif
+                    }
+                }
+            }
+            stamp(3);      // epilogue (+ its DMA issue)
+            close_stage();
+        }
+        if (!im.decode(c_item + 1, m_blk, n_blk)) break;
+    }
+    if (X3S_TIMING && timing) { for (int k = 0; k < 6; ++k) p.dbg[k] = tm[k]; }
+}
+
+}  // namespace
+
+// Shapes this kernel takes: whole K = 32 steps, 16-byte aligned rows, and enough (256 x 128) items to give every CU one.
+bool gemm_x3s_eligible(const X3Gemm& g) {
+    if (g.prec != 4 || g.a_mode != X3_ROW || g.b_mode != X3_PLANES) return false;
+    if (g.accumulate || g.C2 != nullptr || g.B2 != nullptr || g.n_split != 0 || g.a_colsum != nullptr) return false;
+    if (g.a_bf16 || g.b_bf16 || g.c_bf16 || g.aux_bf16) return false;
+    if (g.bias != nullptr && ((reinterpret_cast<uintptr_t>(g.bias) & 15) != 0 || (g.N % SB_N == 0 && g.nbias < g.N))) return false;      // the epilogue's bias loads
+    if (g.K < SB_K || g.K % SB_K || (g.N & 3) || (g.lda & 3) || (g.ldb & 7) || (g.ldc & 3) || (g.aux != nullptr && (g.ldaux & 3))) return false;
+    if ((long long)g.M * g.lda * 4 >= (1LL << 32) - (1 << 20) || 2 * g.b_plane * 2 + (long long)g.N * g.ldb * 2 >= (1LL << 32) - (1 << 20)) return false;      // 32-bit DMA offsets
+    const long items = (long)((g.M + SB_M - 1) / SB_M) * ((g.N + SB_N - 1) / SB_N);
+    return items >= 192;
+}
+
+int gemm_x3s(const X3Gemm& g, hipStream_t stream) {
+    static bool attr_done[2] = {false, false};
+    const bool partial = (g.N % SB_N) != 0;
+    if (!attr_done[partial]) {
+        hipError_t e = partial ? hipFuncSetAttribute((const void*)gemm_x3s_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3S_LDS)
+                               : hipFuncSetAttribute((const void*)gemm_x3s_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3S_LDS);
+        if (e != hipSuccess) { set_error("gemm_x3s: hipFuncSetAttribute", (int)e); return (int)e; }
+        attr_done[partial] = true;
+    }
+    X3SArgs a{};
+    a.A = static_cast<const float*>(g.A); a.B = static_cast<const uint16_t*>(g.B);
+    a.C = g.C; a.bias = g.bias; a.aux = g.aux; a.b_plane = g.b_plane;
+    a.M = g.M; a.N = g.N; a.K = g.K; a.lda = g.lda; a.ldb = g.ldb; a.ldc = g.ldc; a.ldaux = g.ldaux; a.relu = g.relu;
+    a.nbias = g.bias ? g.nbias : 0;
+    a.sa = g.sa; a.inv = 1.f / (g.sa * g.sb);
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    ItemMap im;
+    im.mt = (g.M + SB_M - 1) / SB_M; im.nt = (g.N + SB_N - 1) / SB_N;
+    im.n_items = im.mt * im.nt;
+    im.run = im.nt <= 2 ? im.nt : 1;
+    int grid = (im.n_items + im.run - 1) / im.run;
+    if (grid > cus) grid = cus;
+    im.xcd = ((im.mt & 7) == 0 && (grid & 7) == 0) ? 1 : 0;
+#if X3S_TIMING
+    static long long* dbg = nullptr;
+    if (!dbg) (void)hipMalloc(&dbg, 64);
+    (void)hipMemsetAsync(dbg, 0, 64, stream);
+    a.dbg = dbg;
+#endif
+    if (partial) hipLaunchKernelGGL(gemm_x3s_kernel<true>, dim3(grid), dim3(SB_THREADS), X3S_LDS, stream, a, im);
+    else hipLaunchKernelGGL(gemm_x3s_kernel<false>, dim3(grid), dim3(SB_THREADS), X3S_LDS, stream, a, im);
+#if X3S_TIMING
+    {
+        long long h[6];
+        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        const double items = (double)((im.n_items + grid - 1) / grid), stages = items * (g.K / SB_K);
+        fprintf(stderr, "gemm_x3s M %d N %d K %d items/wg %.0f stages/item %d | clocks per stage: loop %.0f  reads+split+mfma+dma issue %.0f  dma wait %.0f  barrier %.0f | per item: epilogue %.0f\n",
+                g.M, g.N, g.K, items, g.K / SB_K, h[0] / stages, h[2] / stages, h[4] / stages, h[5] / stages, h[3] / items);
+    }
+#endif
+    return launch_check("gemm_x3s");
+}
+
+}  // namespace dc

@@ -89,11 +89,16 @@ struct X3Gemm {
     // bf16 storage (prec 1; configs[4]): the operand / the output / the relu mask `aux` live in HBM as bf16 with the same shape and ld
     // (elements).  b_bf16: X3_KMAJ B only (a second B is bf16 as well); c_bf16: no accumulate, no C2, no split-K (no scratch).
     int a_bf16 = 0, b_bf16 = 0, c_bf16 = 0, aux_bf16 = 0;
+    int tile128 = 0;              // 1: keep the 128 x 128 split-on-load kernel where gemm_x3s.hip's row-streaming kernel would take the product (A/B, tests)
     float* a_colsum = nullptr;    // X3_KMAJ A only: a_colsum[m] += sum_k A[k][m] (the bias gradient that goes with a weight gradient),
                                   // summed while the tiles pass through the loader - no second pass over A
 };
 bool gemm_x3_shape_ok(int M, int N, int K, int lda, int ldb, int a_mode, int b_mode);
 int gemm_x3(const X3Gemm& g, hipStream_t stream);
+// gemm_x3s.hip: the row-streaming kernel for prec 4, X3_ROW x X3_PLANES (both operands by LDS-DMA, 256 x 128 tiles, epilogue from the
+// registers); gemm_x3 dispatches to it when the shape is eligible and tile128 is clear
+bool gemm_x3s_eligible(const X3Gemm& g);
+int gemm_x3s(const X3Gemm& g, hipStream_t stream);
 // weight matrices -> bf16 planes [prec == 1 ? 1 : 3][rows_pad (zero rows past `rows`)][cols], or of the transpose
 struct X3SplitJob { const float* src; uint16_t* dst; int rows, cols, ld, transpose, rows_pad; };
 int split_weight_planes(const X3SplitJob* jobs, int n, int prec, hipStream_t s, float scale = 1.f);   // prec 4: [2] f16 planes of w * scale

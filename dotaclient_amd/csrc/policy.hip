@@ -234,6 +234,7 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
         g.C = y; g.ldc = ldy; g.M = (int)NR; g.N = Npad; g.K = K; g.bias = bias; g.nbias = N; g.relu = relu; g.prec = prec;
         g.sa = F16X2_S_ACT; g.sb = F16X2_S_W;
         g.c_bf16 = y_bf16; g.a_bf16 = x_bf16;
+        g.tile128 = (d->flags & DC_DIMS_GEMM_TILE128) ? 1 : 0;
         return gemm_x3(g, s);
     };
     // pre-rnn projection (policy.py:138)
@@ -316,6 +317,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         g.C = dx; g.ldc = N; g.M = (int)NR; g.N = N; g.K = K; g.aux = aux; g.ldaux = N; g.prec = prec; g.transposed_w = 1;
         g.sa = s_grad; g.sb = F16X2_S_W;
         g.a_bf16 = dy_bf16; g.aux_bf16 = aux_bf16;
+        g.tile128 = (d->flags & DC_DIMS_GEMM_TILE128) ? 1 : 0;
         return gemm_x3(g, s);
     };
     // dW[M][N] += dy[rows][lda: M]^T x[rows][ldb: N] (contraction over the env-steps, split-K); optional second x behind N

@@ -59,10 +59,11 @@ def advantage_returns(rewards, values, gamma, lam):
     return adv, ret
 
 
-def prec_f16x2(log2_sa=0, log2_sb=0):
+def prec_f16x2(log2_sa=0, log2_sb=0, tile128=False):
     """`x3` value for the two-f16-piece products with power-of-two pre-scales 2^log2_sa / 2^log2_sb of the A / B operand
-    (DC_GEMM_PREC_F16X2, include/dotaclient_hip.h): what the network passes for activations (4), weights (8), gradients (ceil(log2 rows) + 2)."""
-    return 4 | ((log2_sa & 0xff) << 8) | ((log2_sb & 0xff) << 16)
+    (DC_GEMM_PREC_F16X2, include/dotaclient_hip.h): what the network passes for activations (4), weights (8), gradients (ceil(log2 rows) + 2).
+    tile128 (DC_GEMM_PREC_TILE128): keep x W^T / dy W on the 128 x 128 split-on-load kernel where the row-streaming kernel would run."""
+    return 4 | ((log2_sa & 0xff) << 8) | ((log2_sb & 0xff) << 16) | (int(tile128) << 24)
 
 
 def prec_bf16_store(a=False, b=False, c=False, aux=False):

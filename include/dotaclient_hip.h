@@ -78,6 +78,9 @@ int dc_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, i
  * matrix in the first two forms and is split into bf16 planes inside the call (into `scratch`, which must hold
  * 3 * N * K / 2 floats for it, plus splits * M * N for split-K).  K % 16 == 0, N % 4 == 0.  No relu/aux with split-K. */
 #define DC_GEMM_PREC_F16X2(la, lb) (4 | (((la) & 0xff) << 8) | (((lb) & 0xff) << 16))
+/* prec 4, x W^T / dy W: OR this in to keep the product on the 128 x 128 split-on-load kernel (default: the row-streaming kernel of
+ * csrc/gemm_x3s.hip whenever K % 32 == 0 and the shape has at least 192 tiles of 256 x 128). */
+#define DC_GEMM_PREC_TILE128 (1 << 24)
 /* prec 1 with operands / results STORED as bf16 (BASELINE.json configs[4]'s path keeps its gate buffers that way): a, b, c, aux = 1 when
  * A, B, C, aux point at bf16 elements of the same shape and ld (in elements).  b: the k-major form only; c: no accumulate, no split-K. */
 #define DC_GEMM_PREC_BF16_STORE(a, b, c, aux) (1 | ((a) << 8) | ((b) << 9) | ((c) << 10) | ((aux) << 11))
@@ -183,6 +186,10 @@ typedef struct dc_dims {
  *                            activated gates and the gate gradients are STORED as bf16 (round 5: csrc/policy.hip bf16_store()); this flag
  *                            keeps them f32 (A/B; the comparison with the launch-per-step kernels, whose buffers are f32). */
 #define DC_DIMS_BF16_F32_STORE 4194304
+/*   DC_DIMS_GEMM_TILE128   : with DC_DIMS_F16X2 the x W^T / dy W products run on the row-streaming kernel (csrc/gemm_x3s.hip, round 6: both
+ *                            operands by LDS-DMA, 256 x 128 tiles, eight waves that split the rows, epilogue from the registers); this flag
+ *                            keeps them on the 128 x 128 split-on-load kernel of csrc/gemm_x3.hip (A/B, and the parity test between the two). */
+#define DC_DIMS_GEMM_TILE128 8388608
 
 /* index into poff[]; policy.py:54-75 names in comments */
 enum dc_param_index {

@@ -178,6 +178,70 @@ def test_gemm_x3_layouts(prec, tol, akm, bkm, M, N, K):
         assert (C3.cpu().double() - (ref + 2)).abs().max() / ref.abs().max() < tol
 
 
+@pytest.mark.parametrize('bkm', [False, True])
+@pytest.mark.parametrize('M,N,K', [(65536, 256, 896), (49152, 1024, 256), (50000, 896, 256), (65536, 160, 256), (50001, 256, 160), (33000, 768, 32),
+                                   (25000, 1024, 1024), (24577, 288, 64)])
+def test_gemm_x3s_row_streaming_kernel(bkm, M, N, K):
+    # gemm_x3s.hip (round 6): the kernel the network's x W^T / dy W products take at bench-sized batches - both operands by LDS-DMA, 256 x 128
+    # tiles, eight waves that split the rows, epilogue from the registers.  Shapes of the network (pre-rnn, gates, d(xcat), heads, dH), row
+    # counts that are / are not a multiple of 8 x 256 (the XCD item map / the plain one), ragged last row tile, a column count that is not a
+    # multiple of 128 (the PARTIAL form), K = 32 (one stage per item) .. 1024, padded leading dimensions; bias, relu, mask.  Bar: 2e-6 of
+    # max |C| against f64 (the 128 x 128 kernel's), and the two kernels agree to 1e-6 (same pieces, same three MFMAs, another summation order)
+    from dotaclient_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + 3 * N + K + int(bkm))
+    lda, ldb, ldc = K + 4, (N if bkm else K) + 8, N + 4
+    A = torch.randn(M, lda, generator=g).to(dev)
+    B = (torch.randn((K if bkm else N), ldb, generator=g) / 16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    aux = torch.randn(M, N, generator=g).to(dev)
+    ref = A[:, :K].double() @ (B[:, :N] if bkm else B[:, :K].t()).double() + bias.double()
+    scale = ref.abs().max().item()
+    scratch = torch.empty(2 * N * K + 1024, device=dev)
+    outs = {}
+    for tile128 in (False, True):
+        prec = ops.prec_f16x2(4, 8, tile128=tile128)
+        C = torch.full((M, ldc), 7.0, device=dev)
+        ops.gemm(A, B, C, M, N, K, lda, ldb, ldc, False, bkm, bias=bias, scratch=scratch, x3=prec)
+        assert torch.all(C[:, N:] == 7.0), 'wrote outside the N columns'
+        assert ((C[:, :N].double() - ref).abs().max().item() / scale) < 2e-6
+        outs[tile128] = C[:, :N].clone()
+        C2 = torch.empty(M, N, device=dev)
+        ops.gemm(A, B, C2, M, N, K, lda, ldb, N, False, bkm, bias=bias, relu=True, scratch=scratch, x3=prec)
+        assert ((C2.double() - ref.clamp(min=0)).abs().max().item() / scale) < 2e-6
+        ops.gemm(A, B, C2, M, N, K, lda, ldb, N, False, bkm, bias=bias, aux=aux, ldaux=N, scratch=scratch, x3=prec)
+        assert ((C2.double() - ref * (aux > 0)).abs().max().item() / scale) < 2e-6
+        ops.gemm(A, B, C2, M, N, K, lda, ldb, N, False, bkm, scratch=scratch, x3=prec)          # no bias
+        assert ((C2.double() - (ref - bias.double())).abs().max().item() / scale) < 2e-6
+    assert ((outs[False] - outs[True]).abs().max().item() / scale) < 1e-6
+
+
+def test_gemm_x3s_repeated_launches_are_bit_identical():
+    # the DMA pipeline of gemm_x3s.hip is synchronised by hand (counted vmcnt + one barrier per stage): a race shows up as run-to-run
+    # differences.  Forty launches of the gates' product on fresh outputs, under a concurrent copy stream, must all be bit-identical.
+    from dotaclient_amd import ops
+    dev = _dev()
+    M, N, K = 65536, 1024, 256
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g).to(dev)
+    B = (torch.randn(N, K, generator=g) / 16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    scratch = torch.empty(2 * N * K + 1024, device=dev)
+    first = None
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, device=dev)
+    for it in range(40):
+        C = torch.full((M, N), float(it), device=dev)
+        with torch.cuda.stream(side):
+            junk.add_(1.0)                      # HBM traffic from another stream while the product runs
+        ops.gemm(A, B, C, M, N, K, K, K, N, False, False, bias=bias, scratch=scratch, x3=ops.prec_f16x2(4, 8))
+        if first is None:
+            first = C.clone()
+        else:
+            assert torch.equal(C, first), it
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize('form', ['x W^T', 'dy W', 'dy^T x', 'dy^T x (both stored)', 'dy^T x (B stored)'])
 @pytest.mark.parametrize('M,N,K', [(1000, 256, 896), (130, 72, 160), (2048, 768, 256), (152, 256, 8192), (33, 12, 16)])
 def test_gemm_x3_bf16_storage(form, M, N, K):
