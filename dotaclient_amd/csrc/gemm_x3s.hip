@@ -22,6 +22,7 @@
 //     row-tile order, so the column tiles of a row tile meet in that XCD's L2.
 // Arithmetic is gemm_x3.hip's PREC 4 exactly: x sa = h + m (two f16 pieces), a b = (hh + hm + mh) / (sa sb), f32 accumulate.
 #include <cstdio>
+#include <type_traits>
 #include "kernels.h"
 #include "gemm_tiles.h"
 
@@ -34,7 +35,7 @@ namespace {
 
 enum { SB_M = 256, SB_N = 128, SB_K = 32, SB_WAVES = 8, SB_THREADS = 512, SB_NST = 3 };
 enum { SA_BYTES = SB_M * SB_K * 4 /* 32768 */, SPLANE_BYTES = SB_N * SB_K * 2 /* 8192 */, SB_BYTES = 2 * SPLANE_BYTES,
-       SSTAGE_BYTES = SA_BYTES + SB_BYTES /* 49152 */, X3S_LDS = SB_NST * SSTAGE_BYTES /* 147456 */ };
+       SSTAGE_BYTES = SA_BYTES + SB_BYTES /* 49152 */, X3S_LDS = SB_NST * SSTAGE_BYTES + 4 * 4096 /* 163840 = all of a CU's LDS: three stages + the epilogue images */ };
 enum { SA_PIECES = SA_BYTES / 1024 / SB_WAVES /* 4 */, SB_PIECES = SB_BYTES / 1024 / SB_WAVES /* 2 */, S_DMA = SA_PIECES + SB_PIECES /* 6 per lane and stage */ };
 
 struct X3SArgs {
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void gemm_x3s_kernel(X3SArgs p, Item
     unsigned a_voff[SA_PIECES], b_voff[SB_PIECES];      // byte offsets of this lane's pieces from A / B at k = 0 (per item)
     int d_item = 0, d_kt = 0;                           // next stage to issue
     bool d_on;
-    auto d_open = [&]() {
+    auto d_open = [&]() __attribute__((always_inline)) {
         int m_blk, n_blk;
         d_on = im.decode(d_item, m_blk, n_blk);
         if (!d_on) return;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void gemm_x3s_kernel(X3SArgs p, Item
             b_voff[i] = (unsigned)((n >> 3) * p.b_plane * 2) + ((unsigned)rg * (unsigned)p.ldb + 8u * ((lane & 3) ^ ((row >> 2) & 3))) * 2u;
         }
     };
-    auto d_issue = [&](int buf) {        // one stage into LDS buffer `buf`; advances the stream
+    auto d_issue = [&](int buf) __attribute__((always_inline)) {        // one stage into LDS buffer `buf`; advances the stream
         const unsigned st = lds0 + (unsigned)buf * SSTAGE_BYTES;
 #ifndef X3S_NO_DMA           // ablation build: timing only
         dma_stage(p.A + d_kt * SB_K, p.B + d_kt * SB_K, a_voff, b_voff, st + wave * (SA_PIECES * 1024), st + SA_BYTES + wave * (SB_PIECES * 1024));
@@ -182,6 +183,11 @@ __global__ __launch_bounds__(SB_THREADS, 2) void gemm_x3s_kernel(X3SArgs p, Item
 
     int m_blk, n_blk;
     if (!im.decode(0, m_blk, n_blk)) return;
+    long long tm[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+    const bool timing = X3S_TIMING && p.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+    auto stamp = [&](int k) __attribute__((always_inline)) {
+        if (X3S_TIMING && timing) { const long long now = (long long)__builtin_amdgcn_s_memtime(); tm[k] += now - tlast; tlast = now; }
+    };
     d_open();
     d_issue(0);
     {
@@ -194,179 +200,186 @@ __global__ __launch_bounds__(SB_THREADS, 2) void gemm_x3s_kernel(X3SArgs p, Item
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    long long tm[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
-    const bool timing = X3S_TIMING && p.dbg != nullptr && blockIdx.x == 0 && tid == 0;
-    auto stamp = [&](int k) {
-        if (X3S_TIMING && timing) { const long long now = (long long)__builtin_amdgcn_s_memtime(); tm[k] += now - tlast; tlast = now; }
-    };
+    // ---- two wave groups half a stage apart ------------------------------------------------------------------------------------------
+    // A stage is two phases, each closed by a workgroup barrier: MEMORY (DMA pieces of the stage after next, fragment reads of this stage
+    // into registers, split) and MATRIX (24 MFMAs from registers).  Waves 4-7 take one extra barrier up front and none behind their last
+    // MATRIX phase: from then on a SIMD's two waves (w and w + 4) are always in OPPOSITE phases - the matrix pipe of a SIMD belongs to one
+    // wave while the other one issues its DMA and LDS reads.  (First form of this kernel, all eight waves in step: every wave blocked
+    // ~170 cycles per DMA piece behind the seven others' on the 64 B/clk address path with nobody left to issue MFMAs, ~3 700 cycles per
+    // stage for 1 536 of matrix work per SIMD.)
+    //   global phase p:        2t          2t + 1        2t + 2        2t + 3
+    //   waves 0-3 (G0):     MEMORY(t)    MATRIX(t)    MEMORY(t+1)   MATRIX(t+1)
+    //   waves 4-7 (G1):     MATRIX(t-1)  MEMORY(t)    MATRIX(t)     MEMORY(t+1)
+    // DMA(t + 2) goes out in MEMORY(t) into buffer (t + 2) % 3 = (t - 1) % 3, last read in phase 2t - 1 (G1's MEMORY(t - 1)): free.
+    // Stage t + 1 is first read in phase 2t + 2 (G0), so every piece of it must have landed before the barrier that closes phase 2t + 1:
+    //   G0 waits at the END of MATRIX(t) for "at most the S_DMA pieces of DMA(t + 2) in flight" (its DMA(t + 1) went out in phase 2t - 2);
+    //   G1 waits at the START of MEMORY(t) for everything (its DMA(t + 1) went out in phase 2t - 1 and nothing younger exists yet).
+    // Stores of an epilogue are older than the DMA that follows them in program order, so the same counts cover them.
+    const bool g1 = wave >= SB_WAVES / 2;
+    if (g1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
     if (X3S_TIMING && timing) tlast = (long long)__builtin_amdgcn_s_memtime();
+
     int buf = 0;
     f32x16 acc[4];
-    int nj = 4;
-    // One stage: the MFMAs of LDS buffer `buf`; inside an item (LAST = false) the six DMA pieces of the stage after next go out one
-    // behind each MFMA group, into the buffer the previous stage vacated (every wave passed that stage's closing barrier).
-    auto compute = [&](bool spread) {
-        const unsigned nst = lds0 + (unsigned)(buf >= 1 ? buf - 1 : SB_NST - 1) * SSTAGE_BYTES;
-        const float* da = p.A + d_kt * SB_K;
-        const uint16_t* db = p.B + d_kt * SB_K;
-        auto piece = [&](int i, f32x16& pin) {
-            if (!spread) return;
-#ifndef X3S_NO_DMA
-            if (i < SA_PIECES) dma_piece(da, a_voff[i], nst + (wave * SA_PIECES + i) * 1024, pin);
-            else dma_piece(db, b_voff[i - SA_PIECES], nst + SA_BYTES + (wave * SB_PIECES + i - SA_PIECES) * 1024, pin);
-#endif
-        };
-        const char* st = smem + buf * SSTAGE_BYTES;
-#ifndef X3S_NO_MFMA          // ablation build: timing only
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const float4 x0 = *reinterpret_cast<const float4*>(st + a_off[s][0]);
-            const float4 x1 = *reinterpret_cast<const float4*>(st + a_off[s][1]);
-            f16x8 wh[4], wm[4];
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                wh[j] = *reinterpret_cast<const f16x8*>(st + b_off[s] + j * 2048);
-                wm[j] = *reinterpret_cast<const f16x8*>(st + b_off[s] + j * 2048 + SPLANE_BYTES);
-            }
-            const Split2h a = split2h<true>(x0, x1, p.sa);
-            // piece-major, smallest terms first: the four accumulators take turns
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (!PARTIAL || j < nj) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm[j], a.h, acc[j], 0, 0, 0);
-            piece(3 * s + 0, acc[0]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (!PARTIAL || j < nj) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], a.m, acc[j], 0, 0, 0);
-            piece(3 * s + 1, acc[0]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (!PARTIAL || j < nj) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], a.h, acc[j], 0, 0, 0);
-            piece(3 * s + 2, acc[0]);
-        }
-#else
-#pragma unroll
-        for (int i = 0; i < S_DMA; ++i) piece(i, acc[0]);
-#endif
-        if (spread && ++d_kt == nk) { d_kt = 0; ++d_item; d_open(); }      // the stream moves on (as d_issue does)
-    };
-    auto close_stage = [&]() {
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        stamp(5);      // barrier
-        buf = buf == SB_NST - 1 ? 0 : buf + 1;
-    };
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    int nj = PARTIAL ? min(4, (p.N - n_blk + 31) >> 5) : 4;
 
-    for (int c_item = 0;; ++c_item) {
+    // Epilogue of the item (em, en).  D[n][m] of the 32x32 MFMA has col = lane & 31 (an output ROW here), row = (reg & 3) + 8 (reg >> 2)
+    // + 4 (lane >> 5): registers 4 q .. 4 q + 3 are output columns n0 + 8 q + 4 fg .. + 3 of row m.  Stored straight from there - one row per
+    // lane, 16 bytes - every wave-instruction is 32 pieces of 32 bytes on 32 different lines, and the L2 takes them one write request
+    // each: 7 500 cycles per item (phase clocks of that form).  So a 32 x 32 block goes through a 4 KB LDS image of the wave (the 16 KB
+    // behind the stage buffers: only one wave group is in its epilogue at a time) and leaves as WHOLE 128-byte lines, eight rows per
+    // instruction.  Image: row m = 128 bytes, its 16-byte chunk c at position c ^ (m & 7) - conflict-free both ways.  Bias, relu and the
+    // mask are applied on the way out (a lane keeps one 4-column group for all its rows: one bias float4 per block).  Leaves acc zeroed.
+    auto epilogue_t = [&](int em, int en, char* img, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;       // every row of the tile is inside M: no per-row guards (a workgroup-uniform fact)
+        const int orow = lane >> 3;                                 // + 8 it: the image row this lane takes out
+        const int ochunk = (lane & 7) ^ orow;                       // its logical 16-byte chunk (row & 7 == orow for all four rows)
+        const int enj = PARTIAL ? min(4, (p.N - en + 31) >> 5) : 4; // live 32-column blocks (N % 32 == 0: a block is all in or all out)
+        // this lane's bias values of the four column blocks, all in flight together
+        float4 bvs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = en + j * 32 + ochunk * 4;
+            bvs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias != nullptr) {
+                if (!PARTIAL) bvs[j] = *reinterpret_cast<const float4*>(p.bias + col);   // whole-tile shapes: every column has a bias, 16-byte aligned (gemm_x3s_eligible)
+                else {
+                    const int nb = p.nbias - 1;          // (clamped addresses, selected values: no load under a lane-divergent branch)
+                    const float b0 = p.bias[min(col, nb)], b1 = p.bias[min(col + 1, nb)], b2 = p.bias[min(col + 2, nb)], b3 = p.bias[min(col + 3, nb)];
+                    bvs[j] = make_float4(col <= nb ? b0 : 0.f, col + 1 <= nb ? b1 : 0.f, col + 2 <= nb ? b2 : 0.f, col + 3 <= nb ? b3 : 0.f);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (PARTIAL && j >= enj) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(img + fr * 128 + 16 * ((2 * q + fg) ^ (fr & 7))) =
+                    make_float4(acc[j][4 * q] * p.inv, acc[j][4 * q + 1] * p.inv, acc[j][4 * q + 2] * p.inv, acc[j][4 * q + 3] * p.inv);
+            const int col = en + j * 32 + ochunk * 4;
+            const float4 bv = bvs[j];
+            // (rows past M work on a clamped row and skip only the store itself: every load is consumed on every path - a load whose use
+            //  a lane-divergent branch skips stays "pending" in hipcc's bookkeeping and drew a vmcnt(0) into the K loop's header)
+            float4 mv[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) mv[it] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (p.aux != nullptr) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = em + wave * 32 + it * 8 + orow;
+                    mv[it] = *reinterpret_cast<const float4*>(p.aux + (size_t)(FULL ? row : min(row, p.M - 1)) * p.ldaux + col);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = em + wave * 32 + it * 8 + orow;
+                float4 v = *reinterpret_cast<const float4*>(img + (it * 8 + orow) * 128 + 16 * (lane & 7));
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (p.relu) { v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w); }      // NaN-propagating (common.h)
+                v.x = mv[it].x > 0.f ? v.x : 0.f; v.y = mv[it].y > 0.f ? v.y : 0.f; v.z = mv[it].z > 0.f ? v.z : 0.f; v.w = mv[it].w > 0.f ? v.w : 0.f;
+                float* c = p.C + (size_t)(FULL ? row : min(row, p.M - 1)) * p.ldc + col;
+#ifdef X3S_NO_STORE          // ablation build: timing only
+                if (v.x == 12345.678f) *reinterpret_cast<float4*>(c) = v;
+#else
+                if (FULL || row < p.M) *reinterpret_cast<float4*>(c) = v;
+#endif
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        nj = PARTIAL ? min(4, (p.N - n_blk + 31) >> 5) : 4;
+    };
+    // `final`: the epilogue behind a workgroup's last stage - there the two wave groups are NOT a phase apart (G1 takes no barrier behind
+    // its last MATRIX phase), so every wave takes an image of its own out of stage buffer 0 (no DMA is in flight and nobody reads a
+    // stage any more); everywhere else wave w and wave w + 4 alternate on the four images behind the stage buffers
+    auto epilogue = [&](int em, int en, bool final) __attribute__((always_inline)) {
+        char* img = final ? smem + wave * 4096 : smem + SB_NST * SSTAGE_BYTES + (wave & 3) * 4096;
+        if (em + SB_M <= p.M) epilogue_t(em, en, img, std::true_type{});
+        else epilogue_t(em, en, img, std::false_type{});
+    };
 
-        // ---- the item's stages but the last -------------------------------------------------------------------------------------------
-        for (int kt = 0; kt < nk - 1; ++kt) {
-            const bool ahead = d_on;
-            stamp(0);      // loop control
-            compute(ahead);
-            stamp(2);      // fragment reads, split, MFMAs (+ the spread DMA pieces)
-            // the next stage (issued one iteration ago) has landed: at most the stage just issued may still be in flight.  (The first wait
-            // of an item also covers the previous item's stores: "at most S_DMA operations outstanding" with the S_DMA youngest being
-            // loads, which return in order, means everything older is done.)
-            if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_DMA) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            stamp(4);      // wait for the next stage's DMA
-            close_stage();
-        }
-
-        // ---- the last stage and the epilogue -------------------------------------------------------------------------------------------
-        {
-            const bool ahead = d_on;
+    int pend_m = -1, pend_n = 0;          // the item whose accumulators still wait for their epilogue (written at the start of the next MEMORY phase)
+    for (int c_item = 0;; ++c_item) {
+        for (int kt = 0; kt < nk; ++kt) {
+            // ================= MEMORY phase =================
             stamp(0);
-            compute(false);
-            stamp(2);
-            // the bias values of this lane's 4 x 4 float4 (whole-tile shapes: every column has a bias and the vector is 16-byte aligned -
-            // gemm_x3s_eligible; the PARTIAL form loads them below, guarded).  Issued HERE, consumed right below: fetched under the last
-            // stage's MFMAs they left a load pending across the loop in hipcc's bookkeeping, and it answered with a vmcnt(0) in the K
-            // loop's header (tools/x3s_isa_check.py) - one L2 round trip per item is the cheaper evil.
-            float4 bv[4][4];
+            if (g1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // G1: its pieces of the next stage have landed (see above)
+            if (pend_m >= 0) {
+                epilogue(pend_m, pend_n, false);
+                pend_m = -1;
+                nj = PARTIAL ? min(4, (p.N - n_blk + 31) >> 5) : 4;
+            }
+            stamp(3);      // (epilogue, when there was one)
+            const bool ahead = d_on;
+            if (ahead) d_issue(buf >= 1 ? buf - 1 : SB_NST - 1);
+            const char* st = smem + buf * SSTAGE_BYTES;
+            f16x8 wh[2][4], wm[2][4];
+            Split2h a[2];
+#ifndef X3S_NO_MFMA          // ablation build: timing only
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int s = 0; s < 2; ++s) {
+                const float4 x0 = *reinterpret_cast<const float4*>(st + a_off[s][0]);
+                const float4 x1 = *reinterpret_cast<const float4*>(st + a_off[s][1]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bv[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!PARTIAL && p.bias != nullptr) {
+                for (int j = 0; j < 4; ++j) {
+                    wh[s][j] = *reinterpret_cast<const f16x8*>(st + b_off[s] + j * 2048);
+                    wm[s][j] = *reinterpret_cast<const f16x8*>(st + b_off[s] + j * 2048 + SPLANE_BYTES);
+                }
+                a[s] = split2h<true>(x0, x1, p.sa);
+            }
+#endif
+            stamp(1);      // DMA issue, fragment reads, split
+            __builtin_amdgcn_sched_barrier(0);      // nothing of the MEMORY phase sinks below its barrier
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(5);      // barrier
+            // ================= MATRIX phase =================
+#ifndef X3S_NO_MFMA
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                // piece-major, smallest terms first: the four accumulators take turns
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
+                    if (!PARTIAL || j < nj) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm[s][j], a[s].h, acc[j], 0, 0, 0);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const float4*>(p.bias + n_blk + fg * 4 + j * 32 + q * 8);
+                for (int j = 0; j < 4; ++j)
+                    if (!PARTIAL || j < nj) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s][j], a[s].m, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (!PARTIAL || j < nj) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s][j], a[s].h, acc[j], 0, 0, 0);
             }
-            // nothing but the next stage's DMA (and the bias loads) is in flight here: wait for it now, start the stage after next, and only
-            // then store - the stores are never waited for inside this item
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            stamp(4);
-            if (ahead) d_issue(buf >= 1 ? buf - 1 : SB_NST - 1);
-            // ---- epilogue from the registers: D[n][m] of the 32x32 MFMA has col = lane & 31 (an output ROW here), row = (reg & 3) +
-            // 8 (reg >> 2) + 4 (lane >> 5): registers 4 q .. 4 q + 3 are output columns n0 + 8 q + 4 fg .. + 3 of row m
-            int fge = fg;
-            asm volatile("" : "+v"(fge));      // (opaque here: keeps the per-column predicates below out of the K loop's live ranges)
-            // (rows past M compute on a clamped row and skip only the store itself: every load below is consumed on every path - a load
-            //  whose use a lane-divergent branch skips stays "pending" in hipcc's bookkeeping and drew a vmcnt(0) into the K loop's header)
-            const int row = m_blk + wave * 32 + fr;
-            const bool row_ok = row < p.M;
-            const int rowc = min(row, p.M - 1);
-            float* crow = p.C + (size_t)rowc * p.ldc;
-            const float* xrow = p.aux != nullptr ? p.aux + (size_t)rowc * p.ldaux : nullptr;
-#pragma unroll
-            for (int jh = 0; jh < 4; jh += 2) {
-                // two 32-column blocks at a time: their mask loads all in flight together (workgroup-uniform branches only), then the stores
-                float4 mv[2][4];
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) mv[jj][q] = make_float4(1.f, 1.f, 1.f, 1.f);
-                if (xrow != nullptr) {
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int col = n_blk + (jh + jj) * 32 + q * 8 + fge * 4;
-                            mv[jj][q] = *reinterpret_cast<const float4*>(xrow + (PARTIAL ? min(col, p.N - 4) : col));
-                        }
-                }
-                if (PARTIAL && p.bias != nullptr) {
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int col = n_blk + (jh + jj) * 32 + q * 8 + fge * 4;
-                            const int nb = p.nbias - 1;          // (clamped addresses, selected values: no load under a lane-divergent branch)
-                            const float b0 = p.bias[min(col, nb)], b1 = p.bias[min(col + 1, nb)], b2 = p.bias[min(col + 2, nb)], b3 = p.bias[min(col + 3, nb)];
-                            bv[jh + jj][q] = make_float4(col <= nb ? b0 : 0.f, col + 1 <= nb ? b1 : 0.f, col + 2 <= nb ? b2 : 0.f, col + 3 <= nb ? b3 : 0.f);
-                        }
-                }
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int j = jh + jj;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int col = n_blk + j * 32 + q * 8 + fge * 4;
-                        float4 v = make_float4(acc[j][4 * q] * p.inv + bv[j][q].x, acc[j][4 * q + 1] * p.inv + bv[j][q].y,
-                                               acc[j][4 * q + 2] * p.inv + bv[j][q].z, acc[j][4 * q + 3] * p.inv + bv[j][q].w);
-                        if (p.relu) { v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w); }      // NaN-propagating (common.h)
-                        v.x = mv[jj][q].x > 0.f ? v.x : 0.f; v.y = mv[jj][q].y > 0.f ? v.y : 0.f;
-                        v.z = mv[jj][q].z > 0.f ? v.z : 0.f; v.w = mv[jj][q].w > 0.f ? v.w : 0.f;
-#ifdef X3S_NO_STORE          // ablation build: timing only
-                        if (v.x == 12345.678f) *reinterpret_cast<float4*>(crow + col) = v;
-#else
-                        if (row_ok && (!PARTIAL || col < p.N)) *reinterpret_cast<float4*>(crow + col) = v;      // N % 4 == 0 (host check)
 #endif
-                    }
-                }
+            stamp(2);      // MFMAs
+            buf = buf == SB_NST - 1 ? 0 : buf + 1;
+            const bool last = kt == nk - 1;
+            if (last) { pend_m = m_blk; pend_n = n_blk; }
+            bool more = true;
+            if (last) more = im.decode(c_item + 1, m_blk, n_blk);
+            if (!g1) {
+                // G0: the next stage's pieces of this wave have landed - at most the stage just issued may still be in flight
+                if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_DMA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            stamp(3);      // epilogue (+ its DMA issue)
-            close_stage();
+            stamp(4);      // wait for the next stage's DMA
+            if (!(g1 && last && !more)) {          // (G1 took its extra barrier up front)
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            stamp(5);
+            if (last && !more) goto done;
         }
-        if (!im.decode(c_item + 1, m_blk, n_blk)) break;
     }
+done:
+    if (pend_m >= 0) epilogue(pend_m, pend_n, true);
     if (X3S_TIMING && timing) { for (int k = 0; k < 6; ++k) p.dbg[k] = tm[k]; }
 }
 
@@ -378,7 +391,7 @@ bool gemm_x3s_eligible(const X3Gemm& g) {
     if (g.accumulate || g.C2 != nullptr || g.B2 != nullptr || g.n_split != 0 || g.a_colsum != nullptr) return false;
     if (g.a_bf16 || g.b_bf16 || g.c_bf16 || g.aux_bf16) return false;
     if (g.bias != nullptr && ((reinterpret_cast<uintptr_t>(g.bias) & 15) != 0 || (g.N % SB_N == 0 && g.nbias < g.N))) return false;      // the epilogue's bias loads
-    if (g.K < SB_K || g.K % SB_K || (g.N & 3) || (g.lda & 3) || (g.ldb & 7) || (g.ldc & 3) || (g.aux != nullptr && (g.ldaux & 3))) return false;
+    if (g.K < SB_K || g.K % SB_K || (g.N & 31) || (g.lda & 3) || (g.ldb & 7) || (g.ldc & 3) || (g.aux != nullptr && (g.ldaux & 3))) return false;
     if ((long long)g.M * g.lda * 4 >= (1LL << 32) - (1 << 20) || 2 * g.b_plane * 2 + (long long)g.N * g.ldb * 2 >= (1LL << 32) - (1 << 20)) return false;      // 32-bit DMA offsets
     const long items = (long)((g.M + SB_M - 1) / SB_M) * ((g.N + SB_N - 1) / SB_N);
     return items >= 192;
@@ -424,8 +437,8 @@ int gemm_x3s(const X3Gemm& g, hipStream_t stream) {
         long long h[6];
         (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
         const double items = (double)((im.n_items + grid - 1) / grid), stages = items * (g.K / SB_K);
-        fprintf(stderr, "gemm_x3s M %d N %d K %d items/wg %.0f stages/item %d | clocks per stage: loop %.0f  reads+split+mfma+dma issue %.0f  dma wait %.0f  barrier %.0f | per item: epilogue %.0f\n",
-                g.M, g.N, g.K, items, g.K / SB_K, h[0] / stages, h[2] / stages, h[4] / stages, h[5] / stages, h[3] / items);
+        fprintf(stderr, "gemm_x3s M %d N %d K %d items/wg %.0f stages/item %d | clocks per stage (wave 0): loop %.0f  MEMORY phase (dma issue, reads, split) %.0f  MATRIX phase %.0f  dma wait %.0f  barriers %.0f | per item: epilogue %.0f\n",
+                g.M, g.N, g.K, items, g.K / SB_K, h[0] / stages, h[1] / stages, h[2] / stages, h[4] / stages, h[5] / stages, h[3] / items);
     }
 #endif
     return launch_check("gemm_x3s");

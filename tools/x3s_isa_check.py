@@ -19,27 +19,29 @@ with tempfile.TemporaryDirectory() as d:
 bad = 0
 for name in re.findall(r'^(_ZN2dc\S*gemm_x3s_kernel\S*):', asm, re.M):
     body = asm[asm.index(name + ':'):]
-    body = body[:body.index('s_endpgm')].splitlines()
-    # the K loop = the depth-2 loop: every basic block whose header comment names it (blocks start at a label or a "; %bb." line)
-    m = re.search(r'^\.(LBB\d+_\d+):[^\n]*\n(?:[^\n]*\n)?[^\n]*This Inner Loop Header: Depth=2', '\n'.join(body), re.M)
-    if not m:
-        print(name[-30:], ': no depth-2 loop found'); bad += 1; continue
-    hdr = m.group(1)[1:]
-    seg, inside = [], False
-    for i, l in enumerate(body):
+    body = body[:body.index('.Lfunc_end')].splitlines()
+    # every basic block (it starts at a label or a "; %bb." line) that issues MFMAs, fragment reads or DMA pieces - the hot path of the K
+    # loop; the epilogue's blocks (global loads / stores only) may wait as hipcc sees fit
+    blocks, cur = [], []
+    for l in body:
         if re.match(r'^\.LBB\d+_\d+:', l) or l.startswith('; %bb.'):
-            ctx = ' '.join(body[i:i + 3])
-            inside = ('Header=' + hdr + ' ') in ctx + ' ' or ('.' + hdr + ':') in l
-        if inside:
-            seg.append(l)
-    n_mfma = sum('v_mfma' in l for l in seg)
-    n_dma = sum('global_load_lds' in l for l in seg)
-    own, in_asm = [], False
-    for l in seg:
-        if '#ASMSTART' in l: in_asm = True
-        elif '#ASMEND' in l: in_asm = False
-        elif 's_waitcnt' in l and 'vmcnt' in l and not in_asm: own.append(l.strip())
-    print('%s: K loop %s: %d lines, %d MFMAs, %d DMA pieces, compiler vmcnt waits: %s' % (name[-30:], hdr, len(seg), n_mfma, n_dma, own or 'none'))
-    if own or n_mfma < 16:
+            blocks.append(cur); cur = []
+        cur.append(l)
+    blocks.append(cur)
+    n_mfma = n_dma = n_hot = 0
+    own = []
+    for b in blocks:
+        hot = any(('v_mfma' in l or 'ds_read_b128' in l or 'global_load_lds' in l) for l in b)
+        if not hot or not any('Loop' in l for l in b[:4]):
+            continue
+        n_hot += 1
+        n_mfma += sum('v_mfma' in l for l in b); n_dma += sum('global_load_lds' in l for l in b)
+        in_asm = False
+        for l in b:
+            if '#ASMSTART' in l: in_asm = True
+            elif '#ASMEND' in l: in_asm = False
+            elif 's_waitcnt' in l and 'vmcnt' in l and not in_asm: own.append(l.strip())
+    print('%s: %d hot blocks inside loops: %d MFMAs, %d DMA pieces, compiler vmcnt waits: %s' % (name[-30:], n_hot, n_mfma, n_dma, own or 'none'))
+    if own or n_mfma < 24:
         bad += 1
 sys.exit(1 if bad else 0)
