@@ -26,6 +26,9 @@
 #include "kernels.h"
 #include "gemm_tiles.h"
 
+#ifndef X3S_EPI_DIRECT
+#define X3S_EPI_DIRECT 1     // 1: epilogue straight from the accumulators (row-major MFMA output, whole lines per half-wave); 0: through LDS images (A/B)
+#endif
 #ifndef X3S_TIMING
 #define X3S_TIMING 0      // developer build: s_memtime stamps of (workgroup 0, wave 0), summed per phase; a blocking read-back and a line on stderr per launch
 #endif
@@ -37,6 +40,14 @@ enum { SB_M = 256, SB_N = 128, SB_K = 32, SB_WAVES = 8, SB_THREADS = 512, SB_NST
 enum { SA_BYTES = SB_M * SB_K * 4 /* 32768 */, SPLANE_BYTES = SB_N * SB_K * 2 /* 8192 */, SB_BYTES = 2 * SPLANE_BYTES,
        SSTAGE_BYTES = SA_BYTES + SB_BYTES /* 49152 */, X3S_LDS = SB_NST * SSTAGE_BYTES + 4 * 4096 /* 163840 = all of a CU's LDS: three stages + the epilogue images */ };
 enum { SA_PIECES = SA_BYTES / 1024 / SB_WAVES /* 4 */, SB_PIECES = SB_BYTES / 1024 / SB_WAVES /* 2 */, S_DMA = SA_PIECES + SB_PIECES /* 6 per lane and stage */ };
+
+// D = W_tile x_tile^T (a lane holds four consecutive output columns of one row: the LDS-image epilogue) or x_tile W_tile^T (a lane holds one
+// output column, a register one row: a half-wave's 32 lanes are a whole 128-byte line of C)
+#if X3S_EPI_DIRECT
+#define X3S_MFMA(w, x, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w, c, 0, 0, 0)
+#else
+#define X3S_MFMA(w, x, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0)
+#endif
 
 struct X3SArgs {
     const float* A; const uint16_t* B;
@@ -188,6 +199,10 @@ __global__ __launch_bounds__(SB_THREADS, 2) void gemm_x3s_kernel(X3SArgs p, Item
     auto stamp = [&](int k) __attribute__((always_inline)) {
         if (X3S_TIMING && timing) { const long long now = (long long)__builtin_amdgcn_s_memtime(); tm[k] += now - tlast; tlast = now; }
     };
+#if X3S_EPI_DIRECT
+    if (p.bias != nullptr)               // the bias vector into its LDS table (N <= 4096: gemm_x3s_eligible); the prologue's barrier publishes it
+        for (int i = tid; i < p.N; i += SB_THREADS) reinterpret_cast<float*>(smem + SB_NST * SSTAGE_BYTES)[i] = i < p.nbias ? p.bias[i] : 0.f;
+#endif
     d_open();
     d_issue(0);
     {
@@ -298,12 +313,66 @@ __global__ __launch_bounds__(SB_THREADS, 2) void gemm_x3s_kernel(X3SArgs p, Item
     // `final`: the epilogue behind a workgroup's last stage - there the two wave groups are NOT a phase apart (G1 takes no barrier behind
     // its last MATRIX phase), so every wave takes an image of its own out of stage buffer 0 (no DMA is in flight and nobody reads a
     // stage any more); everywhere else wave w and wave w + 4 alternate on the four images behind the stage buffers
+#if X3S_EPI_DIRECT
+    // Epilogue straight from the accumulators (round 6, third form).  With D = x_tile W_tile^T the 32x32 MFMA leaves output column
+    // n0 + (lane & 31) in every lane and row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) in register reg: one store instruction writes two
+    // whole 128-byte lines (one per half-wave), 64 instructions per wave and item, no LDS round trip, no dependent chain longer than
+    // scale - bias - relu - store.  (The LDS-image form above: 4 500 cycles per wave and item, most of it the write -> read -> store chains
+    // of its four blocks and the bias fetch; the one-row-per-lane form before it: 7 500, the L2 taking 32-byte pieces one request each.)
+    // The bias comes from an LDS table of the whole vector (the 16 KB behind the stage buffers), filled once per workgroup.
+    const float* bias_lds = reinterpret_cast<const float*>(smem + SB_NST * SSTAGE_BYTES);
+    auto epilogue_d = [&](int em, int en, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;       // every row of the tile is inside M: no per-row guards (a workgroup-uniform fact)
+        const int enj = PARTIAL ? min(4, (p.N - en + 31) >> 5) : 4; // live 32-column blocks (N % 32 == 0: a block is all in or all out)
+        float bj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bj[j] = p.bias != nullptr ? bias_lds[min(en + j * 32 + fr, p.N - 1)] : 0.f;
+        const int row0 = em + wave * 32 + 4 * fg;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (PARTIAL && j >= enj) continue;
+            const int col = en + j * 32 + fr;
+            float mv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mv[r] = 1.f;
+            if (p.aux != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + (r & 3) + 8 * (r >> 2);
+                    mv[r] = p.aux[(size_t)(FULL ? row : min(row, p.M - 1)) * p.ldaux + col];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2);
+                float v = acc[j][r] * p.inv + bj[j];
+                if (p.relu) v = relu_nan(v);          // NaN-propagating (common.h)
+                v = mv[r] > 0.f ? v : 0.f;
+                float* c = p.C + (size_t)(FULL ? row : min(row, p.M - 1)) * p.ldc + col;
+#ifdef X3S_NO_STORE          // ablation build: timing only
+                if (v == 12345.678f) *c = v;
+#else
+                if (FULL || row < p.M) *c = v;
+#endif
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    };
+    auto epilogue = [&](int em, int en, bool) __attribute__((always_inline)) {
+        if (em + SB_M <= p.M) epilogue_d(em, en, std::true_type{});
+        else epilogue_d(em, en, std::false_type{});
+    };
+#else
     auto epilogue = [&](int em, int en, bool final) __attribute__((always_inline)) {
         char* img = final ? smem + wave * 4096 : smem + SB_NST * SSTAGE_BYTES + (wave & 3) * 4096;
         if (em + SB_M <= p.M) epilogue_t(em, en, img, std::true_type{});
         else epilogue_t(em, en, img, std::false_type{});
     };
 
+#endif
     int pend_m = -1, pend_n = 0;          // the item whose accumulators still wait for their epilogue (written at the start of the next MEMORY phase)
     for (int c_item = 0;; ++c_item) {
         for (int kt = 0; kt < nk; ++kt) {
@@ -347,13 +416,13 @@ __global__ __launch_bounds__(SB_THREADS, 2) void gemm_x3s_kernel(X3SArgs p, Item
                 // piece-major, smallest terms first: the four accumulators take turns
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (!PARTIAL || j < nj) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm[s][j], a[s].h, acc[j], 0, 0, 0);
+                    if (!PARTIAL || j < nj) acc[j] = X3S_MFMA(wm[s][j], a[s].h, acc[j]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (!PARTIAL || j < nj) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s][j], a[s].m, acc[j], 0, 0, 0);
+                    if (!PARTIAL || j < nj) acc[j] = X3S_MFMA(wh[s][j], a[s].m, acc[j]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (!PARTIAL || j < nj) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s][j], a[s].h, acc[j], 0, 0, 0);
+                    if (!PARTIAL || j < nj) acc[j] = X3S_MFMA(wh[s][j], a[s].h, acc[j]);
             }
 #endif
             stamp(2);      // MFMAs
@@ -390,7 +459,11 @@ bool gemm_x3s_eligible(const X3Gemm& g) {
     if (g.prec != 4 || g.a_mode != X3_ROW || g.b_mode != X3_PLANES) return false;
     if (g.accumulate || g.C2 != nullptr || g.B2 != nullptr || g.n_split != 0 || g.a_colsum != nullptr) return false;
     if (g.a_bf16 || g.b_bf16 || g.c_bf16 || g.aux_bf16) return false;
+#if X3S_EPI_DIRECT
+    if (g.N > 4096) return false;                                  // the bias table in LDS
+#else
     if (g.bias != nullptr && ((reinterpret_cast<uintptr_t>(g.bias) & 15) != 0 || (g.N % SB_N == 0 && g.nbias < g.N))) return false;      // the epilogue's bias loads
+#endif
     if (g.K < SB_K || g.K % SB_K || (g.N & 31) || (g.lda & 3) || (g.ldb & 7) || (g.ldc & 3) || (g.aux != nullptr && (g.ldaux & 3))) return false;
     if ((long long)g.M * g.lda * 4 >= (1LL << 32) - (1 << 20) || 2 * g.b_plane * 2 + (long long)g.N * g.ldb * 2 >= (1LL << 32) - (1 << 20)) return false;      // 32-bit DMA offsets
     const long items = (long)((g.M + SB_M - 1) / SB_M) * ((g.N + SB_N - 1) / SB_N);

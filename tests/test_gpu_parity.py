@@ -217,6 +217,28 @@ def test_dense_product_kernels_both_match(which, case, cell, hidden, layers):
         compare(out, ref, n_ep, ref['param_names'])
 
 
+@pytest.mark.parametrize('cell,hidden,B', [('lstm', 256, 128), ('gru', 256, 64)])
+def test_row_streaming_products_agree_with_the_tile_kernel(cell, hidden, B):
+    # round 6: at bench-sized batches the x W^T / dy W products of the default arithmetic run on the row-streaming kernel
+    # (csrc/gemm_x3s.hip: LDS-DMA for both operands, two wave groups half a stage apart); DC_DIMS_GEMM_TILE128 keeps them on round 4's
+    # 128 x 128 split-on-load kernel.  Same pieces, same three MFMAs per product, another summation order: one epoch of configs[3]'s shard
+    # (LSTM-256, 128 x 256: pre-rnn, gates, heads and their input gradients all eligible) and of the reference's GRU at 64 x 256 (gates and
+    # d(xcat) eligible, the 256-column products stay on the tile kernel) must agree far inside the parity bar
+    from dotaclient_amd import engine as E
+    S = 256
+    g = {'seq_len': S, 'lr': 5e-5, 'entropy_coef': 5e-4, 'vf_coef': 0.5, 'epochs': 1}
+    rollouts = synth.make_rollouts(1000, [S] * B)
+    a, _ = run_hip(g, rollouts, cell, hidden, 1, epochs=1)
+    b, eng = run_hip(g, rollouts, cell, hidden, 1, epochs=1, kernel_flags=E.DC_DIMS_GEMM_TILE128)
+    for key in ['values', 'advantages'] + ['old_logp_' + k for k in L.OUTPUT_KEYS]:
+        assert util.scaled_err(a[key], b[key]) < 5e-6, (key, util.scaled_err(a[key], b[key]))
+    assert np.array_equal(a['argmax'], b['argmax'])
+    for key in ['losses', 'entropies', 'grad_norms']:
+        assert _loss_err(a['ep0_' + key], b['ep0_' + key], key) < 1e-5, key
+    assert util.scaled_err(a['ep0_grad_samples'], b['ep0_grad_samples']) < 2e-5
+    assert eng.fault() is None
+
+
 @pytest.mark.parametrize('variant', ['mfma', 'valu'])
 @pytest.mark.parametrize('hidden,layers', [(128, 1), (64, 2)])
 def test_lstm_persist_variants_match_oracle(variant, hidden, layers):
