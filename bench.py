@@ -255,6 +255,9 @@ def parity_report(got, ref, tol=1e-4, argmax_min_equal=None, sub_batch=None, che
     rep['losses'] = float(err[:, :4].max())
     rep['entropies'] = float(err[:, 4:9].max())
     rep['grad_norms'] = float(err[:, 9:11].max())
+    # the plain relative error of the TOTAL loss, |a - b| / |b| per epoch, beside the sum-of-|parts| yardstick above (reported,
+    # not part of `ok` - the total is a sum of signed parts and may cancel)
+    total_plain = float((np.abs(ge[:, 0] - re_[:, 0]) / (np.abs(re_[:, 0]) + 1e-30)).max())
     if argmax_min_equal is not None:
         rep.pop('returns', None)       # do not depend on the network: bit-exact either way
     worst = max(rep.values())
@@ -266,7 +269,7 @@ def parity_report(got, ref, tol=1e-4, argmax_min_equal=None, sub_batch=None, che
                           re_.shape[0]),
             'parity_rel_err': worst, 'tolerance': tol, 'argmax_bit_exact': argmax_equal, 'argmax_equal_fraction': argmax_frac,
             'argmax_rule': 'bit-exact' if argmax_min_equal is None else 'bf16 path: >= %.2f of the masked argmax indices equal (near-ties flip under a 2^-9 perturbation; tests/test_gpu_bf16.py)' % argmax_min_equal,
-            'ok': bool(worst < tol and argmax_ok), 'per_quantity': {k: float('%.3g' % v) for k, v in rep.items()},
+            'ok': bool(worst < tol and argmax_ok), 'per_quantity': dict({k: float('%.3g' % v) for k, v in rep.items()}, total_loss_plain_relative=float('%.3g' % total_plain)),
             'yardstick': 'vectors: max|a-b| / max|b|; loss parts: relative (floor 1 % of the largest part), total loss against the sum of |parts|',
             'elementwise_rel_err': {k: float('%.3g' % v) for k, v in elem.items()},
             'elementwise_note': 'reported beside the scaled figures, not part of `ok`: max over entries with |ref| > 1e-3 * max|ref| of '
@@ -699,7 +702,7 @@ def main():
                 sys.stderr.write('bench.py: weak_scaling_unit failed: %r\n' % (e,))
         if want_cpu:
             bf16 = bool(KERNEL_FLAGS & 4096)
-            tol, amin = (3e-2, 0.97) if bf16 else (1e-4, None)       # bf16 path: the stated tolerances of tests/test_gpu_bf16.py
+            tol, amin = (1e-2, 0.995) if bf16 else (1e-4, None)      # bf16 path: the stated tolerances of tests/test_gpu_bf16.py (round 6: 3e-2 / 0.97 before)
             if B * S > PARITY_FULL_MAX:
                 # a batch the oracle would need minutes (and tens of GB) for: checker and CPU baseline run on a bounded sample, the first
                 # 64 trajectories, which the HIP path runs again as a batch of its own (first iteration from the same initial weights)
@@ -826,7 +829,7 @@ def secondary_measurements(args, dev, E, parity_ref_path):
                                                                  'rollout pass + one epoch from the same initial weights'))
             else:
                 sub, ref = _cfg4_fixture_pair(got, os.path.join(GOLDEN_DIR, 'cfg4_shard_oracle.npz'))
-                e['parity'] = _slim_parity(parity_report(sub, ref, 3e-2, 0.97,
+                e['parity'] = _slim_parity(parity_report(sub, ref, 1e-2, 0.995,
                                                          checker='tests/golden/cfg4_shard_oracle.npz: the fp32 oracle (oracle/ref_optimizer.py; no reference '
                                                                  'exists for this cell, SURVEY.md 8(c)) on the same seeded 131 072 env-steps, strided samples, rollout '
                                                                  'pass + one epoch; bf16 path judged by its STATED tolerance (tests/test_gpu_bf16.py)'))

@@ -26,9 +26,6 @@
 #include "kernels.h"
 #include "gemm_tiles.h"
 
-#ifndef X3S_EPI_DIRECT
-#define X3S_EPI_DIRECT 1     // 1: epilogue straight from the accumulators (row-major MFMA output, whole lines per half-wave); 0: through LDS images (A/B)
-#endif
 #ifndef X3S_TIMING
 #define X3S_TIMING 0      // developer build: s_memtime stamps of (workgroup 0, wave 0), summed per phase; a blocking read-back and a line on stderr per launch
 #endif
@@ -41,13 +38,8 @@ enum { SA_BYTES = SB_M * SB_K * 4 /* 32768 */, SPLANE_BYTES = SB_N * SB_K * 2 /*
        SSTAGE_BYTES = SA_BYTES + SB_BYTES /* 49152 */, X3S_LDS = SB_NST * SSTAGE_BYTES + 4 * 4096 /* 163840 = all of a CU's LDS: three stages + the epilogue images */ };
 enum { SA_PIECES = SA_BYTES / 1024 / SB_WAVES /* 4 */, SB_PIECES = SB_BYTES / 1024 / SB_WAVES /* 2 */, S_DMA = SA_PIECES + SB_PIECES /* 6 per lane and stage */ };
 
-// D = W_tile x_tile^T (a lane holds four consecutive output columns of one row: the LDS-image epilogue) or x_tile W_tile^T (a lane holds one
-// output column, a register one row: a half-wave's 32 lanes are a whole 128-byte line of C)
-#if X3S_EPI_DIRECT
+// D = x_tile W_tile^T: a lane holds one output column, a register one row - a half-wave's 32 lanes are a whole 128-byte line of C
 #define X3S_MFMA(w, x, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w, c, 0, 0, 0)
-#else
-#define X3S_MFMA(w, x, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0)
-#endif
 
 struct X3SArgs {
     const float* A; const uint16_t* B;
@@ -195,14 +187,13 @@ __global__ __launch_bounds__(SB_THREADS, 2) void gemm_x3s_kernel(X3SArgs p, Item
     int m_blk, n_blk;
     if (!im.decode(0, m_blk, n_blk)) return;
     long long tm[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
-    const bool timing = X3S_TIMING && p.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+    const bool timing = X3S_TIMING && p.dbg != nullptr && tid == 0;      // (every workgroup's wave 0: the per-phase sums of workgroup 0, the totals of all)
+    const long long t_begin = X3S_TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
     auto stamp = [&](int k) __attribute__((always_inline)) {
         if (X3S_TIMING && timing) { const long long now = (long long)__builtin_amdgcn_s_memtime(); tm[k] += now - tlast; tlast = now; }
     };
-#if X3S_EPI_DIRECT
     if (p.bias != nullptr)               // the bias vector into its LDS table (N <= 4096: gemm_x3s_eligible); the prologue's barrier publishes it
         for (int i = tid; i < p.N; i += SB_THREADS) reinterpret_cast<float*>(smem + SB_NST * SSTAGE_BYTES)[i] = i < p.nbias ? p.bias[i] : 0.f;
-#endif
     d_open();
     d_issue(0);
     {
@@ -242,83 +233,14 @@ __global__ __launch_bounds__(SB_THREADS, 2) void gemm_x3s_kernel(X3SArgs p, Item
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     int nj = PARTIAL ? min(4, (p.N - n_blk + 31) >> 5) : 4;
 
-    // Epilogue of the item (em, en).  D[n][m] of the 32x32 MFMA has col = lane & 31 (an output ROW here), row = (reg & 3) + 8 (reg >> 2)
-    // + 4 (lane >> 5): registers 4 q .. 4 q + 3 are output columns n0 + 8 q + 4 fg .. + 3 of row m.  Stored straight from there - one row per
-    // lane, 16 bytes - every wave-instruction is 32 pieces of 32 bytes on 32 different lines, and the L2 takes them one write request
-    // each: 7 500 cycles per item (phase clocks of that form).  So a 32 x 32 block goes through a 4 KB LDS image of the wave (the 16 KB
-    // behind the stage buffers: only one wave group is in its epilogue at a time) and leaves as WHOLE 128-byte lines, eight rows per
-    // instruction.  Image: row m = 128 bytes, its 16-byte chunk c at position c ^ (m & 7) - conflict-free both ways.  Bias, relu and the
-    // mask are applied on the way out (a lane keeps one 4-column group for all its rows: one bias float4 per block).  Leaves acc zeroed.
-    auto epilogue_t = [&](int em, int en, char* img, auto full_tag) __attribute__((always_inline)) {
-        constexpr bool FULL = decltype(full_tag)::value;       // every row of the tile is inside M: no per-row guards (a workgroup-uniform fact)
-        const int orow = lane >> 3;                                 // + 8 it: the image row this lane takes out
-        const int ochunk = (lane & 7) ^ orow;                       // its logical 16-byte chunk (row & 7 == orow for all four rows)
-        const int enj = PARTIAL ? min(4, (p.N - en + 31) >> 5) : 4; // live 32-column blocks (N % 32 == 0: a block is all in or all out)
-        // this lane's bias values of the four column blocks, all in flight together
-        float4 bvs[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = en + j * 32 + ochunk * 4;
-            bvs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias != nullptr) {
-                if (!PARTIAL) bvs[j] = *reinterpret_cast<const float4*>(p.bias + col);   // whole-tile shapes: every column has a bias, 16-byte aligned (gemm_x3s_eligible)
-                else {
-                    const int nb = p.nbias - 1;          // (clamped addresses, selected values: no load under a lane-divergent branch)
-                    const float b0 = p.bias[min(col, nb)], b1 = p.bias[min(col + 1, nb)], b2 = p.bias[min(col + 2, nb)], b3 = p.bias[min(col + 3, nb)];
-                    bvs[j] = make_float4(col <= nb ? b0 : 0.f, col + 1 <= nb ? b1 : 0.f, col + 2 <= nb ? b2 : 0.f, col + 3 <= nb ? b3 : 0.f);
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (PARTIAL && j >= enj) continue;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4*>(img + fr * 128 + 16 * ((2 * q + fg) ^ (fr & 7))) =
-                    make_float4(acc[j][4 * q] * p.inv, acc[j][4 * q + 1] * p.inv, acc[j][4 * q + 2] * p.inv, acc[j][4 * q + 3] * p.inv);
-            const int col = en + j * 32 + ochunk * 4;
-            const float4 bv = bvs[j];
-            // (rows past M work on a clamped row and skip only the store itself: every load is consumed on every path - a load whose use
-            //  a lane-divergent branch skips stays "pending" in hipcc's bookkeeping and drew a vmcnt(0) into the K loop's header)
-            float4 mv[4];
-#pragma unroll
-            for (int it = 0; it < 4; ++it) mv[it] = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (p.aux != nullptr) {
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int row = em + wave * 32 + it * 8 + orow;
-                    mv[it] = *reinterpret_cast<const float4*>(p.aux + (size_t)(FULL ? row : min(row, p.M - 1)) * p.ldaux + col);
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int row = em + wave * 32 + it * 8 + orow;
-                float4 v = *reinterpret_cast<const float4*>(img + (it * 8 + orow) * 128 + 16 * (lane & 7));
-                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                if (p.relu) { v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w); }      // NaN-propagating (common.h)
-                v.x = mv[it].x > 0.f ? v.x : 0.f; v.y = mv[it].y > 0.f ? v.y : 0.f; v.z = mv[it].z > 0.f ? v.z : 0.f; v.w = mv[it].w > 0.f ? v.w : 0.f;
-                float* c = p.C + (size_t)(FULL ? row : min(row, p.M - 1)) * p.ldc + col;
-#ifdef X3S_NO_STORE          // ablation build: timing only
-                if (v.x == 12345.678f) *reinterpret_cast<float4*>(c) = v;
-#else
-                if (FULL || row < p.M) *reinterpret_cast<float4*>(c) = v;
-#endif
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    };
-    // `final`: the epilogue behind a workgroup's last stage - there the two wave groups are NOT a phase apart (G1 takes no barrier behind
-    // its last MATRIX phase), so every wave takes an image of its own out of stage buffer 0 (no DMA is in flight and nobody reads a
-    // stage any more); everywhere else wave w and wave w + 4 alternate on the four images behind the stage buffers
-#if X3S_EPI_DIRECT
-    // Epilogue straight from the accumulators (round 6, third form).  With D = x_tile W_tile^T the 32x32 MFMA leaves output column
+    // Epilogue straight from the accumulators (third form).  With D = x_tile W_tile^T the 32x32 MFMA leaves output column
     // n0 + (lane & 31) in every lane and row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) in register reg: one store instruction writes two
     // whole 128-byte lines (one per half-wave), 64 instructions per wave and item, no LDS round trip, no dependent chain longer than
-    // scale - bias - relu - store.  (The LDS-image form above: 4 500 cycles per wave and item, most of it the write -> read -> store chains
-    // of its four blocks and the bias fetch; the one-row-per-lane form before it: 7 500, the L2 taking 32-byte pieces one request each.)
+    // scale - bias - relu - store.  (The forms before it, both with D = W x^T - a lane holding four consecutive columns of one row: 16-byte stores of one row per lane
+    // 7 500 ticks per wave and item, the L2 taking 32-byte pieces one request each; through 4 KB LDS images as whole lines, eight rows per
+    // instruction, 5 400.  This form: 5 400 as well - the 64 KB a wave group writes per item leave the CU at ~12 bytes per clock whatever the
+    // instructions, whether the workgroups start staggered or not; and trickled out of parked registers under the next item's MFMAs the
+    // stores slowed the K loop more than they saved (gates 160 -> 190 us): the DMA waits count them - vmcnt is in order.)
     // The bias comes from an LDS table of the whole vector (the 16 KB behind the stage buffers), filled once per workgroup.
     const float* bias_lds = reinterpret_cast<const float*>(smem + SB_NST * SSTAGE_BYTES);
     auto epilogue_d = [&](int em, int en, auto full_tag) __attribute__((always_inline)) {
@@ -365,14 +287,6 @@ __global__ __launch_bounds__(SB_THREADS, 2) void gemm_x3s_kernel(X3SArgs p, Item
         if (em + SB_M <= p.M) epilogue_d(em, en, std::true_type{});
         else epilogue_d(em, en, std::false_type{});
     };
-#else
-    auto epilogue = [&](int em, int en, bool final) __attribute__((always_inline)) {
-        char* img = final ? smem + wave * 4096 : smem + SB_NST * SSTAGE_BYTES + (wave & 3) * 4096;
-        if (em + SB_M <= p.M) epilogue_t(em, en, img, std::true_type{});
-        else epilogue_t(em, en, img, std::false_type{});
-    };
-
-#endif
     int pend_m = -1, pend_n = 0;          // the item whose accumulators still wait for their epilogue (written at the start of the next MEMORY phase)
     for (int c_item = 0;; ++c_item) {
         for (int kt = 0; kt < nk; ++kt) {
@@ -411,6 +325,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void gemm_x3s_kernel(X3SArgs p, Item
             stamp(5);      // barrier
             // ================= MATRIX phase =================
 #ifndef X3S_NO_MFMA
+            __builtin_amdgcn_s_setprio(1);      // the SIMD's other wave is in its MEMORY phase: its VALU / DS / DMA issue must not delay these MFMAs
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 // piece-major, smallest terms first: the four accumulators take turns
@@ -424,6 +339,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void gemm_x3s_kernel(X3SArgs p, Item
                 for (int j = 0; j < 4; ++j)
                     if (!PARTIAL || j < nj) acc[j] = X3S_MFMA(wh[s][j], a[s].h, acc[j]);
             }
+            __builtin_amdgcn_s_setprio(0);
 #endif
             stamp(2);      // MFMAs
             buf = buf == SB_NST - 1 ? 0 : buf + 1;
@@ -449,7 +365,11 @@ __global__ __launch_bounds__(SB_THREADS, 2) void gemm_x3s_kernel(X3SArgs p, Item
     }
 done:
     if (pend_m >= 0) epilogue(pend_m, pend_n, true);
-    if (X3S_TIMING && timing) { for (int k = 0; k < 6; ++k) p.dbg[k] = tm[k]; }
+    if (X3S_TIMING && timing) {
+        if (blockIdx.x == 0) for (int k = 0; k < 6; ++k) p.dbg[k] = tm[k];
+        p.dbg[8 + 2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memtime() - t_begin;
+        p.dbg[9 + 2 * blockIdx.x] = tm[4] + tm[5];       // waits: DMA + barriers
+    }
 }
 
 }  // namespace
@@ -459,11 +379,7 @@ bool gemm_x3s_eligible(const X3Gemm& g) {
     if (g.prec != 4 || g.a_mode != X3_ROW || g.b_mode != X3_PLANES) return false;
     if (g.accumulate || g.C2 != nullptr || g.B2 != nullptr || g.n_split != 0 || g.a_colsum != nullptr) return false;
     if (g.a_bf16 || g.b_bf16 || g.c_bf16 || g.aux_bf16) return false;
-#if X3S_EPI_DIRECT
     if (g.N > 4096) return false;                                  // the bias table in LDS
-#else
-    if (g.bias != nullptr && ((reinterpret_cast<uintptr_t>(g.bias) & 15) != 0 || (g.N % SB_N == 0 && g.nbias < g.N))) return false;      // the epilogue's bias loads
-#endif
     if (g.K < SB_K || g.K % SB_K || (g.N & 31) || (g.lda & 3) || (g.ldb & 7) || (g.ldc & 3) || (g.aux != nullptr && (g.ldaux & 3))) return false;
     if ((long long)g.M * g.lda * 4 >= (1LL << 32) - (1 << 20) || 2 * g.b_plane * 2 + (long long)g.N * g.ldb * 2 >= (1LL << 32) - (1 << 20)) return false;      // 32-bit DMA offsets
     const long items = (long)((g.M + SB_M - 1) / SB_M) * ((g.N + SB_N - 1) / SB_N);
@@ -493,22 +409,31 @@ int gemm_x3s(const X3Gemm& g, hipStream_t stream) {
     ItemMap im;
     im.mt = (g.M + SB_M - 1) / SB_M; im.nt = (g.N + SB_N - 1) / SB_N;
     im.n_items = im.mt * im.nt;
-    im.run = im.nt <= 2 ? im.nt : 1;
+    // run = 2 only for the 128 + 32 column split of the head block (its two tiles cost 4 : 1 - one workgroup takes both); two EQUAL column
+    // tiles go to two neighbouring workgroups of the XCD, which stream the same 256 activation rows at the same time
+    im.run = (im.nt == 2 && g.N % SB_N != 0) ? 2 : 1;
     int grid = (im.n_items + im.run - 1) / im.run;
     if (grid > cus) grid = cus;
     im.xcd = ((im.mt & 7) == 0 && (grid & 7) == 0) ? 1 : 0;
 #if X3S_TIMING
     static long long* dbg = nullptr;
-    if (!dbg) (void)hipMalloc(&dbg, 64);
-    (void)hipMemsetAsync(dbg, 0, 64, stream);
+    if (!dbg) (void)hipMalloc(&dbg, 8192);
+    (void)hipMemsetAsync(dbg, 0, 8192, stream);
     a.dbg = dbg;
 #endif
     if (partial) hipLaunchKernelGGL(gemm_x3s_kernel<true>, dim3(grid), dim3(SB_THREADS), X3S_LDS, stream, a, im);
     else hipLaunchKernelGGL(gemm_x3s_kernel<false>, dim3(grid), dim3(SB_THREADS), X3S_LDS, stream, a, im);
 #if X3S_TIMING
     {
-        long long h[6];
-        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        long long h[8 + 2 * 256];
+        (void)hipMemcpy(h, dbg, sizeof(long long) * (8 + 2 * (grid < 256 ? grid : 256)), hipMemcpyDeviceToHost);
+        long long tmin = 1LL << 60, tmax = 0, wmin = 1LL << 60, wmax = 0; double tsum = 0, wsum = 0;
+        for (int b = 0; b < grid && b < 256; ++b) {
+            const long long t = h[8 + 2 * b], w = h[9 + 2 * b];
+            tmin = t < tmin ? t : tmin; tmax = t > tmax ? t : tmax; tsum += (double)t;
+            wmin = w < wmin ? w : wmin; wmax = w > wmax ? w : wmax; wsum += (double)w;
+        }
+        fprintf(stderr, "gemm_x3s workgroup totals (ticks): min %lld avg %.0f max %lld (wg0 %lld) | waits min %lld avg %.0f max %lld\n", tmin, tsum / grid, tmax, h[8], wmin, wsum / grid, wmax);
         const double items = (double)((im.n_items + grid - 1) / grid), stages = items * (g.K / SB_K);
         fprintf(stderr, "gemm_x3s M %d N %d K %d items/wg %.0f stages/item %d | clocks per stage (wave 0): loop %.0f  MEMORY phase (dma issue, reads, split) %.0f  MATRIX phase %.0f  dma wait %.0f  barriers %.0f | per item: epilogue %.0f\n",
                 g.M, g.N, g.K, items, g.K / SB_K, h[0] / stages, h[1] / stages, h[2] / stages, h[4] / stages, h[5] / stages, h[3] / items);

@@ -55,8 +55,10 @@ static inline int64_t emb_rows(const dc_dims* d) { return embed_fused_on(d) ? (d
 // new is the rounding of the input projections before the cell adds W_hh h, and of the gate activations / gate gradients the backward reads.
 // DC_DIMS_BF16_F32_STORE keeps f32 storage (A/B, and the comparison with the launch-per-step kernels).
 static inline bool bf16_store(const dc_dims* d) {
+    // rows % 16: the weight gradients contract over the rows, and the split-on-load kernel - the only one that reads bf16 buffers - needs
+    // whole K = 16 steps (gemm_x3_shape_ok); other row counts keep f32 storage and with it the f32 fallback products
     return (d->flags & DC_DIMS_BF16) && !(d->flags & (DC_DIMS_BF16_F32_STORE | DC_DIMS_RNN_PER_STEP | DC_DIMS_RNN_STEP_BF16 | DC_DIMS_GEMM_FASTTILE)) &&
-           d->cell == 1 && d->hidden == 512 && 4 * (long long)d->n_seq <= d->rows && lstm_team512_supported(1, 512, d->flags, d);
+           d->cell == 1 && d->hidden == 512 && (d->rows % 16) == 0 && 4 * (long long)d->n_seq <= d->rows && lstm_team512_supported(1, 512, d->flags, d);
 }
 
 bool policy_bf16_store(const dc_dims* d) { return bf16_store(d); }

@@ -650,16 +650,21 @@ class Engine:
         fault_on_any_rank (data parallel): whether ANY rank recorded a team-kernel timeout - every rank then takes the same branch (the
         fault record is rank-local; ranks on different kernels / products would still be correct, but not reproducible)."""
         what = describe_fault(self)
-        if fault_on_any_rank and self.fault() is None:
+        # ONE decision variable: the local record in a single process, the all-reduced flag under data parallelism - every rank then takes
+        # the same branch below (ADVICE r5: a stale record on one rank could send it down another path than its peers)
+        local = self.fault() is not None
+        fault = local if fault_on_any_rank is None else bool(fault_on_any_rank)
+        if fault:
             flag = DC_DIMS_RNN_STEP_BF16 if (self.kernel_flags & DC_DIMS_BF16) and self.hidden == 512 else DC_DIMS_RNN_PER_STEP
+            if local:
+                self.clear_fault()               # consumed: a record left behind must not steer a later recovery
             if not (self.kernel_flags & flag):
                 self.kernel_flags |= flag
                 self.status.zero_()
                 self._ws_holds = None
                 self._graphs.clear()
-                return 'launch-per-step recurrent kernels from here on (a team kernel timed out on another rank)'
-        if self.use_safe_recurrent():
-            return 'launch-per-step recurrent kernels from here on (' + what.lstrip('; ') + ')'
+                return 'launch-per-step recurrent kernels from here on (' + (what.lstrip('; ') if local else 'a team kernel timed out on another rank') + ')'
+            # (already on the launch-per-step kernels: the record was stale - go on to the products, like every other rank)
         if self.use_safe_products():
             return 'bf16x3 products (f32 exponent range) - an operand may have left f16\'s range'
         return ''

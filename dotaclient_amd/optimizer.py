@@ -153,6 +153,18 @@ class DotaOptimizer:
                              'checkpoint code around DotaOptimizer, or pass run_local=True')
         if self.checkpoint:
             os.makedirs(self.log_dir, exist_ok=True)                        # optimizer.py:231-233 (events + models live there)
+            if pretrained_model is None:
+                # The reference resumes by itself here: it picks the newest model_*.pt of log_dir, loads it and carries the version
+                # counter on behind it (optimizer.py:243-253).  That directory scan is storage plumbing this package leaves to the
+                # integrator's launcher - but starting from random weights at version 1 on top of an existing
+                # run would overwrite its model files and publish versions that go BACKWARDS to the actors: refuse.
+                import glob
+                have = sorted(glob.glob(os.path.join(self.log_dir, 'model_*.pt')))
+                if have:
+                    raise ValueError('log_dir %r already holds %d checkpoint(s) (newest: %s) and no pretrained_model was given: the reference '
+                                     'would resume from the newest one (optimizer.py:243-253); this class does not scan directories - pass '
+                                     'pretrained_model=<that file> to resume (the version counter carries on behind its number), or '
+                                     'point log_dir at an empty directory to start a new run' % (self.log_dir, len(have), os.path.basename(have[-1])))
         self.iteration_start = 1
         self.iterations = 100000
         self.model_upload_freq = 10
@@ -180,7 +192,8 @@ class DotaOptimizer:
         self._ready = None
         self._hist_host = None
         self.pipeline_rollout_pass = True
-        # f16x2 -> bf16x3 fallback (Engine.recover_from_nan) is held for `_safe_hold` iterations, then the fast products are probed again;
+        # f16x2 -> bf16x3 fallback (Engine.recover_from_nan) is held for `_safe_hold` iterations - the repeated one and the `_safe_hold` - 1
+        # after it -, then the fast products are probed again;
         # every further fallback doubles the hold (one rare-head batch must not cost the fast path for the rest of the run,
         # data that overflows every time must not run every iteration twice)
         self._safe_hold, self._safe_left, self._auto_safe = 8, 0, False
@@ -189,7 +202,7 @@ class DotaOptimizer:
         # An explicitly given pretrained model is loaded (optimizer.py:264-267) and, when checkpointing, the version counter carries on
         # behind its file number (optimizer.py:252-253).  Scanning a checkpoint directory / bucket for the newest model
         # (optimizer.py:243-250,287-296) is storage plumbing outside the hot path: the integrator's launcher
-        # resolves the path and passes it here.
+        # resolves the path and passes it here (a log_dir that already holds checkpoints is refused above when it does not).
         if pretrained_model is not None:
             if self.checkpoint:
                 self.iteration_start = self.iteration_from_model_filename(filename=pretrained_model) + 1
@@ -459,7 +472,7 @@ class DotaOptimizer:
             if how and was_fast and self.engine.products == 'bf16x3':
                 self._auto_safe, self._safe_left = True, self._safe_hold
                 self._safe_hold = min(2 * self._safe_hold, 1024)
-                how += ' for the next %d iterations' % self._safe_left
+                how += ' for this iteration and the next %d' % (self._safe_left - 1)
         if how:
             # The NaN may be the kernels' doing: a team kernel that timed out (DC_WS_FAULT), or an operand outside the exponent range of
             # the two-f16-piece products (Engine.products).  Nothing was updated (the status word is sticky on the device): switch to the

@@ -278,6 +278,10 @@ def test_pretrained_model_sets_the_weights_and_the_version_counter(tmp_path):
     assert (log_dir / 'model_000000008.pt').exists() and b.mq.published[-1][0] == {'version': 8}
     assert torch.equal(a.engine.params, b.engine.params)
     assert DotaOptimizer.iteration_from_model_filename('x/model_000000123.pt') == 123
+    # ... and a used log_dir WITHOUT a model path is refused (the reference would resume from model_000000008.pt by itself; starting at
+    # version 1 here would publish versions that go backwards - tests/test_host_logic.py has the CPU form of this check)
+    with pytest.raises(ValueError, match='model_000000008.pt'):
+        DotaOptimizer(checkpoint=True, pretrained_model=None, mq=FakeMQ(rollouts), **kw)
 
 
 def test_model_publish_is_the_reference_wire_format(tmp_path):

@@ -10,9 +10,10 @@ H <= 256 recurrences, the loss, the norms and Adam stay f32.  There is no bf16 r
 separately-stated tolerance"), so the tolerances below ARE the statement:
 
   quantity (one epoch from the same weights, oracle fp32)          tolerance      why
-  values / old log-probs / advantages (scaled by max |ref|)        3e-2           three chained bf16 products, K up to 896: ~2^-9 * sqrt(depth)
-  losses (util.loss_rel_err), entropies, gradient norms            3e-2           means over >= 10^3 steps of the above
-  masked argmax indices                                            >= 97 % equal  near-ties flip under a 2^-9 perturbation of the logits
+  values / old log-probs / advantages (scaled by max |ref|)        1e-2           three chained bf16 products, K up to 896: ~2^-9 * sqrt(depth); measured 2e-3 .. 5e-3
+  losses (util.loss_rel_err), entropies, gradient norms            1e-2           means over >= 10^3 steps of the above; measured <= 4e-3
+  masked argmax indices                                            >= 99.5 % equal  near-ties flip under a 2^-9 perturbation of the logits; measured 99.9 .. 100 %
+  (round 6: the bars were 3e-2 / 97 % - eight times what is measured, VERDICT r5 - and are now ~2x the measured figures)
   post-step parameters (scaled)                                    1e-3           one Adam step moves a parameter by <= lr = 5e-5 whatever the gradient
   bf16 storage against f32 storage of the same kernels             1e-2           one more bf16 rounding of the input projections, the stored gates and gate gradients
   persistent LSTM-512 kernels against the launch-per-step ones      5e-3           same arithmetic (both f32-stored), another summation order
@@ -29,6 +30,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize('cell,hidden,layers,lens,S', [('lstm', 512, 2, [64] * 6, 64), ('lstm', 256, 1, [50, 64, 33], 16), ('gru', 256, 1, [128] * 4, 128),
+                                                       # rows % 16 != 0 on configs[4]'s cell (5 rollouts x 10 steps = 50 rows): the weight gradients contract
+                                                       # over the rows in K = 16 steps, so these dims must keep f32 storage and the f32 fallback
+                                                       # products instead of failing with error 1005 (policy.hip bf16_store())
+                                                       ('lstm', 512, 2, [10] * 5, 10),
                                                        # a sub-batch of BASELINE.json configs[4]'s shard: 64 of its 256 trajectories x 512 steps
                                                        ('lstm', 512, 2, [512] * 64, 512)])
 def test_bf16_path_within_stated_tolerance_of_fp32_oracle(cell, hidden, layers, lens, S):
@@ -38,15 +43,19 @@ def test_bf16_path_within_stated_tolerance_of_fp32_oracle(cell, hidden, layers, 
     ref, _, _ = util.oracle_run(g, rollouts, cell, hidden, layers, epochs=1)
     out, _ = run_hip(g, rollouts, cell, hidden, layers, epochs=1, kernel_flags=E.DC_DIMS_BF16)
     f32, _ = run_hip(g, rollouts, cell, hidden, layers, epochs=1)
+    errs = {}
     for key in ['advantages', 'values'] + ['old_logp_' + k for k in ('enum', 'x', 'y', 'target_unit', 'ability')]:
-        assert util.scaled_err(out[key], ref[key]) < 3e-2, (key, util.scaled_err(out[key], ref[key]))
+        errs[key] = util.scaled_err(out[key], ref[key])
         assert util.scaled_err(f32[key], ref[key]) < 1e-4, key          # the default path on the same inputs: the fp32 bar
     assert np.array_equal(out['returns'], f32['returns'])               # returns do not depend on the network
-    same = (out['argmax'] == ref['argmax'].reshape(out['argmax'].shape)).mean()
-    assert same >= 0.97, same
-    assert util.loss_rel_err(out['ep0_losses'], ref['ep0_losses']) < 3e-2
-    assert util.rel_err(out['ep0_entropies'], ref['ep0_entropies']) < 3e-2
-    assert util.rel_err(out['ep0_grad_norms'], ref['ep0_grad_norms']) < 3e-2
+    same = float((out['argmax'] == ref['argmax'].reshape(out['argmax'].shape)).mean())
+    errs['losses'] = util.loss_rel_err(out['ep0_losses'], ref['ep0_losses'])
+    errs['entropies'] = util.rel_err(out['ep0_entropies'], ref['ep0_entropies'])
+    errs['grad_norms'] = util.rel_err(out['ep0_grad_norms'], ref['ep0_grad_norms'])
+    print('bf16 path vs fp32 oracle:', {k: float('%.3g' % v) for k, v in errs.items()}, 'argmax equal %.5f' % same)
+    for k, v in errs.items():
+        assert v < 1e-2, (k, errs)
+    assert same >= 0.995, same
     assert util.scaled_err(out['ep0_param_samples'], ref['ep0_param_samples']) < 1e-3
     # and it is really a different arithmetic: the bf16 run must NOT meet the fp32 bar
     assert util.scaled_err(out['values'], ref['values']) > 1e-5
@@ -128,17 +137,17 @@ def test_bf16_path_on_the_full_configs4_shard_against_the_oracle_fixture():
         got = np.asarray(out[key]).ravel()
         assert got.size == int(f[key + '_n']), key
         errs[key] = float(np.abs(got[::stride] - f[key]).max() / float(f[key + '_max']))
-        assert errs[key] < 3e-2, (key, errs[key])
+        assert errs[key] < 1e-2, (key, errs[key])
     # returns do not depend on the network: bit-exact against the oracle's
     assert np.array_equal(np.asarray(out['returns']).ravel()[::stride], f['returns'])
     same = float((out['argmax'].reshape(-1, 5)[::16] == f['argmax_rows16']).mean())
     errs['argmax_equal'] = same
-    assert same >= 0.97, same
+    assert same >= 0.995, same
     errs['losses'] = util.loss_rel_err(out['ep0_losses'], f['ep0_losses'])
     errs['entropies'] = util.rel_err(out['ep0_entropies'], f['ep0_entropies'])
     errs['grad_norms'] = util.rel_err(out['ep0_grad_norms'], f['ep0_grad_norms'])
     errs['param_samples'] = util.scaled_err(out['ep0_param_samples'], f['ep0_param_samples'])
     errs['grad_tensor_norms'] = util.scaled_err(out['ep0_grad_summary'][:, 2], f['ep0_grad_summary'][:, 2])
     print('configs[4] full shard, bf16 path vs fp32 oracle fixture:', {k: float('%.3g' % v) for k, v in errs.items()})
-    assert errs['losses'] < 3e-2 and errs['entropies'] < 3e-2 and errs['grad_norms'] < 3e-2 and errs['param_samples'] < 1e-3
-    assert errs['grad_tensor_norms'] < 5e-2
+    assert errs['losses'] < 1e-2 and errs['entropies'] < 1e-2 and errs['grad_norms'] < 1e-2 and errs['param_samples'] < 1e-3
+    assert errs['grad_tensor_norms'] < 2e-2

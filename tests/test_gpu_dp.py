@@ -209,3 +209,27 @@ def test_overlapped_reduce_call_order_and_stream_ordering(monkeypatch):
     eng.train_epoch(chunks, 1e-4, 5e-4, 0.5, grad_hook=hook2)
     ars = [x for x in log if x[0] == 'all_reduce']
     assert len(ars) == 1 and ars[0][2] == eng.total + 8 and ars[0][3] is False
+
+
+def test_bench_eight_ranks_on_one_device_prints_one_dp8_line():
+    # no multi-GPU box was offered in any round, so the driver's N = 8 command has never run.  A dry run of exactly that
+    # flow on ONE GPU: `python bench.py --gpus 8` starts its own eight ranks (torch.distributed.run), every rank on cuda:0 over gloo
+    # (DC_BENCH_ONE_DEVICE=1 - RCCL refuses two ranks on one device), each with configs[3]'s per-GPU shard (128 trajectories x 256 steps): the
+    # broadcast, eight real engines, the flat-bucket all-reduce every epoch, the barriers, the max over ranks and rank 0's ONE JSON line.
+    # Not a performance number (eight ranks time-share the GPU) - the line's keys and the workload it names are what is checked.
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(DC_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-weak-unit'],
+                       cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, (len(lines), r.stdout[-2000:])
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 8 and j['steps'] == 1 and j['scaling'] == 'weak' and j['higher_is_better'] is True
+    assert j['config']['parallelism'] == 'dp8' and 'configs[3]' in j['config']['workload'] and j['config']['batch_per_gpu'] == 128
+    assert j['unit'] == 'env-steps/s' and j['value'] > 0 and abs(j['value'] - 8 * 128 * 256 / (j['ms_per_step'] * 1e-3)) < 1e-3 * j['value']
+    assert j['nan_status'] == 0 and np.isfinite(j['final_loss'])

@@ -341,13 +341,21 @@ def test_sparse_pool_backward_matches_dense(lens):
         outs[mode] = (g, res.cpu().numpy().copy(), eng.params.cpu().numpy().copy())
     # All variants evaluate the relu mask of the first layer with exact-f32 MFMAs (a first version of the on-chip kernel took the forward's
     # two-f16-piece sequence: one pre-activation in ~10^6 got the other sign, a whole term of ONE hidden unit's row of dW1 / db1 - 3.6e-3 of
-    # the largest entry at 1 536 steps).  The check stays tolerant of such a flip (different f32 summation orders can still produce one):
-    # every tensor at 2e-5, except that up to two hidden units' rows of dW1 / db1 may sit at 1e-2.
+    # the largest entry at 1 536 steps).  Two exact-f32 evaluations in different summation orders can still disagree on the sign of a
+    # pre-activation that is zero to f32 round-off - and only there.  So: every tensor at 2e-5; a hidden unit's row of
+    # dW1 / db1 may exceed that ONLY IF that unit has a pre-activation within f32 round-off of zero somewhere in the batch (float64
+    # evaluation of z = W1 x + b1 over all unit records: |z| < 4e-6, i.e. ~30 ulp of the O(1) terms that sum to it), and then stays below 1e-2.
+    sd = synth.init_state_dict(7, 'lstm', 128, 1)
+    units = batch.obs.cpu().double()[:, 3:].reshape(-1, 12)
+    z = units @ sd['affine_unit_basic_stats.weight'].double().t() + sd['affine_unit_basic_stats.bias'].double()
+    may_flip = (z.abs().min(dim=0).values < 4e-6).numpy()          # [128]: hidden units with a pre-activation on the relu's kink
     for n in outs['0'][0]:
         a, b = outs['1'][0][n], outs['0'][0][n]
         if n.startswith('affine_unit_basic_stats'):
             row_err = np.abs(a - b).reshape(128, -1).max(axis=1) / np.abs(b).max()
-            assert (row_err >= 2e-5).sum() <= 2 and row_err.max() < 1e-2, (n, np.sort(row_err)[-4:])
+            off = row_err >= 2e-5
+            assert not (off & ~may_flip).any(), (n, 'rows off without a pre-activation on the kink', np.nonzero(off & ~may_flip)[0], np.sort(row_err)[-4:])
+            assert row_err.max() < 1e-2, (n, np.sort(row_err)[-4:])
         else:
             assert util.scaled_err(a, b) < 2e-5, (n, util.scaled_err(a, b))
     assert util.scaled_err(outs['1'][1][:11], outs['0'][1][:11]) < 2e-5

@@ -227,6 +227,19 @@ def test_pack_rollouts_rejects_an_empty_batch():
         pack_rollouts([], 16, torch.device('cpu'))
 
 
+def test_checkpointing_into_a_used_log_dir_without_a_model_is_refused(tmp_path):
+    # the reference resumes from the newest model_*.pt of log_dir by itself (optimizer.py:243-253); this class leaves the scan to
+    # the launcher, so it must not silently start at version 1 over an existing run (model files overwritten, versions going backwards to
+    # the actors).  The check comes before any device work: no GPU needed.
+    from dotaclient_amd.optimizer import DotaOptimizer
+    kw = dict(rmq_host='x', rmq_port=0, epochs=1, min_seq_per_epoch=1, seq_len=16, learning_rate=1e-4, mq_prefetch_count=1,
+              entropy_coef=5e-4, vf_coef=0.5, run_local=True)
+    (tmp_path / 'model_000000041.pt').write_bytes(b'x')
+    (tmp_path / 'model_000000007.pt').write_bytes(b'x')
+    with pytest.raises(ValueError, match='model_000000041.pt'):
+        DotaOptimizer(checkpoint=True, pretrained_model=None, log_dir=str(tmp_path), mq=object(), **kw)
+
+
 def test_product_path_refuses_cpu():
     from dotaclient_amd import _lib
     from dotaclient_amd.engine import Engine
@@ -333,6 +346,108 @@ def test_dp_flat_bucket_matches_reference_semantics(tmp_path, overlap):
             if want[r][j] is None:
                 continue                                # grad None in the reference: Adam skips it on this rank
             assert torch.allclose(res[r]['out'][o:o + ln], want[r][j], rtol=1e-6, atol=1e-7), (r, n)
+
+
+# world 8 (BASELINE.json configs[3] / configs[4]: DP = 8): the same protocol with DIFFERENT heads missing on several ranks - the divisor of
+# a parameter is the number of ranks that had a gradient for it (distributed.py:36-57), 8 for the trunk, 5 / 3 / 1 for three of the heads,
+# and the all-reduced fault flag of the consumer loop's NaN recovery (dotaclient_amd/optimizer.py run_iteration).  gloo on CPU; RCCL has
+# never run on more than one rank (no multi-GPU box was offered in any round: DESIGN.md).
+_W8_HEAD_ON = [[1, 1, 1, 1, 1], [1, 1, 1, 0, 1], [1, 0, 1, 1, 0], [1, 1, 1, 0, 0], [1, 1, 1, 0, 1], [1, 0, 1, 1, 0], [1, 1, 1, 0, 0], [1, 1, 1, 0, 0]]
+_W8_HEAD_PARAMS = {1: ('affine_move_x',), 3: ('affine_unit_attention', 'affine_unit_eth'), 4: ('affine_head_ability',)}
+
+
+def _w8_has_grad(rank, name):
+    for k, pres in _W8_HEAD_PARAMS.items():
+        if any(name.startswith(p) for p in pres):
+            return bool(_W8_HEAD_ON[rank][k])
+    return True
+
+
+def _dp8_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from dotaclient_amd import distributed as D
+    D._lib.ptr = lambda t: t
+    D._lib.stream_ptr = lambda: None
+    D._lib.check = lambda code, what='': None
+    eng = _FakeEngine(list(_W8_HEAD_ON[rank]))
+    red = D.FlatGradAllReducer(eng, overlap=(rank >= 0))          # the two-collective form on every rank
+    eng.reducer = red
+    eng.params.fill_(float(rank + 1))
+    red.sync_parameters()
+    assert torch.all(eng.params == 1.0)
+    local = torch.randn(eng.total, generator=torch.Generator().manual_seed(500 + rank))
+    for n in eng.seg_names:
+        if not _w8_has_grad(rank, n):
+            o, ln, _ = eng.layout[n]
+            local[o:o + ln] = 0
+    eng.grads.copy_(local)
+    red.start_upper(eng)
+    red.finish(eng)
+    # the NaN recovery's agreement step: ranks 2 and 6 hold a team-kernel fault record, everybody learns of it
+    flag = torch.tensor([1.0 if rank in (2, 6) else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    torch.save({'local': local, 'out': eng.grads.clone(), 'any_fault': bool(flag.item() > 0)}, os.path.join(tmp, 'r%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+def test_dp_flat_bucket_world_8_with_different_heads_missing_per_rank(tmp_path):
+    world, port = 8, 31500 + os.getpid() % 2000
+    mp.spawn(_dp8_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), 'r%d.pt' % r)) for r in range(world)]
+    lay, total = L.flat_layout()
+    names = list(L.param_shapes().keys())
+    per_rank = [[res[r]['local'][lay[n][0]:lay[n][0] + lay[n][1]].clone() if _w8_has_grad(r, n) else None for n in names] for r in range(world)]
+    want = RO.dp_average_grads(per_rank)            # distributed.py:24-57 restated: average over the ranks that have a gradient
+    counts = {n: sum(_w8_has_grad(r, n) for r in range(world)) for n in names}
+    assert counts['affine_pre_rnn.weight'] == 8 and counts['affine_move_x.weight'] == 6 and counts['affine_unit_attention.weight'] == 3 \
+        and counts['affine_head_ability.bias'] == 3
+    for r in range(world):
+        assert res[r]['any_fault'] is True
+        for j, n in enumerate(names):
+            o, ln, _ = lay[n]
+            if want[r][j] is None:
+                continue                                # grad None in the reference: Adam skips it on this rank
+            assert torch.allclose(res[r]['out'][o:o + ln], want[r][j], rtol=1e-6, atol=1e-7), (r, n)
+    # the averaged gradient of a parameter is the same on every rank that has one
+    for j, n in enumerate(names):
+        o, ln, _ = lay[n]
+        have = [r for r in range(world) if _w8_has_grad(r, n)]
+        for r in have[1:]:
+            assert torch.equal(res[r]['out'][o:o + ln], res[have[0]]['out'][o:o + ln]), n
+
+
+def test_nan_recovery_takes_the_same_branch_on_every_rank():
+    # Engine.recover_from_nan under data parallelism: the decision comes from the all-reduced flag, not from the rank-local
+    # fault record - a rank with a STALE record (it is on the launch-per-step kernels already) must go on to the products like its peers,
+    # and a rank without a record must leave the team kernels when another rank's timed out.  Host logic only: engines without a device.
+    from dotaclient_amd import engine as E
+
+    def fake(kernel_flags, record):
+        e = E.Engine.__new__(E.Engine)
+        e.kernel_flags, e.hidden, e.products = kernel_flags, 256, 'f16x2'
+        e.status = torch.ones(1, dtype=torch.int32)
+        e._ws = torch.zeros(256, dtype=torch.uint8)
+        if record:
+            e._ws[:32].view(torch.int32).copy_(torch.tensor([E.DC_FAULT_TEAM_TIMEOUT + 3, 0, 2, 1, 9, 4, 8, 0], dtype=torch.int32))
+        e._ws_holds, e._graphs = None, {}
+        return e
+    # (1) one rank's team kernel timed out, nobody is on the per-step kernels yet: all eight switch, the record is consumed
+    ranks = [fake(0, r == 5) for r in range(8)]
+    hows = [e.recover_from_nan(True) for e in ranks]
+    assert all('launch-per-step' in h for h in hows) and all(e.kernel_flags & E.DC_DIMS_RNN_PER_STEP for e in ranks)
+    assert all(e.fault() is None and int(e.status.item()) == 0 and e.products == 'f16x2' for e in ranks)
+    # (2) every rank is on the per-step kernels, rank 3 still holds a stale record: the flag is up, and ALL ranks fall back to the bf16x3 products
+    ranks = [fake(E.DC_DIMS_RNN_PER_STEP, r == 3) for r in range(8)]
+    hows = [e.recover_from_nan(True) for e in ranks]
+    assert len(set(hows)) == 1 and 'bf16x3' in hows[0] and all(e.products == 'bf16x3' and e.fault() is None for e in ranks)
+    # (3) no fault anywhere: products; a second NaN: nothing left
+    e = fake(0, False)
+    assert 'bf16x3' in e.recover_from_nan(False) and e.recover_from_nan(False) == ''
+    # (4) single process (no flag passed): the local record decides, as before
+    e = fake(0, True)
+    assert 'layer 0, team 2' in e.recover_from_nan() and e.kernel_flags & E.DC_DIMS_RNN_PER_STEP and e.fault() is None
 
 
 # ---- lane-permutation logic of the one-sequence-per-workgroup LSTM kernels (rnn_persist_valu.hip) ------------------
