@@ -100,8 +100,8 @@ def pmc_traffic(path, kernel, workload_key):
                       'lstm_fwd_team': ['team_mfma_fwd_col', 'team_mfma_fwd', 'team8_fwd', 'rnn_team_fwd'], 'lstm_bwd_team': ['team_mfma_bwd', 'team8_bwd', 'rnn_team_bwd'],
                       'lstm_fwd_persist': ['lstm_fwd_valu'], 'lstm_bwd_persist': ['lstm_bwd_valu'],
                       'gemm_f32_dW': ['gemm_x3'], 'gemm_f32_fwd': ['gemm_fast', 'gemm_x3'], 'gemm_f32_dX': ['gemm_fast', 'gemm_x3']}
-    if PRODUCTS == 'f16x2':       # every dense product runs the split-on-load kernel then (one PMC row: the average over its launches)
-        region_kernels['gemm_f32_fwd'] = region_kernels['gemm_f32_dX'] = ['gemm_x3', 'gemm_fast']
+    if PRODUCTS == 'f16x2':       # x W^T / dy W: the row-streaming kernel (gemm_x3s.hip, round 6; one PMC row: the average over its launches), else the split-on-load kernel
+        region_kernels['gemm_f32_fwd'] = region_kernels['gemm_f32_dX'] = ['gemm_x3s', 'gemm_x3', 'gemm_fast']
     for cand in region_kernels.get(kernel, [kernel]):
         if isinstance(cand, tuple):                   # a region of several kernels, each launched once per pass: the sum
             ks = [j.get('kernels', {}).get(c + '_kernel') for c in cand]

@@ -6,20 +6,28 @@
 // Why another kernel.  gemm_x3.hip (PREC 4) sits at 0.23-0.27 of the three-MFMA ceiling with its matrix pipes ~30 % busy: per K = 16 step
 // a workgroup stages both operands through registers (split VALU + ds_write at ~80 B/clk) and meets at a barrier after only twelve MFMAs
 // per wave; LDS stores, LDS reads, VALU and MFMA each take about as long as the others and do not overlap (profiles/r05/
-// gemm_x3_ablation.txt).  This kernel removes the LDS stores and the register staging altogether and does twice the MFMAs per barrier:
+// gemm_x3_ablation.txt).  Here (measurements of every step on the way: profiles/r06/gemm_x3s_development.txt):
 //   * BOTH operands go global -> LDS by DMA (global_load_lds_dwordx4: no VGPRs, no ds_write): the activations as the f32 they are in HBM
 //     (FastTile's lane-linear [row][32 k] image, XOR-swizzled on the source side), the weights as their pre-split f16 planes
-//     (PlaneTile<128, 2>);
+//     (PlaneTile<128, 2>).  The DMA is issued from inline asm and counted by hand: hipcc puts a vmcnt(0) in front of every ds_read that
+//     follows a builtin LDS-DMA it knows of - the whole queue drained every stage (tools/x3s_isa_check.py keeps its waits out of the K loop);
 //   * the eight waves of a workgroup split the 256 ROWS of its tile and each takes all 128 columns: an activation element is read from
-//     LDS, scaled and split into its two f16 pieces by exactly ONE wave (16 elements per lane and stage), in registers, right before the
-//     MFMAs that consume it - the weight fragments need no arithmetic at all;
-//   * three LDS stages of 48 KB (K = 32 each), DMA two stages ahead, ONE raw s_barrier per stage with a COUNTED vmcnt (the DMA of the
-//     stage after next stays in flight across the barrier), 24 MFMAs per wave and barrier;
-//   * the MFMA operands are swapped (D = W_tile x_tile^T): a lane then holds FOUR CONSECUTIVE output columns of one output row in four
-//     consecutive accumulator registers - the epilogue is bias / relu / mask on registers and 16-byte stores, no LDS round trip, so
-//     the next item's first two stages are already in flight while the tile is written;
-//   * persistent workgroups (one per CU: 144 KB of LDS, two waves per SIMD) walk the (row tile, column tile) items of an XCD in
-//     row-tile order, so the column tiles of a row tile meet in that XCD's L2.
+//     LDS, scaled and split into its two f16 pieces by exactly ONE wave (16 elements per lane and stage), in registers - the weight
+//     fragments need no arithmetic at all;
+//   * three LDS stages of 48 KB (K = 32 each), DMA two stages ahead, raw s_barrier with COUNTED vmcnt (the DMA of the stage after next
+//     stays in flight across the barriers), 24 MFMAs per wave and stage;
+//   * TWO WAVE GROUPS HALF A STAGE APART: a stage is a MEMORY phase (DMA pieces, fragment reads into registers, split) and a MATRIX phase
+//     (24 MFMAs from registers, s_setprio 1); waves 4-7 run one barrier behind waves 0-3, so the two waves of a SIMD are always in
+//     opposite phases - its matrix pipe belongs to one while the other issues its DMA and LDS reads (all eight in step: ~170 cycles per
+//     DMA piece blocked behind the others' on the 64 B/clk address path with nobody issuing MFMAs, ~3 700 cycles per stage for 1 536 of
+//     matrix work);
+//   * D = x_tile W_tile^T leaves one output column per lane and one row per register: the epilogue is scale - bias - relu - mask on the
+//     accumulators and stores of whole 128-byte lines (a half-wave each), no LDS round trip; the bias comes from an LDS table filled once;
+//   * persistent workgroups (one per CU: all 160 KB of LDS, two waves per SIMD) walk the (row tile, column tile) items of an XCD in
+//     row-tile order, so the column tiles of a row tile meet in that XCD's L2 (HBM traffic 1.15 x the algorithmic bytes).
+// What bounds it now: the MATRIX phases (2 x ~1 140 ticks of ~3 000 per stage, at the socket's power cap) and the epilogue - the 64 KB a
+// wave group writes per item leave the CU at ~12 bytes per clock (5 400 ticks: 30-45 % of a K = 256 item) whatever the store instructions;
+// staggered workgroup starts and stores trickled out of parked registers under the next item's MFMAs were measured and not kept.
 // Arithmetic is gemm_x3.hip's PREC 4 exactly: x sa = h + m (two f16 pieces), a b = (hh + hm + mh) / (sa sb), f32 accumulate.
 #include <cstdio>
 #include <type_traits>

@@ -249,6 +249,7 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
         DC_TRY(linear(x, in, P.p(pb + 0), wp.fwd(wp.ih[l]), G * H, G * H, P.p(pb + 2), 0, w.fl(l, DC_WSL_GATES), G * H, bs, bs));
         RnnStepArgs a{};
         a.bf16_store = bs;
+        a.fwd_only = (d->flags & DC_DIMS_FWD_ONLY) ? 1 : 0;
         a.h0 = h0 ? h0 + (size_t)l * B * H : nullptr;
         a.c0 = (c0 && d->cell == 1) ? c0 + (size_t)l * B * H : nullptr;
         a.seq_off = seq_off; a.seq_len = seq_len; a.n_seq = B; a.H = H;

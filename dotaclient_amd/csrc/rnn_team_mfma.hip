@@ -215,6 +215,9 @@ __device__ __forceinline__ constexpr int tn_korder(int kk) { return 16 * (kk & 1
 
 template <int CELL>     // 1: LSTM, 0: GRU
 __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_col_kernel(RnnStepArgs p, u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
+    // fwd_only (DC_DIMS_FWD_ONLY: the optimizer's no-grad rollout pass, optimizer.py:344-385): what only a backward would read - the activated
+    // gates, h / c of the step before - is not written (562 -> ~135 MB per launch: h and c go out, the gate rows stay as the input projection left them)
+    const bool keep = p.fwd_only == 0;
     constexpr bool LSTM = CELL == 1;
     constexpr int H = TM_H, G = LSTM ? 4 : 3, GH = G * H;
     __shared__ __attribute__((aligned(16))) float h_lds[2][4 * TN_HLD];
@@ -283,11 +286,11 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_col_kernel(RnnSte
             auto hook = [&](auto K) {
                 constexpr int k = decltype(K)::value;          // 0 .. 63
                 if constexpr (k >= 1 && k <= G) xnext[k - 1] = tm_ld(lp + (k - 1) * H);
-                else if constexpr (k >= 8 && k < 8 + G) tm_st(gs + (k - 8) * H, sv[k - 8]);
-                else if constexpr (k == 12) tm_st(cs, sv[LSTM ? 4 : 3]);
+                else if constexpr (k >= 8 && k < 8 + G) { if (keep) tm_st(gs + (k - 8) * H, sv[k - 8]); }
+                else if constexpr (k == 12) { if (keep || LSTM) tm_st(cs, sv[LSTM ? 4 : 3]); }       // (the GRU's W_hn h + b_hn: the backward's only)
                 else if constexpr (k == 13) tm_st(hs, sv[5]);
-                else if constexpr (k == 14 && LSTM) tm_st(cp, svp0);
-                else if constexpr (k == 15) tm_st(hp, svp1);
+                else if constexpr (k == 14 && LSTM) { if (keep) tm_st(cp, svp0); }
+                else if constexpr (k == 15) { if (keep) tm_st(hp, svp1); }
             };
             f32x4 pa[4];
             FwdProductCol<H>::run(pa, w, lds_addr(&h_lds[cur][(lane & 3) * TN_HLD + (lane >> 2) * 16]), hook);
@@ -335,12 +338,14 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_col_kernel(RnnSte
             if (!step(t, xc, xn, std::integral_constant<int, 0>{})) { failed = true; break; }
             if (t + 1 < tmax && !step(t + 1, xn, xc, std::integral_constant<int, 1>{})) { failed = true; break; }
         }
+        if (keep) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) p.gates[st_g + g * H] = sv[g];
-        if constexpr (LSTM) { p.cseq[st_s] = sv[4]; p.cprev[st_p] = svp0; }
-        else p.hn[st_s] = sv[3];
+            for (int g = 0; g < G; ++g) p.gates[st_g + g * H] = sv[g];
+        }
+        if constexpr (LSTM) { p.cseq[st_s] = sv[4]; if (keep) p.cprev[st_p] = svp0; }
+        else if (keep) p.hn[st_s] = sv[3];
         p.hseq[st_s] = failed ? __builtin_nanf("") : sv[5];
-        p.hprev[st_p] = svp1;
+        if (keep) p.hprev[st_p] = svp1;
         __syncthreads();
     }
 }

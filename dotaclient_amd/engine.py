@@ -51,6 +51,7 @@ DC_DIMS_TEAM4 = 1048576     # ... never (by itself the library takes them for 65
 DC_DIMS_POOL16_VALU = 2097152   # keep the sparse VALU max-pool backward in f16x2 mode too (default there: csrc/embed_pool16m.hip)
 DC_DIMS_BF16_F32_STORE = 4194304   # configs[4]: keep the gate buffers f32 (default on that path since round 5: bf16 storage)
 DC_DIMS_GEMM_TILE128 = 8388608   # keep x W^T / dy W on the 128 x 128 split-on-load kernel (default since round 6: csrc/gemm_x3s.hip's row-streaming kernel)
+DC_DIMS_FWD_ONLY = 16777216      # dc_policy_forward: no backward will follow this pass (the no-grad rollout pass)
 DC_DIMS_F16X2 = 131072   # f32-grade products from two f16 pieces (three MFMAs) instead of three bf16 pieces (six): include/dotaclient_hip.h
 
 WS_FIXED = ['FAULT', 'BASIC', 'EMB', 'DEMB', 'XCAT', 'AMAX', 'PRE', 'HEADOUT', 'TU', 'DHEADOUT', 'DTU', 'DPRE', 'DXCAT',
@@ -715,11 +716,15 @@ class Engine:
         return self._ws[offs[idx]:nxt].view(dtype)
 
     # ---- C-ABI calls -----------------------------------------------------------------------------
-    def forward(self, batch, h0=None, c0=None, want_final=False, lazy_tu=False, hT_out=None, cT_out=None):
+    def forward(self, batch, h0=None, c0=None, want_final=False, lazy_tu=False, hT_out=None, cT_out=None, fwd_only=False):
+        """fwd_only: DC_DIMS_FWD_ONLY - no backward will read this pass (the no-grad rollout pass): kernels skip what only a backward needs."""
         d = self.dims(batch, lazy_tu)
+        if fwd_only:
+            d = DcDims(d.cell, d.hidden, d.layers, d.n_seq, d.max_len, d.flags | DC_DIMS_FWD_ONLY, d.rows)
         ws = self._workspace(d)
-        # what the workspace's activations are a function of (Engine.reuse_rollout_forward compares it)
-        self._ws_holds = (batch.rows, batch.obs.data_ptr(), self._param_version, bool(lazy_tu), self.kernel_flags, self.products)
+        # what the workspace's activations are a function of (Engine.reuse_rollout_forward compares it; a forward-only pass leaves
+        # nothing a backward could start from)
+        self._ws_holds = None if fwd_only else (batch.rows, batch.obs.data_ptr(), self._param_version, bool(lazy_tu), self.kernel_flags, self.products)
         hT = cT = None
         if want_final:       # (hT_out / cT_out: caller-owned result buffers - nothing is allocated, e.g. inside a graph capture)
             hT = hT_out if hT_out is not None else device_empty((self.layers, batch.n_seq, self.hidden), torch.float32, self.device)
@@ -787,7 +792,8 @@ class Engine:
         if batch.ready is not None:                   # the batch's H2D copies ran on a side stream
             torch.cuda.current_stream(self.device).wait_event(batch.ready)
             batch.ready = None
-        d, _, _ = self.forward(batch, lazy_tu=True)
+        # (with reuse_rollout_forward the first epoch back-propagates THIS pass's activations: then it is not forward-only)
+        d, _, _ = self.forward(batch, lazy_tu=True, fwd_only=not self.reuse_rollout_forward)
         batch.old_logp, batch.values, batch.argmax = self.select_logp(d, batch)
         dev = self.device
         batch.adv, batch.ret = ops.gae_scan(batch.rew, batch.values, batch.seq_off, batch.seq_len, batch.max_len, gamma, lam,

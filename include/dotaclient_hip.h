@@ -190,6 +190,12 @@ typedef struct dc_dims {
  *                            operands by LDS-DMA, 256 x 128 tiles, eight waves that split the rows, epilogue from the registers); this flag
  *                            keeps them on the 128 x 128 split-on-load kernel of csrc/gemm_x3.hip (A/B, and the parity test between the two). */
 #define DC_DIMS_GEMM_TILE128 8388608
+/*   DC_DIMS_FWD_ONLY       : dc_policy_forward for a pass that NO dc_policy_backward will follow (the optimizer's no-grad rollout pass,
+ *                            optimizer.py:344-385): kernels may skip what only a backward reads.  Used by the H = 256 MFMA team forward (the
+ *                            activated gates and the previous step's h / c are not written: 562 -> ~135 MB per launch); DC_WS_HEADOUT, DC_WS_TU, hT / cT
+ *                            and what dc_chunk_initial_state / dc_select_logp read are complete.  Calling dc_policy_backward after such a
+ *                            forward is a caller error (the gradients would be garbage, not an error code). */
+#define DC_DIMS_FWD_ONLY 16777216
 
 /* index into poff[]; policy.py:54-75 names in comments */
 enum dc_param_index {

@@ -217,6 +217,30 @@ def test_dense_product_kernels_both_match(which, case, cell, hidden, layers):
         compare(out, ref, n_ep, ref['param_names'])
 
 
+@pytest.mark.parametrize('cell,B', [('lstm', 160), ('gru', 160), ('lstm', 24)])
+def test_forward_only_rollout_pass_is_bit_identical(cell, B):
+    # DC_DIMS_FWD_ONLY (round 6): the no-grad rollout pass (optimizer.py:344-385) tells the library that no backward will read it; the H = 256
+    # MFMA team forward (more than 128 sequences) then skips the stores only a backward needs (activated gates, previous h / c).  Everything
+    # the pass is FOR - old log-probs, values, masked argmax, advantages, the chunks' initial states - must not change by a bit; 24
+    # sequences: kernels that ignore the flag.
+    from dotaclient_amd.engine import Engine, pack_rollouts
+    dev = torch.device('cuda:0')
+    S = 64
+    rollouts = synth.make_rollouts(77, [S * 2] * B)            # two chunks per rollout: the carried state matters
+    outs = []
+    for reuse in (False, True):                                 # reuse_rollout_forward = True keeps the full forward (its first epoch reads it)
+        eng = Engine(cell, 256, 1, dev)
+        eng.reuse_rollout_forward = reuse
+        eng.load_state_dict(synth.init_state_dict(7, cell, 256, 1))
+        batch = pack_rollouts(rollouts, S, dev)
+        chunks = eng.rollout_pass(batch, S)
+        outs.append([batch.old_logp.clone(), batch.values.clone(), batch.argmax.clone(), batch.adv.clone(), chunks.h0.clone()] +
+                    ([chunks.c0.clone()] if cell == 'lstm' else []))
+        assert eng.fault() is None
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('cell,hidden,B', [('lstm', 256, 128), ('gru', 256, 64)])
 def test_row_streaming_products_agree_with_the_tile_kernel(cell, hidden, B):
     # round 6: at bench-sized batches the x W^T / dy W products of the default arithmetic run on the row-streaming kernel
