@@ -137,7 +137,9 @@ __device__ __forceinline__ void dma_piece(const void* base, unsigned voff, unsig
 static_assert(SA_PIECES == 4 && SB_PIECES == 2, "dma_stage is written for 4 + 2 pieces per wave");
 
 // PARTIAL: N is not a multiple of 128 - the last column tile multiplies only its live 32-column blocks
-template <bool PARTIAL>
+// EPI: what the epilogue does besides scale + bias - compile-time, because it is the epilogue's instruction count that costs (below)
+enum { X3S_PLAIN = 0, X3S_RELU = 1, X3S_MASK = 2 };
+template <bool PARTIAL, int EPI>
 __global__ __launch_bounds__(SB_THREADS, 2) void gemm_x3s_kernel(X3SArgs p, ItemMap im) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -235,66 +237,66 @@ __global__ __launch_bounds__(SB_THREADS, 2) void gemm_x3s_kernel(X3SArgs p, Item
 
     int buf = 0;
     f32x16 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     int nj = PARTIAL ? min(4, (p.N - n_blk + 31) >> 5) : 4;
 
-    // Epilogue straight from the accumulators (third form).  With D = x_tile W_tile^T the 32x32 MFMA leaves output column
-    // n0 + (lane & 31) in every lane and row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) in register reg: one store instruction writes two
-    // whole 128-byte lines (one per half-wave), 64 instructions per wave and item, no LDS round trip, no dependent chain longer than
-    // scale - bias - relu - store.  (The forms before it, both with D = W x^T - a lane holding four consecutive columns of one row: 16-byte stores of one row per lane
-    // 7 500 ticks per wave and item, the L2 taking 32-byte pieces one request each; through 4 KB LDS images as whole lines, eight rows per
-    // instruction, 5 400.  This form: 5 400 as well - the 64 KB a wave group writes per item leave the CU at ~12 bytes per clock whatever the
-    // instructions, whether the workgroups start staggered or not; and trickled out of parked registers under the next item's MFMAs the
-    // stores slowed the K loop more than they saved (gates 160 -> 190 us): the DMA waits count them - vmcnt is in order.)
-    // The bias comes from an LDS table of the whole vector (the 16 KB behind the stage buffers), filled once per workgroup.
+    // Epilogue straight from the accumulators.  With D = x_tile W_tile^T the 32x32 MFMA leaves output column n0 + (lane & 31) in every lane
+    // and row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) in register reg: one store instruction writes two whole 128-byte lines (one per
+    // half-wave), 64 per wave and item, no LDS round trip.  What an epilogue costs is its VALU instructions - 5 400 ticks per wave and item
+    // for ~11 per element (two 64-bit multiplies for the address of every store, a compare + select for a mask that is not there, a select
+    // for a relu that is not asked for; the forms before this one, with D = W x^T: 16-byte stores of one row per lane 7 500, whole lines
+    // through 4 KB LDS images 5 400 - phase clocks in profiles/r06/gemm_x3s_development.txt, where staggered workgroup starts and stores
+    // trickled out of parked registers are recorded as well: no gain / slower).  So: relu / mask are compile-time (EPI), a row's address
+    // is a SCALAR base (advanced on the SALU) plus ONE per-lane offset for the whole kernel, the accumulators are not zeroed (the next
+    // item's first MFMAs take a zero C operand): a fused multiply-add (+ a max) per element.  The bias comes from an LDS table of the
+    // whole vector (the 16 KB behind the stage buffers), filled once per workgroup.  Rows past M (the last row tile): the guarded form.
     const float* bias_lds = reinterpret_cast<const float*>(smem + SB_NST * SSTAGE_BYTES);
-    auto epilogue_d = [&](int em, int en, auto full_tag) __attribute__((always_inline)) {
-        constexpr bool FULL = decltype(full_tag)::value;       // every row of the tile is inside M: no per-row guards (a workgroup-uniform fact)
+    const unsigned lane_c = (unsigned)(4 * fg) * (unsigned)p.ldc + (unsigned)fr;            // this lane's element offset inside a wave's 32-row block
+    const unsigned lane_x = (unsigned)(4 * fg) * (unsigned)p.ldaux + (unsigned)fr;
+    auto epilogue = [&](int em, int en, bool) __attribute__((always_inline)) {
         const int enj = PARTIAL ? min(4, (p.N - en + 31) >> 5) : 4; // live 32-column blocks (N % 32 == 0: a block is all in or all out)
         float bj[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bj[j] = p.bias != nullptr ? bias_lds[min(en + j * 32 + fr, p.N - 1)] : 0.f;
-        const int row0 = em + wave * 32 + 4 * fg;
+        if (em + SB_M <= p.M) {
+            float* const cb = p.C + (size_t)(em + wave * 32) * p.ldc + en;                 // workgroup-uniform: scalar registers
+            const float* const xb = EPI == X3S_MASK ? p.aux + (size_t)(em + wave * 32) * p.ldaux + en : nullptr;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (PARTIAL && j >= enj) continue;
-            const int col = en + j * 32 + fr;
-            float mv[16];
+            for (int j = 0; j < 4; ++j) {
+                if (PARTIAL && j >= enj) continue;
+                float mv[16];
+                if constexpr (EPI == X3S_MASK) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mv[r] = 1.f;
-            if (p.aux != nullptr) {
+                    for (int r = 0; r < 16; ++r) mv[r] = (xb + (size_t)((r & 3) + 8 * (r >> 2)) * p.ldaux + j * 32)[lane_x];
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + (r & 3) + 8 * (r >> 2);
-                    mv[r] = p.aux[(size_t)(FULL ? row : min(row, p.M - 1)) * p.ldaux + col];
+                    float v = fmaf(acc[j][r], p.inv, bj[j]);
+                    if constexpr (EPI == X3S_RELU) v = relu_nan(v);          // NaN-propagating (common.h)
+                    if constexpr (EPI == X3S_MASK) v = mv[r] > 0.f ? v : 0.f;
+#ifdef X3S_NO_STORE          // ablation build: timing only
+                    if (v == 12345.678f)
+#endif
+                    (cb + (size_t)((r & 3) + 8 * (r >> 2)) * p.ldc + j * 32)[lane_c] = v;
                 }
             }
+        } else {
+            const int row0 = em + wave * 32 + 4 * fg;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + (r & 3) + 8 * (r >> 2);
-                float v = acc[j][r] * p.inv + bj[j];
-                if (p.relu) v = relu_nan(v);          // NaN-propagating (common.h)
-                v = mv[r] > 0.f ? v : 0.f;
-                float* c = p.C + (size_t)(FULL ? row : min(row, p.M - 1)) * p.ldc + col;
-#ifdef X3S_NO_STORE          // ablation build: timing only
-                if (v == 12345.678f) *c = v;
-#else
-                if (FULL || row < p.M) *c = v;
-#endif
+            for (int j = 0; j < 4; ++j) {
+                if (PARTIAL && j >= enj) continue;
+                const int col = en + j * 32 + fr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + (r & 3) + 8 * (r >> 2), rowc = min(row, p.M - 1);      // (clamped: no load under a lane-divergent branch)
+                    float v = fmaf(acc[j][r], p.inv, bj[j]);
+                    if constexpr (EPI == X3S_RELU) v = relu_nan(v);
+                    if constexpr (EPI == X3S_MASK) v = p.aux[(size_t)rowc * p.ldaux + col] > 0.f ? v : 0.f;
+                    if (row < p.M) p.C[(size_t)rowc * p.ldc + col] = v;
+                }
             }
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     };
-    auto epilogue = [&](int em, int en, bool) __attribute__((always_inline)) {
-        if (em + SB_M <= p.M) epilogue_d(em, en, std::true_type{});
-        else epilogue_d(em, en, std::false_type{});
-    };
+    bool fresh = true;                    // the next MATRIX phase is an item's first: its first MFMA group takes a zero C operand
     int pend_m = -1, pend_n = 0;          // the item whose accumulators still wait for their epilogue (written at the start of the next MEMORY phase)
     for (int c_item = 0;; ++c_item) {
         for (int kt = 0; kt < nk; ++kt) {
@@ -337,9 +339,17 @@ __global__ __launch_bounds__(SB_THREADS, 2) void gemm_x3s_kernel(X3SArgs p, Item
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 // piece-major, smallest terms first: the four accumulators take turns
+                if (s == 0 && fresh) {
+                    f32x16 zero;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (!PARTIAL || j < nj) acc[j] = X3S_MFMA(wm[s][j], a[s].h, acc[j]);
+                    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = X3S_MFMA(wm[s][j], a[s].h, zero);      // (every block, live or not: the epilogue skips the dead ones)
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (!PARTIAL || j < nj) acc[j] = X3S_MFMA(wm[s][j], a[s].h, acc[j]);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (!PARTIAL || j < nj) acc[j] = X3S_MFMA(wh[s][j], a[s].m, acc[j]);
@@ -352,6 +362,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void gemm_x3s_kernel(X3SArgs p, Item
             stamp(2);      // MFMAs
             buf = buf == SB_NST - 1 ? 0 : buf + 1;
             const bool last = kt == nk - 1;
+            fresh = last;
             if (last) { pend_m = m_blk; pend_n = n_blk; }
             bool more = true;
             if (last) more = im.decode(c_item + 1, m_blk, n_blk);
@@ -386,7 +397,7 @@ done:
 bool gemm_x3s_eligible(const X3Gemm& g) {
     if (g.prec != 4 || g.a_mode != X3_ROW || g.b_mode != X3_PLANES) return false;
     if (g.accumulate || g.C2 != nullptr || g.B2 != nullptr || g.n_split != 0 || g.a_colsum != nullptr) return false;
-    if (g.a_bf16 || g.b_bf16 || g.c_bf16 || g.aux_bf16) return false;
+    if (g.a_bf16 || g.b_bf16 || g.c_bf16 || g.aux_bf16 || (g.relu && g.aux != nullptr)) return false;
     if (g.N > 4096) return false;                                  // the bias table in LDS
     if (g.K < SB_K || g.K % SB_K || (g.N & 31) || (g.lda & 3) || (g.ldb & 7) || (g.ldc & 3) || (g.aux != nullptr && (g.ldaux & 3))) return false;
     if ((long long)g.M * g.lda * 4 >= (1LL << 32) - (1 << 20) || 2 * g.b_plane * 2 + (long long)g.N * g.ldb * 2 >= (1LL << 32) - (1 << 20)) return false;      // 32-bit DMA offsets
@@ -394,15 +405,20 @@ bool gemm_x3s_eligible(const X3Gemm& g) {
     return items >= 192;
 }
 
-int gemm_x3s(const X3Gemm& g, hipStream_t stream) {
-    static bool attr_done[2] = {false, false};
-    const bool partial = (g.N % SB_N) != 0;
-    if (!attr_done[partial]) {
-        hipError_t e = partial ? hipFuncSetAttribute((const void*)gemm_x3s_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3S_LDS)
-                               : hipFuncSetAttribute((const void*)gemm_x3s_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3S_LDS);
+template <bool PARTIAL, int EPI>
+static int launch_x3s(const X3SArgs& a, const ItemMap& im, int grid, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_x3s_kernel<PARTIAL, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, X3S_LDS);
         if (e != hipSuccess) { set_error("gemm_x3s: hipFuncSetAttribute", (int)e); return (int)e; }
-        attr_done[partial] = true;
+        attr_done = true;
     }
+    hipLaunchKernelGGL((gemm_x3s_kernel<PARTIAL, EPI>), dim3(grid), dim3(SB_THREADS), X3S_LDS, stream, a, im);
+    return launch_check("gemm_x3s");
+}
+
+int gemm_x3s(const X3Gemm& g, hipStream_t stream) {
+    const bool partial = (g.N % SB_N) != 0;
     X3SArgs a{};
     a.A = static_cast<const float*>(g.A); a.B = static_cast<const uint16_t*>(g.B);
     a.C = g.C; a.bias = g.bias; a.aux = g.aux; a.b_plane = g.b_plane;
@@ -429,8 +445,11 @@ int gemm_x3s(const X3Gemm& g, hipStream_t stream) {
     (void)hipMemsetAsync(dbg, 0, 8192, stream);
     a.dbg = dbg;
 #endif
-    if (partial) hipLaunchKernelGGL(gemm_x3s_kernel<true>, dim3(grid), dim3(SB_THREADS), X3S_LDS, stream, a, im);
-    else hipLaunchKernelGGL(gemm_x3s_kernel<false>, dim3(grid), dim3(SB_THREADS), X3S_LDS, stream, a, im);
+    const int epi = g.aux != nullptr ? X3S_MASK : (g.relu ? X3S_RELU : X3S_PLAIN);
+    int rc;
+    if (partial) rc = epi == X3S_MASK ? launch_x3s<true, X3S_MASK>(a, im, grid, stream) : (epi == X3S_RELU ? launch_x3s<true, X3S_RELU>(a, im, grid, stream) : launch_x3s<true, X3S_PLAIN>(a, im, grid, stream));
+    else rc = epi == X3S_MASK ? launch_x3s<false, X3S_MASK>(a, im, grid, stream) : (epi == X3S_RELU ? launch_x3s<false, X3S_RELU>(a, im, grid, stream) : launch_x3s<false, X3S_PLAIN>(a, im, grid, stream));
+    if (rc) return rc;
 #if X3S_TIMING
     {
         long long h[8 + 2 * 256];
@@ -447,7 +466,7 @@ int gemm_x3s(const X3Gemm& g, hipStream_t stream) {
                 g.M, g.N, g.K, items, g.K / SB_K, h[0] / stages, h[1] / stages, h[2] / stages, h[4] / stages, h[5] / stages, h[3] / items);
     }
 #endif
-    return launch_check("gemm_x3s");
+    return 0;
 }
 
 }  // namespace dc
