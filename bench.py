@@ -230,7 +230,25 @@ def cpu_baseline(cell, hidden, layers, rollouts, seq_len, epochs, lr, ent, vf):
                   '`sample_rates`); oracle/ref_optimizer.py, torch CPU fp32, %d of %d host threads (best of sweep %s)'
                   % (t_roll, epochs, t_train, len(rollouts), seq_len, len(sample), [round(r, 1) for r in rates], best, ncpu, cands),
         'sample_rates': [round(r, 1) for r in rates], 'sample_trajectories': len(sample),
+        'reference_check': _reference_check(),
     }, ref
+
+
+def _reference_check():
+    """Why a "port" may stand in for the reference's CPU speed: the committed measurement of the REAL reference's functions next to this port
+    (tools/reference_cpu_step.py in the build container, where /root/reference is - it does not exist on the GPU box).  Quoted, with its
+    provenance, inside `cpu_baseline`; None if the file is missing."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r05', 'reference_vs_port_cpu.json')
+    try:
+        with open(path) as f:
+            j = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return {'source': 'profiles/r05/reference_vs_port_cpu.json (tools/reference_cpu_step.py, build container, 8-core host, no GPU)',
+            'workload': j.get('workload'),
+            'reference_env_steps_per_s': j.get('reference', {}).get('env_steps_per_s'), 'port_env_steps_per_s': j.get('port', {}).get('env_steps_per_s'),
+            'port_over_reference_rate': j.get('port_over_reference_rate'), 'same_final_loss': j.get('same_final_loss'),
+            'note': 'the reference is Python under /root/reference and cannot travel to the GPU box; the port is pinned to its golden outputs (tests/test_oracle.py)'}
 
 
 def parity_report(got, ref, tol=1e-4, argmax_min_equal=None, sub_batch=None, checker=None):

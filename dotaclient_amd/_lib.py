@@ -51,7 +51,7 @@ class DotaHipError(RuntimeError):
 
 
 def load():
-    """Loads the shared library once; raises DotaHipError if it has not been built."""
+    """Loads the shared library once; raises DotaHipError if it has not been built, is stale, or speaks another ABI version."""
     global _lib
     if _lib is not None:
         return _lib
@@ -62,6 +62,18 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise DotaHipError('libdotaclient_hip.so not found at %s - run `python -m dotaclient_amd.build` '
                            '(or __graft_entry__.build()); there is no CPU fallback' % LIB_PATH)
+    if not os.environ.get('DC_LIB'):
+        # stale? the build left the digest of its sources next to the library (build.py); a library older than the sources beside it
+        # would run yesterday's kernels under today's tests
+        from . import build as _build
+        try:
+            with open(LIB_PATH + '.sha1') as f:
+                stamp = f.read().strip()
+        except OSError:
+            stamp = None
+        if stamp != _build.sources_digest():
+            raise DotaHipError('%s is STALE (built from other sources than the ones in dotaclient_amd/csrc: %s) - run `python -m '
+                               'dotaclient_amd.build` (or __graft_entry__.build())' % (LIB_PATH, 'no build stamp' if stamp is None else 'digest mismatch'))
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)        # AttributeError if the symbol is missing

@@ -1,7 +1,9 @@
 """Builds libdotaclient_hip.so (hipcc, --offload-arch=gfx950) in-tree next to the sources.
 
 The .so is git-ignored but travels to the GPU box with the gpurun snapshot.  There is no JIT and no
-fallback: `dotaclient_amd._lib` refuses to load a stale or missing library.
+fallback: `dotaclient_amd._lib` refuses to load a missing library, one of another ABI version, or a STALE one - the
+build leaves the digest of every source it compiled next to the library (`<lib>.sha1`), and the loader compares it with
+the sources it finds (A/B builds loaded through DC_LIB are exempt: they are built with other flags on purpose).
 """
 import concurrent.futures
 import hashlib
@@ -30,6 +32,17 @@ def _digest(paths):
         with open(p, 'rb') as f:
             h.update(f.read())
     h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def sources_digest():
+    """Digest of everything the default library is built from (sources, headers, the C ABI header, the default flags)."""
+    paths = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(('.hip', '.h'))]
+    paths.append(os.path.join(HERE, '..', 'include', 'dotaclient_hip.h'))
+    h = hashlib.sha1()
+    for p in paths:
+        with open(p, 'rb') as f:
+            h.update(f.read())
     return h.hexdigest()
 
 
@@ -64,6 +77,8 @@ def build_library(verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+    with open(LIB + '.sha1', 'w') as f:       # what the loader checks the sources against (dotaclient_amd/_lib.py)
+        f.write(sources_digest() + ('' if not (VARIANT or os.environ.get('DC_BUILD_FLAGS')) else ' variant'))
     if verbose:
         print('libdotaclient_hip.so: %s (%d sources, %s)' % (LIB, len(srcs), 'rebuilt' if rebuilt else 'up to date'))
     return LIB

@@ -130,12 +130,19 @@ class Policy(nn.Module):
             st['batch'] = PackedBatch(st['obs'], None, None, None, st['off'], st['len'], 1)
         # the observation row on the host (the actor's tensors are CPU tensors, agent.py:640-650), one pinned H2D copy
         if all(not kw[k].is_cuda for k in L.INPUT_KEYS):
+            # (the previous call's asynchronous H2D copy may still be reading the pinned row if the caller did not read a result in
+            #  between: wait for it before the host writes the row again - ADVICE r5)
+            if st.get('h2d_done') is not None:
+                st['h2d_done'].synchronize()
             row, o = st['obs_host'][0], 0
             for k in L.INPUT_KEYS:
                 v = kw[k].reshape(-1)
                 row[o:o + v.numel()].copy_(v)
                 o += v.numel()
             st['obs'].copy_(st['obs_host'], non_blocking=True)
+            if st.get('h2d_done') is None:
+                st['h2d_done'] = torch.cuda.Event()
+            st['h2d_done'].record()
         else:                                             # observation tensors already on the device: assembled there
             st['obs'].copy_(torch.cat([kw[k].reshape(1, -1).to(dev, torch.float32) for k in L.INPUT_KEYS], dim=1))
         if self.cell == 'gru':

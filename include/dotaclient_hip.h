@@ -33,6 +33,8 @@ typedef void* dc_stream_t; /* hipStream_t */
  * DC_WS_TEAM_XBUF / DC_WS_WPLANES) were version 2 in effect.
  * 4 (round 4): dc_policy_forward takes the action masks (unit_mask); otherwise same signatures, changed contracts - dc_gradnorm_clip_adam's status word is sticky (a non-zero word makes later calls
  * skip their update until the caller clears it); dc_gae_scan / dc_discount / dc_advantage_returns accept any length (error 1001 is gone).
+ * (round 6 added dc_dims.flags / prec BITS only - DC_DIMS_GEMM_TILE128, DC_DIMS_FWD_ONLY, DC_GEMM_PREC_TILE128: a caller that does not set them gets
+ * the same results as before from the same signatures, so the number stays.)
  * The Python binding refuses any other value. */
 #define DC_ABI_VERSION 4
 int dc_abi_version(void);
@@ -298,7 +300,9 @@ int dc_gradnorm_clip_adam(const int64_t* seg_off, const int32_t* seg_len, const 
 /* Replaces the per-parameter averaging of DistributedDataParallelSparseParamCPU (distributed.py:24-57)
  * AFTER the caller has SUM-all-reduced the flat gradient bucket (RCCL via torch.distributed): every
  * parameter is divided by the number of ranks that had a gradient for it.
- *   counts f32[6] (device): [k<5] = ranks whose head k acted in their shard, [5] = world size. */
+ *   counts f32[6] (device): [k<5] = ranks whose head k acted in their shard, [5] = world size.
+ *   vf_coef: RESERVED, ignored (kept so that the signature stays ABI 4: the value head's parameters have a gradient on every rank
+ *   whatever the coefficient - a zero one - so their divisor is always counts[5]). */
 int dc_dp_average_grads(const int64_t* seg_off, const int32_t* seg_len, const int32_t* seg_gate, int n_seg,
                         int max_seg_len, float* grads, const float* counts, float vf_coef, dc_stream_t stream);
 

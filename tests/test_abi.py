@@ -2,6 +2,8 @@
 import os
 import re
 
+import pytest
+
 from dotaclient_amd import _lib
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,3 +30,22 @@ def test_library_exports_every_declared_symbol():
 def test_every_declaration_cites_the_reference():
     txt = open(os.path.join(REPO, 'include', 'dotaclient_hip.h')).read()
     assert txt.count('optimizer.py:') + txt.count('policy.py:') >= 3
+
+
+def test_loader_refuses_a_stale_library(tmp_path, monkeypatch):
+    # build.py leaves the digest of the sources it compiled next to the library; the loader compares it with the sources it finds and
+    # refuses a library built from other ones (build.py's docstring promised this, the loader only checked the ABI number)
+    import shutil
+    from dotaclient_amd import _lib, build
+    assert open(_lib.LIB_PATH + '.sha1').read().strip() == build.sources_digest(), 'rebuild: python -m dotaclient_amd.build'
+    monkeypatch.delenv('DC_LIB', raising=False)
+    fake = tmp_path / 'libdotaclient_hip.so'
+    shutil.copy(_lib.LIB_PATH, fake)
+    (tmp_path / 'libdotaclient_hip.so.sha1').write_text('0' * 40)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(fake))
+    monkeypatch.setattr(_lib, '_lib', None)
+    with pytest.raises(_lib.DotaHipError, match='STALE'):
+        _lib.load()
+    (tmp_path / 'libdotaclient_hip.so.sha1').unlink()
+    with pytest.raises(_lib.DotaHipError, match='no build stamp'):
+        _lib.load()
