@@ -25,9 +25,10 @@
 //     accumulators and stores of whole 128-byte lines (a half-wave each), no LDS round trip; the bias comes from an LDS table filled once;
 //   * persistent workgroups (one per CU: all 160 KB of LDS, two waves per SIMD) walk the (row tile, column tile) items of an XCD in
 //     row-tile order, so the column tiles of a row tile meet in that XCD's L2 (HBM traffic 1.15 x the algorithmic bytes).
-// What bounds it now: the MATRIX phases (2 x ~1 140 ticks of ~3 000 per stage, at the socket's power cap) and the epilogue - the 64 KB a
-// wave group writes per item leave the CU at ~12 bytes per clock (5 400 ticks: 30-45 % of a K = 256 item) whatever the store instructions;
-// staggered workgroup starts and stores trickled out of parked registers under the next item's MFMAs were measured and not kept.
+// What bounds it now: the MATRIX phases (2 x ~1 120 ticks of ~2 900 per stage: 24 MFMAs measure ~46 ticks each at the socket's power cap,
+// not 32) and what the phases leave uncovered - barriers, loop control, the DMA wait ~700 per stage -, then the epilogue (~3 000 ticks per
+// wave group and item: 64 stores of a whole line each).  Not kept: staggered workgroup starts, stores trickled out of parked registers
+// under the next item's MFMAs (slower: vmcnt retires in order, every DMA wait then waits for the stores in front of it).
 // Arithmetic is gemm_x3.hip's PREC 4 exactly: x sa = h + m (two f16 pieces), a b = (hh + hm + mh) / (sa sb), f32 accumulate.
 #include <cstdio>
 #include <type_traits>
