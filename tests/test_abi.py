@@ -49,3 +49,15 @@ def test_loader_refuses_a_stale_library(tmp_path, monkeypatch):
     (tmp_path / 'libdotaclient_hip.so.sha1').unlink()
     with pytest.raises(_lib.DotaHipError, match='no build stamp'):
         _lib.load()
+
+
+def test_gemm_x3s_k_loop_carries_no_compiler_vmcnt_wait():
+    # csrc/gemm_x3s.hip counts its LDS-DMA by hand (inline asm, vmcnt(6) across the barriers).  Twice while it was written hipcc put a
+    # vmcnt(0) of its own into the K loop - in front of a ds_read behind a builtin LDS-DMA, and in the loop header for a load whose use a
+    # divergent branch skipped - and drained the pipeline every stage: results right, kernel 1.5x slower.  tools/x3s_isa_check.py compiles
+    # the file and inspects the basic blocks that issue MFMAs / fragment reads / DMA pieces.
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'x3s_isa_check.py')], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count('compiler vmcnt waits: none') == 6, r.stdout[-3000:]       # PARTIAL x {plain, relu, mask}
