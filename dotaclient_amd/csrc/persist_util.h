@@ -230,6 +230,66 @@ struct FwdProductCol {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------
+// The same product with BOTH operands as two f16 planes (x 2^s = h + m, gemm_x3.hip's PREC = 4 arithmetic) on
+// v_mfma_f32_4x4x4_16b_f16: one instruction contracts FOUR k at the 4x4x1 f32 instruction's issue rate (8.6 cycles,
+// tools/ubench/mfma4x4_f16.hip), and three of them (h h, h m, m h) replace four: 192 instead of 256 per wave and step.
+// Lane 4b + i reads, per plane, the sixteen halfs [i][16 b .. 16 b + 15] of the plain-order image as four ds_read_b64;
+// k-group g (abid = g & 15 of read g >> 4) contracts k = 16 (g & 15) + 4 (g >> 4) + {0 .. 3}.  Three accumulator chains, one per piece
+// product: the two small ones sum apart from the large one.
+// ---------------------------------------------------------------------------------------------------
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void lds_read8(f16x4& dst, uint32_t addr) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <bool ZERO, int ABID>
+__device__ __forceinline__ void mfma3_f16(f32x4& c0, f32x4& c1, f32x4& c2, const f16x4& ah, const f16x4& am, const f16x4& wh, const f16x4& wm) {
+    if constexpr (ZERO) {
+        asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %3, %5, 0 cbsz:4 abid:%7\n\tv_mfma_f32_4x4x4_16b_f16 %1, %3, %6, 0 cbsz:4 abid:%7\n\t"
+                     "v_mfma_f32_4x4x4_16b_f16 %2, %4, %5, 0 cbsz:4 abid:%7"
+                     : "=&v"(c0), "=&v"(c1), "=&v"(c2)
+                     : "v"(ah), "v"(am), "a"(wh), "a"(wm), "i"(ABID));
+    } else {
+        asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %3, %5, %0 cbsz:4 abid:%7\n\tv_mfma_f32_4x4x4_16b_f16 %1, %3, %6, %1 cbsz:4 abid:%7\n\t"
+                     "v_mfma_f32_4x4x4_16b_f16 %2, %4, %5, %2 cbsz:4 abid:%7"
+                     : "+v"(c0), "+v"(c1), "+v"(c2)
+                     : "v"(ah), "v"(am), "a"(wh), "a"(wm), "i"(ABID));
+    }
+}
+__device__ __forceinline__ void mfma_tail_pad3(f32x4& a, f32x4& b, f32x4& c) {
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b), "+v"(c));
+}
+template <int K, int PLANE_BYTES>
+struct FwdProductColH {
+    static constexpr int NG = K / 4;         // k-groups = hook points per step
+    static constexpr int NJ = K / 64;        // ds_read_b64 per plane and step
+    static constexpr int HOOKS = NG;
+    template <int Gi, class Hook>
+    static __device__ __forceinline__ void group(const f16x4 (&rh)[NJ], const f16x4 (&rm)[NJ], f32x4 (&acc)[3], const f16x4 (&wh)[NG],
+                                                 const f16x4 (&wm)[NG], Hook& hook) {
+        if constexpr (Gi % 16 == 0) wait_lgkm<2 * (NJ - 1 - Gi / 16)>();
+        mfma3_f16<Gi == 0, Gi & 15>(acc[0], acc[1], acc[2], rh[Gi >> 4], rm[Gi >> 4], wh[Gi], wm[Gi]);
+        hook(std::integral_constant<int, Gi>{});
+    }
+    template <class Hook, int... Gs>
+    static __device__ __forceinline__ void groups(const f16x4 (&rh)[NJ], const f16x4 (&rm)[NJ], f32x4 (&acc)[3], const f16x4 (&wh)[NG],
+                                                  const f16x4 (&wm)[NG], Hook& hook, std::integer_sequence<int, Gs...>) {
+        (group<Gs>(rh, rm, acc, wh, wm, hook), ...);
+    }
+    template <int... Js>
+    static __device__ __forceinline__ void reads(f16x4 (&rh)[NJ], f16x4 (&rm)[NJ], uint32_t addr, std::integer_sequence<int, Js...>) {
+        ((lds_read8<8 * Js>(rh[Js], addr), lds_read8<PLANE_BYTES + 8 * Js>(rm[Js], addr)), ...);
+    }
+    template <class Hook>
+    static __device__ __forceinline__ void run(f32x4 (&acc)[3], const f16x4 (&wh)[NG], const f16x4 (&wm)[NG], uint32_t addr, Hook& hook) {
+        f16x4 rh[NJ], rm[NJ];
+        reads(rh, rm, addr, std::make_integer_sequence<int, NJ>{});
+        groups(rh, rm, acc, wh, wm, hook, std::make_integer_sequence<int, NG>{});
+        mfma_tail_pad3(acc[0], acc[1], acc[2]);
+    }
+};
+
 template <int KH>
 struct BwdProduct {
     // the two wave halves contract different k ranges, so the broadcast stays inside a half (cbsz:3):

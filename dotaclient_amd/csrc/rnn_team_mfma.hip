@@ -213,14 +213,30 @@ enum { TN_HLD = 260 };     // floats per sequence row of the LDS image (k in pla
                            // ds_read_b128; 260 / 4 = 65 = 1 mod 16: the sixteen lanes of a read group start at 16-byte units i + 4 b - all different
 __device__ __forceinline__ constexpr int tn_korder(int kk) { return 16 * (kk & 15) + (kk >> 4); }
 
-template <int CELL>     // 1: LSTM, 0: GRU
+// F16P (round 6, DC_DIMS_F16X2): W_hh and h as two f16 planes each (x 2^s = h + m, the x W^T products' arithmetic: weights x 2^8, states x 2^4)
+// on v_mfma_f32_4x4x4_16b_f16 - three instructions per four k instead of four (persist_util.h, FwdProductColH).  The LDS image is then
+// two planes of halfs (rows TN_HLD halfs apart: 520 bytes = 2 banks more than a multiple of 64, so the 32 lanes of a ds_read_b64 half
+// touch 64 different banks) and a granule carries the two halfs of a state instead of its float.  A weight beyond 65504 / 2^8 becomes
+// inf - inf = NaN in every step's output, the f16x2 contract of the other products (include/dotaclient_hip.h).
+__device__ __forceinline__ unsigned f16_planes(float v, float scale) {
+    const float x = v * scale;
+    const _Float16 h = (_Float16)x;
+    const _Float16 m = (_Float16)(x - (float)h);
+    return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, m) << 16);
+}
+template <int CELL, bool F16P, bool KEEP>     // CELL 1: LSTM, 0: GRU
 __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_col_kernel(RnnStepArgs p, u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
     // fwd_only (DC_DIMS_FWD_ONLY: the optimizer's no-grad rollout pass, optimizer.py:344-385): what only a backward would read - the activated
     // gates, h / c of the step before - is not written (562 -> ~135 MB per launch: h and c go out, the gate rows stay as the input projection left them)
-    const bool keep = p.fwd_only == 0;
+    // KEEP is a template parameter, not a run-time flag: with the stores behind uniform branches the compiler's vmcnt bookkeeping assumes the
+    // path with the fewest stores, and its wait for the NEXT step's input-projection loads then also waits for this step's first stores to be
+    // acknowledged by memory (measured: it ate two thirds of what the f16 planes saved)
+    constexpr bool keep = KEEP;
     constexpr bool LSTM = CELL == 1;
     constexpr int H = TM_H, G = LSTM ? 4 : 3, GH = G * H;
-    __shared__ __attribute__((aligned(16))) float h_lds[2][4 * TN_HLD];
+    __shared__ __attribute__((aligned(16))) float h_lds[2][4 * TN_HLD];      // F16P: [buffer][plane][4 * TN_HLD] halfs (same bytes)
+    unsigned short* const h_img = reinterpret_cast<unsigned short*>(&h_lds[0][0]);
+    constexpr int IMG_PLANE = 4 * TN_HLD, IMG_BUF = 2 * IMG_PLANE;           // halfs
     __shared__ int dead;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -236,12 +252,31 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_col_kernel(RnnSte
     if (tid == 0) dead = 0;
 
     // ---- weights: row (gate H + u) of W_hh, all k, in the order the product contracts them ---------------------------
-    float w[H];
+    float w[F16P ? 1 : H];
+    f16x4 wh[F16P ? H / 4 : 1], wm[F16P ? H / 4 : 1];
     {
         const bool has = row < G;                      // the GRU has no gate 3: zero weights in that row
         const float* r0 = p.Whh + (size_t)((has ? row : 0) * H + u) * H;
+        if constexpr (F16P) {
 #pragma unroll
-        for (int kk = 0; kk < H; ++kk) w[kk] = has ? r0[tn_korder(kk)] : 0.f;
+            for (int g = 0; g < H / 4; ++g) {          // k-group g: k = 16 (g & 15) + 4 (g >> 4) + e
+                const float4 v = *reinterpret_cast<const float4*>(r0 + 16 * (g & 15) + 4 * (g >> 4));
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x = has ? e[q] * 256.f : 0.f;
+                    const _Float16 hi = (_Float16)x;
+                    wh[g][q] = hi;
+                    wm[g][q] = (_Float16)(x - (float)hi);
+                }
+                // pin each plane entry to ONE 64-bit AGPR pair here: left to itself the compiler keeps the four dwords of (wh, wm) apart and
+                // gathers them with four v_accvgpr_mov in front of every k-group of every step
+                asm volatile("" : "+a"(wh[g]), "+a"(wm[g]));
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < H; ++kk) w[kk] = has ? r0[tn_korder(kk)] : 0.f;
+        }
     }
     float bh[4];
 #pragma unroll
@@ -265,7 +300,12 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_col_kernel(RnnSte
         for (int e = tid; e < 4 * H; e += TM_THREADS) {
             const int q = e >> 8, jj = e & (H - 1);
             const int bq = q == 0 ? bmap[0] : (q == 1 ? bmap[1] : (q == 2 ? bmap[2] : bmap[3]));
-            h_lds[0][q * TN_HLD + jj] = p.h0 ? p.h0[(size_t)bq * H + jj] : 0.f;
+            const float hv = p.h0 ? p.h0[(size_t)bq * H + jj] : 0.f;
+            if constexpr (F16P) {
+                const unsigned pk = f16_planes(hv, 16.f);
+                h_img[q * TN_HLD + jj] = (unsigned short)pk;
+                h_img[IMG_PLANE + q * TN_HLD + jj] = (unsigned short)(pk >> 16);
+            } else h_lds[0][q * TN_HLD + jj] = hv;
         }
         float xc[4] = {0.f, 0.f, 0.f, 0.f}, xn[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -273,6 +313,9 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_col_kernel(RnnSte
         u64* const xb = xbuf + (size_t)(team * 4 + slot) * (TEAM_SLOTS * H);      // ring of this lane's sequence slot
         __syncthreads();
 
+#ifdef TM_TIMING
+        long long tacc[5] = {0, 0, 0, 0, 0};
+#endif
         auto step = [&](const int t, float (&xcur)[4], float (&xnext)[4], auto CUR) {
             constexpr int cur = decltype(CUR)::value;
             const bool on = t < len, on1 = t + 1 < len;
@@ -292,9 +335,22 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_col_kernel(RnnSte
                 else if constexpr (k == 14 && LSTM) { if (keep) tm_st(cp, svp0); }
                 else if constexpr (k == 15) { if (keep) tm_st(hp, svp1); }
             };
-            f32x4 pa[4];
-            FwdProductCol<H>::run(pa, w, lds_addr(&h_lds[cur][(lane & 3) * TN_HLD + (lane >> 2) * 16]), hook);
-            const f32x4 tot = (pa[0] + pa[1]) + (pa[2] + pa[3]);     // gate `row` of unit u for the four sequences
+#ifdef TM_TIMING
+            const long long tq0 = __builtin_amdgcn_s_memtime();
+#endif
+            f32x4 tot;                                               // gate `row` of unit u for the four sequences
+            if constexpr (F16P) {
+                f32x4 pa[3];
+                FwdProductColH<H, 2 * IMG_PLANE>::run(pa, wh, wm, lds_addr(h_img + cur * IMG_BUF + (lane & 3) * TN_HLD + (lane >> 2) * 16), hook);
+                tot = (pa[0] + (pa[1] + pa[2])) * (1.f / 4096.f);
+            } else {
+                f32x4 pa[4];
+                FwdProductCol<H>::run(pa, w, lds_addr(&h_lds[cur][(lane & 3) * TN_HLD + (lane >> 2) * 16]), hook);
+                tot = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+            }
+#ifdef TM_TIMING
+            const long long tq1 = __builtin_amdgcn_s_memtime();
+#endif
             float a[4] = {tot[0], tot[1], tot[2], tot[3]};
             rows_transpose4(a);                                      // a[g] = gate g of (sequence `row`, unit u)
             const float y0 = a[0], y1 = a[1], x0 = a[2], x1 = a[3];
@@ -306,8 +362,18 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_col_kernel(RnnSte
             const float hn = LSTM ? og * fast_tanh(cn) : cn;
             const float hpub = on ? hn : 0.f;
             ++tag;
-            granule_store(xb + (tag & 3) * H + u, hpub, tag, plain);
-            h_lds[cur ^ 1][slot * TN_HLD + u] = hpub;
+            if constexpr (F16P) {
+                const unsigned pk = f16_planes(hpub, 16.f);
+                granule_store(xb + (tag & 3) * H + u, __uint_as_float(pk), tag, plain);
+                h_img[(cur ^ 1) * IMG_BUF + slot * TN_HLD + u] = (unsigned short)pk;
+                h_img[(cur ^ 1) * IMG_BUF + IMG_PLANE + slot * TN_HLD + u] = (unsigned short)(pk >> 16);
+            } else {
+                granule_store(xb + (tag & 3) * H + u, hpub, tag, plain);
+                h_lds[cur ^ 1][slot * TN_HLD + u] = hpub;
+            }
+#ifdef TM_TIMING
+            const long long tq2 = __builtin_amdgcn_s_memtime();
+#endif
             c = on ? cn : c;
             sv[0] = on ? ig : sv[0]; sv[1] = on ? fg : sv[1]; sv[2] = on ? gg : sv[2];
             sv[3] = on ? og : sv[3]; sv[4] = on ? cn : sv[4]; sv[5] = on ? hn : sv[5];
@@ -328,16 +394,37 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_col_kernel(RnnSte
                 }
                 if (!granule_wait_all<3>(gr, ga, tag)) { dead = 1; team_report_timeout(p.fault, TEAM_K_MFMA_FWD, p.layer, team, member, t, b, tag); }
 #pragma unroll
-                for (int q = 1; q < TEAM_M; ++q)
-                    h_lds[cur ^ 1][slot * TN_HLD + TEAM_US * ((member + q) & 3) + ul] = __uint_as_float((unsigned)gr[q - 1]);
+                for (int q = 1; q < TEAM_M; ++q) {
+                    const int at = slot * TN_HLD + TEAM_US * ((member + q) & 3) + ul;
+                    if constexpr (F16P) {
+                        h_img[(cur ^ 1) * IMG_BUF + at] = (unsigned short)gr[q - 1];
+                        h_img[(cur ^ 1) * IMG_BUF + IMG_PLANE + at] = (unsigned short)((unsigned)gr[q - 1] >> 16);
+                    } else h_lds[cur ^ 1][at] = __uint_as_float((unsigned)gr[q - 1]);
+                }
             }
+#ifdef TM_TIMING
+            const long long tq3 = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();
+#ifdef TM_TIMING
+            const long long tq4 = __builtin_amdgcn_s_memtime();
+            tacc[0] += tq1 - tq0; tacc[1] += tq2 - tq1; tacc[2] += tq3 - tq2; tacc[3] += tq4 - tq3; tacc[4] += 1;
+#endif
             return dead == 0;
         };
+#ifdef TM_TIMING
+        const long long tg0 = __builtin_amdgcn_s_memtime();
+#endif
         for (int t = 0; t < tmax; t += 2) {
             if (!step(t, xc, xn, std::integral_constant<int, 0>{})) { failed = true; break; }
             if (t + 1 < tmax && !step(t + 1, xn, xc, std::integral_constant<int, 1>{})) { failed = true; break; }
         }
+#ifdef TM_TIMING
+        if (tid == 0 && (team == 0 || team == 37) && member < 2)
+            printf("team_fwd_col F16P=%d team %d member %d plain %d: steps %lld  product %.0f  cell+publish %.0f  gather %.0f  barrier %.0f  loop total/step %.0f (s_memtime ticks per step)\n",
+                   (int)F16P, team, member, plain, tacc[4], (double)tacc[0] / tacc[4], (double)tacc[1] / tacc[4], (double)tacc[2] / tacc[4], (double)tacc[3] / tacc[4],
+                   (double)(__builtin_amdgcn_s_memtime() - tg0) / tacc[4]);
+#endif
         if (keep) {
 #pragma unroll
             for (int g = 0; g < G; ++g) p.gates[st_g + g * H] = sv[g];
@@ -569,8 +656,20 @@ int lstm_team_mfma_forward(int cell, RnnStepArgs a, int max_len, int n_teams, hi
         if (cell == 1) hipLaunchKernelGGL(team_mfma_fwd_kernel<1>, grid, block, 0, s, a, xb, nt, allow);
         else hipLaunchKernelGGL(team_mfma_fwd_kernel<0>, grid, block, 0, s, a, xb, nt, allow);
     } else {
-        if (cell == 1) hipLaunchKernelGGL(team_mfma_fwd_col_kernel<1>, grid, block, 0, s, a, xb, nt, allow);
-        else hipLaunchKernelGGL(team_mfma_fwd_col_kernel<0>, grid, block, 0, s, a, xb, nt, allow);
+        // DC_DIMS_F16X2: W_hh and h as f16 planes like the other products of that mode (-DTEAM_FWD_F32: keep the f32 instruction, A/B)
+#ifdef TEAM_FWD_F32
+        const bool planes = false;
+#else
+        const bool planes = (a.flags & DC_DIMS_F16X2) && !(a.flags & DC_DIMS_BF16);
+#endif
+        void (*kern)(RnnStepArgs, u64*, int, int);
+        const bool keep = a.fwd_only == 0;
+        if (planes) {
+            if (cell == 1) kern = keep ? team_mfma_fwd_col_kernel<1, true, true> : team_mfma_fwd_col_kernel<1, true, false>;
+            else kern = keep ? team_mfma_fwd_col_kernel<0, true, true> : team_mfma_fwd_col_kernel<0, true, false>;
+        } else if (cell == 1) kern = keep ? team_mfma_fwd_col_kernel<1, false, true> : team_mfma_fwd_col_kernel<1, false, false>;
+        else kern = keep ? team_mfma_fwd_col_kernel<0, false, true> : team_mfma_fwd_col_kernel<0, false, false>;
+        hipLaunchKernelGGL(kern, grid, block, 0, s, a, xb, nt, allow);
     }
     return launch_check("lstm_team_mfma_forward");
 }

@@ -18,6 +18,7 @@ __global__ __launch_bounds__(256, 1) void k(float* out, long long* cyc, int iter
     f16x8 b8[4];
     const float a = threadIdx.x * 0.001f;
     const f16x4 ah = {(_Float16)a, (_Float16)(a + 1), (_Float16)(a + 2), (_Float16)(a + 3)};
+    const f16x4 ah2 = {(_Float16)(a + 2), (_Float16)(a + 1), (_Float16)(a + 2), (_Float16)(a + 3)};
     const f16x8 a8 = {(_Float16)a, (_Float16)(a + 1), (_Float16)(a + 2), (_Float16)(a + 3), (_Float16)a, (_Float16)a, (_Float16)a, (_Float16)a};
     for (int i = 0; i < NC; ++i) c[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) C[i][r] = 0.f;
@@ -31,6 +32,9 @@ __global__ __launch_bounds__(256, 1) void k(float* out, long long* cyc, int iter
             if constexpr (MODE == 0) { asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(c[i % NC]) : "v"(a), "v"(b[i & 7])); }
             if constexpr (MODE == 1) { asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %0" : "+v"(c[i % NC]) : "v"(ah), "v"(bh[i & 7])); }
             if constexpr (MODE == 2) { asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %0 cbsz:4 abid:3" : "+v"(c[i % NC]) : "v"(ah), "v"(bh[i & 7])); }
+            if constexpr (MODE == 4) { asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0 cbsz:4 abid:3" : "+v"(c[i % NC]) : "v"(a), "a"(b[i & 7])); }
+            if constexpr (MODE == 5) { asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %0 cbsz:4 abid:3" : "+v"(c[i % NC]) : "v"(ah), "a"(bh[i & 7])); }
+            if constexpr (MODE == 6 && NC >= 3) { asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %3, %4, %0 cbsz:4 abid:3\n\tv_mfma_f32_4x4x4_16b_f16 %1, %3, %5, %1 cbsz:4 abid:3\n\tv_mfma_f32_4x4x4_16b_f16 %2, %6, %4, %2 cbsz:4 abid:3" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]) : "v"(ah), "a"(bh[i & 7]), "a"(bh[(i + 1) & 7]), "v"(ah2)); }
             if constexpr (MODE == 3) { asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(C[i & 3]) : "v"(a8), "v"(b8[i & 3])); }
         }
     }
@@ -63,5 +67,14 @@ int main() {
         run<3, 4>("32x32x16_f16, C in VGPRs, 4 chains", out, cyc, 256, blocks);
     }
     run<3, 4>("32x32x16_f16, 512 threads (2 waves per SIMD)", out, cyc, 512, 256);
+    run<4, 4>("4x4x1_16b_f32 cbsz:4, B in AGPR", out, cyc, 256, 256);
+    run<5, 4>("4x4x4_16b_f16 cbsz:4, B in AGPR", out, cyc, 256, 256);
+    run<6, 4>("4x4x4_16b_f16 cbsz:4, B in AGPR, the kernel's triple (per 3 MFMAs)", out, cyc, 256, 256);
+    // dependent-issue distance: how many independent chains does the 4x4 instruction need?
+    run<2, 3>("4x4x4_16b_f16 cbsz:4, 3 chains", out, cyc, 256, 256);
+    run<2, 2>("4x4x4_16b_f16 cbsz:4, 2 chains", out, cyc, 256, 256);
+    run<2, 1>("4x4x4_16b_f16 cbsz:4, 1 chain", out, cyc, 256, 256);
+    run<0, 2>("4x4x1_16b_f32, 2 chains", out, cyc, 256, 256);
+    run<0, 1>("4x4x1_16b_f32, 1 chain", out, cyc, 256, 256);
     return 0;
 }
