@@ -33,6 +33,7 @@ struct RnnStepArgs {
     float* dc;             // [rows][H]  LSTM: total dL/dc_t
     float* dgx;            // [rows][G*H] grad wrt (W_ih x + b_ih)
     float* dgh;            // [rows][G*H] grad wrt (W_hh h + b_hh)   (GRU; LSTM: == dgx)
+    float s_grad;          // DC_DIMS_F16X2: power-of-two pre-scale of the gate gradients for rnn_team_mfma.hip's backward on f16 planes (0: f32 product)
     int fwd_only;          // rnn_team_mfma.hip's forward (LSTM-256, > 128 sequences): no backward will read this pass - skip the stores only it would need (DC_DIMS_FWD_ONLY)
     int bf16_store;        // rnn_team512.hip only (configs[4]): `gates`, `dgx` [rows][G*H] and `hseq`, `hprev` [rows][H] are bf16 buffers (policy.hip: bf16_store())
     long long* dbg;        // DC_LSTM_TIMING=1: phase cycle sums of workgroup 0 (else nullptr)

@@ -290,6 +290,60 @@ struct FwdProductColH {
     }
 };
 
+// The two-plane product in TWO phases, for a team member that knows its OWN 64 units' states a hand-off earlier than the other members':
+// with the image in member-local k order (own units first) the k-groups of broadcast blocks 0 .. 3 contract own states only.
+//   phase A: those 16 k-groups (48 MFMAs), issued while the other members' granules are in flight;
+//   phase B: the other 48 (144 MFMAs) after the gather, from a second set of LDS reads.
+// Hook numbers: 0 .. 15 in phase A, 16 .. 63 in phase B.
+template <int K, int PLANE_BYTES>
+struct FwdProductOwnFirst {
+    static_assert(K == 256, "four members x 64 units");
+    static constexpr int NG = K / 4, NJ = K / 64;
+    template <int... Js>
+    static __device__ __forceinline__ void reads(f16x4 (&rh)[NJ], f16x4 (&rm)[NJ], uint32_t addr, std::integer_sequence<int, Js...>) {
+        ((lds_read8<8 * Js>(rh[Js], addr), lds_read8<PLANE_BYTES + 8 * Js>(rm[Js], addr)), ...);
+    }
+    template <int A, class Hook>           // phase A position A: read J = A / 4, block A % 4
+    static __device__ __forceinline__ void group_a(const f16x4 (&rh)[NJ], const f16x4 (&rm)[NJ], f32x4 (&acc)[3], const f16x4 (&wh)[NG],
+                                                   const f16x4 (&wm)[NG], Hook& hook) {
+        constexpr int J = A / 4, B = A % 4, g = 16 * J + B;
+        if constexpr (A % 4 == 0) wait_lgkm<2 * (NJ - 1 - J)>();
+        mfma3_f16<A == 0, B>(acc[0], acc[1], acc[2], rh[J], rm[J], wh[g], wm[g]);
+        hook(std::integral_constant<int, A>{});
+    }
+    template <int Q, class Hook>           // phase B position Q: read J = Q / 12, block 4 + Q % 12
+    static __device__ __forceinline__ void group_b(const f16x4 (&rh)[NJ], const f16x4 (&rm)[NJ], f32x4 (&acc)[3], const f16x4 (&wh)[NG],
+                                                   const f16x4 (&wm)[NG], Hook& hook) {
+        constexpr int J = Q / 12, B = 4 + Q % 12, g = 16 * J + B;
+        if constexpr (Q % 12 == 0) wait_lgkm<2 * (NJ - 1 - J)>();
+        mfma3_f16<false, B>(acc[0], acc[1], acc[2], rh[J], rm[J], wh[g], wm[g]);
+        hook(std::integral_constant<int, 16 + Q>{});
+    }
+    template <class Hook, int... As>
+    static __device__ __forceinline__ void groups_a(const f16x4 (&rh)[NJ], const f16x4 (&rm)[NJ], f32x4 (&acc)[3], const f16x4 (&wh)[NG],
+                                                    const f16x4 (&wm)[NG], Hook& hook, std::integer_sequence<int, As...>) {
+        (group_a<As>(rh, rm, acc, wh, wm, hook), ...);
+    }
+    template <class Hook, int... Qs>
+    static __device__ __forceinline__ void groups_b(const f16x4 (&rh)[NJ], const f16x4 (&rm)[NJ], f32x4 (&acc)[3], const f16x4 (&wh)[NG],
+                                                    const f16x4 (&wm)[NG], Hook& hook, std::integer_sequence<int, Qs...>) {
+        (group_b<Qs>(rh, rm, acc, wh, wm, hook), ...);
+    }
+    template <class Hook>
+    static __device__ __forceinline__ void phase_a(f32x4 (&acc)[3], const f16x4 (&wh)[NG], const f16x4 (&wm)[NG], uint32_t addr, Hook& hook) {
+        f16x4 rh[NJ], rm[NJ];
+        reads(rh, rm, addr, std::make_integer_sequence<int, NJ>{});
+        groups_a(rh, rm, acc, wh, wm, hook, std::make_integer_sequence<int, 16>{});
+    }
+    template <class Hook>
+    static __device__ __forceinline__ void phase_b(f32x4 (&acc)[3], const f16x4 (&wh)[NG], const f16x4 (&wm)[NG], uint32_t addr, Hook& hook) {
+        f16x4 rh[NJ], rm[NJ];
+        reads(rh, rm, addr, std::make_integer_sequence<int, NJ>{});
+        groups_b(rh, rm, acc, wh, wm, hook, std::make_integer_sequence<int, 48>{});
+        mfma_tail_pad3(acc[0], acc[1], acc[2]);
+    }
+};
+
 template <int KH>
 struct BwdProduct {
     // the two wave halves contract different k ranges, so the broadcast stays inside a half (cbsz:3):

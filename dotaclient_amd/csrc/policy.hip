@@ -389,6 +389,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         a.Whh = P.p(pb + 1); a.WhhT = w.f(DC_WS_WHHT); a.dh = w.fl(l, DC_WSL_DH); a.dc = w.fl(l, DC_WSL_DC);
         a.dgx = w.fl(l, DC_WSL_DGX);
         a.dgh = d->cell == 0 ? w.fl(l, DC_WSL_DGH) : w.fl(l, DC_WSL_DGX);
+        a.s_grad = f16x2 ? s_grad : 0.f;
         a.bf16_store = bs;
         DC_TRY(rnn_backward_layer(d->cell, a, d->max_len, s));
         const float* xin = l == 0 ? w.f(DC_WS_PRE) : w.fl(l - 1, DC_WSL_HSEQ);

@@ -439,6 +439,225 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_col_kernel(RnnSte
 
 
 // ---------------------------------------------------------------------------------------------------
+// Forward, f16 planes, OWN UNITS FIRST (round 6; the default with DC_DIMS_F16X2).  In the kernel above a step is a chain
+//   product (all 256 k) -> cell -> publish h -> wait for the three other members' h -> barrier -> next product,
+// and the wait is two L2 trips long (TM_TIMING: product 1 945 ticks, cell + publish 395, gather 980, barrier 155).  But a member's own 64
+// units never leave the CU: with the LDS image in member-LOCAL k order (k_local = (k - 64 member) mod 256, weights loaded to match) the 16
+// k-groups of broadcast blocks 0 .. 3 contract own states only.  So a step becomes
+//   publish h_t | own h_t -> LDS, barrier | phase A: 48 MFMAs on the own quarter of k (the poll loads for the others' granules are issued
+//   from one of its hooks: late enough to find them in L2, early enough to be back by its end) | gather, foreign h_t -> LDS, barrier |
+//   phase B: 144 MFMAs on the other three quarters, next step's input loads and this step's stores from its hooks | cell -> publish ...
+// and the hand-off hides behind phase A and the first barrier.  One more barrier and one more set of LDS reads per step.
+// PG: the phase A hook the poll loads are issued from.
+// ---------------------------------------------------------------------------------------------------
+#ifndef TM_OF_PG
+#define TM_OF_PG 4
+#endif
+template <int CELL, bool KEEP>     // CELL 1: LSTM, 0: GRU; KEEP: also store what only a backward reads (see above)
+__global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_of_kernel(RnnStepArgs p, u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
+    constexpr bool keep = KEEP;
+    constexpr bool LSTM = CELL == 1;
+    constexpr int H = TM_H, G = LSTM ? 4 : 3, GH = G * H, PG = TM_OF_PG;
+    constexpr int IMG_PLANE = 4 * TN_HLD, IMG_BUF = 2 * IMG_PLANE;           // halfs
+    __shared__ __attribute__((aligned(16))) unsigned short h_img[2 * IMG_BUF];      // [buffer][plane][sequence][TN_HLD], member-local k order
+    __shared__ int dead;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = lane >> 4, j = lane & 15;          // product role: gate `row`; cell role: sequence slot `row`
+    int team, member;
+    team_claim_role(reinterpret_cast<unsigned*>(xbuf_all), n_teams, team, member);
+    if (team < 0) return;
+    u64* const xbuf = xbuf_all + TEAM_HDR + TEAM_MAX * TEAM_M;
+    const int plain = team_same_xcd(xbuf_all + TEAM_HDR + team * TEAM_M, member, allow_plain);
+    const int ul = 16 * wave + j;                      // unit inside the member's 64 = its local k
+    const int u = TEAM_US * member + ul;
+    const int slot = row;
+    if (tid == 0) dead = 0;
+
+    // ---- weights: row (gate H + u) of W_hh as two f16 planes (x 2^8); k-group g holds local k = 16 (g & 15) + 4 (g >> 4) + e ----------
+    f16x4 wh[H / 4], wm[H / 4];
+    {
+        const bool has = row < G;                      // the GRU has no gate 3: zero weights in that row
+        const float* r0 = p.Whh + (size_t)((has ? row : 0) * H + u) * H;
+#pragma unroll
+        for (int g = 0; g < H / 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(r0 + ((16 * (g & 15) + 4 * (g >> 4) + TEAM_US * member) & (H - 1)));
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float x = has ? e[q] * 256.f : 0.f;
+                const _Float16 hi = (_Float16)x;
+                wh[g][q] = hi;
+                wm[g][q] = (_Float16)(x - (float)hi);
+            }
+            asm volatile("" : "+a"(wh[g]), "+a"(wm[g]));      // one 64-bit AGPR pair each (see the kernel above)
+        }
+    }
+    float bh[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bh[g] = g < G ? p.bhh[g * H + u] : 0.f;
+
+    unsigned tag = 0;
+    bool failed = false;
+    const int n_groups = (p.n_seq + 3) >> 2;
+    for (int grp = team; grp < n_groups && !failed; grp += n_teams) {
+        int bmap[4], tmax;
+        if (!map_slots(p, 4 * grp, bmap, tmax)) continue;
+        const int b = slot == 0 ? bmap[0] : (slot == 1 ? bmap[1] : (slot == 2 ? bmap[2] : bmap[3]));
+        const int len = p.seq_len[b];
+        const unsigned row0 = (unsigned)p.seq_off[b];
+        unsigned goff = row0 * GH + u, soff = row0 * H + u;
+        unsigned st_g = goff, st_s = soff, st_p = soff;
+        const float h0v = p.h0 ? p.h0[(size_t)b * H + u] : 0.f;
+        float c = LSTM ? (p.c0 ? p.c0[(size_t)b * H + u] : 0.f) : h0v;
+        float sv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float svp0 = c, svp1 = h0v;
+        for (int e = tid; e < 4 * H; e += TM_THREADS) {
+            const int q = e >> 8, jj = e & (H - 1);
+            const int bq = q == 0 ? bmap[0] : (q == 1 ? bmap[1] : (q == 2 ? bmap[2] : bmap[3]));
+            const unsigned pk = f16_planes(p.h0 ? p.h0[(size_t)bq * H + jj] : 0.f, 16.f);
+            const int at = q * TN_HLD + ((jj - TEAM_US * member) & (H - 1));
+            h_img[at] = (unsigned short)pk;
+            h_img[IMG_PLANE + at] = (unsigned short)(pk >> 16);
+        }
+        float xc[4] = {0.f, 0.f, 0.f, 0.f}, xn[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < G; ++g) xc[g] = p.gates[goff + g * H];
+        u64* const xb = xbuf + (size_t)(team * 4 + slot) * (TEAM_SLOTS * H);      // ring of this lane's sequence slot
+        __syncthreads();
+#ifdef TM_TIMING
+        long long tacc[6] = {0, 0, 0, 0, 0, 0}, tpub = 0, tpub0 = 0;
+        int tmiss = 0;
+#endif
+        // step t: gates of step t from h_{t-1} in image `cur` (own quarter complete on entry, the other three arrive during phase A)
+        auto step = [&](const int t, float (&xcur)[4], float (&xnext)[4], auto CUR) __attribute__((always_inline)) {
+            constexpr int cur = decltype(CUR)::value;
+            const bool on = t < len, on1 = t + 1 < len;
+            const unsigned gnx = goff + (on1 ? GH : 0);
+            const float* const lp = p.gates + gnx;
+            float* const gs = p.gates + st_g;
+            float* const cs = (LSTM ? p.cseq : p.hn) + st_s;
+            float* const hs = p.hseq + st_s;
+            float* const cp = LSTM ? p.cprev + st_p : nullptr;
+            float* const hp = p.hprev + st_p;
+            const bool gather = t > 0;                 // (step 0 reads the initial state, complete in the image)
+            u64 gr[3] = {0, 0, 0};
+            const u64* ga[3];
+#pragma unroll
+            for (int q = 1; q < TEAM_M; ++q) ga[q - 1] = xb + (tag & 3) * H + TEAM_US * ((member + q) & 3) + ul;
+            auto hook = [&](auto K) __attribute__((always_inline)) {
+                constexpr int k = decltype(K)::value;          // 0 .. 15: phase A, 16 .. 63: phase B
+                if constexpr (k == PG) {
+                    if (gather) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) gr[q] = granule_load(ga[q]);
+                    }
+                }
+                else if constexpr (k >= 17 && k <= 16 + G) xnext[k - 17] = tm_ld(lp + (k - 17) * H);
+                else if constexpr (k >= 24 && k < 24 + G) { if constexpr (keep) tm_st(gs + (k - 24) * H, sv[k - 24]); }
+                else if constexpr (k == 28) { if constexpr (keep || LSTM) tm_st(cs, sv[LSTM ? 4 : 3]); }       // (the GRU's W_hn h + b_hn: the backward's only)
+                else if constexpr (k == 29) tm_st(hs, sv[5]);
+                else if constexpr (k == 30 && LSTM) { if constexpr (keep) tm_st(cp, svp0); }
+                else if constexpr (k == 31) { if constexpr (keep) tm_st(hp, svp1); }
+            };
+            using Prod = FwdProductOwnFirst<H, 2 * IMG_PLANE>;
+            const uint32_t addr = lds_addr(h_img + cur * IMG_BUF + (lane & 3) * TN_HLD + (lane >> 2) * 16);
+#ifdef TM_TIMING
+            const long long tq0 = __builtin_amdgcn_s_memtime();
+#endif
+            f32x4 pa[3];
+            Prod::phase_a(pa, wh, wm, addr, hook);
+#ifdef TM_TIMING
+            const long long tq1 = __builtin_amdgcn_s_memtime();
+#endif
+            if (gather) {
+#ifdef TM_TIMING
+                for (int q = 0; q < 3; ++q) if ((unsigned)(gr[q] >> 32) != tag) { ++tmiss; break; }
+                tpub += tq1 - tpub0;
+#endif
+                if (!granule_wait_all<3>(gr, ga, tag)) { dead = 1; team_report_timeout(p.fault, TEAM_K_MFMA_FWD, p.layer, team, member, t, b, tag); }
+#pragma unroll
+                for (int q = 1; q < TEAM_M; ++q) {
+                    const int at = cur * IMG_BUF + slot * TN_HLD + TEAM_US * q + ul;
+                    h_img[at] = (unsigned short)gr[q - 1];
+                    h_img[IMG_PLANE + at] = (unsigned short)((unsigned)gr[q - 1] >> 16);
+                }
+            }
+#ifdef TM_TIMING
+            const long long tq2 = __builtin_amdgcn_s_memtime();
+#endif
+            __syncthreads();
+#ifdef TM_TIMING
+            const long long tq3 = __builtin_amdgcn_s_memtime();
+#endif
+            Prod::phase_b(pa, wh, wm, addr, hook);
+#ifdef TM_TIMING
+            const long long tq4 = __builtin_amdgcn_s_memtime();
+#endif
+            const f32x4 tot = (pa[0] + (pa[1] + pa[2])) * (1.f / 4096.f);      // gate `row` of unit u for the four sequences
+            float a[4] = {tot[0], tot[1], tot[2], tot[3]};
+            rows_transpose4(a);                                      // a[g] = gate g of (sequence `row`, unit u)
+            const float y0 = a[0], y1 = a[1], x0 = a[2], x1 = a[3];
+            const float ig = fast_sigmoid(xcur[0] + (y0 + bh[0]));
+            const float fg = fast_sigmoid(xcur[1] + (y1 + bh[1]));
+            const float og = LSTM ? fast_sigmoid(xcur[3] + (x1 + bh[3])) : x0 + bh[2];
+            const float gg = LSTM ? fast_tanh(xcur[2] + (x0 + bh[2])) : fast_tanh(xcur[2] + ig * og);
+            const float cn = LSTM ? fg * c + ig * gg : (1.f - fg) * gg + fg * c;
+            const float hn = LSTM ? og * fast_tanh(cn) : cn;
+            const float hpub = on ? hn : 0.f;
+            ++tag;
+            const unsigned pk = f16_planes(hpub, 16.f);
+            granule_store(xb + (tag & 3) * H + u, __uint_as_float(pk), tag, plain);
+            h_img[(cur ^ 1) * IMG_BUF + slot * TN_HLD + ul] = (unsigned short)pk;
+            h_img[(cur ^ 1) * IMG_BUF + IMG_PLANE + slot * TN_HLD + ul] = (unsigned short)(pk >> 16);
+            c = on ? cn : c;
+            sv[0] = on ? ig : sv[0]; sv[1] = on ? fg : sv[1]; sv[2] = on ? gg : sv[2];
+            sv[3] = on ? og : sv[3]; sv[4] = on ? cn : sv[4]; sv[5] = on ? hn : sv[5];
+            st_g = on ? goff : st_g;
+            st_s = on ? soff : st_s;
+            svp0 = on1 ? cn : svp0;
+            svp1 = on1 ? hn : svp1;
+            st_p = on1 ? soff + H : st_p;
+            goff = gnx;
+            soff += on1 ? H : 0;
+#ifdef TM_TIMING
+            const long long tq5 = __builtin_amdgcn_s_memtime();
+            tpub0 = tq5;
+#endif
+            __syncthreads();
+#ifdef TM_TIMING
+            const long long tq6 = __builtin_amdgcn_s_memtime();
+            tacc[0] += tq1 - tq0; tacc[1] += tq2 - tq1; tacc[2] += tq3 - tq2; tacc[3] += tq4 - tq3; tacc[4] += tq5 - tq4; tacc[5] += tq6 - tq5;
+#endif
+            return dead == 0;
+        };
+#ifdef TM_TIMING
+        const long long tg0 = __builtin_amdgcn_s_memtime();
+#endif
+        for (int t = 0; t < tmax; t += 2) {
+            if (!step(t, xc, xn, std::integral_constant<int, 0>{})) { failed = true; break; }
+            if (t + 1 < tmax && !step(t + 1, xn, xc, std::integral_constant<int, 1>{})) { failed = true; break; }
+        }
+#ifdef TM_TIMING
+        if (tid == 0 && (team == 0 || team == 37) && member < 2)
+            printf("team_fwd_of PG=%d team %d member %d plain %d: steps %d  first poll stale in %d steps (lane 0), publish -> end of phase A %.0f;  phase A %.0f  gather %.0f  barrier %.0f  phase B %.0f  cell+publish %.0f  barrier %.0f  loop total/step %.0f (s_memtime ticks per step)\n",
+                   PG, team, member, plain, tmax, tmiss, (double)tpub / tmax, (double)tacc[0] / tmax, (double)tacc[1] / tmax, (double)tacc[2] / tmax, (double)tacc[3] / tmax, (double)tacc[4] / tmax,
+                   (double)tacc[5] / tmax, (double)(__builtin_amdgcn_s_memtime() - tg0) / tmax);
+#endif
+        if constexpr (keep) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) p.gates[st_g + g * H] = sv[g];
+        }
+        if constexpr (LSTM) { p.cseq[st_s] = sv[4]; if constexpr (keep) p.cprev[st_p] = svp0; }
+        else if constexpr (keep) p.hn[st_s] = sv[3];
+        p.hseq[st_s] = failed ? __builtin_nanf("") : sv[5];
+        if constexpr (keep) p.hprev[st_p] = svp1;
+        __syncthreads();
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
 // backward through time.  The forward is COLUMN-parallel (a member owns the gate columns of its 64 units and needs all of
 // h_{t-1}: an all-gather of 192 foreign values per sequence).  Done the same way, the backward would need all 1 024 gate
 // gradients of every sequence in every member - 3 072 eight-byte reads per member and step, and that exchange, not the
@@ -462,11 +681,17 @@ __device__ __forceinline__ int tb_pos(int kk) { return TB_BLK * (kk >> 5) + (kk 
 // [i][32 b' ..]: with the image in PLAIN order it contracts kk = 32 (kk' & 7) + (kk' >> 3); the weights are loaded in that order
 __device__ __forceinline__ constexpr int tb_korder(int kk) { return 32 * (kk & 7) + (kk >> 3); }
 
-template <int CELL>     // 1: LSTM, 0: GRU (contracts dgh = d(W_hh h + b_hh) of step t + 1; writes dgx and dgh)
+// F16P (round 6, DC_DIMS_F16X2 with RnnStepArgs::s_grad > 0): the product on f16 planes like the forward's - W_hh x 2^8, the gate gradients
+// x s_grad (the power of two the other backward products of the mode use, policy.hip: f16x2_grad_scale) - with FwdProductColH: a lane's
+// output unit is its "column", the image holds the gate gradients as two planes of halfs in plain kk order.
+template <int CELL, bool F16P>     // 1: LSTM, 0: GRU (contracts dgh = d(W_hh h + b_hh) of step t + 1; writes dgx and dgh)
 __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_bwd_kernel(RnnStepArgs p, u64* __restrict__ xbuf_all, int n_teams, int allow_plain) {
     constexpr bool LSTM = CELL == 1;
     constexpr int H = TM_H, G = LSTM ? 4 : 3, GH = G * H, KH = TB_KH;
     __shared__ __attribute__((aligned(16))) float g_lds[2][4 * TB_GLD];      // own gate gradients [seq][pos(kk)], kk = 64 gate + own unit
+    static_assert(sizeof(float) * 2 * 4 * TB_GLD >= sizeof(unsigned short) * 2 * 2 * 4 * TN_HLD, "the planes fit the f32 image");
+    unsigned short* const g_img = reinterpret_cast<unsigned short*>(&g_lds[0][0]);      // F16P: [buffer][plane][4 * TN_HLD] halfs
+    constexpr int IMG_PLANE = 4 * TN_HLD, IMG_BUF = 2 * IMG_PLANE;
     __shared__ float own[4][TEAM_US];                                         // own partial sums dh_rec[seq][own unit]
     __shared__ int dead;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -482,12 +707,29 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_bwd_kernel(RnnStepArg
     if (tid == 0) dead = 0;
 
     // ---- weights: W_hh[(kk >> 6) H + 64 m + (kk & 63)][u'], kk = 0 .. 255 ---------------------------------------------
-    float w[KH];
+    float w[F16P ? 1 : KH];
+    f16x4 wh[F16P ? KH / 4 : 1], wm[F16P ? KH / 4 : 1];
+    if constexpr (F16P) {
 #pragma unroll
-    for (int kk = 0; kk < KH; ++kk) {
-        const int k = tb_korder(kk);                   // own gate column 64 gate + own unit (GRU: slot 3 is empty)
-        w[kk] = (k >> 6) < G ? p.Whh[(size_t)((k >> 6) * H + TEAM_US * member + (k & 63)) * H + up] : 0.f;
+        for (int g = 0; g < KH / 4; ++g) {             // k-group g: kk = 16 (g & 15) + 4 (g >> 4) + e
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 16 * (g & 15) + 4 * (g >> 4) + e;
+                const float x = (k >> 6) < G ? p.Whh[(size_t)((k >> 6) * H + TEAM_US * member + (k & 63)) * H + up] * 256.f : 0.f;
+                const _Float16 hi = (_Float16)x;
+                wh[g][e] = hi;
+                wm[g][e] = (_Float16)(x - (float)hi);
+            }
+            asm volatile("" : "+a"(wh[g]), "+a"(wm[g]));      // one 64-bit AGPR pair each (see the forward)
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) {
+            const int k = tb_korder(kk);                   // own gate column 64 gate + own unit (GRU: slot 3 is empty)
+            w[kk] = (k >> 6) < G ? p.Whh[(size_t)((k >> 6) * H + TEAM_US * member + (k & 63)) * H + up] : 0.f;
+        }
     }
+    const float s_grad = p.s_grad, inv_scale = F16P ? 1.f / (256.f * p.s_grad) : 1.f;
 
     // ring of a team: [tag & 3][owner member][source member][sequence slot][64 units] granules
     u64* const ring0 = xbuf + (size_t)team * (TEAM_SLOTS * 4 * 4 * 4 * TEAM_US);
@@ -511,7 +753,7 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_bwd_kernel(RnnStepArg
         if constexpr (LSTM) { cur_v[4] = p.cseq[soff]; cur_v[5] = p.cprev[soff]; }
         else { cur_v[3] = p.hn[soff]; cur_v[5] = p.hprev[soff]; }
         cur_v[6] = p.dh[soff];
-        for (int e = tid; e < 4 * TB_GLD; e += TM_THREADS) g_lds[0][e] = 0.f;      // "step tmax" has no gradient
+        for (int e = tid; e < 4 * TB_GLD; e += TM_THREADS) g_lds[0][e] = 0.f;      // "step tmax" has no gradient (F16P: buffer 0 lies inside)
         __syncthreads();
 
         auto step = [&](const int t, float (&cv)[7], float (&nv)[7], auto CUR) {
@@ -536,9 +778,16 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_bwd_kernel(RnnStepArg
                 else if constexpr (!LSTM && k == 16) tm_st(ghs + 2 * H, svh2);
             };
             // ---- partial dh_rec[seq 0..3][u'] over this member's 256 gate columns ------------------------------------------
-            f32x4 pa[4];
-            BwdProduct<KH>::run(pa, w, lds_addr(&g_lds[cur][(lane & 3) * TB_GLD + ((lane >> 2) & 7) * TB_BLK]), hook);
-            const f32x4 acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+            f32x4 acc;
+            if constexpr (F16P) {
+                f32x4 pa[3];
+                FwdProductColH<KH, 2 * IMG_PLANE>::run(pa, wh, wm, lds_addr(g_img + cur * IMG_BUF + (lane & 3) * TN_HLD + (lane >> 2) * 16), hook);
+                acc = (pa[0] + (pa[1] + pa[2])) * inv_scale;
+            } else {
+                f32x4 pa[4];
+                BwdProduct<KH>::run(pa, w, lds_addr(&g_lds[cur][(lane & 3) * TB_GLD + ((lane >> 2) & 7) * TB_BLK]), hook);
+                acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+            }
             ++tag;
             u64* const ring = ring0 + (size_t)(tag & 3) * (4 * 4 * 4 * TEAM_US);
             if (xchg) {
@@ -589,7 +838,13 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_bwd_kernel(RnnStepArg
                 dc_next = on ? dh : dc_next;
             }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) g_lds[cur ^ 1][slot * TB_GLD + tb_pos(TEAM_US * g + ul)] = dgr[g];
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (F16P) {
+                    const unsigned pk = f16_planes(dgr[g], s_grad);
+                    g_img[(cur ^ 1) * IMG_BUF + slot * TN_HLD + TEAM_US * g + ul] = (unsigned short)pk;
+                    g_img[(cur ^ 1) * IMG_BUF + IMG_PLANE + slot * TN_HLD + TEAM_US * g + ul] = (unsigned short)(pk >> 16);
+                } else g_lds[cur ^ 1][slot * TB_GLD + tb_pos(TEAM_US * g + ul)] = dgr[g];
+            }
             st_g = on ? goff : st_g;
             f_next = on ? fg : f_next;
             goff = gnx;
@@ -664,7 +919,15 @@ int lstm_team_mfma_forward(int cell, RnnStepArgs a, int max_len, int n_teams, hi
 #endif
         void (*kern)(RnnStepArgs, u64*, int, int);
         const bool keep = a.fwd_only == 0;
-        if (planes) {
+#ifdef TEAM_FWD_COL_PLANES
+        const bool own_first = false;                   // A/B: the f16 planes without the own-units-first split
+#else
+        const bool own_first = planes;
+#endif
+        if (own_first) {
+            if (cell == 1) kern = keep ? team_mfma_fwd_of_kernel<1, true> : team_mfma_fwd_of_kernel<1, false>;
+            else kern = keep ? team_mfma_fwd_of_kernel<0, true> : team_mfma_fwd_of_kernel<0, false>;
+        } else if (planes) {
             if (cell == 1) kern = keep ? team_mfma_fwd_col_kernel<1, true, true> : team_mfma_fwd_col_kernel<1, true, false>;
             else kern = keep ? team_mfma_fwd_col_kernel<0, true, true> : team_mfma_fwd_col_kernel<0, true, false>;
         } else if (cell == 1) kern = keep ? team_mfma_fwd_col_kernel<1, false, true> : team_mfma_fwd_col_kernel<1, false, false>;
@@ -684,8 +947,15 @@ int lstm_team_mfma_backward(int cell, RnnStepArgs a, int max_len, int n_teams, h
     if (int rc = zero_async(xb, ((size_t)TEAM_HDR + (size_t)TEAM_MAX * TEAM_M + (size_t)nt * 4 * TEAM_SLOTS * 4 * TEAM_H) * sizeof(u64), s)) return rc;
     // (the member's own partial sums through the ring instead of LDS + barrier - one barrier per step - was measured: 535-540 us against
     // 517-518, profiles/r04/team_fwd_without_k_split.txt)
-    if (cell == 1) hipLaunchKernelGGL(team_mfma_bwd_kernel<1>, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
-    else hipLaunchKernelGGL(team_mfma_bwd_kernel<0>, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
+#ifdef TEAM_BWD_F32
+    const bool planes = false;
+#else
+    const bool planes = (a.flags & DC_DIMS_F16X2) && !(a.flags & DC_DIMS_BF16) && a.s_grad > 0.f;
+#endif
+    void (*kern)(RnnStepArgs, u64*, int, int);
+    if (cell == 1) kern = planes ? team_mfma_bwd_kernel<1, true> : team_mfma_bwd_kernel<1, false>;
+    else kern = planes ? team_mfma_bwd_kernel<0, true> : team_mfma_bwd_kernel<0, false>;
+    hipLaunchKernelGGL(kern, dim3(nt * TEAM_M), dim3(TM_THREADS), 0, s, a, xb, nt, !(a.flags & DC_DIMS_TEAM_DEVICE_SCOPE));
     return launch_check("lstm_team_mfma_backward");
 }
 

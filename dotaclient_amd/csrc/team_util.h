@@ -35,8 +35,16 @@ __device__ __forceinline__ bool granule_wait(u64 g, const u64* p, unsigned tag, 
 // N granules at once: every granule whose tag is still missing is re-read in the SAME round, so once the data is there the wait ends
 // one L2 round trip later - waited for one after the other, each stale first read paid a round trip of its own (rnn_team512.hip measured
 // that on 30 granules per thread).  g = first reads (possibly issued long ago); false on timeout.
+// The usual case - every lane's first reads already carry the tag - leaves through one ballot and a wave-uniform branch: the loop's
+// lane-divergent exit and re-reads cost ~450 cycles of exec-mask bookkeeping per call even when nothing is missing (round 6, TM_TIMING).
 template <int N>
 __device__ __forceinline__ bool granule_wait_all(u64 (&g)[N], const u64* const (&p)[N], unsigned tag) {
+    {
+        bool missing = false;
+#pragma unroll
+        for (int i = 0; i < N; ++i) missing = missing || (unsigned)(g[i] >> 32) != tag;
+        if (__builtin_amdgcn_ballot_w64(missing) == 0) return true;
+    }
     for (int n = 0;; ++n) {
         bool ok = true;
 #pragma unroll
