@@ -607,7 +607,8 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_fwd_of_kernel(RnnStep
             const float hpub = on ? hn : 0.f;
             ++tag;
             const unsigned pk = f16_planes(hpub, 16.f);
-            granule_store(xb + (tag & 3) * H + u, __uint_as_float(pk), tag, plain);
+            if (plain) granule_store(xb + (tag & 3) * H + u, __uint_as_float(pk), tag, 1);
+            else granule_store(xb + (tag & 3) * H + u, __uint_as_float(pk), tag, 0);
             h_img[(cur ^ 1) * IMG_BUF + slot * TN_HLD + ul] = (unsigned short)pk;
             h_img[(cur ^ 1) * IMG_BUF + IMG_PLANE + slot * TN_HLD + ul] = (unsigned short)(pk >> 16);
             c = on ? cn : c;
@@ -756,6 +757,9 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_bwd_kernel(RnnStepArg
         for (int e = tid; e < 4 * TB_GLD; e += TM_THREADS) g_lds[0][e] = 0.f;      // "step tmax" has no gradient (F16P: buffer 0 lies inside)
         __syncthreads();
 
+#ifdef TM_TIMING
+        long long tacc[6] = {0, 0, 0, 0, 0, 0};
+#endif
         auto step = [&](const int t, float (&cv)[7], float (&nv)[7], auto CUR) {
             constexpr int cur = decltype(CUR)::value;
             const bool on = t < len, has_next = t + 1 < len, dec = t < len && t > 0;      // dec: the row below is next
@@ -778,6 +782,9 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_bwd_kernel(RnnStepArg
                 else if constexpr (!LSTM && k == 16) tm_st(ghs + 2 * H, svh2);
             };
             // ---- partial dh_rec[seq 0..3][u'] over this member's 256 gate columns ------------------------------------------
+#ifdef TM_TIMING
+            const long long tq0 = __builtin_amdgcn_s_memtime();
+#endif
             f32x4 acc;
             if constexpr (F16P) {
                 f32x4 pa[3];
@@ -788,6 +795,9 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_bwd_kernel(RnnStepArg
                 BwdProduct<KH>::run(pa, w, lds_addr(&g_lds[cur][(lane & 3) * TB_GLD + ((lane >> 2) & 7) * TB_BLK]), hook);
                 acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
             }
+#ifdef TM_TIMING
+            const long long tq1 = __builtin_amdgcn_s_memtime();
+#endif
             ++tag;
             u64* const ring = ring0 + (size_t)(tag & 3) * (4 * 4 * 4 * TEAM_US);
             if (xchg) {
@@ -796,45 +806,74 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_bwd_kernel(RnnStepArg
                     for (int q = 0; q < 4; ++q) own[q][lane] = acc[q];
                 } else {                                               // the owner's: [owner = wave][source = member][seq][unit]
                     u64* dst = ring + ((size_t)(wave * 4 + member) * 4) * TEAM_US + lane;
+                    if (plain) {                                       // (one uniform branch, not one per store)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) granule_store(dst + q * TEAM_US, acc[q], tag, plain);
+                        for (int q = 0; q < 4; ++q) granule_store(dst + q * TEAM_US, acc[q], tag, 1);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) granule_store(dst + q * TEAM_US, acc[q], tag, 0);
+                    }
                 }
             }
+#ifdef TM_TIMING
+            const long long tq2 = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();
+#ifdef TM_TIMING
+            const long long tq3 = __builtin_amdgcn_s_memtime();
+#endif
             float rec = 0.f;
+            u64 gr[3] = {0, 0, 0};
+            const u64* ga[3];
             if (xchg) {
-                u64 gr[3];
-                const u64* ga[3];
 #pragma unroll
                 for (int j = 1; j < TEAM_M; ++j) {
                     ga[j - 1] = ring + ((size_t)(member * 4 + ((member + j) & 3)) * 4 + slot) * TEAM_US + ul;
                     gr[j - 1] = granule_load(ga[j - 1]);
                 }
                 rec = own[slot][ul];
+            }
+            // everything of the cell's backward that does not need dh_rec, while the granules are in flight: afterwards the gate gradients
+            // are one fma and four multiplies away.  LSTM: dcv = dh A + B, dg = dcv C0..2, dh C3;  GRU: dg = dh D0..2, dgh_n = dh D3
+            const float ig = cv[0], fg = cv[1], gg = cv[2], og = cv[3];
+            float cA = 0.f, cB = 0.f, cC[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (LSTM) {
+                const float tc = fast_tanh(cv[4]);
+                cA = og * (1.f - tc * tc);
+                cB = has_next ? dc_next * f_next : 0.f;
+                cC[0] = on ? gg * ig * (1.f - ig) : 0.f; cC[1] = on ? cv[5] * fg * (1.f - fg) : 0.f;
+                cC[2] = on ? ig * (1.f - gg * gg) : 0.f; cC[3] = on ? tc * og * (1.f - og) : 0.f;
+            } else {                                       // r = ig, z = fg, n = gg, og = W_hn h + b_hn, cv[5] = h_{t-1}  (rnn.hip)
+                cB = has_next ? dc_next * f_next : 0.f;    // direct path h_{t+1} = ... + z_{t+1} h_t
+                const float d0 = (1.f - fg) * (1.f - gg * gg);
+                cC[2] = d0;                                // dn_pre = dh d0
+                cC[1] = (cv[5] - gg) * fg * (1.f - fg);    // dz_pre
+                cC[0] = d0 * og * ig * (1.f - ig);         // dr_pre
+                cC[3] = d0 * ig;                           // the n column of dgh
+            }
+            if (xchg) {
                 if (!granule_wait_all<3>(gr, ga, tag)) { dead = 1; team_report_timeout(p.fault, TEAM_K_MFMA_BWD, p.layer, team, member, t, b, tag); }
 #pragma unroll
                 for (int j = 1; j < TEAM_M; ++j) rec += __uint_as_float((unsigned)gr[j - 1]);
             }
+#ifdef TM_TIMING
+            asm volatile("" : "+v"(rec));
+            const long long tq4 = __builtin_amdgcn_s_memtime();
+#endif
             float dh = cv[6];
             dh += has_next ? rec : 0.f;
-            const float ig = cv[0], fg = cv[1], gg = cv[2], og = cv[3];
             float dgr[4];                                  // what the next product contracts: d(W_hh h + b_hh) of this step
             if constexpr (LSTM) {
-                const float tc = fast_tanh(cv[4]);
-                float dcv = dh * og * (1.f - tc * tc);
-                dcv += has_next ? dc_next * f_next : 0.f;
-                dgr[0] = on ? dcv * gg * ig * (1.f - ig) : 0.f; dgr[1] = on ? dcv * cv[5] * fg * (1.f - fg) : 0.f;
-                dgr[2] = on ? dcv * ig * (1.f - gg * gg) : 0.f; dgr[3] = on ? dh * tc * og * (1.f - og) : 0.f;
+                const float dcv = dh * cA + cB;
+                dgr[0] = dcv * cC[0]; dgr[1] = dcv * cC[1]; dgr[2] = dcv * cC[2]; dgr[3] = dh * cC[3];
                 sv[0] = on ? dgr[0] : sv[0]; sv[1] = on ? dgr[1] : sv[1]; sv[2] = on ? dgr[2] : sv[2]; sv[3] = on ? dgr[3] : sv[3];
                 dc_next = on ? dcv : dc_next;
-            } else {                                       // r = ig, z = fg, n = gg, og = W_hn h + b_hn, cv[5] = h_{t-1}  (rnn.hip)
-                dh += has_next ? dc_next * f_next : 0.f;   // direct path h_{t+1} = ... + z_{t+1} h_t
-                const float dn_pre = dh * (1.f - fg) * (1.f - gg * gg);
-                const float dz_pre = dh * (cv[5] - gg) * fg * (1.f - fg);
-                const float dr_pre = dn_pre * og * ig * (1.f - ig);
-                dgr[0] = on ? dr_pre : 0.f; dgr[1] = on ? dz_pre : 0.f; dgr[2] = on ? dn_pre * ig : 0.f; dgr[3] = 0.f;
+            } else {
+                dh += cB;
+                const float dn_pre = dh * cC[2], dz_pre = dh * cC[1], dr_pre = dh * cC[0], dnr = dh * cC[3];
+                dgr[0] = on ? dr_pre : 0.f; dgr[1] = on ? dz_pre : 0.f; dgr[2] = on ? dnr : 0.f; dgr[3] = 0.f;
                 sv[0] = on ? dr_pre : sv[0]; sv[1] = on ? dz_pre : sv[1]; sv[2] = on ? dn_pre : sv[2];
-                svh2 = on ? dn_pre * ig : svh2;
+                svh2 = on ? dnr : svh2;
                 dc_next = on ? dh : dc_next;
             }
 #pragma unroll
@@ -849,13 +888,29 @@ __global__ __launch_bounds__(TM_THREADS, 1) void team_mfma_bwd_kernel(RnnStepArg
             f_next = on ? fg : f_next;
             goff = gnx;
             soff = snx;
+#ifdef TM_TIMING
+            const long long tq5 = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();
+#ifdef TM_TIMING
+            const long long tq6 = __builtin_amdgcn_s_memtime();
+            tacc[0] += tq1 - tq0; tacc[1] += tq2 - tq1; tacc[2] += tq3 - tq2; tacc[3] += tq4 - tq3; tacc[4] += tq5 - tq4; tacc[5] += tq6 - tq5;
+#endif
             return dead == 0;
         };
+#ifdef TM_TIMING
+        const long long tg0 = __builtin_amdgcn_s_memtime();
+#endif
         for (int t = tmax - 1; t >= 0; t -= 2) {
             if (!step(t, cur_v, nxt_v, std::integral_constant<int, 0>{})) { failed = true; break; }
             if (t - 1 >= 0 && !step(t - 1, nxt_v, cur_v, std::integral_constant<int, 1>{})) { failed = true; break; }
         }
+#ifdef TM_TIMING
+        if (lane == 0 && (team == 0 || team == 37) && member == 1)
+            printf("team_bwd F16P=%d team %d member %d wave %d plain %d: steps %d  product %.0f  publish %.0f  barrier %.0f  gather %.0f  cell+LDS %.0f  barrier %.0f  loop total/step %.0f (s_memtime ticks per step)\n",
+                   (int)F16P, team, member, wave, plain, tmax, (double)tacc[0] / tmax, (double)tacc[1] / tmax, (double)tacc[2] / tmax, (double)tacc[3] / tmax, (double)tacc[4] / tmax,
+                   (double)tacc[5] / tmax, (double)(__builtin_amdgcn_s_memtime() - tg0) / tmax);
+#endif
         // drain the deferred stores of step 0
 #pragma unroll
         for (int g = 0; g < G; ++g) p.dgx[st_g + g * H] = failed ? __builtin_nanf("") : sv[g];

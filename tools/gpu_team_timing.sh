@@ -4,5 +4,5 @@
 OUT=gpurun_out/${1:-teamt}; mkdir -p $OUT
 for v in $VARIANTS; do
   DC_LIB=$(pwd)/dotaclient_amd/libdotaclient_hip_$v.so timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-weak-unit > $OUT/bench_$v.txt 2>&1
-  echo "--- $v"; grep "^team_fwd_col" $OUT/bench_$v.txt | sort | uniq -c | sort -rn | head -6; grep "^team_fwd_col" $OUT/bench_$v.txt | tail -8
+  echo "--- $v"; grep "^team_" $OUT/bench_$v.txt | tail -${TAIL:-12} | cut -c1-320
 done
