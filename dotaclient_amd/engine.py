@@ -527,7 +527,7 @@ class Engine:
         self.seg_step = device_zeros(len(seg_names), torch.int32, dev)
         self.segsq = device_zeros(len(seg_names) * (1 + (self.max_seg_len + 4095) // 4096), torch.float64, dev)   # totals + per-chunk partial sums
         self.out = device_zeros(16, torch.float32, dev)     # 0..8 losses/entropies, 9..10 norms
-        self.ctl = device_zeros(4, torch.float32, dev)     # clip coefficient, ok flag, arrival counter (u32), unused
+        self.ctl = device_zeros(4, torch.float32, dev)     # clip coefficient, ok flag, arrival counter (u32), release generation (u32)
         self.head_on = device_zeros(8, torch.int32, dev)
         self.status = device_zeros(1, torch.int32, dev)
         # flat offset of the first parameter that is not part of the unit / env embeddings (they come first in the layout)

@@ -286,8 +286,10 @@ int dc_policy_backward(const dc_dims* dims, const float* params, const int64_t* 
 /* optimizer.py:674-681: mean_gradient_norm (before/after), clip_grad_norm_(0.5), NaN guards, Adam.
  *   seg_off i64 / seg_len i32 / seg_gate i32 [n_seg] (device): the named parameters inside the flat
  *   buffer; seg_gate -1 = always has a gradient, 0..4 = only when head k acted, 5 = only if vf_coef>0;
- *   m, v: Adam moments (flat); segsq f64[n_seg * (1 + ceil(max_seg_len / 4096))] (scratch: per-segment totals, then the
- *   per-chunk partial sums), ctl f32[4] (ZERO before the first call; [2] is an arrival counter the call leaves at zero),
+ *   m, v: Adam moments (flat); segsq f64[n_seg * (1 + ceil(max_seg_len / 4096))] (scratch, ZERO before the first call and not to be touched
+ *   between calls: per-segment totals, the per-chunk partial sums, then sixteen arrival counters the call leaves at zero),
+ *   ctl f32[4] (ZERO before the first call; [0] clip coefficient, [1] 1.0 = the update was applied, [2] an arrival counter the call leaves
+ *   at zero, [3] a release generation that grows by one per call),
  *   seg_step i32[n_seg] (persistent step counters), status i32[1] (0 ok, 1 NaN loss, 2 NaN or infinite grad norm: nothing updated; STICKY - while it is non-zero every
  *   later call skips its update too, the caller clears it after handling the error) - all device;
  *   norms_out f32[2] = unclipped, clipped mean gradient norm. */

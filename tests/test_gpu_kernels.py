@@ -431,3 +431,94 @@ def test_gemm_epilogues():
     ops.gemm(A2.to(dev), B2.to(dev), C2, 96, 80, K2, 96, 80, 80, True, True, accumulate=True, splits=8)
     ref2 = A2.double().t() @ B2.double() + 2
     assert (C2.cpu().double() - ref2).abs().max() / ref2.abs().max() < 2e-6
+
+
+def _adam_reference(p, g, m, v, segs, gates, head_on, vf_coef, step, lr, loss):
+    """optimizer.py:674-681 on flat f32 arrays (numpy, f32 arithmetic like torch's): per-parameter norms over the segments that have a
+    gradient, clip_grad_norm_(0.5), Adam(betas 0.9/0.999, eps 1e-8); the NaN guards leave everything alone."""
+    act = [gt < 0 or (gt < 5 and head_on[gt]) or (gt == 5 and vf_coef > 0) for gt in gates]
+    norms = np.array([np.sqrt(np.sum(g[o:o + n].astype(np.float64) ** 2)) for (o, n) in segs], np.float64).astype(np.float32)
+    on = [i for i, a in enumerate(act) if a]
+    unclipped = np.float32(np.mean(norms[on].astype(np.float64)))
+    total = np.float32(np.sqrt(np.sum(norms[on].astype(np.float64) ** 2)))
+    coef = np.float32(min(1.0, 0.5 / (float(total) + 1e-6)))
+    p, g, m, v = p.copy(), g.copy(), m.copy(), v.copy()
+    if np.isnan(loss) or not np.isfinite(total):
+        return p, g, m, v, unclipped, coef, (1 if np.isnan(loss) else 2), step.copy()
+    step = step.copy()
+    for i in on:
+        o, n = segs[i]
+        step[i] += 1
+        gj = g[o:o + n] * coef
+        g[o:o + n] = gj
+        m[o:o + n] = m[o:o + n] + np.float32(1.0 - 0.9) * (gj - m[o:o + n])
+        v[o:o + n] = v[o:o + n] * np.float32(0.999) + np.float32(1.0 - 0.999) * gj * gj
+        bc1, bc2 = 1.0 - 0.9 ** int(step[i]), 1.0 - 0.999 ** int(step[i])
+        denom = np.sqrt(v[o:o + n]) / np.float32(np.sqrt(bc2)) + np.float32(1e-8)
+        p[o:o + n] = p[o:o + n] - np.float32(lr / bc1) * m[o:o + n] / denom
+    return p, g, m, v, unclipped, coef, 0, step
+
+
+@pytest.mark.parametrize('case', ['small', 'ragged', 'beyond_one_chunk_per_block', 'nan_loss', 'inf_grad'])
+def test_gradnorm_clip_adam_single_launch(case):
+    # the one-launch norm -> clip -> Adam kernel (csrc/adam.hip) against optimizer.py:674-681 restated in numpy: segments that are not
+    # multiples of the 4096-element chunk, heads without a gradient, a parameter count beyond ADAM_GRID x 4096 (blocks with several
+    # chunks: only the first stays in registers), both NaN guards (nothing changes), and - every case - three calls in a row: the arrival
+    # counters must be back at zero after each ('small' has no room for the first ticket level: one counter)
+    from dotaclient_amd import _lib
+    dev = _dev()
+    lib = _lib.load()
+    rng = np.random.Generator(np.random.PCG64(11))
+    if case == 'beyond_one_chunk_per_block':
+        lens = [1_500_000, 700_001, 4096, 5, 262_144, 333]
+    elif case == 'small':
+        lens = [7, 1, 300, 4096, 4097]
+    else:
+        lens = [262_144, 1024, 65_536, 1024, 40_960, 160, 12_288, 128, 16_384, 4096 * 3 + 1, 26, 2]
+    gates = [(-1, 0, 3, 5, 4, -1, 1, 2)[i % 8] for i in range(len(lens))]
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    segs = list(zip(offs.tolist(), lens))
+    n = int(sum(lens))
+    head_on = np.array([1, 0, 1, 1, 0], np.int32)
+    vf = 0.5
+    p = rng.standard_normal(n).astype(np.float32)
+    m = (0.01 * rng.standard_normal(n)).astype(np.float32)
+    v = (1e-4 * rng.random(n)).astype(np.float32)
+    step = np.arange(len(lens), dtype=np.int32) % 3
+    t = lambda a: torch.from_numpy(a).to(dev)
+    P, M, V, STEP = t(p), t(m), t(v), t(step)
+    nchunk = (max(lens) + 4095) // 4096
+    segsq = torch.zeros(len(lens) * (1 + nchunk), dtype=torch.float64, device=dev)
+    ctl = torch.zeros(4, dtype=torch.float32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    norms = torch.zeros(2, dtype=torch.float32, device=dev)
+    d_off, d_len, d_gate, d_on = t(offs), t(np.array(lens, np.int32)), t(np.array(gates, np.int32)), t(head_on)
+    for it in range(3):
+        g = (rng.standard_normal(n) * (1e-3 if it == 1 else 1e-1)).astype(np.float32)      # (it 1: norm below the clip, coef = 1)
+        loss = np.float32(0.3)
+        if case == 'nan_loss' and it == 1: loss = np.float32('nan')
+        if case == 'inf_grad' and it == 1: g[5] = np.float32(3e38); g[7] = np.float32(3e38)
+        G = t(g)
+        before = [x.clone() for x in (P, M, V, G, STEP)]
+        losses = t(np.array([loss] + [0] * 8, np.float32))
+        _lib.check(lib.dc_gradnorm_clip_adam(_lib.ptr(d_off), _lib.ptr(d_len), _lib.ptr(d_gate), len(lens), max(lens), _lib.ptr(P), _lib.ptr(G),
+                                             _lib.ptr(M), _lib.ptr(V), _lib.ptr(segsq), _lib.ptr(d_on), _lib.ptr(losses), _lib.ptr(norms),
+                                             _lib.ptr(ctl), _lib.ptr(STEP), _lib.ptr(status), 0.5, vf, 1e-3, 0.9, 0.999, 1e-8,
+                                             _lib.stream_ptr()), 'dc_gradnorm_clip_adam')
+        torch.cuda.synchronize()
+        st_before = int(status.item())
+        ep, eg, em, ev, unclipped, coef, st, estep = _adam_reference(p, g, m, v, segs, gates, head_on, vf, step, 1e-3, loss)
+        raw = ctl.cpu().numpy().view(np.uint32)
+        assert raw[2] == 0 and raw[3] == it + 1, (case, it, raw)          # arrival counter back at zero, one release generation per call
+        assert float(segsq[len(lens) + sum((n + 4095) // 4096 for n in lens):].abs().sum()) == 0.0, (case, it)      # first-level counters too
+        if st_before == 0 and st == 0:
+            assert abs(float(norms[0]) - float(unclipped)) <= 1e-6 * float(unclipped), (case, it)
+            assert abs(float(ctl[0]) - float(coef)) <= 2e-6 * float(coef), (case, it, float(ctl[0]), float(coef))
+            for name, got, exp in (('p', P, ep), ('g', G, eg), ('m', M, em), ('v', V, ev)):
+                assert util.scaled_err(exp, got.cpu().numpy()) < 2e-6, (case, it, name)
+            assert np.array_equal(STEP.cpu().numpy(), estep), (case, it)
+            p, m, v, step = ep, em, ev, estep
+        else:
+            # a guard tripped (this call or, sticky, an earlier one): parameters, moments, gradients and step counters untouched
+            assert st_before == (1 if case == 'nan_loss' else 2), (case, it, st_before)
+            assert all(torch.equal(x, y) for x, y in zip((P, M, V, G, STEP), before)), (case, it)
