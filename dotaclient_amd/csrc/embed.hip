@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(
                 sum_dt += d;
                 float g = d * qc;
                 if (u == am[t]) g += pool[t];
-                p[u * EMB] = g;
+                if (skip16 != 2) p[u * EMB] = g;       // (2: the small types' backward forms its d(emb) on chip too, embed_small.hip)
             }
             gb2[t] += sum_dt * qc + pool[t];           // column sum of this step's demb rows of type t
         }
@@ -328,7 +328,7 @@ int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, c
     const int nblk = (int)((nr + spb - 1) / spb);        // <= 2048 -> <= 10.5 MB of scratch
     // algorithmic bytes: d(emb) rows written for the units this pass owns (8 of 40 with skip16), xcat / dxcat rows, the
     // attention query, the target-unit gradients
-    const double units = skip16 ? 8.0 : 40.0;
+    const double units = skip16 == 2 ? 0.0 : (skip16 ? 8.0 : 40.0);
     ProfScope prof("embed_scatter_bwd(+reduce)", 2.0 * nr * units * 128, 4.0 * nr * (units * 128 + 896 * 2 + 128 + 40), s);
     hipLaunchKernelGGL(embed_scatter_bwd_kernel, dim3(nblk), dim3(256), 0, s, obs, xcat, dxcat, dtu, q, ldq, amax, demb,
                        scratch, nr, nrp, spb, skip16);

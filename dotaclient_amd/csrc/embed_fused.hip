@@ -723,9 +723,16 @@ int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const 
                     const EmbSparseIn* sp, hipStream_t s, F16x2Scales f16) {
     int nwg;
     const bool sparse16 = sp != nullptr;
-    const EmbTypes ty = make_types(nr, nr_valid, &nwg, sparse16);
+    EmbTypes ty = make_types(nr, nr_valid, &nwg, sparse16);
+    const bool small_fused = embed_small_fused(sparse16, f16, sp);
+    if (small_fused) {
+        // embed_small.hip's 256 workgroups (32 per unit of a small type) around the 2 x 128 of the 16-unit types, in splitk_reduce_grouped's order
+        const int wb[7] = {0, 32, 192, 192 + SPARSE_WG_PER_TYPE, 192 + 2 * SPARSE_WG_PER_TYPE, 224 + 2 * SPARSE_WG_PER_TYPE, 256 + 2 * SPARSE_WG_PER_TYPE};
+        for (int t = 0; t <= 6; ++t) ty.wg_begin[t] = wb[t];
+        nwg = wb[6];
+    }
     const long long sp_floats = sparse16 ? 2LL * SPARSE_WG_PER_TYPE * (1664 + 128) : 0;
-    if ((long long)nwg * EF_EMB * EF_EMB + sp_floats > scratch_floats || 512LL * 1664 + sp_floats > scratch_floats) {
+    if ((long long)nwg * EF_EMB * EF_EMB + sp_floats + (small_fused ? 256LL * 1664 : 0) > scratch_floats || 512LL * 1664 + sp_floats > scratch_floats) {
         set_error("embed_bwd_fused: scratch too small", 1040);
         return 1040;
     }
@@ -741,6 +748,14 @@ int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const 
         } else if (int e = embed_bwd_pool16(obs, sp->dxcat, sp->amax, sp->dtu, sp->q, sp->ldq, W1, b1, W2,
                                             scratch + (size_t)ty.wg_begin[2] * EF_EMB * EF_EMB, part1, part2, sp->prep, nr_valid, SPARSE_WG_PER_TYPE, s, sp->eight_waves))
             return e;
+    }
+    if (small_fused) {
+        // the four small types in one kernel with on-chip operands (embed_small.hip): d(emb) does not exist for any type on this path
+        float* const part_small = scratch + (size_t)nwg * EF_EMB * EF_EMB;
+        if (int e = embed_bwd_small(obs, sp->dxcat, sp->amax, sp->dtu, sp->q, sp->ldq, W1, b1, W2, scratch, 2 * SPARSE_WG_PER_TYPE, part_small, nr_valid, s, f16))
+            return e;
+        if (int e = splitk_reduce_grouped(scratch, dW2, EF_EMB, EF_EMB, 6, ty.wg_begin, s)) return e;
+        return embed_tail_reduce(part_small, 256, part1, 2 * SPARSE_WG_PER_TYPE, dW1, db1, part2, SPARSE_WG_PER_TYPE, sp->db2 + 2 * 128, s);
     }
     {
         const size_t lds = (size_t)(4 * 4096) * sizeof(float);

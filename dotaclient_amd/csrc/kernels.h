@@ -135,7 +135,13 @@ int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const fl
 // inputs of the sparse max-pool backward of the two 16-unit types (embed_sparse.hip); db2 [6][128] is accumulated into
 // (prep: 2 * nr * 736 floats of scratch - it lives in the d(emb) rows of the two types, which the sparse path never writes)
 struct EmbSparseIn { const float* dxcat; const uint8_t* amax; const float* dtu; const float* q; int ldq; float* db2; float* prep;
-                     int eight_waves = 0; int valu = 0; };      // valu: keep embed_sparse.hip's kernels in f16x2 mode too (DC_DIMS_POOL16_VALU)
+                     int eight_waves = 0; int valu = 0;         // valu: keep embed_sparse.hip's kernels in f16x2 mode too (DC_DIMS_POOL16_VALU)
+                     int small_dense = 0; };                    // small_dense: the four small types through d(emb) in HBM and the dense kernels (DC_DIMS_SMALL_DENSE)
+// the four small types' backward fused (embed_small.hip) - decided in one place: policy.hip (what embed_scatter_bwd writes) and
+// embed_bwd_fused (what it launches) must agree
+inline bool embed_small_fused(bool sparse16, const F16x2Scales& f16, const EmbSparseIn* sp) {
+    return sparse16 && f16.on && sp && !sp->valu && !sp->eight_waves && !sp->small_dense;
+}
 int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const float* b1, const float* W2, float* dW2,
                     float* dW1, float* db1, float* scratch, long long scratch_floats, long long nr_valid, long long nr_padded,
                     const EmbSparseIn* sp, hipStream_t s, F16x2Scales f16 = F16x2Scales());
@@ -147,6 +153,9 @@ int embed_bwd_pool16(const float* obs, const float* dxcat, const uint8_t* amax, 
 int embed_bwd_pool16m(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq,
                       const float* W1, const float* b1, const float* W2, float* slab, float* part1, float* part2, float* scratch_r,
                       long long nr, int wg_per_type, hipStream_t s, const F16x2Scales& f16);      // scratch_r: 2 * nr * 128 floats
+// embed_small.hip: the four small types (needs F16x2Scales.on); slab / part in the dense kernels' formats
+int embed_bwd_small(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq, const float* W1,
+                    const float* b1, const float* W2, float* slab, int slab_skip, float* part, long long nr, hipStream_t s, const F16x2Scales& f16);
 // heads.hip
 int attn_logits(const float* headout, const float* emb, float* tu, long long nr, long long nrp, hipStream_t s);
 // target-unit logits of the units whose mask byte (mask[n][22 + u]) is set; 0 elsewhere

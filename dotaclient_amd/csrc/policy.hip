@@ -422,10 +422,18 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     const long long NRp = emb_rows(d);
     const bool sparse16 = fusedb && embed_sparse_enabled(d);
     const uint8_t* amaxp = reinterpret_cast<const uint8_t*>(w.base + w.off[DC_WS_AMAX]);
+    // the inputs of the on-chip backward kernels (embed_pool16m.hip, embed_small.hip), and which of them run
+    const EmbSparseIn sp{w.f(DC_WS_DXCAT), amaxp, w.f(DC_WS_DTU), w.f(DC_WS_HEADOUT), HO_LD, Gd.p(DC_P_UNIT_B),
+                         w.f(DC_WS_DEMB) + (size_t)NRp * T_CUM[2] * EMBW, (d->flags & DC_DIMS_POOL16_8W) ? 1 : 0,
+                         (d->flags & DC_DIMS_POOL16_VALU) ? 1 : 0, (d->flags & DC_DIMS_SMALL_DENSE) ? 1 : 0};
+    F16x2Scales fs;
+    fs.on = (d->flags & DC_DIMS_F16X2) && !(d->flags & DC_DIMS_GEMM_FASTTILE);
+    fs.s_act = F16X2_S_ACT; fs.s_w = F16X2_S_W; fs.s_grad = s_grad;
+    const bool small_fused = embed_small_fused(sparse16, fs, &sp);      // then d(emb) is not written for ANY type
     DC_TRY(embed_scatter_bwd(obs, w.f(DC_WS_XCAT), w.f(DC_WS_DXCAT), w.f(DC_WS_DTU), w.f(DC_WS_HEADOUT), HO_LD, amaxp,
                              w.f(DC_WS_DEMB), Gd.p(DC_P_ENV_W), Gd.p(DC_P_ENV_B), Gd.p(DC_P_UNIT_B), w.f(DC_WS_SCRATCH), NR,
-                             NRp, sparse16 ? 1 : 0, s));
-    if (fusedb && NRp > NR) {
+                             NRp, small_fused ? 2 : (sparse16 ? 1 : 0), s));
+    if (fusedb && NRp > NR && !small_fused) {
         // padding steps of the type-major d(emb) blocks the dense kernels read: zero gradients
         for (int t = 0; t < 6; ++t) {
             if (sparse16 && (t == 2 || t == 3)) continue;
@@ -438,12 +446,6 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         // accumulators) - neither `basic` nor d(basic) exists in HBM on this path
         // the prepared staging blocks of the sparse path live in the d(emb) rows of the two 16-unit types (2 * 16 * 128 floats per
         // step, never written on that path; the prepared blocks take 2 * 736)
-        const EmbSparseIn sp{w.f(DC_WS_DXCAT), amaxp, w.f(DC_WS_DTU), w.f(DC_WS_HEADOUT), HO_LD, Gd.p(DC_P_UNIT_B),
-                             w.f(DC_WS_DEMB) + (size_t)NRp * T_CUM[2] * EMBW, (d->flags & DC_DIMS_POOL16_8W) ? 1 : 0,
-                             (d->flags & DC_DIMS_POOL16_VALU) ? 1 : 0};
-        F16x2Scales fs;
-        fs.on = (d->flags & DC_DIMS_F16X2) && !(d->flags & DC_DIMS_GEMM_FASTTILE);
-        fs.s_act = F16X2_S_ACT; fs.s_w = F16X2_S_W; fs.s_grad = s_grad;
         DC_TRY(embed_bwd_fused(obs, w.f(DC_WS_DEMB), P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), P.p(DC_P_UNIT_W), Gd.p(DC_P_UNIT_W),
                                Gd.p(DC_P_BASIC_W), Gd.p(DC_P_BASIC_B), w.f(DC_WS_SCRATCH), DC_SCRATCH_FLOATS, NR, NRp,
                                sparse16 ? &sp : nullptr, s, fs));

@@ -198,6 +198,10 @@ typedef struct dc_dims {
  *                            and what dc_chunk_initial_state / dc_select_logp read are complete.  Calling dc_policy_backward after such a
  *                            forward is a caller error (the gradients would be garbage, not an error code). */
 #define DC_DIMS_FWD_ONLY 16777216
+/*   DC_DIMS_SMALL_DENSE    : with DC_DIMS_F16X2 the backward of the four small unit types (8 of the 40 units) runs as ONE kernel with every
+ *                            operand formed on chip (csrc/embed_small.hip, round 6) and d(emb) is written for no type; this flag keeps rounds
+ *                            1-5's path for them - d(emb) rows in HBM, embed_bwd_dw2 + embed_bwd_dw1 - for A/B. */
+#define DC_DIMS_SMALL_DENSE 33554432
 
 /* index into poff[]; policy.py:54-75 names in comments */
 enum dc_param_index {

@@ -349,9 +349,11 @@ def test_sparse_pool_backward_matches_dense(lens):
     from dotaclient_amd.engine import Engine, pack_rollouts
     dev = torch.device('cuda:0')
     outs = {}
-    for mode in ('0', '1', '16w', '8w'):   # dense kernels / on-chip dense (default) / sparse sixteen-wave kernel / sparse eight-wave kernel
+    # (round 6: by default the four SMALL types are on chip too - embed_small.hip, no d(emb) for any type; 'sd' = DC_DIMS_SMALL_DENSE keeps
+    # them on d(emb) in HBM + the dense kernels next to the on-chip 16-unit kernels)
+    for mode in ('0', '1', 'sd', '16w', '8w'):   # dense kernels / on-chip (default) / on-chip 16-unit types only / sparse sixteen-wave kernel / sparse eight-wave kernel
         eng = Engine('lstm', 128, 1, dev)
-        eng.kernel_flags = {'0': E.DC_DIMS_DENSE_POOL_BWD, '1': 0, '16w': E.DC_DIMS_POOL16_VALU, '8w': E.DC_DIMS_POOL16_8W}[mode]
+        eng.kernel_flags = {'0': E.DC_DIMS_DENSE_POOL_BWD, '1': 0, 'sd': E.DC_DIMS_SMALL_DENSE, '16w': E.DC_DIMS_POOL16_VALU, '8w': E.DC_DIMS_POOL16_8W}[mode]
         eng.load_state_dict(synth.init_state_dict(7, 'lstm', 128, 1))
         rollouts = synth.make_rollouts(91, lens)
         batch = pack_rollouts(rollouts, 128, dev)
@@ -361,7 +363,8 @@ def test_sparse_pool_backward_matches_dense(lens):
         g = {n: eng.param_view(n, eng.grads).cpu().numpy().copy() for n in
              ('affine_unit_basic_stats.weight', 'affine_unit_basic_stats.bias', 'affine_unit_anh.weight',
               'affine_unit_enh.weight', 'affine_unit_anh.bias', 'affine_unit_enh.bias', 'affine_unit_eh.weight',
-              'affine_unit_ah.bias', 'affine_env.weight')}
+              'affine_unit_ah.weight', 'affine_unit_ath.weight', 'affine_unit_eth.weight', 'affine_unit_eh.bias',
+              'affine_unit_ah.bias', 'affine_unit_ath.bias', 'affine_unit_eth.bias', 'affine_env.weight', 'affine_env.bias')}
         outs[mode] = (g, res.cpu().numpy().copy(), eng.params.cpu().numpy().copy())
     # All variants evaluate the relu mask of the first layer with exact-f32 MFMAs (a first version of the on-chip kernel took the forward's
     # two-f16-piece sequence: one pre-activation in ~10^6 got the other sign, a whole term of ONE hidden unit's row of dW1 / db1 - 3.6e-3 of
@@ -384,6 +387,10 @@ def test_sparse_pool_backward_matches_dense(lens):
             assert util.scaled_err(a, b) < 2e-5, (n, util.scaled_err(a, b))
     assert util.scaled_err(outs['1'][1][:11], outs['0'][1][:11]) < 2e-5
     assert util.scaled_err(outs['1'][2], outs['0'][2]) < 5e-5
+    for n in outs['0'][0]:              # the 16-unit types on chip, the small ones dense: between the two
+        if not n.startswith('affine_unit_basic_stats'):
+            assert util.scaled_err(outs['sd'][0][n], outs['0'][0][n]) < 2e-5, n
+    assert not np.array_equal(outs['sd'][0]['affine_unit_eh.weight'], outs['1'][0]['affine_unit_eh.weight'])     # really another kernel
     for n in outs['0'][0]:              # the sparse VALU kernels: the same sums in another order
         assert util.scaled_err(outs['8w'][0][n], outs['0'][0][n]) < 2e-5, n
         assert util.scaled_err(outs['16w'][0][n], outs['0'][0][n]) < 2e-5, n
