@@ -95,9 +95,10 @@ def pmc_traffic(path, kernel, workload_key):
     if j.get('meta', {}).get('workload') not in (None, workload_key):
         return None
     # profiling region -> kernel(s) that run inside it (the first one present in the summary wins)
-    region_kernels = {'embed_bwd_pool16': ['embed_bwd_pool16w', 'embed_bwd_pool16'], 'embed_bwd_pool16m': [('embed_pool16m_dw2', 'embed_pool16m_dw1')], 'gru_fwd_team': ['team_mfma_fwd_col', 'team_mfma_fwd', 'team8_fwd', 'rnn_team_fwd'],
+    region_kernels = {'embed_bwd_pool16': ['embed_bwd_pool16w', 'embed_bwd_pool16'], 'embed_bwd_pool16m': [('embed_pool16m_dw2', 'embed_pool16m_dw1')], 'gru_fwd_team': ['team_mfma_fwd_of', 'team_mfma_fwd_col', 'team_mfma_fwd', 'team8_fwd', 'rnn_team_fwd'],
                       'gru_bwd_team': ['team_mfma_bwd', 'team8_bwd', 'rnn_team_bwd'],
-                      'lstm_fwd_team': ['team_mfma_fwd_col', 'team_mfma_fwd', 'team8_fwd', 'rnn_team_fwd'], 'lstm_bwd_team': ['team_mfma_bwd', 'team8_bwd', 'rnn_team_bwd'],
+                      'lstm_fwd_team': ['team_mfma_fwd_of', 'team_mfma_fwd_col', 'team_mfma_fwd', 'team8_fwd', 'rnn_team_fwd'], 'lstm_bwd_team': ['team_mfma_bwd', 'team8_bwd', 'rnn_team_bwd'],
+                      'embed_bwd_small': ['embed_small_bwd'], 'gradnorm_clip_adam': ['gradnorm_clip_adam'],
                       'lstm_fwd_persist': ['lstm_fwd_valu'], 'lstm_bwd_persist': ['lstm_bwd_valu'],
                       'gemm_f32_dW': ['gemm_x3'], 'gemm_f32_fwd': ['gemm_fast', 'gemm_x3'], 'gemm_f32_dX': ['gemm_fast', 'gemm_x3']}
     if PRODUCTS == 'f16x2':       # x W^T / dy W: the row-streaming kernel (gemm_x3s.hip, round 6; one PMC row: the average over its launches), else the split-on-load kernel
@@ -326,7 +327,7 @@ def latency_peak(region, prec_bf16, hidden):
 REGION_BOUND = {
     'embed_fwd_fused': 'mfma', 'embed_bwd_dw2': 'mfma', 'embed_bwd_dw1': 'mfma', 'gemm_f32_fwd(NT)': 'mfma', 'gemm_f32_dX(NN)': 'mfma',
     'gemm_f32_dW(TN,split-K)': 'mfma',
-    'embed_bwd_pool16': 'valu', 'embed_bwd_pool16m': 'mfma',
+    'embed_bwd_pool16': 'valu', 'embed_bwd_pool16m': 'mfma', 'embed_bwd_small': 'mfma',
     'lstm_fwd_persist': 'latency', 'lstm_bwd_persist': 'latency', 'gru_fwd_team': 'latency', 'gru_bwd_team': 'latency',
     'lstm_fwd_team': 'latency', 'lstm_bwd_team': 'latency', 'rnn_fwd_steps': 'latency', 'rnn_bwd_steps': 'latency',
     'pool_env_fwd': 'hbm', 'embed_scatter_bwd(+reduce)': 'hbm', 'ppo_loss(stats+loss+finalize)': 'hbm', 'gradnorm_clip_adam': 'hbm',
@@ -347,6 +348,9 @@ BOUND_NOTES = {
     'hbm': 'streams its operands once: priced against the 8 TB/s HBM peak',
 }
 REGION_NOTES = {
+    'embed_bwd_small': 'embedding backward of the four small unit types (8 of the 40 units; policy.py:100-105,118-127 under optimizer.py:672) as one '
+                       'kernel with every operand formed on chip (csrc/embed_small.hip, round 6: d(emb) exists for no type): flops = 2 x rows x 128 x '
+                       '(2 x 128 + 24); rounds 1-5: embed_scatter_bwd wrote d(emb), embed_bwd_dw2 + embed_bwd_dw1 read it back (0.16 / 0.12 of the ceiling)',
     'embed_bwd_pool16m': 'max-pool backward of the two 16-unit types as the DENSE products of the reference\'s autograd (policy.py:102-136 under '
                          'optimizer.py:672) on the f16 matrix cores, every operand generated on chip (csrc/embed_pool16m.hip: two kernels, dW2 and '
                          'd(basic) -> dW1): flops = the dense count SURVEY.md 8(d) uses; round 4 ran the sparse form on the vector unit '
