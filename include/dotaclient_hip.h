@@ -33,7 +33,7 @@ typedef void* dc_stream_t; /* hipStream_t */
  * DC_WS_TEAM_XBUF / DC_WS_WPLANES) were version 2 in effect.
  * 4 (round 4): dc_policy_forward takes the action masks (unit_mask); otherwise same signatures, changed contracts - dc_gradnorm_clip_adam's status word is sticky (a non-zero word makes later calls
  * skip their update until the caller clears it); dc_gae_scan / dc_discount / dc_advantage_returns accept any length (error 1001 is gone).
- * (round 6 added dc_dims.flags / prec BITS only - DC_DIMS_GEMM_TILE128, DC_DIMS_FWD_ONLY, DC_GEMM_PREC_TILE128: a caller that does not set them gets
+ * (round 6 added dc_dims.flags / prec BITS only - DC_DIMS_GEMM_TILE128, DC_DIMS_FWD_ONLY, DC_DIMS_SMALL_DENSE, DC_GEMM_PREC_TILE128: a caller that does not set them gets
  * the same results as before from the same signatures, so the number stays.)
  * The Python binding refuses any other value. */
 #define DC_ABI_VERSION 4
