@@ -191,7 +191,9 @@ __global__ __launch_bounds__(ES_THREADS, 1) void embed_small_bwd_kernel(SmallArg
                 c0m[i] = __builtin_amdgcn_perm(o.pm[2 * i + 1][h2], o.pm[2 * i][h2], 0x05040100u);
                 c1m[i] = __builtin_amdgcn_perm(o.pm[2 * i + 1][h2], o.pm[2 * i][h2], 0x07060302u);
             }
-            _Float16* const ch = dcm + (4 * cq + 2 * h2) * ES_CM_LD + 16 * W + 8 * hf;
+            // (the 16-byte chunk of eight rows sits at chunk ^ ((c >> 4) & 3) of its channel's row: lanes four channels apart would otherwise put
+            // these stores four to a bank group; P2's reads stay conflict-free - the XOR's lane part there is fq ^ (fr >> 4))
+            _Float16* const ch = dcm + (4 * cq + 2 * h2) * ES_CM_LD + 8 * ((2 * W + hf) ^ ((cq >> 2) & 3));
             *reinterpret_cast<u32x4*>(ch) = c0h;
             *reinterpret_cast<u32x4*>(ch + ES_CM_LD) = c1h;
             *reinterpret_cast<u32x4*>(ch + ES_CM_PLANE) = c0m;
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(ES_THREADS, 1) void embed_small_bwd_kernel(SmallArg
         // ---- P2: dW2^T[k][c] += basic^T demb, K = the tile's rows: this wave's 32 hidden units x all 128 channels ------------------------
         {
             const _Float16* const ak = h1t + (32 * W + fr) * ES_CM_LD + 8 * fq;
-            const _Float16* const bc = dcm + fr * ES_CM_LD + 8 * fq;
+            const _Float16* const bc = dcm + fr * ES_CM_LD + 8 * (fq ^ (fr >> 4));        // ([c][row] image: chunk swizzle, see build_store)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const f16x8 ah = *reinterpret_cast<const f16x8*>(ak + 16 * ks);
@@ -307,8 +309,8 @@ __global__ __launch_bounds__(ES_THREADS, 1) void embed_small_bwd_kernel(SmallArg
                 f16x8 bh[4], bm[4];
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
-                    bh[cb] = *reinterpret_cast<const f16x8*>(bc + cb * 32 * ES_CM_LD + 16 * ks);
-                    bm[cb] = *reinterpret_cast<const f16x8*>(bc + cb * 32 * ES_CM_LD + ES_CM_PLANE + 16 * ks);
+                    bh[cb] = *reinterpret_cast<const f16x8*>(bc + cb * 32 * ES_CM_LD + 16 * (ks ^ (cb & 1)));
+                    bm[cb] = *reinterpret_cast<const f16x8*>(bc + cb * 32 * ES_CM_LD + ES_CM_PLANE + 16 * (ks ^ (cb & 1)));
                 }
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) acc2[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh[cb], acc2[cb], 0, 0, 0);

@@ -339,12 +339,14 @@ def test_rnn_team_kernels_agree_with_per_step(cell, S, lens):
             assert util.scaled_err(a, b) < 2e-5, (key, util.scaled_err(a, b))
 
 
-@pytest.mark.parametrize('lens', [[128] * 4, [256] * 6, [384, 128, 256], [128] * 3])
+@pytest.mark.parametrize('lens', [[128] * 4, [256] * 6, [384, 128, 256], [128] * 3, [100, 150, 77], [33]])
 def test_sparse_pool_backward_matches_dense(lens):
     # fused embedding path (rows % 128 == 0): the max-pool backward of the two 16-unit types - default (f16x2 products): dense products on
     # the f16 matrix cores with on-chip operands (embed_pool16m.hip); DC_DIMS_POOL16_VALU / _8W: the sparse VALU kernels (embed_sparse.hip) -
     # against the dense MFMA kernels that read d(emb) from HBM, on the same batch: gradients and post-step parameters.  [128] * 3: 384 steps
     # over 128 workgroups = an odd number of steps per workgroup (the matrix-core kernel works on PAIRS of steps)
+    # [100, 150, 77] / [33]: 327 / 33 steps that exist inside 384 / 128 padded ones - the small-type kernel's last tile is partial (33 steps of the 5-unit
+    # type: 165 rows = two tiles and 37 rows) and most of its workgroups have no rows at all
     from dotaclient_amd import engine as E
     from dotaclient_amd.engine import Engine, pack_rollouts
     dev = torch.device('cuda:0')
