@@ -280,6 +280,21 @@ struct LossArgs {
 // (66 us per launch; this one is bound by its ~1 KB per step of traffic).  Same arithmetic per element:
 // no max-subtraction (policy.py:172), tie/clamp gradient rules of torch.min / clamp, batch sums in f64.
 __device__ __forceinline__ int head_of_col(int c) { return c < 4 ? 0 : (c < 13 ? 1 : (c < 22 ? 2 : (c < 62 ? 3 : 4))); }
+// Slot m of a lane is column j + 16 m: columns 0..15 belong to heads 0, 1, 2 only, 16..31 to heads 2, 3, 32..47 to head 3, 48..63 to heads 3, 4, 64 to
+// head 4.  The loops over slots are unrolled, so these fold to constants and the per-head select chains below keep 9 of their 25 links (the
+// kernel is bound by its instruction count: ~1 800 per 16-lane group and step before).
+__device__ __forceinline__ constexpr bool slot_has(int m, int kk) {
+    return m == 0 ? kk <= 2 : (m == 1 ? (kk == 2 || kk == 3) : (m == 2 ? kk == 3 : (m == 3 ? (kk == 3 || kk == 4) : kk == 4)));
+}
+__device__ __forceinline__ constexpr int slot_top(int m) { return m == 0 ? 2 : (m <= 2 ? 3 : 4); }      // highest head a slot can hold: the chain's default
+template <class T>
+__device__ __forceinline__ T pick_head(int m, int k, const T (&a)[5]) {
+    T r = a[slot_top(m)];
+#pragma unroll
+    for (int kk = 3; kk >= 0; --kk)
+        if (slot_has(m, kk) && kk != slot_top(m)) r = k == kk ? a[kk] : r;
+    return r;
+}
 
 // losses[0..3] = loss, policy_loss, entropy_loss, value_loss ; losses[4..8] = entropies per head
 // (optimizer.py:649-665, 682-689); flags[0..4] = 1 if head k had at least one action in the batch.  One thread.
@@ -385,6 +400,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
         cand[m] = ac ? c : 127;
 #pragma unroll
         for (int kk = 0; kk < 5; ++kk) {
+            if (!slot_has(m, kk)) continue;
             se_c[kk] += (valid && k == kk) ? e[m] : 0.f;
             amin_c[kk] = (valid && k == kk) ? min(amin_c[kk], cand[m]) : amin_c[kk];
         }
@@ -407,18 +423,16 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
         const int c = j + 16 * m;
         const bool valid = c < ACT;
         const int k = head_of_col(valid ? c : 0);
-        float lsek = lse[4];
-        lsek = k == 3 ? lse[3] : lsek; lsek = k == 2 ? lse[2] : lsek; lsek = k == 1 ? lse[1] : lsek; lsek = k == 0 ? lse[0] : lsek;
+        const float lsek = pick_head(m, k, lse);
         lp[m] = z[m] - lsek;
         pc[m] = mk[m] ? expf(lp[m]) : 0.f;
         const float ht = mk[m] ? pc[m] * lp[m] : 0.f;
 #pragma unroll
-        for (int kk = 0; kk < 5; ++kk) h_c[kk] -= (valid && k == kk) ? ht : 0.f;
+        for (int kk = 0; kk < 5; ++kk)
+            if (slot_has(m, kk)) h_c[kk] -= (valid && k == kk) ? ht : 0.f;
         // owner of the head's selected action (lowest set column)
-        int amk = amin[4];
-        amk = k == 3 ? amin[3] : amk; amk = k == 2 ? amin[2] : amk; amk = k == 1 ? amin[1] : amk; amk = k == 0 ? amin[0] : amk;
-        float nsk = nselv[4];
-        nsk = k == 3 ? nselv[3] : nsk; nsk = k == 2 ? nselv[2] : nsk; nsk = k == 1 ? nselv[1] : nsk; nsk = k == 0 ? nselv[0] : nsk;
+        const int amk = pick_head(m, k, amin);
+        const float nsk = pick_head(m, k, nselv);
         if (valid && c == amk && nsk > 0.f) {     // at most one column per head in the whole row
             const float ratio = expf(lp[m] - p.old_logp[nn * 5 + k]);
             const float s1 = ratio * A;
@@ -430,11 +444,12 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
             float w1, w2;
             if (s1 < s2) { w1 = 1.f; w2 = 0.f; } else if (s1 > s2) { w1 = 0.f; w2 = 1.f; } else { w1 = 0.5f; w2 = 0.5f; }
             const float dmin_dr = A * (w1 + (inr ? w2 : 0.f));
-            double i5n = sh_inv[4];
-            i5n = k == 3 ? sh_inv[3] : i5n; i5n = k == 2 ? sh_inv[2] : i5n; i5n = k == 1 ? sh_inv[1] : i5n; i5n = k == 0 ? sh_inv[0] : i5n;
+            const double i5v[5] = {sh_inv[0], sh_inv[1], sh_inv[2], sh_inv[3], sh_inv[4]};
+            const double i5n = pick_head(m, k, i5v);
             const float g = (float)(-(double)dmin_dr * (double)ratio * i5n);
 #pragma unroll
             for (int kk = 0; kk < 5; ++kk) {
+                if (!slot_has(m, kk)) continue;
                 glp_c[kk] += k == kk ? g : 0.f;
                 polc[kk] += k == kk ? polv : 0.f;
             }
@@ -461,12 +476,8 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
         const int c = j + 16 * m;
         if (c < ACT && on) {
             const int k = head_of_col(c);
-            float gl = glp[4], ge = gent[4], hr = Hrow[4];
-            int amk = amin[4];
-#pragma unroll
-            for (int kk = 3; kk >= 0; --kk) {
-                gl = k == kk ? glp[kk] : gl; ge = k == kk ? gent[kk] : ge; hr = k == kk ? Hrow[kk] : hr; amk = k == kk ? amin[kk] : amk;
-            }
+            const float gl = pick_head(m, k, glp), ge = pick_head(m, k, gent), hr = pick_head(m, k, Hrow);
+            const int amk = pick_head(m, k, amin);
             float g = mk[m] ? (-gl * pc[m] + ge * pc[m] * (lp[m] + hr)) : 0.f;
             // (k == 3: an action on a masked-out unit - the actors never send one, agent.py:666-671 - gets no gradient, so that d(tu) is
             // exactly zero outside the mask: the backward may then rely on "dtu != 0 => the unit's embedding row was stored")
