@@ -190,39 +190,9 @@ __device__ __forceinline__ int head_grad_col(int k, int c) {
 
 // ---------------------------------------------------------------------------------------------------
 // rollout-pass epilogue (optimizer.py:387-390): log-prob of the selected action per head (0 where the
-// head has no action in that step), the value, and the masked argmax per head (-1 on an empty mask).
-// One thread per (env-step, head).
+// head has no action in that step), the value, and the masked argmax per head (-1 on an empty mask):
+// select_logp_kernel, further down (next to ppo_loss_kernel, whose lane layout and helpers it shares).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void select_logp_kernel(const float* __restrict__ headout, const float* __restrict__ tu,
-                                                          const uint8_t* __restrict__ act, const uint8_t* __restrict__ mask,
-                                                          float* __restrict__ logp_sel, float* __restrict__ values,
-                                                          int32_t* __restrict__ argmax, long long nr) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nr * 5) return;
-    const long long n = idx / 5;
-    const int k = (int)(idx - n * 5);
-    const float* ho = headout + n * HO_LD;
-    const float* tun = tu + n * NUNITS;
-    const int o = c_head_off[k], C = c_head_off[k + 1] - o;
-    const uint8_t* m = mask + n * ACT + o;
-    const uint8_t* a = act + n * ACT + o;
-    float se = 0.f, best = -INFINITY;
-    int bi = -1, ai = -1;
-    for (int c = 0; c < C; ++c) {
-        const float z = head_logit(ho, tun, k, c);
-        if (m[c]) {
-            se += expf(z);                     // policy.py:172-175: no max-subtraction
-            if (z > best) { best = z; bi = c; }
-        }
-        if (a[c] && ai < 0) ai = c;
-    }
-    float lp = 0.f;
-    if (ai >= 0) lp = head_logit(ho, tun, k, ai) - logf(se);
-    logp_sel[n * 5 + k] = lp;
-    if (argmax) argmax[n * 5 + k] = bi;
-    if (k == 0) values[n] = ho[HO_VALUE];
-}
-
 // ---------------------------------------------------------------------------------------------------
 // batch statistics needed before the loss: sum / sum-of-squares of the advantages (optimizer.py:588)
 // and the number of steps that took an action per head (optimizer.py:626,643)
@@ -294,6 +264,83 @@ __device__ __forceinline__ T pick_head(int m, int k, const T (&a)[5]) {
     for (int kk = 3; kk >= 0; --kk)
         if (slot_has(m, kk) && kk != slot_top(m)) r = k == kk ? a[kk] : r;
     return r;
+}
+
+// rollout-pass epilogue (optimizer.py:387-390; see the banner further up): 16 lanes per env-step like ppo_loss_kernel - lane j owns columns
+// j, j + 16, .. of the 65 - instead of one thread per (step, head) walking up to 40 logits in a serial loop behind dependent loads
+// (37-41 us per launch for 24 MB).  Same arithmetic per element (no max-subtraction, policy.py:172); the soft-max sum is the row
+// all-reduce ppo_loss_kernel takes too, so the first epoch's ratio starts from the very same log-prob.
+__global__ __launch_bounds__(256) void select_logp_kernel(const float* __restrict__ headout, const float* __restrict__ tu,
+                                                          const uint8_t* __restrict__ act, const uint8_t* __restrict__ mask,
+                                                          float* __restrict__ logp_sel, float* __restrict__ values,
+                                                          int32_t* __restrict__ argmax, long long nr) {
+    const int j = threadIdx.x & 15;
+    const long long n = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool on = n < nr;
+    const long long nn = on ? n : nr - 1;           // idle rows of the last block recompute a valid step and store nothing
+    const float* ho = headout + nn * HO_LD;
+    const float* tun = tu + nn * NUNITS;
+    const uint8_t* mrow = mask + nn * ACT;
+    const uint8_t* arow = act + nn * ACT;
+    float z[5];
+    bool mk[5];
+    float se_c[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, mx_c[5] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int amin_c[5] = {127, 127, 127, 127, 127};
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        const int c = j + 16 * m;
+        const bool valid = c < ACT;
+        const int cc = valid ? c : 0;
+        const int k = head_of_col(cc);
+        z[m] = k == 3 ? tun[cc - 22] : ho[(k == 4 ? 88 : 128) + cc];
+        mk[m] = valid && mrow[cc] != 0;
+        const bool ac = valid && arow[cc] != 0;
+        const float e = mk[m] ? expf(z[m]) : 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk) {
+            if (!slot_has(m, kk)) continue;
+            const bool mine = valid && k == kk;
+            se_c[kk] += mine ? e : 0.f;
+            amin_c[kk] = (mine && ac) ? min(amin_c[kk], c) : amin_c[kk];
+            mx_c[kk] = (mine && mk[m]) ? fmaxf(mx_c[kk], z[m]) : mx_c[kk];      // (a NaN logit is never the maximum: like `z > best`)
+        }
+    }
+    float lse[5], mx[5];
+    int amin[5];
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) {
+        lse[kk] = logf(row_sum16(se_c[kk]));
+        amin[kk] = row_min16_i(amin_c[kk]);
+        float v = mx_c[kk];
+        v = fmaxf(v, row_dpp<0x128>(v)); v = fmaxf(v, row_dpp<0x124>(v)); v = fmaxf(v, row_dpp<0x122>(v)); v = fmaxf(v, row_dpp<0x121>(v));
+        mx[kk] = v;
+    }
+    // the selected action's logit (one owner lane per head) and the first column that holds the masked maximum
+    float zsel_c[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    int best_c[5] = {127, 127, 127, 127, 127};
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        const int c = j + 16 * m;
+        const bool valid = c < ACT;
+        const int k = head_of_col(valid ? c : 0);
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk) {
+            if (!slot_has(m, kk)) continue;
+            const bool mine = valid && k == kk;
+            zsel_c[kk] += (mine && c == amin[kk]) ? z[m] : 0.f;
+            best_c[kk] = (mine && mk[m] && z[m] == mx[kk] && mx[kk] > -INFINITY) ? min(best_c[kk], c) : best_c[kk];
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) {
+        const float zs = row_sum16(zsel_c[kk]);               // exact: one non-zero lane
+        const int bc = row_min16_i(best_c[kk]);
+        if (on && j == kk) {
+            logp_sel[n * 5 + kk] = amin[kk] < 127 ? zs - lse[kk] : 0.f;
+            if (argmax) argmax[n * 5 + kk] = bc < 127 ? bc - c_head_off[kk] : -1;
+        }
+    }
+    if (on && j == 5) values[n] = ho[HO_VALUE];
 }
 
 // losses[0..3] = loss, policy_loss, entropy_loss, value_loss ; losses[4..8] = entropies per head
@@ -569,7 +616,7 @@ int attn_bwd_q(const float* dtu, const float* emb, float* dheadout, long long nr
 int select_logp(const float* headout, const float* tu, const uint8_t* act, const uint8_t* mask, float* logp_sel,
                 float* values, int32_t* argmax, long long nr, hipStream_t s) {
     ProfScope prof("select_logp", 0.0, (double)nr * (4.0 * (26 + 40) + 2.0 * 65 + 4.0 * (5 + 1 + 5)), s);
-    hipLaunchKernelGGL(select_logp_kernel, dim3((unsigned)((nr * 5 + 255) / 256)), dim3(256), 0, s, headout, tu, act, mask,
+    hipLaunchKernelGGL(select_logp_kernel, dim3((unsigned)((nr + 15) / 16)), dim3(256), 0, s, headout, tu, act, mask,
                        logp_sel, values, argmax, nr);
     return launch_check("select_logp");
 }
