@@ -24,7 +24,11 @@ enum { ST_ADV_SUM = 0, ST_ADV_SQ = 1, ST_NSEL = 2 /*5*/, ST_POL = 7 /*5*/, ST_EN
 // for inspection), [ST_PART1, +ST_G1 * 8) batch_stats_kernel's per-block partial sums, [ST_PART2, +ST_G2 * 12) ppo_loss_kernel's,
 // [ST_TICKET] a 32-bit arrival counter.  Per-block partials summed in a fixed order instead of f64 atomics on eleven words:
 // 4 096 blocks x 11 same-address atomics serialised at one L2 channel (the kernel's tail), and made the sums order-dependent.
-enum { ST_G1 = 256, ST_G2 = 1024, ST_PART1 = 64, ST_PART2 = ST_PART1 + ST_G1 * 8, ST_TICKET = ST_PART2 + ST_G2 * 12, ST_DOUBLES = ST_TICKET + 8 };
+#ifndef DC_LOSS_GRID
+#define DC_LOSS_GRID 1024
+#endif
+enum { ST_G1 = 256, ST_G2 = DC_LOSS_GRID,      // (policy.hip sizes DC_WS_STATS for up to 4 096 blocks)
+       ST_PART1 = 64, ST_PART2 = ST_PART1 + ST_G1 * 8, ST_TICKET = ST_PART2 + ST_G2 * 12, ST_L1 = 32, ST_GPART = ST_TICKET + 8 + ST_L1, ST_DOUBLES = ST_GPART + ST_L1 * 12 };      // [ST_TICKET]: second-level counter, [ST_TICKET + 8 ..): ST_L1 first-level ones, [ST_GPART ..): the groups' rows
 
 // sixteen-lane (DPP row) all-reduces
 template <int CTRL>
@@ -225,7 +229,8 @@ __global__ __launch_bounds__(256) void batch_stats_kernel(const float* __restric
         const double r = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
         stats[ST_PART1 + blockIdx.x * 8 + threadIdx.x] = r;   // ST_ADV_SUM, ST_ADV_SQ, ST_NSEL..: summed by ppo_loss_kernel's blocks
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<unsigned*>(stats + ST_TICKET) = 0u;   // ppo_loss_kernel's arrival counter
+    if (blockIdx.x == 0 && threadIdx.x <= ST_L1)            // ppo_loss_kernel's arrival counters (second level, then the ST_L1 first-level ones)
+        *reinterpret_cast<unsigned*>(stats + ST_TICKET + (threadIdx.x == 0 ? 0 : 7 + threadIdx.x)) = 0u;
 }
 
 struct LossArgs {
@@ -368,6 +373,13 @@ __device__ __forceinline__ void loss_finalize(const double* stats, float* out, i
 }
 
 __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
+#ifdef PL_TIMING
+    long long ts[10]; int nts = 0;
+#define PL_STAMP() do { if (threadIdx.x == 0) ts[nts++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PL_STAMP() do { } while (0)
+#endif
+    PL_STAMP();
     __shared__ float sh_norm[2];
     __shared__ double sh_tot[ST_COUNT];
     __shared__ double sh[4][11];
@@ -379,9 +391,18 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
     // butterfly): bit-identical in every block and from run to run
     if (threadIdx.x < 64) {
         double v[7] = {0, 0, 0, 0, 0, 0, 0};
-        for (int b = threadIdx.x; b < p.g1; b += 64)
+        // (all ST_G1 / 64 x 7 loads requested before the first add: a `for (b < g1)` loop was four dependent round trips in front of every block)
+        double ld[ST_G1 / 64][7];
 #pragma unroll
-            for (int q = 0; q < 7; ++q) v[q] += p.stats[ST_PART1 + b * 8 + q];
+        for (int i = 0; i < ST_G1 / 64; ++i) {
+            const int b = min(threadIdx.x + 64 * i, p.g1 - 1);
+#pragma unroll
+            for (int q = 0; q < 7; ++q) ld[i][q] = p.stats[ST_PART1 + b * 8 + q];
+        }
+#pragma unroll
+        for (int i = 0; i < ST_G1 / 64; ++i)
+#pragma unroll
+            for (int q = 0; q < 7; ++q) v[q] += (int)threadIdx.x + 64 * i < p.g1 ? ld[i][q] : 0.0;
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
             const double r = wave_sum(v[q]);
@@ -407,6 +428,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
     }
     if (threadIdx.x < 192) (&accs[0][0])[threadIdx.x] = 0.0;
     __syncthreads();
+    PL_STAMP();      // 1: prologue
     const int j = threadIdx.x & 15;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long groups = (p.nr + 15) / 16;
@@ -544,6 +566,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
     }
     }   // groups of this block
     __syncthreads();
+    PL_STAMP();      // 2: body
     // The last block to arrive sums all rows (fixed order) and finalises the losses.  Hand-off without fences (an agent-scope release
     // writes back every dirty line of the XCD's L2 - here the d(headout) rows the whole chip has just written - once per block):
     // the row goes out as 8-byte write-through (sc1) stores, drained (vmcnt(0)) before the ticket is taken; the last block
@@ -556,30 +579,52 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(p.stats + ST_TICKET), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sh_last = t == gridDim.x - 1;
+    // Two levels, tickets and sums alike: block b belongs to group b mod ST_L1; the last block of a group to arrive adds the group's rows
+    // (fixed order) into ONE group row, then takes a second-level ticket; the last group adds the ST_L1 group rows and finalises.  A thousand
+    // blocks finishing together queued at one L2 address for ~17 us, and the one last block then walked 1 024 x 11 partial sums through
+    // eleven f64 wave reductions: 17 us more (PL_TIMING) - now the groups reduce side by side and the tail holds 32 x 11 values.
+    __shared__ double sh_rows[ST_L1][12];
+    const unsigned grp = blockIdx.x % ST_L1, n_grp = (gridDim.x - grp + ST_L1 - 1) / ST_L1;
+    if (threadIdx.x == 0)
+        sh_last = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(p.stats + ST_TICKET + 8 + grp), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_grp - 1;
+    __syncthreads();
+    PL_STAMP();      // 3: partials stored + ticket
+    if (!sh_last) return;
+    for (int e = threadIdx.x; e < (int)n_grp * 11; e += 256) {
+        const int i = e / 11, q = e - 11 * i;
+        sh_rows[i][q] = __hip_atomic_load(&p.stats[ST_PART2 + (size_t)(grp + ST_L1 * i) * 12 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    if (threadIdx.x < 11) {
+        double t = 0.0;
+        for (int i = 0; i < (int)n_grp; ++i) t += sh_rows[i][threadIdx.x];      // fixed order
+        __hip_atomic_store(&p.stats[ST_GPART + grp * 12 + threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const unsigned n_top = min((unsigned)gridDim.x, (unsigned)ST_L1);
+    if (threadIdx.x == 0)
+        sh_last = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(p.stats + ST_TICKET), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_top - 1;
+    __syncthreads();
     if (!sh_last) return;
-    {
-        double v[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int b = threadIdx.x; b < (int)gridDim.x; b += 256)
-#pragma unroll
-            for (int q = 0; q < 11; ++q) v[q] += __hip_atomic_load(&p.stats[ST_PART2 + b * 12 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int q = 0; q < 11; ++q) {
-            const double r = wave_sum(v[q]);
-            if (lane == 0) sh[wave][q] = r;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int q = 0; q < 7; ++q) p.stats[q] = sh_tot[q];
-#pragma unroll
-            for (int q = 0; q < 11; ++q) p.stats[ST_POL + q] = (sh[0][q] + sh[1][q]) + (sh[2][q] + sh[3][q]);
-            loss_finalize(p.stats, p.losses_out, p.head_on, p.nr, p.entropy_coef, p.vf_coef);
-        }
+    for (int e = threadIdx.x; e < (int)n_top * 11; e += 256) {
+        const int i = e / 11, q = e - 11 * i;
+        sh_rows[i][q] = __hip_atomic_load(&p.stats[ST_GPART + i * 12 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (threadIdx.x < 11) {
+        double t = 0.0;
+        for (int i = 0; i < (int)n_top; ++i) t += sh_rows[i][threadIdx.x];
+        p.stats[ST_POL + threadIdx.x] = t;
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 71) p.stats[threadIdx.x - 64] = sh_tot[threadIdx.x - 64];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        loss_finalize(p.stats, p.losses_out, p.head_on, p.nr, p.entropy_coef, p.vf_coef);
+#ifdef PL_TIMING
+        ts[nts++] = __builtin_readcyclecounter();
+        printf("ppo_loss last block %d: prologue %lld body %lld ticket %lld finalised %lld\n", (int)blockIdx.x, ts[1] - ts[0], ts[2] - ts[0], ts[3] - ts[0], ts[4] - ts[0]);
+#endif
     }
 }
 

@@ -111,7 +111,7 @@ int64_t workspace_layout(const dc_dims* d, int64_t* out) {
     put(DC_WS_DTU, NR * 40 * 4);
     put(DC_WS_DPRE, NR * PREW * 4);
     put(DC_WS_DXCAT, NR * XCATW * 4);
-    put(DC_WS_STATS, 64 * 8 + 256 * 8 * 8 + 1024 * 12 * 8 + 64);   // totals + per-block partial sums of the two loss kernels + arrival counter (heads.hip: ST_*)
+    put(DC_WS_STATS, 64 * 8 + 256 * 8 * 8 + 4096 * 12 * 8 + 64 + 32 * 8 + 32 * 12 * 8);   // totals + per-block partial sums of the two loss kernels + arrival counter (heads.hip: ST_*)
     put(DC_WS_WHHT, H * G * H * 4);
     put(DC_WS_SCRATCH, (int64_t)DC_SCRATCH_FLOATS * 4);   // two-stage reductions / split-K slabs
     put(DC_WS_HEADW_PAD, (int64_t)HO_LD * H * 4);          // head weights zero-padded to 160 rows (K of dH)
