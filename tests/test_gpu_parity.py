@@ -321,10 +321,12 @@ def test_rnn_team_kernels_agree_with_per_step(cell, S, lens):
     # team step); 'v' = the VALU team kernels whatever the batch
     # '8' = teams of eight workgroups (DC_DIMS_TEAM8, rnn_team8.hip: the default's choice for 65 .. 128 sequences only), '4' = never those
     # 'k' = the MFMA team forward with the k halves (round 2's; DC_DIMS_TEAM_NS(2) without the VALU flag) where the MFMA kernels run
-    for mode, ns in (('0', None), ('1', None), ('8', None), ('4', None), ('k', '2'), ('v', None), ('v', '1'), ('v', '2'), ('v', '4')):
+    # 'd' = the default selection with DC_DIMS_TEAM_DEVICE_SCOPE: the hand-off as write-through stores even when a team sits on one XCD
+    for mode, ns in (('0', None), ('1', None), ('d', None), ('8', None), ('4', None), ('k', '2'), ('v', None), ('v', '1'), ('v', '2'), ('v', '4')):
         eng = Engine(cell, 256, 1, dev)
         eng.kernel_flags = E.DC_DIMS_RNN_PER_STEP if mode == '0' else \
             ((E.DC_DIMS_TEAM_VALU if mode == 'v' else 0) | (E.DC_DIMS_TEAM8 if mode == '8' else 0) | (E.DC_DIMS_TEAM4 if mode == '4' else 0) |
+             (E.DC_DIMS_TEAM_DEVICE_SCOPE if mode == 'd' else 0) |
              (E.DC_DIMS_TEAM_NS(int(ns)) if ns else 0))
         eng.load_state_dict(synth.init_state_dict(7, cell, 256, 1))
         rollouts = synth.make_rollouts(78, lens)
