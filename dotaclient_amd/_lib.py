@@ -34,6 +34,7 @@ SIGNATURES = {
     'dc_workspace_layout': (c_i64, [c_ptr, c_ptr]),
     'dc_policy_forward': (c_int, [c_ptr] * 13),
     'dc_chunk_initial_state': (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr]),
+    'dc_policy_single': (c_int, [c_ptr] * 11),
     'dc_select_logp': (c_int, [c_ptr] * 8),
     'dc_ppo_loss_fwd_bwd': (c_int, [c_ptr] * 9 + [c_flt, c_flt, c_flt, c_ptr]),
     'dc_policy_backward': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
@@ -41,6 +42,7 @@ SIGNATURES = {
                               [c_flt, c_flt, c_dbl, c_dbl, c_dbl, c_flt, c_ptr]),
 }
 
+DC_SINGLE_SCRATCH_FLOATS = 8192      # include/dotaclient_hip.h
 ABI_VERSION = 4      # include/dotaclient_hip.h DC_ABI_VERSION: a library built from other sources would mis-call silently
 
 _lib = None

@@ -136,6 +136,12 @@ int dc_chunk_initial_state(const dc_dims* dims, const void* ws, const int64_t* p
     return 0;
 }
 
+int dc_policy_single(const dc_dims* dims, const float* params, const int64_t* poff_host, const float* obs, const float* h0, const float* c0,
+                     float* out, float* hT, float* cT, float* scratch, dc_stream_t stream) {
+    DC_ENTER();
+    return dc::policy_single(dims, params, poff_host, obs, h0, c0, out, hT, cT, scratch, (hipStream_t)stream);
+}
+
 int dc_select_logp(const dc_dims* dims, const void* ws, const uint8_t* act, const uint8_t* mask, float* logp_sel,
                    float* values, int32_t* argmax, dc_stream_t stream) {
     DC_ENTER();

@@ -156,6 +156,9 @@ int embed_bwd_pool16m(const float* obs, const float* dxcat, const uint8_t* amax,
 // embed_small.hip: the four small types (needs F16x2Scales.on); slab / part in the dense kernels' formats
 int embed_bwd_small(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq, const float* W1,
                     const float* b1, const float* W2, float* slab, int slab_skip, float* part, long long nr, hipStream_t s, const F16x2Scales& f16);
+// policy_single.hip: Policy.single as one kernel
+int policy_single(const dc_dims* d, const float* params, const int64_t* poff, const float* obs, const float* h0, const float* c0, float* out,
+                  float* hT, float* cT, float* scratch, hipStream_t s);
 // heads.hip
 int attn_logits(const float* headout, const float* emb, float* tu, long long nr, long long nrp, hipStream_t s);
 // target-unit logits of the units whose mask byte (mask[n][22 + u]) is set; 0 elsewhere

@@ -11,12 +11,15 @@ What changes: the parameters are views into ONE flat fp32 device buffer owned by
 autograd graph) - training goes through `DotaOptimizer.train`, which runs the fused
 forward/loss/backward/Adam path on the same buffer.
 """
+import ctypes
+
 import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _lib
 from . import layout as L
-from .engine import Engine, PackedBatch
+from .engine import CELL_ID, DcDims, Engine, PackedBatch
 
 
 class _Affine(nn.Module):
@@ -102,18 +105,22 @@ class Policy(nn.Module):
         return z if self.cell == 'gru' else (z, z.clone())
 
     def single(self, hidden, **kwargs):                                # policy.py:80-84
-        """One env-step of one hero (what the rollout actor calls every 0.5 s of game time, agent.py:652).  `single_graph` (default on):
-        the actor-latency path - the step's ~14 kernel launches are captured ONCE into a hipGraph over static buffers and replayed:
-        one host->device copy of the 483-float observation row, the hidden state into its static buffer, ONE graph launch, one copy of
-        the 200 result floats.  Same kernels, same results as the eager forward (tests/test_gpu_api.py)."""
+        """One env-step of one hero (what the rollout actor calls every 0.5 s of game time, agent.py:652).
+        `single_kernel` (default on): the whole step is ONE kernel (csrc/policy_single.hip, dc_policy_single) over static buffers - one
+        host->device copy of the 483-float observation row, the hidden state into its static buffer, one launch, one copy of the 200
+        result floats; exact f32 arithmetic.  Off: the batch path's ~14 launches on a padded tile, replayed as one hipGraph
+        (`single_graph`, the path of rounds 4-5) or launched eagerly."""
+        if self.single_kernel:
+            return self._single_static(hidden, kwargs, fused=True)
         if self.single_graph:
-            return self._single_graphed(hidden, kwargs)
+            return self._single_static(hidden, kwargs, fused=False)
         return self.__call__(**{k: v.unsqueeze(0).unsqueeze(0) for k, v in kwargs.items()}, hidden=hidden)
 
+    single_kernel = True
     single_graph = True
 
     @torch.no_grad()
-    def _single_graphed(self, hidden, kw):
+    def _single_static(self, hidden, kw, fused):
         e, dev = self.engine, self.engine.device
         st = getattr(self, '_single_state', None)
         if st is None:
@@ -155,19 +162,27 @@ class Policy(nn.Module):
             st['out'][:L.HEADOUT_LD].copy_(e.ws_view(d, 'HEADOUT')[:L.HEADOUT_LD])
             st['out'][L.HEADOUT_LD:].copy_(e.ws_view(d, 'TU')[:L.MAX_UNITS])
 
-        key = (0 if e._ws is None else e._ws.data_ptr(), e.params.data_ptr(), e.kernel_flags, e.products)
-        if st['graph'] is None or st['key'] != key:
-            run()                                        # eager: the first call also allocates the workspace and sets kernel attributes
-            st['calls'] += 1
-            key = (e._ws.data_ptr(), e.params.data_ptr(), e.kernel_flags, e.products)
-            if st['calls'] >= 2 or st['key'] is not None:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    run()
-                st['graph'] = g
-            st['key'] = key
+        if fused:
+            if st.get('scratch') is None:                # zero once: afterwards the kernel keeps its grid barrier's words there
+                st['scratch'] = torch.zeros(_lib.DC_SINGLE_SCRATCH_FLOATS, dtype=torch.float32, device=dev)
+                st['dims'] = DcDims(CELL_ID[self.cell], self.hidden_size, self.layers, 1, 1, 0, 1)
+            _lib.check(e.lib.dc_policy_single(ctypes.byref(st['dims']), _lib.ptr(e.params), e.poff, _lib.ptr(st['obs']), _lib.ptr(st['h0']),
+                                              _lib.ptr(st['c0']), _lib.ptr(st['out']), _lib.ptr(st['hT']), _lib.ptr(st['cT']),
+                                              _lib.ptr(st['scratch']), _lib.stream_ptr()), 'dc_policy_single')
         else:
-            st['graph'].replay()
+            key = (0 if e._ws is None else e._ws.data_ptr(), e.params.data_ptr(), e.kernel_flags, e.products)
+            if st['graph'] is None or st['key'] != key:
+                run()                                    # eager: the first call also allocates the workspace and sets kernel attributes
+                st['calls'] += 1
+                key = (e._ws.data_ptr(), e.params.data_ptr(), e.kernel_flags, e.products)
+                if st['calls'] >= 2 or st['key'] is not None:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        run()
+                    st['graph'] = g
+                st['key'] = key
+            else:
+                st['graph'].replay()
         out = st['out'].clone()
         ho, tu = out[:L.HEADOUT_LD].view(1, 1, -1), out[L.HEADOUT_LD:].view(1, 1, -1)
         logits = {'enum': ho[..., L.HEADOUT_ENUM:L.HEADOUT_ENUM + 4], 'x': ho[..., L.HEADOUT_X:L.HEADOUT_X + 9],

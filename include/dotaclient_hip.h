@@ -267,6 +267,17 @@ int dc_policy_forward(const dc_dims* dims, const float* params, const int64_t* p
 int dc_chunk_initial_state(const dc_dims* dims, const void* ws, const int64_t* prev_row, int n_chunks, float* h0, float* c0,
                            dc_stream_t stream);
 
+/* policy.py:80-84 `Policy.single` (what a rollout actor calls per env-step, agent.py:652): ONE env-step of ONE hero as one kernel
+ * (csrc/policy_single.hip, round 6) - no workspace, no padding to tiles, exact f32 arithmetic.  An entry point added in round 6: callers
+ * of ABI 4 that do not use it are unaffected.
+ *   dims: cell, hidden (a multiple of 64 up to 512), layers are read; obs f32[483] (device): env(3) | 40 units x 12 (layout.py);
+ *   h0 / c0 f32[layers, H] (device; NULL = zeros; c0 LSTM only); out f32[200] = the head row (DC_WS_HEADOUT's 160 columns) | the 40
+ *   target-unit logits; hT / cT f32[layers, H] out (cT may be NULL for the GRU);
+ *   scratch f32[DC_SINGLE_SCRATCH_FLOATS]: ZERO before the first call, afterwards left to this function (it holds its grid barrier). */
+#define DC_SINGLE_SCRATCH_FLOATS 8192
+int dc_policy_single(const dc_dims* dims, const float* params, const int64_t* poff_host, const float* obs, const float* h0, const float* c0,
+                     float* out, float* hT, float* cT, float* scratch, dc_stream_t stream);
+
 /* Rollout-pass epilogue, optimizer.py:387-390 + policy.py:169-178: log-prob of the selected action
  * per head (0 where the head took no action), value, masked argmax per head (-1 on empty mask).
  *   act/mask u8 [rows,65]; logp_sel f32 [rows,5]; values f32 [rows]; argmax i32 [rows,5] or NULL. */

@@ -84,29 +84,52 @@ def test_policy_forward_matches_oracle():
     assert lg['target_unit'].shape == (1, 24, 40) and v.shape == (1, 24, 1) and h.shape == (1, 1, 256)
 
 
-@pytest.mark.parametrize('cell,hidden', [('gru', 256), ('lstm', 128)])
-def test_policy_single_step_matches_oracle(cell, hidden):
-    # the actor-side entry point (policy.py:80-84, agent.py:652): B = 1, S = 1, hidden state carried by the caller
+@pytest.mark.parametrize('mode', ['kernel', 'graph', 'eager'])
+@pytest.mark.parametrize('cell,hidden,layers', [('gru', 256, 1), ('lstm', 128, 1), ('lstm', 256, 1), ('lstm', 512, 2), ('gru', 64, 3)])
+def test_policy_single_step_matches_oracle(cell, hidden, layers, mode):
+    # the actor-side entry point (policy.py:80-84, agent.py:652): B = 1, S = 1, hidden state carried by the caller.  'kernel' = the one-kernel
+    # step (csrc/policy_single.hip, the default), 'graph' / 'eager' = the batch path's kernels on a padded tile
     from dotaclient_amd.policy import Policy
-    sd = synth.init_state_dict(7, cell, hidden, 1)
-    pol = Policy(cell, hidden, 1)
+    if mode != 'kernel' and (hidden, layers) == (64, 3):
+        pytest.skip('the batch kernels take H in (128, 256, 512)')
+    sd = synth.init_state_dict(7, cell, hidden, layers)
+    pol = Policy(cell, hidden, layers)
     pol.load_state_dict(sd)
-    ref = RO.make_policy(sd, cell, hidden, 1)
+    pol.single_kernel, pol.single_graph = mode == 'kernel', mode == 'graph'
+    ref = RO.make_policy(sd, cell, hidden, layers)
     r = synth.make_rollouts(12, [6])[0]
     hid = pol.init_hidden()
     rhid = ref.init_hidden(1)
     for t in range(6):
         obs_t = {k: r['observations'][k][t] for k in L.INPUT_KEYS}
-        lg, v, hid = pol.single(**{k: x.cuda() for k, x in obs_t.items()}, hidden=hid)
+        lg, v, hid = pol.single(**{k: (x.cuda() if t % 2 else x) for k, x in obs_t.items()}, hidden=hid)
         with torch.no_grad():
             rl, rv, rhid = ref({k: x[None, None] for k, x in obs_t.items()}, rhid)
         for k in L.OUTPUT_KEYS:
             assert lg[k].shape == rl[k].shape == (1, 1, L.HEAD_COUNTS[k])
             assert util.scaled_err(lg[k].cpu().numpy(), rl[k].numpy()) < 1e-5, (t, k)
         assert v.shape == (1, 1, 1) and util.scaled_err(v.cpu().numpy(), rv.numpy()) < 1e-5
-        h_got = hid if cell == 'gru' else hid[0]
-        h_ref = rhid if cell == 'gru' else rhid[0]
-        assert h_got.shape == (1, 1, hidden) and util.scaled_err(h_got.cpu().numpy(), h_ref.numpy()) < 1e-5
+        for h_got, h_ref in zip([hid] if cell == 'gru' else hid, [rhid] if cell == 'gru' else rhid):
+            assert h_got.shape == (layers, 1, hidden) and util.scaled_err(h_got.cpu().numpy(), h_ref.numpy()) < 1e-5
+
+
+def test_policy_single_kernel_refuses_what_it_cannot_run():
+    # dc_policy_single's argument checks (include/dotaclient_hip.h): no silent fallback
+    import ctypes
+    from dotaclient_amd import _lib
+    from dotaclient_amd.engine import DcDims
+    from dotaclient_amd.policy import Policy
+    pol = Policy('gru', 256, 1)
+    e = pol.engine
+    buf = torch.zeros(_lib.DC_SINGLE_SCRATCH_FLOATS, device='cuda')
+    for dims, code in ((DcDims(0, 96, 1, 1, 1, 0, 1), 1022), (DcDims(0, 1024, 1, 1, 1, 0, 1), 1022), (DcDims(2, 256, 1, 1, 1, 0, 1), 1021),
+                       (DcDims(0, 256, 0, 1, 1, 0, 1), 1020)):
+        rc = e.lib.dc_policy_single(ctypes.byref(dims), _lib.ptr(e.params), e.poff, _lib.ptr(buf), None, None, _lib.ptr(buf), _lib.ptr(buf), None,
+                                    _lib.ptr(buf), _lib.stream_ptr())
+        assert rc == code
+    rc = e.lib.dc_policy_single(ctypes.byref(DcDims(0, 256, 1, 1, 1, 0, 1)), _lib.ptr(e.params), e.poff, _lib.ptr(buf), None, None, None,
+                                _lib.ptr(buf), None, _lib.ptr(buf), _lib.stream_ptr())
+    assert rc == 1024
 
 
 @pytest.mark.parametrize('cell,hidden', [('gru', 256), ('lstm', 256)])
@@ -119,6 +142,7 @@ def test_policy_single_graph_replay_equals_eager(cell, hidden):
     pol = Policy(cell, hidden, 1)
     pol.load_state_dict(synth.init_state_dict(7, cell, hidden, 1))
     r = synth.make_rollouts(13, [40])[0]
+    pol.single_kernel = False
     outs = {}
     for mode in (True, False):
         pol.single_graph = mode
@@ -134,8 +158,8 @@ def test_policy_single_graph_replay_equals_eager(cell, hidden):
     assert torch.equal(outs[True], outs[False])
     assert pol._single_state['graph'] is not None
     lat = {}
-    for mode in (True, False):
-        pol.single_graph = mode
+    for mode in ('kernel', True, False):
+        pol.single_kernel, pol.single_graph = mode == 'kernel', mode is True
         hid = pol.init_hidden()
         for t in range(3):
             _, _, hid = pol.single(**{k: r['observations'][k][t] for k in L.INPUT_KEYS}, hidden=hid)
@@ -145,8 +169,9 @@ def test_policy_single_graph_replay_equals_eager(cell, hidden):
             lg, v, hid = pol.single(**{k: r['observations'][k][t] for k in L.INPUT_KEYS}, hidden=hid)
             v.cpu()                                                                 # the actor reads the result every step
         lat[mode] = (time.perf_counter() - t0) / 30 * 1e6
-    print('Policy.single latency per env-step (%s-%d): graph replay %.0f us, eager %.0f us' % (cell, hidden, lat[True], lat[False]))
-    assert lat[True] < lat[False]
+    print('Policy.single latency per env-step (%s-%d): one kernel %.0f us, graph replay %.0f us, eager %.0f us'
+          % (cell, hidden, lat['kernel'], lat[True], lat[False]))
+    assert lat['kernel'] < lat[True] < lat[False]
 
 
 @pytest.mark.parametrize('case', ['ragged_s16', 'clip_s16'])
