@@ -42,7 +42,7 @@ SIGNATURES = {
                               [c_flt, c_flt, c_dbl, c_dbl, c_dbl, c_flt, c_ptr]),
 }
 
-DC_SINGLE_SCRATCH_FLOATS = 8192      # include/dotaclient_hip.h
+DC_SINGLE_SCRATCH_FLOATS = 20480      # include/dotaclient_hip.h
 ABI_VERSION = 4      # include/dotaclient_hip.h DC_ABI_VERSION: a library built from other sources would mis-call silently
 
 _lib = None

@@ -106,21 +106,71 @@ class Policy(nn.Module):
 
     def single(self, hidden, **kwargs):                                # policy.py:80-84
         """One env-step of one hero (what the rollout actor calls every 0.5 s of game time, agent.py:652).
-        `single_kernel` (default on): the whole step is ONE kernel (csrc/policy_single.hip, dc_policy_single) over static buffers - one
-        host->device copy of the 483-float observation row, the hidden state into its static buffer, one launch, one copy of the 200
-        result floats; exact f32 arithmetic.  Off: the batch path's ~14 launches on a padded tile, replayed as one hipGraph
-        (`single_graph`, the path of rounds 4-5) or launched eagerly."""
+        `single_kernel` (default on): the whole step is ONE kernel (csrc/policy_single.hip, dc_policy_single) - the 483-float observation
+        row is assembled in a pinned host row the kernel reads directly (the actor's tensors are CPU tensors, agent.py:640-650), the
+        hidden state is read where the caller holds it, the results land in fresh tensors: one launch, no copies; exact f32 arithmetic.
+        Off: the batch path's ~14 launches on a padded tile, replayed as one hipGraph over static buffers (`single_graph`, the path of
+        rounds 4-5) or launched eagerly."""
         if self.single_kernel:
-            return self._single_static(hidden, kwargs, fused=True)
+            return self._single_fused(hidden, kwargs)
         if self.single_graph:
-            return self._single_static(hidden, kwargs, fused=False)
+            return self._single_graphed(hidden, kwargs)
         return self.__call__(**{k: v.unsqueeze(0).unsqueeze(0) for k, v in kwargs.items()}, hidden=hidden)
 
     single_kernel = True
     single_graph = True
 
+    @staticmethod
+    def _single_result(out, hid):
+        ho, tu = out[:L.HEADOUT_LD].view(1, 1, -1), out[L.HEADOUT_LD:].view(1, 1, -1)
+        logits = {'enum': ho[..., L.HEADOUT_ENUM:L.HEADOUT_ENUM + 4], 'x': ho[..., L.HEADOUT_X:L.HEADOUT_X + 9],
+                  'y': ho[..., L.HEADOUT_Y:L.HEADOUT_Y + 9], 'target_unit': tu,
+                  'ability': ho[..., L.HEADOUT_ABILITY:L.HEADOUT_ABILITY + 3]}
+        return logits, ho[..., L.HEADOUT_VALUE:L.HEADOUT_VALUE + 1], hid
+
     @torch.no_grad()
-    def _single_static(self, hidden, kw, fused):
+    def _single_fused(self, hidden, kw):
+        e, dev = self.engine, self.engine.device
+        st = getattr(self, '_fused_state', None)
+        if st is None:
+            st = self._fused_state = {
+                'rows': torch.empty(2, L.OBS_DIM, dtype=torch.float32).pin_memory(), 'busy': [None, None], 'turn': 0,
+                # zero once: afterwards the kernel keeps its granules and its launch generation there
+                'scratch': torch.zeros(_lib.DC_SINGLE_SCRATCH_FLOATS, dtype=torch.float32, device=dev),
+                'dims': DcDims(CELL_ID[self.cell], self.hidden_size, self.layers, 1, 1, 0, 1)}
+        vals = [kw[k] for k in L.INPUT_KEYS]
+        if all(not v.is_cuda for v in vals):
+            # two pinned rows in turn; a row is rewritten only after the launch that read it has finished (a caller that does not read a
+            # result between two calls would otherwise race the kernel: ADVICE r5)
+            i = st['turn']
+            st['turn'] = i ^ 1
+            if st['busy'][i] is not None:
+                st['busy'][i].synchronize()
+            obs = st['rows'][i]
+            torch.cat([v.reshape(-1) for v in vals], out=obs)
+        else:                                             # observation tensors already on the device: assembled there
+            i = None
+            obs = torch.cat([v.reshape(-1).to(dev, torch.float32) for v in vals])
+        lstm = self.cell == 'lstm'
+        fit = lambda t: t if (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()) else t.to(dev, torch.float32).contiguous()
+        h0 = fit(hidden[0] if lstm else hidden)
+        c0 = fit(hidden[1]) if lstm else None
+        if h0.numel() != self.layers * self.hidden_size:
+            raise ValueError('Policy.single: hidden must be (layers, 1, hidden)')
+        out = torch.empty(L.HEADOUT_LD + L.MAX_UNITS, dtype=torch.float32, device=dev)
+        hT = torch.empty(self.layers, 1, self.hidden_size, dtype=torch.float32, device=dev)
+        cT = torch.empty_like(hT) if lstm else None
+        _lib.check(e.lib.dc_policy_single(ctypes.byref(st['dims']), _lib.ptr(e.params), e.poff, _lib.ptr(obs), _lib.ptr(h0), _lib.ptr(c0),
+                                          _lib.ptr(out), _lib.ptr(hT), _lib.ptr(cT), _lib.ptr(st['scratch']), _lib.stream_ptr()),
+                   'dc_policy_single')
+        if i is not None:
+            if st['busy'][i] is None:
+                st['busy'][i] = torch.cuda.Event()
+            st['busy'][i].record()
+        return self._single_result(out, (hT, cT) if lstm else hT)
+
+    @torch.no_grad()
+    def _single_graphed(self, hidden, kw):
         e, dev = self.engine, self.engine.device
         st = getattr(self, '_single_state', None)
         if st is None:
@@ -162,35 +212,21 @@ class Policy(nn.Module):
             st['out'][:L.HEADOUT_LD].copy_(e.ws_view(d, 'HEADOUT')[:L.HEADOUT_LD])
             st['out'][L.HEADOUT_LD:].copy_(e.ws_view(d, 'TU')[:L.MAX_UNITS])
 
-        if fused:
-            if st.get('scratch') is None:                # zero once: afterwards the kernel keeps its grid barrier's words there
-                st['scratch'] = torch.zeros(_lib.DC_SINGLE_SCRATCH_FLOATS, dtype=torch.float32, device=dev)
-                st['dims'] = DcDims(CELL_ID[self.cell], self.hidden_size, self.layers, 1, 1, 0, 1)
-            _lib.check(e.lib.dc_policy_single(ctypes.byref(st['dims']), _lib.ptr(e.params), e.poff, _lib.ptr(st['obs']), _lib.ptr(st['h0']),
-                                              _lib.ptr(st['c0']), _lib.ptr(st['out']), _lib.ptr(st['hT']), _lib.ptr(st['cT']),
-                                              _lib.ptr(st['scratch']), _lib.stream_ptr()), 'dc_policy_single')
+        key = (0 if e._ws is None else e._ws.data_ptr(), e.params.data_ptr(), e.kernel_flags, e.products)
+        if st['graph'] is None or st['key'] != key:
+            run()                                        # eager: the first call also allocates the workspace and sets kernel attributes
+            st['calls'] += 1
+            key = (e._ws.data_ptr(), e.params.data_ptr(), e.kernel_flags, e.products)
+            if st['calls'] >= 2 or st['key'] is not None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    run()
+                st['graph'] = g
+            st['key'] = key
         else:
-            key = (0 if e._ws is None else e._ws.data_ptr(), e.params.data_ptr(), e.kernel_flags, e.products)
-            if st['graph'] is None or st['key'] != key:
-                run()                                    # eager: the first call also allocates the workspace and sets kernel attributes
-                st['calls'] += 1
-                key = (e._ws.data_ptr(), e.params.data_ptr(), e.kernel_flags, e.products)
-                if st['calls'] >= 2 or st['key'] is not None:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        run()
-                    st['graph'] = g
-                st['key'] = key
-            else:
-                st['graph'].replay()
-        out = st['out'].clone()
-        ho, tu = out[:L.HEADOUT_LD].view(1, 1, -1), out[L.HEADOUT_LD:].view(1, 1, -1)
-        logits = {'enum': ho[..., L.HEADOUT_ENUM:L.HEADOUT_ENUM + 4], 'x': ho[..., L.HEADOUT_X:L.HEADOUT_X + 9],
-                  'y': ho[..., L.HEADOUT_Y:L.HEADOUT_Y + 9], 'target_unit': tu,
-                  'ability': ho[..., L.HEADOUT_ABILITY:L.HEADOUT_ABILITY + 3]}
-        value = ho[..., L.HEADOUT_VALUE:L.HEADOUT_VALUE + 1]
+            st['graph'].replay()
         hid = st['hT'].clone() if self.cell == 'gru' else (st['hT'].clone(), st['cT'].clone())
-        return logits, value, hid
+        return self._single_result(st['out'].clone(), hid)
 
     def sequence(self, hidden, **kwargs):                              # policy.py:86-90
         return self.__call__(**{k: v.unsqueeze(0) for k, v in kwargs.items()}, hidden=hidden)

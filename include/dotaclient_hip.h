@@ -268,13 +268,17 @@ int dc_chunk_initial_state(const dc_dims* dims, const void* ws, const int64_t* p
                            dc_stream_t stream);
 
 /* policy.py:80-84 `Policy.single` (what a rollout actor calls per env-step, agent.py:652): ONE env-step of ONE hero as one kernel
- * (csrc/policy_single.hip, round 6) - no workspace, no padding to tiles, exact f32 arithmetic.  An entry point added in round 6: callers
- * of ABI 4 that do not use it are unaffected.
- *   dims: cell, hidden (a multiple of 64 up to 512), layers are read; obs f32[483] (device): env(3) | 40 units x 12 (layout.py);
+ * (csrc/policy_single.hip, round 6) - no workspace, no padding to tiles, exact f32 arithmetic, 17-21 us per launch.  An entry point added in
+ * round 6: callers of ABI 4 that do not use it are unaffected.
+ *   dims: cell, hidden (a multiple of 64 up to 512), layers are read; obs f32[483]: env(3) | 40 units x 12 (layout.py) - device memory OR
+ *   page-locked host memory (every workgroup reads the row once: an actor hands over its pinned row, no copy);
  *   h0 / c0 f32[layers, H] (device; NULL = zeros; c0 LSTM only); out f32[200] = the head row (DC_WS_HEADOUT's 160 columns) | the 40
- *   target-unit logits; hT / cT f32[layers, H] out (cT may be NULL for the GRU);
- *   scratch f32[DC_SINGLE_SCRATCH_FLOATS]: ZERO before the first call, afterwards left to this function (it holds its grid barrier). */
-#define DC_SINGLE_SCRATCH_FLOATS 8192
+ *   target-unit logits; hT / cT f32[layers, H] out (cT may be NULL for the GRU; hT / cT must not alias h0 / c0);
+ *   scratch f32[DC_SINGLE_SCRATCH_FLOATS], 8-byte aligned: ZERO before the first call, afterwards left to this function (the {value, tag}
+ *   granules its stages hand over and its launch generation).  One call at a time per scratch buffer (calls on one stream are).
+ *   Errors: 1020 layers, 1021 cell, 1022 hidden, 1024 a NULL buffer, 1025 alignment.  A stage whose input never arrives (its
+ *   producers never ran) gives up after ~1 s and hands on NaN: no hang. */
+#define DC_SINGLE_SCRATCH_FLOATS 20480
 int dc_policy_single(const dc_dims* dims, const float* params, const int64_t* poff_host, const float* obs, const float* h0, const float* c0,
                      float* out, float* hT, float* cT, float* scratch, dc_stream_t stream);
 

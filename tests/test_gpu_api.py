@@ -113,6 +113,32 @@ def test_policy_single_step_matches_oracle(cell, hidden, layers, mode):
             assert h_got.shape == (layers, 1, hidden) and util.scaled_err(h_got.cpu().numpy(), h_ref.numpy()) < 1e-5
 
 
+def test_policy_single_kernel_back_to_back_calls_do_not_race():
+    # the one-kernel step reads the observation straight from a pinned host row: a caller that issues calls WITHOUT reading a result in
+    # between (nothing synchronises) must still get every step computed on its own observation (two rows in turn, each guarded by an
+    # event - ADVICE r5's hazard); the same steps with a read-back after each are the yardstick (bit-identical: same kernel, same inputs)
+    from dotaclient_amd.policy import Policy
+    pol = Policy('lstm', 256, 1)
+    pol.load_state_dict(synth.init_state_dict(7, 'lstm', 256, 1))
+    r = synth.make_rollouts(14, [24])[0]
+    runs = {}
+    for read_back in (True, False):
+        hid, seq = pol.init_hidden(), []
+        for t in range(24):
+            lg, v, hid = pol.single(**{k: r['observations'][k][t] for k in L.INPUT_KEYS}, hidden=hid)
+            if read_back:
+                v.cpu()
+            seq.append((lg, v, hid))
+        runs[read_back] = torch.stack([torch.cat([lg[k].flatten() for k in L.OUTPUT_KEYS] + [v.flatten(), hid[0].flatten(), hid[1].flatten()])
+                                       for lg, v, hid in seq]).cpu()
+    assert torch.equal(runs[True], runs[False])
+    assert not torch.isnan(runs[True]).any()
+    # a hidden state handed over as CPU tensors / a non-contiguous view is taken too
+    hid = tuple(h.cpu() for h in pol.init_hidden())
+    lg, v, hid2 = pol.single(**{k: r['observations'][k][0] for k in L.INPUT_KEYS}, hidden=hid)
+    assert torch.equal(torch.cat([lg[k].flatten() for k in L.OUTPUT_KEYS]).cpu(), runs[True][0, :65])
+
+
 def test_policy_single_kernel_refuses_what_it_cannot_run():
     # dc_policy_single's argument checks (include/dotaclient_hip.h): no silent fallback
     import ctypes

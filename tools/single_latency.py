@@ -15,7 +15,10 @@ for cell, hidden, layers in (('gru', 256, 1), ('lstm', 256, 1), ('lstm', 512, 2)
     hid = pol.init_hidden()
     for t in range(3):
         lg, v, hid = pol.single(**{k: r['observations'][k][t] for k in L.INPUT_KEYS}, hidden=hid)
-    st, e = pol._single_state, pol.engine
+    st, e = pol._fused_state, pol.engine
+    import torch as _t
+    st.update(obs=st['rows'][0], h0=_t.zeros(layers, hidden, device='cuda'), c0=_t.zeros(layers, hidden, device='cuda') if cell == 'lstm' else None,
+              out=_t.zeros(200, device='cuda'), hT=_t.zeros(layers, hidden, device='cuda'), cT=_t.zeros(layers, hidden, device='cuda') if cell == 'lstm' else None)
     call = lambda: e.lib.dc_policy_single(ctypes.byref(st['dims']), _lib.ptr(e.params), e.poff, _lib.ptr(st['obs']), _lib.ptr(st['h0']),
                                           _lib.ptr(st['c0']), _lib.ptr(st['out']), _lib.ptr(st['hT']), _lib.ptr(st['cT']),
                                           _lib.ptr(st['scratch']), _lib.stream_ptr())
