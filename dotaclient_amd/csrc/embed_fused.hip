@@ -41,7 +41,12 @@ struct EmbTypes {
                               // the last valid step (forward results land in pad rows nobody reads, backward sees zero gradients)
     int sparse16;             // backward: the two 16-unit types are handled by embed_bwd_pool16 (embed_sparse.hip);
                               // their dW2 slab ranges [wg_begin[2], wg_begin[4]) are written by that kernel
+    // forward only (embed_fwd_fused): first tile of type t.  pool5 = 0: tile_begin.  pool5 = 1: a tile of the five-unit type holds 24 WHOLE
+    // env-steps - six per 32-row block (rows 30, 31 of a block are padding) - so that its max-pool can be taken in the epilogue too
+    int ftile_begin[7];
+    int pool5;
 };
+enum { EF_P5_STEPS = 24 };
 
 __device__ __forceinline__ int ef_type_of_tile(const EmbTypes& ty, int tile) {
     int t = 0;
@@ -49,6 +54,22 @@ __device__ __forceinline__ int ef_type_of_tile(const EmbTypes& ty, int tile) {
     for (int i = 1; i < 6; ++i)
         if (tile >= ty.tile_begin[i]) t = i;
     return t;
+}
+__device__ __forceinline__ int ef_ftype_of_tile(const EmbTypes& ty, int tile) {
+    int t = 0;
+#pragma unroll
+    for (int i = 1; i < 6; ++i)
+        if (tile >= ty.ftile_begin[i]) t = i;
+    return t;
+}
+// type-major row of the tile's row `r` (forward tiling): rows of the five-unit type with pool5 - block b = r >> 5 holds the steps
+// 24 tile + 6 b .. + 5, row 5 s + u of the block = unit u of its step s; the block's rows 30, 31 repeat its last unit
+__device__ __forceinline__ long long ef_frow(const EmbTypes& ty, int t, int tile, int r) {
+    if (t == 1 && ty.pool5) {
+        const int b = r >> 5, q = min(r & 31, 29);
+        return ty.row_begin[1] + 5LL * ((long long)(tile - ty.ftile_begin[1]) * EF_P5_STEPS + 6 * b) + q;
+    }
+    return ty.row_begin[t] + (long long)(tile - ty.ftile_begin[t]) * EF_TILE + r;
 }
 __device__ __forceinline__ int ef_units(int t) { return t == 1 ? 5 : ((t == 2 || t == 3) ? 16 : 1); }
 __device__ __forceinline__ int ef_cum(int t) { return t == 0 ? 0 : (t == 1 ? 1 : (t == 2 ? 6 : (t == 3 ? 22 : (t == 4 ? 38 : 39)))); }
@@ -97,7 +118,8 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
                                                                  const float* __restrict__ b2, float* __restrict__ emb,
                                                                  float* __restrict__ xcat, uint8_t* __restrict__ amax,
                                                                  EmbTypes ty, int n_tiles, long long* __restrict__ dbg, float s_act, float inv,
-                                                                 const uint8_t* __restrict__ umask) {
+                                                                 const uint8_t* __restrict__ umask, const float* __restrict__ Wenv,
+                                                                 const float* __restrict__ benv) {
     static_assert(!F16 || BPL, "the f16 pieces need the pre-split weight planes");
     long long tm_k = 0, tm_e = 0, tm_b = 0, tm0 = 0, tm_start = 0;
     if constexpr (TIMING) tm_start = __builtin_amdgcn_s_memtime();
@@ -164,9 +186,9 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
     constexpr int XR = F16 ? 8 : 6;
     auto load_x = [&](int tile, float (&x)[XR]) {
         const int tl = min(tile, n_tiles - 1);                      // past the end: a valid tile, never used
-        const int tt = ef_type_of_tile(ty, tl);
+        const int tt = ef_ftype_of_tile(ty, tl);
         if constexpr (F16) {
-            const float* xp = ef_record(obs, tt, (long long)tl * EF_TILE + 32 * wave + fr - ty.row_begin[tt], ty.nr_valid) + 8 * fq;
+            const float* xp = ef_record(obs, tt, ef_frow(ty, tt, tl, 32 * wave + fr) - ty.row_begin[tt], ty.nr_valid) + 8 * fq;
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = xp[e];
@@ -177,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
 #pragma unroll
             for (int e = 0; e < 4; ++e) { x[e] = __uint_as_float(hh[e]); x[4 + e] = __uint_as_float(mm[e]); }
         } else {
-            const float* xp = ef_record(obs, tt, (long long)tl * EF_TILE + 32 * wave + fr - ty.row_begin[tt], ty.nr_valid) + fq;
+            const float* xp = ef_record(obs, tt, ef_frow(ty, tt, tl, 32 * wave + fr) - ty.row_begin[tt], ty.nr_valid) + fq;
 #pragma unroll
             for (int kk = 0; kk < 6; ++kk) x[kk] = xp[2 * kk];
         }
@@ -212,15 +234,16 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
     load_x(tile, xa);
     if constexpr (F16) __syncthreads();            // the W1 planes
     {   // step-0 operands of the first tile
-        const int t0 = ef_type_of_tile(ty, tile);
+        const int t0 = ef_ftype_of_tile(ty, tile);
         issue_b(t0, 0, stage + 4096);
         gen_a(std::integral_constant<int, 0>{}, xa, stage);
     }
     __syncthreads();
 
     for (; tile < n_tiles; tile += gridDim.x) {
-        const int t = ef_type_of_tile(ty, tile);
-        const long long row0 = (long long)tile * EF_TILE;
+        const int t = ef_ftype_of_tile(ty, tile);
+        const bool p5 = F16 && ty.pool5 && t == 1;                         // this tile: 24 whole steps of the five-unit type
+        const long long row0 = ef_frow(ty, t, tile, 0);                    // (p5: of block 0 only - see ef_frow)
         const int ntile = tile + gridDim.x;
         const bool more = ntile < n_tiles;
         load_x(ntile, xn);              // lands behind the K loop
@@ -230,7 +253,18 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
         // The 64 rows of this wave = four env-steps x sixteen units: lane l takes the byte of (step l >> 4, unit l & 15) of each half.
         int mb[2] = {1, 1};
         if constexpr (F16) {
-            if (umask != nullptr && (t == 2 || t == 3)) {
+            if (p5) {
+                // the five-unit type pooled here (pool5): its rows too are read by the attention only.  Row l < 30 of half i = unit l % 5
+                // of step 24 tile + 6 (2 wm + i) + l / 5; rows 30, 31 and steps past the end are never stored
+                const long long st0 = (long long)(tile - ty.ftile_begin[1]) * EF_P5_STEPS;
+                const long long nsteps = (ty.row_begin[2] - ty.row_begin[1]) / 5;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int l = lane & 31, sl = (l * 13) >> 6;
+                    const long long n = st0 + 6 * (2 * wm + i) + sl;
+                    mb[i] = (l < 30 && n < nsteps) ? (umask != nullptr ? umask[min(n, ty.nr_valid - 1) * 65 + 22 + 1 + (l - 5 * sl)] : 1) : 0;
+                }
+            } else if (umask != nullptr && (t == 2 || t == 3)) {
                 const long long lr = row0 - ty.row_begin[t] + wm * 64;            // type-local row of this wave's row 0: a multiple of 16
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -270,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
                 else if (kt == 1) gen_a(std::integral_constant<int, 2>{}, xa, nxt);
                 else gen_a(std::integral_constant<int, 3>{}, xa, nxt);
             } else if (more) {          // the next tile's step 0, into the buffer step 3 does not read
-                const int t1 = ef_type_of_tile(ty, ntile);
+                const int t1 = ef_ftype_of_tile(ty, ntile);
                 issue_b(t1, 0, nxt + 4096);
                 gen_a(std::integral_constant<int, 0>{}, xn, nxt);
             }
@@ -339,10 +373,42 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_fused_kernel(const float* __
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         xcat[(lr + (r & 3) + 8 * (r >> 2) + 4 * fq) * 896 + (1 + t) * EF_EMB + col] = v[r];
+                    if (F16 && ty.pool5 && t == 0) {
+                        // the env embedding (policy.py:97) rides on the own-hero tiles (a row = an env-step): pool_env_fwd's arithmetic
+                        const float w0 = Wenv[col * 3 + 0], w1 = Wenv[col * 3 + 1], w2 = Wenv[col * 3 + 2], be = benv[col];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const long long n = lr + (r & 3) + 8 * (r >> 2) + 4 * fq;
+                            const float* e = obs + min(n, ty.nr_valid - 1) * EF_OBS;
+                            xcat[n * 896 + col] = relu_nan(fmaf(e[2], w2, fmaf(e[1], w1, fmaf(e[0], w0, be))));
+                        }
+                    }
+                }
+            }
+            if (p5 && xcat != nullptr) {
+                // max over the five units of a step, from the block's [32][64] image (this wave wrote it; LDS ops of a wave are in order):
+                // lane = column, six steps; "first maximum wins" and NaN propagation like pool_env_fwd / torch.max
+                const long long st0 = (long long)(tile - ty.ftile_begin[1]) * EF_P5_STEPS + 6 * (2 * wm + i);
+                const long long nsteps = (ty.row_begin[2] - ty.row_begin[1]) / 5;
+#pragma unroll
+                for (int sl = 0; sl < 6; ++sl) {
+                    float m = tr[(5 * sl) * 64 + lane];
+                    int am = 0;
+#pragma unroll
+                    for (int u = 1; u < 5; ++u) {
+                        const float x = tr[(5 * sl + u) * 64 + lane];
+                        am = x > m ? u : am;
+                        m = max_nan(m, x);
+                    }
+                    const long long n = st0 + sl;
+                    if (n < nsteps) {
+                        xcat[n * 896 + 2 * EF_EMB + wn * 64 + lane] = m;
+                        amax[(n * 3 + 0) * EF_EMB + wn * 64 + lane] = (uint8_t)am;
+                    }
                 }
             }
             // rows 4*it + lane/16 of the half, 16 bytes at column 4*(lane%16): one wave, LDS ops in order
-            float* eo = emb + (size_t)(row0 + wm * 64 + i * 32) * EF_EMB + wn * 64;
+            float* eo = emb + (size_t)(p5 ? row0 + 30 * (2 * wm + i) : row0 + wm * 64 + i * 32) * EF_EMB + wn * 64;
             const unsigned live = F16 ? (unsigned)__ballot(mb[i] != 0) : 0xffffffffu;      // bit rr: row rr of this half is read by someone
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
@@ -660,6 +726,8 @@ static EmbTypes make_types(long long nr, long long nr_valid, int* total_wg, bool
     }
     ty.wg_begin[6] = wg;
     *total_wg = wg;
+    for (int t = 0; t <= 6; ++t) ty.ftile_begin[t] = ty.tile_begin[t];
+    ty.pool5 = 0;
     return ty;
 }
 
@@ -673,17 +741,25 @@ static int set_lds(K kernel, size_t bytes, bool* done) {
 }
 
 int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const float* W2, const uint16_t* W2p, const float* b2, float* emb,
-                    float* xcat, uint8_t* amax, long long nr_valid, long long nr, hipStream_t s, F16x2Scales f16, const uint8_t* unit_mask) {
+                    float* xcat, uint8_t* amax, long long nr_valid, long long nr, hipStream_t s, F16x2Scales f16, const uint8_t* unit_mask,
+                    const float* Wenv, const float* benv) {
     int nwg;
-    const EmbTypes ty = make_types(nr, nr_valid, &nwg);
+    EmbTypes ty = make_types(nr, nr_valid, &nwg);
     const bool bpl = W2p != nullptr;
     const bool h = f16.on && bpl;
+    int tiles = (int)(nr * 40 / EF_TILE);
+    if (Wenv != nullptr) {     // env embedding + the five-unit pool in this kernel too (embed_fwd_pools_all): 24-step tiles for that type
+        if (!h || xcat == nullptr) { set_error("embed_fwd_fused: the in-kernel env / five-unit pooling needs the f16x2 variant", 1041); return 1041; }
+        ty.pool5 = 1;
+        const int t5 = (int)((nr + EF_P5_STEPS - 1) / EF_P5_STEPS), shift = t5 - (ty.tile_begin[2] - ty.tile_begin[1]);
+        for (int t = 2; t <= 6; ++t) ty.ftile_begin[t] = ty.tile_begin[t] + shift;
+        tiles += shift;
+    }
     const size_t lds = (size_t)(2 * (4096 + (bpl ? (h ? PlaneTile<128, 2>::LDS_FLOATS : PlaneTile<128>::LDS_FLOATS) : 4096)) + (h ? 2048 : 0)) * sizeof(float);
     static bool attr = false, attr_p = false, attr_h = false;
     if (h) { if (int e = set_lds(embed_fwd_fused_kernel<false, true, true>, lds, &attr_h)) return e; }
     else if (bpl) { if (int e = set_lds(embed_fwd_fused_kernel<false, true>, lds, &attr_p)) return e; }
     else if (int e = set_lds(embed_fwd_fused_kernel<false, false>, lds, &attr)) return e;
-    const int tiles = (int)(nr * 40 / EF_TILE);
     const int grid = tiles < 512 ? tiles : 512;      // two resident workgroups per CU
     ProfScope prof("embed_fwd_fused", 2.0 * nr * 40 * 128 * (128 + 12), 4.0 * nr * 40 * (12 + 128), s);
     constexpr bool timing = DC_DEV_TIMING != 0;
@@ -693,7 +769,7 @@ int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const fl
         static long long* dbg = nullptr;
         if (!dbg) (void)hipMalloc(&dbg, 512 * 4 * sizeof(long long));
         hipLaunchKernelGGL((embed_fwd_fused_kernel<true, false>), dim3(grid), dim3(256), (size_t)(4 * 4096) * sizeof(float), s, obs, W1, b1, W2,
-                           (const uint16_t*)nullptr, b2, emb, xcat, amax, ty, tiles, dbg, 1.f, 1.f, (const uint8_t*)nullptr);
+                           (const uint16_t*)nullptr, b2, emb, xcat, amax, ty, tiles, dbg, 1.f, 1.f, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
         long long h[512 * 4];
         (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
         double ph[4] = {0, 0, 0, 0};
@@ -704,11 +780,11 @@ int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const fl
         return launch_check("embed_fwd_fused");
     }
     if (h) hipLaunchKernelGGL((embed_fwd_fused_kernel<false, true, true>), dim3(grid), dim3(256), lds, s, obs, W1, b1, W2, W2p, b2, emb, xcat, amax, ty,
-                              tiles, (long long*)nullptr, f16.s_act, 1.f / (f16.s_act * f16.s_w), unit_mask);
+                              tiles, (long long*)nullptr, f16.s_act, 1.f / (f16.s_act * f16.s_w), unit_mask, Wenv, benv);
     else if (bpl) hipLaunchKernelGGL((embed_fwd_fused_kernel<false, true>), dim3(grid), dim3(256), lds, s, obs, W1, b1, W2, W2p, b2, emb, xcat, amax, ty,
-                                tiles, (long long*)nullptr, 1.f, 1.f, (const uint8_t*)nullptr);
+                                tiles, (long long*)nullptr, 1.f, 1.f, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
     else hipLaunchKernelGGL((embed_fwd_fused_kernel<false, false>), dim3(grid), dim3(256), lds, s, obs, W1, b1, W2, W2p, b2, emb, xcat, amax, ty,
-                            tiles, (long long*)nullptr, 1.f, 1.f, (const uint8_t*)nullptr);
+                            tiles, (long long*)nullptr, 1.f, 1.f, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
     return launch_check("embed_fwd_fused");
 }
 

@@ -131,7 +131,9 @@ bool embed_fused_supported(long long nr_padded);
 struct F16x2Scales { bool on = false; float s_act = 1.f, s_w = 1.f, s_grad = 1.f; };
 int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const float* W2, const uint16_t* W2p, const float* b2, float* emb,
                     float* xcat, uint8_t* amax, long long nr_valid, long long nr_padded, hipStream_t s, F16x2Scales f16 = F16x2Scales(),
-                    const uint8_t* unit_mask = nullptr);   // unit_mask (f16 variant only): emb rows of masked-out units of the 16-unit types are not stored
+                    const uint8_t* unit_mask = nullptr,    // unit_mask (f16 variant only): emb rows of masked-out units are not stored
+                    const float* Wenv = nullptr, const float* benv = nullptr);   // f16 variant only: the env embedding and the five-unit pool in
+                                                                                  // this kernel too - pool_env_fwd is then not needed at all
 // inputs of the sparse max-pool backward of the two 16-unit types (embed_sparse.hip); db2 [6][128] is accumulated into
 // (prep: 2 * nr * 736 floats of scratch - it lives in the d(emb) rows of the two types, which the sparse path never writes)
 struct EmbSparseIn { const float* dxcat; const uint8_t* amax; const float* dtu; const float* q; int ldq; float* db2; float* prep;

@@ -173,6 +173,7 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
     uint8_t* amax = reinterpret_cast<uint8_t*>(w.base + w.off[DC_WS_AMAX]);
     const bool fused = embed_fused_on(d);
     const long long NRp = emb_rows(d);               // rows per unit of the type-major blocks
+    bool pools_done = false;
     if (fused) {
         // W2 of the six unit types as bf16 planes (one tiny pre-pass): the fused kernel's weight operand then needs no split
         const WPlanes wpe = wplanes_of(d, w.base, w.off);
@@ -184,8 +185,11 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
         }
         F16x2Scales fs;
         fs.on = eh; fs.s_act = F16X2_S_ACT; fs.s_w = F16X2_S_W;
+        // (round 6) the f16x2 variant also takes the env embedding and the five-unit pool: no pool_env_fwd launch (DC_DIMS_POOL_ENV_SEPARATE: A/B)
+        pools_done = eh && !(d->flags & DC_DIMS_POOL_ENV_SEPARATE);
         DC_TRY(embed_fwd_fused(obs, P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), P.p(DC_P_UNIT_W), bpl ? wpe.fwd(wpe.unit) : nullptr, P.p(DC_P_UNIT_B),
-                               w.f(DC_WS_EMB), w.f(DC_WS_XCAT), amax, NR, NRp, s, fs, (d->flags & DC_DIMS_LAZY_TU) ? unit_mask : nullptr));
+                               w.f(DC_WS_EMB), w.f(DC_WS_XCAT), amax, NR, NRp, s, fs, (d->flags & DC_DIMS_LAZY_TU) ? unit_mask : nullptr,
+                               pools_done ? P.p(DC_P_ENV_W) : nullptr, pools_done ? P.p(DC_P_ENV_B) : nullptr));
     } else {
         DC_TRY(unit_basic_fwd(obs, P.p(DC_P_BASIC_W), P.p(DC_P_BASIC_B), w.f(DC_WS_BASIC), NR, s));
         for (int t = 0; t < 6; ++t) {
@@ -197,7 +201,7 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
     }
     // env embedding + max-pools -> xcat (policy.py:97,102-136)
     // (fused: only the env embedding and the 5-unit type are left to do - the GEMM epilogue pooled the rest)
-    DC_TRY(pool_env_fwd(obs, w.f(DC_WS_EMB), P.p(DC_P_ENV_W), P.p(DC_P_ENV_B), w.f(DC_WS_XCAT), amax, NR, NRp, fused ? 1 : 0, s));
+    if (!pools_done) DC_TRY(pool_env_fwd(obs, w.f(DC_WS_EMB), P.p(DC_P_ENV_W), P.p(DC_P_ENV_B), w.f(DC_WS_XCAT), amax, NR, NRp, fused ? 1 : 0, s));
     // the dense products read their weights as bf16 planes (gemm_x3.hip): one pre-pass per forward over the three / four matrices
     // (measured, tools/gemm_bench.py at 256 x 256: x W^T / dy W run at 145-150 TF on either kernel - the round-1 tile kernel with
     // its fragments split after the LDS reads needs no pre-pass and is the default there; the split-on-load kernel is 1.5x

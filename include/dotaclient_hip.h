@@ -202,6 +202,9 @@ typedef struct dc_dims {
  *                            operand formed on chip (csrc/embed_small.hip, round 6) and d(emb) is written for no type; this flag keeps rounds
  *                            1-5's path for them - d(emb) rows in HBM, embed_bwd_dw2 + embed_bwd_dw1 - for A/B. */
 #define DC_DIMS_SMALL_DENSE 33554432
+/* A/B: keep the env embedding and the five-unit max-pool as their own launch (pool_env_fwd) behind the fused embedding forward, as up to
+ * round 5; default since round 6: the fused forward's epilogue takes them (24-step tiles for the five-unit type), no such launch */
+#define DC_DIMS_POOL_ENV_SEPARATE 67108864
 
 /* index into poff[]; policy.py:54-75 names in comments */
 enum dc_param_index {

@@ -682,3 +682,44 @@ def test_f16x2_fused_embedding_first_layer_at_the_range_edge(key, unit):
     v, lp = values_for(1.01 * LIMIT, 'f16x2', E.DC_DIMS_EMBED_UNFUSED)
     fin = np.isfinite(over_lp)
     assert np.isfinite(v).all() and util.scaled_err(v, over_v) < 1e-5 and util.scaled_err(lp[fin], over_lp[fin]) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('lens', [[128] * 4, [256] * 6, [100, 150, 77], [33], [128] * 3, [24] * 16, [120, 8]])
+@pytest.mark.parametrize('lazy', [False, True])
+def test_fused_forward_pools_every_type_itself(lens, lazy):
+    # round 6: the fused embedding forward also produces the env embedding (policy.py:97) and the five-unit type's max-pool (its tiles hold 24
+    # whole env-steps, six per 32-row block) - there is no pool_env_fwd launch any more.  Against the same kernel followed by pool_env_fwd
+    # (DC_DIMS_POOL_ENV_SEPARATE): xcat and the arg-max bytes bit for bit (the same arithmetic, "first maximum wins"), and everything downstream.
+    # Step counts that are / are not multiples of 24, 33 steps inside 128 padded ones, one tile and many; lazy: with the action masks, the
+    # five-unit type's emb rows are stored for targetable units only (the attention reads no others)
+    from dotaclient_amd import engine as E
+    from dotaclient_amd.engine import Engine, pack_rollouts
+    dev = torch.device('cuda:0')
+    outs = {}
+    rollouts = synth.make_rollouts(92, lens)
+    # a NaN statistic in one enemy hero of one step: the pooled value of that step must be NaN both ways (torch.max propagates it)
+    rollouts[0]['observations']['enemy_heroes'][3, 2, 5] = float('nan')
+    for mode in (0, E.DC_DIMS_POOL_ENV_SEPARATE):
+        eng = Engine('lstm', 128, 1, dev)
+        eng.kernel_flags = mode
+        eng.load_state_dict(synth.init_state_dict(7, 'lstm', 128, 1))
+        batch = pack_rollouts(rollouts, 128, dev)
+        nr = batch.rows
+        d, _, _ = eng.forward(batch, lazy_tu=lazy)
+        xcat = eng.ws_view(d, 'XCAT')[:nr * 896].view(nr, 896).cpu()
+        amax = eng.ws_view(d, 'AMAX', dtype=torch.uint8)[:nr * 3 * 128].view(nr, 3, 128).cpu()
+        ho = eng.ws_view(d, 'HEADOUT')[:nr * L.HEADOUT_LD].cpu()
+        if lazy:     # the target-unit logits of the unmasked units, through the masked log-softmax (reads the stored emb rows)
+            logp, _, am = eng.select_logp(d, batch)
+            tu = torch.cat([logp.flatten(), am.flatten().float()]).cpu()
+        else:
+            tu = eng.ws_view(d, 'TU')[:nr * 40].cpu()
+        outs[mode] = (xcat, amax, ho, tu)
+    a, b = outs[0], outs[E.DC_DIMS_POOL_ENV_SEPARATE]
+    assert torch.isnan(a[0][3, 256:384]).all() and torch.isnan(b[0][3, 256:384]).all()
+    for x, y, name in zip(a, b, ('xcat', 'amax', 'headout', 'tu')):
+        if x.dtype == torch.uint8:
+            assert torch.equal(x, y), name
+        else:
+            assert torch.equal(torch.nan_to_num(x, nan=12345.0), torch.nan_to_num(y, nan=12345.0)), name
