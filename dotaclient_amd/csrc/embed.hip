@@ -155,6 +155,11 @@ __global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(
     float gb2[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (long long n = n0 + sub; n < n1; n += 2) {
         const float* dx = dxcat + n * XCAT;
+        // env embedding backward (policy.py:97)
+        const float de = (xcat[n * XCAT + c] > 0.f) ? dx[c] : 0.f;
+        const float* e = obs + n * OBS_DIM;
+        gw0 = fmaf(de, e[0], gw0); gw1 = fmaf(de, e[1], gw1); gw2 = fmaf(de, e[2], gw2); gb += de;
+        if (skip16 == 3) continue;                     // (3: every type's bias gradient is summed by its on-chip backward kernel - env only here)
         const float qc = q[n * ldq + c];
         const float* dt = dtu + n * 40;
         float pool[6];
@@ -168,10 +173,6 @@ __global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(
         am[1] = amax[(n * 3 + 0) * EMB + c];
         am[2] = amax[(n * 3 + 1) * EMB + c];
         am[3] = amax[(n * 3 + 2) * EMB + c];
-        // env embedding backward (policy.py:97)
-        const float de = (xcat[n * XCAT + c] > 0.f) ? dx[c] : 0.f;
-        const float* e = obs + n * OBS_DIM;
-        gw0 = fmaf(de, e[0], gw0); gw1 = fmaf(de, e[1], gw1); gw2 = fmaf(de, e[2], gw2); gb += de;
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
             if (skip16 && (t == 2 || t == 3)) continue;     // handled by embed_bwd_pool16 without materialising d(emb)
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(
                 sum_dt += d;
                 float g = d * qc;
                 if (u == am[t]) g += pool[t];
-                if (skip16 != 2) p[u * EMB] = g;       // (2: the small types' backward forms its d(emb) on chip too, embed_small.hip)
+                if (skip16 < 2) p[u * EMB] = g;        // (2: the small types' backward forms its d(emb) on chip too, embed_small.hip)
             }
             gb2[t] += sum_dt * qc + pool[t];           // column sum of this step's demb rows of type t
         }
@@ -328,11 +329,12 @@ int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, c
     const int nblk = (int)((nr + spb - 1) / spb);        // <= 2048 -> <= 10.5 MB of scratch
     // algorithmic bytes: d(emb) rows written for the units this pass owns (8 of 40 with skip16), xcat / dxcat rows, the
     // attention query, the target-unit gradients
-    const double units = skip16 == 2 ? 0.0 : (skip16 ? 8.0 : 40.0);
+    const double units = skip16 >= 2 ? 0.0 : (skip16 ? 8.0 : 40.0);
     ProfScope prof("embed_scatter_bwd(+reduce)", 2.0 * nr * units * 128, 4.0 * nr * (units * 128 + 896 * 2 + 128 + 40), s);
     hipLaunchKernelGGL(embed_scatter_bwd_kernel, dim3(nblk), dim3(256), 0, s, obs, xcat, dxcat, dtu, q, ldq, amax, demb,
                        scratch, nr, nrp, spb, skip16);
-    hipLaunchKernelGGL(embed_scatter_reduce_kernel, dim3(5, 32), dim3(256), 0, s, scratch, nblk, dWenv, dbenv, db2);
+    // (env only: the partials' rows 0 .. 3 are all there is)
+    hipLaunchKernelGGL(embed_scatter_reduce_kernel, dim3(skip16 == 3 ? 2 : 5, 32), dim3(256), 0, s, scratch, nblk, dWenv, dbenv, db2);
     return launch_check("embed_scatter_bwd");
 }
 
@@ -351,7 +353,17 @@ int unit_basic_bwd(const float* obs, const float* dbasic, float* dW1, float* db1
 // sparse kernel's [nb][13][128]; db2 of the two 16-unit types += the sparse kernel's [2][n2][128] bias partials.
 __global__ __launch_bounds__(256) void embed_tail_reduce_kernel(const float* __restrict__ pa, int na, const float* __restrict__ pb,
                                                                 int nb, float* __restrict__ dW1, float* __restrict__ db1,
-                                                                const float* __restrict__ p2, int n2, float* __restrict__ db2) {
+                                                                const float* __restrict__ p2, int n2, float* __restrict__ db2,
+                                                                const float* __restrict__ p3, float* __restrict__ db2_small) {
+    if (blockIdx.x >= 8) {                              // bias gradients of the small types (embed_small.hip's column sums): thread = (type of the pair, channel)
+        const int pair = blockIdx.x - 8, h = threadIdx.x >> 7, c = threadIdx.x & 127;
+        const int t = pair == 0 ? h : 4 + h;
+        const int lo = t == 0 ? 0 : (t == 1 ? 32 : (t == 4 ? 192 : 224)), hi = t == 0 ? 32 : (t == 1 ? 192 : (t == 4 ? 224 : 256));
+        float acc = 0.f;
+        for (int b = lo + blockIdx.y; b < hi; b += gridDim.y) acc += p3[(size_t)b * 128 + c];
+        atomicAdd(&db2_small[t * 128 + c], acc);
+        return;
+    }
     if (blockIdx.x == 7) {                              // bias gradients of types 2, 3: thread = (type, channel)
         const int t = threadIdx.x >> 7, c = threadIdx.x & 127;
         float acc = 0.f;
@@ -370,8 +382,8 @@ __global__ __launch_bounds__(256) void embed_tail_reduce_kernel(const float* __r
 }
 
 int embed_tail_reduce(const float* pa, int na, const float* pb, int nb, float* dW1, float* db1, const float* p2, int n2,
-                      float* db2, hipStream_t s) {
-    hipLaunchKernelGGL(embed_tail_reduce_kernel, dim3(8, 32), dim3(256), 0, s, pa, na, pb, nb, dW1, db1, p2, n2, db2);
+                      float* db2, hipStream_t s, const float* p3, float* db2_small) {
+    hipLaunchKernelGGL(embed_tail_reduce_kernel, dim3(p3 != nullptr ? 10 : 8, 32), dim3(256), 0, s, pa, na, pb, nb, dW1, db1, p2, n2, db2, p3, db2_small);
     return launch_check("embed_tail_reduce");
 }
 

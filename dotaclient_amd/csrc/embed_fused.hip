@@ -808,7 +808,7 @@ int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const 
         nwg = wb[6];
     }
     const long long sp_floats = sparse16 ? 2LL * SPARSE_WG_PER_TYPE * (1664 + 128) : 0;
-    if ((long long)nwg * EF_EMB * EF_EMB + sp_floats + (small_fused ? 256LL * 1664 : 0) > scratch_floats || 512LL * 1664 + sp_floats > scratch_floats) {
+    if ((long long)nwg * EF_EMB * EF_EMB + sp_floats + (small_fused ? 256LL * (1664 + 128) : 0) > scratch_floats || 512LL * 1664 + sp_floats > scratch_floats) {
         set_error("embed_bwd_fused: scratch too small", 1040);
         return 1040;
     }
@@ -828,10 +828,12 @@ int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const 
     if (small_fused) {
         // the four small types in one kernel with on-chip operands (embed_small.hip): d(emb) does not exist for any type on this path
         float* const part_small = scratch + (size_t)nwg * EF_EMB * EF_EMB;
-        if (int e = embed_bwd_small(obs, sp->dxcat, sp->amax, sp->dtu, sp->q, sp->ldq, W1, b1, W2, scratch, 2 * SPARSE_WG_PER_TYPE, part_small, nr_valid, s, f16))
+        float* const db2_small = sp->small_db2 ? part_small + 256 * 1664 : nullptr;     // [256][128] column sums of demb
+        if (int e = embed_bwd_small(obs, sp->dxcat, sp->amax, sp->dtu, sp->q, sp->ldq, W1, b1, W2, scratch, 2 * SPARSE_WG_PER_TYPE, part_small, db2_small,
+                                    nr_valid, s, f16))
             return e;
         if (int e = splitk_reduce_grouped(scratch, dW2, EF_EMB, EF_EMB, 6, ty.wg_begin, s)) return e;
-        return embed_tail_reduce(part_small, 256, part1, 2 * SPARSE_WG_PER_TYPE, dW1, db1, part2, SPARSE_WG_PER_TYPE, sp->db2 + 2 * 128, s);
+        return embed_tail_reduce(part_small, 256, part1, 2 * SPARSE_WG_PER_TYPE, dW1, db1, part2, SPARSE_WG_PER_TYPE, sp->db2 + 2 * 128, s, db2_small, sp->db2);
     }
     {
         const size_t lds = (size_t)(4 * 4096) * sizeof(float);

@@ -25,10 +25,15 @@
 // Per tile and wave 12 f32 + 108 f16 MFMAs; LDS 143 KB; three barriers.
 // Register layouts as in embed_pool16m.hip: A[row fr][K slot 8 fq + j], B[K slot 8 fq + j][col fr], D register r = D[row 8 (r >> 2) + 4 fq + (r & 3)][col fr].
 // Outputs in the dense kernels' formats: slab[workgroup][c][k] (splitk_reduce_grouped) and partials[workgroup][13][128] (embed_tail_reduce).
-// The env-embedding and second-layer bias gradients stay with embed_scatter_bwd, which then writes no d(emb) at all.
+// The second-layer bias gradients d(b2_t) = the column sums of demb are taken here too (db2part; a pass of their own over d(xcat), q and dtu until
+// the middle of round 6); only the env-embedding gradient stays with embed_scatter_bwd, which writes no d(emb) at all.
 #include <stdio.h>
 #include "kernels.h"
 #include "gemm_tiles.h"
+
+#ifndef ES_DB2
+#define ES_DB2 1      // 0 (A/B build): no column sums of demb in the build phase (db2part then holds zeros)
+#endif
 
 namespace dc {
 namespace {
@@ -53,6 +58,7 @@ struct SmallArgs {
     float* slab;              // [.][128][128]: workgroup g writes block g (g < 192) or g + skip (see embed_bwd_fused)
     int slab_skip;
     float* part;              // [256][13][128]
+    float* db2part;           // [256][128] or NULL: the workgroup's column sums of demb = its share of the type's second-layer bias gradient
     long long nr;             // env-steps that exist (padding steps have no gradient: never visited)
     float s_act, s_w, s_grad;
 };
@@ -116,6 +122,8 @@ __global__ __launch_bounds__(ES_THREADS, 1) void embed_small_bwd_kernel(SmallArg
     // dW1^T[f][k] (f = 12: db1) x s_act s_grad of the wave's 32 hidden units: the fold is a product on the matrix cores too (13 fmas per
     // element on the vector unit were a quarter of the kernel's time) - A = the records (feature f; f = 12: ones), B = the masked dbasic
     f32x16 accf = {};
+    f32x16 accs = {};                                             // ones^T demb of channel block W (every row of D the same): d(b2_t) x s_grad
+    const f16x8 ones8 = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
     const float inv_sw = 1.f / p.s_w;
     const float xsel = fr < 12 ? 1.f : 0.f, xone = fr == 12 ? 1.f : 0.f;
 
@@ -318,14 +326,23 @@ __global__ __launch_bounds__(ES_THREADS, 1) void embed_small_bwd_kernel(SmallArg
                 for (int cb = 0; cb < 4; ++cb) acc2[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm[cb], acc2[cb], 0, 0, 0);
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) acc2[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[cb], acc2[cb], 0, 0, 0);
+#if ES_DB2
+                {   // d(b2_t) = the column sums of demb = ones^T demb: wave W takes channel block W (its fragments once more: the block index is
+                    // not a compile-time one), two MFMAs with a constant A - as vector adds in the build phase the sums cost 60 us per launch
+                    const _Float16* const bw = bc + W * 32 * ES_CM_LD + 16 * (ks ^ (W & 1));
+                    const f16x8 bhw = *reinterpret_cast<const f16x8*>(bw), bmw = *reinterpret_cast<const f16x8*>(bw + ES_CM_PLANE);
+                    accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones8, bmw, accs, 0, 0, 0);
+                    accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones8, bhw, accs, 0, 0, 0);
+                }
+#endif
                 // a quarter of the next tile's demb arithmetic behind these twelve MFMAs (its inputs were requested at the top of the tile)
                 build_row(raw, built, 2 * ks); build_row(raw, built, 2 * ks + 1);
                 // (issue order for the scheduler: one MFMA, then a few of the vector instructions above, twelve times - left to itself it issues
                 // the twelve MFMAs back to back and the ~90 vector instructions after them, one wave per SIMD: nothing overlaps)
 #pragma unroll
-                for (int i = 0; i < 12; ++i) {
+                for (int i = 0; i < (ES_DB2 ? 14 : 12); ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, ES_DB2 ? 7 : 8, 0);
                 }
                 asm volatile("" ::: "memory");
             }
@@ -358,6 +375,7 @@ __global__ __launch_bounds__(ES_THREADS, 1) void embed_small_bwd_kernel(SmallArg
                                                                      acc2[cb][4 * grp + 3] * inv2);
         }
     }
+    if (p.db2part != nullptr && fq == 0) p.db2part[(size_t)g * 128 + 32 * W + fr] = accs[0] * (1.f / s_grad);   // d(b2_t)[c] of this workgroup's rows
     {   // dW1 / db1 of this wave's hidden units: D register r of the fold = feature 8 (r >> 2) + 4 fq + (r & 3) (12 = the bias)
         float* const o = p.part + (size_t)g * 1664 + 32 * W + fr;
         const float inv_fold = 1.f / (s_act * s_grad);
@@ -372,14 +390,15 @@ __global__ __launch_bounds__(ES_THREADS, 1) void embed_small_bwd_kernel(SmallArg
 // slab: the workgroups' dW2 blocks in splitk_reduce_grouped's order - ah: 0 .. 31, eh: 32 .. 191, then `slab_skip` blocks of other
 // kernels (the two 16-unit types'), ath: 192 + skip .., eth: 224 + skip ..; part: [256][13][128]
 int embed_bwd_small(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq, const float* W1,
-                    const float* b1, const float* W2, float* slab, int slab_skip, float* part, long long nr, hipStream_t s, const F16x2Scales& f16) {
+                    const float* b1, const float* W2, float* slab, int slab_skip, float* part, float* db2part, long long nr, hipStream_t s,
+                    const F16x2Scales& f16) {
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)embed_small_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ES_LDS);
         if (e != hipSuccess) { set_error("embed_bwd_small: hipFuncSetAttribute", (int)e); return (int)e; }
         attr = true;
     }
-    SmallArgs a{obs, dxcat, amax, dtu, q, ldq, W1, b1, W2, slab, slab_skip, part, nr, f16.s_act, f16.s_w, f16.s_grad};
+    SmallArgs a{obs, dxcat, amax, dtu, q, ldq, W1, b1, W2, slab, slab_skip, part, db2part, nr, f16.s_act, f16.s_w, f16.s_grad};
     ProfScope prof("embed_bwd_small", 2.0 * nr * 8 * 128 * (2 * 128 + 24), 4.0 * nr * (8 * 12 + 4 * 128 + 128 + 8), s);
     hipLaunchKernelGGL(embed_small_bwd_kernel, dim3(256), dim3(ES_THREADS), ES_LDS, s, a);
     return launch_check("embed_bwd_small");

@@ -117,8 +117,9 @@ int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, c
                       long long nr, long long nrp, int skip16, hipStream_t s);
 int unit_basic_bwd(const float* obs, const float* dbasic, float* dW1, float* db1, float* scratch, long long nr,
                    hipStream_t s);
+// p3 != nullptr: embed_small.hip's [256][128] column sums -> db2_small [6][128] rows 0, 1, 4, 5 (workgroups 0-31, 32-191, 192-223, 224-255)
 int embed_tail_reduce(const float* pa, int na, const float* pb, int nb, float* dW1, float* db1, const float* p2, int n2,
-                      float* db2, hipStream_t s);
+                      float* db2, hipStream_t s, const float* p3 = nullptr, float* db2_small = nullptr);
 int colsum(const float* X, int ld, long long rows, int cols, float* out, hipStream_t s);
 int unit_basic_reduce(const float* partials, int nblk, float* dW1, float* db1, hipStream_t s);   // partials [nblk][13][128]
 // embed_fused.hip (rows % 128 == 0: first embedding layer recomputed on chip, `basic` never stored)
@@ -138,7 +139,8 @@ int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const fl
 // (prep: 2 * nr * 736 floats of scratch - it lives in the d(emb) rows of the two types, which the sparse path never writes)
 struct EmbSparseIn { const float* dxcat; const uint8_t* amax; const float* dtu; const float* q; int ldq; float* db2; float* prep;
                      int eight_waves = 0; int valu = 0;         // valu: keep embed_sparse.hip's kernels in f16x2 mode too (DC_DIMS_POOL16_VALU)
-                     int small_dense = 0; };                    // small_dense: the four small types through d(emb) in HBM and the dense kernels (DC_DIMS_SMALL_DENSE)
+                     int small_dense = 0;                       // small_dense: the four small types through d(emb) in HBM and the dense kernels (DC_DIMS_SMALL_DENSE)
+                     int small_db2 = 0; };                      // embed_small.hip also sums the small types' second-layer bias gradients (then embed_scatter_bwd: env only)
 // the four small types' backward fused (embed_small.hip) - decided in one place: policy.hip (what embed_scatter_bwd writes) and
 // embed_bwd_fused (what it launches) must agree
 inline bool embed_small_fused(bool sparse16, const F16x2Scales& f16, const EmbSparseIn* sp) {
@@ -157,7 +159,8 @@ int embed_bwd_pool16m(const float* obs, const float* dxcat, const uint8_t* amax,
                       long long nr, int wg_per_type, hipStream_t s, const F16x2Scales& f16);      // scratch_r: 2 * nr * 128 floats
 // embed_small.hip: the four small types (needs F16x2Scales.on); slab / part in the dense kernels' formats
 int embed_bwd_small(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq, const float* W1,
-                    const float* b1, const float* W2, float* slab, int slab_skip, float* part, long long nr, hipStream_t s, const F16x2Scales& f16);
+                    const float* b1, const float* W2, float* slab, int slab_skip, float* part, float* db2part, long long nr, hipStream_t s,
+                    const F16x2Scales& f16);
 // policy_single.hip: Policy.single as one kernel
 int policy_single(const dc_dims* d, const float* params, const int64_t* poff, const float* obs, const float* h0, const float* c0, float* out,
                   float* hT, float* cT, float* scratch, hipStream_t s);

@@ -429,14 +429,15 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     // the inputs of the on-chip backward kernels (embed_pool16m.hip, embed_small.hip), and which of them run
     const EmbSparseIn sp{w.f(DC_WS_DXCAT), amaxp, w.f(DC_WS_DTU), w.f(DC_WS_HEADOUT), HO_LD, Gd.p(DC_P_UNIT_B),
                          w.f(DC_WS_DEMB) + (size_t)NRp * T_CUM[2] * EMBW, (d->flags & DC_DIMS_POOL16_8W) ? 1 : 0,
-                         (d->flags & DC_DIMS_POOL16_VALU) ? 1 : 0, (d->flags & DC_DIMS_SMALL_DENSE) ? 1 : 0};
+                         (d->flags & DC_DIMS_POOL16_VALU) ? 1 : 0, (d->flags & DC_DIMS_SMALL_DENSE) ? 1 : 0,
+                         (d->flags & DC_DIMS_DB2_SCATTER) ? 0 : 1};
     F16x2Scales fs;
     fs.on = (d->flags & DC_DIMS_F16X2) && !(d->flags & DC_DIMS_GEMM_FASTTILE);
     fs.s_act = F16X2_S_ACT; fs.s_w = F16X2_S_W; fs.s_grad = s_grad;
     const bool small_fused = embed_small_fused(sparse16, fs, &sp);      // then d(emb) is not written for ANY type
     DC_TRY(embed_scatter_bwd(obs, w.f(DC_WS_XCAT), w.f(DC_WS_DXCAT), w.f(DC_WS_DTU), w.f(DC_WS_HEADOUT), HO_LD, amaxp,
                              w.f(DC_WS_DEMB), Gd.p(DC_P_ENV_W), Gd.p(DC_P_ENV_B), Gd.p(DC_P_UNIT_B), w.f(DC_WS_SCRATCH), NR,
-                             NRp, small_fused ? 2 : (sparse16 ? 1 : 0), s));
+                             NRp, small_fused ? (sp.small_db2 ? 3 : 2) : (sparse16 ? 1 : 0), s));
     if (fusedb && NRp > NR && !small_fused) {
         // padding steps of the type-major d(emb) blocks the dense kernels read: zero gradients
         for (int t = 0; t < 6; ++t) {

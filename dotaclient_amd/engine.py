@@ -52,6 +52,7 @@ DC_DIMS_POOL16_VALU = 2097152   # keep the sparse VALU max-pool backward in f16x
 DC_DIMS_BF16_F32_STORE = 4194304   # configs[4]: keep the gate buffers f32 (default on that path since round 5: bf16 storage)
 DC_DIMS_GEMM_TILE128 = 8388608   # keep x W^T / dy W on the 128 x 128 split-on-load kernel (default since round 6: csrc/gemm_x3s.hip's row-streaming kernel)
 DC_DIMS_FWD_ONLY = 16777216      # dc_policy_forward: no backward will follow this pass (the no-grad rollout pass)
+DC_DIMS_DB2_SCATTER = 134217728   # small types' second-layer bias gradients by embed_scatter_bwd's own pass (A/B)
 DC_DIMS_POOL_ENV_SEPARATE = 67108864   # env embedding + five-unit pool as their own launch behind the fused embedding forward (A/B)
 DC_DIMS_SMALL_DENSE = 33554432   # keep the small unit types' backward on d(emb) in HBM + the dense kernels (A/B): include/dotaclient_hip.h
 DC_DIMS_F16X2 = 131072   # f32-grade products from two f16 pieces (three MFMAs) instead of three bf16 pieces (six): include/dotaclient_hip.h

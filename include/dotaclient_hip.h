@@ -205,6 +205,9 @@ typedef struct dc_dims {
 /* A/B: keep the env embedding and the five-unit max-pool as their own launch (pool_env_fwd) behind the fused embedding forward, as up to
  * round 5; default since round 6: the fused forward's epilogue takes them (24-step tiles for the five-unit type), no such launch */
 #define DC_DIMS_POOL_ENV_SEPARATE 67108864
+/* A/B: the small unit types' second-layer bias gradients from embed_scatter_bwd's own pass over d(xcat), q and dtu (the first half of round 6);
+ * default: csrc/embed_small.hip sums them from the d(emb) patches it forms anyway, and embed_scatter_bwd reads the env slot only */
+#define DC_DIMS_DB2_SCATTER 134217728
 
 /* index into poff[]; policy.py:54-75 names in comments */
 enum dc_param_index {

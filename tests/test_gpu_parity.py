@@ -355,9 +355,11 @@ def test_sparse_pool_backward_matches_dense(lens):
     outs = {}
     # (round 6: by default the four SMALL types are on chip too - embed_small.hip, no d(emb) for any type; 'sd' = DC_DIMS_SMALL_DENSE keeps
     # them on d(emb) in HBM + the dense kernels next to the on-chip 16-unit kernels)
-    for mode in ('0', '1', 'sd', '16w', '8w'):   # dense kernels / on-chip (default) / on-chip 16-unit types only / sparse sixteen-wave kernel / sparse eight-wave kernel
+    # 'db2s' = DC_DIMS_DB2_SCATTER: the small types' second-layer bias gradients from embed_scatter_bwd's own pass instead of embed_small.hip's column sums
+    for mode in ('0', '1', 'sd', 'db2s', '16w', '8w'):   # dense kernels / on-chip (default) / on-chip 16-unit types only / .. / sparse sixteen-wave kernel / sparse eight-wave kernel
         eng = Engine('lstm', 128, 1, dev)
-        eng.kernel_flags = {'0': E.DC_DIMS_DENSE_POOL_BWD, '1': 0, 'sd': E.DC_DIMS_SMALL_DENSE, '16w': E.DC_DIMS_POOL16_VALU, '8w': E.DC_DIMS_POOL16_8W}[mode]
+        eng.kernel_flags = {'0': E.DC_DIMS_DENSE_POOL_BWD, '1': 0, 'sd': E.DC_DIMS_SMALL_DENSE, 'db2s': E.DC_DIMS_DB2_SCATTER, '16w': E.DC_DIMS_POOL16_VALU,
+                            '8w': E.DC_DIMS_POOL16_8W}[mode]
         eng.load_state_dict(synth.init_state_dict(7, 'lstm', 128, 1))
         rollouts = synth.make_rollouts(91, lens)
         batch = pack_rollouts(rollouts, 128, dev)
@@ -395,6 +397,15 @@ def test_sparse_pool_backward_matches_dense(lens):
         if not n.startswith('affine_unit_basic_stats'):
             assert util.scaled_err(outs['sd'][0][n], outs['0'][0][n]) < 2e-5, n
     assert not np.array_equal(outs['sd'][0]['affine_unit_eh.weight'], outs['1'][0]['affine_unit_eh.weight'])     # really another kernel
+    for n in outs['0'][0]:              # the small types' bias gradients from the scatter pass: everything else is the default's bit for bit
+        if n in ('affine_unit_eh.bias', 'affine_unit_ah.bias', 'affine_unit_ath.bias', 'affine_unit_eth.bias'):
+            assert util.scaled_err(outs['db2s'][0][n], outs['1'][0][n]) < 2e-6, n
+            assert util.scaled_err(outs['db2s'][0][n], outs['0'][0][n]) < 2e-5, n
+        elif not n.startswith('affine_env'):          # (atomics in the reductions of the env gradient: order varies)
+            assert np.array_equal(outs['db2s'][0][n], outs['1'][0][n]) or util.scaled_err(outs['db2s'][0][n], outs['1'][0][n]) < 2e-6, n
+        else:
+            assert util.scaled_err(outs['db2s'][0][n], outs['1'][0][n]) < 2e-6, n
+    assert not np.array_equal(outs['db2s'][0]['affine_unit_eh.bias'], outs['1'][0]['affine_unit_eh.bias'])        # really another summation
     for n in outs['0'][0]:              # the sparse VALU kernels: the same sums in another order
         assert util.scaled_err(outs['8w'][0][n], outs['0'][0][n]) < 2e-5, n
         assert util.scaled_err(outs['16w'][0][n], outs['0'][0][n]) < 2e-5, n
