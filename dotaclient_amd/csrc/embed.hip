@@ -207,6 +207,40 @@ __global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(
     }
 }
 
+// embed_scatter_bwd's env-only form (every type's bias gradient comes from its on-chip backward kernel): the env embedding's backward
+// (policy.py:97) alone - per env-step 512 B of d(xcat), 512 B of xcat (the relu mask), 12 B of the observation.  Eight rows per thread in
+// flight (the general kernel walks its rows one at a time behind dependent loads: 47 us for these 68 MB).  Partials [block][0..3][128].
+__global__ __launch_bounds__(256) void embed_env_bwd_kernel(const float* __restrict__ obs, const float* __restrict__ xcat,
+                                                            const float* __restrict__ dxcat, float* __restrict__ partials, long long nr,
+                                                            int steps_per_block) {
+    const int c = threadIdx.x & 127;
+    const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
+    const long long n0 = (long long)blockIdx.x * steps_per_block;
+    const long long n1 = min(nr, n0 + steps_per_block);
+    float gw0 = 0.f, gw1 = 0.f, gw2 = 0.f, gb = 0.f;
+    for (long long n = n0 + sub; n < n1; n += 16) {
+        float de[8], e0[8], e1[8], e2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool valid = n + 2 * i < n1;
+            const long long m = valid ? n + 2 * i : n1 - 1;
+            const float dx = dxcat[m * XCAT + c], x = xcat[m * XCAT + c];
+            const float* e = obs + m * OBS_DIM;
+            e0[i] = e[0]; e1[i] = e[1]; e2[i] = e[2];
+            de[i] = (valid && x > 0.f) ? dx : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { gw0 = fmaf(de[i], e0[i], gw0); gw1 = fmaf(de[i], e1[i], gw1); gw2 = fmaf(de[i], e2[i], gw2); gb += de[i]; }
+    }
+    __shared__ float sh[4][128];
+    if (sub == 1) { sh[0][c] = gw0; sh[1][c] = gw1; sh[2][c] = gw2; sh[3][c] = gb; }
+    __syncthreads();
+    if (sub == 0) {
+        float* o = partials + (size_t)blockIdx.x * 1280;
+        o[0 * 128 + c] = gw0 + sh[0][c]; o[1 * 128 + c] = gw1 + sh[1][c]; o[2 * 128 + c] = gw2 + sh[2][c]; o[3 * 128 + c] = gb + sh[3][c];
+    }
+}
+
 // stage 2: dWenv[c][f] / dbenv[c] / db2[t][c] += sum over blocks
 __global__ __launch_bounds__(256) void embed_scatter_reduce_kernel(const float* __restrict__ partials, int nblk,
                                                                    float* __restrict__ dWenv, float* __restrict__ dbenv,
@@ -331,8 +365,9 @@ int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, c
     // attention query, the target-unit gradients
     const double units = skip16 >= 2 ? 0.0 : (skip16 ? 8.0 : 40.0);
     ProfScope prof("embed_scatter_bwd(+reduce)", 2.0 * nr * units * 128, 4.0 * nr * (units * 128 + 896 * 2 + 128 + 40), s);
-    hipLaunchKernelGGL(embed_scatter_bwd_kernel, dim3(nblk), dim3(256), 0, s, obs, xcat, dxcat, dtu, q, ldq, amax, demb,
-                       scratch, nr, nrp, spb, skip16);
+    if (skip16 == 3) hipLaunchKernelGGL(embed_env_bwd_kernel, dim3(nblk), dim3(256), 0, s, obs, xcat, dxcat, scratch, nr, spb);
+    else hipLaunchKernelGGL(embed_scatter_bwd_kernel, dim3(nblk), dim3(256), 0, s, obs, xcat, dxcat, dtu, q, ldq, amax, demb,
+                            scratch, nr, nrp, spb, skip16);
     // (env only: the partials' rows 0 .. 3 are all there is)
     hipLaunchKernelGGL(embed_scatter_reduce_kernel, dim3(skip16 == 3 ? 2 : 5, 32), dim3(256), 0, s, scratch, nblk, dWenv, dbenv, db2);
     return launch_check("embed_scatter_bwd");
