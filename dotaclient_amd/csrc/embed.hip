@@ -364,7 +364,9 @@ int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, c
     // algorithmic bytes: d(emb) rows written for the units this pass owns (8 of 40 with skip16), xcat / dxcat rows, the
     // attention query, the target-unit gradients
     const double units = skip16 >= 2 ? 0.0 : (skip16 ? 8.0 : 40.0);
-    ProfScope prof("embed_scatter_bwd(+reduce)", 2.0 * nr * units * 128, 4.0 * nr * (units * 128 + 896 * 2 + 128 + 40), s);
+    // (env only: the env slots of xcat and d(xcat) and three observation floats per step)
+    ProfScope prof("embed_scatter_bwd(+reduce)", skip16 == 3 ? 2.0 * nr * 128 * 4 : 2.0 * nr * units * 128,
+                   skip16 == 3 ? 4.0 * nr * (128 * 2 + 3) : 4.0 * nr * (units * 128 + 896 * 2 + 128 + 40), s);
     if (skip16 == 3) hipLaunchKernelGGL(embed_env_bwd_kernel, dim3(nblk), dim3(256), 0, s, obs, xcat, dxcat, scratch, nr, spb);
     else hipLaunchKernelGGL(embed_scatter_bwd_kernel, dim3(nblk), dim3(256), 0, s, obs, xcat, dxcat, dtu, q, ldq, amax, demb,
                             scratch, nr, nrp, spb, skip16);
