@@ -819,7 +819,8 @@ int embed_bwd_fused(const float* obs, const float* demb, const float* W1, const 
         // products: f32's exponent range; A/B flags) the sparse form on the packed-f32 VALU (embed_sparse.hip).  Same partial formats.
         if (f16.on && !sp->valu && !sp->eight_waves) {
             if (int e = embed_bwd_pool16m(obs, sp->dxcat, sp->amax, sp->dtu, sp->q, sp->ldq, W1, b1, W2,
-                                          scratch + (size_t)ty.wg_begin[2] * EF_EMB * EF_EMB, part1, part2, sp->prep, nr_valid, SPARSE_WG_PER_TYPE, s, f16))
+                                          scratch + (size_t)ty.wg_begin[2] * EF_EMB * EF_EMB, part1, part2, sp->prep, nr_valid, SPARSE_WG_PER_TYPE, s, f16,
+                                          sp->w2t_planes))
                 return e;
         } else if (int e = embed_bwd_pool16(obs, sp->dxcat, sp->amax, sp->dtu, sp->q, sp->ldq, W1, b1, W2,
                                             scratch + (size_t)ty.wg_begin[2] * EF_EMB * EF_EMB, part1, part2, sp->prep, nr_valid, SPARSE_WG_PER_TYPE, s, sp->eight_waves))

@@ -588,7 +588,7 @@ __global__ __launch_bounds__(64 * KSPLIT * NSTREAM) void embed_pool16m_dw1_kerne
 // scratch: 2 * nr * 128 floats (R) + 2 * ceil(nr / 2) * 64 lanes x 8 bytes (the relu masks) = 384 floats per step
 int embed_bwd_pool16m(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq,
                       const float* W1, const float* b1, const float* W2, float* slab, float* part1, float* part2, float* scratch,
-                      long long nr, int wg_per_type, hipStream_t s, const F16x2Scales& f16) {
+                      long long nr, int wg_per_type, hipStream_t s, const F16x2Scales& f16, const uint16_t* w2t_planes) {
     PoolMArgs a{obs, dxcat, amax, dtu, q, ldq, W1, b1, W2, slab, part1, part2, nr, wg_per_type,
                 (int)(((nr + wg_per_type - 1) / wg_per_type + 1) / 2 * 2),      // even: a pair never straddles two workgroups
                 f16.s_act, f16.s_w, f16.s_grad, scratch, reinterpret_cast<uint16_t*>(scratch + 2 * nr * 128)};
@@ -602,10 +602,22 @@ int embed_bwd_pool16m(const float* obs, const float* dxcat, const uint8_t* amax,
         attr = true;
     }
     // R[n][k] = sum_c q[n][c] W2_t[c][k] of every step and type: the attention term of d(basic) is dtu[u] R[k] (2 x 2 GFLOP, f32)
-    for (int t = 2; t < 4; ++t)
-        if (int e = gemm_f32(q, W2 + (size_t)t * 128 * 128, scratch + (size_t)(t - 2) * nr * 128, (int)nr, 128, 128, ldq, 128, 128, 0, 1,
-                             nullptr, 0, nullptr, 0, 0, 1, s))
-            return e;
+    // (round 6: as an f16x2 product like every other one - the row-streaming kernel, W2_t^T from policy_backward's plane pre-pass: 21 -> ~10 us each)
+    for (int t = 2; t < 4; ++t) {
+        float* const R = scratch + (size_t)(t - 2) * nr * 128;
+        if (w2t_planes != nullptr) {
+            X3Gemm g;
+            g.A = q; g.a_mode = X3_ROW; g.lda = ldq;
+            g.B = w2t_planes + 3 * (size_t)t * 128 * 128; g.b_mode = X3_PLANES; g.ldb = 128; g.b_plane = 128 * 128;
+            g.C = R; g.ldc = 128; g.M = (int)nr; g.N = 128; g.K = 128; g.prec = 4; g.transposed_w = 1;
+            g.sa = f16.s_act; g.sb = f16.s_w;
+            if (gemm_x3_shape_ok(g.M, g.N, g.K, g.lda, g.ldb, g.a_mode, g.b_mode)) {
+                if (int e = gemm_x3(g, s)) return e;
+                continue;
+            }
+        }
+        if (int e = gemm_f32(q, W2 + (size_t)t * 128 * 128, R, (int)nr, 128, 128, ldq, 128, 128, 0, 1, nullptr, 0, nullptr, 0, 0, 1, s)) return e;
+    }
     // work = the DENSE form (what the reference's autograd computes for these units, what SURVEY.md 8(d) counts, and what executes here):
     // per step and type the two 16 x 128 x 128 products, the first layer (K = 12) and the fold (13 rows); bytes: each kernel reads the
     // step's records, d(xcat) slot(s), arg-max bytes, dtu and q or R once, plus the 256 B of relu masks written and read

@@ -140,7 +140,8 @@ int embed_fwd_fused(const float* obs, const float* W1, const float* b1, const fl
 struct EmbSparseIn { const float* dxcat; const uint8_t* amax; const float* dtu; const float* q; int ldq; float* db2; float* prep;
                      int eight_waves = 0; int valu = 0;         // valu: keep embed_sparse.hip's kernels in f16x2 mode too (DC_DIMS_POOL16_VALU)
                      int small_dense = 0;                       // small_dense: the four small types through d(emb) in HBM and the dense kernels (DC_DIMS_SMALL_DENSE)
-                     int small_db2 = 0; };                      // embed_small.hip also sums the small types' second-layer bias gradients (then embed_scatter_bwd: env only)
+                     int small_db2 = 0;
+                     const uint16_t* w2t_planes = nullptr; };   // f16x2: [6][2 planes (of 3 slots)][128 k][128 c] = W2_t^T x s_w of types 2, 3 (policy_backward's pre-pass): R = q W2_t as a product of the same kind                      // embed_small.hip also sums the small types' second-layer bias gradients (then embed_scatter_bwd: env only)
 // the four small types' backward fused (embed_small.hip) - decided in one place: policy.hip (what embed_scatter_bwd writes) and
 // embed_bwd_fused (what it launches) must agree
 inline bool embed_small_fused(bool sparse16, const F16x2Scales& f16, const EmbSparseIn* sp) {
@@ -156,7 +157,8 @@ int embed_bwd_pool16(const float* obs, const float* dxcat, const uint8_t* amax, 
 // embed_pool16m.hip: the same gradient as dense f16x2 products with on-chip operands (same partial formats; needs F16x2Scales.on)
 int embed_bwd_pool16m(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq,
                       const float* W1, const float* b1, const float* W2, float* slab, float* part1, float* part2, float* scratch_r,
-                      long long nr, int wg_per_type, hipStream_t s, const F16x2Scales& f16);      // scratch_r: 2 * nr * 128 floats
+                      long long nr, int wg_per_type, hipStream_t s, const F16x2Scales& f16,       // scratch_r: 2 * nr * 128 floats
+                      const uint16_t* w2t_planes = nullptr);      // EmbSparseIn::w2t_planes (NULL: R = q W2_t by the exact-f32 tile kernel)
 // embed_small.hip: the four small types (needs F16x2Scales.on); slab / part in the dense kernels' formats
 int embed_bwd_small(const float* obs, const float* dxcat, const uint8_t* amax, const float* dtu, const float* q, int ldq, const float* W1,
                     const float* b1, const float* W2, float* slab, int slab_skip, float* part, float* db2part, long long nr, hipStream_t s,

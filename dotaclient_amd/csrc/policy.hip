@@ -351,10 +351,13 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     };
     if (do_upper) {
     if (x3) {   // W^T of the matrices the input gradients contract with, as bf16 planes: one pre-pass per backward
-        X3SplitJob jobs[2 + DC_MAX_LAYERS];
+        X3SplitJob jobs[4 + DC_MAX_LAYERS];
         int nj = 0;
         jobs[nj++] = X3SplitJob{P.p(DC_P_PRE_W), wp.bwd(wp.pre), PREW, XCATW, XCATW, 1, PREW};          // -> [896][256]
         jobs[nj++] = X3SplitJob{P.p(DC_P_HEADS_W), wp.bwd(wp.heads), HO_N, H, H, 1, HO_LD};             // -> [H][160], zero k-padding
+        if (f16x2)      // W2^T of the two 16-unit types: R = q W2_t (the attention term of their d(basic), embed_pool16m.hip) as an f16x2 product
+            for (int t = 2; t < 4; ++t)
+                jobs[nj++] = X3SplitJob{P.p(DC_P_UNIT_W) + (size_t)t * EMBW * EMBW, wp.bwd(wp.unit) + 3 * (size_t)t * EMBW * EMBW, EMBW, EMBW, EMBW, 1, EMBW};
         for (int l = 0; l < L; ++l) {
             const int in = l == 0 ? PREW : H;
             jobs[nj++] = X3SplitJob{P.p(DC_P_RNN0 + 4 * l), wp.bwd(wp.ih[l]), G * H, in, in, 1, G * H};  // -> [in][G*H]
@@ -430,7 +433,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
     const EmbSparseIn sp{w.f(DC_WS_DXCAT), amaxp, w.f(DC_WS_DTU), w.f(DC_WS_HEADOUT), HO_LD, Gd.p(DC_P_UNIT_B),
                          w.f(DC_WS_DEMB) + (size_t)NRp * T_CUM[2] * EMBW, (d->flags & DC_DIMS_POOL16_8W) ? 1 : 0,
                          (d->flags & DC_DIMS_POOL16_VALU) ? 1 : 0, (d->flags & DC_DIMS_SMALL_DENSE) ? 1 : 0,
-                         (d->flags & DC_DIMS_DB2_SCATTER) ? 0 : 1};
+                         (d->flags & DC_DIMS_DB2_SCATTER) ? 0 : 1, f16x2 ? wp.bwd(wp.unit) : nullptr};
     F16x2Scales fs;
     fs.on = (d->flags & DC_DIMS_F16X2) && !(d->flags & DC_DIMS_GEMM_FASTTILE);
     fs.s_act = F16X2_S_ACT; fs.s_w = F16X2_S_W; fs.s_grad = s_grad;
