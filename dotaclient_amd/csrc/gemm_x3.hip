@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256, X3Cfg<PREC>::kOcc) void gemm_x3_kernel(X3Args 
 
 // weights -> bf16 planes, in the orientation the consumer contracts over
 struct SplitJob { const float* src; uint16_t* dst; int rows, cols, ld, transpose, rows_pad; };
-struct SplitJobs { SplitJob j[8]; int n; float scale; };
+struct SplitJobs { SplitJob j[16]; int n; float scale; };
 template <int NP, bool F16 = false>
 __global__ __launch_bounds__(256) void split_planes_kernel(SplitJobs jobs) {
     const SplitJob jb = jobs.j[blockIdx.y];
@@ -624,7 +624,7 @@ int gemm_x3(const X3Gemm& g, hipStream_t stream) {
 
 int split_weight_planes(const X3SplitJob* jobs, int n, int prec, hipStream_t s, float scale) {
     if (n <= 0) return 0;
-    if (n > 8) { set_error("split_weight_planes: too many jobs", 1006); return 1006; }
+    if (n > 16) { set_error("split_weight_planes: too many jobs", 1006); return 1006; }
     SplitJobs sj{};
     sj.n = n; sj.scale = scale;
     for (int i = 0; i < n; ++i) {

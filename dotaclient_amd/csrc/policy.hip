@@ -153,6 +153,15 @@ static int check_dims(const dc_dims* d) {
 
 #define DC_TRY(x) do { int _e = (x); if (_e) return _e; } while (0)
 
+// Default mode (fused embedding + f16x2 products): EVERY plane set a pass needs - the unit types' W2, the dense matrices, and unless the pass
+// is forward-only their transposes for the backward (incl. W2_t^T of the 16-unit types) - comes from ONE pre-pass launch at the top of
+// policy_forward (round 6: 14 -> 5 split launches per configs[2] step).  policy_backward then relies on the workspace holding them: it
+// always follows a forward over the same parameters and flags (whose activations it reads from the same workspace anyway).
+static bool planes_in_one_launch(const dc_dims* d) {
+    return embed_fused_on(d) && (d->flags & DC_DIMS_F16X2) && !(d->flags & DC_DIMS_BF16) && !(d->flags & DC_DIMS_GEMM_FASTTILE) &&
+           !(d->flags & DC_DIMS_GEMM_X3_ALL) && d->layers <= 4;
+}
+
 // The two 16-unit types go through the sparse max-pool backward (embed_sparse.hip: a sixteenth of the MACs, no d(emb)
 // in HBM; 290 us against 385 us for the dense MFMA kernels on the same units at the bench batch).  DC_DIMS_DENSE_POOL_BWD
 // forces the dense kernels for every type (per call: the GPU tests run both paths in one process).
@@ -174,12 +183,30 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
     const bool fused = embed_fused_on(d);
     const long long NRp = emb_rows(d);               // rows per unit of the type-major blocks
     bool pools_done = false;
+    const bool one_split = planes_in_one_launch(d);
+    if (one_split) {
+        const WPlanes wq = wplanes_of(d, w.base, w.off);
+        X3SplitJob jobs[16];
+        int nj = 0;
+        jobs[nj++] = X3SplitJob{P.p(DC_P_UNIT_W), wq.fwd(wq.unit), 6 * EMBW, EMBW, EMBW, 0, 6 * EMBW};
+        jobs[nj++] = X3SplitJob{P.p(DC_P_PRE_W), wq.fwd(wq.pre), PREW, XCATW, XCATW, 0, PREW};
+        jobs[nj++] = X3SplitJob{P.p(DC_P_HEADS_W), wq.fwd(wq.heads), HO_N, H, H, 0, HO_LD};
+        for (int l = 0; l < d->layers; ++l) jobs[nj++] = X3SplitJob{P.p(DC_P_RNN0 + 4 * l), wq.fwd(wq.ih[l]), G * H, l == 0 ? PREW : H, l == 0 ? PREW : H, 0, G * H};
+        if (!(d->flags & DC_DIMS_FWD_ONLY)) {       // the transposes policy_backward contracts with
+            jobs[nj++] = X3SplitJob{P.p(DC_P_PRE_W), wq.bwd(wq.pre), PREW, XCATW, XCATW, 1, PREW};
+            jobs[nj++] = X3SplitJob{P.p(DC_P_HEADS_W), wq.bwd(wq.heads), HO_N, H, H, 1, HO_LD};
+            for (int l = 0; l < d->layers; ++l) jobs[nj++] = X3SplitJob{P.p(DC_P_RNN0 + 4 * l), wq.bwd(wq.ih[l]), G * H, l == 0 ? PREW : H, l == 0 ? PREW : H, 1, G * H};
+            for (int t = 2; t < 4; ++t)
+                jobs[nj++] = X3SplitJob{P.p(DC_P_UNIT_W) + (size_t)t * EMBW * EMBW, wq.bwd(wq.unit) + 3 * (size_t)t * EMBW * EMBW, EMBW, EMBW, EMBW, 1, EMBW};
+        }
+        DC_TRY(split_weight_planes(jobs, nj, 4, s, F16X2_S_W));
+    }
     if (fused) {
         // W2 of the six unit types as bf16 planes (one tiny pre-pass): the fused kernel's weight operand then needs no split
         const WPlanes wpe = wplanes_of(d, w.base, w.off);
         const bool bpl = !(d->flags & DC_DIMS_GEMM_FASTTILE);
         const bool eh = (d->flags & DC_DIMS_F16X2) && bpl;        // (the embedding MLP stays f32-grade in bf16 mode, so it may take the f16 pieces there too)
-        if (bpl) {
+        if (bpl && !one_split) {
             X3SplitJob job{P.p(DC_P_UNIT_W), wpe.fwd(wpe.unit), 6 * EMBW, EMBW, EMBW, 0, 6 * EMBW};
             DC_TRY(split_weight_planes(&job, 1, eh ? 4 : 6, s, F16X2_S_W));
         }
@@ -210,7 +237,7 @@ int policy_forward(const dc_dims* d, const float* params, const int64_t* poff, c
     const bool x3 = ((d->flags & DC_DIMS_BF16) || (d->flags & DC_DIMS_GEMM_X3_ALL) || f16x2) && !(d->flags & DC_DIMS_GEMM_FASTTILE);
     const int prec = (d->flags & DC_DIMS_BF16) ? 1 : (f16x2 ? 4 : 6);
     const WPlanes wp = wplanes_of(d, w.base, w.off);
-    if (x3) {
+    if (x3 && !one_split) {
         X3SplitJob jobs[2 + DC_MAX_LAYERS];
         int nj = 0;
         jobs[nj++] = X3SplitJob{P.p(DC_P_PRE_W), wp.fwd(wp.pre), PREW, XCATW, XCATW, 0, PREW};
@@ -350,7 +377,7 @@ int policy_backward(const dc_dims* d, const float* params, const int64_t* poff, 
         return gemm_f32(dy, x1, dW1, M, N1, (int)NR, lda, N1, N1, 1, 1, nullptr, 0, nullptr, 0, 1, 0, s, sc);
     };
     if (do_upper) {
-    if (x3) {   // W^T of the matrices the input gradients contract with, as bf16 planes: one pre-pass per backward
+    if (x3 && !planes_in_one_launch(d)) {   // W^T of the matrices the input gradients contract with, as bf16 planes: one pre-pass per backward
         X3SplitJob jobs[4 + DC_MAX_LAYERS];
         int nj = 0;
         jobs[nj++] = X3SplitJob{P.p(DC_P_PRE_W), wp.bwd(wp.pre), PREW, XCATW, XCATW, 1, PREW};          // -> [896][256]
