@@ -1025,8 +1025,8 @@ def side_measurements(args, dev, B, S, E):
         for cell_, hid_ in (('gru', 256), (args.cell, args.hidden)):
             pol = Policy(cell_, hid_, args.layers if cell_ == args.cell else 1, dev)
             r0 = rollouts[0]
-            for mode in (True, False):
-                pol.single_graph = mode
+            for mode in ('one_kernel', 'graph_replay', 'eager'):
+                pol.single_kernel, pol.single_graph = mode == 'one_kernel', mode == 'graph_replay'
                 h = pol.init_hidden()
                 for t in range(4):
                     _, _, h = pol.single(**{k: r0['observations'][k][t] for k in L_.INPUT_KEYS}, hidden=h)
@@ -1037,11 +1037,12 @@ def side_measurements(args, dev, B, S, E):
                     _, v, h = pol.single(**{k: r0['observations'][k][t % S] for k in L_.INPUT_KEYS}, hidden=h)
                     v.cpu()
                     ts.append((time.perf_counter() - t0) * 1e6)
-                lat['%s-%d %s' % (cell_, hid_, 'graph_replay' if mode else 'eager')] = round(float(np.median(ts)), 1)
+                lat['%s-%d %s' % (cell_, hid_, mode)] = round(float(np.median(ts)), 1)
             del pol
         out['actor_single_step_latency_us'] = dict(lat, note='Policy.single, B = 1, S = 1, CPU observation tensors in, value read back on the host every step '
-                                                             '(median of 100): graph_replay = the step\'s launches replayed as ONE hipGraph over static buffers '
-                                                             '(Policy.single_graph, the default), eager = the same kernels launched one by one')
+                                                             '(median of 100): one_kernel = the whole step as ONE kernel reading the pinned observation row in place '
+                                                             '(csrc/policy_single.hip, Policy.single_kernel, the default since round 6); graph_replay = the batch path\'s '
+                                                             'launches replayed as ONE hipGraph over static buffers (rounds 4-5); eager = the same kernels launched one by one')
     except Exception as e:                                  # noqa: BLE001
         out['actor_single_step_latency_us'] = {'error': repr(e)}
     torch.cuda.empty_cache()
