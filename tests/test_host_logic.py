@@ -846,3 +846,34 @@ def test_lstm512_backward_wide_access_chunk_maps():
     for s in range(16):
         for u in range(US):
             assert f32[s * US + u] == (s, U0 + u)
+
+
+@pytest.mark.parametrize('nr', [128, 256, 384, 24 * 16, 65536, 100 * 128])
+def test_fused_forward_five_unit_tiles_cover_every_unit_row_once(nr):
+    # host model of embed_fused.hip's forward tiling of the five-unit type since round 6 (ef_frow / the epilogue's pool and store guards): a tile
+    # holds 24 whole env-steps, block b (32 accumulator rows) the steps 24 tile + 6 b .. + 5, block row 5 s + u = unit u of its step s, rows 30 / 31
+    # are padding; the block's 30 emb rows are contiguous in the type-major emb block (row 5 n + u); steps past the end are neither pooled nor stored
+    n_tiles = (nr + 23) // 24
+    seen = np.zeros((nr, 5), np.int32)
+    pooled = np.zeros(nr, np.int32)
+    for tile in range(n_tiles):
+        row0 = 5 * 24 * tile                                            # ef_frow(ty, 1, tile, 0) - row_begin[1]
+        for b in range(4):
+            st0 = 24 * tile + 6 * b
+            for r in range(32):
+                q = min(r, 29)                                          # rows 30, 31 repeat the block's last unit (computed, never stored)
+                local = 5 * (24 * tile + 6 * b) + q                     # the record the row is computed from
+                n, u = local // 5, local % 5
+                assert (n, u) == (st0 + q // 5, q % 5)
+                sl = (r * 13) >> 6                                      # the kernel's r / 5 for r < 32
+                if r < 30:
+                    assert sl == r // 5
+                    if st0 + sl < nr:                                   # the store guard (mask bit of the row)
+                        assert row0 + 30 * b + r == 5 * n + u           # store address: the block's rows are contiguous
+                        seen[n, u] += 1
+            for sl in range(6):                                         # the pool: six steps per block, five consecutive image rows each
+                if st0 + sl < nr:
+                    pooled[st0 + sl] += 1
+    assert (seen == 1).all() and (pooled == 1).all()
+    # the types behind it start `shift` tiles later than in the 128-row tiling (ftile_begin)
+    assert n_tiles - nr * 5 // 128 >= 0
