@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import layout as L
-from .engine import CELL_ID, DcDims, Engine, PackedBatch
+from .engine import CELL_ID, DcDims, Engine, PackedBatch, device_empty, device_zeros
 
 
 class _Affine(nn.Module):
@@ -136,7 +136,7 @@ class Policy(nn.Module):
             st = self._fused_state = {
                 'rows': torch.empty(2, L.OBS_DIM, dtype=torch.float32).pin_memory(), 'busy': [None, None], 'turn': 0,
                 # zero once: afterwards the kernel keeps its granules and its launch generation there
-                'scratch': torch.zeros(_lib.DC_SINGLE_SCRATCH_FLOATS, dtype=torch.float32, device=dev),
+                'scratch': device_zeros(_lib.DC_SINGLE_SCRATCH_FLOATS, torch.float32, dev),
                 'dims': DcDims(CELL_ID[self.cell], self.hidden_size, self.layers, 1, 1, 0, 1)}
         vals = [kw[k] for k in L.INPUT_KEYS]
         if all(not v.is_cuda for v in vals):
@@ -157,9 +157,9 @@ class Policy(nn.Module):
         c0 = fit(hidden[1]) if lstm else None
         if h0.numel() != self.layers * self.hidden_size:
             raise ValueError('Policy.single: hidden must be (layers, 1, hidden)')
-        out = torch.empty(L.HEADOUT_LD + L.MAX_UNITS, dtype=torch.float32, device=dev)
-        hT = torch.empty(self.layers, 1, self.hidden_size, dtype=torch.float32, device=dev)
-        cT = torch.empty_like(hT) if lstm else None
+        out = device_empty((L.HEADOUT_LD + L.MAX_UNITS,), torch.float32, dev)     # (engine.DEVICE_ALLOC_HOOK: the guard allocator of tools/guard_soak.py)
+        hT = device_empty((self.layers, 1, self.hidden_size), torch.float32, dev)
+        cT = device_empty((self.layers, 1, self.hidden_size), torch.float32, dev) if lstm else None
         _lib.check(e.lib.dc_policy_single(ctypes.byref(st['dims']), _lib.ptr(e.params), e.poff, _lib.ptr(obs), _lib.ptr(h0), _lib.ptr(c0),
                                           _lib.ptr(out), _lib.ptr(hT), _lib.ptr(cT), _lib.ptr(st['scratch']), _lib.stream_ptr()),
                    'dc_policy_single')

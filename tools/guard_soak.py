@@ -31,6 +31,10 @@ WORKLOADS = {
     'graph:cfg2_lstm256_256x256': ('lstm', 256, 1, 256, 256, 0, False),
     'graph:cfg1_lstm128_64x256': ('lstm', 128, 1, 64, 256, 0, False),
     'graph:gru256_s16_ragged': ('gru', 256, 1, 'ragged', 16, 0, False),
+    # Policy.single as one kernel (csrc/policy_single.hip): 40 env-steps, every device buffer of the call guarded (the observation row is pinned host memory)
+    'single:gru256': ('gru', 256, 1, [40], 16, 0, False),
+    'single:lstm512x2': ('lstm', 512, 2, [40], 16, 0, False),
+    'single:gru64x3': ('gru', 64, 3, [40], 16, 0, False),
 }
 
 
@@ -172,6 +176,18 @@ def one(name, iters):
     if os.environ.get('DC_GUARD_TRACE') == '1':
         trace_calls(_lib.load())
     dev = torch.device('cuda:0')
+    if name.startswith('single:'):
+        from dotaclient_amd.policy import Policy
+        from dotaclient_amd import layout as L
+        pol = Policy(cell, hidden, layers, dev)
+        r = synth.make_rollouts(1000, lengths_of(spec, S))[0]
+        hid, t0, fin = pol.init_hidden(), time.time(), True
+        for t in range(len(r['rewards'])):
+            lg, v, hid = pol.single(**{k: r['observations'][k][t] for k in L.INPUT_KEYS}, hidden=hid)
+            torch.cuda.synchronize()
+            fin = fin and bool(torch.isfinite(v).all()) and all(bool(torch.isfinite(x).all()) for x in lg.values())
+        print('%s %s steps=%d finite=%s %.1fs' % ('OK' if fin else 'FAIL', name, len(r['rewards']), fin, time.time() - t0))
+        sys.exit(0 if fin else 2)
     eng = Engine(cell, hidden, layers, dev)
     eng.kernel_flags = flags
     eng.reuse_rollout_forward = reuse
