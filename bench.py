@@ -99,6 +99,7 @@ def pmc_traffic(path, kernel, workload_key):
                       'gru_bwd_team': ['team_mfma_bwd', 'team8_bwd', 'rnn_team_bwd'],
                       'lstm_fwd_team': ['team_mfma_fwd_of', 'team_mfma_fwd_col', 'team_mfma_fwd', 'team8_fwd', 'rnn_team_fwd'], 'lstm_bwd_team': ['team_mfma_bwd', 'team8_bwd', 'rnn_team_bwd'],
                       'embed_bwd_small': ['embed_small_bwd'], 'gradnorm_clip_adam': ['gradnorm_clip_adam'],
+                      'embed_scatter_bwd': ['embed_env_bwd', 'embed_scatter_bwd'], 'attn_logits': ['attn_logits_masked', 'attn_logits'],
                       'lstm_fwd_persist': ['lstm_fwd_valu'], 'lstm_bwd_persist': ['lstm_bwd_valu'],
                       'gemm_f32_dW': ['gemm_x3'], 'gemm_f32_fwd': ['gemm_fast', 'gemm_x3'], 'gemm_f32_dX': ['gemm_fast', 'gemm_x3']}
     if PRODUCTS == 'f16x2':       # x W^T / dy W: the row-streaming kernel (gemm_x3s.hip, round 6; one PMC row: the average over its launches), else the split-on-load kernel

@@ -24,7 +24,7 @@ def test_every_timed_region_finds_its_kernel_in_the_pmc_summary():
     j = json.load(open(TRAFFIC))
     assert j['meta']['workload'] == 'lstm-256-256x256'
     for region in ['embed_fwd_fused', 'embed_bwd_pool16m', 'lstm_fwd_team', 'lstm_bwd_team', 'gemm_f32_dW', 'gemm_f32_fwd', 'gemm_f32_dX',
-                   'embed_bwd_small', 'pool_env_fwd']:
+                   'embed_bwd_small', 'embed_scatter_bwd', 'attn_logits', 'attn_bwd_q']:      # (pool_env_fwd: folded into embed_fwd_fused in round 6)
         t = bench.pmc_traffic(TRAFFIC, region, 'lstm-256-256x256')
         assert isinstance(t, int) and t > 0, region
     assert bench.pmc_traffic(TRAFFIC, 'embed_fwd_fused', 'gru-256-64x256') is None      # a summary of another workload is not used
@@ -32,7 +32,7 @@ def test_every_timed_region_finds_its_kernel_in_the_pmc_summary():
 
 def test_whole_step_traffic_is_computed_from_the_summary():
     step = bench.pmc_whole_step(TRAFFIC, 'lstm-256-256x256', 5)
-    assert 3e10 < step < 1e11                           # ~44 GB per configs[2] step
+    assert 1.5e10 < step < 1e11                         # 29.7 GB per configs[2] step at the end of round 6 (round 3: ~44)
     assert bench.pmc_whole_step(TRAFFIC, 'other', 5) is None
 
 
