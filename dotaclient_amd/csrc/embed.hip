@@ -159,7 +159,6 @@ __global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(
         const float de = (xcat[n * XCAT + c] > 0.f) ? dx[c] : 0.f;
         const float* e = obs + n * OBS_DIM;
         gw0 = fmaf(de, e[0], gw0); gw1 = fmaf(de, e[1], gw1); gw2 = fmaf(de, e[2], gw2); gb += de;
-        if (skip16 == 3) continue;                     // (3: every type's bias gradient is summed by its on-chip backward kernel - env only here)
         const float qc = q[n * ldq + c];
         const float* dt = dtu + n * 40;
         float pool[6];

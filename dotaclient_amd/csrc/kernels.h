@@ -111,7 +111,8 @@ int unit_basic_fwd(const float* obs, const float* W1, const float* b1, float* ba
 // nrp (here and below): env-steps per unit of the type-major emb / d(emb) blocks = nr padded to a multiple of 128 on the fused path
 int pool_env_fwd(const float* obs, const float* emb, const float* Wenv, const float* benv, float* xcat, uint8_t* amax,
                  long long nr, long long nrp, int residual, hipStream_t s);
-// skip16: the two 16-unit types are left out (no d(emb) rows written, no db2 contribution): embed_bwd_pool16 has them
+// skip16 = 1: the two 16-unit types are left out (no d(emb) rows written, no db2 contribution): embed_bwd_pool16 has them; 2: no d(emb) rows at all
+// (embed_small.hip forms the small types' on chip), their db2 still summed here; 3: env-embedding gradient only (embed_env_bwd_kernel)
 int embed_scatter_bwd(const float* obs, const float* xcat, const float* dxcat, const float* dtu, const float* q, int ldq,
                       const uint8_t* amax, float* demb, float* dWenv, float* dbenv, float* db2, float* scratch,
                       long long nr, long long nrp, int skip16, hipStream_t s);

@@ -141,11 +141,11 @@ __global__ __launch_bounds__(PS_THREADS) void policy_single_kernel(SingleArgs a)
     for (int i = 0; i < 3; ++i) w1[i] = *reinterpret_cast<const f32x4*>(P + a.off[DC_P_BASIC_W] + bk * 12 + i * 4);
     const float b1 = P[a.off[DC_P_BASIC_B] + bk];
     // A: this wave's (type, column) items
-    int it_t[2] = {0, 0}, it_n = 0;
+    int it_t[2] = {0, 0};
     const int ic = gw & 127;
-    if (gw < 256) { it_t[0] = 2 + (gw >> 7); it_n = 1; }                         // anh / enh: 16 units
-    else if (gw < 384) { it_t[0] = 1; it_t[1] = 0; it_n = 2; }                   // eh (5 units) + ah (1)
-    else { it_t[0] = 4; it_t[1] = 5; it_n = 2; }                                 // ath + eth (1 each) (+ the env embedding)
+    if (gw < 256) { it_t[0] = 2 + (gw >> 7); }                                   // anh / enh: 16 units
+    else if (gw < 384) { it_t[0] = 1; it_t[1] = 0; }                             // eh (5 units) + ah (1)
+    else { it_t[0] = 4; it_t[1] = 5; }                                           // ath + eth (1 each) (+ the env embedding)
     float2 w2[2]; float b2[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -178,7 +178,6 @@ __global__ __launch_bounds__(PS_THREADS) void policy_single_kernel(SingleArgs a)
             pub(G + PS_G_XCAT + ic, relu_nan(fmaf(sh_obs[2], we[2], fmaf(sh_obs[1], we[1], fmaf(sh_obs[0], we[0], P[a.off[DC_P_ENV_B] + ic])))), tag);
         }
     }
-    (void)it_n;
 
     // ---- the weight rows of a recurrent layer / of the heads, requested a hop ahead of their input ----------------------------------------------
     f32x4 wr[16];                                                               // C: [gate][x piece 0, 1 | h piece 0, 1]
