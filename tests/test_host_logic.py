@@ -877,3 +877,47 @@ def test_fused_forward_five_unit_tiles_cover_every_unit_row_once(nr):
     assert (seen == 1).all() and (pooled == 1).all()
     # the types behind it start `shift` tiles later than in the 128-row tiling (ftile_begin)
     assert n_tiles - nr * 5 // 128 >= 0
+
+
+def test_policy_single_wave_items_cover_every_output_once():
+    # host model of csrc/policy_single.hip's work split (64 workgroups x 8 waves): stage A's (unit type, column) items publish every emb[u][c]
+    # and every pooled xcat slot exactly once (slot 6 = the enh max again, policy.py:127; eth is never pooled), stage B / C rows one wave
+    # each, stage D: workgroup 0 the 128 query rows (16 per wave) and the 40 target-unit logits (units wave + 8 i), workgroup 1 rows 128 .. 159
+    WG, WPB = 64, 8
+    u0_of = {0: 0, 1: 1, 2: 6, 3: 22, 4: 38, 5: 39}
+    nu_of = {0: 1, 1: 5, 2: 16, 3: 16, 4: 1, 5: 1}
+    emb = np.zeros((40, 128), np.int32)
+    xcat = np.zeros(896, np.int32)
+    for gw in range(WG * WPB):
+        c = gw & 127
+        if gw < 256:
+            items = [(2 + (gw >> 7), [(2 + (gw >> 7)) + 1] + ([6] if gw >> 7 == 1 else []))]
+        elif gw < 384:
+            items = [(1, [2]), (0, [1])]
+        else:
+            items = [(4, [5]), (5, [])]
+            xcat[c] += 1                                   # the env embedding: slot 0
+        for t, slots in items:
+            for u in range(nu_of[t]):
+                emb[u0_of[t] + u, c] += 1
+            for s in slots:
+                xcat[s * 128 + c] += 1
+    assert (emb == 1).all() and (xcat == 1).all()
+    for H in (64, 128, 256, 512):                          # B: a row per wave gw < 256; C: a hidden unit per wave gw < H
+        assert H <= WG * WPB and 256 <= WG * WPB
+    out = np.zeros(200, np.int32)
+    for wave in range(WPB):
+        for i in range(16):
+            out[wave * 16 + i] += 1                        # workgroup 0: query rows
+        for i in range(5):
+            if wave + 8 * i < 40:
+                out[160 + wave + 8 * i] += 1               # ... and the target-unit logits
+        for i in range(4):
+            out[128 + i * 8 + wave] += 1                   # workgroup 1: rows 128 .. 159 (154 .. 159: zero weights, zero bias)
+    assert (out == 1).all()
+    # scratch: granules (8 bytes) of the launch generation, emb, xcat, pre, h of every layer - inside what the header promises
+    words = 8 + 40 * 128 + 896 + 256 + 4 * 512
+    from dotaclient_amd import _lib
+    assert 2 * words <= _lib.DC_SINGLE_SCRATCH_FLOATS
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'dotaclient_hip.h')).read()
+    assert '#define DC_SINGLE_SCRATCH_FLOATS %d' % _lib.DC_SINGLE_SCRATCH_FLOATS in hdr
