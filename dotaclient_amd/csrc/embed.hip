@@ -240,6 +240,21 @@ __global__ __launch_bounds__(256) void embed_env_bwd_kernel(const float* __restr
     }
 }
 
+// sum of p[b * stride + idx] over b = b0, b0 + step, .. < n: eight loads in flight (a plain loop is a chain of dependent round trips: the
+// scatter reduce took 19 us for 4 MB, the tail reduce 15 us)
+__device__ __forceinline__ float strided_sum(const float* __restrict__ p, size_t stride, int idx, int b0, int step, int n) {
+    float acc = 0.f;
+    int b = b0;
+    for (; b + 7 * step < n; b += 8 * step) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = p[(size_t)(b + i * step) * stride + idx];
+        acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; b < n; b += step) acc += p[(size_t)b * stride + idx];
+    return acc;
+}
+
 // stage 2: dWenv[c][f] / dbenv[c] / db2[t][c] += sum over blocks
 __global__ __launch_bounds__(256) void embed_scatter_reduce_kernel(const float* __restrict__ partials, int nblk,
                                                                    float* __restrict__ dWenv, float* __restrict__ dbenv,
@@ -247,8 +262,7 @@ __global__ __launch_bounds__(256) void embed_scatter_reduce_kernel(const float* 
     const int idx = blockIdx.x * 256 + threadIdx.x;   // 0..1279
     if (idx >= 1280) return;
     // blockIdx.y strides over the partial blocks: 32 atomics per output instead of thousands
-    float acc = 0.f;
-    for (int b = blockIdx.y; b < nblk; b += gridDim.y) acc += partials[(size_t)b * 1280 + idx];
+    const float acc = strided_sum(partials, 1280, idx, blockIdx.y, gridDim.y, nblk);
     const int k = idx >> 7, c = idx & 127;
     if (k < 3) atomicAdd(&dWenv[c * 3 + k], acc);
     else if (k == 3) atomicAdd(&dbenv[c], acc);
@@ -395,23 +409,17 @@ __global__ __launch_bounds__(256) void embed_tail_reduce_kernel(const float* __r
         const int pair = blockIdx.x - 8, h = threadIdx.x >> 7, c = threadIdx.x & 127;
         const int t = pair == 0 ? h : 4 + h;
         const int lo = t == 0 ? 0 : (t == 1 ? 32 : (t == 4 ? 192 : 224)), hi = t == 0 ? 32 : (t == 1 ? 192 : (t == 4 ? 224 : 256));
-        float acc = 0.f;
-        for (int b = lo + blockIdx.y; b < hi; b += gridDim.y) acc += p3[(size_t)b * 128 + c];
-        atomicAdd(&db2_small[t * 128 + c], acc);
+        atomicAdd(&db2_small[t * 128 + c], strided_sum(p3, 128, c, lo + blockIdx.y, gridDim.y, hi));
         return;
     }
     if (blockIdx.x == 7) {                              // bias gradients of types 2, 3: thread = (type, channel)
         const int t = threadIdx.x >> 7, c = threadIdx.x & 127;
-        float acc = 0.f;
-        for (int b = blockIdx.y; b < n2; b += gridDim.y) acc += p2[((size_t)t * n2 + b) * 128 + c];
-        atomicAdd(&db2[t * 128 + c], acc);
+        atomicAdd(&db2[t * 128 + c], strided_sum(p2 + (size_t)t * n2 * 128, 128, c, blockIdx.y, gridDim.y, n2));
         return;
     }
     const int idx = blockIdx.x * 256 + threadIdx.x;   // 0..1663
     if (idx >= 1664) return;
-    float acc = 0.f;
-    for (int b = blockIdx.y; b < na; b += gridDim.y) acc += pa[(size_t)b * 1664 + idx];
-    for (int b = blockIdx.y; b < nb; b += gridDim.y) acc += pb[(size_t)b * 1664 + idx];
+    const float acc = strided_sum(pa, 1664, idx, blockIdx.y, gridDim.y, na) + strided_sum(pb, 1664, idx, blockIdx.y, gridDim.y, nb);
     const int f = idx >> 7, c = idx & 127;
     if (f < 12) atomicAdd(&dW1[c * 12 + f], acc);
     else atomicAdd(&db1[c], acc);
